@@ -1,0 +1,97 @@
+"""ctypes binding of libgsvc_hip.so (the C-ABI declared in include/gsvc_hip.h).
+
+There is no fallback: if the library has not been built (``python -c 'import __graft_entry__ as g; g.build()'``
+or ``make -C gsvc_amd/csrc``) every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgsvc_hip.so")
+_lib = None
+
+
+class GsvcError(RuntimeError):
+    pass
+
+
+class RasterSettingsC(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32),
+        ("image_width", C.c_int32),
+        ("x_min", C.c_float),
+        ("y_min", C.c_float),
+        ("scale", C.c_float),
+        ("threshold", C.c_float),
+        ("scale_modifier", C.c_float),
+        ("bg", C.c_float * 3),
+        ("viewmatrix", C.c_float * 16),
+    ]
+
+
+class RasterSizesC(C.Structure):
+    _fields_ = [("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)]
+
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_u32 = C.c_uint32
+_f = C.c_float
+
+_SIGNATURES = {
+    "gsvc_last_error": (C.c_char_p, []),
+    "gsvc_version": (C.c_char_p, []),
+    "gsvc_raster_sizes_query": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64, C.POINTER(RasterSizesC)]),
+    "gsvc_raster_visible_filter": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_raster_forward": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64] + [_vp] * 11),
+    "gsvc_raster_backward": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64] + [_vp] * 18),
+    "gsvc_raster_binning_layout": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "gsvc_raster_image_layout": (C.c_int, [C.POINTER(RasterSettingsC), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "gsvc_grid_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "gsvc_grid_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "gsvc_rate_forward": (C.c_int, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "gsvc_rate_backward": (C.c_int, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+def declared_symbols():
+    """Every entry point include/gsvc_hip.h declares (checked by tests/test_abi.py against the header text)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load the HIP library, failing loudly when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GsvcError(
+                f"{LIB_PATH} is not built. Build the gfx950 HIP library first: `make -C gsvc_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). gsvc_amd has no CPU fallback.")
+        import torch  # noqa: F401  (loads the HIP runtime this library links against)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().gsvc_last_error().decode("utf-8", "replace")
+        raise GsvcError(f"{what} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

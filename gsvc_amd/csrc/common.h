@@ -1,0 +1,35 @@
+// gsvc_amd/csrc/common.h — shared host-side helpers of libgsvc_hip.so (error slot, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/gsvc_hip.h"
+
+namespace gsvc {
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return GSVC_E_LAUNCH;
+    }
+    return GSVC_OK;
+}
+
+inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace gsvc
+
+#define GSVC_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            gsvc::set_error(__VA_ARGS__);  \
+            return GSVC_E_INVALID;         \
+        }                                  \
+    } while (0)

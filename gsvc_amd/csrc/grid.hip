@@ -1,0 +1,339 @@
+// gsvc_amd/csrc/grid.hip — multi-resolution hash-grid encoder (forward, dy_dx, table and input backward), gfx950.
+//
+// Replaces `_gridencoder.grid_encode_forward / grid_encode_backward` (reference
+// submodules/gridencoder.zip!gridencoder/src/gridencoder.cu: kernel_grid :100-660, kernel_grid_backward
+// :664-853, kernel_input_backward :856-882; call sites reference utils/encodings.py:529-553,582-610).
+// Semantics kept: position = x*(res-2)+0.5, corners on the border cell are dropped and the remaining
+// weights renormalised (forward/table-backward), dy_dx is the un-renormalised finite difference, dense
+// index while the running stride fits the level's table else the prime-XOR hash, out-of-range inputs
+// give zeros.  binary_vxl / per-point min_level_id are never passed by GSVC and are not part of this ABI.
+//
+// Mapping to the hardware: one lane per (point, level); a corner's C features are one 4*C-byte row, read
+// with 16-byte loads; the [L,N,C] output row of a lane is contiguous so a wave writes 64*4*C contiguous
+// bytes.  The table backward reduces nothing on chip (corners of neighbouring lanes differ) and uses one
+// float atomic wave-instruction per (corner, feature).
+#include "common.h"
+
+namespace gsvc {
+
+template <uint32_t D>
+__device__ __forceinline__ uint32_t fast_hash(const uint32_t (&p)[D])
+{
+    constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+    uint32_t h = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) h ^= p[d] * primes[d];
+    return h;
+}
+
+template <uint32_t D>
+__device__ __forceinline__ uint32_t grid_row(const uint32_t (&p)[D], uint32_t hashmap_size, uint32_t resolution)
+{
+    uint32_t stride = 1, index = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += p[d] * stride;
+            stride *= resolution;
+        }
+    }
+    if (stride > hashmap_size) index = fast_hash<D>(p);
+    return index % hashmap_size;
+}
+
+template <uint32_t D>
+struct Cell {
+    float frac[D];
+    uint32_t cell[D];
+    float w[1 << D];
+    uint32_t row[1 << D];
+    uint32_t valid;  // bit per corner
+    float wn_re;
+};
+
+template <uint32_t D>
+__device__ __forceinline__ void locate(const float (&x)[D], uint32_t resolution, uint32_t hashmap_size, Cell<D> &c)
+{
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float pos = x[d] * (float)(resolution - 2) + 0.5f;
+        c.cell[d] = (uint32_t)floorf(pos);
+        c.frac[d] = pos - (float)c.cell[d];
+    }
+    float wn = 0.f;
+    c.valid = 0;
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1.f;
+        uint32_t pl[D];
+        bool border = false;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) {
+                w *= 1.f - c.frac[d];
+                pl[d] = c.cell[d];
+            } else {
+                w *= c.frac[d];
+                pl[d] = min(c.cell[d] + 1, resolution - 1);
+            }
+            border |= (pl[d] == 0) | (pl[d] == resolution - 1);
+        }
+        c.w[idx] = w;
+        c.row[idx] = 0;
+        if (!border) {
+            c.row[idx] = grid_row<D>(pl, hashmap_size, resolution);
+            c.valid |= 1u << idx;
+            wn += w;
+        }
+    }
+    if (wn == 0.f) wn = 1e-9f;
+    c.wn_re = 1.0f / wn;
+}
+
+template <uint32_t C>
+__device__ __forceinline__ void load_row(const float *__restrict__ p, float (&v)[C])
+{
+    if constexpr (C >= 4) {
+#pragma unroll
+        for (uint32_t k = 0; k < C / 4; k++) {
+            const float4 t = reinterpret_cast<const float4 *>(p)[k];
+            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+        }
+    } else if constexpr (C == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        v[0] = t.x; v[1] = t.y;
+    } else {
+        v[0] = p[0];
+    }
+}
+
+template <uint32_t C>
+__device__ __forceinline__ void store_row(float *__restrict__ p, const float (&v)[C])
+{
+    if constexpr (C >= 4) {
+#pragma unroll
+        for (uint32_t k = 0; k < C / 4; k++)
+            reinterpret_cast<float4 *>(p)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    } else if constexpr (C == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+    } else {
+        p[0] = v[0];
+    }
+}
+
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inputs, const float *__restrict__ grid,
+                                                  const int32_t *__restrict__ offsets,
+                                                  const int32_t *__restrict__ resolutions, float *__restrict__ outputs,
+                                                  uint32_t N, uint32_t L, float *__restrict__ dy_dx)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    const uint32_t level = blockIdx.y;
+    grid += (size_t)(uint32_t)offsets[level] * C;
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t resolution = (uint32_t)resolutions[level];
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        oob |= (x[d] < 0.f) | (x[d] > 1.f);
+    }
+    float *out = outputs + ((size_t)level * N + b) * C;
+    float *dd = dy_dx ? dy_dx + (size_t)b * D * L * C + (size_t)level * D * C : nullptr;
+    float res[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) res[ch] = 0.f;
+    if (oob) {
+        store_row<C>(out, res);
+        if (dd) {
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) store_row<C>(dd + d * C, res);
+        }
+        return;
+    }
+    Cell<D> c;
+    locate<D>(x, resolution, hashmap_size, c);
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        if (c.valid & (1u << idx)) {
+            float g[C];
+            load_row<C>(grid + (size_t)c.row[idx] * C, g);
+            const float w = c.w[idx] * c.wn_re;
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) res[ch] += w * g[ch];
+        }
+    }
+    store_row<C>(out, res);
+    if (!dd) return;
+#pragma unroll
+    for (uint32_t gd = 0; gd < D; gd++) {
+        float rg[C];
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) rg[ch] = 0.f;
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+            float w = (float)(resolution - 2);
+            uint32_t pl[D];
+#pragma unroll
+            for (uint32_t nd = 0; nd + 1 < D; nd++) {
+                const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                if ((idx & (1u << nd)) == 0) {
+                    w *= 1.f - c.frac[d];
+                    pl[d] = c.cell[d];
+                } else {
+                    w *= c.frac[d];
+                    pl[d] = min(c.cell[d] + 1, resolution - 1);
+                }
+            }
+            bool other_border = false;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++)
+                if (d != gd) other_border |= (pl[d] == 0) | (pl[d] == resolution - 1);
+            float gl[C], gr[C];
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) { gl[ch] = 0.f; gr[ch] = 0.f; }
+            pl[gd] = c.cell[gd];
+            if (!(other_border || pl[gd] == 0 || pl[gd] == resolution - 1))
+                load_row<C>(grid + (size_t)grid_row<D>(pl, hashmap_size, resolution) * C, gl);
+            pl[gd] = min(c.cell[gd] + 1, resolution - 1);
+            if (!(other_border || pl[gd] == 0 || pl[gd] == resolution - 1))
+                load_row<C>(grid + (size_t)grid_row<D>(pl, hashmap_size, resolution) * C, gr);
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) rg[ch] += w * (gr[ch] - gl[ch]);
+        }
+        store_row<C>(dd + gd * C, rg);
+    }
+}
+
+// table backward: one lane per (point, level); all C features of a corner go out as C atomics on one row
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_bwd(const float *__restrict__ grad, const float *__restrict__ inputs,
+                                                  const int32_t *__restrict__ offsets,
+                                                  const int32_t *__restrict__ resolutions,
+                                                  float *__restrict__ grad_grid, uint32_t N)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    const uint32_t level = blockIdx.y;
+    grad_grid += (size_t)(uint32_t)offsets[level] * C;
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t resolution = (uint32_t)resolutions[level];
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        oob |= (x[d] < 0.f) | (x[d] > 1.f);
+    }
+    if (oob) return;
+    float g[C];
+    load_row<C>(grad + ((size_t)level * N + b) * C, g);
+    Cell<D> c;
+    locate<D>(x, resolution, hashmap_size, c);
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        if (c.valid & (1u << idx)) {
+            const float w = c.w[idx] * c.wn_re;
+            float *dst = grad_grid + (size_t)c.row[idx] * C;
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) atomicAdd(dst + ch, w * g[ch]);
+        }
+    }
+}
+
+// grad_inputs[b,d] = sum_l sum_c grad[l,b,c] * dy_dx[b,l,d,c]
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_input_bwd(const float *__restrict__ grad, const float *__restrict__ dy_dx,
+                                                        float *__restrict__ grad_inputs, uint32_t N, uint32_t L)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const float *dd = dy_dx + (size_t)b * L * D * C;
+    float r = 0.f;
+    for (uint32_t l = 0; l < L; l++) {
+        float g[C], y[C];
+        load_row<C>(grad + ((size_t)l * N + b) * C, g);
+        load_row<C>(dd + (size_t)l * D * C + d * C, y);
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) r += g[ch] * y[ch];
+    }
+    grad_inputs[t] = r;
+}
+
+template <uint32_t D, uint32_t C>
+static void launch_fwd(const float *inputs, const float *emb, const int32_t *off, const int32_t *res, float *out,
+                       uint32_t N, uint32_t L, float *dy_dx, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_grid_fwd<D, C>), dim3((N + 255) / 256, L), dim3(256), 0, s, inputs, emb, off, res, out, N, L,
+                       dy_dx);
+}
+
+template <uint32_t D, uint32_t C>
+static void launch_bwd(const float *grad, const float *inputs, const int32_t *off, const int32_t *res, float *gemb,
+                       uint32_t N, uint32_t L, const float *dy_dx, float *ginp, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_grid_bwd<D, C>), dim3((N + 255) / 256, L), dim3(256), 0, s, grad, inputs, off, res, gemb, N);
+    if (dy_dx && ginp)
+        hipLaunchKernelGGL((k_grid_input_bwd<D, C>), dim3((N * D + 255) / 256), dim3(256), 0, s, grad, dy_dx, ginp, N, L);
+}
+
+#define GSVC_DISPATCH_C(D_, CALL)                                                        \
+    switch (C) {                                                                         \
+        case 1: CALL(D_, 1); break;                                                      \
+        case 2: CALL(D_, 2); break;                                                      \
+        case 4: CALL(D_, 4); break;                                                      \
+        case 8: CALL(D_, 8); break;                                                      \
+        case 16: CALL(D_, 16); break;                                                    \
+        case 32: CALL(D_, 32); break;                                                    \
+        default:                                                                         \
+            set_error("GridEncoding: n_fearures must be 1, 2, 4, 8, 16 or 32.");         \
+            return GSVC_E_UNSUPPORTED;                                                   \
+    }
+
+#define GSVC_DISPATCH_DC(CALL)                                             \
+    switch (D) {                                                           \
+        case 1: GSVC_DISPATCH_C(1, CALL) break;                            \
+        case 2: GSVC_DISPATCH_C(2, CALL) break;                            \
+        case 3: GSVC_DISPATCH_C(3, CALL) break;                            \
+        default:                                                           \
+            set_error("GridEncoding: num_dim must be 1, 2, 3.");           \
+            return GSVC_E_UNSUPPORTED;                                     \
+    }
+
+}  // namespace gsvc
+
+using namespace gsvc;
+
+extern "C" int gsvc_grid_forward(const float *inputs, const float *embeddings, const int32_t *offsets,
+                                 const int32_t *resolutions, float *outputs, uint32_t N, uint32_t D, uint32_t C,
+                                 uint32_t L, float *dy_dx, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0 || L == 0) {
+        if (!(D >= 1 && D <= 3)) { set_error("GridEncoding: num_dim must be 1, 2, 3."); return GSVC_E_UNSUPPORTED; }
+        return GSVC_OK;
+    }
+    GSVC_REQUIRE(inputs && embeddings && offsets && resolutions && outputs, "grid_forward: NULL pointer");
+#define FWD_CALL(D_, C_) launch_fwd<D_, C_>(inputs, embeddings, offsets, resolutions, outputs, N, L, dy_dx, s)
+    GSVC_DISPATCH_DC(FWD_CALL)
+#undef FWD_CALL
+    return check_launch("grid_forward");
+}
+
+extern "C" int gsvc_grid_backward(const float *grad, const float *inputs, const float *embeddings,
+                                  const int32_t *offsets, const int32_t *resolutions, float *grad_embeddings, uint32_t N,
+                                  uint32_t D, uint32_t C, uint32_t L, const float *dy_dx, float *grad_inputs,
+                                  void *stream)
+{
+    (void)embeddings;
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0 || L == 0) return GSVC_OK;
+    GSVC_REQUIRE(grad && inputs && offsets && resolutions && grad_embeddings, "grid_backward: NULL pointer");
+#define BWD_CALL(D_, C_) launch_bwd<D_, C_>(grad, inputs, offsets, resolutions, grad_embeddings, N, L, dy_dx, grad_inputs, s)
+    GSVC_DISPATCH_DC(BWD_CALL)
+#undef BWD_CALL
+    return check_launch("grid_backward");
+}

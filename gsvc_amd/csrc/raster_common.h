@@ -1,0 +1,181 @@
+// gsvc_amd/csrc/raster_common.h — per-Gaussian preprocess of the orthographic rasterizer (device) and the
+// layout of the three state blobs shared by forward and backward.
+//
+// Replaces the external CUDA extension GSVC imports as
+// diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer (reference README.md:52; call sites
+// reference ortho_gaussian_renderer/renderer.py:63-98, preprocess.py:58-104).  Spec: DESIGN.md "Raster spec".
+#pragma once
+#include "common.h"
+
+namespace gsvc {
+
+constexpr int TILE = 16;
+constexpr float LOWPASS = 0.3f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float T_MIN = 0.0001f;
+
+// One Gaussian as the blend kernels read it: 48 B, three 16-B loads.
+struct alignas(16) GeomRec {
+    float u, v, A, B;            // pixel-space centre, conic xx, xy
+    float C, opacity, r, g;      // conic yy, opacity, colour
+    float b, depth;              // colour, view-space z
+    uint32_t rect_x, rect_y;     // x0 | x1<<16,  y0 | y1<<16 (tile units, upper exclusive); 0 when culled
+};
+static_assert(sizeof(GeomRec) == 48, "GeomRec must be 48 bytes");
+
+struct RasterLayout {
+    int gx, gy, tiles;
+    uint64_t geom_bytes;
+    // binning blob
+    uint64_t off_counters, off_tile_offsets, off_tile_fill, off_keys, off_point_list, binning_bytes;
+    // image blob
+    uint64_t off_final_T, off_n_contrib, image_bytes;
+};
+
+inline RasterLayout raster_layout(const gsvc_raster_settings &s, int64_t P, int64_t max_instances)
+{
+    RasterLayout L;
+    L.gx = (s.image_width + TILE - 1) / TILE;
+    L.gy = (s.image_height + TILE - 1) / TILE;
+    L.tiles = L.gx * L.gy;
+    const uint64_t p = (uint64_t)(P > 0 ? P : 1), m = (uint64_t)(max_instances > 0 ? max_instances : 1);
+    L.geom_bytes = align_up(p * sizeof(GeomRec), 256);
+    uint64_t o = 0;
+    L.off_counters = o;      o += 256;
+    L.off_tile_offsets = o;  o += align_up((uint64_t)(L.tiles + 1) * 4, 256);
+    L.off_tile_fill = o;     o += align_up((uint64_t)L.tiles * 4, 256);
+    L.off_keys = o;          o += align_up(m * 8, 256);
+    L.off_point_list = o;    o += align_up(m * 4, 256);
+    L.binning_bytes = o;
+    const uint64_t hw = (uint64_t)s.image_height * (uint64_t)s.image_width;
+    L.off_final_T = 0;
+    L.off_n_contrib = align_up(hw * 4, 256);
+    L.image_bytes = L.off_n_contrib + align_up(hw * 4, 256);
+    return L;
+}
+
+// settings as the kernels take them (by value, in SGPRs)
+struct RasterParams {
+    int H, W, gx, gy;
+    float x_min, y_min, scale, threshold, scale_modifier;
+    float bg0, bg1, bg2;
+    float m[12];  // rows 0..2 of the view matrix
+};
+
+inline RasterParams make_params(const gsvc_raster_settings &s)
+{
+    RasterParams p;
+    p.H = s.image_height; p.W = s.image_width;
+    p.gx = (p.W + TILE - 1) / TILE; p.gy = (p.H + TILE - 1) / TILE;
+    p.x_min = s.x_min; p.y_min = s.y_min; p.scale = s.scale; p.threshold = s.threshold;
+    p.scale_modifier = s.scale_modifier;
+    p.bg0 = s.bg[0]; p.bg1 = s.bg[1]; p.bg2 = s.bg[2];
+    for (int i = 0; i < 12; i++) p.m[i] = s.viewmatrix[i];
+    return p;
+}
+
+#ifdef __HIPCC__
+
+__device__ __forceinline__ uint32_t order_bits(float f)
+{
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ int tile_clamp(float t, int g)
+{
+    t = fmaxf(t, -1.0f);
+    t = fminf(t, (float)g + 1.0f);
+    int i = (int)t;
+    i = i < 0 ? 0 : i;
+    i = i > g ? g : i;
+    return i;
+}
+
+struct PreOut {
+    float u, v, depth;
+    float A, B, C;     // conic
+    float a, b, c;     // 2-D covariance (low-pass included)
+    int radius;
+    int x0, y0, x1, y1;
+};
+
+// Steps 1-7 of the raster spec.  Every operation here decides an integer downstream (radius, tile
+// rectangle, depth key), so it is plain IEEE binary32 in a fixed order with no FMA contraction — the CPU
+// oracle repeats it bit for bit.  sqrt and division are the correctly rounded forms.
+__device__ __forceinline__ int preprocess_gaussian(const RasterParams &st, float px, float py, float pz,
+                                                   float s0, float s1, float s2, float qr, float qx, float qy,
+                                                   float qz, PreOut &o)
+{
+#pragma clang fp contract(off)
+    const float *M = st.m;
+    float xv = M[0] * px + M[1] * py + M[2] * pz + M[3];
+    float yv = M[4] * px + M[5] * py + M[6] * pz + M[7];
+    float zv = M[8] * px + M[9] * py + M[10] * pz + M[11];
+    o.radius = 0;
+    if (!(fabsf(zv) <= st.threshold)) return 0;
+
+    float R00 = 1.f - 2.f * (qy * qy + qz * qz);
+    float R01 = 2.f * (qx * qy - qr * qz);
+    float R02 = 2.f * (qx * qz + qr * qy);
+    float R10 = 2.f * (qx * qy + qr * qz);
+    float R11 = 1.f - 2.f * (qx * qx + qz * qz);
+    float R12 = 2.f * (qy * qz - qr * qx);
+    float R20 = 2.f * (qx * qz - qr * qy);
+    float R21 = 2.f * (qy * qz + qr * qx);
+    float R22 = 1.f - 2.f * (qx * qx + qy * qy);
+    float S0 = st.scale_modifier * s0, S1 = st.scale_modifier * s1, S2 = st.scale_modifier * s2;
+    float L00 = R00 * S0, L01 = R01 * S1, L02 = R02 * S2;
+    float L10 = R10 * S0, L11 = R11 * S1, L12 = R12 * S2;
+    float L20 = R20 * S0, L21 = R21 * S1, L22 = R22 * S2;
+    float c00 = L00 * L00 + L01 * L01 + L02 * L02;
+    float c01 = L00 * L10 + L01 * L11 + L02 * L12;
+    float c02 = L00 * L20 + L01 * L21 + L02 * L22;
+    float c11 = L10 * L10 + L11 * L11 + L12 * L12;
+    float c12 = L10 * L20 + L11 * L21 + L12 * L22;
+    float c22 = L20 * L20 + L21 * L21 + L22 * L22;
+
+    float T00 = st.scale * M[0], T01 = st.scale * M[1], T02 = st.scale * M[2];
+    float T10 = st.scale * M[4], T11 = st.scale * M[5], T12 = st.scale * M[6];
+    float U00 = c00 * T00 + c01 * T01 + c02 * T02;
+    float U01 = c01 * T00 + c11 * T01 + c12 * T02;
+    float U02 = c02 * T00 + c12 * T01 + c22 * T02;
+    float U10 = c00 * T10 + c01 * T11 + c02 * T12;
+    float U11 = c01 * T10 + c11 * T11 + c12 * T12;
+    float U12 = c02 * T10 + c12 * T11 + c22 * T12;
+    float ca = T00 * U00 + T01 * U01 + T02 * U02 + LOWPASS;
+    float cb = T00 * U10 + T01 * U11 + T02 * U12;
+    float cc = T10 * U10 + T11 * U11 + T12 * U12 + LOWPASS;
+    float det = ca * cc - cb * cb;
+    if (!(det != 0.0f)) return 0;
+    float det_inv = (1.0f / det);
+    o.a = ca; o.b = cb; o.c = cc;
+    o.A = cc * det_inv;
+    o.B = -cb * det_inv;
+    o.C = ca * det_inv;
+    float mid = 0.5f * (ca + cc);
+    float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+    float lam = fmaxf(mid + disc, mid - disc);
+    float rad_f = ceilf(3.0f * sqrtf(lam));
+    if (!(rad_f >= 0.0f)) return 0;
+    if (rad_f > 1.0e9f) rad_f = 1.0e9f;
+    int radius = (int)rad_f;
+
+    float u = (xv - st.x_min) * st.scale - 0.5f;
+    float v = (yv - st.y_min) * st.scale - 0.5f;
+    float rf = (float)radius;
+    int x0 = tile_clamp(((u - rf) / (float)TILE), st.gx);
+    int x1 = tile_clamp(((u + rf + (float)(TILE - 1)) / (float)TILE), st.gx);
+    int y0 = tile_clamp(((v - rf) / (float)TILE), st.gy);
+    int y1 = tile_clamp(((v + rf + (float)(TILE - 1)) / (float)TILE), st.gy);
+    if ((x1 - x0) * (y1 - y0) <= 0) return 0;
+    o.u = u; o.v = v; o.depth = zv;
+    o.radius = radius;
+    o.x0 = x0; o.y0 = y0; o.x1 = x1; o.y1 = y1;
+    return radius;
+}
+
+#endif  // __HIPCC__
+
+}  // namespace gsvc

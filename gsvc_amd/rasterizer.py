@@ -1,0 +1,223 @@
+"""Drop-in for ``diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer`` (external CUDA extension of
+GSVC, reference README.md:52) backed by the gfx950 HIP kernels of ``csrc/raster_{fwd,bwd}.hip``.
+
+Mirrors the surface GSVC uses:
+  * ``GaussianRasterizationSettings(image_height, image_width, x_min, y_min, scale, threshold, bg,
+    scale_modifier, viewmatrix, sh_degree, campos, prefiltered, debug)`` — keyword construction,
+    reference ortho_gaussian_renderer/renderer.py:63-83;
+  * ``GaussianRasterizer(raster_settings=...)(means3D=, means2D=, shs=, colors_precomp=, opacities=,
+    scales=, rotations=, cov3D_precomp=) -> (image[3,H,W], radii[P], num_rendered)``, renderer.py:85-98;
+  * ``GaussianRasterizer.visible_filter(means3D=, scales=, rotations=, cov3D_precomp=) -> radii``,
+    reference ortho_gaussian_renderer/preprocess.py:99-104;
+  * an autograd node: ``means2D.grad`` receives the screen-space gradient (renderer.py:37-42,
+    scene/gaussian_model.py:1311).
+
+Error behaviour follows the 3DGS lineage: missing scales/rotations, or both/neither of shs and
+colors_precomp, raise ``Exception``; shs and cov3D_precomp are not used by GSVC (it always passes
+colors_precomp / scales+rotations) and raise NotImplementedError here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    x_min: float
+    y_min: float
+    scale: float
+    threshold: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    sh_degree: int = 0
+    campos: Optional[torch.Tensor] = None
+    prefiltered: bool = False
+    debug: bool = False
+
+
+def _host_floats(t, n):
+    if isinstance(t, torch.Tensor):
+        a = t.detach().to("cpu", torch.float32).contiguous().view(-1).numpy()  # syncs if t lives on the GPU
+    else:
+        a = np.asarray(t, dtype=np.float32).reshape(-1)
+    if a.size != n:
+        raise ValueError(f"expected {n} floats, got {a.size}")
+    return a
+
+
+def settings_to_c(rs: GaussianRasterizationSettings) -> _lib.RasterSettingsC:
+    s = _lib.RasterSettingsC()
+    s.image_height, s.image_width = int(rs.image_height), int(rs.image_width)
+    s.x_min, s.y_min, s.scale = float(rs.x_min), float(rs.y_min), float(rs.scale)
+    s.threshold, s.scale_modifier = float(rs.threshold), float(rs.scale_modifier)
+    s.bg[:] = _host_floats(rs.bg, 3).tolist()
+    s.viewmatrix[:] = _host_floats(rs.viewmatrix, 16).tolist()
+    return s
+
+
+def _as_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class RasterState:
+    """Opaque state of one forward (geom / binning / image blobs) kept for backward and inspection."""
+
+    def __init__(self, cs, P, max_instances, geom, binning, image_state, radii):
+        self.cs, self.P, self.max_instances = cs, P, max_instances
+        self.geom, self.binning, self.image_state, self.radii = geom, binning, image_state, radii
+        self._counters = None
+
+    def counters(self):
+        """(num_rendered, overflow, num_visible, max_tile_len) — one 16-byte D2H copy (synchronises), cached."""
+        if self._counters is None:
+            self._counters = tuple(int(v) for v in self.binning[:16].view(torch.int32).tolist())
+        return self._counters
+
+    def tile_lists(self):
+        """(tile_offsets[T+1], point_list[num_rendered]) as int32 tensors (views into the binning blob)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(_lib.lib().gsvc_raster_binning_layout(C.byref(self.cs), self.P, self.max_instances, C.byref(a), C.byref(b)),
+                   "gsvc_raster_binning_layout")
+        H, W = self.cs.image_height, self.cs.image_width
+        T = ((H + 15) // 16) * ((W + 15) // 16)
+        n = self.counters()[0]
+        off = self.binning[a.value:a.value + 4 * (T + 1)].view(torch.int32)
+        pl = self.binning[b.value:b.value + 4 * n].view(torch.int32)
+        return off, pl
+
+    def image_aux(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(_lib.lib().gsvc_raster_image_layout(C.byref(self.cs), C.byref(a), C.byref(b)), "gsvc_raster_image_layout")
+        H, W = self.cs.image_height, self.cs.image_width
+        fT = self.image_state[a.value:a.value + 4 * H * W].view(torch.float32).view(H, W)
+        nc = self.image_state[b.value:b.value + 4 * H * W].view(torch.int32).view(H, W)
+        return fT, nc
+
+
+_capacity_hint = {}
+
+
+def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales, rotations, max_instances=None,
+                   sync=True):
+    """Launch the forward pipeline.  Returns (image, radii, state).  With ``sync`` the instance counters
+    are read back (16 B) and the call is repeated with a larger instance capacity if it overflowed; without
+    it the caller must check ``state.counters()[1]`` itself."""
+    L = _lib.lib()
+    P = int(means3D.shape[0])
+    dev = means3D.device
+    H, W = cs.image_height, cs.image_width
+    key = (H, W)
+    if max_instances is None:
+        max_instances = max(_capacity_hint.get(key, 0), 4 * P, 1 << 16)
+    stream = _lib.current_stream(dev)
+    while True:
+        sizes = _lib.RasterSizesC()
+        _lib.check(L.gsvc_raster_sizes_query(C.byref(cs), P, max_instances, C.byref(sizes)), "gsvc_raster_sizes_query")
+        geom = torch.empty(sizes.geom_bytes, dtype=torch.uint8, device=dev)
+        binning = torch.empty(sizes.binning_bytes, dtype=torch.uint8, device=dev)
+        image_state = torch.empty(sizes.image_bytes, dtype=torch.uint8, device=dev)
+        image = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        _lib.check(L.gsvc_raster_forward(C.byref(cs), P, max_instances, _lib.ptr(means3D), _lib.ptr(colors),
+                                         _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(image),
+                                         _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(binning), _lib.ptr(image_state), stream),
+                   "gsvc_raster_forward")
+        state = RasterState(cs, P, max_instances, geom, binning, image_state, radii)
+        if not sync:
+            return image, radii, state
+        n, overflow, _, _ = state.counters()
+        if not overflow:
+            _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 1024)
+            return image, radii, state
+        max_instances = int(n * 1.25) + 1024
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, cs, holder):
+        means3D, colors = _as_f32(means3D, "means3D"), _as_f32(colors, "colors_precomp")
+        opacities, scales, rotations = _as_f32(opacities, "opacities"), _as_f32(scales, "scales"), _as_f32(rotations, "rotations")
+        image, radii, state = raster_forward(cs, means3D, colors, opacities, scales, rotations)
+        ctx.state = state
+        ctx.save_for_backward(means3D, colors, opacities, scales, rotations)
+        ctx.mark_non_differentiable(radii)
+        holder["state"] = state
+        return image, radii
+
+    @staticmethod
+    def backward(ctx, grad_image, _grad_radii):
+        means3D, colors, opacities, scales, rotations = ctx.saved_tensors
+        st = ctx.state
+        P = st.P
+        dev = means3D.device
+        g = _as_f32(grad_image, "grad_image")
+        d3 = torch.empty(P, 3, device=dev)
+        d2 = torch.empty(P, 3, device=dev)
+        dc = torch.empty(P, 3, device=dev)
+        do = torch.empty(P, 1, device=dev)
+        ds = torch.empty(P, 3, device=dev)
+        dq = torch.empty(P, 4, device=dev)
+        scratch = torch.empty(max(P, 1) * 16, device=dev)
+        _lib.check(_lib.lib().gsvc_raster_backward(
+            C.byref(st.cs), P, st.max_instances, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opacities),
+            _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(st.radii), _lib.ptr(st.geom), _lib.ptr(st.binning),
+            _lib.ptr(st.image_state), _lib.ptr(g), _lib.ptr(d3), _lib.ptr(d2), _lib.ptr(dc), _lib.ptr(do), _lib.ptr(ds),
+            _lib.ptr(dq), _lib.ptr(scratch), _lib.current_stream(dev)), "gsvc_raster_backward")
+        return d3, d2, dc, do, ds, dq, None, None
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+        self._cs = None
+        self.last_state: Optional[RasterState] = None
+
+    def _c_settings(self):
+        if self._cs is None:
+            self._cs = settings_to_c(self.raster_settings)
+        return self._cs
+
+    def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
+        if cov3D_precomp is not None:
+            raise NotImplementedError("cov3D_precomp is not used by GSVC (pipe.compute_cov3D_python is False)")
+        if scales is None or rotations is None:
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        with torch.no_grad():
+            m, s, q = _as_f32(means3D, "means3D"), _as_f32(scales, "scales"), _as_f32(rotations, "rotations")
+            P = int(m.shape[0])
+            radii = torch.empty(P, dtype=torch.int32, device=m.device)
+            _lib.check(_lib.lib().gsvc_raster_visible_filter(C.byref(self._c_settings()), P, _lib.ptr(m), _lib.ptr(s),
+                                                             _lib.ptr(q), _lib.ptr(radii), _lib.current_stream(m.device)),
+                       "gsvc_raster_visible_filter")
+        return radii
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if shs is not None:
+            raise NotImplementedError("SH colours are not used by GSVC (sh_degree=0, colors_precomp always given)")
+        if cov3D_precomp is not None:
+            raise NotImplementedError("cov3D_precomp is not used by GSVC")
+        if scales is None or rotations is None:
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        holder = {}
+        image, radii = _RasterizeGaussians.apply(means3D, means2D, colors_precomp, opacities, scales, rotations,
+                                                 self._c_settings(), holder)
+        self.last_state = holder["state"]
+        num_rendered = self.last_state.counters()[0]
+        return image, radii, num_rendered

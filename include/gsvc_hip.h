@@ -1,0 +1,155 @@
+/*
+ * include/gsvc_hip.h — C-ABI of libgsvc_hip.so, the MI355X (gfx950) hot path of GSVC.
+ *
+ * Drop-in boundary: these entry points are what a GSVC maintainer binds in place of the two native
+ * extensions the renderer path imports (INTEGRATION.md shows the ctypes stubs):
+ *
+ *   diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer   (external pip dependency, reference README.md:52)
+ *       GaussianRasterizer.visible_filter   call site reference ortho_gaussian_renderer/preprocess.py:99-104
+ *       GaussianRasterizer.forward          call site reference ortho_gaussian_renderer/renderer.py:90-98
+ *       GaussianRasterizer.backward         implicit via autograd, reference pipeline/train.py:462
+ *   _gridencoder                                                  (reference submodules/gridencoder.zip)
+ *       grid_encode_forward / grid_encode_backward   gridencoder.zip!gridencoder/src/gridencoder.h:12-36,
+ *                                                    call sites reference utils/encodings.py:529-553,582-610
+ *   utils/entropy_models.py EntropyGaussian (+Low_bound)           reference utils/entropy_models.py:32-68,159-175
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless its name ends in _host;
+ *   - the caller owns every buffer (outputs, scratch blobs); nothing is allocated or freed inside, nothing
+ *     synchronises the device, so every call may be captured into a hipGraph;
+ *   - every call is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - return value: 0 = ok, negative = GSVC_E_*; gsvc_last_error() gives the message of the calling
+ *     thread's last failure;
+ *   - float = IEEE binary32, row-major, contiguous.
+ */
+#ifndef GSVC_HIP_H
+#define GSVC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSVC_OK 0
+#define GSVC_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
+#define GSVC_E_LAUNCH (-2)    /* HIP reported a launch error */
+#define GSVC_E_UNSUPPORTED (-3)
+
+const char *gsvc_last_error(void);
+/* "gsvc_hip <version> gfx950" */
+const char *gsvc_version(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Orthographic sliding-window rasterizer
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Fields of GaussianRasterizationSettings the extension reads (reference renderer.py:63-83).
+ * sh_degree / campos / prefiltered / debug carry no information for the colours_precomp path and are
+ * not part of the ABI.  viewmatrix is the LOGICAL 4x4 the reference passes (`frame.view_matrix.permute(1,0)`),
+ * row-major: p_view = M[:3,:3] p + M[:3,3]. */
+typedef struct gsvc_raster_settings {
+    int32_t image_height;
+    int32_t image_width;
+    float x_min;
+    float y_min;
+    float scale;
+    float threshold;
+    float scale_modifier;
+    float bg[3];
+    float viewmatrix[16];
+} gsvc_raster_settings;
+
+/* Byte sizes of the three opaque state blobs of one forward call (the 3DGS-lineage "geomBuffer /
+ * binningBuffer / imgBuffer" the reference extension hands back to autograd). */
+typedef struct gsvc_raster_sizes {
+    uint64_t geom_bytes;
+    uint64_t binning_bytes;
+    uint64_t image_bytes;
+} gsvc_raster_sizes;
+
+/* counters written by forward into the first 16 bytes of the binning blob */
+typedef struct gsvc_raster_counters {
+    int32_t num_rendered; /* sum of tiles touched = instances (true count even when it overflowed) */
+    int32_t overflow;     /* 1 when num_rendered > max_instances: image/state are NOT valid, retry bigger */
+    int32_t num_visible;  /* Gaussians with radius > 0 */
+    int32_t max_tile_len; /* longest per-tile list */
+} gsvc_raster_counters;
+
+int gsvc_raster_sizes_query(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
+                            gsvc_raster_sizes *sizes_host);
+
+/* radii[P] (int32): >0 iff the Gaussian's 3-sigma ellipse intersects the z-slab and the screen. */
+int gsvc_raster_visible_filter(const gsvc_raster_settings *settings, int64_t P, const float *means3D,
+                               const float *scales, const float *rotations, int32_t *radii, void *stream);
+
+/* Forward: means3D[P,3] colors[P,3] opacities[P] scales[P,3] rotations[P,4]  ->  image[3,H,W], radii[P].
+ * State blobs sized by gsvc_raster_sizes_query(settings, P, max_instances).  The counters struct sits at
+ * byte 0 of `binning`; copy it to the host when num_rendered is needed (the reference API returns it as a
+ * python int, reference renderer.py:90). */
+int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
+                        const float *means3D, const float *colors, const float *opacities, const float *scales,
+                        const float *rotations, float *image, int32_t *radii, void *geom, void *binning,
+                        void *image_state, void *stream);
+
+/* Backward: dL_dimage[3,H,W] + the forward's inputs and state  ->  gradients (all overwritten):
+ * dL_dmeans3D[P,3], dL_dmeans2D[P,3] (screen-space gradient in NDC units, the tensor GSVC's densification
+ * reads, reference scene/gaussian_model.py:1311), dL_dcolors[P,3], dL_dopacities[P], dL_dscales[P,3],
+ * dL_drotations[P,4].  `scratch` = P*16*4 bytes, zeroed inside. */
+int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
+                         const float *means3D, const float *colors, const float *opacities, const float *scales,
+                         const float *rotations, const int32_t *radii, const void *geom, const void *binning,
+                         const void *image_state, const float *dL_dimage, float *dL_dmeans3D, float *dL_dmeans2D,
+                         float *dL_dcolors, float *dL_dopacities, float *dL_dscales, float *dL_drotations,
+                         void *scratch, void *stream);
+
+/* Test/inspection helpers: locate the sorted per-tile lists inside the binning blob.
+ * tile_offsets_host_out: byte offset of int32 tile_offsets[T+1]; point_list: byte offset of int32 ids. */
+int gsvc_raster_binning_layout(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
+                               uint64_t *tile_offsets_byte_off_host, uint64_t *point_list_byte_off_host);
+int gsvc_raster_image_layout(const gsvc_raster_settings *settings, uint64_t *final_T_byte_off_host,
+                             uint64_t *n_contrib_byte_off_host);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Multi-resolution hash grid (replaces _gridencoder.grid_encode_forward / grid_encode_backward)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* inputs[N,D] in [0,1]; embeddings[rows,C]; offsets[L+1], resolutions[L] (int32, device, already sliced to
+ * the levels to compute); outputs[L,N,C]; dy_dx[N, L*D*C] or NULL.
+ * D in {1,2,3}, C in {1,2,4,8,16,32} (else GSVC_E_UNSUPPORTED with the reference's message). */
+int gsvc_grid_forward(const float *inputs, const float *embeddings, const int32_t *offsets,
+                      const int32_t *resolutions, float *outputs, uint32_t N, uint32_t D, uint32_t C, uint32_t L,
+                      float *dy_dx, void *stream);
+
+/* grad[L,N,C]; grad_embeddings[rows,C] is ACCUMULATED into (caller zero-fills, reference encodings.py:574);
+ * grad_inputs[N,D] is overwritten when dy_dx != NULL. */
+int gsvc_grid_backward(const float *grad, const float *inputs, const float *embeddings, const int32_t *offsets,
+                       const int32_t *resolutions, float *grad_embeddings, uint32_t N, uint32_t D, uint32_t C,
+                       uint32_t L, const float *dy_dx, float *grad_inputs, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Entropy-rate estimator (replaces utils/entropy_models.py EntropyGaussian.forward + Low_bound backward)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* bits[n,c] = -log2(max(Phi((x+Q/2-mu)/sigma) - Phi((x-Q/2-mu)/sigma), 2^-16)) with x clamped to
+ * [x_lo, x_hi] first (the caller computes x_mean -/+ 15000*mean(Q), reference entropy_models.py:40-47;
+ * pass -inf/+inf to disable).  x, mean, scale: [n,c];  Q: [n] (per row) or NULL with Q_scalar.
+ * row_weight: [n,c] multiplier folded into the sum (the offsets mask) or NULL.
+ * Outputs: bits[n,c] (may be NULL) and bits_sum[1] (double precision accumulate, float result, ADDED to). */
+int gsvc_rate_forward(const float *x, const float *mean, const float *scale, const float *Q, float Q_scalar,
+                      const float *weight, const float *x_lo, const float *x_hi, int64_t n, int64_t c,
+                      float *bits, float *bits_sum, void *stream);
+
+/* d(sum(weight*bits)*gscale)/d{x, mean, scale, Q[n], weight}; any output pointer may be NULL.
+ * Low_bound rule: gradient passes only where the likelihood >= 2^-16 (reference entropy_models.py:166-175,
+ * net effect). gscale_dev: device scalar multiplying every gradient (dL/d bits_sum). dQ[n] is accumulated. */
+int gsvc_rate_backward(const float *x, const float *mean, const float *scale, const float *Q, float Q_scalar,
+                       const float *weight, const float *x_lo, const float *x_hi, int64_t n, int64_t c,
+                       const float *gscale_dev, float *dx, float *dmean, float *dscale, float *dQ, float *dweight,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSVC_HIP_H */

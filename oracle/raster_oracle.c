@@ -267,10 +267,10 @@ int64_t gsvc_oracle_raster_forward(const oracle_raster_settings *st, int64_t P, 
                     if (power > 0.0f) continue;
                     float o = opacities[id];
                     float alpha = fminf(ALPHA_MAX, o * expf(power));
-                    if (fabsf(alpha - ALPHA_MIN) < 1e-4f * ALPHA_MIN) bl = 1;
+                    if (fabsf(alpha - ALPHA_MIN) < 2e-5f * ALPHA_MIN) bl = 1;
                     if (alpha < ALPHA_MIN) continue;
                     float test_T = T * (1.0f - alpha);
-                    if (fabsf(test_T - T_MIN) < 1e-3f * T_MIN) bl = 1;
+                    if (fabsf(test_T - T_MIN) < 1e-4f * T_MIN) bl = 1;
                     if (test_T < T_MIN) break;
                     const float *c = colors + 3 * id;
                     float w = alpha * T;
