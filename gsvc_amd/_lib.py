@@ -43,6 +43,8 @@ _f = C.c_float
 _SIGNATURES = {
     "gsvc_last_error": (C.c_char_p, []),
     "gsvc_version": (C.c_char_p, []),
+    "gsvc_profile_enable": (C.c_int, [C.c_int]),
+    "gsvc_profile_collect": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int]),
     "gsvc_raster_sizes_query": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64, C.POINTER(RasterSizesC)]),
     "gsvc_raster_visible_filter": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_raster_forward": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64] + [_vp] * 11),
@@ -95,3 +97,22 @@ def ptr(t):
 def current_stream(device=None):
     import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def profile_enable(on: bool):
+    check(lib().gsvc_profile_enable(1 if on else 0), "gsvc_profile_enable")
+
+
+def profile_collect(max_kernels: int = 64):
+    """{kernel name: (launches, total_ms)} since the last collect (synchronises the recorded events)."""
+    names = C.create_string_buffer(64 * max_kernels)
+    launches = (C.c_int32 * max_kernels)()
+    ms = (C.c_float * max_kernels)()
+    n = lib().gsvc_profile_collect(names, launches, ms, max_kernels)
+    if n < 0:
+        check(n, "gsvc_profile_collect")
+    out = {}
+    for i in range(n):
+        name = names.raw[64 * i:64 * (i + 1)].split(b"\0", 1)[0].decode()
+        out[name] = (int(launches[i]), float(ms[i]))
+    return out

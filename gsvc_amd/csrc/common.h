@@ -22,6 +22,24 @@ inline int check_launch(const char *what)
     return GSVC_OK;
 }
 
+// bench.py's per-kernel timer: brackets a launch with events on its stream when profiling is enabled
+bool profile_enabled();
+void profile_begin(const char *name, hipStream_t s);
+void profile_end(hipStream_t s);
+
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfScope(const char *name, hipStream_t stream) : s(stream), on(profile_enabled())
+    {
+        if (on) profile_begin(name, s);
+    }
+    ~ProfScope()
+    {
+        if (on) profile_end(s);
+    }
+};
+
 inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace gsvc

@@ -267,17 +267,17 @@ template <uint32_t D, uint32_t C>
 static void launch_fwd(const float *inputs, const float *emb, const int32_t *off, const int32_t *res, float *out,
                        uint32_t N, uint32_t L, float *dy_dx, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_grid_fwd<D, C>), dim3((N + 255) / 256, L), dim3(256), 0, s, inputs, emb, off, res, out, N, L,
-                       dy_dx);
+    { ProfScope _prof("k_grid_fwd", s); hipLaunchKernelGGL((k_grid_fwd<D, C>), dim3((N + 255) / 256, L), dim3(256), 0, s, inputs, emb, off, res, out, N, L,
+                       dy_dx); }
 }
 
 template <uint32_t D, uint32_t C>
 static void launch_bwd(const float *grad, const float *inputs, const int32_t *off, const int32_t *res, float *gemb,
                        uint32_t N, uint32_t L, const float *dy_dx, float *ginp, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_grid_bwd<D, C>), dim3((N + 255) / 256, L), dim3(256), 0, s, grad, inputs, off, res, gemb, N);
+    { ProfScope _prof("k_grid_bwd", s); hipLaunchKernelGGL((k_grid_bwd<D, C>), dim3((N + 255) / 256, L), dim3(256), 0, s, grad, inputs, off, res, gemb, N); }
     if (dy_dx && ginp)
-        hipLaunchKernelGGL((k_grid_input_bwd<D, C>), dim3((N * D + 255) / 256), dim3(256), 0, s, grad, dy_dx, ginp, N, L);
+        { ProfScope _prof("k_grid_input_bwd", s); hipLaunchKernelGGL((k_grid_input_bwd<D, C>), dim3((N * D + 255) / 256), dim3(256), 0, s, grad, dy_dx, ginp, N, L); }
 }
 
 #define GSVC_DISPATCH_C(D_, CALL)                                                        \

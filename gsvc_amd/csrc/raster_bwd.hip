@@ -234,10 +234,10 @@ extern "C" int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_
         set_error("raster_backward: hipMemsetAsync failed");
         return GSVC_E_LAUNCH;
     }
-    hipLaunchKernelGGL(k_blend_bwd, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list,
-                       (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters);
-    hipLaunchKernelGGL(k_gaussian_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D, scales,
+    { ProfScope _prof("k_blend_bwd", s); hipLaunchKernelGGL(k_blend_bwd, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list,
+                       (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters); }
+    { ProfScope _prof("k_gaussian_bwd", s); hipLaunchKernelGGL(k_gaussian_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D, scales,
                        rotations, radii, (const float *)scratch, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacities,
-                       dL_dscales, dL_drotations);
+                       dL_dscales, dL_drotations); }
     return check_launch("raster_backward");
 }

@@ -321,9 +321,9 @@ extern "C" int gsvc_raster_visible_filter(const gsvc_raster_settings *settings, 
     GSVC_REQUIRE(means3D && scales && rotations && radii, "visible_filter: NULL pointer");
     const RasterParams p = make_params(*settings);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_preprocess<true>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
+    { ProfScope _prof("k_preprocess", s); hipLaunchKernelGGL(k_preprocess<true>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
                        (const float *)nullptr, (const float *)nullptr, scales, rotations, radii, (GeomRec *)nullptr,
-                       (int32_t *)nullptr, (gsvc_raster_counters *)nullptr);
+                       (int32_t *)nullptr, (gsvc_raster_counters *)nullptr); }
     return check_launch("visible_filter");
 }
 
@@ -355,20 +355,20 @@ extern "C" int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t
         return GSVC_E_LAUNCH;
     }
     if (P > 0) {
-        hipLaunchKernelGGL(k_preprocess<false>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
-                           colors, opacities, scales, rotations, radii, (GeomRec *)geom, tile_fill, counters);
+        { ProfScope _prof("k_preprocess", s); hipLaunchKernelGGL(k_preprocess<false>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
+                           colors, opacities, scales, rotations, radii, (GeomRec *)geom, tile_fill, counters); }
     }
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, L.tiles, tile_fill, tile_offsets, counters,
-                       (long long)max_instances);
+    { ProfScope _prof("k_scan_tiles", s); hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, L.tiles, tile_fill, tile_offsets, counters,
+                       (long long)max_instances); }
     if (P > 0) {
-        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (int)P, L.gx,
-                           (const GeomRec *)geom, tile_offsets, tile_fill, keys, counters);
-        hipLaunchKernelGGL(k_sort_tiles_wave, dim3(L.tiles), dim3(64), 0, s, L.tiles, tile_offsets, keys, point_list,
-                           counters);
-        hipLaunchKernelGGL(k_sort_tiles_wg, dim3(L.tiles), dim3(256), SORT_WG_MAX * sizeof(uint64_t), s, L.tiles,
-                           tile_offsets, keys, point_list, counters);
+        { ProfScope _prof("k_scatter", s); hipLaunchKernelGGL(k_scatter, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (int)P, L.gx,
+                           (const GeomRec *)geom, tile_offsets, tile_fill, keys, counters); }
+        { ProfScope _prof("k_sort_tiles_wave", s); hipLaunchKernelGGL(k_sort_tiles_wave, dim3(L.tiles), dim3(64), 0, s, L.tiles, tile_offsets, keys, point_list,
+                           counters); }
+        { ProfScope _prof("k_sort_tiles_wg", s); hipLaunchKernelGGL(k_sort_tiles_wg, dim3(L.tiles), dim3(256), SORT_WG_MAX * sizeof(uint64_t), s, L.tiles,
+                           tile_offsets, keys, point_list, counters); }
     }
-    hipLaunchKernelGGL(k_blend, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list,
-                       (const GeomRec *)geom, image, final_T, n_contrib, counters);
+    { ProfScope _prof("k_blend", s); hipLaunchKernelGGL(k_blend, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list,
+                       (const GeomRec *)geom, image, final_T, n_contrib, counters); }
     return check_launch("raster_forward");
 }

@@ -123,8 +123,8 @@ extern "C" int gsvc_rate_forward(const float *x, const float *mean, const float 
     const long long total = (long long)n * c;
     long long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_rate_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, scale, Q, Q_scalar,
-                       weight, x_lo, x_hi, total, (int)c, bits, bits_sum);
+    { ProfScope _prof("k_rate_fwd", (hipStream_t)stream); hipLaunchKernelGGL(k_rate_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, scale, Q, Q_scalar,
+                       weight, x_lo, x_hi, total, (int)c, bits, bits_sum); }
     return check_launch("rate_forward");
 }
 
@@ -138,7 +138,7 @@ extern "C" int gsvc_rate_backward(const float *x, const float *mean, const float
     GSVC_REQUIRE(x && mean && scale, "rate_backward: NULL input");
     long long blocks = (n + 3) / 4;  // 4 waves (rows) per workgroup
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_rate_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, scale, Q, Q_scalar,
-                       weight, x_lo, x_hi, (long long)n, (int)c, gscale_dev, dx, dmean, dscale, dQ, dweight);
+    { ProfScope _prof("k_rate_bwd", (hipStream_t)stream); hipLaunchKernelGGL(k_rate_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, scale, Q, Q_scalar,
+                       weight, x_lo, x_hi, (long long)n, (int)c, gscale_dev, dx, dmean, dscale, dQ, dweight); }
     return check_launch("rate_backward");
 }

@@ -41,6 +41,13 @@ const char *gsvc_last_error(void);
 /* "gsvc_hip <version> gfx950" */
 const char *gsvc_version(void);
 
+/* Per-kernel timing for bench.py (not a drop-in entry point).  While enabled, every kernel launch made by
+ * this library is bracketed by hipEvents on its own stream.  gsvc_profile_collect synchronises those events
+ * and returns, per kernel name, the launch count and total milliseconds since the last collect/enable.
+ * names_out: `max_kernels` slots of 64 bytes.  Returns the number of kernels written (<0 on error). */
+int gsvc_profile_enable(int on);
+int gsvc_profile_collect(char *names_out_host, int32_t *launches_out_host, float *total_ms_out_host, int max_kernels);
+
 /* ------------------------------------------------------------------------------------------------------
  * Orthographic sliding-window rasterizer
  * ---------------------------------------------------------------------------------------------------- */
