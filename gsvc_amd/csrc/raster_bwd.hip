@@ -17,35 +17,77 @@ namespace gsvc {
 
 constexpr int ACC_STRIDE = 16;  // floats per Gaussian in the accumulator (9 used, 64-B rows)
 
-__device__ __forceinline__ float wave_sum(float v)
+// DPP wave reduction of nine values at once (sums of the 64 lanes land in lane 63): two quad_perm steps and
+// row_shr:4 / row_shr:8 inside each 16-lane row, then row_bcast:15 / row_bcast:31 across rows.  VALU only (no
+// LDS traffic, unlike ds_bpermute shuffles).  Written as one asm block of 54 v_add_f32_dpp so hipcc neither
+// splits them into v_mov_dpp + packed adds nor reorders them; the nine chains are interleaved, which also
+// keeps every DPP read >= 2 instructions behind the write of its source (the DPP wait-state rule; the
+// leading s_nop covers the compiler-scheduled producer of the inputs).  EXEC must be all ones.
+#define GSVC_DPP9(CTRL)                                  \
+    "v_add_f32_dpp %0, %0, %0 " CTRL "\n"                \
+    "v_add_f32_dpp %1, %1, %1 " CTRL "\n"                \
+    "v_add_f32_dpp %2, %2, %2 " CTRL "\n"                \
+    "v_add_f32_dpp %3, %3, %3 " CTRL "\n"                \
+    "v_add_f32_dpp %4, %4, %4 " CTRL "\n"                \
+    "v_add_f32_dpp %5, %5, %5 " CTRL "\n"                \
+    "v_add_f32_dpp %6, %6, %6 " CTRL "\n"                \
+    "v_add_f32_dpp %7, %7, %7 " CTRL "\n"                \
+    "v_add_f32_dpp %8, %8, %8 " CTRL "\n"
+
+__device__ __forceinline__ void wave_sum9_to_lane63(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
+                                                    float &a6, float &a7, float &a8)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    asm volatile("s_nop 1\n"
+                 GSVC_DPP9("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 GSVC_DPP9("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 GSVC_DPP9("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 GSVC_DPP9("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 GSVC_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 GSVC_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
 }
 
+__device__ __forceinline__ int sext16b(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
+
+__device__ __forceinline__ bool bbox_hits_b(uint2 bb, int qx0, int qy0)
+{
+    return !(sext16b(bb.x) > qx0 + 7 || sext16b(bb.x >> 16) < qx0 || sext16b(bb.y) > qy0 + 7 || sext16b(bb.y >> 16) < qy0);
+}
+
+// One workgroup per 16x16 tile, one wave per 8x8 quadrant.  The tile list is walked back to front in chunks
+// of 64 entries; per chunk each wave keeps only the entries whose alpha bounding box touches its quadrant
+// (one vector test for 64 entries), replays the compositing for those, reduces the nine per-Gaussian sums
+// over its 64 pixels with DPP, and adds them to a per-chunk LDS accumulator shared by the four waves.
+// The accumulator is flushed with one 36-byte atomic segment per touched entry.
 __global__ void __launch_bounds__(256) k_blend_bwd(RasterParams st, const int32_t *__restrict__ tile_offsets,
                                                    const int32_t *__restrict__ point_list,
+                                                   const uint2 *__restrict__ inst_bbox,
                                                    const GeomRec *__restrict__ geom,
                                                    const float *__restrict__ final_T,
                                                    const int32_t *__restrict__ n_contrib,
                                                    const float *__restrict__ dL_dimage, float *__restrict__ acc,
                                                    const gsvc_raster_counters *__restrict__ counters)
 {
-    __shared__ int sid[256];
-    __shared__ float4 s0[256];  // u v A B
-    __shared__ float4 s1[256];  // C opacity r g
-    __shared__ float s2[256];   // b
+    __shared__ float4 s_f0[4][64];   // u v A B
+    __shared__ float4 s_f1[4][64];   // C opacity r g
+    __shared__ float2 s_f2[4][64];   // b, (chunk-local entry index | list position << 8) as int bits
+    __shared__ float s_part[4][64][9];   // per wave, per chunk entry: du dv dA dB dC dopacity dr dg db
+    __shared__ int s_id[64];
+    __shared__ unsigned long long s_touched[4];  // per wave: chunk entries it wrote partial sums for
+    __shared__ int s_last[4];
     if (counters->overflow) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int lx = tid & 15, ly = tid >> 4;
-    const int tile = blockIdx.y * st.gx + blockIdx.x;
-    const int px = blockIdx.x * TILE + lx, py = blockIdx.y * TILE + ly;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qx0 = blockIdx.x * TILE + 8 * (wave & 1), qy0 = blockIdx.y * TILE + 8 * (wave >> 1);
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < st.W && py < st.H;
-    const int beg = tile_offsets[tile], end = tile_offsets[tile + 1];
-    const int n = end - beg;
+    const int tile = blockIdx.y * st.gx + blockIdx.x;
+    const int beg = tile_offsets[tile];
     const float fx = (float)px, fy = (float)py;
     const int HW = st.H * st.W, pix = py * st.W + px;
+    float4 *w_f0 = s_f0[wave];
+    float4 *w_f1 = s_f1[wave];
+    float2 *w_f2 = s_f2[wave];
 
     const float Tf = inside ? final_T[pix] : 0.f;
     const int last = inside ? n_contrib[pix] : 0;
@@ -56,75 +98,104 @@ __global__ void __launch_bounds__(256) k_blend_bwd(RasterParams st, const int32_
     float T = Tf;
     float behind0 = 0.f, behind1 = 0.f, behind2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
 
-    // the whole workgroup can stop once it is past every pixel's last contributor
-    int wg_last = last;
+    // nobody in the workgroup reaches list entries past the largest n_contrib
+    int wl = last;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) wg_last = max(wg_last, __shfl_xor(wg_last, m, 64));
-    __shared__ int s_last[4];
-    if (lane == 0) s_last[tid >> 6] = wg_last;
+    for (int m = 32; m >= 1; m >>= 1) wl = max(wl, __shfl_xor(wl, m, 64));
+    if (lane == 0) s_last[wave] = wl;
     __syncthreads();
-    wg_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-    const int skip = n - wg_last;  // list tail nobody reached
+    const int wg_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
 
-    for (int base = skip; base < n; base += 256) {
-        __syncthreads();
-        const int k = end - 1 - (base + tid);
-        if (k >= beg) {
-            const int id = point_list[k];
-            const float4 *src = reinterpret_cast<const float4 *>(geom + id);
-            sid[tid] = id;
-            s0[tid] = src[0];
-            s1[tid] = src[1];
-            s2[tid] = src[2].x;
+    for (int c1 = beg + wg_last; c1 > beg; c1 -= 64) {
+        // chunk = list entries [c1-64, c1) ∩ [beg, c1); chunk-local index e = c1 - 1 - k (back to front)
+        if (tid < 64) {
+            const int k = c1 - 1 - tid;
+            s_id[tid] = k >= beg ? point_list[k] : -1;
         }
         __syncthreads();
-        const int m = min(256, n - base);
-        for (int j = 0; j < m; j++) {
-            const int contributor = n - base - j;  // 1-based position in the tile list
-            const float4 a = s0[j];
-            const float4 b = s1[j];
-            const float cb = s2[j];
-            const float dx = a.x - fx, dy = a.y - fy;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(ALPHA_MAX, b.y * G);
-            const bool valid = (contributor <= last) && (power <= 0.0f) && (alpha >= ALPHA_MIN);
-            if (__ballot(valid) == 0ull) continue;  // wave-uniform
-            float v_du = 0.f, v_dv = 0.f, v_dA = 0.f, v_dB = 0.f, v_dC = 0.f, v_do = 0.f, v_r = 0.f, v_g = 0.f, v_b = 0.f;
-            if (valid) {
-                T = T / (1.0f - alpha);
-                const float w = alpha * T;
-                behind0 = last_alpha * lc0 + (1.0f - last_alpha) * behind0;
-                behind1 = last_alpha * lc1 + (1.0f - last_alpha) * behind1;
-                behind2 = last_alpha * lc2 + (1.0f - last_alpha) * behind2;
-                lc0 = b.z; lc1 = b.w; lc2 = cb;
-                float dL_dalpha = (b.z - behind0) * d0 + (b.w - behind1) * d1 + (cb - behind2) * d2;
-                v_r = w * d0; v_g = w * d1; v_b = w * d2;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-Tf / (1.0f - alpha)) * bg_dot;
-                const float dL_dG = b.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                v_du = dL_dG * (-gdx * a.z - gdy * a.w);
-                v_dv = dL_dG * (-gdy * b.x - gdx * a.w);
-                v_dA = -0.5f * gdx * dx * dL_dG;
-                v_dB = -gdx * dy * dL_dG;
-                v_dC = -0.5f * gdy * dy * dL_dG;
-                v_do = G * dL_dalpha;
+        {
+            unsigned long long touched = 0ull;
+            const int k = c1 - 1 - lane;
+            bool hit = false;
+            if (k >= beg && (k - beg) < wl) hit = bbox_hits_b(inst_bbox[k], qx0, qy0);
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull) {
+                if (hit) {
+                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                    const float4 *rec = reinterpret_cast<const float4 *>(geom + s_id[lane]);
+                    w_f0[pos] = rec[0];
+                    w_f1[pos] = rec[1];
+                    w_f2[pos] = make_float2(rec[2].x, __int_as_float(lane | ((k - beg + 1) << 8)));
+                }
+                const int cnt = __popcll(mask);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int j = 0; j < cnt; j++) {
+                    const float4 a = w_f0[j];
+                    const float4 b = w_f1[j];
+                    const float2 c = w_f2[j];
+                    const int tag = __float_as_int(c.y);
+                    const int contributor = tag >> 8;
+                    const float dx = a.x - fx, dy = a.y - fy;
+                    const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                    const float G = __expf(power);
+                    const float alpha = fminf(ALPHA_MAX, b.y * G);
+                    const bool valid = (contributor <= last) && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+                    if (__ballot(valid) == 0ull) continue;  // wave-uniform
+                    float v_du = 0.f, v_dv = 0.f, v_dA = 0.f, v_dB = 0.f, v_dC = 0.f, v_do = 0.f, v_r = 0.f, v_g = 0.f, v_b = 0.f;
+                    if (valid) {
+                        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+                        T = T * inv;
+                        const float w = alpha * T;
+                        behind0 = last_alpha * lc0 + (1.0f - last_alpha) * behind0;
+                        behind1 = last_alpha * lc1 + (1.0f - last_alpha) * behind1;
+                        behind2 = last_alpha * lc2 + (1.0f - last_alpha) * behind2;
+                        lc0 = b.z; lc1 = b.w; lc2 = c.x;
+                        float dL_dalpha = (b.z - behind0) * d0 + (b.w - behind1) * d1 + (c.x - behind2) * d2;
+                        v_r = w * d0; v_g = w * d1; v_b = w * d2;
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha -= Tf * inv * bg_dot;
+                        const float dL_dG = b.y * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        v_du = dL_dG * (-gdx * a.z - gdy * a.w);
+                        v_dv = dL_dG * (-gdy * b.x - gdx * a.w);
+                        v_dA = -0.5f * gdx * dx * dL_dG;
+                        v_dB = -gdx * dy * dL_dG;
+                        v_dC = -0.5f * gdy * dy * dL_dG;
+                        v_do = G * dL_dalpha;
+                    }
+                    wave_sum9_to_lane63(v_du, v_dv, v_dA, v_dB, v_dC, v_do, v_r, v_g, v_b);
+                    const int e = tag & 0xff;
+                    touched |= 1ull << e;
+                    if (lane == 63) {
+                        float *dst = s_part[wave][e];
+                        dst[0] = v_du; dst[1] = v_dv; dst[2] = v_dA; dst[3] = v_dB; dst[4] = v_dC; dst[5] = v_do;
+                        dst[6] = v_r; dst[7] = v_g; dst[8] = v_b;
+                    }
+                }
             }
-            v_du = wave_sum(v_du); v_dv = wave_sum(v_dv); v_dA = wave_sum(v_dA); v_dB = wave_sum(v_dB);
-            v_dC = wave_sum(v_dC); v_do = wave_sum(v_do); v_r = wave_sum(v_r); v_g = wave_sum(v_g); v_b = wave_sum(v_b);
-            float out = v_du;
-            out = lane == 1 ? v_dv : out;
-            out = lane == 2 ? v_dA : out;
-            out = lane == 3 ? v_dB : out;
-            out = lane == 4 ? v_dC : out;
-            out = lane == 5 ? v_do : out;
-            out = lane == 6 ? v_r : out;
-            out = lane == 7 ? v_g : out;
-            out = lane == 8 ? v_b : out;
-            if (lane < 9) atomicAdd(acc + (size_t)sid[j] * ACC_STRIDE + lane, out);
+            if (lane == 0) s_touched[wave] = touched;
         }
+        __syncthreads();
+        // flush: 9 consecutive lanes per touched entry -> one 36-byte atomic segment in the entry's 64-byte row
+        {
+            const unsigned long long t0 = s_touched[0], t1 = s_touched[1], t2 = s_touched[2], t3 = s_touched[3];
+            const unsigned long long any = t0 | t1 | t2 | t3;
+            for (int v = tid; v < 64 * 9; v += 256) {
+                const int e = v / 9, comp = v - e * 9;
+                if ((any >> e) & 1ull) {
+                    float sum = 0.f;
+                    if ((t0 >> e) & 1ull) sum += s_part[0][e][comp];
+                    if ((t1 >> e) & 1ull) sum += s_part[1][e][comp];
+                    if ((t2 >> e) & 1ull) sum += s_part[2][e][comp];
+                    if ((t3 >> e) & 1ull) sum += s_part[3][e][comp];
+                    atomicAdd(acc + (size_t)s_id[e] * ACC_STRIDE + comp, sum);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -228,13 +299,14 @@ extern "C" int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_
     auto *counters = (const gsvc_raster_counters *)(bin + L.off_counters);
     auto *tile_offsets = (const int32_t *)(bin + L.off_tile_offsets);
     auto *point_list = (const int32_t *)(bin + L.off_point_list);
+    auto *inst_bbox = (const uint2 *)(bin + L.off_inst_bbox);
     auto *final_T = (const float *)((const char *)image_state + L.off_final_T);
     auto *n_contrib = (const int32_t *)((const char *)image_state + L.off_n_contrib);
     if (hipMemsetAsync(scratch, 0, (size_t)P * ACC_STRIDE * sizeof(float), s) != hipSuccess) {
         set_error("raster_backward: hipMemsetAsync failed");
         return GSVC_E_LAUNCH;
     }
-    { ProfScope _prof("k_blend_bwd", s); hipLaunchKernelGGL(k_blend_bwd, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list,
+    { ProfScope _prof("k_blend_bwd", s); hipLaunchKernelGGL(k_blend_bwd, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list, inst_bbox,
                        (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters); }
     { ProfScope _prof("k_gaussian_bwd", s); hipLaunchKernelGGL(k_gaussian_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D, scales,
                        rotations, radii, (const float *)scratch, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacities,

@@ -15,20 +15,33 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_MIN = 0.0001f;
 
-// One Gaussian as the blend kernels read it: 48 B, three 16-B loads.
+// One Gaussian as the blend kernels read it: 48 B, three 16-B (scalar) loads.
 struct alignas(16) GeomRec {
     float u, v, A, B;            // pixel-space centre, conic xx, xy
     float C, opacity, r, g;      // conic yy, opacity, colour
-    float b, depth;              // colour, view-space z
-    uint32_t rect_x, rect_y;     // x0 | x1<<16,  y0 | y1<<16 (tile units, upper exclusive); 0 when culled
+    float b;                     // colour
+    uint32_t bbox_x, bbox_y;     // int16 pairs lo|hi<<16: pixels outside can never reach alpha >= 1/255
+    float depth;                 // view-space z
 };
 static_assert(sizeof(GeomRec) == 48, "GeomRec must be 48 bytes");
 
+// One Gaussian as the binning kernels read it: 32 B.
+constexpr int BIN_SLOTS = 4;     // instance slots resolved by K1's LDS histogram; further tiles take the atomic path
+struct alignas(16) BinRec {
+    float depth;
+    uint32_t rect_x, rect_y;     // x0 | x1<<16,  y0 | y1<<16 (tile units, upper exclusive); 0 when culled
+    uint32_t pad;
+    int32_t slot[BIN_SLOTS];     // position of the Gaussian's first tiles inside each tile's segment
+};
+static_assert(sizeof(BinRec) == 32, "BinRec must be 32 bytes");
+
 struct RasterLayout {
     int gx, gy, tiles;
-    uint64_t geom_bytes;
+    // geom blob
+    uint64_t off_geom, off_bin, geom_bytes;
     // binning blob
-    uint64_t off_counters, off_tile_offsets, off_tile_fill, off_keys, off_point_list, binning_bytes;
+    uint64_t off_counters, off_tile_offsets, off_tile_count, off_tile_extra, off_keys, off_point_list, off_inst_bbox,
+        binning_bytes;
     // image blob
     uint64_t off_final_T, off_n_contrib, image_bytes;
 };
@@ -40,13 +53,17 @@ inline RasterLayout raster_layout(const gsvc_raster_settings &s, int64_t P, int6
     L.gy = (s.image_height + TILE - 1) / TILE;
     L.tiles = L.gx * L.gy;
     const uint64_t p = (uint64_t)(P > 0 ? P : 1), m = (uint64_t)(max_instances > 0 ? max_instances : 1);
-    L.geom_bytes = align_up(p * sizeof(GeomRec), 256);
+    L.off_geom = 0;
+    L.off_bin = align_up(p * sizeof(GeomRec), 256);
+    L.geom_bytes = L.off_bin + align_up(p * sizeof(BinRec), 256);
     uint64_t o = 0;
     L.off_counters = o;      o += 256;
     L.off_tile_offsets = o;  o += align_up((uint64_t)(L.tiles + 1) * 4, 256);
-    L.off_tile_fill = o;     o += align_up((uint64_t)L.tiles * 4, 256);
+    L.off_tile_count = o;    o += align_up((uint64_t)L.tiles * 4, 256);
+    L.off_tile_extra = o;    o += align_up((uint64_t)L.tiles * 4, 256);
     L.off_keys = o;          o += align_up(m * 8, 256);
     L.off_point_list = o;    o += align_up(m * 4, 256);
+    L.off_inst_bbox = o;     o += align_up(m * 8, 256);
     L.binning_bytes = o;
     const uint64_t hw = (uint64_t)s.image_height * (uint64_t)s.image_width;
     L.off_final_T = 0;

@@ -4,131 +4,288 @@
 // (call sites reference ortho_gaussian_renderer/renderer.py:90-98, preprocess.py:99-104).
 //
 // Pipeline (all on the caller's stream, no host sync, no allocation):
-//   K1 preprocess      one lane per Gaussian: project, cull to slab/screen, conic, radius, tile rectangle;
-//                      writes the 48-B GeomRec and counts instances per tile (integer atomics)
-//   K2 scan_tiles      one workgroup: exclusive scan of the per-tile counts -> tile_offsets[T+1], counters
-//   K3 scatter         one lane per Gaussian: appends (depth_bits<<32 | id) to each touched tile's segment
-//   K4 sort_tiles      one WAVE per tile (<=1024 entries, LDS bitonic) / one workgroup per tile (longer):
-//                      orders each segment by (depth, id) -> point_list.  No device-wide radix sort: the
-//                      per-tile segments are independent, so the depth ordering is a wavefront-local
-//                      problem and the tile boundaries come for free from the scan.
-//   K5 blend           one 256-lane workgroup per 16x16 tile: LDS-staged batches of 256 GeomRecs,
-//                      front-to-back alpha compositing, early exit when every pixel is saturated
+//   K1 preprocess   1024-lane workgroups, one lane per Gaussian: project, cull to slab/screen, conic, radius,
+//                   tile rectangle, exact alpha>=1/255 pixel bounding box.  Instances are counted per tile in
+//                   an LDS histogram of the whole tile grid (LDS atomics give each instance its rank inside
+//                   the workgroup); the histogram is then flushed with CONTIGUOUS 256-B returning atomic
+//                   wave-instructions (the shape that runs at the full memory-side atomic rate — scattered
+//                   per-instance atomics are ~16x slower on MI355X), which also yields each workgroup's base
+//                   inside every tile, so every instance leaves K1 knowing its slot in its tile's segment.
+//   K2 scan_tiles   one workgroup: exclusive scan of the per-tile counts -> tile_offsets[T+1], counters
+//   K3 scatter      one lane per Gaussian: writes (depth_bits<<32 | id) at tile_offsets[tile] + slot.  No atomics
+//                   (Gaussians touching more than BIN_SLOTS tiles use a per-tile cursor for the remainder).
+//   K4 sort_tiles   one WAVE per tile: rank sort in LDS (<=256 entries: every key is compared with every
+//                   other, no barriers), bitonic in LDS (<=1024); one workgroup per tile beyond that.
+//                   Orders each segment by (depth, id) -> point_list.  No device-wide radix sort: segments
+//                   are independent, depth ordering is a wavefront-local problem, and the tile boundaries
+//                   come for free from the scan.
+//   K5 blend        one wave per 8x8 pixel quadrant of a 16x16 tile, no barriers.  Per chunk of 64 list entries
+//                   one vector test of the entries' alpha bounding boxes against the wave's quadrant keeps
+//                   only the Gaussians that can reach alpha >= 1/255 there (exact: skipped pairs contribute
+//                   nothing in the spec either); survivors are compacted into a wave-private LDS strip and
+//                   composited front to back from LDS broadcast reads.
 #include "raster_common.h"
 
 namespace gsvc {
 
-// ---------------------------------------------------------------------------------------------- K1
-template <bool FILTER_ONLY>
-__global__ void __launch_bounds__(256) k_preprocess(RasterParams st, int P, const float *__restrict__ means3D,
-                                                    const float *__restrict__ colors,
-                                                    const float *__restrict__ opacities,
-                                                    const float *__restrict__ scales,
-                                                    const float *__restrict__ rotations, int32_t *__restrict__ radii,
-                                                    GeomRec *__restrict__ geom, int32_t *__restrict__ tile_count,
-                                                    gsvc_raster_counters *__restrict__ counters)
+__device__ __forceinline__ uint32_t pack_i16(int lo, int hi)
+{
+    return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+}
+
+// Pixel bounding box outside which alpha = opacity*exp(power) < 1/255 for certain (margins cover the
+// rounding of power in the blend loop).  Derived from the conic the blend loop itself uses.
+__device__ __forceinline__ void alpha_bbox(float u, float v, float A, float B, float C, float opacity,
+                                           uint32_t &bx, uint32_t &by)
+{
+    const float BIG = 30000.0f;
+    float x0 = -BIG, x1 = BIG, y0 = -BIG, y1 = BIG;
+    const float tau = logf(255.0f * opacity) + 1e-3f;
+    const float detc = A * C - B * B;
+    if (opacity <= 0.0f || tau < 0.0f) {
+        x0 = 1.0f; x1 = 0.0f; y0 = 1.0f; y1 = 0.0f;  // can never reach 1/255: empty box
+    } else if (detc > 1e-3f * A * C && tau == tau) {
+        const float ex = sqrtf(2.0f * tau * C / detc) * 1.002f + 0.02f;
+        const float ey = sqrtf(2.0f * tau * A / detc) * 1.002f + 0.02f;
+        x0 = fmaxf(floorf(u - ex), -BIG); x1 = fminf(ceilf(u + ex), BIG);
+        y0 = fmaxf(floorf(v - ey), -BIG); y1 = fminf(ceilf(v + ey), BIG);
+    }
+    bx = pack_i16((int)x0, (int)x1);
+    by = pack_i16((int)y0, (int)y1);
+}
+
+// ------------------------------------------------------------------------------------------- K1 (filter)
+__global__ void __launch_bounds__(256) k_visible_filter(RasterParams st, int P, const float *__restrict__ means3D,
+                                                        const float *__restrict__ scales,
+                                                        const float *__restrict__ rotations, int32_t *__restrict__ radii)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const float px = means3D[3 * i + 0], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
-    const float s0 = scales[3 * i + 0], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
     const float4 q = reinterpret_cast<const float4 *>(rotations)[i];
     PreOut o;
-    const int radius = preprocess_gaussian(st, px, py, pz, s0, s1, s2, q.x, q.y, q.z, q.w, o);
-    radii[i] = radius;
-    if (FILTER_ONLY) return;
-    GeomRec rec;
-    if (radius > 0) {
-        rec.u = o.u; rec.v = o.v; rec.A = o.A; rec.B = o.B;
-        rec.C = o.C; rec.opacity = opacities[i];
-        rec.r = colors[3 * i + 0]; rec.g = colors[3 * i + 1]; rec.b = colors[3 * i + 2];
-        rec.depth = o.depth;
-        rec.rect_x = (uint32_t)o.x0 | ((uint32_t)o.x1 << 16);
-        rec.rect_y = (uint32_t)o.y0 | ((uint32_t)o.y1 << 16);
-        for (int ty = o.y0; ty < o.y1; ty++)
-            for (int tx = o.x0; tx < o.x1; tx++) atomicAdd(&tile_count[ty * st.gx + tx], 1);
-        atomicAdd(&counters->num_visible, 1);
-    } else {
-        rec.u = rec.v = rec.A = rec.B = rec.C = rec.opacity = rec.r = rec.g = rec.b = rec.depth = 0.f;
-        rec.rect_x = rec.rect_y = 0u;
-    }
-    float4 *dst = reinterpret_cast<float4 *>(geom + i);
-    const float4 *src = reinterpret_cast<const float4 *>(&rec);
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    radii[i] = preprocess_gaussian(st, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], scales[3 * i],
+                                   scales[3 * i + 1], scales[3 * i + 2], q.x, q.y, q.z, q.w, o);
 }
 
-// ---------------------------------------------------------------------------------------------- K2
-// Exclusive scan of tile_count[T] -> tile_offsets[T+1]; tile_count is zeroed afterwards (K3 reuses it as
-// the per-tile fill cursor).  One workgroup of 1024 lanes walks the array in chunks of 1024.
-__global__ void __launch_bounds__(1024) k_scan_tiles(int T, int32_t *__restrict__ tile_count,
+// ------------------------------------------------------------------------------------------------- K1
+// USE_LDS: per-workgroup histogram of the whole tile grid in dynamic LDS (4*T bytes).  Otherwise (grids too
+// large for LDS) every instance does its own global atomic.
+template <bool USE_LDS>
+__global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, const float *__restrict__ means3D,
+                                                     const float *__restrict__ colors,
+                                                     const float *__restrict__ opacities,
+                                                     const float *__restrict__ scales,
+                                                     const float *__restrict__ rotations, int32_t *__restrict__ radii,
+                                                     GeomRec *__restrict__ geom, BinRec *__restrict__ bins,
+                                                     int32_t *__restrict__ tile_count, int32_t *__restrict__ tile_extra,
+                                                     gsvc_raster_counters *__restrict__ counters)
+{
+    extern __shared__ int hist[];
+    const int T = st.gx * st.gy;
+    const int tid = threadIdx.x;
+    if (USE_LDS) {
+        for (int t = tid; t < T; t += 1024) hist[t] = 0;
+        __syncthreads();
+    }
+    const int i = blockIdx.x * 1024 + tid;
+    int radius = 0;
+    PreOut o;
+    int slot[BIN_SLOTS] = {0, 0, 0, 0};
+    if (i < P) {
+        const float4 q = reinterpret_cast<const float4 *>(rotations)[i];
+        radius = preprocess_gaussian(st, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], scales[3 * i],
+                                     scales[3 * i + 1], scales[3 * i + 2], q.x, q.y, q.z, q.w, o);
+        radii[i] = radius;
+        GeomRec rec;
+        BinRec br;
+        if (radius > 0) {
+            rec.u = o.u; rec.v = o.v; rec.A = o.A; rec.B = o.B;
+            rec.C = o.C; rec.opacity = opacities[i];
+            rec.r = colors[3 * i + 0]; rec.g = colors[3 * i + 1]; rec.b = colors[3 * i + 2];
+            rec.depth = o.depth;
+            alpha_bbox(o.u, o.v, o.A, o.B, o.C, rec.opacity, rec.bbox_x, rec.bbox_y);
+            br.depth = o.depth;
+            br.rect_x = (uint32_t)o.x0 | ((uint32_t)o.x1 << 16);
+            br.rect_y = (uint32_t)o.y0 | ((uint32_t)o.y1 << 16);
+            int j = 0;
+            for (int ty = o.y0; ty < o.y1; ty++)
+                for (int tx = o.x0; tx < o.x1; tx++, j++) {
+                    const int t = ty * st.gx + tx;
+                    if (j < BIN_SLOTS) {
+                        const int r = USE_LDS ? atomicAdd(&hist[t], 1) : atomicAdd(&tile_count[t], 1);
+                        if (j == 0) slot[0] = r;
+                        if (j == 1) slot[1] = r;
+                        if (j == 2) slot[2] = r;
+                        if (j == 3) slot[3] = r;
+                    } else {
+                        atomicAdd(&tile_extra[t], 1);
+                    }
+                }
+        } else {
+            rec.u = rec.v = rec.A = rec.B = rec.C = rec.opacity = rec.r = rec.g = rec.b = rec.depth = 0.f;
+            rec.bbox_x = pack_i16(1, 0); rec.bbox_y = pack_i16(1, 0);
+            br.depth = 0.f; br.rect_x = br.rect_y = 0u;
+        }
+        br.pad = 0u;
+        float4 *dst = reinterpret_cast<float4 *>(geom + i);
+        const float4 *src = reinterpret_cast<const float4 *>(&rec);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+        if (!USE_LDS || radius == 0) {
+            br.slot[0] = slot[0]; br.slot[1] = slot[1]; br.slot[2] = slot[2]; br.slot[3] = slot[3];
+            float4 *bd = reinterpret_cast<float4 *>(bins + i);
+            const float4 *bs = reinterpret_cast<const float4 *>(&br);
+            bd[0] = bs[0]; bd[1] = bs[1];
+        } else {
+            reinterpret_cast<float4 *>(bins + i)[0] = reinterpret_cast<const float4 *>(&br)[0];
+        }
+    }
+    {
+        // visible count: one atomic per workgroup
+        __shared__ int s_vis;
+        if (tid == 0) s_vis = 0;
+        __syncthreads();
+        const unsigned long long vm = __ballot(radius > 0);
+        if ((tid & 63) == 0 && vm != 0ull) atomicAdd(&s_vis, __popcll(vm));
+        __syncthreads();
+        if (tid == 0 && s_vis != 0) atomicAdd(&counters->num_visible, s_vis);
+    }
+    if (!USE_LDS) return;
+    // flush: 64 consecutive tiles per wave-instruction = 256 contiguous bytes of returning atomics; a wave's
+    // (up to 8) groups are issued back to back and waited for once — a memory-side atomic takes microseconds
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int g0 = wave * 64; g0 < T; g0 += 8 * 1024) {
+            int v[8], base[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int t = g0 + r * 1024 + lane;
+                v[r] = t < T ? hist[t] : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int t = g0 + r * 1024 + lane;
+                base[r] = 0;
+                if (__ballot(v[r] != 0) != 0ull && t < T) base[r] = atomicAdd(&tile_count[t], v[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int t = g0 + r * 1024 + lane;
+                if (t < T) hist[t] = base[r];
+            }
+        }
+    }
+    __syncthreads();
+    if (i < P && radius > 0) {
+        int j = 0;
+        for (int ty = o.y0; ty < o.y1 && j < BIN_SLOTS; ty++)
+            for (int tx = o.x0; tx < o.x1 && j < BIN_SLOTS; tx++, j++) {
+                const int base = hist[ty * st.gx + tx];
+                if (j == 0) slot[0] += base;
+                if (j == 1) slot[1] += base;
+                if (j == 2) slot[2] += base;
+                if (j == 3) slot[3] += base;
+            }
+        reinterpret_cast<int4 *>(bins + i)[1] = make_int4(slot[0], slot[1], slot[2], slot[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- K2
+// tile_offsets = exclusive scan of (tile_count + tile_extra); tile_extra is zeroed (K3's cursor for the
+// instances beyond BIN_SLOTS, which sit behind the tile_count[t] slotted ones).  One workgroup, 8 tiles per lane
+// per round.
+__global__ void __launch_bounds__(1024) k_scan_tiles(int T, const int32_t *__restrict__ tile_count,
+                                                     int32_t *__restrict__ tile_extra,
                                                      int32_t *__restrict__ tile_offsets,
                                                      gsvc_raster_counters *__restrict__ counters,
                                                      long long max_instances)
 {
     __shared__ int wave_sum[16];
-    __shared__ int carry_s;
-    __shared__ int max_s;
+    __shared__ int wave_max[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { carry_s = 0; max_s = 0; }
-    __syncthreads();
-    int local_max = 0;
-    for (int base = 0; base < T; base += 1024) {
-        const int idx = base + tid;
-        const int v = idx < T ? tile_count[idx] : 0;
-        local_max = v > local_max ? v : local_max;
-        int x = v;  // inclusive wave scan
+    int carry = 0, local_max = 0;
+    for (int base = 0; base < T; base += 8192) {
+        int v[8];
+        int sum = 0;
+        const int first = base + tid * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int idx = first + k;
+            v[k] = idx < T ? tile_count[idx] + tile_extra[idx] : 0;
+            local_max = max(local_max, v[k]);
+            sum += v[k];
+        }
+        int x = sum;  // inclusive wave scan of the per-lane sums
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            int y = __shfl_up(x, d, 64);
+            const int y = __shfl_up(x, d, 64);
             if (lane >= d) x += y;
         }
+        __syncthreads();  // previous round's wave_sum readers are done
         if (lane == 63) wave_sum[wave] = x;
         __syncthreads();
-        int wave_prefix = 0;
-        for (int w = 0; w < wave; w++) wave_prefix += wave_sum[w];
-        const int carry = carry_s;
-        if (idx < T) {
-            tile_offsets[idx] = carry + wave_prefix + x - v;
-            tile_count[idx] = 0;
+        int prefix = carry, total = 0;
+        for (int w = 0; w < 16; w++) {
+            const int ws = wave_sum[w];
+            if (w < wave) prefix += ws;
+            total += ws;
         }
-        __syncthreads();
-        if (tid == 1023) carry_s = carry + wave_prefix + x;
-        __syncthreads();
+        int run = prefix + x - sum;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int idx = first + k;
+            if (idx < T) {
+                tile_offsets[idx] = run;
+                tile_extra[idx] = 0;
+            }
+            run += v[k];
+        }
+        carry += total;
     }
-    atomicMax(&max_s, local_max);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) local_max = max(local_max, __shfl_xor(local_max, m, 64));
+    if (lane == 0) wave_max[wave] = local_max;
     __syncthreads();
     if (tid == 0) {
-        const int total = carry_s;
-        tile_offsets[T] = total;
-        counters->num_rendered = total;
-        counters->overflow = ((long long)total > max_instances) ? 1 : 0;
-        counters->max_tile_len = max_s;
+        int mx = 0;
+        for (int w = 0; w < 16; w++) mx = max(mx, wave_max[w]);
+        tile_offsets[T] = carry;
+        counters->num_rendered = carry;
+        counters->overflow = ((long long)carry > max_instances) ? 1 : 0;
+        counters->max_tile_len = mx;
     }
 }
 
-// ---------------------------------------------------------------------------------------------- K3
-__global__ void __launch_bounds__(256) k_scatter(int P, int gx, const GeomRec *__restrict__ geom,
+// ------------------------------------------------------------------------------------------------- K3
+__global__ void __launch_bounds__(256) k_scatter(int P, int gx, const BinRec *__restrict__ bins,
                                                  const int32_t *__restrict__ tile_offsets,
-                                                 int32_t *__restrict__ tile_fill, uint64_t *__restrict__ keys,
+                                                 const int32_t *__restrict__ tile_count,
+                                                 int32_t *__restrict__ tile_extra, uint64_t *__restrict__ keys,
                                                  const gsvc_raster_counters *__restrict__ counters)
 {
     if (counters->overflow) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const float4 r2 = reinterpret_cast<const float4 *>(geom + i)[2];
-    const uint32_t rx = __float_as_uint(r2.z), ry = __float_as_uint(r2.w);
+    const float4 b0 = reinterpret_cast<const float4 *>(bins + i)[0];
+    const uint32_t rx = __float_as_uint(b0.y), ry = __float_as_uint(b0.z);
     if ((rx | ry) == 0u) return;
+    const int4 sl = reinterpret_cast<const int4 *>(bins + i)[1];
     const int x0 = rx & 0xffff, x1 = rx >> 16, y0 = ry & 0xffff, y1 = ry >> 16;
-    const uint64_t key = ((uint64_t)order_bits(r2.y) << 32) | (uint32_t)i;
+    const uint64_t key = ((uint64_t)order_bits(b0.x) << 32) | (uint32_t)i;
+    int j = 0;
     for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++) {
+        for (int tx = x0; tx < x1; tx++, j++) {
             const int t = ty * gx + tx;
-            const int slot = atomicAdd(&tile_fill[t], 1);
+            int slot;
+            if (j == 0) slot = sl.x;
+            else if (j == 1) slot = sl.y;
+            else if (j == 2) slot = sl.z;
+            else if (j == 3) slot = sl.w;
+            else slot = tile_count[t] + atomicAdd(&tile_extra[t], 1);
             keys[tile_offsets[t] + slot] = key;
         }
 }
 
-// ---------------------------------------------------------------------------------------------- K4
+// ------------------------------------------------------------------------------------------------- K4
 // Ascending-only ("flip") bitonic network: every compare-exchange moves the smaller key to the lower
 // index, so positions >= n (virtual +inf padding) never move and n need not be a power of two.
 __device__ __forceinline__ void cmpswap(uint64_t *a, int i, int j, int n)
@@ -162,29 +319,70 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *a, int n, int tid)
     }
 }
 
+constexpr int SORT_RANK_MAX = 256;    // entries one wave rank-sorts (4 keys per lane)
 constexpr int SORT_WAVE_MAX = 1024;   // entries one wave sorts in LDS (8 KiB)
 constexpr int SORT_WG_MAX = 8192;     // entries one workgroup sorts in LDS (64 KiB)
 
 // one wave per tile, segments of <= SORT_WAVE_MAX entries
+// every sorted entry gets its Gaussian id (point_list) and that Gaussian's alpha bounding box (inst_bbox), so the
+// blend kernels test 64 entries per wave-instruction without touching the Gaussian records
+__device__ __forceinline__ void emit_entry(int pos, uint64_t key, const GeomRec *__restrict__ geom,
+                                           int32_t *__restrict__ point_list, uint2 *__restrict__ inst_bbox)
+{
+    const uint32_t id = (uint32_t)key;
+    point_list[pos] = (int32_t)id;
+    const float4 f2 = reinterpret_cast<const float4 *>(geom + id)[2];
+    inst_bbox[pos] = make_uint2(__float_as_uint(f2.y), __float_as_uint(f2.z));
+}
+
 __global__ void __launch_bounds__(64) k_sort_tiles_wave(int T, const int32_t *__restrict__ tile_offsets,
-                                                        uint64_t *__restrict__ keys, int32_t *__restrict__ point_list,
+                                                        const uint64_t *__restrict__ keys,
+                                                        const GeomRec *__restrict__ geom,
+                                                        int32_t *__restrict__ point_list,
+                                                        uint2 *__restrict__ inst_bbox,
                                                         const gsvc_raster_counters *__restrict__ counters)
 {
     __shared__ uint64_t s[SORT_WAVE_MAX];
     if (counters->overflow) return;
-    const int t = blockIdx.x, tid = threadIdx.x;
+    const int t = blockIdx.x, lane = threadIdx.x;
     const int beg = tile_offsets[t], n = tile_offsets[t + 1] - beg;
     if (n <= 0 || n > SORT_WAVE_MAX) return;
-    for (int i = tid; i < n; i += 64) s[i] = keys[beg + i];
+    if (n <= SORT_RANK_MAX) {
+        // keys are unique (the id sits in the low word): rank = number of smaller keys = final position
+        uint64_t k0 = ~0ull, k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;
+        if (lane < n) { k0 = keys[beg + lane]; s[lane] = k0; }
+        if (lane + 64 < n) { k1 = keys[beg + lane + 64]; s[lane + 64] = k1; }
+        if (lane + 128 < n) { k2 = keys[beg + lane + 128]; s[lane + 128] = k2; }
+        if (lane + 192 < n) { k3 = keys[beg + lane + 192]; s[lane + 192] = k3; }
+        __syncthreads();
+        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        if (n <= 64) {
+            for (int j = 0; j < n; j++) r0 += s[j] < k0;
+        } else if (n <= 128) {
+            for (int j = 0; j < n; j++) { const uint64_t kj = s[j]; r0 += kj < k0; r1 += kj < k1; }
+        } else {
+            for (int j = 0; j < n; j++) {
+                const uint64_t kj = s[j];
+                r0 += kj < k0; r1 += kj < k1; r2 += kj < k2; r3 += kj < k3;
+            }
+        }
+        if (lane < n) emit_entry(beg + r0, k0, geom, point_list, inst_bbox);
+        if (lane + 64 < n) emit_entry(beg + r1, k1, geom, point_list, inst_bbox);
+        if (lane + 128 < n) emit_entry(beg + r2, k2, geom, point_list, inst_bbox);
+        if (lane + 192 < n) emit_entry(beg + r3, k3, geom, point_list, inst_bbox);
+        return;
+    }
+    for (int i = lane; i < n; i += 64) s[i] = keys[beg + i];
     __syncthreads();
-    bitonic_sort<64>(s, n, tid);
-    for (int i = tid; i < n; i += 64) point_list[beg + i] = (int32_t)(uint32_t)s[i];
+    bitonic_sort<64>(s, n, lane);
+    for (int i = lane; i < n; i += 64) emit_entry(beg + i, s[i], geom, point_list, inst_bbox);
 }
 
 // one 256-lane workgroup per tile, segments longer than SORT_WAVE_MAX: LDS up to SORT_WG_MAX, in place in
 // global memory beyond that (correct for any length; such tiles are pathological)
 __global__ void __launch_bounds__(256) k_sort_tiles_wg(int T, const int32_t *__restrict__ tile_offsets,
-                                                       uint64_t *__restrict__ keys, int32_t *__restrict__ point_list,
+                                                       uint64_t *__restrict__ keys, const GeomRec *__restrict__ geom,
+                                                       int32_t *__restrict__ point_list, uint2 *__restrict__ inst_bbox,
                                                        const gsvc_raster_counters *__restrict__ counters)
 {
     extern __shared__ uint64_t sbig[];
@@ -196,65 +394,97 @@ __global__ void __launch_bounds__(256) k_sort_tiles_wg(int T, const int32_t *__r
         for (int i = tid; i < n; i += 256) sbig[i] = keys[beg + i];
         __syncthreads();
         bitonic_sort<256>(sbig, n, tid);
-        for (int i = tid; i < n; i += 256) point_list[beg + i] = (int32_t)(uint32_t)sbig[i];
+        for (int i = tid; i < n; i += 256) emit_entry(beg + i, sbig[i], geom, point_list, inst_bbox);
     } else {
         uint64_t *a = keys + beg;
         __threadfence_block();
         bitonic_sort<256>(a, n, tid);  // __syncthreads() orders the workgroup's own global accesses
-        for (int i = tid; i < n; i += 256) point_list[beg + i] = (int32_t)(uint32_t)a[i];
+        for (int i = tid; i < n; i += 256) emit_entry(beg + i, a[i], geom, point_list, inst_bbox);
     }
 }
 
-// ---------------------------------------------------------------------------------------------- K5
+// ------------------------------------------------------------------------------------------------- K5
+__device__ __forceinline__ int sext16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
+
+// Does the alpha bounding box (int16 pairs) touch the 8x8 quadrant at (qx0, qy0)?
+__device__ __forceinline__ bool bbox_hits(uint2 bb, int qx0, int qy0)
+{
+    return !(sext16(bb.x) > qx0 + 7 || sext16(bb.x >> 16) < qx0 || sext16(bb.y) > qy0 + 7 || sext16(bb.y >> 16) < qy0);
+}
+
 __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *__restrict__ tile_offsets,
                                                const int32_t *__restrict__ point_list,
-                                               const GeomRec *__restrict__ geom, float *__restrict__ image,
-                                               float *__restrict__ final_T, int32_t *__restrict__ n_contrib,
+                                               const uint2 *__restrict__ inst_bbox, const GeomRec *__restrict__ geom,
+                                               float *__restrict__ image, float *__restrict__ final_T,
+                                               int32_t *__restrict__ n_contrib,
                                                const gsvc_raster_counters *__restrict__ counters)
 {
-    __shared__ float4 s0[256];  // u v A B
-    __shared__ float4 s1[256];  // C opacity r g
-    __shared__ float s2[256];   // b
+    // per-wave staging of the entries that survive the quadrant test (no cross-wave sharing, no barriers)
+    __shared__ float4 s_f0[4][64];  // u v A B
+    __shared__ float4 s_f1[4][64];  // C opacity r g
+    __shared__ float2 s_f2[4][64];  // b, 1-based list position (as int bits)
     if (counters->overflow) return;
-    const int tid = threadIdx.x;
-    const int lx = tid & 15, ly = tid >> 4;
-    const int tile = blockIdx.y * st.gx + blockIdx.x;
-    const int px = blockIdx.x * TILE + lx, py = blockIdx.y * TILE + ly;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // wave = one 8x8 quadrant of the 16x16 tile
+    const int qx0 = blockIdx.x * TILE + 8 * (wave & 1), qy0 = blockIdx.y * TILE + 8 * (wave >> 1);
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < st.W && py < st.H;
+    const int tile = blockIdx.y * st.gx + blockIdx.x;
     const int beg = tile_offsets[tile], end = tile_offsets[tile + 1];
     const float fx = (float)px, fy = (float)py;
+    float4 *w_f0 = s_f0[wave];
+    float4 *w_f1 = s_f1[wave];
+    float2 *w_f2 = s_f2[wave];
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    int last = 0, contributor = 0;
+    int last = 0;
     bool done = !inside;
-    for (int base = beg; base < end; base += 256) {
-        if (__syncthreads_count(done) == 256) break;
-        const int k = base + tid;
+    for (int c0 = beg; c0 < end; c0 += 64) {
+        // phase 1: 64 list entries per wave-instruction against this wave's quadrant
+        const int k = c0 + lane;
+        bool hit = false;
+        int id = 0;
         if (k < end) {
-            const int id = point_list[k];
-            const float4 *src = reinterpret_cast<const float4 *>(geom + id);
-            s0[tid] = src[0];
-            s1[tid] = src[1];
-            s2[tid] = src[2].x;
+            hit = bbox_hits(inst_bbox[k], qx0, qy0);
+            id = point_list[k];
         }
-        __syncthreads();
-        const int m = min(256, end - base);
-        for (int j = 0; j < m && !done; j++) {
-            contributor++;
-            const float4 a = s0[j];
-            const float4 b = s1[j];
+        const unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;
+        if (hit) {
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            const float4 *rec = reinterpret_cast<const float4 *>(geom + id);
+            w_f0[pos] = rec[0];
+            w_f1[pos] = rec[1];
+            w_f2[pos] = make_float2(rec[2].x, __int_as_float(k - beg + 1));
+        }
+        const int cnt = __popcll(mask);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // phase 2: composite the survivors front to back
+        for (int j = 0; j < cnt; j++) {
+            const float4 a = w_f0[j];
+            const float4 b = w_f1[j];
+            const float2 c = w_f2[j];
             const float dx = a.x - fx, dy = a.y - fy;
             const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            if (power > 0.0f) continue;
             const float alpha = fminf(ALPHA_MAX, b.y * __expf(power));
-            if (alpha < ALPHA_MIN) continue;
             const float test_T = T * (1.0f - alpha);
-            if (test_T < T_MIN) { done = true; continue; }
-            const float w = alpha * T;
-            C0 += b.z * w; C1 += b.w * w; C2 += s2[j] * w;
-            T = test_T;
-            last = contributor;
+            const bool skip = done || (power > 0.0f) || (alpha < ALPHA_MIN);
+            if (!skip) {
+                if (test_T < T_MIN) {
+                    done = true;
+                } else {
+                    const float w = alpha * T;
+                    C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
+                    T = test_T;
+                    last = __float_as_int(c.y);
+                }
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+        if (__ballot(!done) == 0ull) break;
     }
     if (inside) {
         const int HW = st.H * st.W, pix = py * st.W + px;
@@ -272,10 +502,11 @@ static int check_settings(const gsvc_raster_settings *s, int64_t P)
     GSVC_REQUIRE(s->image_height > 0 && s->image_width > 0, "raster: image size must be positive (got %d x %d)",
                  s->image_height, s->image_width);
     GSVC_REQUIRE(P >= 0 && P < (int64_t)1 << 31, "raster: P out of range (%lld)", (long long)P);
-    GSVC_REQUIRE((s->image_width + TILE - 1) / TILE < 65536 && (s->image_height + TILE - 1) / TILE < 65536,
-                 "raster: image too large for 16-bit tile coordinates");
+    GSVC_REQUIRE(s->image_width <= 16384 && s->image_height <= 16384, "raster: image larger than 16384 pixels a side");
     return GSVC_OK;
 }
+
+constexpr int LDS_HIST_MAX_TILES = 36 * 1024;  // 144 KiB of the 160 KiB LDS
 
 }  // namespace gsvc
 
@@ -321,9 +552,11 @@ extern "C" int gsvc_raster_visible_filter(const gsvc_raster_settings *settings, 
     GSVC_REQUIRE(means3D && scales && rotations && radii, "visible_filter: NULL pointer");
     const RasterParams p = make_params(*settings);
     hipStream_t s = (hipStream_t)stream;
-    { ProfScope _prof("k_preprocess", s); hipLaunchKernelGGL(k_preprocess<true>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
-                       (const float *)nullptr, (const float *)nullptr, scales, rotations, radii, (GeomRec *)nullptr,
-                       (int32_t *)nullptr, (gsvc_raster_counters *)nullptr); }
+    {
+        ProfScope _prof("k_visible_filter", s);
+        hipLaunchKernelGGL(k_visible_filter, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
+                           scales, rotations, radii);
+    }
     return check_launch("visible_filter");
 }
 
@@ -343,32 +576,65 @@ extern "C" int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t
     char *bin = (char *)binning;
     auto *counters = (gsvc_raster_counters *)(bin + L.off_counters);
     auto *tile_offsets = (int32_t *)(bin + L.off_tile_offsets);
-    auto *tile_fill = (int32_t *)(bin + L.off_tile_fill);
+    auto *tile_count = (int32_t *)(bin + L.off_tile_count);
+    auto *tile_extra = (int32_t *)(bin + L.off_tile_extra);
     auto *keys = (uint64_t *)(bin + L.off_keys);
     auto *point_list = (int32_t *)(bin + L.off_point_list);
+    auto *inst_bbox = (uint2 *)(bin + L.off_inst_bbox);
+    auto *grec = (GeomRec *)((char *)geom + L.off_geom);
+    auto *brec = (BinRec *)((char *)geom + L.off_bin);
     auto *final_T = (float *)((char *)image_state + L.off_final_T);
     auto *n_contrib = (int32_t *)((char *)image_state + L.off_n_contrib);
 
-    // counters + tile_offsets + tile_fill are contiguous at the head of the blob
+    // counters + tile_offsets + tile_count + tile_extra are contiguous at the head of the blob
     if (hipMemsetAsync(bin, 0, L.off_keys, s) != hipSuccess) {
         set_error("raster_forward: hipMemsetAsync failed");
         return GSVC_E_LAUNCH;
     }
     if (P > 0) {
-        { ProfScope _prof("k_preprocess", s); hipLaunchKernelGGL(k_preprocess<false>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
-                           colors, opacities, scales, rotations, radii, (GeomRec *)geom, tile_fill, counters); }
+        const unsigned blocks = (unsigned)((P + 1023) / 1024);
+        ProfScope _prof("k_preprocess", s);
+        if (L.tiles <= LDS_HIST_MAX_TILES) {
+            static bool attr_set = false;
+            const size_t lds = (size_t)L.tiles * sizeof(int);
+            if (lds > 48 * 1024 && !attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_preprocess<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_MAX_TILES * 4);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(1024), lds, s, p, (int)P, means3D, colors,
+                               opacities, scales, rotations, radii, grec, brec, tile_count, tile_extra, counters);
+        } else {
+            hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(1024), 0, s, p, (int)P, means3D, colors,
+                               opacities, scales, rotations, radii, grec, brec, tile_count, tile_extra, counters);
+        }
     }
-    { ProfScope _prof("k_scan_tiles", s); hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, L.tiles, tile_fill, tile_offsets, counters,
-                       (long long)max_instances); }
+    {
+        ProfScope _prof("k_scan_tiles", s);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, L.tiles, tile_count, tile_extra, tile_offsets,
+                           counters, (long long)max_instances);
+    }
     if (P > 0) {
-        { ProfScope _prof("k_scatter", s); hipLaunchKernelGGL(k_scatter, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (int)P, L.gx,
-                           (const GeomRec *)geom, tile_offsets, tile_fill, keys, counters); }
-        { ProfScope _prof("k_sort_tiles_wave", s); hipLaunchKernelGGL(k_sort_tiles_wave, dim3(L.tiles), dim3(64), 0, s, L.tiles, tile_offsets, keys, point_list,
-                           counters); }
-        { ProfScope _prof("k_sort_tiles_wg", s); hipLaunchKernelGGL(k_sort_tiles_wg, dim3(L.tiles), dim3(256), SORT_WG_MAX * sizeof(uint64_t), s, L.tiles,
-                           tile_offsets, keys, point_list, counters); }
+        {
+            ProfScope _prof("k_scatter", s);
+            hipLaunchKernelGGL(k_scatter, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (int)P, L.gx, brec,
+                               tile_offsets, tile_count, tile_extra, keys, counters);
+        }
+        {
+            ProfScope _prof("k_sort_tiles_wave", s);
+            hipLaunchKernelGGL(k_sort_tiles_wave, dim3(L.tiles), dim3(64), 0, s, L.tiles, tile_offsets, keys, grec,
+                               point_list, inst_bbox, counters);
+        }
+        {
+            ProfScope _prof("k_sort_tiles_wg", s);
+            hipLaunchKernelGGL(k_sort_tiles_wg, dim3(L.tiles), dim3(256), SORT_WG_MAX * sizeof(uint64_t), s, L.tiles,
+                               tile_offsets, keys, grec, point_list, inst_bbox, counters);
+        }
     }
-    { ProfScope _prof("k_blend", s); hipLaunchKernelGGL(k_blend, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list,
-                       (const GeomRec *)geom, image, final_T, n_contrib, counters); }
+    {
+        ProfScope _prof("k_blend", s);
+        hipLaunchKernelGGL(k_blend, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list, inst_bbox, grec,
+                           image, final_T, n_contrib, counters);
+    }
     return check_launch("raster_forward");
 }

@@ -1,0 +1,106 @@
+"""Losses of the fitting step: L1, SSIM (11x11 Gaussian window, sigma 1.5, zero padding), optical-flow
+consistency of Gaussian motion between adjacent frames.
+
+Same values as reference utils/loss_utils.py:20-72 (l1_loss_func, ssim_func/_ssim) and :76-153
+(calc_optical_loss_one_frame / calc_optical_loss).  SSIM uses the separability of the window (two 1-D
+passes instead of one 11x11 depthwise conv per moment) and filters the five moments in one batched call.
+"""
+from __future__ import annotations
+
+from functools import lru_cache
+from math import exp
+
+import torch
+import torch.nn.functional as F
+
+
+def l1_loss_func(network_output, gt):
+    return (network_output - gt).abs().mean()
+
+
+def l2_loss_func(network_output, gt):
+    return ((network_output - gt) ** 2).mean()
+
+
+@lru_cache(maxsize=4)
+def _window_1d(window_size: int, sigma: float):
+    g = torch.tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    return g / g.sum()
+
+
+def _blur(x, w1d, pad):
+    """Depthwise separable Gaussian blur of [B,C,H,W] with zero padding."""
+    C = x.shape[1]
+    kh = w1d.view(1, 1, -1, 1).expand(C, 1, -1, 1)
+    kw = w1d.view(1, 1, 1, -1).expand(C, 1, 1, -1)
+    x = F.conv2d(x, kh, padding=(pad, 0), groups=C)
+    return F.conv2d(x, kw, padding=(0, pad), groups=C)
+
+
+def ssim_func(img1, img2, window_size=11, size_average=True):
+    squeeze = img1.dim() == 3
+    a = img1.unsqueeze(0) if squeeze else img1
+    b = img2.unsqueeze(0) if squeeze else img2
+    w = _window_1d(window_size, 1.5).to(device=a.device, dtype=a.dtype)
+    pad = window_size // 2
+    B = a.shape[0]
+    m = _blur(torch.cat([a, b, a * a, b * b, a * b], dim=0), w, pad)
+    mu1, mu2, e11, e22, e12 = m[:B], m[B:2 * B], m[2 * B:3 * B], m[3 * B:4 * B], m[4 * B:]
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1, s2, s12 = e11 - mu1_sq, e22 - mu2_sq, e12 - mu12
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    if size_average:
+        return ssim_map.mean()
+    return ssim_map.mean(1).mean(1).mean(1)
+
+
+def _alive_slots(res, n_offsets):
+    """Flat (anchor*K + slot) indices of the Gaussians a render generated (opacity > 0), in generation order."""
+    vis = res.visible_mask
+    idx = torch.arange(vis.shape[0] * n_offsets, device=vis.device).view(-1, n_offsets)
+    return idx[vis].reshape(-1)[res.generated_gaussians.mask]
+
+
+def _world_xy(res, keep):
+    rows = res.generated_gaussians.concatenated_all[keep]
+    scaling, anchor, offsets = rows[:, 0:6], rows[:, 6:9], rows[:, 22:25]
+    return (anchor + offsets * scaling[:, :3])[:, :2]
+
+
+def calc_optical_loss_one_frame(render_results1, render_results2, optical_flow, x_min, y_min, scale,
+                                x_pix_max: int, y_pix_max: int, n_offsets=10):
+    """Gaussians alive in both renders (same anchor, same offset slot): their world-xy displacement should
+    equal the optical flow sampled at the frame-1 pixel (reference loss_utils.py:76-135)."""
+    dev = render_results1.visible_mask.device
+    total = render_results1.visible_mask.shape[0] * n_offsets
+    alive1 = torch.zeros(total, dtype=torch.bool, device=dev)
+    alive2 = torch.zeros(total, dtype=torch.bool, device=dev)
+    alive1[_alive_slots(render_results1, n_offsets)] = True
+    alive2[_alive_slots(render_results2, n_offsets)] = True
+    common = (alive1 & alive2).view(-1, n_offsets)
+    keep1 = common[render_results1.visible_mask].reshape(-1) & render_results1.generated_gaussians.mask
+    keep2 = common[render_results2.visible_mask].reshape(-1) & render_results2.generated_gaussians.mask
+    xy1 = _world_xy(render_results1, keep1)
+    xy2 = _world_xy(render_results2, keep2)
+    pix = ((xy1 - torch.tensor([[x_min, y_min]], dtype=xy1.dtype, device=dev)) * scale).round().long()
+    ok = (pix[:, 0] >= 0) & (pix[:, 1] >= 0) & (pix[:, 0] < x_pix_max) & (pix[:, 1] < y_pix_max)
+    pix = pix[ok]
+    flow = optical_flow.permute(2, 1, 0).to(dev)
+    uv = flow[pix[:, 0], pix[:, 1], ...] / scale
+    d = xy2[ok] - xy1[ok]
+    return (d - uv).abs().mean(), pix, d * scale
+
+
+def calc_optical_loss(render_results1_f, render_results1_b, render_results2_f, render_results2_b, optical_flow,
+                      x_min, y_min, scale, x_pix_max: int, y_pix_max: int, n_offsets=10):
+    lf, _, _ = calc_optical_loss_one_frame(render_results1_f, render_results2_f, optical_flow, x_min, y_min, scale,
+                                           x_pix_max, y_pix_max, n_offsets)
+    lb, _, _ = calc_optical_loss_one_frame(render_results1_b, render_results2_b, optical_flow, x_min, y_min, scale,
+                                           x_pix_max, y_pix_max, n_offsets)
+    return lf + lb
+
+
+def psnr_func(img1, img2, data_range=1):
+    """reference utils/metric_utils.py:10-13"""
+    return 10 * torch.log10((data_range ** 2) / torch.mean((img1 - img2) ** 2))
