@@ -54,6 +54,9 @@ struct Cell {
 template <uint32_t D>
 __device__ __forceinline__ void locate(const float (&x)[D], uint32_t resolution, uint32_t hashmap_size, Cell<D> &c)
 {
+    // the cell index and the fractional position must round exactly as in the reference (float product, then
+    // + 0.5): an FMA here moves points across cell boundaries / changes weights by ~1e-5
+#pragma clang fp contract(off)
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
         const float pos = x[d] * (float)(resolution - 2) + 0.5f;

@@ -1,0 +1,126 @@
+"""Frame description and the cube <-> camera conventions of GSVC.
+
+Same quantities as reference frame_cube/frame.py: ``make_view_matrix`` (:18-43, glm.lookAt from (x,y,z) towards
+-/+ the plane normal), ``Frame`` (:46-59) and ``FrameCubeDataset.get_z_frame`` (:156-190):
+``scale = max(H, W, T)/2``, ``x_min = -W/2/scale``, ``y_min = -H/2/scale``, ``z = (id - T/2)/scale``.
+pyglm is not needed: lookAt is written out.  As in the reference the stored ``view_matrix`` is the TRANSPOSE of
+the math matrix (np.array(glm.mat4) is column-major), and the renderer passes ``view_matrix.permute(1, 0)``.
+File loading (PNG / optical-flow pickles) is out of scope; ``SyntheticFrameCube`` provides frames instead.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+
+def _look_at(eye, center, up):
+    f = center - eye
+    f = f / np.linalg.norm(f)
+    s = np.cross(f, up)
+    s = s / np.linalg.norm(s)
+    u = np.cross(s, f)
+    M = np.eye(4, dtype=np.float64)
+    M[0, :3], M[1, :3], M[2, :3] = s, u, -f
+    M[0, 3], M[1, 3], M[2, 3] = -s.dot(eye), -u.dot(eye), f.dot(eye)
+    return M
+
+
+def make_view_matrix(x=0, y=0, z=0, plane="xy"):
+    """Returns (view_matrix, view_matrix_s, cam_pos) as float32 tensors; the matrices are stored transposed."""
+    eye = np.array([x, y, z], dtype=np.float64)
+    axis = {"xy": 2, "yz": 0, "zx": 1}[plane]
+    up = {"xy": [0, 1, 0], "yz": [0, 0, 1], "zx": [1, 0, 0]}[plane]
+    d = np.zeros(3)
+    d[axis] = 0.1
+    Mf = _look_at(eye, eye - d, np.array(up, dtype=np.float64))
+    Ms = _look_at(eye, eye + d, np.array(up, dtype=np.float64))
+    return (torch.tensor(Mf.T.copy(), dtype=torch.float32), torch.tensor(Ms.T.copy(), dtype=torch.float32),
+            torch.tensor(eye, dtype=torch.float32))
+
+
+@dataclass
+class Frame:
+    image_id: int
+    plane: str
+    image: torch.Tensor      # stored [3, W, H] as in the reference (permuted back at use)
+    x_min: float
+    y_min: float
+    z: float
+    image_width: int
+    image_height: int
+    view_matrix: torch.Tensor
+    view_matrix_s: torch.Tensor
+    scale: float
+    cam_pos: torch.Tensor
+
+
+class SyntheticFrameCube:
+    """T procedural frames (moving Gaussian blobs on a gradient) with their analytic backward flow, shaped
+    and addressed like the reference's FrameCubeDataset."""
+
+    def __init__(self, height: int, width: int, frames: int, seed: int = 1234, blobs: int = 32, device="cpu"):
+        self.height, self.width, self.len = height, width, frames
+        self.scale = max(height, width, frames) / 2
+        self.x_min = -width / 2 / self.scale
+        self.y_min = -height / 2 / self.scale
+        self.z_min = -frames / 2 / self.scale
+        self.device = torch.device(device)
+        rng = np.random.default_rng(seed)
+        self._p0 = rng.uniform([0, 0], [width, height], (blobs, 2))
+        self._vel = rng.uniform(-2.0, 2.0, (blobs, 2))
+        self._sig = rng.uniform(0.03, 0.12, blobs) * min(height, width)
+        self._col = rng.uniform(0.1, 1.0, (blobs, 3))
+        self._cache = {}
+
+    def __len__(self):
+        return self.len
+
+    @property
+    def len_z_frames(self):
+        return self.len
+
+    def _image(self, t):
+        if t in self._cache:
+            return self._cache[t]
+        H, W = self.height, self.width
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=self.device),
+                                torch.arange(W, dtype=torch.float32, device=self.device), indexing="ij")
+        img = torch.stack([xs / W * 0.2, ys / H * 0.2, torch.full_like(xs, 0.1)], 0)
+        for k in range(self._p0.shape[0]):
+            cx, cy = self._p0[k] + self._vel[k] * t
+            g = torch.exp(-((xs - float(cx) % W) ** 2 + (ys - float(cy) % H) ** 2) / (2 * float(self._sig[k]) ** 2))
+            img = img + g[None] * torch.tensor(self._col[k], dtype=torch.float32, device=self.device)[:, None, None] * 0.5
+        img = img.clamp(0, 1)
+        if len(self._cache) < 64:
+            self._cache[t] = img
+        return img
+
+    def get_z_frame(self, image_id, load_image=True):
+        z = (image_id - self.len / 2) / self.scale
+        vm, vms, cam = make_view_matrix(z=z, plane="xy")
+        img = self._image(image_id).permute(0, 2, 1) if load_image else None
+        return Frame(image_id=image_id, plane="xy", image=img, x_min=self.x_min, y_min=self.y_min, z=z,
+                     image_width=self.width, image_height=self.height, view_matrix=vm, view_matrix_s=vms,
+                     scale=self.scale, cam_pos=cam)
+
+    def __getitem__(self, idx):
+        return self.get_z_frame(idx)
+
+    def get_dummy_frame(self, image_id):
+        return self.get_z_frame(image_id, load_image=False)
+
+    def get_optical_flow(self, idx):
+        """Backward flow [2, H, W] (pixels/frame): a smooth field blended from the blob velocities."""
+        H, W = self.height, self.width
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=self.device),
+                                torch.arange(W, dtype=torch.float32, device=self.device), indexing="ij")
+        num = torch.zeros(2, H, W, device=self.device)
+        den = torch.full((H, W), 1e-3, device=self.device)
+        for k in range(self._p0.shape[0]):
+            cx, cy = self._p0[k] + self._vel[k] * idx
+            g = torch.exp(-((xs - float(cx) % W) ** 2 + (ys - float(cy) % H) ** 2) / (2 * float(self._sig[k]) ** 2))
+            num += g[None] * torch.tensor(self._vel[k], dtype=torch.float32, device=self.device)[:, None, None]
+            den += g
+        return num / den

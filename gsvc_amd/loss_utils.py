@@ -64,7 +64,7 @@ def _alive_slots(res, n_offsets):
 
 def _world_xy(res, keep):
     rows = res.generated_gaussians.concatenated_all[keep]
-    scaling, anchor, offsets = rows[:, 0:6], rows[:, 6:9], rows[:, 22:25]
+    scaling, anchor, offsets = rows[:, 0:6], rows[:, 6:9], rows[:, 19:22]
     return (anchor + offsets * scaling[:, :3])[:, :2]
 
 

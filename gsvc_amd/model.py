@@ -1,0 +1,372 @@
+"""GaussianModel — the hot-path half of reference scene/gaussian_model.py.
+
+What is here (reference line ranges in brackets):
+  * EntropyContext, Mix3d2dEncoding [81-147], FiLM / GeneratorNet / EntropyParamsNet [150-232]
+  * constructor wiring: 4 hash grids, two positional embedders, 3 generator MLPs, deform MLP, 3 entropy nets,
+    quantiser and rate model [268-505]
+  * getters get_anchor / get_scaling / get_mask / get_mask_anchor / get_rotation / get_*_mlp [641-700]
+  * update_anchor_bound, calc_interp_feat [706-732], create_from_pcd (initialisation) [754-800]
+  * training_setup / update_learning_rate: 15 Adam groups, eps 1e-15, exponential LR [833-1058, 1148-1154]
+  * training_statis [1281-1314], calc_entropy_context [1569-1597], get_encoding_params [506-518]
+Parameter / sub-module names equal the reference's, so a reference ``state_dict`` loads unchanged.
+Densification (adjust_anchor), bit accounting, the codec and ply/checkpoint IO are out of scope
+(SURVEY.md section 2 #7, section 8f).
+
+Differences in mechanism, not in values: the device is a constructor argument instead of a hard-coded
+"cuda"; ``get_anchor`` etc. stay properties but the renderer caches them per render instead of recomputing
+per access; the 3-NN initial scale uses chunked torch.cdist instead of simple_knn.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .encodings import GridEncoder, Quantize_anchor, STE_binary, UniformQuantizer
+from .entropy_models import EntropyGaussian
+from .time_util import get_embedder
+
+
+@dataclass
+class EntropyContext:
+    mean_feat: torch.Tensor
+    scale_feat: torch.Tensor
+    mean_scaling: torch.Tensor
+    scale_scaling: torch.Tensor
+    mean_offsets: torch.Tensor
+    scale_offsets: torch.Tensor
+    Q_feat_adj: torch.Tensor
+    Q_scaling_adj: torch.Tensor
+    Q_offsets_adj: torch.Tensor
+
+
+class Mix3d2dEncoding(nn.Module):
+    """One 3-D hash grid on (x,y,z) plus three 2-D grids on (x,y), (x,z), (y,z); outputs concatenated."""
+
+    def __init__(self, n_features, resolutions_list, log2_hashmap_size, resolutions_list_2D, log2_hashmap_size_2D,
+                 ste_binary, ste_multistep, add_noise, Q):
+        super().__init__()
+        kw = dict(n_features=n_features, ste_binary=ste_binary, ste_multistep=ste_multistep, add_noise=add_noise, Q=Q)
+        self.encoding_xyz = GridEncoder(num_dim=3, resolutions_list=resolutions_list, log2_hashmap_size=log2_hashmap_size, **kw)
+        self.encoding_xy = GridEncoder(num_dim=2, resolutions_list=resolutions_list_2D, log2_hashmap_size=log2_hashmap_size_2D, **kw)
+        self.encoding_xz = GridEncoder(num_dim=2, resolutions_list=resolutions_list_2D, log2_hashmap_size=log2_hashmap_size_2D, **kw)
+        self.encoding_yz = GridEncoder(num_dim=2, resolutions_list=resolutions_list_2D, log2_hashmap_size=log2_hashmap_size_2D, **kw)
+        self.output_dim = sum(e.output_dim for e in (self.encoding_xyz, self.encoding_xy, self.encoding_xz, self.encoding_yz))
+
+    def forward(self, x):
+        xy, xz, yz = x[..., [0, 1]], x[..., [0, 2]], x[..., [1, 2]]
+        return torch.cat([self.encoding_xyz(x), self.encoding_xy(xy), self.encoding_xz(xz), self.encoding_yz(yz)], dim=-1)
+
+
+class FiLM(nn.Module):
+    """gamma(cond) * x + beta(cond), both from 2-layer ReLU MLPs."""
+
+    def __init__(self, condition_dim, input_dim):
+        super().__init__()
+        self.fc_gamma0 = nn.Linear(condition_dim, condition_dim)
+        self.fc_beta0 = nn.Linear(condition_dim, condition_dim)
+        self.fc_gamma1 = nn.Linear(condition_dim, input_dim)
+        self.fc_beta1 = nn.Linear(condition_dim, input_dim)
+        self.act = nn.ReLU()
+
+    def forward(self, x, condition):
+        gamma = self.fc_gamma1(self.act(self.fc_gamma0(condition)))
+        beta = self.fc_beta1(self.act(self.fc_beta0(condition)))
+        return gamma * x + beta
+
+
+class GeneratorNet(nn.Module):
+    def __init__(self, input_dim, output_dim, inner_dim, condition_dim, out_act=None):
+        super().__init__()
+        self.linear1 = nn.Linear(input_dim, inner_dim)
+        self.linear2 = nn.Linear(inner_dim, inner_dim)
+        self.act = nn.GELU()
+        self.out_linear = nn.Linear(inner_dim, output_dim)
+        self.film = FiLM(condition_dim, inner_dim)
+        self.out_act = nn.Identity() if out_act is None else out_act
+
+    def forward(self, feature, condition):
+        h = self.linear2(self.act(self.linear1(feature)))
+        return self.out_act(self.out_linear(self.film(h, condition)))
+
+
+class EntropyParamsNet(nn.Module):
+    def __init__(self, input_dim, inner_dim, inner_dim2, output_dim, layer=2):
+        super().__init__()
+        if layer == 2:
+            self.dist_net = nn.Sequential(nn.Linear(input_dim, inner_dim), nn.GELU(), nn.Linear(inner_dim, output_dim * 2))
+        else:
+            assert layer == 3
+            self.dist_net = nn.Sequential(nn.Linear(input_dim, inner_dim), nn.GELU(), nn.Linear(inner_dim, inner_dim),
+                                          nn.GELU(), nn.Linear(inner_dim, output_dim * 2))
+        self.quant_step_net = nn.Sequential(nn.Linear(input_dim, inner_dim2), nn.GELU(), nn.Linear(inner_dim2, 1))
+
+    def forward(self, x):
+        params = self.dist_net(x)
+        half = params.shape[1] // 2
+        return params[:, :half], params[:, half:], self.quant_step_net(x)
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000, step_sub=0):
+    """Log-linear interpolation lr_init -> lr_final over max_steps (reference utils/general_utils.py:49-82)."""
+
+    def helper(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        if lr_delay_steps > 0:
+            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+        else:
+            delay_rate = 1.0
+        t = np.clip((step - step_sub) / (max_steps - step_sub), 0, 1)
+        return delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
+
+    return helper
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def mean_3nn_dist2(points: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
+    """Mean squared distance to the 3 nearest neighbours (what simple_knn.distCUDA2 returns), by chunked cdist."""
+    n = points.shape[0]
+    out = torch.empty(n, device=points.device, dtype=points.dtype)
+    for s in range(0, n, chunk):
+        d = torch.cdist(points[s:s + chunk], points) ** 2
+        k = min(4, n)
+        near = torch.topk(d, k, dim=1, largest=False).values[:, 1:]
+        out[s:s + chunk] = near.mean(dim=1) if k > 1 else 0.0
+    return out
+
+
+class GaussianModel(nn.Module):
+    def __init__(self, model_config, feat_dim: int = 32, n_offsets: int = 5, voxel_size: float = 0.01,
+                 update_depth: int = 3, update_init_factor: int = 100, update_hierachy_factor: int = 4,
+                 use_feat_bank=False, n_features_per_level: int = 2, log2_hashmap_size: int = 19,
+                 log2_hashmap_size_2D: int = 17,
+                 resolutions_list=(18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514),
+                 resolutions_list_2D=(130, 258, 514, 1026), ste_binary: bool = True, ste_multistep: bool = False,
+                 add_noise: bool = False, Q=1, use_2D: bool = True, decoded_version: bool = False, device=None):
+        super().__init__()
+        assert not use_feat_bank, "the feature bank is disabled in GSVC (gaussian_model.py:532)"
+        self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.model_config = model_config
+        self.feat_dim, self.n_offsets, self.voxel_size = feat_dim, n_offsets, voxel_size
+        self.update_depth, self.update_init_factor, self.update_hierachy_factor = update_depth, update_init_factor, update_hierachy_factor
+        self.use_feat_bank = use_feat_bank
+        self.x_bound_min = torch.zeros(1, 3, device=self.device)
+        self.x_bound_max = torch.ones(1, 3, device=self.device)
+        self.n_features_per_level = n_features_per_level
+        self.log2_hashmap_size, self.log2_hashmap_size_2D = log2_hashmap_size, log2_hashmap_size_2D
+        self.resolutions_list, self.resolutions_list_2D = resolutions_list, resolutions_list_2D
+        self.ste_binary, self.ste_multistep, self.add_noise, self.Q = ste_binary, ste_multistep, add_noise, Q
+        self.use_2D, self.decoded_version = use_2D, decoded_version
+
+        for name in ("_anchor", "_offset", "_mask", "_anchor_feat", "_scaling", "_rotation", "_opacity"):
+            setattr(self, name, torch.empty(0))
+        self.opacity_accum = self.offset_gradient_accum = self.offset_denom = self.anchor_demon = torch.empty(0)
+        self.max_radii2D = torch.empty(0)
+        self.optimizer = None
+        self.percent_dense = 0
+        self.spatial_lr_scale = 0
+        self.scaling_activation, self.scaling_inverse_activation = torch.exp, torch.log
+        self.opacity_activation, self.inverse_opacity_activation = torch.sigmoid, inverse_sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+        grid_kw = dict(n_features=n_features_per_level, resolutions_list=resolutions_list,
+                       log2_hashmap_size=log2_hashmap_size, ste_binary=ste_binary, ste_multistep=ste_multistep,
+                       add_noise=add_noise, Q=Q)
+        if use_2D:
+            self.encoding_xyz = Mix3d2dEncoding(resolutions_list_2D=resolutions_list_2D,
+                                                log2_hashmap_size_2D=log2_hashmap_size_2D, **grid_kw)
+        else:
+            self.encoding_xyz = GridEncoder(num_dim=3, **grid_kw)
+
+        self.embed_time_fn, time_ch = get_embedder(model_config.time_multi_res, 1)
+        self.embed_fn, z_ch = get_embedder(model_config.offset_multi_res, 1)
+        cond = time_ch + z_ch
+        inner = feat_dim * 2
+        self.mlp_opacity = GeneratorNet(feat_dim, n_offsets, inner, cond, out_act=nn.Tanh())
+        self.mlp_cov = GeneratorNet(feat_dim, 7 * n_offsets, inner, cond)
+        self.mlp_color = GeneratorNet(feat_dim, 3 * n_offsets, inner, cond, out_act=nn.Sigmoid())
+        self.mlp_deform = nn.Sequential(
+            nn.Linear(feat_dim + cond, inner), nn.GELU(), nn.Linear(inner, inner), nn.GELU(),
+            nn.Linear(inner, inner), nn.GELU(), nn.Linear(inner, inner), nn.GELU(), nn.Linear(inner, 3 * n_offsets))
+        gdim = self.encoding_xyz.output_dim
+        self.mlp_feature_enet = EntropyParamsNet(gdim, feat_dim * 3, feat_dim, feat_dim)
+        self.mlp_scaling_enet = EntropyParamsNet(gdim, feat_dim * 2, feat_dim, 6, layer=3)
+        self.mlp_offset_enet = EntropyParamsNet(gdim, feat_dim * 3, feat_dim, 3 * n_offsets)
+        self.noise_quantizer = UniformQuantizer()
+        self.entropy_gaussian = EntropyGaussian(Q=1)
+        self.to(self.device)
+
+    # ------------------------------------------------------------------ getters (reference :641-700)
+    @property
+    def get_scaling(self):
+        return self._scaling if self.decoded_version else 1.0 * self.scaling_activation(self._scaling)
+
+    @property
+    def get_mask(self):
+        if self.decoded_version:
+            return self._mask
+        s = torch.sigmoid(self._mask)
+        return ((s > 0.01).float() - s).detach() + s  # hard threshold forward, sigmoid gradient
+
+    @property
+    def get_mask_anchor(self):
+        with torch.no_grad():
+            m = self._mask if self.decoded_version else (torch.sigmoid(self._mask) > 0.01).float()
+            return (torch.sum(m, dim=1)[:, 0]) > 0
+
+    @property
+    def get_opacity_mlp(self):
+        return self.mlp_opacity
+
+    @property
+    def get_cov_mlp(self):
+        return self.mlp_cov
+
+    @property
+    def get_color_mlp(self):
+        return self.mlp_color
+
+    @property
+    def get_deform_mlp(self):
+        return self.mlp_deform
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_anchor(self):
+        if self.decoded_version:
+            return self._anchor
+        return Quantize_anchor.apply(self._anchor, self.x_bound_min, self.x_bound_max)[0]
+
+    @property
+    def quantized_anchor(self):
+        return Quantize_anchor.quantized(self._anchor, self.x_bound_min, self.x_bound_max)
+
+    @property
+    def get_opacity(self):
+        return self.opacity_activation(self._opacity)
+
+    def get_encoding_params(self):
+        enc = self.encoding_xyz
+        tables = [enc.encoding_xyz.params, enc.encoding_xy.params, enc.encoding_xz.params, enc.encoding_yz.params] \
+            if self.use_2D else [enc.params]
+        p = torch.cat(tables, dim=0)
+        return STE_binary.apply(p) if self.ste_binary else p
+
+    @torch.no_grad()
+    def update_anchor_bound(self, x_lim, y_lim, z_lim, bleed=0.1):
+        lim = [x_lim * (1 + bleed), y_lim * (1 + bleed), z_lim * (1 + bleed)]  # python floats, rounded once to fp32
+        self.x_bound_min = torch.tensor([lim], dtype=torch.float32, device=self.device)
+        self.x_bound_max = torch.tensor([[-v for v in lim]], dtype=torch.float32, device=self.device)
+
+    def calc_interp_feat(self, x):
+        assert x.dim() == 2 and x.shape[1] == 3
+        x = (x - self.x_bound_min) / (self.x_bound_max - self.x_bound_min)
+        return self.encoding_xyz(x)
+
+    def calc_entropy_context(self, anchor) -> EntropyContext:
+        ctx = self.calc_interp_feat(anchor)
+        mean_f, scale_f, q_f = self.mlp_feature_enet(ctx)
+        mean_s, scale_s, q_s = self.mlp_scaling_enet(ctx)
+        mean_o, scale_o, q_o = self.mlp_offset_enet(ctx)
+        adj = lambda q: torch.exp(torch.clamp(q, min=-10, max=10))  # noqa: E731
+        return EntropyContext(mean_f, torch.clamp(scale_f, 1e-9), mean_s, torch.clamp(scale_s, 1e-9),
+                              mean_o, torch.clamp(scale_o, 1e-9), adj(q_f), adj(q_s), adj(q_o))
+
+    # ------------------------------------------------------------------ initialisation (reference :748-800)
+    def voxelize_sample(self, data, voxel_size=0.01):
+        np.random.shuffle(data)
+        return np.unique(np.round(data / voxel_size), axis=0) * voxel_size
+
+    def create_from_points(self, points: np.ndarray, spatial_lr_scale: float = 1.0):
+        self.spatial_lr_scale = spatial_lr_scale
+        dev = self.device
+        if self.voxel_size <= 0:
+            d = mean_3nn_dist2(torch.tensor(points).float().to(dev))
+            self.voxel_size = torch.kthvalue(d, int(d.shape[0] * 0.5)).values.item()
+        pts = torch.tensor(np.asarray(self.voxelize_sample(points, voxel_size=self.voxel_size))).float().to(dev)
+        A, K = pts.shape[0], self.n_offsets
+        dist2 = torch.clamp_min(mean_3nn_dist2(pts), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 6)
+        rots = torch.zeros(A, 4, device=dev)
+        rots[:, 0] = 1
+        self._anchor = nn.Parameter(pts.requires_grad_(True))
+        self._offset = nn.Parameter(torch.zeros(A, K, 3, device=dev).requires_grad_(True))
+        self._mask = nn.Parameter(torch.ones(A, K, 1, device=dev).requires_grad_(True))
+        self._anchor_feat = nn.Parameter(torch.zeros(A, self.feat_dim, device=dev).requires_grad_(True))
+        self._scaling = nn.Parameter(scales.requires_grad_(True))
+        self._rotation = nn.Parameter(rots.requires_grad_(False))
+        self._opacity = nn.Parameter(inverse_sigmoid(0.1 * torch.ones(A, 1, device=dev)).requires_grad_(False))
+        self.max_radii2D = torch.zeros(A, device=dev)
+
+    def create_from_pcd(self, pcd, spatial_lr_scale: float):
+        self.create_from_points(np.asarray(pcd.points), spatial_lr_scale)
+
+    # ------------------------------------------------------------------ optimiser (reference :833-1058)
+    def register_training_params(self, name, module, lr, scheduler_func=None):
+        assert name not in self.net_params_registry
+        self.net_params_registry[name] = {"params": module if isinstance(module, list) else module.parameters(),
+                                          "lr": lr, "name": name}
+        self.scheduler_registry[name] = scheduler_func if scheduler_func is not None else (lambda x: lr)
+
+    def training_setup(self, training_args):
+        self.net_params_registry, self.scheduler_registry = OrderedDict(), OrderedDict()
+        self.percent_dense = training_args.percent_dense
+        A, K, dev = self._anchor.shape[0], self.n_offsets, self.device
+        self.opacity_accum = torch.zeros(A, 1, device=dev)
+        self.offset_gradient_accum = torch.zeros(A * K, 1, device=dev)
+        self.offset_denom = torch.zeros(A * K, 1, device=dev)
+        self.anchor_demon = torch.zeros(A, 1, device=dev)
+        ta, sl = training_args, self.spatial_lr_scale
+
+        def sched(prefix, scale=1.0, **kw):
+            return get_expon_lr_func(lr_init=getattr(ta, prefix + "_lr_init") * scale, lr_final=getattr(ta, prefix + "_lr_final") * scale,
+                                     lr_delay_mult=getattr(ta, prefix + "_lr_delay_mult"), max_steps=getattr(ta, prefix + "_lr_max_steps"), **kw)
+
+        reg = self.register_training_params
+        reg("anchor", [self._anchor], ta.position_lr_init * sl, sched("position", sl))
+        reg("offset", [self._offset], ta.offset_lr_init * sl, sched("offset", sl))
+        reg("mask", [self._mask], ta.mask_lr_init * sl, sched("mask", sl))
+        reg("anchor_feat", [self._anchor_feat], ta.feature_lr)
+        reg("opacity", [self._opacity], ta.opacity_lr)
+        reg("scaling", [self._scaling], ta.scaling_lr)
+        reg("rotation", [self._rotation], ta.rotation_lr)
+        reg("mlp_opacity", self.mlp_opacity, ta.mlp_opacity_lr_init, sched("mlp_opacity"))
+        reg("mlp_cov", self.mlp_cov, ta.mlp_cov_lr_init, sched("mlp_cov"))
+        reg("mlp_color", self.mlp_color, ta.mlp_color_lr_init, sched("mlp_color"))
+        reg("encoding_xyz", self.encoding_xyz, ta.encoding_xyz_lr_init,
+            sched("encoding_xyz", step_sub=0 if self.ste_binary else 10000))
+        reg("mlp_deform", self.mlp_deform, ta.mlp_deform_lr_init, sched("mlp_deform"))
+        for name in ("mlp_feature_enet", "mlp_scaling_enet", "mlp_offset_enet"):
+            reg(name, getattr(self, name), ta.mlp_entropy_net_lr_init, sched("mlp_entropy_net"))
+        self.optimizer = torch.optim.Adam(self.net_params_registry.values(), lr=0.0, eps=1e-15)
+
+    def update_learning_rate(self, iteration):
+        for group in self.optimizer.param_groups:
+            group["lr"] = self.scheduler_registry[group["name"]](iteration)
+
+    # ------------------------------------------------------------------ densification statistics (:1281-1314)
+    @torch.no_grad()
+    def training_statis(self, render_results):
+        """Accumulate, through the nested masks visible anchor -> opacity>0 -> radius>0: per-anchor positive
+        opacity sums and visit counts, per-offset screen-gradient norms and counts."""
+        K = self.n_offsets
+        vis = render_results.visible_mask
+        op = render_results.neural_opacity.detach().view(-1).clamp_min(0).view(-1, K)
+        self.opacity_accum[vis] += op.sum(dim=1, keepdim=True)
+        self.anchor_demon[vis] += 1
+        # flat (anchor*K + slot) index of every rasterised Gaussian that ended up with radius > 0
+        slots = torch.arange(vis.shape[0] * K, device=vis.device).view(-1, K)[vis].reshape(-1)
+        slots = slots[render_results.selection_mask][render_results.visibility_filter]
+        g = render_results.viewspace_points.grad[render_results.visibility_filter, :2]
+        self.offset_gradient_accum[slots] += torch.norm(g, dim=-1, keepdim=True)
+        self.offset_denom[slots] += 1

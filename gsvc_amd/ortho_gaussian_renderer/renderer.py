@@ -1,0 +1,36 @@
+"""``render`` — prefilter anchors, generate the frame's neural Gaussians, rasterize, pack RenderResults.
+
+Same signature and RenderResults fields as reference ortho_gaussian_renderer/renderer.py:14-119.
+"""
+from __future__ import annotations
+
+import torch
+
+from ..common.base import RenderResults
+from ..generate import GenerateMode, generate_neural_gaussians
+from ..rasterizer import GaussianRasterizer
+from .preprocess import prefilter_voxel, raster_settings_for
+
+
+def render(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain_grad=False,
+           mode=GenerateMode.TRAINING_FULL_PRECISION):
+    visible_mask = prefilter_voxel(frame, pc, pipe, bg_color)
+    gss = generate_neural_gaussians(frame, pc, visible_mask, mode)
+    # zero tensor whose .grad receives the screen-space gradient (densification statistics read it)
+    screenspace_points = torch.zeros_like(gss.xyz, dtype=pc.get_anchor.dtype, requires_grad=True) + 0
+    if retain_grad:
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier))
+    rendered_image, radii, num_rendered = rasterizer(
+        means3D=gss.xyz, means2D=screenspace_points, shs=None, colors_precomp=gss.color, opacities=gss.opacity,
+        scales=gss.scaling, rotations=gss.rot, cov3D_precomp=None)
+    return RenderResults(
+        rendered_image=rendered_image, viewspace_points=screenspace_points, visibility_filter=radii > 0,
+        visible_mask=visible_mask, radii=radii, active_gaussains=(radii > 0).sum(), num_rendered=num_rendered,
+        selection_mask=gss.mask, neural_opacity=gss.neural_opacity, scaling=gss.scaling,
+        bit_per_param=gss.bit_per_param, bit_per_feat_param=gss.bit_per_feat_param,
+        bit_per_scaling_param=gss.bit_per_scaling_param, bit_per_offsets_param=gss.bit_per_offsets_param,
+        entropy_constrained=(gss.bit_per_param is not None), generated_gaussians=gss, time_sub=gss.time_sub)

@@ -1,0 +1,111 @@
+"""The fitting step: 4 renders (2 adjacent frames x 2 opposite views), distortion + regularisers + optical-flow
+consistency + lambda * rate, backward, densification statistics, Adam.
+
+Same loss and order of operations as the step body of reference pipeline/train.py:325-462,559-581; logging,
+evaluation, tensorboard and the codec calls around it are out of scope.  Differences in mechanism: no per-step
+`.item()` / synchronize (the reference syncs ~10x per step for logging), the hash-table bit count stays on the
+device, and under torch.distributed each rank steps on its own frame pair and gradients are averaged with one
+collective (gsvc_amd/dist.py).  Anchor growing/pruning (adjust_anchor) is the next row of SURVEY.md section 8f
+and is not performed here.
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass
+
+import torch
+
+from . import dist as gdist
+from .encodings import get_binary_vxl_size
+from .generate import GenerateMode
+from .loss_utils import calc_optical_loss, l1_loss_func, ssim_func
+from .ortho_gaussian_renderer import render
+from .train_util import TrainingController
+
+
+@dataclass
+class StepOutput:
+    loss: torch.Tensor
+    image1: torch.Tensor
+    image2: torch.Tensor
+    renders: tuple
+    active_gaussians: torch.Tensor  # sum over the 4 renders of Gaussians with radius > 0 (device scalar)
+    frame_idx: int
+
+
+def hash_grid_bits(pc):
+    """Bernoulli code length of the binarised hash tables (reference pipeline/train.py:456)."""
+    return get_binary_vxl_size_device((pc.get_encoding_params() + 1) / 2)
+
+
+def get_binary_vxl_size_device(binary_vxl):
+    total = binary_vxl.numel()
+    ones = binary_vxl.sum()
+    p = torch.clamp(ones / total, min=1e-6, max=1 - 1e-6)
+    return ones * (-torch.log2(p)) + (total - ones) * (-torch.log2(1 - p)) + 32
+
+
+class Trainer:
+    def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0):
+        self.pc, self.dataset, self.opt, self.pipe, self.mp = gaussians, dataset, opt, pipe, model_params
+        self.controller = TrainingController(opt)
+        self.controller.step()  # iterations are 1-based
+        self.rng = random.Random(seed + gdist.rank())
+        self.lo, self.hi = gdist.frame_shard(dataset.len_z_frames)
+        bg = [1, 1, 1] if model_params.white_background else [0, 0, 0]
+        self.background = torch.tensor(bg, dtype=torch.float32)  # host tensor: the kernels take bg by value
+
+    def _two_views(self, frame, mode, retain_grad):
+        f = render(frame, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode)
+        frame.view_matrix, frame.view_matrix_s = frame.view_matrix_s, frame.view_matrix
+        b = render(frame, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode)
+        image = (f.rendered_image + torch.flip(b.rendered_image, dims=(-1,))) / 2
+        return f, b, image
+
+    def step(self, iteration: int, frame_idx: int | None = None) -> StepOutput:
+        opt, pc = self.opt, self.pc
+        dev = pc.device
+        pc.update_learning_rate(iteration)
+        if frame_idx is None:
+            frame_idx = self.rng.randint(self.lo, max(self.lo, self.hi - 1))
+        frame1, frame2 = self.dataset[frame_idx], self.dataset[frame_idx + 1]
+        mode = self.controller.render_mode
+        retain_grad = opt.update_until > iteration >= 0
+
+        r1f, r1b, image1 = self._two_views(frame1, mode, retain_grad)
+        r2f, r2b, image2 = self._two_views(frame2, mode, retain_grad)
+        renders = (r1f, r1b, r2f, r2b)
+        gt1 = frame1.image.to(dev).permute(0, 2, 1)
+        gt2 = frame2.image.to(dev).permute(0, 2, 1)
+        Ll1 = l1_loss_func(image1, gt1) + l1_loss_func(image2, gt2)
+        ssim_loss = (1.0 - ssim_func(image1, gt1)) + (1.0 - ssim_func(image2, gt2))
+        scaling_reg = sum(r.scaling.prod(dim=1).mean() for r in renders)
+        opacity_reg = sum((1 - r.neural_opacity).mean() for r in renders)
+        if opt.optical_lambda == 0:
+            optical_loss = 0
+        else:
+            flow = self.dataset.get_optical_flow(frame_idx)
+            optical_loss = calc_optical_loss(r1f, r1b, r2f, r2b, flow, self.dataset.x_min, self.dataset.y_min,
+                                             self.dataset.scale, self.dataset.width, self.dataset.height, pc.n_offsets)
+        loss = ((1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * ssim_loss + opt.scaling_reg * scaling_reg
+                + opt.opacity_reg * opacity_reg + opt.optical_lambda * optical_loss)
+        if self.controller.entropy_constrained:
+            assert all(r.entropy_constrained for r in renders)
+            bit_per_param = sum(r.bit_per_param for r in renders)
+            denom = pc._anchor.shape[0] * (pc.feat_dim + 6 + 3 * pc.n_offsets)
+            loss = loss + opt.lmbda * (bit_per_param + hash_grid_bits(pc) / denom)
+            loss = loss + 5e-4 * torch.mean(torch.sigmoid(pc._mask))
+        loss.backward()
+        gdist.allreduce_gradients([p for g in pc.optimizer.param_groups for p in g["params"]])
+
+        with torch.no_grad():
+            if self.controller.gaussian_statis:
+                for r in renders:
+                    pc.training_statis(r)
+            if iteration < opt.iterations:
+                pc.optimizer.step()
+                pc.optimizer.zero_grad(set_to_none=True)
+        self.controller.step()
+        active = sum(r.active_gaussains for r in renders)
+        return StepOutput(loss=loss.detach(), image1=image1.detach(), image2=image2.detach(), renders=renders,
+                          active_gaussians=active, frame_idx=frame_idx)

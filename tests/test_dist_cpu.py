@@ -1,0 +1,75 @@
+"""world_size-2 gloo tests of the multi-GPU layer (gsvc_amd/dist.py): frame sharding, the one-bucket
+gradient all-reduce and the densification-statistics reduction.  Runs on CPU."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from gsvc_amd import dist as gd
+    r, w, _ = gd.init_from_env("gloo")
+    assert (r, w) == (rank, world) and gd.rank() == rank and gd.world_size() == world
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    extra = torch.nn.Parameter(torch.zeros(4))          # a parameter that gets no gradient on any rank
+    if rank == 1:
+        for p in model.parameters():
+            p.data.add_(1.0)
+    gd.broadcast_parameters(model, src=0)
+    x = torch.full((2, 5), float(rank + 1))
+    model(x).sum().backward()
+    local = [p.grad.clone() for p in model.parameters()]
+    n = gd.allreduce_gradients(list(model.parameters()) + [extra])
+    assert n == sum(p.numel() for p in model.parameters()) and extra.grad is None
+    gathered = [[torch.zeros_like(g) for _ in range(world)] for g in local]
+    for g, out in zip(local, gathered):
+        dist.all_gather(out, g)
+    for p, out in zip(model.parameters(), gathered):
+        assert torch.allclose(p.grad, sum(out) / world, atol=1e-6)
+    pc = type("PC", (), {})()
+    pc.opacity_accum = torch.full((3, 1), float(rank + 1))
+    pc.anchor_demon = torch.ones(3, 1)
+    pc.offset_gradient_accum = torch.full((6, 1), 0.5 * (rank + 1))
+    pc.offset_denom = torch.ones(6, 1)
+    gd.allreduce_statistics(pc)
+    assert torch.all(pc.opacity_accum == 3.0) and torch.all(pc.anchor_demon == 2.0) and torch.all(pc.offset_gradient_accum == 1.5)
+    q.put((rank, gd.frame_shard(600), [float(p.data.sum()) for p in model.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, w0), (r1, s1, w1) = res
+    assert s0 == (0, 300) and s1 == (300, 599)       # blocks partition the 599 adjacent pairs
+    assert w0 == w1                                   # broadcast made the replicas identical
+
+
+def test_frame_shard_partitions():
+    from gsvc_amd.dist import frame_shard
+    for T, W in ((600, 8), (300, 8), (17, 4), (9, 8), (2, 1)):
+        blocks = [frame_shard(T, r, W) for r in range(W)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == T - 1
+        for a, b in zip(blocks, blocks[1:]):
+            assert a[1] == b[0]
+        sizes = [hi - lo for lo, hi in blocks]
+        assert max(sizes) - min(sizes) <= 1
+    from gsvc_amd import dist as gd
+    assert gd.world_size() == 1 and gd.rank() == 0 and gd.allreduce_gradients([]) == 0
