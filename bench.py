@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the GSVC hot path on MI355X (contract: see the task statement).
 
-    python bench.py --gpus N --steps K --warmup W [--workload raster_fwd|raster_fwdbwd]
+    python bench.py --gpus N --steps K --warmup W [--workload raster_fwd|raster_fwdbwd|train_step]
 
 A "step" is one pass of the hot path over one synthetic UVG-shaped 1080p frame resident in HBM.
   raster_fwd     BASELINE.json configs[1]: 1080p single frame, 200k Gaussians, forward raster only
   raster_fwdbwd  same scene, forward + backward of the rasterizer (dL/dimage random)
+  train_step     BASELINE.json configs[2]: 1080p, 16-frame z-slab, ~50k visible anchors x K=10 (<=500k Gaussians per
+                 render), one full fitting step = 4 renders (2 frames x 2 views) fwd+bwd, hash grid, entropy
+                 loss (lambda 0.004, TRAINING_ENTROPY mode), SSIM/L1/optical losses, Adam
 N > 1: launched by torch.distributed.run, one rank per GPU; frames shard across ranks (each rank rasterizes
 its own frame of the same video; no data-path collective in these workloads) -> weak scaling.
 
@@ -36,12 +39,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="raster_fwd", choices=["raster_fwd", "raster_fwdbwd"])
+    ap.add_argument("--workload", default="raster_fwd", choices=["raster_fwd", "raster_fwdbwd", "train_step"])
     ap.add_argument("--gaussians", type=int, default=200_000)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--frames", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--anchors", type=int, default=220_000, help="train_step: anchors in the 64-frame cube")
+    ap.add_argument("--train-frames", type=int, default=64, help="train_step: frames of the synthetic video")
+    ap.add_argument("--pretrain", type=int, default=0, help="train_step: extra untimed steps before warmup")
     return ap.parse_args()
 
 
@@ -71,6 +77,122 @@ def cpu_baseline(sc, workload):
             "seconds": round(t, 3)}
 
 
+def run_train_step(args, rank, world, local_rank, dev):
+    """BASELINE.json configs[2] on one GPU; frames shard over ranks with one gradient all-reduce per step."""
+    import torch.distributed as dist
+    from gsvc_amd import _lib, synthetic
+    from gsvc_amd.arguments import cfg_20240919
+    from gsvc_amd.frame import SyntheticFrameCube
+    from gsvc_amd.model import GaussianModel
+    from gsvc_amd.train import Trainer
+
+    H, W, T = args.height, args.width, args.train_frames
+    mp_, opt, pipe = cfg_20240919()
+    cube = SyntheticFrameCube(H, W, T, seed=1234, device=dev)
+    mp_.threshold = 8.0 / cube.scale                      # 16-frame sliding window
+    # jump straight to the entropy-constrained phase (lambda = 0.004, noise quantisation + sampled rate)
+    opt.full_precision_training_total, opt.quantized_training_total = 0, 0
+    opt.entropy_constrained_train_total = 10 ** 9
+    opt.start_stat, opt.update_until = 0, 10 ** 9         # densification statistics on; growing itself is out of scope
+    opt.pause_densification = 0
+    torch.manual_seed(0)
+    np.random.seed(0)
+    pc = GaussianModel(mp_, mp_.anchor_feature_dim, mp_.n_offsets, mp_.voxel_size, mp_.update_depth, mp_.update_init_factor,
+                       mp_.update_hierarchy_factor, mp_.use_feat_bank, n_features_per_level=mp_.grid_feature_dim,
+                       log2_hashmap_size=mp_.log2, log2_hashmap_size_2D=mp_.log2_2D, device=dev)
+    rng = np.random.default_rng(0)
+    lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
+    pts = rng.uniform(lim, -lim, (args.anchors, 3))
+    pc.create_from_points(pts, spatial_lr_scale=1.0)
+    pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+    pc.training_setup(opt)
+    trainer = Trainer(pc, cube, opt, pipe, mp_, seed=0)
+    it = [0]
+
+    def step():
+        it[0] += 1
+        return trainer.step(it[0])
+
+    for _ in range(args.pretrain + args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    active = torch.zeros((), device=dev, dtype=torch.float64)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        active += out.active_gaussians
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stats = torch.tensor([float(active.item()), elapsed], device=dev, dtype=torch.float64)
+    total_units = stats[0:1].clone()
+    tmax = stats[1:2].clone()
+    if world > 1:
+        dist.all_reduce(total_units, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_units, elapsed = float(total_units.item()), float(tmax.item())
+
+    _lib.profile_enable(True)
+    inst = 0
+    for _ in range(args.steps):
+        out = step()
+        inst += sum(r.num_rendered for r in out.renders)
+    torch.cuda.synchronize()
+    prof = _lib.profile_collect()
+    _lib.profile_enable(False)
+    if rank != 0:
+        return
+    HW = H * W
+    n_inst = inst / (4 * args.steps)                      # instances per render
+    P = float(sum(r.radii.numel() for r in out.renders)) / 4
+    n_vis = total_units / (4 * args.steps * world)
+    kern = {k: {"launches": n, "avg_us": 1e3 * ms / max(n, 1)} for k, (n, ms) in prof.items()}
+    alg = {"k_blend": 40 * n_inst + 20 * HW, "k_blend_bwd": 40 * n_inst + 20 * HW, "k_preprocess": 60 * P + 44 * n_vis,
+           "k_gaussian_bwd": 88 * n_vis + 124 * P}
+    dom = max(kern, key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
+    dom_bytes = alg.get(dom, 0)
+    achieved = dom_bytes / (kern[dom]["avg_us"] * 1e-6) / 1e9 if dom_bytes else 0.0
+    kernel_us = sum(v["avg_us"] * v["launches"] for v in kern.values()) / args.steps
+    res = {
+        "metric": "train-step Gaussians/sec + render fps @1080p", "value": total_units / elapsed, "unit": "Gaussians/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"train_step: {H}x{W}, {T}-frame synthetic video, {pc._anchor.shape[0]} anchors x K=10, 16-frame "
+                               f"z-slab (BASELINE.json configs[2]); 4 renders/step fwd+bwd + hash grid + entropy loss "
+                               f"(lambda={opt.lmbda}, TRAINING_ENTROPY) + L1/SSIM/optical + Adam; one frame pair per rank",
+                   "gaussians_per_render": P, "active_per_render": n_vis, "instances_per_render": n_inst,
+                   "parallelism": f"frame-shard x{world} + grad all-reduce"},
+        "render_fps": None,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": dom_bytes,
+                     "avg_launch_us": kern[dom]["avg_us"]},
+        "gsvc_kernel_us_per_step": kernel_us,
+        "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] / args.steps} for k, v in kern.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle
+        oracle.build()
+        r = out.renders[0]
+        gs = r.generated_gaussians
+        fr = cube.get_dummy_frame(out.frame_idx)
+        st = oracle.make_settings(H, W, fr.x_min, fr.y_min, fr.scale, mp_.threshold, fr.view_matrix.permute(1, 0).contiguous().numpy())
+        arrs = [t.detach().cpu().numpy() for t in (gs.xyz, gs.color, gs.opacity, gs.scaling, gs.rot)]
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        fwd = oracle.raster_forward(st, *arrs, num_threads=cores)
+        oracle.raster_backward(st, *arrs, fwd, np.ones((3, H, W), np.float32))
+        tc = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": float((fwd.radii > 0).sum()) / tc, "unit": "Gaussians/s", "cores": cores, "kind": "port",
+                               "sample": "rasterizer forward (OpenMP) + backward (scalar) of ONE of the step's 4 renders; "
+                                         "MLPs/grid/loss not included", "seconds": round(tc, 3)}
+    print(json.dumps(res))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -81,6 +203,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+    if args.workload == "train_step":
+        run_train_step(args, rank, world, local_rank, dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     from gsvc_amd import _lib, rasterizer, synthetic
 
     H, W, T, P = args.height, args.width, args.frames, args.gaussians

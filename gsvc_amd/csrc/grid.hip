@@ -10,8 +10,8 @@
 //
 // Mapping to the hardware: one lane per (point, level); a corner's C features are one 4*C-byte row, read
 // with 16-byte loads; the [L,N,C] output row of a lane is contiguous so a wave writes 64*4*C contiguous
-// bytes.  The table backward reduces nothing on chip (corners of neighbouring lanes differ) and uses one
-// float atomic wave-instruction per (corner, feature).
+// bytes.  The table backward reduces nothing on chip (corners of neighbouring points differ); it gives C
+// consecutive lanes to a point so that every corner costs one contiguous 4*C-byte atomic segment.
 #include "common.h"
 
 namespace gsvc {
@@ -210,14 +210,17 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inpu
     }
 }
 
-// table backward: one lane per (point, level); all C features of a corner go out as C atomics on one row
+// table backward: C consecutive lanes per (point, level), lane c owns feature c.  A corner's C atomics then
+// sit in one wave-instruction on one 4*C-byte row segment (one memory-side request per corner and point
+// instead of one per feature: float atomics on MI355X are priced per 64-byte request, not per lane).
 template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(256) k_grid_bwd(const float *__restrict__ grad, const float *__restrict__ inputs,
                                                   const int32_t *__restrict__ offsets,
                                                   const int32_t *__restrict__ resolutions,
                                                   float *__restrict__ grad_grid, uint32_t N)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t / C, ch = t - b * C;
     if (b >= N) return;
     const uint32_t level = blockIdx.y;
     grad_grid += (size_t)(uint32_t)offsets[level] * C;
@@ -231,18 +234,12 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float *__restrict__ grad
         oob |= (x[d] < 0.f) | (x[d] > 1.f);
     }
     if (oob) return;
-    float g[C];
-    load_row<C>(grad + ((size_t)level * N + b) * C, g);
+    const float g = grad[((size_t)level * N + b) * C + ch];
     Cell<D> c;
     locate<D>(x, resolution, hashmap_size, c);
 #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
-        if (c.valid & (1u << idx)) {
-            const float w = c.w[idx] * c.wn_re;
-            float *dst = grad_grid + (size_t)c.row[idx] * C;
-#pragma unroll
-            for (uint32_t ch = 0; ch < C; ch++) atomicAdd(dst + ch, w * g[ch]);
-        }
+        if (c.valid & (1u << idx)) atomicAdd(grad_grid + (size_t)c.row[idx] * C + ch, c.w[idx] * c.wn_re * g);
     }
 }
 
@@ -278,7 +275,7 @@ template <uint32_t D, uint32_t C>
 static void launch_bwd(const float *grad, const float *inputs, const int32_t *off, const int32_t *res, float *gemb,
                        uint32_t N, uint32_t L, const float *dy_dx, float *ginp, hipStream_t s)
 {
-    { ProfScope _prof("k_grid_bwd", s); hipLaunchKernelGGL((k_grid_bwd<D, C>), dim3((N + 255) / 256, L), dim3(256), 0, s, grad, inputs, off, res, gemb, N); }
+    { ProfScope _prof("k_grid_bwd", s); hipLaunchKernelGGL((k_grid_bwd<D, C>), dim3((unsigned)(((uint64_t)N * C + 255) / 256), L), dim3(256), 0, s, grad, inputs, off, res, gemb, N); }
     if (dy_dx && ginp)
         { ProfScope _prof("k_grid_input_bwd", s); hipLaunchKernelGGL((k_grid_input_bwd<D, C>), dim3((N * D + 255) / 256), dim3(256), 0, s, grad, dy_dx, ginp, N, L); }
 }

@@ -63,25 +63,35 @@ def calc_sampled_rate(pc, visible_mask, feat, grid_scaling, grid_offsets, Q_feat
     """Bits per parameter estimated on a 5 % Bernoulli sample of the visible anchors that still own at least
     one live offset, scaled by the fraction of such anchors."""
     K = pc.n_offsets
-    anchor = pc.get_anchor[visible_mask]
-    mask_anchor = pc.get_mask_anchor[visible_mask]
+    vis = _as_index(visible_mask)
+    mask_anchor = pc.get_mask_anchor.index_select(0, vis)
     keep_rate = (mask_anchor.sum() / mask_anchor.numel()).detach()
-    offset_masks = pc.get_mask[visible_mask]
-    chosen = (torch.rand_like(anchor[:, 0]) <= SAMPLE_RATE) & mask_anchor.to(torch.bool)
+    offset_masks = pc.get_mask.index_select(0, vis)
+    # same draw as the reference's rand_like(anchor[:, 0]) (one uniform per visible anchor)
+    chosen = (torch.rand_like(feat[:, 0]) <= SAMPLE_RATE) & mask_anchor.to(torch.bool)
+    sel = chosen.nonzero(as_tuple=False).squeeze(1)
+    take = lambda t: t.index_select(0, sel)  # noqa: E731
     ec = entropy_context
-    bit_feat = pc.entropy_gaussian(feat[chosen], ec.mean_feat[chosen], ec.scale_feat[chosen], Q_feat[chosen],
-                                   pc._anchor_feat.mean())
-    bit_scaling = pc.entropy_gaussian(grid_scaling[chosen], ec.mean_scaling[chosen], ec.scale_scaling[chosen],
-                                      Q_scaling[chosen], pc.get_scaling.mean())
-    bit_offsets = pc.entropy_gaussian(grid_offsets[chosen].view(-1, 3 * K), ec.mean_offsets[chosen],
-                                      ec.scale_offsets[chosen], Q_offsets[chosen], pc._offset.mean())
-    bit_offsets = bit_offsets * offset_masks[chosen].repeat(1, 1, 3).view(-1, 3 * K)
+    bit_feat = pc.entropy_gaussian(take(feat), take(ec.mean_feat), take(ec.scale_feat), take(Q_feat), pc._anchor_feat.mean())
+    bit_scaling = pc.entropy_gaussian(take(grid_scaling), take(ec.mean_scaling), take(ec.scale_scaling), take(Q_scaling),
+                                      pc.get_scaling.mean())
+    bit_offsets = pc.entropy_gaussian(take(grid_offsets).view(-1, 3 * K), take(ec.mean_offsets), take(ec.scale_offsets),
+                                      take(Q_offsets), pc._offset.mean())
+    bit_offsets = bit_offsets * take(offset_masks).repeat(1, 1, 3).view(-1, 3 * K)
     sf, ss, so = bit_feat.sum(), bit_scaling.sum(), bit_offsets.sum()
     nf, ns, no = bit_feat.numel(), bit_scaling.numel(), bit_offsets.numel()
     return RatePack(bit_per_param=(sf + ss + so) / (nf + ns + no) * keep_rate,
                     bit_per_feat_param=sf / nf * keep_rate,
                     bit_per_scaling_param=ss / ns * keep_rate,
                     bit_per_offsets_param=so / no * keep_rate)
+
+
+def _as_index(mask_or_index):
+    """Boolean mask -> int64 index list (one nonzero); index tensors pass through.  Gathers by index have a
+    scatter-add backward (atomics) instead of the sort-based index_put a boolean mask triggers."""
+    if mask_or_index.dtype == torch.bool:
+        return mask_or_index.nonzero(as_tuple=False).squeeze(1)
+    return mask_or_index
 
 
 def _sync(t):
@@ -95,11 +105,12 @@ def generate_neural_gaussians(frame, pc, visible_mask=None, mode=GenerateMode.TR
     if visible_mask is None:
         visible_mask = torch.ones(all_anchor.shape[0], dtype=torch.bool, device=all_anchor.device)
     K = pc.n_offsets
-    anchor = all_anchor[visible_mask]
-    feat = pc._anchor_feat[visible_mask]
-    grid_offsets = pc._offset[visible_mask]
-    grid_scaling = pc.get_scaling[visible_mask]
-    offset_masks = pc.get_mask[visible_mask]
+    vis = _as_index(visible_mask)            # one nonzero for the five per-anchor gathers
+    anchor = all_anchor.index_select(0, vis)
+    feat = pc._anchor_feat.index_select(0, vis)
+    grid_offsets = pc._offset.index_select(0, vis)
+    grid_scaling = pc.get_scaling.index_select(0, vis)
+    offset_masks = pc.get_mask.index_select(0, vis)
     rate = RatePack()
     Q_feat, Q_scaling, Q_offsets = BASE_Q_FEAT, BASE_Q_SCALING, BASE_Q_OFFSETS
 
@@ -115,7 +126,7 @@ def generate_neural_gaussians(frame, pc, visible_mask=None, mode=GenerateMode.TR
         feat = pc.noise_quantizer(feat, Q_feat)
         grid_scaling = pc.noise_quantizer(grid_scaling, Q_scaling)
         grid_offsets = pc.noise_quantizer(grid_offsets, Q_offsets.unsqueeze(1))
-        rate = calc_sampled_rate(pc, visible_mask, feat, grid_scaling, grid_offsets, Q_feat, Q_scaling, Q_offsets, ec)
+        rate = calc_sampled_rate(pc, vis, feat, grid_scaling, grid_offsets, Q_feat, Q_scaling, Q_offsets, ec)
     elif mode == GenerateMode.TRAININ_STE_ENTROPY:
         _sync(anchor)
         t1 = time.time()
@@ -128,7 +139,7 @@ def generate_neural_gaussians(frame, pc, visible_mask=None, mode=GenerateMode.TR
         grid_offsets = STE_multistep.apply(grid_offsets, Q_offsets.unsqueeze(1), pc._offset.mean()).detach()
         _sync(anchor)
         time_sub = time.time() - t1
-        rate = calc_sampled_rate(pc, visible_mask, feat, grid_scaling, grid_offsets, Q_feat, Q_scaling, Q_offsets, ec)
+        rate = calc_sampled_rate(pc, vis, feat, grid_scaling, grid_offsets, Q_feat, Q_scaling, Q_offsets, ec)
     else:
         raise ValueError(f"Unknown mode {mode}")
 
@@ -151,7 +162,8 @@ def generate_neural_gaussians(frame, pc, visible_mask=None, mode=GenerateMode.TR
     # optical-flow loss of the training step reads it (reference utils/loss_utils.py:108-118)
     per_anchor = torch.cat([grid_scaling, anchor], dim=-1)
     concatenated_all = torch.cat([per_anchor.repeat_interleave(K, dim=0), color, scale_rot, offsets], dim=-1)
-    alive = concatenated_all[mask]
+    alive_idx = mask.nonzero(as_tuple=False).squeeze(1)
+    alive = concatenated_all.index_select(0, alive_idx)
     scaling_rep, anchor_rep = alive[:, 0:6], alive[:, 6:9]
     color_a, scale_rot_a, offsets_a = alive[:, 9:12], alive[:, 12:19], alive[:, 19:22]
 
@@ -159,7 +171,8 @@ def generate_neural_gaussians(frame, pc, visible_mask=None, mode=GenerateMode.TR
     rot = pc.rotation_activation(scale_rot_a[:, 3:7])
     xyz = torch.clamp(anchor_rep + offsets_a * scaling_rep[:, :3], pc.x_bound_min, pc.x_bound_max)
     return GeneratedGaussians(
-        xyz=xyz, color=color_a, opacity=neural_opacity[mask], scaling=scaling, rot=rot,
+        xyz=xyz, color=color_a, opacity=neural_opacity.index_select(0, alive_idx),
+        scaling=scaling, rot=rot,
         neural_opacity=neural_opacity, visable_mask=visible_mask, mask=mask,
         bit_per_param=rate.bit_per_param, bit_per_feat_param=rate.bit_per_feat_param,
         bit_per_scaling_param=rate.bit_per_scaling_param, bit_per_offsets_param=rate.bit_per_offsets_param,

@@ -14,6 +14,44 @@ import torch
 import torch.nn.functional as F
 
 
+class _SsimL1(torch.autograd.Function):
+    """(mean SSIM, mean |a-b|) of two [C,H,W] CUDA images through csrc/ssim.hip; gradient w.r.t. the first."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        from . import _lib
+        a, b = img1.contiguous().float(), img2.contiguous().float()
+        C_, H, W = a.shape
+        need = img1.requires_grad
+        sums = torch.empty(2, device=a.device, dtype=torch.float32)
+        work = torch.empty(2048, device=a.device, dtype=torch.float32)
+        maps = [torch.empty_like(a) for _ in range(3)] if need else [None, None, None]
+        _lib.check(_lib.lib().gsvc_ssim_l1_forward(_lib.ptr(a), _lib.ptr(b), C_, H, W, _lib.ptr(sums), _lib.ptr(work), _lib.ptr(maps[0]),
+                                                   _lib.ptr(maps[1]), _lib.ptr(maps[2]), _lib.current_stream(a.device)),
+                   "gsvc_ssim_l1_forward")
+        if need:
+            ctx.save_for_backward(a, b, *maps)
+        out = sums / float(C_ * H * W)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_ssim, g_l1):
+        from . import _lib
+        a, b, m0, m1, m2 = ctx.saved_tensors
+        C_, H, W = a.shape
+        grads = torch.stack([g_ssim, g_l1]).float().contiguous()
+        d = torch.empty_like(a)
+        _lib.check(_lib.lib().gsvc_ssim_l1_backward(_lib.ptr(a), _lib.ptr(b), C_, H, W, _lib.ptr(grads), _lib.ptr(m0),
+                                                    _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(d), _lib.current_stream(a.device)),
+                   "gsvc_ssim_l1_backward")
+        return d, None
+
+
+def ssim_l1(img1, img2):
+    """Fused (ssim_func(img1, img2), l1_loss_func(img1, img2)) for [3,H,W] CUDA images (one kernel each way)."""
+    return _SsimL1.apply(img1, img2)
+
+
 def l1_loss_func(network_output, gt):
     return (network_output - gt).abs().mean()
 
@@ -38,6 +76,12 @@ def _blur(x, w1d, pad):
 
 
 def ssim_func(img1, img2, window_size=11, size_average=True):
+    if img1.is_cuda and window_size == 11:
+        # GPU tensors always take the fused HIP kernel (per image when a batch is given)
+        if img1.dim() == 3:
+            return _SsimL1.apply(img1, img2)[0]
+        per = torch.stack([_SsimL1.apply(a, b)[0] for a, b in zip(img1, img2)])
+        return per.mean() if size_average else per
     squeeze = img1.dim() == 3
     a = img1.unsqueeze(0) if squeeze else img1
     b = img2.unsqueeze(0) if squeeze else img2

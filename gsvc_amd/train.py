@@ -18,7 +18,7 @@ import torch
 from . import dist as gdist
 from .encodings import get_binary_vxl_size
 from .generate import GenerateMode
-from .loss_utils import calc_optical_loss, l1_loss_func, ssim_func
+from .loss_utils import calc_optical_loss, ssim_l1
 from .ortho_gaussian_renderer import render
 from .train_util import TrainingController
 
@@ -77,8 +77,10 @@ class Trainer:
         renders = (r1f, r1b, r2f, r2b)
         gt1 = frame1.image.to(dev).permute(0, 2, 1)
         gt2 = frame2.image.to(dev).permute(0, 2, 1)
-        Ll1 = l1_loss_func(image1, gt1) + l1_loss_func(image2, gt2)
-        ssim_loss = (1.0 - ssim_func(image1, gt1)) + (1.0 - ssim_func(image2, gt2))
+        ssim1, l1_1 = ssim_l1(image1, gt1.contiguous())
+        ssim2, l1_2 = ssim_l1(image2, gt2.contiguous())
+        Ll1 = l1_1 + l1_2
+        ssim_loss = (1.0 - ssim1) + (1.0 - ssim2)
         scaling_reg = sum(r.scaling.prod(dim=1).mean() for r in renders)
         opacity_reg = sum((1 - r.neural_opacity).mean() for r in renders)
         if opt.optical_lambda == 0:

@@ -156,6 +156,22 @@ int gsvc_rate_backward(const float *x, const float *mean, const float *scale, co
                        const float *gscale_dev, float *dx, float *dmean, float *dscale, float *dQ, float *dweight,
                        void *stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Image distortion of the fitting step (replaces utils/loss_utils.py l1_loss_func + ssim_func and their autograd)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* img1, img2: [C,H,W].  workspace: 2048 floats of scratch.  sums[2] (device): sums[0] = sum of the SSIM map (11x11 Gaussian window,
+ * sigma 1.5, zero padding, C1=.01^2, C2=.03^2, reference loss_utils.py:52-72), sums[1] = sum |img1-img2|
+ * (:20-21); divide by C*H*W for the reference's means.  dm_*: [C,H,W] partial maps kept for the backward, or
+ * all three NULL when no gradient is needed. */
+int gsvc_ssim_l1_forward(const float *img1, const float *img2, int32_t C, int32_t H, int32_t W, float *sums,
+                         float *workspace, float *dm_dmu1, float *dm_de11, float *dm_de12, void *stream);
+
+/* dL_dimg1[C,H,W] = grads[0] * d(mean SSIM)/d img1 + grads[1] * d(mean |img1-img2|)/d img1; grads: device [2]. */
+int gsvc_ssim_l1_backward(const float *img1, const float *img2, int32_t C, int32_t H, int32_t W, const float *grads,
+                          const float *dm_dmu1, const float *dm_de11, const float *dm_de12, float *dL_dimg1,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -285,3 +285,40 @@ def test_compat_install_provides_the_native_module_names():
     for k in ("_gridencoder", "diff_gaussian_rasterization", "diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer",
               "ortho_gaussian_renderer", "gaussian_renderer"):
         sys.modules.pop(k, None)
+
+
+@pytest.mark.parametrize("H,W", [(48, 64), (37, 53), (16, 16), (5, 7)])
+def test_fused_ssim_l1_matches_torch_and_reference(H, W):
+    """csrc/ssim.hip vs the plain PyTorch fp32 statement of the same op (five 11x11 depthwise convs) and, at
+    48x64, vs the reference's own numbers (tests/golden/image_losses.npz).  fp32: 2e-6 on the means, 1e-5
+    relative on the gradient."""
+    import torch.nn.functional as F
+    from gsvc_amd import loss_utils as LU
+    if (H, W) == (48, 64):
+        g = load("image_losses")
+        a, b = C(g["img1"]), C(g["img2"])
+    else:
+        gen = torch.Generator().manual_seed(H * 100 + W)
+        a = torch.rand(3, H, W, generator=gen).cuda()
+        b = (a + 0.2 * torch.randn(3, H, W, generator=gen).cuda()).clamp(0, 1)
+    a.requires_grad_(True)
+    s, l = LU.ssim_l1(a, b)
+    (0.2 * (1 - s) + 0.8 * l).backward()
+    ga = a.grad.clone()
+    # plain torch reference on the GPU
+    a2 = a.detach().clone().requires_grad_(True)
+    w1 = LU._window_1d(11, 1.5).cuda()
+    w2 = (w1[:, None] @ w1[None, :]).expand(3, 1, 11, 11).contiguous()
+    conv = lambda t: F.conv2d(t.unsqueeze(0), w2, padding=5, groups=3)[0]  # noqa: E731
+    mu1, mu2 = conv(a2), conv(b)
+    s1, s2, s12 = conv(a2 * a2) - mu1 * mu1, conv(b * b) - mu2 * mu2, conv(a2 * b) - mu1 * mu2
+    smap = ((2 * mu1 * mu2 + 0.01 ** 2) * (2 * s12 + 0.03 ** 2)) / ((mu1 * mu1 + mu2 * mu2 + 0.01 ** 2) * (s1 + s2 + 0.03 ** 2))
+    s_ref, l_ref = smap.mean(), (a2 - b).abs().mean()
+    (0.2 * (1 - s_ref) + 0.8 * l_ref).backward()
+    assert abs(float(s) - float(s_ref)) < 2e-6 and abs(float(l) - float(l_ref)) < 1e-7
+    assert (ga - a2.grad).abs().max() < 1e-5 * a2.grad.abs().max() + 1e-9
+    if (H, W) == (48, 64):
+        assert abs(float(s) - float(g["ssim"])) < 2e-6 and abs(float(l) - float(g["l1"])) < 1e-7
+        assert abs(float(LU.ssim_func(a.detach(), b)) - float(g["ssim"])) < 2e-6
+        per = LU.ssim_func(a.detach().unsqueeze(0), b.unsqueeze(0), size_average=False)
+        assert np.abs(per.cpu().numpy() - g["ssim_per"]).max() < 2e-6
