@@ -13,6 +13,8 @@
 //                    screen-space -> world mean (constant orthographic Jacobian, no covariance->mean term).
 #include "raster_common.h"
 
+#include <cstdlib>
+
 namespace gsvc {
 
 constexpr int ACC_STRIDE = 16;  // floats per Gaussian in the accumulator (9 used, 64-B rows)
@@ -199,9 +201,156 @@ __global__ void __launch_bounds__(256) k_blend_bwd(RasterParams st, const int32_
     }
 }
 
+// ---- variant T (default): ONE wave per 16x16 tile; lane l owns pixel l of each of the four 8x8 quadrants and
+// walks the quadrants a Gaussian can reach one after the other (wave-uniform 4-bit mask from the bbox test), adding
+// its nine partial sums in registers.  One DPP reduction per (tile, Gaussian) instead of one per (quadrant,
+// Gaussian), no cross-wave combine, no barriers; a chunk's 64 x 9 sums are flushed with nine 64-lane atomic
+// wave-instructions (36 contiguous bytes per list entry).
+struct PixState {
+    float T, tb, d0, d1, d2, behind0, behind1, behind2;  // tb = final_T * (bg . dL/dpixel)
+    int last;
+};
+
+__device__ __forceinline__ void bwd_pixel(PixState &p, bool inq, float dx, float dy, const float4 &a, const float4 &b,
+                                          float cb, int contributor, float &s_h, float &s_x, float &s_y, float &s_xx,
+                                          float &s_xy, float &s_yy, float &s_r, float &s_g, float &s_b)
+{
+    const float pw = a.z * dx * dx + b.x * dy * dy + a.w * dx * dy;   // -power*log2(e), conic pre-scaled
+    const float G = __builtin_amdgcn_exp2f(-pw);
+    const float alpha = fminf(ALPHA_MAX, b.y * G);
+    const bool valid = inq && (contributor <= p.last) && !(pw < 0.0f) && !(alpha < ALPHA_MIN);
+    if (valid) {
+        const float oma = 1.0f - alpha;
+        const float inv = __builtin_amdgcn_rcpf(oma);
+        p.T *= inv;
+        const float w = alpha * p.T;
+        // `behind` = colour composited behind this Gaussian (everything already visited)
+        float dLda = (b.z - p.behind0) * p.d0 + (b.w - p.behind1) * p.d1 + (cb - p.behind2) * p.d2;
+        s_r += w * p.d0; s_g += w * p.d1; s_b += w * p.d2;
+        dLda = dLda * p.T - p.tb * inv;
+        p.behind0 = alpha * b.z + oma * p.behind0;
+        p.behind1 = alpha * b.w + oma * p.behind1;
+        p.behind2 = alpha * cb + oma * p.behind2;
+        // moments of h = G * dL/dalpha; the conic / opacity factors are applied once per Gaussian in B2
+        const float h = G * dLda;
+        const float hx = h * dx, hy = h * dy;
+        s_h += h; s_x += hx; s_y += hy; s_xx += hx * dx; s_xy += hx * dy; s_yy += hy * dy;
+    }
+}
+
+__global__ void __launch_bounds__(64, 5) k_blend_bwd_tile(RasterParams st, const int32_t *__restrict__ tile_offsets,
+                                                       const int32_t *__restrict__ point_list,
+                                                       const uint2 *__restrict__ inst_bbox,
+                                                       const GeomRec *__restrict__ geom,
+                                                       const float *__restrict__ final_T,
+                                                       const int32_t *__restrict__ n_contrib,
+                                                       const float *__restrict__ dL_dimage, float *__restrict__ acc,
+                                                       const gsvc_raster_counters *__restrict__ counters)
+{
+    __shared__ float4 s_f0[64];     // u v A' B'
+    __shared__ float4 s_f1[64];     // C' opacity r g
+    __shared__ float2 s_f2[64];     // b, tag = chunk entry | quadrant mask << 8 | list position << 12
+    __shared__ float s_out[64][9];  // per chunk entry: sum h, h dx, h dy, h dx^2, h dx dy, h dy^2, w d0, w d1, w d2
+    __shared__ int s_id[64];
+    if (counters->overflow) return;
+    const int lane = threadIdx.x;
+    const int tx0 = blockIdx.x * TILE, ty0 = blockIdx.y * TILE;
+    const int tile = blockIdx.y * st.gx + blockIdx.x;
+    const int beg = tile_offsets[tile];
+    const int HW = st.H * st.W;
+    PixState ps[4];
+    const float fx0 = (float)(tx0 + (lane & 7)), fy0 = (float)(ty0 + (lane >> 3));
+    bool inq[4];
+    int wl[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int px = tx0 + 8 * (q & 1) + (lane & 7), py = ty0 + 8 * (q >> 1) + (lane >> 3);
+        inq[q] = px < st.W && py < st.H;
+        const int pix = py * st.W + px;
+        PixState &p = ps[q];
+        const float Tf = inq[q] ? final_T[pix] : 0.f;
+        p.last = inq[q] ? n_contrib[pix] : 0;
+        p.d0 = inq[q] ? dL_dimage[pix] : 0.f;
+        p.d1 = inq[q] ? dL_dimage[HW + pix] : 0.f;
+        p.d2 = inq[q] ? dL_dimage[2 * HW + pix] : 0.f;
+        p.tb = Tf * (st.bg0 * p.d0 + st.bg1 * p.d1 + st.bg2 * p.d2);
+        p.T = Tf;
+        p.behind0 = p.behind1 = p.behind2 = 0.f;
+        int m = p.last;
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) m = max(m, __shfl_xor(m, k, 64));
+        wl[q] = __builtin_amdgcn_readfirstlane(m);
+    }
+    const int tile_last = max(max(wl[0], wl[1]), max(wl[2], wl[3]));
+
+    for (int c1 = beg + tile_last; c1 > beg; c1 -= 64) {
+        // chunk = list entries [c1-64, c1) from the back; chunk-local index e = c1 - 1 - k
+        const int k = c1 - 1 - lane;
+        int qm = 0, id = -1;
+        if (k >= beg) {
+            const uint2 bb = inst_bbox[k];
+            id = point_list[k];
+            const int rel = k - beg;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (rel < wl[q] && bbox_hits_b(bb, tx0 + 8 * (q & 1), ty0 + 8 * (q >> 1))) qm |= 1 << q;
+        }
+        s_id[lane] = id;
+        const unsigned long long mask = __ballot(qm != 0);
+        if (mask == 0ull) continue;
+        if (qm != 0) {
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            const float4 *rec = reinterpret_cast<const float4 *>(geom + id);
+            const float4 r0 = rec[0], r1 = rec[1];
+            s_f0[pos] = make_float4(r0.x, r0.y, (0.5f * 1.44269504088896340736f) * r0.z, 1.44269504088896340736f * r0.w);
+            s_f1[pos] = make_float4((0.5f * 1.44269504088896340736f) * r1.x, r1.y, r1.z, r1.w);
+            s_f2[pos] = make_float2(rec[2].x, __int_as_float(lane | (qm << 8) | ((k - beg + 1) << 12)));
+        }
+        const int cnt = __popcll(mask);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned long long touched = 0ull;
+        for (int j = 0; j < cnt; j++) {
+            const float4 a = s_f0[j];
+            const float4 b = s_f1[j];
+            const float2 c = s_f2[j];
+            const int tag = __builtin_amdgcn_readfirstlane(__float_as_int(c.y));
+            const int contributor = tag >> 12, quads = (tag >> 8) & 0xf, e = tag & 0xff;
+            float s_h = 0.f, s_x = 0.f, s_y = 0.f, s_xx = 0.f, s_xy = 0.f, s_yy = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
+            const float dxb = a.x - fx0, dyb = a.y - fy0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (quads & (1 << q))
+                    bwd_pixel(ps[q], inq[q], dxb - (float)(8 * (q & 1)), dyb - (float)(8 * (q >> 1)), a, b, c.x, contributor,
+                              s_h, s_x, s_y, s_xx, s_xy, s_yy, s_r, s_g, s_b);
+            wave_sum9_to_lane63(s_h, s_x, s_y, s_xx, s_xy, s_yy, s_r, s_g, s_b);
+            touched |= 1ull << e;
+            if (lane == 63) {
+                float *dst = s_out[e];
+                dst[0] = s_h; dst[1] = s_x; dst[2] = s_y; dst[3] = s_xx; dst[4] = s_xy; dst[5] = s_yy;
+                dst[6] = s_r; dst[7] = s_g; dst[8] = s_b;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // flush: lane -> (entry, component); 9 consecutive lanes = one 36-byte atomic segment
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const int v = r * 64 + lane;
+            const int e = v / 9, comp = v - e * 9;
+            if ((touched >> e) & 1ull) atomicAdd(acc + (size_t)s_id[e] * ACC_STRIDE + comp, s_out[e][comp]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <bool MOMENTS>
 __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, const float *__restrict__ means3D,
                                                       const float *__restrict__ scales,
                                                       const float *__restrict__ rotations,
+                                                      const float *__restrict__ opacities,
                                                       const int32_t *__restrict__ radii, const float *__restrict__ acc,
                                                       float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
                                                       float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacities,
@@ -214,18 +363,31 @@ __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, co
         const float4 a0 = reinterpret_cast<const float4 *>(acc + (size_t)i * ACC_STRIDE)[0];
         const float4 a1 = reinterpret_cast<const float4 *>(acc + (size_t)i * ACC_STRIDE)[1];
         const float a2 = acc[(size_t)i * ACC_STRIDE + 8];
-        const float du = a0.x, dv = a0.y, dA = a0.z, dB = a0.w, dC = a1.x;
-        go = a1.y; gc[0] = a1.z; gc[1] = a1.w; gc[2] = a2;
+        float du, dv, dA, dB, dC;
+        PreOut o;
+        preprocess_gaussian(st, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], scales[3 * i], scales[3 * i + 1],
+                            scales[3 * i + 2], rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2],
+                            rotations[4 * i + 3], o);
+        if (MOMENTS) {
+            // accumulator holds moments of h = G dL/dalpha: (sum h, h dx, h dy, h dx^2, h dx dy, h dy^2, colour grads)
+            const float op = opacities[i];
+            const float sh = a0.x, sx = a0.y, sy = a0.z, sxx = a0.w, sxy = a1.x, syy = a1.y;
+            go = sh;
+            du = -op * (o.A * sx + o.B * sy);
+            dv = -op * (o.C * sy + o.B * sx);
+            dA = -0.5f * op * sxx; dB = -op * sxy; dC = -0.5f * op * syy;
+            gc[0] = a1.z; gc[1] = a1.w; gc[2] = a2;
+        } else {
+            du = a0.x; dv = a0.y; dA = a0.z; dB = a0.w; dC = a1.x;
+            go = a1.y; gc[0] = a1.z; gc[1] = a1.w; gc[2] = a2;
+        }
         g2[0] = du * 0.5f * (float)st.W;
         g2[1] = dv * 0.5f * (float)st.H;
         const float *M = st.m;
         for (int j = 0; j < 3; j++) g3[j] = st.scale * (M[j] * du + M[4 + j] * dv);
 
-        const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
         const float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
         const float4 q = reinterpret_cast<const float4 *>(rotations)[i];
-        PreOut o;
-        preprocess_gaussian(st, px, py, pz, s0, s1, s2, q.x, q.y, q.z, q.w, o);
         const float ca = o.a, cb = o.b, cc = o.c;
         const float det = ca * cc - cb * cb;
         const float inv2 = 1.0f / (det * det + 1e-7f);
@@ -284,11 +446,11 @@ extern "C" int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_
                                     float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacities,
                                     float *dL_dscales, float *dL_drotations, void *scratch, void *stream)
 {
-    (void)colors; (void)opacities;
+    (void)colors;
     GSVC_REQUIRE(settings != nullptr, "raster_backward: settings is NULL");
     GSVC_REQUIRE(P >= 0 && P < (int64_t)1 << 31 && max_instances >= 0, "raster_backward: bad sizes");
     if (P == 0) return GSVC_OK;
-    GSVC_REQUIRE(means3D && scales && rotations && radii && geom && binning && image_state && dL_dimage && scratch,
+    GSVC_REQUIRE(means3D && opacities && scales && rotations && radii && geom && binning && image_state && dL_dimage && scratch,
                  "raster_backward: NULL input pointer");
     GSVC_REQUIRE(dL_dmeans3D && dL_dmeans2D && dL_dcolors && dL_dopacities && dL_dscales && dL_drotations,
                  "raster_backward: NULL output pointer");
@@ -306,10 +468,27 @@ extern "C" int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_
         set_error("raster_backward: hipMemsetAsync failed");
         return GSVC_E_LAUNCH;
     }
-    { ProfScope _prof("k_blend_bwd", s); hipLaunchKernelGGL(k_blend_bwd, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list, inst_bbox,
-                       (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters); }
-    { ProfScope _prof("k_gaussian_bwd", s); hipLaunchKernelGGL(k_gaussian_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D, scales,
-                       rotations, radii, (const float *)scratch, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacities,
-                       dL_dscales, dL_drotations); }
+    static const char *variant = getenv("GSVC_BWD_VARIANT");
+    const bool quad = variant && variant[0] == 'q';
+    {
+        ProfScope _prof("k_blend_bwd", s);
+        if (quad)
+            hipLaunchKernelGGL(k_blend_bwd, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list, inst_bbox,
+                               (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters);
+        else
+            hipLaunchKernelGGL(k_blend_bwd_tile, dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, inst_bbox,
+                               (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters);
+    }
+    {
+        ProfScope _prof("k_gaussian_bwd", s);
+        if (quad)
+            hipLaunchKernelGGL(k_gaussian_bwd<false>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
+                               scales, rotations, opacities, radii, (const float *)scratch, dL_dmeans3D, dL_dmeans2D,
+                               dL_dcolors, dL_dopacities, dL_dscales, dL_drotations);
+        else
+            hipLaunchKernelGGL(k_gaussian_bwd<true>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
+                               scales, rotations, opacities, radii, (const float *)scratch, dL_dmeans3D, dL_dmeans2D,
+                               dL_dcolors, dL_dopacities, dL_dscales, dL_drotations);
+    }
     return check_launch("raster_backward");
 }

@@ -40,7 +40,7 @@ struct RasterLayout {
     // geom blob
     uint64_t off_geom, off_bin, geom_bytes;
     // binning blob
-    uint64_t off_counters, off_tile_offsets, off_tile_count, off_tile_extra, off_keys, off_point_list, off_inst_bbox,
+    uint64_t off_counters, off_tile_offsets, off_tile_count, off_tile_extra, off_big_list, off_keys, off_point_list, off_inst_bbox,
         binning_bytes;
     // image blob
     uint64_t off_final_T, off_n_contrib, image_bytes;
@@ -61,6 +61,7 @@ inline RasterLayout raster_layout(const gsvc_raster_settings &s, int64_t P, int6
     L.off_tile_offsets = o;  o += align_up((uint64_t)(L.tiles + 1) * 4, 256);
     L.off_tile_count = o;    o += align_up((uint64_t)L.tiles * 4, 256);
     L.off_tile_extra = o;    o += align_up((uint64_t)L.tiles * 4, 256);
+    L.off_big_list = o;      o += align_up((uint64_t)L.tiles * 4, 256);
     L.off_keys = o;          o += align_up(m * 8, 256);
     L.off_point_list = o;    o += align_up(m * 4, 256);
     L.off_inst_bbox = o;     o += align_up(m * 8, 256);

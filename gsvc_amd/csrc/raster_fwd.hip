@@ -23,8 +23,10 @@
 //                   one vector test of the entries' alpha bounding boxes against the wave's quadrant keeps
 //                   only the Gaussians that can reach alpha >= 1/255 there (exact: skipped pairs contribute
 //                   nothing in the spec either); survivors are compacted into a wave-private LDS strip and
-//                   composited front to back from LDS broadcast reads.
+//                   composited front to back from LDS broadcast reads by a branch-free inner loop.
 #include "raster_common.h"
+
+#include <cstdlib>
 
 namespace gsvc {
 
@@ -191,28 +193,44 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
 
 // ------------------------------------------------------------------------------------------------- K2
 // tile_offsets = exclusive scan of (tile_count + tile_extra); tile_extra is zeroed (K3's cursor for the
-// instances beyond BIN_SLOTS, which sit behind the tile_count[t] slotted ones).  One workgroup, 8 tiles per lane
-// per round.
+// instances beyond BIN_SLOTS, which sit behind the tile_count[t] slotted ones).  One workgroup; rounds of 8192
+// tiles staged through LDS so that every global access is a coalesced 4-byte-per-lane stream.  Tiles whose list
+// is too long for the one-wave sort are appended to big_list for the workgroup sort.
+constexpr int SCAN_CHUNK = 8192;
+constexpr int SORT_RANK_MAX = 256;    // entries one wave rank-sorts (4 keys per lane)
+constexpr int SORT_WAVE_MAX = 1024;   // entries one wave sorts in LDS (8 KiB)
+constexpr int SORT_WG_MAX = 8192;     // entries one workgroup sorts in LDS (64 KiB)
+
 __global__ void __launch_bounds__(1024) k_scan_tiles(int T, const int32_t *__restrict__ tile_count,
                                                      int32_t *__restrict__ tile_extra,
                                                      int32_t *__restrict__ tile_offsets,
+                                                     int32_t *__restrict__ big_list,
                                                      gsvc_raster_counters *__restrict__ counters,
                                                      long long max_instances)
 {
+    __shared__ int s_v[SCAN_CHUNK];
     __shared__ int wave_sum[16];
     __shared__ int wave_max[16];
+    __shared__ int s_big;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_big = 0;
     int carry = 0, local_max = 0;
-    for (int base = 0; base < T; base += 8192) {
-        int v[8];
-        int sum = 0;
-        const int first = base + tid * 8;
+    for (int base = 0; base < T; base += SCAN_CHUNK) {
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int idx = first + k;
-            v[k] = idx < T ? tile_count[idx] + tile_extra[idx] : 0;
+            const int idx = base + k * 1024 + tid;
+            s_v[k * 1024 + tid] = idx < T ? tile_count[idx] + tile_extra[idx] : 0;
+        }
+        __syncthreads();
+        int v[8];
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            v[k] = s_v[tid * 8 + k];
             local_max = max(local_max, v[k]);
             sum += v[k];
+            if (v[k] > SORT_WAVE_MAX) big_list[atomicAdd(&s_big, 1)] = base + tid * 8 + k;
         }
         int x = sum;  // inclusive wave scan of the per-lane sums
 #pragma unroll
@@ -220,7 +238,6 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int T, const int32_t *__res
             const int y = __shfl_up(x, d, 64);
             if (lane >= d) x += y;
         }
-        __syncthreads();  // previous round's wave_sum readers are done
         if (lane == 63) wave_sum[wave] = x;
         __syncthreads();
         int prefix = carry, total = 0;
@@ -232,14 +249,19 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int T, const int32_t *__res
         int run = prefix + x - sum;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int idx = first + k;
-            if (idx < T) {
-                tile_offsets[idx] = run;
-                tile_extra[idx] = 0;
-            }
+            s_v[tid * 8 + k] = run;
             run += v[k];
         }
         carry += total;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int idx = base + k * 1024 + tid;
+            if (idx < T) {
+                tile_offsets[idx] = s_v[k * 1024 + tid];
+                tile_extra[idx] = 0;
+            }
+        }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) local_max = max(local_max, __shfl_xor(local_max, m, 64));
@@ -252,6 +274,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int T, const int32_t *__res
         counters->num_rendered = carry;
         counters->overflow = ((long long)carry > max_instances) ? 1 : 0;
         counters->max_tile_len = mx;
+        counters->num_big_tiles = s_big;
     }
 }
 
@@ -319,10 +342,6 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *a, int n, int tid)
     }
 }
 
-constexpr int SORT_RANK_MAX = 256;    // entries one wave rank-sorts (4 keys per lane)
-constexpr int SORT_WAVE_MAX = 1024;   // entries one wave sorts in LDS (8 KiB)
-constexpr int SORT_WG_MAX = 8192;     // entries one workgroup sorts in LDS (64 KiB)
-
 // one wave per tile, segments of <= SORT_WAVE_MAX entries
 // every sorted entry gets its Gaussian id (point_list) and that Gaussian's alpha bounding box (inst_bbox), so the
 // blend kernels test 64 entries per wave-instruction without touching the Gaussian records
@@ -378,28 +397,34 @@ __global__ void __launch_bounds__(64) k_sort_tiles_wave(int T, const int32_t *__
     for (int i = lane; i < n; i += 64) emit_entry(beg + i, s[i], geom, point_list, inst_bbox);
 }
 
-// one 256-lane workgroup per tile, segments longer than SORT_WAVE_MAX: LDS up to SORT_WG_MAX, in place in
-// global memory beyond that (correct for any length; such tiles are pathological)
-__global__ void __launch_bounds__(256) k_sort_tiles_wg(int T, const int32_t *__restrict__ tile_offsets,
+// 256-lane workgroups walk the list of tiles longer than SORT_WAVE_MAX (built by K2; usually empty, then every
+// workgroup exits after one load): LDS up to SORT_WG_MAX entries, in place in global memory beyond that
+// (correct for any length; such tiles are pathological)
+__global__ void __launch_bounds__(256) k_sort_tiles_wg(const int32_t *__restrict__ big_list,
+                                                       const int32_t *__restrict__ tile_offsets,
                                                        uint64_t *__restrict__ keys, const GeomRec *__restrict__ geom,
                                                        int32_t *__restrict__ point_list, uint2 *__restrict__ inst_bbox,
                                                        const gsvc_raster_counters *__restrict__ counters)
 {
     extern __shared__ uint64_t sbig[];
-    if (counters->overflow || counters->max_tile_len <= SORT_WAVE_MAX) return;
-    const int t = blockIdx.x, tid = threadIdx.x;
-    const int beg = tile_offsets[t], n = tile_offsets[t + 1] - beg;
-    if (n <= SORT_WAVE_MAX) return;
-    if (n <= SORT_WG_MAX) {
-        for (int i = tid; i < n; i += 256) sbig[i] = keys[beg + i];
+    if (counters->overflow) return;
+    const int nbig = counters->num_big_tiles;
+    const int tid = threadIdx.x;
+    for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
+        const int t = big_list[w];
+        const int beg = tile_offsets[t], n = tile_offsets[t + 1] - beg;
         __syncthreads();
-        bitonic_sort<256>(sbig, n, tid);
-        for (int i = tid; i < n; i += 256) emit_entry(beg + i, sbig[i], geom, point_list, inst_bbox);
-    } else {
-        uint64_t *a = keys + beg;
-        __threadfence_block();
-        bitonic_sort<256>(a, n, tid);  // __syncthreads() orders the workgroup's own global accesses
-        for (int i = tid; i < n; i += 256) emit_entry(beg + i, a[i], geom, point_list, inst_bbox);
+        if (n <= SORT_WG_MAX) {
+            for (int i = tid; i < n; i += 256) sbig[i] = keys[beg + i];
+            __syncthreads();
+            bitonic_sort<256>(sbig, n, tid);
+            for (int i = tid; i < n; i += 256) emit_entry(beg + i, sbig[i], geom, point_list, inst_bbox);
+        } else {
+            uint64_t *a = keys + beg;
+            __threadfence_block();
+            bitonic_sort<256>(a, n, tid);  // __syncthreads() orders the workgroup's own global accesses
+            for (int i = tid; i < n; i += 256) emit_entry(beg + i, a[i], geom, point_list, inst_bbox);
+        }
     }
 }
 
@@ -412,6 +437,15 @@ __device__ __forceinline__ bool bbox_hits(uint2 bb, int qx0, int qy0)
     return !(sext16(bb.x) > qx0 + 7 || sext16(bb.x >> 16) < qx0 || sext16(bb.y) > qy0 + 7 || sext16(bb.y >> 16) < qy0);
 }
 
+constexpr float LOG2E = 1.44269504088896340736f;
+
+// One workgroup per 16x16 tile, one wave per 8x8 quadrant, one pixel per lane, no barriers.
+// (Two pixels per lane with packed v_pk_*_f32 math was measured 30 % SLOWER on MI355X: CDNA4 SIMDs are 32 lanes
+// wide, packed f32 does not raise the FLOP rate, and the coarser 8x16 culling keeps more pairs; the file is built
+// with -fno-slp-vectorize for the same reason.)
+// Survivors of the quadrant test are staged with the conic pre-scaled by log2(e) (and the 1/2 folded in), so the
+// per-pixel work is p = A' dx^2 + C' dy^2 + B' dx dy, G = exp2(-p): 6 mul/fma + one v_exp_f32.  The inner loop
+// is branch-free: selects on SGPR masks instead of EXEC-mask branches.
 __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *__restrict__ tile_offsets,
                                                const int32_t *__restrict__ point_list,
                                                const uint2 *__restrict__ inst_bbox, const GeomRec *__restrict__ geom,
@@ -420,13 +454,12 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
                                                const gsvc_raster_counters *__restrict__ counters)
 {
     // per-wave staging of the entries that survive the quadrant test (no cross-wave sharing, no barriers)
-    __shared__ float4 s_f0[4][64];  // u v A B
-    __shared__ float4 s_f1[4][64];  // C opacity r g
+    __shared__ float4 s_f0[4][64];  // u v A' B'
+    __shared__ float4 s_f1[4][64];  // C' opacity r g
     __shared__ float2 s_f2[4][64];  // b, 1-based list position (as int bits)
     if (counters->overflow) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // wave = one 8x8 quadrant of the 16x16 tile
     const int qx0 = blockIdx.x * TILE + 8 * (wave & 1), qy0 = blockIdx.y * TILE + 8 * (wave >> 1);
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < st.W && py < st.H;
@@ -454,8 +487,9 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
         if (hit) {
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
             const float4 *rec = reinterpret_cast<const float4 *>(geom + id);
-            w_f0[pos] = rec[0];
-            w_f1[pos] = rec[1];
+            const float4 r0 = rec[0], r1 = rec[1];
+            w_f0[pos] = make_float4(r0.x, r0.y, (0.5f * LOG2E) * r0.z, LOG2E * r0.w);
+            w_f1[pos] = make_float4((0.5f * LOG2E) * r1.x, r1.y, r1.z, r1.w);
             w_f2[pos] = make_float2(rec[2].x, __int_as_float(k - beg + 1));
         }
         const int cnt = __popcll(mask);
@@ -463,25 +497,23 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // phase 2: composite the survivors front to back
+#pragma unroll 2
         for (int j = 0; j < cnt; j++) {
             const float4 a = w_f0[j];
             const float4 b = w_f1[j];
             const float2 c = w_f2[j];
             const float dx = a.x - fx, dy = a.y - fy;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            const float alpha = fminf(ALPHA_MAX, b.y * __expf(power));
-            const float test_T = T * (1.0f - alpha);
-            const bool skip = done || (power > 0.0f) || (alpha < ALPHA_MIN);
-            if (!skip) {
-                if (test_T < T_MIN) {
-                    done = true;
-                } else {
-                    const float w = alpha * T;
-                    C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
-                    T = test_T;
-                    last = __float_as_int(c.y);
-                }
-            }
+            const float p = a.z * dx * dx + b.x * dy * dy + a.w * dx * dy;   // = -power * log2(e)
+            const float alpha = fminf(ALPHA_MAX, b.y * __builtin_amdgcn_exp2f(-p));
+            const float test_T = T - alpha * T;
+            const bool keep = !done && !(p < 0.0f) && !(alpha < ALPHA_MIN);
+            const bool stop = keep && (test_T < T_MIN);
+            const bool acc = keep && !stop;
+            done |= stop;
+            const float w = acc ? alpha * T : 0.0f;
+            C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
+            T = acc ? test_T : T;
+            last = acc ? __float_as_int(c.y) : last;
         }
         __builtin_amdgcn_wave_barrier();
         if (__ballot(!done) == 0ull) break;
@@ -578,6 +610,7 @@ extern "C" int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t
     auto *tile_offsets = (int32_t *)(bin + L.off_tile_offsets);
     auto *tile_count = (int32_t *)(bin + L.off_tile_count);
     auto *tile_extra = (int32_t *)(bin + L.off_tile_extra);
+    auto *big_list = (int32_t *)(bin + L.off_big_list);
     auto *keys = (uint64_t *)(bin + L.off_keys);
     auto *point_list = (int32_t *)(bin + L.off_point_list);
     auto *inst_bbox = (uint2 *)(bin + L.off_inst_bbox);
@@ -587,7 +620,7 @@ extern "C" int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t
     auto *n_contrib = (int32_t *)((char *)image_state + L.off_n_contrib);
 
     // counters + tile_offsets + tile_count + tile_extra are contiguous at the head of the blob
-    if (hipMemsetAsync(bin, 0, L.off_keys, s) != hipSuccess) {
+    if (hipMemsetAsync(bin, 0, L.off_big_list, s) != hipSuccess) {
         set_error("raster_forward: hipMemsetAsync failed");
         return GSVC_E_LAUNCH;
     }
@@ -612,7 +645,7 @@ extern "C" int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t
     {
         ProfScope _prof("k_scan_tiles", s);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, L.tiles, tile_count, tile_extra, tile_offsets,
-                           counters, (long long)max_instances);
+                           big_list, counters, (long long)max_instances);
     }
     if (P > 0) {
         {
@@ -627,7 +660,7 @@ extern "C" int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t
         }
         {
             ProfScope _prof("k_sort_tiles_wg", s);
-            hipLaunchKernelGGL(k_sort_tiles_wg, dim3(L.tiles), dim3(256), SORT_WG_MAX * sizeof(uint64_t), s, L.tiles,
+            hipLaunchKernelGGL(k_sort_tiles_wg, dim3(128), dim3(256), SORT_WG_MAX * sizeof(uint64_t), s, big_list,
                                tile_offsets, keys, grec, point_list, inst_bbox, counters);
         }
     }

@@ -113,6 +113,9 @@ class SyntheticFrameCube:
 
     def get_optical_flow(self, idx):
         """Backward flow [2, H, W] (pixels/frame): a smooth field blended from the blob velocities."""
+        key = ("flow", idx)
+        if key in self._cache:
+            return self._cache[key]
         H, W = self.height, self.width
         ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=self.device),
                                 torch.arange(W, dtype=torch.float32, device=self.device), indexing="ij")
@@ -123,4 +126,7 @@ class SyntheticFrameCube:
             g = torch.exp(-((xs - float(cx) % W) ** 2 + (ys - float(cy) % H) ** 2) / (2 * float(self._sig[k]) ** 2))
             num += g[None] * torch.tensor(self._vel[k], dtype=torch.float32, device=self.device)[:, None, None]
             den += g
-        return num / den
+        flow = num / den
+        if len(self._cache) < 64:
+            self._cache[key] = flow
+        return flow

@@ -64,9 +64,10 @@ def calc_sampled_rate(pc, visible_mask, feat, grid_scaling, grid_offsets, Q_feat
     one live offset, scaled by the fraction of such anchors."""
     K = pc.n_offsets
     vis = _as_index(visible_mask)
-    mask_anchor = pc.get_mask_anchor.index_select(0, vis)
+    offset_masks = _visible_mask(pc, vis)
+    with torch.no_grad():
+        mask_anchor = (torch.sum(offset_masks, dim=1)[:, 0]) > 0     # get_mask_anchor restricted to the visible anchors
     keep_rate = (mask_anchor.sum() / mask_anchor.numel()).detach()
-    offset_masks = pc.get_mask.index_select(0, vis)
     # same draw as the reference's rand_like(anchor[:, 0]) (one uniform per visible anchor)
     chosen = (torch.rand_like(feat[:, 0]) <= SAMPLE_RATE) & mask_anchor.to(torch.bool)
     sel = chosen.nonzero(as_tuple=False).squeeze(1)
@@ -84,6 +85,20 @@ def calc_sampled_rate(pc, visible_mask, feat, grid_scaling, grid_offsets, Q_feat
                     bit_per_feat_param=sf / nf * keep_rate,
                     bit_per_scaling_param=ss / ns * keep_rate,
                     bit_per_offsets_param=so / no * keep_rate)
+
+
+def _visible_mask(pc, vis):
+    """pc.get_mask[vis] evaluated on the gathered rows only (same values: the activation is elementwise)."""
+    raw = pc._mask.index_select(0, vis)
+    if pc.decoded_version:
+        return raw
+    s = torch.sigmoid(raw)
+    return ((s > 0.01).float() - s).detach() + s
+
+
+def _visible_scaling(pc, vis):
+    raw = pc._scaling.index_select(0, vis)
+    return raw if pc.decoded_version else 1.0 * pc.scaling_activation(raw)
 
 
 def _as_index(mask_or_index):
@@ -109,8 +124,8 @@ def generate_neural_gaussians(frame, pc, visible_mask=None, mode=GenerateMode.TR
     anchor = all_anchor.index_select(0, vis)
     feat = pc._anchor_feat.index_select(0, vis)
     grid_offsets = pc._offset.index_select(0, vis)
-    grid_scaling = pc.get_scaling.index_select(0, vis)
-    offset_masks = pc.get_mask.index_select(0, vis)
+    grid_scaling = _visible_scaling(pc, vis)
+    offset_masks = _visible_mask(pc, vis)
     rate = RatePack()
     Q_feat, Q_scaling, Q_offsets = BASE_Q_FEAT, BASE_Q_SCALING, BASE_Q_OFFSETS
 

@@ -107,7 +107,7 @@ def _alive_slots(res, n_offsets):
 
 
 def _world_xy(res, keep):
-    rows = res.generated_gaussians.concatenated_all[keep]
+    rows = res.generated_gaussians.concatenated_all.index_select(0, keep.nonzero(as_tuple=False).squeeze(1))
     scaling, anchor, offsets = rows[:, 0:6], rows[:, 6:9], rows[:, 19:22]
     return (anchor + offsets * scaling[:, :3])[:, :2]
 
@@ -129,10 +129,11 @@ def calc_optical_loss_one_frame(render_results1, render_results2, optical_flow, 
     xy2 = _world_xy(render_results2, keep2)
     pix = ((xy1 - torch.tensor([[x_min, y_min]], dtype=xy1.dtype, device=dev)) * scale).round().long()
     ok = (pix[:, 0] >= 0) & (pix[:, 1] >= 0) & (pix[:, 0] < x_pix_max) & (pix[:, 1] < y_pix_max)
-    pix = pix[ok]
+    oki = ok.nonzero(as_tuple=False).squeeze(1)
+    pix = pix.index_select(0, oki)
     flow = optical_flow.permute(2, 1, 0).to(dev)
     uv = flow[pix[:, 0], pix[:, 1], ...] / scale
-    d = xy2[ok] - xy1[ok]
+    d = xy2.index_select(0, oki) - xy1.index_select(0, oki)
     return (d - uv).abs().mean(), pix, d * scale
 
 

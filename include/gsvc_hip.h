@@ -76,12 +76,14 @@ typedef struct gsvc_raster_sizes {
     uint64_t image_bytes;
 } gsvc_raster_sizes;
 
-/* counters written by forward into the first 16 bytes of the binning blob */
+/* counters written by forward into the first 32 bytes of the binning blob */
 typedef struct gsvc_raster_counters {
     int32_t num_rendered; /* sum of tiles touched = instances (true count even when it overflowed) */
     int32_t overflow;     /* 1 when num_rendered > max_instances: image/state are NOT valid, retry bigger */
     int32_t num_visible;  /* Gaussians with radius > 0 */
     int32_t max_tile_len; /* longest per-tile list */
+    int32_t num_big_tiles; /* tiles whose list is sorted by the workgroup kernel (internal) */
+    int32_t reserved[3];
 } gsvc_raster_counters;
 
 int gsvc_raster_sizes_query(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
