@@ -37,15 +37,16 @@ __global__ void __launch_bounds__(256) k_rate_fwd(const float *__restrict__ x, c
                                                   const float *__restrict__ scale, const float *__restrict__ Q,
                                                   float Q_scalar, const float *__restrict__ weight,
                                                   const float *__restrict__ x_lo, const float *__restrict__ x_hi,
-                                                  long long total, int c, float *__restrict__ bits,
+                                                  int bounds_per_row, long long total, int c, float *__restrict__ bits,
                                                   float *__restrict__ bits_sum)
 {
     __shared__ float smem[4];
-    const float lo = x_lo ? *x_lo : -INFINITY, hi = x_hi ? *x_hi : INFINITY;
+    float lo = (x_lo && !bounds_per_row) ? *x_lo : -INFINITY, hi = (x_hi && !bounds_per_row) ? *x_hi : INFINITY;
     float acc = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long row = i / c;
         const float q = Q ? Q[row] : Q_scalar;
+        if (bounds_per_row) { lo = x_lo[row]; hi = x_hi[row]; }
         const float xv = fminf(fmaxf(x[i], lo), hi);
         const float mu = mean[i], inv_sigma = 1.0f / scale[i];
         const float lower = normal_cdf(xv - 0.5f * q, mu, inv_sigma);
@@ -66,18 +67,20 @@ __global__ void __launch_bounds__(256) k_rate_bwd(const float *__restrict__ x, c
                                                   const float *__restrict__ scale, const float *__restrict__ Q,
                                                   float Q_scalar, const float *__restrict__ weight,
                                                   const float *__restrict__ x_lo, const float *__restrict__ x_hi,
-                                                  long long n, int c, const float *__restrict__ gscale_dev,
+                                                  int bounds_per_row, long long n, int c,
+                                                  const float *__restrict__ gscale_dev,
                                                   float *__restrict__ dx, float *__restrict__ dmean,
                                                   float *__restrict__ dscale, float *__restrict__ dQ,
                                                   float *__restrict__ dweight)
 {
-    const float lo = x_lo ? *x_lo : -INFINITY, hi = x_hi ? *x_hi : INFINITY;
+    float lo = (x_lo && !bounds_per_row) ? *x_lo : -INFINITY, hi = (x_hi && !bounds_per_row) ? *x_hi : INFINITY;
     const float gs = gscale_dev ? *gscale_dev : 1.0f;
     const int lane = threadIdx.x & 63;
     const long long wave_global = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
     for (long long row = wave_global; row < n; row += n_waves) {
         const float q = Q ? Q[row] : Q_scalar;
+        if (bounds_per_row) { lo = x_lo[row]; hi = x_hi[row]; }
         float dq_acc = 0.f;
         for (int col = lane; col < c; col += 64) {
             const long long i = row * c + col;
@@ -114,8 +117,8 @@ __global__ void __launch_bounds__(256) k_rate_bwd(const float *__restrict__ x, c
 using namespace gsvc;
 
 extern "C" int gsvc_rate_forward(const float *x, const float *mean, const float *scale, const float *Q, float Q_scalar,
-                                 const float *weight, const float *x_lo, const float *x_hi, int64_t n, int64_t c,
-                                 float *bits, float *bits_sum, void *stream)
+                                 const float *weight, const float *x_lo, const float *x_hi, int32_t bounds_per_row,
+                                 int64_t n, int64_t c, float *bits, float *bits_sum, void *stream)
 {
     GSVC_REQUIRE(n >= 0 && c >= 0 && c < (1 << 30), "rate_forward: bad shape");
     if (n == 0 || c == 0) return GSVC_OK;
@@ -124,13 +127,13 @@ extern "C" int gsvc_rate_forward(const float *x, const float *mean, const float 
     long long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     { ProfScope _prof("k_rate_fwd", (hipStream_t)stream); hipLaunchKernelGGL(k_rate_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, scale, Q, Q_scalar,
-                       weight, x_lo, x_hi, total, (int)c, bits, bits_sum); }
+                       weight, x_lo, x_hi, (int)bounds_per_row, total, (int)c, bits, bits_sum); }
     return check_launch("rate_forward");
 }
 
 extern "C" int gsvc_rate_backward(const float *x, const float *mean, const float *scale, const float *Q, float Q_scalar,
-                                  const float *weight, const float *x_lo, const float *x_hi, int64_t n, int64_t c,
-                                  const float *gscale_dev, float *dx, float *dmean, float *dscale, float *dQ,
+                                  const float *weight, const float *x_lo, const float *x_hi, int32_t bounds_per_row,
+                                  int64_t n, int64_t c, const float *gscale_dev, float *dx, float *dmean, float *dscale, float *dQ,
                                   float *dweight, void *stream)
 {
     GSVC_REQUIRE(n >= 0 && c >= 0 && c < (1 << 30), "rate_backward: bad shape");
@@ -139,6 +142,6 @@ extern "C" int gsvc_rate_backward(const float *x, const float *mean, const float
     long long blocks = (n + 3) / 4;  // 4 waves (rows) per workgroup
     if (blocks > 4096) blocks = 4096;
     { ProfScope _prof("k_rate_bwd", (hipStream_t)stream); hipLaunchKernelGGL(k_rate_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, scale, Q, Q_scalar,
-                       weight, x_lo, x_hi, (long long)n, (int)c, gscale_dev, dx, dmean, dscale, dQ, dweight); }
+                       weight, x_lo, x_hi, (int)bounds_per_row, (long long)n, (int)c, gscale_dev, dx, dmean, dscale, dQ, dweight); }
     return check_launch("rate_backward");
 }

@@ -42,16 +42,17 @@ class _GaussianBits(torch.autograd.Function):
     """bits[n,c] through csrc/rate.hip; Q is a per-row [n] tensor or None (then Q_scalar)."""
 
     @staticmethod
-    def forward(ctx, x, mean, scale, Q_rows, Q_scalar, x_lo, x_hi):
+    def forward(ctx, x, mean, scale, Q_rows, Q_scalar, x_lo, x_hi, per_row=False):
         x, mean, scale = x.contiguous(), mean.contiguous(), scale.contiguous()
         n, c = x.shape
         bits = torch.empty_like(x)
         q = Q_rows.contiguous() if Q_rows is not None else None
         _lib.check(_lib.lib().gsvc_rate_forward(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(q), float(Q_scalar),
-                                                None, _lib.ptr(x_lo), _lib.ptr(x_hi), n, c, _lib.ptr(bits), None,
+                                                None, _lib.ptr(x_lo), _lib.ptr(x_hi), int(per_row), n, c, _lib.ptr(bits), None,
                                                 _lib.current_stream(x.device)), "gsvc_rate_forward")
         ctx.save_for_backward(x, mean, scale, q, x_lo, x_hi)
         ctx.Q_scalar = float(Q_scalar)
+        ctx.per_row = bool(per_row)
         return bits
 
     @staticmethod
@@ -63,10 +64,11 @@ class _GaussianBits(torch.autograd.Function):
         dQ = torch.zeros(n, device=x.device, dtype=x.dtype) if q is not None else None
         # the kernel multiplies by `weight`; feeding dL/dbits as the weight gives the vector-Jacobian product
         _lib.check(_lib.lib().gsvc_rate_backward(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(q), ctx.Q_scalar,
-                                                 _lib.ptr(g), _lib.ptr(x_lo), _lib.ptr(x_hi), n, c, None, _lib.ptr(dx),
+                                                 _lib.ptr(g), _lib.ptr(x_lo), _lib.ptr(x_hi), int(ctx.per_row), n, c, None,
+                                                 _lib.ptr(dx),
                                                  _lib.ptr(dmean), _lib.ptr(dscale), _lib.ptr(dQ), None,
                                                  _lib.current_stream(x.device)), "gsvc_rate_backward")
-        return dx, dmean, dscale, dQ, None, None, None
+        return dx, dmean, dscale, dQ, None, None, None, None
 
 
 class EntropyGaussian(nn.Module):
@@ -74,7 +76,9 @@ class EntropyGaussian(nn.Module):
         super().__init__()
         self.Q = Q
 
-    def forward(self, x, mean, scale, Q=None, x_mean=None, quantized=False):
+    def forward(self, x, mean, scale, Q=None, x_mean=None, quantized=False, row_bounds=None):
+        """``row_bounds=(lo[n], hi[n])`` replaces the clamp bounds computed from x_mean / mean(Q) by one pair per
+        row (used when several renders are batched into one call; each row carries its own render's bounds)."""
         if quantized:
             raise NotImplementedError("quantized=True is only used by the offline codec's bit accounting (out of scope)")
         if Q is None:
@@ -99,7 +103,11 @@ class EntropyGaussian(nn.Module):
         else:
             q_mean = torch.ones(1, device=x.device) * Q
             q_rows, q_scalar = None, float(Q)
-        lo = (x_mean - CLAMP_STEPS * q_mean).detach().reshape(1).float().contiguous()
-        hi = (x_mean + CLAMP_STEPS * q_mean).detach().reshape(1).float().contiguous()
-        bits = _GaussianBits.apply(x2, mean2, scale2, q_rows, q_scalar, lo, hi)
+        if row_bounds is not None:
+            lo = row_bounds[0].detach().reshape(-1).float().contiguous()
+            hi = row_bounds[1].detach().reshape(-1).float().contiguous()
+        else:
+            lo = (x_mean - CLAMP_STEPS * q_mean).detach().reshape(1).float().contiguous()
+            hi = (x_mean + CLAMP_STEPS * q_mean).detach().reshape(1).float().contiguous()
+        bits = _GaussianBits.apply(x2, mean2, scale2, q_rows, q_scalar, lo, hi, row_bounds is not None)
         return bits.view(shape)

@@ -192,3 +192,167 @@ def generate_neural_gaussians(frame, pc, visible_mask=None, mode=GenerateMode.TR
         bit_per_param=rate.bit_per_param, bit_per_feat_param=rate.bit_per_feat_param,
         bit_per_scaling_param=rate.bit_per_scaling_param, bit_per_offsets_param=rate.bit_per_offsets_param,
         concatenated_all=concatenated_all, time_sub=time_sub)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Batched generation: the fitting step renders 4 views per step (2 adjacent frames x 2 opposite views).  Their
+# anchor -> Gaussian generation is the same arithmetic on different rows, so the rows of all R renders are
+# concatenated and every MLP / grid / rate / elementwise op runs once on the batch (4x fewer launches, 4x larger
+# GEMMs) instead of once per render.  Per-render statistics the reference takes over one render's visible set
+# (clamp bounds from the visible mean, sampled-rate means, keep rate) are taken per segment, so each render's
+# values are what a stand-alone `generate_neural_gaussians` call computes; only the order of the random draws
+# differs (one draw over the batch instead of R draws).
+class _Segments:
+    def __init__(self, counts, device):
+        self.counts = [int(c) for c in counts]
+        self.R = len(self.counts)
+        self.bounds = [0]
+        for c in self.counts:
+            self.bounds.append(self.bounds[-1] + c)
+        self.rows = self.bounds[-1]
+        self.counts_t = torch.tensor(self.counts, device=device)
+        self.seg_id = torch.repeat_interleave(torch.arange(self.R, device=device), self.counts_t)
+
+    def mean(self, x):
+        """Per-segment mean of x over all trailing dims, returned per row ([rows] + [1]*(x.dim()-1))."""
+        flat = x.reshape(x.shape[0], -1)
+        sums = torch.zeros(self.R, device=x.device, dtype=x.dtype).index_add_(0, self.seg_id, flat.sum(dim=1))
+        means = sums / (self.counts_t.to(x.dtype) * flat.shape[1]).clamp_min(1)
+        return means.index_select(0, self.seg_id).view([-1] + [1] * (x.dim() - 1))
+
+    def slices(self, per_row=1):
+        return [slice(self.bounds[r] * per_row, self.bounds[r + 1] * per_row) for r in range(self.R)]
+
+
+def _seg_bounds(x, Q, seg, x_mean=None):
+    """centre -+ 15000 steps per row, centre = mean(x)/mean(Q) of the row's render (encodings.py:398-409,434-447)."""
+    xm = seg.mean(x) if x_mean is None else x_mean
+    qm = seg.mean(Q).view([-1] + [1] * (x.dim() - 1)) if isinstance(Q, torch.Tensor) else Q
+    centre = (xm / qm).detach()
+    return centre - 15_000, centre + 15_000
+
+
+def _seg_noise_quant(x, Q, seg):
+    lo, hi = _seg_bounds(x, Q, seg)
+    x = torch.clamp(x / Q, min=lo, max=hi) * Q
+    return x + torch.empty_like(x).uniform_(-0.5, 0.5) * Q
+
+
+def _seg_ste(x, Q, seg, x_mean):
+    lo, hi = _seg_bounds(x, Q, seg, x_mean)
+    x = torch.clamp(x / Q, min=torch.trunc(lo), max=torch.trunc(hi)) * Q
+    return (x + (torch.round(x / Q) * Q - x).detach()).detach()
+
+
+def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec):
+    K = pc.n_offsets
+    with torch.no_grad():
+        mask_anchor = (torch.sum(offset_masks, dim=1)[:, 0]) > 0
+        keep_rate = seg.mean(mask_anchor.float().unsqueeze(1)).view(-1)          # per row, constant per render
+        chosen = (torch.rand_like(feat[:, 0]) <= SAMPLE_RATE) & mask_anchor
+        sel = chosen.nonzero(as_tuple=False).squeeze(1)
+        sel_seg = seg.seg_id.index_select(0, sel)
+        n_sel = torch.zeros(seg.R, device=feat.device).index_add_(0, sel_seg, torch.ones_like(sel_seg, dtype=torch.float32))
+    take = lambda t: t.index_select(0, sel)  # noqa: E731
+
+    def seg_mean_sel(q):   # mean of the chosen rows' Q per render, per chosen row
+        s = torch.zeros(seg.R, device=q.device).index_add_(0, sel_seg, q.detach().view(-1))
+        return (s / n_sel.clamp_min(1)).index_select(0, sel_seg)
+
+    def bits_of(x, mean, scale, Q, x_mean):
+        q = take(Q)
+        qm = seg_mean_sel(q)
+        lo, hi = x_mean.detach() - 15_000 * qm, x_mean.detach() + 15_000 * qm
+        return pc.entropy_gaussian(take(x), take(mean), take(scale), q, x_mean, row_bounds=(lo, hi))
+
+    bit_feat = bits_of(feat, ec.mean_feat, ec.scale_feat, Q_feat, pc._anchor_feat.mean())
+    bit_scaling = bits_of(grid_scaling, ec.mean_scaling, ec.scale_scaling, Q_scaling, pc.get_scaling.mean())
+    bit_offsets = bits_of(grid_offsets.view(-1, 3 * K), ec.mean_offsets, ec.scale_offsets, Q_offsets, pc._offset.mean())
+    bit_offsets = bit_offsets * take(offset_masks).repeat(1, 1, 3).view(-1, 3 * K)
+
+    def seg_sum(b):
+        return torch.zeros(seg.R, device=b.device, dtype=b.dtype).index_add_(0, sel_seg, b.sum(dim=1))
+
+    sf, ss, so = seg_sum(bit_feat), seg_sum(bit_scaling), seg_sum(bit_offsets)
+    nf, ns, no = n_sel * bit_feat.shape[1], n_sel * bit_scaling.shape[1], n_sel * bit_offsets.shape[1]
+    kr = torch.stack([keep_rate[seg.bounds[r]] if seg.counts[r] else keep_rate.new_zeros(()) for r in range(seg.R)])
+    return [RatePack(bit_per_param=((sf + ss + so) / (nf + ns + no) * kr)[r], bit_per_feat_param=(sf / nf * kr)[r],
+                     bit_per_scaling_param=(ss / ns * kr)[r], bit_per_offsets_param=(so / no * kr)[r]) for r in range(seg.R)]
+
+
+def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.TRAINING_FULL_PRECISION):
+    """`generate_neural_gaussians` for R renders at once; returns a list of R GeneratedGaussians."""
+    R = len(frames)
+    K = pc.n_offsets
+    vis_list = [_as_index(m) for m in visible_masks]
+    dev = vis_list[0].device
+    seg = _Segments([v.shape[0] for v in vis_list], dev)
+    vis = torch.cat(vis_list)
+    anchor = pc.get_anchor.index_select(0, vis)
+    feat = pc._anchor_feat.index_select(0, vis)
+    grid_offsets = pc._offset.index_select(0, vis)
+    grid_scaling = _visible_scaling(pc, vis)
+    offset_masks = _visible_mask(pc, vis)
+    rates = [RatePack() for _ in range(R)]
+    Q_feat, Q_scaling, Q_offsets = BASE_Q_FEAT, BASE_Q_SCALING, BASE_Q_OFFSETS
+    time_sub = 0
+
+    if mode in (GenerateMode.TRAINING_FULL_PRECISION, GenerateMode.DECODING_AS_IS):
+        pass
+    elif mode == GenerateMode.TRAINING_QUANTIZED:
+        feat = _seg_noise_quant(feat, Q_feat, seg)
+        grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
+        grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets, seg)
+    elif mode == GenerateMode.TRAINING_ENTROPY:
+        ec = pc.calc_entropy_context(anchor)
+        Q_feat, Q_scaling, Q_offsets = Q_feat * ec.Q_feat_adj, Q_scaling * ec.Q_scaling_adj, Q_offsets * ec.Q_offsets_adj
+        feat = _seg_noise_quant(feat, Q_feat, seg)
+        grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
+        grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets.unsqueeze(1), seg)
+        rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec)
+    elif mode == GenerateMode.TRAININ_STE_ENTROPY:
+        ec = pc.calc_entropy_context(anchor)
+        Q_feat, Q_scaling, Q_offsets = (Q_feat * ec.Q_feat_adj.detach(), Q_scaling * ec.Q_scaling_adj.detach(),
+                                        Q_offsets * ec.Q_offsets_adj.detach())
+        feat = _seg_ste(feat, Q_feat, seg, pc._anchor_feat.mean())
+        grid_scaling = _seg_ste(grid_scaling, Q_scaling, seg, pc.get_scaling.mean())
+        grid_offsets = _seg_ste(grid_offsets, Q_offsets.unsqueeze(1), seg, pc._offset.mean())
+        rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec)
+    else:
+        raise ValueError(f"Unknown mode {mode}")
+
+    cam_z = torch.tensor([float(f.cam_pos[-1]) for f in frames], device=dev, dtype=anchor.dtype)
+    cam_z_row = cam_z.index_select(0, seg.seg_id).unsqueeze(1)
+    ob_view = anchor[:, 2:] - cam_z_row
+    pe = torch.cat([pc.embed_time_fn(cam_z_row), pc.embed_fn(ob_view)], dim=1)
+
+    rows = seg.rows
+    neural_opacity = pc.get_opacity_mlp(feat, pe).reshape(-1, 1) * offset_masks.view(-1, 1)
+    mask = (neural_opacity > 0.0).view(-1)
+    color = pc.get_color_mlp(feat, pe).reshape(rows * K, 3)
+    scale_rot = pc.get_cov_mlp(feat, pe).reshape(rows * K, 7)
+    neural_offset = pc.get_deform_mlp(torch.cat([feat, pe], dim=1)).reshape(rows * K, 3)
+    offsets = grid_offsets.view(-1, 3) + neural_offset
+    per_anchor = torch.cat([grid_scaling, anchor], dim=-1)
+    concatenated_all = torch.cat([per_anchor.repeat_interleave(K, dim=0), color, scale_rot, offsets], dim=-1)
+    alive_idx = mask.nonzero(as_tuple=False).squeeze(1)
+    alive = concatenated_all.index_select(0, alive_idx)
+    scaling_rep, anchor_rep = alive[:, 0:6], alive[:, 6:9]
+    color_a, scale_rot_a, offsets_a = alive[:, 9:12], alive[:, 12:19], alive[:, 19:22]
+    scaling = scaling_rep[:, 3:] * torch.sigmoid(scale_rot_a[:, :3])
+    rot = pc.rotation_activation(scale_rot_a[:, 3:7])
+    xyz = torch.clamp(anchor_rep + offsets_a * scaling_rep[:, :3], pc.x_bound_min, pc.x_bound_max)
+    opacity = neural_opacity.index_select(0, alive_idx)
+    # split the compacted Gaussians back into the R renders (one host read of R+1 offsets)
+    edges = torch.tensor([b * K for b in seg.bounds], device=dev)
+    cut = torch.searchsorted(alive_idx, edges).tolist()
+    out = []
+    for r, (rs, gs) in enumerate(zip(seg.slices(), seg.slices(K))):
+        a = slice(cut[r], cut[r + 1])
+        out.append(GeneratedGaussians(
+            xyz=xyz[a], color=color_a[a], opacity=opacity[a], scaling=scaling[a], rot=rot[a],
+            neural_opacity=neural_opacity[gs], visable_mask=visible_masks[r], mask=mask[gs],
+            bit_per_param=rates[r].bit_per_param, bit_per_feat_param=rates[r].bit_per_feat_param,
+            bit_per_scaling_param=rates[r].bit_per_scaling_param, bit_per_offsets_param=rates[r].bit_per_offsets_param,
+            concatenated_all=concatenated_all[gs], time_sub=time_sub))
+    return out

@@ -7,7 +7,7 @@ from __future__ import annotations
 import torch
 
 from ..common.base import RenderResults
-from ..generate import GenerateMode, generate_neural_gaussians
+from ..generate import GenerateMode, generate_neural_gaussians, generate_neural_gaussians_many
 from ..rasterizer import GaussianRasterizer
 from .preprocess import prefilter_voxel, raster_settings_for
 
@@ -34,3 +34,32 @@ def render(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain
         bit_per_param=gss.bit_per_param, bit_per_feat_param=gss.bit_per_feat_param,
         bit_per_scaling_param=gss.bit_per_scaling_param, bit_per_offsets_param=gss.bit_per_offsets_param,
         entropy_constrained=(gss.bit_per_param is not None), generated_gaussians=gss, time_sub=gss.time_sub)
+
+
+def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain_grad=False,
+                mode=GenerateMode.TRAINING_FULL_PRECISION):
+    """`render` for several frames/views of one step: the anchor -> Gaussian generation of all of them runs as
+    one batch (gsvc_amd.generate.generate_neural_gaussians_many), then each view is rasterized.  Returns a list
+    of RenderResults with the same fields `render` fills."""
+    visible = [prefilter_voxel(f, pc, pipe, bg_color) for f in frames]
+    gss_list = generate_neural_gaussians_many(frames, pc, visible, mode)
+    results = []
+    for frame, visible_mask, gss in zip(frames, visible, gss_list):
+        screenspace_points = torch.zeros_like(gss.xyz, dtype=pc.get_anchor.dtype, requires_grad=True) + 0
+        if retain_grad:
+            try:
+                screenspace_points.retain_grad()
+            except Exception:
+                pass
+        rasterizer = GaussianRasterizer(raster_settings=raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier))
+        rendered_image, radii, num_rendered = rasterizer(
+            means3D=gss.xyz, means2D=screenspace_points, shs=None, colors_precomp=gss.color, opacities=gss.opacity,
+            scales=gss.scaling, rotations=gss.rot, cov3D_precomp=None)
+        results.append(RenderResults(
+            rendered_image=rendered_image, viewspace_points=screenspace_points, visibility_filter=radii > 0,
+            visible_mask=visible_mask, radii=radii, active_gaussains=(radii > 0).sum(), num_rendered=num_rendered,
+            selection_mask=gss.mask, neural_opacity=gss.neural_opacity, scaling=gss.scaling,
+            bit_per_param=gss.bit_per_param, bit_per_feat_param=gss.bit_per_feat_param,
+            bit_per_scaling_param=gss.bit_per_scaling_param, bit_per_offsets_param=gss.bit_per_offsets_param,
+            entropy_constrained=(gss.bit_per_param is not None), generated_gaussians=gss, time_sub=gss.time_sub))
+    return results

@@ -19,7 +19,7 @@ from . import dist as gdist
 from .encodings import get_binary_vxl_size
 from .generate import GenerateMode
 from .loss_utils import calc_optical_loss, ssim_l1
-from .ortho_gaussian_renderer import render
+from .ortho_gaussian_renderer import render, render_many
 from .train_util import TrainingController
 
 
@@ -46,7 +46,8 @@ def get_binary_vxl_size_device(binary_vxl):
 
 
 class Trainer:
-    def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0):
+    def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0, batched: bool = True):
+        self.batched = batched
         self.pc, self.dataset, self.opt, self.pipe, self.mp = gaussians, dataset, opt, pipe, model_params
         self.controller = TrainingController(opt)
         self.controller.step()  # iterations are 1-based
@@ -72,8 +73,20 @@ class Trainer:
         mode = self.controller.render_mode
         retain_grad = opt.update_until > iteration >= 0
 
-        r1f, r1b, image1 = self._two_views(frame1, mode, retain_grad)
-        r2f, r2b, image2 = self._two_views(frame2, mode, retain_grad)
+        if self.batched:
+            # one generation pass for the 4 views (frame1 f/b, frame2 f/b), then 4 rasterizations
+            import copy
+            views = []
+            for fr in (frame1, frame2):
+                back = copy.copy(fr)
+                back.view_matrix, back.view_matrix_s = fr.view_matrix_s, fr.view_matrix
+                views += [fr, back]
+            r1f, r1b, r2f, r2b = render_many(views, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode)
+            image1 = (r1f.rendered_image + torch.flip(r1b.rendered_image, dims=(-1,))) / 2
+            image2 = (r2f.rendered_image + torch.flip(r2b.rendered_image, dims=(-1,))) / 2
+        else:
+            r1f, r1b, image1 = self._two_views(frame1, mode, retain_grad)
+            r2f, r2b, image2 = self._two_views(frame2, mode, retain_grad)
         renders = (r1f, r1b, r2f, r2b)
         gt1 = frame1.image.to(dev).permute(0, 2, 1)
         gt2 = frame2.image.to(dev).permute(0, 2, 1)

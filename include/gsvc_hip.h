@@ -143,19 +143,20 @@ int gsvc_grid_backward(const float *grad, const float *inputs, const float *embe
 
 /* bits[n,c] = -log2(max(Phi((x+Q/2-mu)/sigma) - Phi((x-Q/2-mu)/sigma), 2^-16)) with x clamped to
  * [x_lo, x_hi] first (the caller computes x_mean -/+ 15000*mean(Q), reference entropy_models.py:40-47;
- * pass -inf/+inf to disable).  x, mean, scale: [n,c];  Q: [n] (per row) or NULL with Q_scalar.
+ * NULL disables; device scalars, or one pair per row [n] when bounds_per_row != 0 — used when several renders
+ * are batched into one call).  x, mean, scale: [n,c];  Q: [n] (per row) or NULL with Q_scalar.
  * row_weight: [n,c] multiplier folded into the sum (the offsets mask) or NULL.
  * Outputs: bits[n,c] (may be NULL) and bits_sum[1] (double precision accumulate, float result, ADDED to). */
 int gsvc_rate_forward(const float *x, const float *mean, const float *scale, const float *Q, float Q_scalar,
-                      const float *weight, const float *x_lo, const float *x_hi, int64_t n, int64_t c,
-                      float *bits, float *bits_sum, void *stream);
+                      const float *weight, const float *x_lo, const float *x_hi, int32_t bounds_per_row, int64_t n,
+                      int64_t c, float *bits, float *bits_sum, void *stream);
 
 /* d(sum(weight*bits)*gscale)/d{x, mean, scale, Q[n], weight}; any output pointer may be NULL.
  * Low_bound rule: gradient passes only where the likelihood >= 2^-16 (reference entropy_models.py:166-175,
  * net effect). gscale_dev: device scalar multiplying every gradient (dL/d bits_sum). dQ[n] is accumulated. */
 int gsvc_rate_backward(const float *x, const float *mean, const float *scale, const float *Q, float Q_scalar,
-                       const float *weight, const float *x_lo, const float *x_hi, int64_t n, int64_t c,
-                       const float *gscale_dev, float *dx, float *dmean, float *dscale, float *dQ, float *dweight,
+                       const float *weight, const float *x_lo, const float *x_hi, int32_t bounds_per_row, int64_t n,
+                       int64_t c, const float *gscale_dev, float *dx, float *dmean, float *dscale, float *dQ, float *dweight,
                        void *stream);
 
 /* ------------------------------------------------------------------------------------------------------

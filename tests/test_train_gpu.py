@@ -73,3 +73,45 @@ def test_averaged_image_is_view_symmetric():
     avg2 = (b + torch.flip(f, dims=(-1,))) / 2
     assert torch.allclose(avg1, torch.flip(avg2, dims=(-1,)), atol=1e-6)
     assert (f - torch.flip(b, dims=(-1,))).abs().max() < 0.5   # same Gaussians at the same pixels, reversed depth order
+
+
+def test_batched_generation_equals_per_render():
+    """render_many (one generation pass for the 4 views of a step) returns what 4 render() calls return in the
+    deterministic mode; in the entropy mode the per-render statistics (rate, masks) agree up to the different
+    noise draws (checked on the noise-free pieces: visible sets, rate of a zero-noise replay)."""
+    import copy
+    from gsvc_amd.generate import GenerateMode
+    from gsvc_amd.ortho_gaussian_renderer import render, render_many
+    pc, cube, opt, pipe, mp, _ = _setup(anchors=4000)
+    bg = torch.zeros(3)
+    frames = []
+    for idx in (4, 5):
+        fr = cube[idx]
+        back = copy.copy(fr)
+        back.view_matrix, back.view_matrix_s = fr.view_matrix_s, fr.view_matrix
+        frames += [fr, back]
+    with torch.no_grad():
+        many = render_many(frames, pc, pipe, bg, mode=GenerateMode.TRAINING_FULL_PRECISION)
+        single = [render(f, pc, pipe, bg, mode=GenerateMode.TRAINING_FULL_PRECISION) for f in frames]
+    for a, b in zip(many, single):
+        assert torch.equal(a.visible_mask, b.visible_mask) and torch.equal(a.selection_mask, b.selection_mask)
+        assert a.num_rendered == b.num_rendered and torch.equal(a.radii, b.radii)
+        assert torch.allclose(a.rendered_image, b.rendered_image, atol=2e-5)
+        assert torch.allclose(a.neural_opacity, b.neural_opacity, atol=1e-5)
+        assert torch.allclose(a.generated_gaussians.concatenated_all, b.generated_gaussians.concatenated_all, atol=1e-5)
+    # entropy mode with the noise replaced by zeros and every anchor sampled: per-render rates must agree
+    import gsvc_amd.generate as G
+    old_rate, old_uniform, old_rand = G.SAMPLE_RATE, torch.Tensor.uniform_, torch.rand_like
+    try:
+        G.SAMPLE_RATE = 2.0
+        torch.Tensor.uniform_ = lambda t, *a, **k: t.zero_()
+        torch.rand_like = lambda x, *a, **k: torch.zeros_like(x)
+        with torch.no_grad():
+            many = render_many(frames, pc, pipe, bg, mode=GenerateMode.TRAINING_ENTROPY)
+            single = [render(f, pc, pipe, bg, mode=GenerateMode.TRAINING_ENTROPY) for f in frames]
+    finally:
+        G.SAMPLE_RATE, torch.Tensor.uniform_, torch.rand_like = old_rate, old_uniform, old_rand
+    for a, b in zip(many, single):
+        for nm in ("bit_per_param", "bit_per_feat_param", "bit_per_scaling_param", "bit_per_offsets_param"):
+            assert abs(float(getattr(a, nm)) - float(getattr(b, nm))) < 1e-4 * max(1.0, abs(float(getattr(b, nm)))), nm
+        assert torch.allclose(a.rendered_image, b.rendered_image, atol=2e-5)
