@@ -61,15 +61,71 @@ class Mix3d2dEncoding(nn.Module):
         return torch.cat([self.encoding_xyz(x), self.encoding_xy(xy), self.encoding_xz(xz), self.encoding_yz(yz)], dim=-1)
 
 
+class _LinearMFMA(torch.autograd.Function):
+    """y = x W^T + b through csrc/linear.hip (tall-skinny fp32 MFMA); backward with the library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import _lib
+        x, w = x.contiguous(), weight.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        b = bias.contiguous() if bias is not None else None
+        _lib.check(_lib.lib().gsvc_linear_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, K, N,
+                                                  _lib.current_stream(x.device)), "gsvc_linear_forward")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        L, st = _lib.lib(), _lib.current_stream(x.device)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if K <= 192:      # dX = G W = linear(G, W^T)
+                gx = torch.empty(M, K, device=x.device, dtype=torch.float32)
+                wt = w.t().contiguous()
+                _lib.check(L.gsvc_linear_forward(_lib.ptr(g), _lib.ptr(wt), None, _lib.ptr(gx), M, N, K, st), "gsvc_linear_forward")
+            else:
+                gx = g @ w
+        if ctx.needs_input_grad[1]:
+            if K <= 192:
+                gw = torch.zeros(N, K, device=x.device, dtype=torch.float32)
+                _lib.check(L.gsvc_linear_wgrad(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gw), M, N, K, st), "gsvc_linear_wgrad")
+            else:
+                gw = g.t() @ x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(dim=0)
+        return gx, gw, gb
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose forward on a tall CUDA matrix runs on the MFMA kernel."""
+
+    MIN_ROWS = 4096
+
+    def forward(self, x):
+        if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= self.MIN_ROWS
+                and self.out_features <= 192):
+            return _LinearMFMA.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class FiLM(nn.Module):
     """gamma(cond) * x + beta(cond), both from 2-layer ReLU MLPs."""
 
     def __init__(self, condition_dim, input_dim):
         super().__init__()
-        self.fc_gamma0 = nn.Linear(condition_dim, condition_dim)
-        self.fc_beta0 = nn.Linear(condition_dim, condition_dim)
-        self.fc_gamma1 = nn.Linear(condition_dim, input_dim)
-        self.fc_beta1 = nn.Linear(condition_dim, input_dim)
+        self.fc_gamma0 = Linear(condition_dim, condition_dim)
+        self.fc_beta0 = Linear(condition_dim, condition_dim)
+        self.fc_gamma1 = Linear(condition_dim, input_dim)
+        self.fc_beta1 = Linear(condition_dim, input_dim)
         self.act = nn.ReLU()
 
     def forward(self, x, condition):
@@ -81,10 +137,10 @@ class FiLM(nn.Module):
 class GeneratorNet(nn.Module):
     def __init__(self, input_dim, output_dim, inner_dim, condition_dim, out_act=None):
         super().__init__()
-        self.linear1 = nn.Linear(input_dim, inner_dim)
-        self.linear2 = nn.Linear(inner_dim, inner_dim)
+        self.linear1 = Linear(input_dim, inner_dim)
+        self.linear2 = Linear(inner_dim, inner_dim)
         self.act = nn.GELU()
-        self.out_linear = nn.Linear(inner_dim, output_dim)
+        self.out_linear = Linear(inner_dim, output_dim)
         self.film = FiLM(condition_dim, inner_dim)
         self.out_act = nn.Identity() if out_act is None else out_act
 
@@ -97,12 +153,12 @@ class EntropyParamsNet(nn.Module):
     def __init__(self, input_dim, inner_dim, inner_dim2, output_dim, layer=2):
         super().__init__()
         if layer == 2:
-            self.dist_net = nn.Sequential(nn.Linear(input_dim, inner_dim), nn.GELU(), nn.Linear(inner_dim, output_dim * 2))
+            self.dist_net = nn.Sequential(Linear(input_dim, inner_dim), nn.GELU(), Linear(inner_dim, output_dim * 2))
         else:
             assert layer == 3
-            self.dist_net = nn.Sequential(nn.Linear(input_dim, inner_dim), nn.GELU(), nn.Linear(inner_dim, inner_dim),
-                                          nn.GELU(), nn.Linear(inner_dim, output_dim * 2))
-        self.quant_step_net = nn.Sequential(nn.Linear(input_dim, inner_dim2), nn.GELU(), nn.Linear(inner_dim2, 1))
+            self.dist_net = nn.Sequential(Linear(input_dim, inner_dim), nn.GELU(), Linear(inner_dim, inner_dim),
+                                          nn.GELU(), Linear(inner_dim, output_dim * 2))
+        self.quant_step_net = nn.Sequential(Linear(input_dim, inner_dim2), nn.GELU(), Linear(inner_dim2, 1))
 
     def forward(self, x):
         params = self.dist_net(x)
@@ -193,8 +249,8 @@ class GaussianModel(nn.Module):
         self.mlp_cov = GeneratorNet(feat_dim, 7 * n_offsets, inner, cond)
         self.mlp_color = GeneratorNet(feat_dim, 3 * n_offsets, inner, cond, out_act=nn.Sigmoid())
         self.mlp_deform = nn.Sequential(
-            nn.Linear(feat_dim + cond, inner), nn.GELU(), nn.Linear(inner, inner), nn.GELU(),
-            nn.Linear(inner, inner), nn.GELU(), nn.Linear(inner, inner), nn.GELU(), nn.Linear(inner, 3 * n_offsets))
+            Linear(feat_dim + cond, inner), nn.GELU(), Linear(inner, inner), nn.GELU(),
+            Linear(inner, inner), nn.GELU(), Linear(inner, inner), nn.GELU(), Linear(inner, 3 * n_offsets))
         gdim = self.encoding_xyz.output_dim
         self.mlp_feature_enet = EntropyParamsNet(gdim, feat_dim * 3, feat_dim, feat_dim)
         self.mlp_scaling_enet = EntropyParamsNet(gdim, feat_dim * 2, feat_dim, 6, layer=3)

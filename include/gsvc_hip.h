@@ -175,6 +175,19 @@ int gsvc_ssim_l1_backward(const float *img1, const float *img2, int32_t C, int32
                           const float *dm_dmu1, const float *dm_de11, const float *dm_de12, float *dL_dimg1,
                           void *stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Linear layers of the generator / deformation / entropy-parameter MLPs (reference scene/gaussian_model.py:
+ * 150-232: every nn.Linear applied to the [anchors, features] matrix)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Y[M,N] = X[M,K] W[N,K]^T + bias[N] (bias may be NULL); fp32 MFMA, N <= 192.  torch.nn.Linear layout. */
+int gsvc_linear_forward(const float *X, const float *W, const float *bias, float *Y, int64_t M, int32_t K, int32_t N,
+                        void *stream);
+
+/* dW[N,K] += G[M,N]^T X[M,K] (weight gradient; dW is accumulated into with float atomics, caller zero-fills).
+ * N, K <= 192.  The input gradient dX = G W is gsvc_linear_forward(G, W^T, NULL, dX, M, N, K). */
+int gsvc_linear_wgrad(const float *G, const float *X, float *dW, int64_t M, int32_t N, int32_t K, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -322,3 +322,30 @@ def test_fused_ssim_l1_matches_torch_and_reference(H, W):
         assert abs(float(LU.ssim_func(a.detach(), b)) - float(g["ssim"])) < 2e-6
         per = LU.ssim_func(a.detach().unsqueeze(0), b.unsqueeze(0), size_average=False)
         assert np.abs(per.cpu().numpy() - g["ssim_per"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("M,K,N", [(5000, 50, 100), (4097, 116, 100), (8192, 192, 150), (4096, 100, 10), (6000, 66, 66),
+                                    (4500, 50, 1), (4096, 8, 16), (70000, 100, 70)])
+def test_mfma_linear_matches_torch(M, K, N):
+    """csrc/linear.hip (fp32 MFMA, tall-skinny) vs torch.nn.functional.linear in fp32 on the same GPU: fp32
+    products and accumulation on both sides, only the summation order differs -> 1e-5 relative to the row scale."""
+    import torch.nn.functional as F
+    from gsvc_amd.model import Linear
+    gen = torch.Generator().manual_seed(M + K + N)
+    lin = Linear(K, N).cuda()
+    x = torch.randn(M, K, generator=gen).cuda().requires_grad_(True)
+    y = lin(x)
+    ref = F.linear(x, lin.weight, lin.bias)
+    scale = ref.abs().max().item()
+    assert (y - ref).abs().max().item() < 1e-5 * max(1.0, scale) * (K ** 0.5)
+    g = torch.randn(M, N, generator=gen).cuda()
+    (y * g).sum().backward()
+    gx, gw, gb = x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()
+    x.grad = None
+    lin.zero_grad()
+    (F.linear(x, lin.weight, lin.bias) * g).sum().backward()
+    assert torch.allclose(gx, x.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(gw, lin.weight.grad, rtol=1e-3, atol=1e-3 * lin.weight.grad.abs().max().item())
+    assert torch.allclose(gb, lin.bias.grad, rtol=1e-3, atol=1e-3 * lin.bias.grad.abs().max().item())
+    # small batches and CPU tensors keep the library path
+    assert torch.equal(lin(x[:10]), F.linear(x[:10], lin.weight, lin.bias))

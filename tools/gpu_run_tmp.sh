@@ -1,2 +1,3 @@
-python -m pytest tests/test_grid_rate_gpu.py tests/test_train_gpu.py -q -m gpu --tb=short -x 2>&1 | tail -12 | cut -c1-250
-python bench.py --workload train_step --steps 8 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['gsvc_kernel_us_per_step'])"
+python bench.py 2>&1 | tail -1 > gpurun_out/bench_headline.json; python -c "
+import json; d=json.load(open('gpurun_out/bench_headline.json')); 
+print(d['value'], d['ms_per_step'], d['render_fps'], d['roofline']); print(d['cpu_baseline']); print({k:v for k,v in d['train_step'].items() if k not in ('kernels','config')})"
