@@ -15,7 +15,7 @@
 //   K3 scatter      one lane per Gaussian: writes (depth_bits<<32 | id) at tile_offsets[tile] + slot.  No atomics
 //                   (Gaussians touching more than BIN_SLOTS tiles use a per-tile cursor for the remainder).
 //   K4 sort_tiles   one WAVE per tile: rank sort in LDS (<=256 entries: every key is compared with every
-//                   other, no barriers), bitonic in LDS (<=1024); one workgroup per tile beyond that.
+//                   other, no barriers), bitonic in LDS (<=1024); whole workgroups for the rare longer lists.
 //                   Orders each segment by (depth, id) -> point_list.  No device-wide radix sort: segments
 //                   are independent, depth ordering is a wavefront-local problem, and the tile boundaries
 //                   come for free from the scan.
@@ -199,7 +199,6 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
 constexpr int SCAN_CHUNK = 8192;
 constexpr int SORT_RANK_MAX = 256;    // entries one wave rank-sorts (4 keys per lane)
 constexpr int SORT_WAVE_MAX = 1024;   // entries one wave sorts in LDS (8 KiB)
-constexpr int SORT_WG_MAX = 8192;     // entries one workgroup sorts in LDS (64 KiB)
 
 __global__ void __launch_bounds__(1024) k_scan_tiles(int T, const int32_t *__restrict__ tile_count,
                                                      int32_t *__restrict__ tile_extra,
@@ -294,18 +293,24 @@ __global__ void __launch_bounds__(256) k_scatter(int P, int gx, const BinRec *__
     const int4 sl = reinterpret_cast<const int4 *>(bins + i)[1];
     const int x0 = rx & 0xffff, x1 = rx >> 16, y0 = ry & 0xffff, y1 = ry >> 16;
     const uint64_t key = ((uint64_t)order_bits(b0.x) << 32) | (uint32_t)i;
-    int j = 0;
-    for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++, j++) {
-            const int t = ty * gx + tx;
-            int slot;
-            if (j == 0) slot = sl.x;
-            else if (j == 1) slot = sl.y;
-            else if (j == 2) slot = sl.z;
-            else if (j == 3) slot = sl.w;
-            else slot = tile_count[t] + atomicAdd(&tile_extra[t], 1);
-            keys[tile_offsets[t] + slot] = key;
-        }
+    const int w = x1 - x0, ntiles = w * (y1 - y0);
+    // first BIN_SLOTS tiles: the four segment offsets are fetched together (independent loads), then stored
+    int tl[BIN_SLOTS], off[BIN_SLOTS];
+    const int slots[BIN_SLOTS] = {sl.x, sl.y, sl.z, sl.w};
+#pragma unroll
+    for (int j = 0; j < BIN_SLOTS; j++) {
+        const int jy = j / w, jx = j - jy * w;     // row-major walk of the rectangle, as in K1
+        tl[j] = (y0 + jy) * gx + x0 + jx;
+        off[j] = j < ntiles ? tile_offsets[tl[j]] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < BIN_SLOTS; j++)
+        if (j < ntiles) keys[off[j] + slots[j]] = key;
+    for (int j = BIN_SLOTS; j < ntiles; j++) {
+        const int jy = j / w, jx = j - jy * w;
+        const int t = (y0 + jy) * gx + x0 + jx;
+        keys[tile_offsets[t] + tile_count[t] + atomicAdd(&tile_extra[t], 1)] = key;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------- K4
@@ -316,6 +321,18 @@ __device__ __forceinline__ void cmpswap(uint64_t *a, int i, int j, int n)
     if (j < n) {
         const uint64_t x = a[i], y = a[j];
         if (y < x) { a[i] = y; a[j] = x; }
+    }
+}
+
+template <bool WAVE_ONLY>
+__device__ __forceinline__ void sort_sync()
+{
+    if (WAVE_ONLY) {   // a single wave owns the array: LDS/global ops of one wave complete in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
     }
 }
 
@@ -331,13 +348,13 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *a, int n, int tid)
             const int i = blk * k + off, j = blk * k + k - 1 - off;
             if (i < n) cmpswap(a, i, j, n);
         }
-        __syncthreads();
+        sort_sync<NT == 64>();
         for (int jj = k >> 2; jj >= 1; jj >>= 1) {
             for (int t = tid; t < (N >> 1); t += NT) {
                 const int i = (t / jj) * 2 * jj + (t % jj);
                 if (i < n) cmpswap(a, i, i + jj, n);
             }
-            __syncthreads();
+            sort_sync<NT == 64>();
         }
     }
 }
@@ -354,76 +371,91 @@ __device__ __forceinline__ void emit_entry(int pos, uint64_t key, const GeomRec 
     inst_bbox[pos] = make_uint2(__float_as_uint(f2.y), __float_as_uint(f2.z));
 }
 
-__global__ void __launch_bounds__(64) k_sort_tiles_wave(int T, const int32_t *__restrict__ tile_offsets,
-                                                        const uint64_t *__restrict__ keys,
-                                                        const GeomRec *__restrict__ geom,
-                                                        int32_t *__restrict__ point_list,
-                                                        uint2 *__restrict__ inst_bbox,
-                                                        const gsvc_raster_counters *__restrict__ counters)
+// One launch sorts every tile: 256-lane workgroups, each wave takes one tile at a time (tile = 4*block + wave):
+//   n <= 256   rank sort: every key is compared with every other from LDS (keys are unique: rank = position);
+//              the bbox gather of the lane's own entries is issued BEFORE the ranking so its latency hides under it
+//   n <= 1024  LDS bitonic by the wave
+// Longer lists (listed by K2, normally none) are then handled by whole workgroups: LDS bitonic up to 4096 entries
+// (the four waves' strips together), in place in global memory beyond.
+__global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__restrict__ tile_offsets,
+                                                    const int32_t *__restrict__ big_list, uint64_t *__restrict__ keys,
+                                                    const GeomRec *__restrict__ geom, int32_t *__restrict__ point_list,
+                                                    uint2 *__restrict__ inst_bbox,
+                                                    const gsvc_raster_counters *__restrict__ counters)
 {
-    __shared__ uint64_t s[SORT_WAVE_MAX];
+    __shared__ uint64_t s_all[4 * SORT_WAVE_MAX];   // 32 KiB: one 8-KiB strip per wave
     if (counters->overflow) return;
-    const int t = blockIdx.x, lane = threadIdx.x;
-    const int beg = tile_offsets[t], n = tile_offsets[t + 1] - beg;
-    if (n <= 0 || n > SORT_WAVE_MAX) return;
-    if (n <= SORT_RANK_MAX) {
-        // keys are unique (the id sits in the low word): rank = number of smaller keys = final position
-        uint64_t k0 = ~0ull, k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;
-        if (lane < n) { k0 = keys[beg + lane]; s[lane] = k0; }
-        if (lane + 64 < n) { k1 = keys[beg + lane + 64]; s[lane + 64] = k1; }
-        if (lane + 128 < n) { k2 = keys[beg + lane + 128]; s[lane + 128] = k2; }
-        if (lane + 192 < n) { k3 = keys[beg + lane + 192]; s[lane + 192] = k3; }
-        __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint64_t *s = s_all + wave * SORT_WAVE_MAX;
+    const int t = blockIdx.x * 4 + wave;
+    int beg = 0, n = 0;
+    if (t < T) {
+        beg = tile_offsets[t];
+        n = tile_offsets[t + 1] - beg;
+    }
+    if (n > 0 && n <= SORT_RANK_MAX) {
+        uint64_t k[4];
+        uint2 bb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = lane + 64 * q;
+            k[q] = ~0ull;
+            bb[q] = make_uint2(0u, 0u);
+            if (i < n) {
+                k[q] = keys[beg + i];
+                s[i] = k[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (lane + 64 * q < n) {
+                const float4 f2 = reinterpret_cast<const float4 *>(geom + (uint32_t)k[q])[2];
+                bb[q] = make_uint2(__float_as_uint(f2.y), __float_as_uint(f2.z));
+            }
+        }
+        sort_sync<true>();
         int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         if (n <= 64) {
-            for (int j = 0; j < n; j++) r0 += s[j] < k0;
+            for (int j = 0; j < n; j++) r0 += s[j] < k[0];
         } else if (n <= 128) {
-            for (int j = 0; j < n; j++) { const uint64_t kj = s[j]; r0 += kj < k0; r1 += kj < k1; }
+            for (int j = 0; j < n; j++) { const uint64_t kj = s[j]; r0 += kj < k[0]; r1 += kj < k[1]; }
         } else {
             for (int j = 0; j < n; j++) {
                 const uint64_t kj = s[j];
-                r0 += kj < k0; r1 += kj < k1; r2 += kj < k2; r3 += kj < k3;
+                r0 += kj < k[0]; r1 += kj < k[1]; r2 += kj < k[2]; r3 += kj < k[3];
             }
         }
-        if (lane < n) emit_entry(beg + r0, k0, geom, point_list, inst_bbox);
-        if (lane + 64 < n) emit_entry(beg + r1, k1, geom, point_list, inst_bbox);
-        if (lane + 128 < n) emit_entry(beg + r2, k2, geom, point_list, inst_bbox);
-        if (lane + 192 < n) emit_entry(beg + r3, k3, geom, point_list, inst_bbox);
-        return;
+        const int r[4] = {r0, r1, r2, r3};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (lane + 64 * q < n) {
+                point_list[beg + r[q]] = (int32_t)(uint32_t)k[q];
+                inst_bbox[beg + r[q]] = bb[q];
+            }
+        }
+    } else if (n > SORT_RANK_MAX && n <= SORT_WAVE_MAX) {
+        for (int i = lane; i < n; i += 64) s[i] = keys[beg + i];
+        sort_sync<true>();
+        bitonic_sort<64>(s, n, lane);
+        for (int i = lane; i < n; i += 64) emit_entry(beg + i, s[i], geom, point_list, inst_bbox);
     }
-    for (int i = lane; i < n; i += 64) s[i] = keys[beg + i];
-    __syncthreads();
-    bitonic_sort<64>(s, n, lane);
-    for (int i = lane; i < n; i += 64) emit_entry(beg + i, s[i], geom, point_list, inst_bbox);
-}
-
-// 256-lane workgroups walk the list of tiles longer than SORT_WAVE_MAX (built by K2; usually empty, then every
-// workgroup exits after one load): LDS up to SORT_WG_MAX entries, in place in global memory beyond that
-// (correct for any length; such tiles are pathological)
-__global__ void __launch_bounds__(256) k_sort_tiles_wg(const int32_t *__restrict__ big_list,
-                                                       const int32_t *__restrict__ tile_offsets,
-                                                       uint64_t *__restrict__ keys, const GeomRec *__restrict__ geom,
-                                                       int32_t *__restrict__ point_list, uint2 *__restrict__ inst_bbox,
-                                                       const gsvc_raster_counters *__restrict__ counters)
-{
-    extern __shared__ uint64_t sbig[];
-    if (counters->overflow) return;
+    // long lists: whole workgroups (uniform loop bounds; usually zero iterations)
     const int nbig = counters->num_big_tiles;
-    const int tid = threadIdx.x;
     for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
-        const int t = big_list[w];
-        const int beg = tile_offsets[t], n = tile_offsets[t + 1] - beg;
+        const int bt = big_list[w];
+        const int bbeg = tile_offsets[bt], bn = tile_offsets[bt + 1] - bbeg;
         __syncthreads();
-        if (n <= SORT_WG_MAX) {
-            for (int i = tid; i < n; i += 256) sbig[i] = keys[beg + i];
+        if (bn <= 4 * SORT_WAVE_MAX) {
+            for (int i = tid; i < bn; i += 256) s_all[i] = keys[bbeg + i];
             __syncthreads();
-            bitonic_sort<256>(sbig, n, tid);
-            for (int i = tid; i < n; i += 256) emit_entry(beg + i, sbig[i], geom, point_list, inst_bbox);
+            bitonic_sort<256>(s_all, bn, tid);
+            for (int i = tid; i < bn; i += 256) emit_entry(bbeg + i, s_all[i], geom, point_list, inst_bbox);
         } else {
-            uint64_t *a = keys + beg;
+            uint64_t *a = keys + bbeg;
             __threadfence_block();
-            bitonic_sort<256>(a, n, tid);  // __syncthreads() orders the workgroup's own global accesses
-            for (int i = tid; i < n; i += 256) emit_entry(beg + i, a[i], geom, point_list, inst_bbox);
+            bitonic_sort<256>(a, bn, tid);  // __syncthreads() orders the workgroup's own global accesses
+            for (int i = tid; i < bn; i += 256) emit_entry(bbeg + i, a[i], geom, point_list, inst_bbox);
         }
     }
 }
@@ -497,7 +529,7 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // phase 2: composite the survivors front to back
-#pragma unroll 2
+#pragma unroll 4
         for (int j = 0; j < cnt; j++) {
             const float4 a = w_f0[j];
             const float4 b = w_f1[j];
@@ -654,14 +686,9 @@ extern "C" int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t
                                tile_offsets, tile_count, tile_extra, keys, counters);
         }
         {
-            ProfScope _prof("k_sort_tiles_wave", s);
-            hipLaunchKernelGGL(k_sort_tiles_wave, dim3(L.tiles), dim3(64), 0, s, L.tiles, tile_offsets, keys, grec,
-                               point_list, inst_bbox, counters);
-        }
-        {
-            ProfScope _prof("k_sort_tiles_wg", s);
-            hipLaunchKernelGGL(k_sort_tiles_wg, dim3(128), dim3(256), SORT_WG_MAX * sizeof(uint64_t), s, big_list,
-                               tile_offsets, keys, grec, point_list, inst_bbox, counters);
+            ProfScope _prof("k_sort_tiles", s);
+            hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)((L.tiles + 3) / 4)), dim3(256), 0, s, L.tiles, tile_offsets,
+                               big_list, keys, grec, point_list, inst_bbox, counters);
         }
     }
     {
