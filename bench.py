@@ -253,6 +253,10 @@ def main():
                 _lib.current_stream(dev)), "gsvc_raster_backward")
         return image
 
+    def step_pair():
+        return rasterizer.raster_forward(cs, d["means3D"], d["colors"], d["opacities"], d["scales"], d["rotations"],
+                                         max_instances=cap, sync=False, pair=True)[0]
+
     def barrier():
         if world > 1:
             import torch.distributed as dist
@@ -281,6 +285,16 @@ def main():
         elapsed, total_units = float(tmax.item()), float(tot.item())
     else:
         total_units = float(units[0].item())
+
+    # two-view frames (the reference's fps definition: view + opposite view + flip + average) from the fused pass
+    for _ in range(3):
+        step_pair()
+    torch.cuda.synchronize()
+    tp0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_pair()
+    torch.cuda.synchronize()
+    pair_fps = args.steps / (time.perf_counter() - tp0)
 
     # per-kernel pass: same K steps with HIP events around every launch on the launch stream
     _lib.profile_enable(True)
@@ -331,6 +345,7 @@ def main():
                        "gaussians": P, "visible": n_vis, "instances": n_inst, "max_tile_list": max_tile,
                        "parallelism": f"frame-shard x{world}"},
             "render_fps": args.steps * world / elapsed,
+            "render_fps_two_view": pair_fps * world,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": kern[dom]["avg_us"]},

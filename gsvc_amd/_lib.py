@@ -48,6 +48,7 @@ _SIGNATURES = {
     "gsvc_raster_sizes_query": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64, C.POINTER(RasterSizesC)]),
     "gsvc_raster_visible_filter": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_raster_forward": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64] + [_vp] * 11),
+    "gsvc_raster_forward_pair": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64] + [_vp] * 11),
     "gsvc_raster_backward": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64] + [_vp] * 18),
     "gsvc_raster_binning_layout": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gsvc_raster_image_layout": (C.c_int, [C.POINTER(RasterSettingsC), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

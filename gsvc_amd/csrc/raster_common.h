@@ -30,7 +30,7 @@ constexpr int BIN_SLOTS = 4;     // instance slots resolved by K1's LDS histogra
 struct alignas(16) BinRec {
     float depth;
     uint32_t rect_x, rect_y;     // x0 | x1<<16,  y0 | y1<<16 (tile units, upper exclusive); 0 when culled
-    uint32_t pad;
+    uint32_t pad;                // pair mode: x range of the opposite view's rectangle, mirrored into this view's tiles
     int32_t slot[BIN_SLOTS];     // position of the Gaussian's first tiles inside each tile's segment
 };
 static_assert(sizeof(BinRec) == 32, "BinRec must be 32 bytes");
@@ -112,6 +112,8 @@ __device__ __forceinline__ int tile_clamp(float t, int g)
 }
 
 struct PreOut {
+    float xv;          // view-space x (the opposite view of a pair sees -xv)
+    int radius_raw;    // 3-sigma radius before the screen-rectangle test (0 when culled by slab / covariance)
     float u, v, depth;
     float A, B, C;     // conic
     float a, b, c;     // 2-D covariance (low-pass included)
@@ -132,6 +134,8 @@ __device__ __forceinline__ int preprocess_gaussian(const RasterParams &st, float
     float yv = M[4] * px + M[5] * py + M[6] * pz + M[7];
     float zv = M[8] * px + M[9] * py + M[10] * pz + M[11];
     o.radius = 0;
+    o.radius_raw = 0;
+    o.xv = xv;
     if (!(fabsf(zv) <= st.threshold)) return 0;
 
     float R00 = 1.f - 2.f * (qy * qy + qz * qz);
@@ -187,10 +191,11 @@ __device__ __forceinline__ int preprocess_gaussian(const RasterParams &st, float
     int x1 = tile_clamp(((u + rf + (float)(TILE - 1)) / (float)TILE), st.gx);
     int y0 = tile_clamp(((v - rf) / (float)TILE), st.gy);
     int y1 = tile_clamp(((v + rf + (float)(TILE - 1)) / (float)TILE), st.gy);
-    if ((x1 - x0) * (y1 - y0) <= 0) return 0;
     o.u = u; o.v = v; o.depth = zv;
-    o.radius = radius;
+    o.radius_raw = radius;
     o.x0 = x0; o.y0 = y0; o.x1 = x1; o.y1 = y1;
+    if ((x1 - x0) * (y1 - y0) <= 0) return 0;
+    o.radius = radius;
     return radius;
 }
 

@@ -72,7 +72,10 @@ __global__ void __launch_bounds__(256) k_visible_filter(RasterParams st, int P, 
 // ------------------------------------------------------------------------------------------------- K1
 // USE_LDS: per-workgroup histogram of the whole tile grid in dynamic LDS (4*T bytes).  Otherwise (grids too
 // large for LDS) every instance does its own global atomic.
-template <bool USE_LDS>
+// PAIR: bin for the two-view frame — a Gaussian is listed in the union of this view's tile rectangle and the
+// opposite view's rectangle mirrored into this view's tile grid (the 3-sigma rectangle formula is not mirror
+// symmetric, so the two differ by up to one tile column); K3 tags every instance with the views it belongs to.
+template <bool USE_LDS, bool PAIR>
 __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, const float *__restrict__ means3D,
                                                      const float *__restrict__ colors,
                                                      const float *__restrict__ opacities,
@@ -93,6 +96,8 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
     int radius = 0;
     PreOut o;
     int slot[BIN_SLOTS] = {0, 0, 0, 0};
+    int bx0 = 0, bx1 = 0;   // x range of the binning rectangle (pair mode: union of the two views)
+    bool listed = false;
     if (i < P) {
         const float4 q = reinterpret_cast<const float4 *>(rotations)[i];
         radius = preprocess_gaussian(st, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], scales[3 * i],
@@ -100,18 +105,34 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         radii[i] = radius;
         GeomRec rec;
         BinRec br;
-        if (radius > 0) {
+        br.pad = 0u;
+        listed = radius > 0;
+        if (!PAIR) {
+            bx0 = o.x0; bx1 = o.x1;
+        } else if (o.radius_raw > 0) {
+            // opposite view: x_view' = -x_view, same y, same radius; rectangle by the same formula, then mirrored
+            const float ub = (-o.xv - st.x_min) * st.scale - 0.5f, rf = (float)o.radius_raw;
+            const int xb0 = tile_clamp((ub - rf) / (float)TILE, st.gx), xb1 = tile_clamp((ub + rf + (float)(TILE - 1)) / (float)TILE, st.gx);
+            const bool vis_b = (xb1 - xb0) * (o.y1 - o.y0) > 0;
+            const int mx0 = st.gx - xb1, mx1 = st.gx - xb0;
+            if (vis_b) br.pad = (uint32_t)mx0 | ((uint32_t)mx1 << 16);
+            if (radius > 0 && vis_b) { bx0 = min(o.x0, mx0); bx1 = max(o.x1, mx1); }
+            else if (radius > 0) { bx0 = o.x0; bx1 = o.x1; }
+            else if (vis_b) { bx0 = mx0; bx1 = mx1; }
+            listed = radius > 0 || vis_b;
+        }
+        if (listed) {
             rec.u = o.u; rec.v = o.v; rec.A = o.A; rec.B = o.B;
             rec.C = o.C; rec.opacity = opacities[i];
             rec.r = colors[3 * i + 0]; rec.g = colors[3 * i + 1]; rec.b = colors[3 * i + 2];
             rec.depth = o.depth;
             alpha_bbox(o.u, o.v, o.A, o.B, o.C, rec.opacity, rec.bbox_x, rec.bbox_y);
             br.depth = o.depth;
-            br.rect_x = (uint32_t)o.x0 | ((uint32_t)o.x1 << 16);
+            br.rect_x = radius > 0 ? ((uint32_t)o.x0 | ((uint32_t)o.x1 << 16)) : 0u;
             br.rect_y = (uint32_t)o.y0 | ((uint32_t)o.y1 << 16);
             int j = 0;
             for (int ty = o.y0; ty < o.y1; ty++)
-                for (int tx = o.x0; tx < o.x1; tx++, j++) {
+                for (int tx = bx0; tx < bx1; tx++, j++) {
                     const int t = ty * st.gx + tx;
                     if (j < BIN_SLOTS) {
                         const int r = USE_LDS ? atomicAdd(&hist[t], 1) : atomicAdd(&tile_count[t], 1);
@@ -128,11 +149,10 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
             rec.bbox_x = pack_i16(1, 0); rec.bbox_y = pack_i16(1, 0);
             br.depth = 0.f; br.rect_x = br.rect_y = 0u;
         }
-        br.pad = 0u;
         float4 *dst = reinterpret_cast<float4 *>(geom + i);
         const float4 *src = reinterpret_cast<const float4 *>(&rec);
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
-        if (!USE_LDS || radius == 0) {
+        if (!USE_LDS || !listed) {
             br.slot[0] = slot[0]; br.slot[1] = slot[1]; br.slot[2] = slot[2]; br.slot[3] = slot[3];
             float4 *bd = reinterpret_cast<float4 *>(bins + i);
             const float4 *bs = reinterpret_cast<const float4 *>(&br);
@@ -177,10 +197,10 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         }
     }
     __syncthreads();
-    if (i < P && radius > 0) {
+    if (i < P && listed) {
         int j = 0;
         for (int ty = o.y0; ty < o.y1 && j < BIN_SLOTS; ty++)
-            for (int tx = o.x0; tx < o.x1 && j < BIN_SLOTS; tx++, j++) {
+            for (int tx = bx0; tx < bx1 && j < BIN_SLOTS; tx++, j++) {
                 const int base = hist[ty * st.gx + tx];
                 if (j == 0) slot[0] += base;
                 if (j == 1) slot[1] += base;
@@ -278,6 +298,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int T, const int32_t *__res
 }
 
 // ------------------------------------------------------------------------------------------------- K3
+template <bool PAIR>
 __global__ void __launch_bounds__(256) k_scatter(int P, int gx, const BinRec *__restrict__ bins,
                                                  const int32_t *__restrict__ tile_offsets,
                                                  const int32_t *__restrict__ tile_count,
@@ -288,11 +309,23 @@ __global__ void __launch_bounds__(256) k_scatter(int P, int gx, const BinRec *__
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const float4 b0 = reinterpret_cast<const float4 *>(bins + i)[0];
-    const uint32_t rx = __float_as_uint(b0.y), ry = __float_as_uint(b0.z);
-    if ((rx | ry) == 0u) return;
+    const uint32_t rx = __float_as_uint(b0.y), ry = __float_as_uint(b0.z), rb = __float_as_uint(b0.w);
+    if (((PAIR ? (rx | rb) : rx) | ry) == 0u || ry == 0u) return;
     const int4 sl = reinterpret_cast<const int4 *>(bins + i)[1];
-    const int x0 = rx & 0xffff, x1 = rx >> 16, y0 = ry & 0xffff, y1 = ry >> 16;
-    const uint64_t key = ((uint64_t)order_bits(b0.x) << 32) | (uint32_t)i;
+    const int fx0 = rx & 0xffff, fx1 = rx >> 16, y0 = ry & 0xffff, y1 = ry >> 16;
+    int x0 = fx0, x1 = fx1;
+    const int mx0 = rb & 0xffff, mx1 = rb >> 16;
+    if (PAIR) {   // union of this view's x range and the mirrored opposite view's (either may be empty)
+        if (rx == 0u) { x0 = mx0; x1 = mx1; }
+        else if (rb != 0u) { x0 = min(fx0, mx0); x1 = max(fx1, mx1); }
+    }
+    // pair mode: low word = id << 2 | (in this view's rectangle) | (in the opposite view's rectangle) << 1
+    const uint64_t key_hi = (uint64_t)order_bits(b0.x) << 32;
+    auto make_key = [&](int tx) -> uint64_t {
+        if (!PAIR) return key_hi | (uint32_t)i;
+        const uint32_t fl = ((rx != 0u && tx >= fx0 && tx < fx1) ? 1u : 0u) | ((rb != 0u && tx >= mx0 && tx < mx1) ? 2u : 0u);
+        return key_hi | (((uint32_t)i << 2) | fl);
+    };
     const int w = x1 - x0, ntiles = w * (y1 - y0);
     // first BIN_SLOTS tiles: the four segment offsets are fetched together (independent loads), then stored
     int tl[BIN_SLOTS], off[BIN_SLOTS];
@@ -305,11 +338,11 @@ __global__ void __launch_bounds__(256) k_scatter(int P, int gx, const BinRec *__
     }
 #pragma unroll
     for (int j = 0; j < BIN_SLOTS; j++)
-        if (j < ntiles) keys[off[j] + slots[j]] = key;
+        if (j < ntiles) keys[off[j] + slots[j]] = make_key(tl[j] % gx);
     for (int j = BIN_SLOTS; j < ntiles; j++) {
         const int jy = j / w, jx = j - jy * w;
         const int t = (y0 + jy) * gx + x0 + jx;
-        keys[tile_offsets[t] + tile_count[t] + atomicAdd(&tile_extra[t], 1)] = key;
+        keys[tile_offsets[t] + tile_count[t] + atomicAdd(&tile_extra[t], 1)] = make_key(x0 + jx);
     }
 }
 
@@ -363,10 +396,10 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *a, int n, int tid)
 // every sorted entry gets its Gaussian id (point_list) and that Gaussian's alpha bounding box (inst_bbox), so the
 // blend kernels test 64 entries per wave-instruction without touching the Gaussian records
 __device__ __forceinline__ void emit_entry(int pos, uint64_t key, const GeomRec *__restrict__ geom,
-                                           int32_t *__restrict__ point_list, uint2 *__restrict__ inst_bbox)
+                                           int32_t *__restrict__ point_list, uint2 *__restrict__ inst_bbox, int id_shift)
 {
-    const uint32_t id = (uint32_t)key;
-    point_list[pos] = (int32_t)id;
+    const uint32_t low = (uint32_t)key, id = low >> id_shift;   // pair mode keeps the two view flags in the low bits
+    point_list[pos] = (int32_t)low;
     const float4 f2 = reinterpret_cast<const float4 *>(geom + id)[2];
     inst_bbox[pos] = make_uint2(__float_as_uint(f2.y), __float_as_uint(f2.z));
 }
@@ -381,7 +414,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
                                                     const int32_t *__restrict__ big_list, uint64_t *__restrict__ keys,
                                                     const GeomRec *__restrict__ geom, int32_t *__restrict__ point_list,
                                                     uint2 *__restrict__ inst_bbox,
-                                                    const gsvc_raster_counters *__restrict__ counters)
+                                                    const gsvc_raster_counters *__restrict__ counters, int id_shift)
 {
     __shared__ uint64_t s_all[4 * SORT_WAVE_MAX];   // 32 KiB: one 8-KiB strip per wave
     if (counters->overflow) return;
@@ -410,7 +443,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (lane + 64 * q < n) {
-                const float4 f2 = reinterpret_cast<const float4 *>(geom + (uint32_t)k[q])[2];
+                const float4 f2 = reinterpret_cast<const float4 *>(geom + ((uint32_t)k[q] >> id_shift))[2];
                 bb[q] = make_uint2(__float_as_uint(f2.y), __float_as_uint(f2.z));
             }
         }
@@ -438,7 +471,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
         for (int i = lane; i < n; i += 64) s[i] = keys[beg + i];
         sort_sync<true>();
         bitonic_sort<64>(s, n, lane);
-        for (int i = lane; i < n; i += 64) emit_entry(beg + i, s[i], geom, point_list, inst_bbox);
+        for (int i = lane; i < n; i += 64) emit_entry(beg + i, s[i], geom, point_list, inst_bbox, id_shift);
     }
     // long lists: whole workgroups (uniform loop bounds; usually zero iterations)
     const int nbig = counters->num_big_tiles;
@@ -450,12 +483,12 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
             for (int i = tid; i < bn; i += 256) s_all[i] = keys[bbeg + i];
             __syncthreads();
             bitonic_sort<256>(s_all, bn, tid);
-            for (int i = tid; i < bn; i += 256) emit_entry(bbeg + i, s_all[i], geom, point_list, inst_bbox);
+            for (int i = tid; i < bn; i += 256) emit_entry(bbeg + i, s_all[i], geom, point_list, inst_bbox, id_shift);
         } else {
             uint64_t *a = keys + bbeg;
             __threadfence_block();
             bitonic_sort<256>(a, bn, tid);  // __syncthreads() orders the workgroup's own global accesses
-            for (int i = tid; i < bn; i += 256) emit_entry(bbeg + i, a[i], geom, point_list, inst_bbox);
+            for (int i = tid; i < bn; i += 256) emit_entry(bbeg + i, a[i], geom, point_list, inst_bbox, id_shift);
         }
     }
 }
@@ -478,6 +511,13 @@ constexpr float LOG2E = 1.44269504088896340736f;
 // Survivors of the quadrant test are staged with the conic pre-scaled by log2(e) (and the 1/2 folded in), so the
 // per-pixel work is p = A' dx^2 + C' dy^2 + B' dx dy, G = exp2(-p): 6 mul/fma + one v_exp_f32.  The inner loop
 // is branch-free: selects on SGPR masks instead of EXEC-mask branches.
+//
+// PAIR = true additionally composites the SAME list back to front ("over" recurrence Cb = c a + (1-a) Cb): that is
+// what the opposite view (view_matrix_s) renders at the mirrored pixel, so image = (front + flip(back)) / 2 — the
+// frame GSVC's evaluation and decoder actually output (reference utils/report_utils.py:297-319, pipeline/train.py:
+// 368-375) — comes out of ONE binning + ONE pass instead of two renders, a flip and an average.  The back composite
+// has no early exit (the opposite view's own T < 1e-4 cut changes a pixel by < 1e-4).
+template <bool PAIR>
 __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *__restrict__ tile_offsets,
                                                const int32_t *__restrict__ point_list,
                                                const uint2 *__restrict__ inst_bbox, const GeomRec *__restrict__ geom,
@@ -503,6 +543,7 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
     float2 *w_f2 = s_f2[wave];
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    float Tb = 1.0f, B0 = 0.f, B1 = 0.f, B2 = 0.f;   // PAIR: back-to-front composite of the same list
     int last = 0;
     bool done = !inside;
     for (int c0 = beg; c0 < end; c0 += 64) {
@@ -518,11 +559,12 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
         if (mask == 0ull) continue;
         if (hit) {
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-            const float4 *rec = reinterpret_cast<const float4 *>(geom + id);
+            const float4 *rec = reinterpret_cast<const float4 *>(geom + (PAIR ? (id >> 2) : id));
             const float4 r0 = rec[0], r1 = rec[1];
             w_f0[pos] = make_float4(r0.x, r0.y, (0.5f * LOG2E) * r0.z, LOG2E * r0.w);
             w_f1[pos] = make_float4((0.5f * LOG2E) * r1.x, r1.y, r1.z, r1.w);
-            w_f2[pos] = make_float2(rec[2].x, __int_as_float(k - beg + 1));
+            // PAIR: the slot's tag carries the two view-membership flags instead of the list position
+            w_f2[pos] = make_float2(rec[2].x, __int_as_float(PAIR ? (id & 3) : (k - beg + 1)));
         }
         const int cnt = __popcll(mask);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -538,25 +580,40 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
             const float p = a.z * dx * dx + b.x * dy * dy + a.w * dx * dy;   // = -power * log2(e)
             const float alpha = fminf(ALPHA_MAX, b.y * __builtin_amdgcn_exp2f(-p));
             const float test_T = T - alpha * T;
-            const bool keep = !done && !(p < 0.0f) && !(alpha < ALPHA_MIN);
+            const int tagv = __float_as_int(c.y);
+            const bool contrib_any = !(p < 0.0f) && !(alpha < ALPHA_MIN);
+            const bool contrib = PAIR ? (contrib_any && (tagv & 1)) : contrib_any;
+            if (PAIR) {
+                const float ab = (contrib_any && inside && (tagv & 2)) ? alpha : 0.0f;
+                const float om = 1.0f - ab;
+                B0 = b.z * ab + om * B0; B1 = b.w * ab + om * B1; B2 = c.x * ab + om * B2;
+                Tb *= om;
+            }
+            const bool keep = !done && contrib;
             const bool stop = keep && (test_T < T_MIN);
             const bool acc = keep && !stop;
             done |= stop;
             const float w = acc ? alpha * T : 0.0f;
             C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
             T = acc ? test_T : T;
-            last = acc ? __float_as_int(c.y) : last;
+            last = acc ? tagv : last;
         }
         __builtin_amdgcn_wave_barrier();
-        if (__ballot(!done) == 0ull) break;
+        if (!PAIR && __ballot(!done) == 0ull) break;
     }
     if (inside) {
         const int HW = st.H * st.W, pix = py * st.W + px;
-        final_T[pix] = T;
-        n_contrib[pix] = last;
-        image[pix] = C0 + T * st.bg0;
-        image[HW + pix] = C1 + T * st.bg1;
-        image[2 * HW + pix] = C2 + T * st.bg2;
+        if (PAIR) {
+            image[pix] = 0.5f * ((C0 + T * st.bg0) + (B0 + Tb * st.bg0));
+            image[HW + pix] = 0.5f * ((C1 + T * st.bg1) + (B1 + Tb * st.bg1));
+            image[2 * HW + pix] = 0.5f * ((C2 + T * st.bg2) + (B2 + Tb * st.bg2));
+        } else {
+            final_T[pix] = T;
+            n_contrib[pix] = last;
+            image[pix] = C0 + T * st.bg0;
+            image[HW + pix] = C1 + T * st.bg1;
+            image[2 * HW + pix] = C2 + T * st.bg2;
+        }
     }
 }
 
@@ -624,14 +681,18 @@ extern "C" int gsvc_raster_visible_filter(const gsvc_raster_settings *settings, 
     return check_launch("visible_filter");
 }
 
-extern "C" int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
-                                   const float *means3D, const float *colors, const float *opacities,
-                                   const float *scales, const float *rotations, float *image, int32_t *radii,
-                                   void *geom, void *binning, void *image_state, void *stream)
+static int raster_forward_impl(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
+                               const float *means3D, const float *colors, const float *opacities, const float *scales,
+                               const float *rotations, float *image, int32_t *radii, void *geom, void *binning,
+                               void *image_state, void *stream, bool pair)
 {
     if (int rc = check_settings(settings, P)) return rc;
     GSVC_REQUIRE(max_instances >= 0 && max_instances < (int64_t)1 << 31, "raster_forward: max_instances out of range");
     GSVC_REQUIRE(image && geom && binning && image_state, "raster_forward: NULL output/state pointer");
+    if (pair && (settings->image_width % TILE != 0 || P >= ((int64_t)1 << 29))) {
+        set_error("raster_forward_pair: needs image_width %% 16 == 0 (tile grids of the two views must mirror) and P < 2^29");
+        return GSVC_E_UNSUPPORTED;
+    }
     GSVC_REQUIRE(P == 0 || (means3D && colors && opacities && scales && rotations && radii),
                  "raster_forward: NULL input pointer");
     const RasterParams p = make_params(*settings);
@@ -659,20 +720,19 @@ extern "C" int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t
     if (P > 0) {
         const unsigned blocks = (unsigned)((P + 1023) / 1024);
         ProfScope _prof("k_preprocess", s);
-        if (L.tiles <= LDS_HIST_MAX_TILES) {
-            static bool attr_set = false;
-            const size_t lds = (size_t)L.tiles * sizeof(int);
-            if (lds > 48 * 1024 && !attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_preprocess<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HIST_MAX_TILES * 4);
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(1024), lds, s, p, (int)P, means3D, colors,
-                               opacities, scales, rotations, radii, grec, brec, tile_count, tile_extra, counters);
-        } else {
-            hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(1024), 0, s, p, (int)P, means3D, colors,
-                               opacities, scales, rotations, radii, grec, brec, tile_count, tile_extra, counters);
-        }
+        const bool use_lds = L.tiles <= LDS_HIST_MAX_TILES;
+        const size_t lds = use_lds ? (size_t)L.tiles * sizeof(int) : 0;
+        auto launch = [&](auto kernel) {
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          LDS_HIST_MAX_TILES * 4);
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds, s, p, (int)P, means3D, colors, opacities, scales,
+                               rotations, radii, grec, brec, tile_count, tile_extra, counters);
+        };
+        if (use_lds && pair) launch(&k_preprocess<true, true>);
+        else if (use_lds) launch(&k_preprocess<true, false>);
+        else if (pair) launch(&k_preprocess<false, true>);
+        else launch(&k_preprocess<false, false>);
     }
     {
         ProfScope _prof("k_scan_tiles", s);
@@ -682,19 +742,45 @@ extern "C" int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t
     if (P > 0) {
         {
             ProfScope _prof("k_scatter", s);
-            hipLaunchKernelGGL(k_scatter, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (int)P, L.gx, brec,
-                               tile_offsets, tile_count, tile_extra, keys, counters);
+            if (pair)
+                hipLaunchKernelGGL(k_scatter<true>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (int)P, L.gx, brec,
+                                   tile_offsets, tile_count, tile_extra, keys, counters);
+            else
+                hipLaunchKernelGGL(k_scatter<false>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (int)P, L.gx, brec,
+                                   tile_offsets, tile_count, tile_extra, keys, counters);
         }
         {
             ProfScope _prof("k_sort_tiles", s);
             hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)((L.tiles + 3) / 4)), dim3(256), 0, s, L.tiles, tile_offsets,
-                               big_list, keys, grec, point_list, inst_bbox, counters);
+                               big_list, keys, grec, point_list, inst_bbox, counters, pair ? 2 : 0);
         }
     }
     {
-        ProfScope _prof("k_blend", s);
-        hipLaunchKernelGGL(k_blend, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list, inst_bbox, grec,
-                           image, final_T, n_contrib, counters);
+        ProfScope _prof(pair ? "k_blend_pair" : "k_blend", s);
+        if (pair)
+            hipLaunchKernelGGL(k_blend<true>, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list, inst_bbox,
+                               grec, image, final_T, n_contrib, counters);
+        else
+            hipLaunchKernelGGL(k_blend<false>, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list, inst_bbox,
+                               grec, image, final_T, n_contrib, counters);
     }
     return check_launch("raster_forward");
+}
+
+extern "C" int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
+                                   const float *means3D, const float *colors, const float *opacities,
+                                   const float *scales, const float *rotations, float *image, int32_t *radii,
+                                   void *geom, void *binning, void *image_state, void *stream)
+{
+    return raster_forward_impl(settings, P, max_instances, means3D, colors, opacities, scales, rotations, image, radii, geom,
+                               binning, image_state, stream, false);
+}
+
+extern "C" int gsvc_raster_forward_pair(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
+                                        const float *means3D, const float *colors, const float *opacities,
+                                        const float *scales, const float *rotations, float *image_pair, int32_t *radii,
+                                        void *geom, void *binning, void *image_state, void *stream)
+{
+    return raster_forward_impl(settings, P, max_instances, means3D, colors, opacities, scales, rotations, image_pair, radii,
+                               geom, binning, image_state, stream, true);
 }

@@ -8,7 +8,7 @@ import torch
 
 from ..common.base import RenderResults
 from ..generate import GenerateMode, generate_neural_gaussians, generate_neural_gaussians_many
-from ..rasterizer import GaussianRasterizer
+from ..rasterizer import GaussianRasterizer, raster_forward, settings_to_c
 from .preprocess import prefilter_voxel, raster_settings_for
 
 
@@ -63,3 +63,29 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
             bit_per_scaling_param=gss.bit_per_scaling_param, bit_per_offsets_param=gss.bit_per_offsets_param,
             entropy_constrained=(gss.bit_per_param is not None), generated_gaussians=gss, time_sub=gss.time_sub))
     return results
+
+
+def render_pair(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, mode=GenerateMode.DECODING_AS_IS):
+    """The frame GSVC's evaluation / decoder outputs, (render(view) + flip_W(render(view_s))) / 2 (reference
+    utils/report_utils.py:297-319), from ONE generation and ONE rasterization pass (gsvc_raster_forward_pair).
+    Inference only and only for the deterministic modes (the noise modes draw different Gaussians per view)."""
+    if mode not in (GenerateMode.DECODING_AS_IS, GenerateMode.TRAINING_FULL_PRECISION, GenerateMode.TRAININ_STE_ENTROPY):
+        raise ValueError("render_pair needs a deterministic GenerateMode")
+    with torch.no_grad():
+        visible_mask = prefilter_voxel(frame, pc, pipe, bg_color)
+        gss = generate_neural_gaussians(frame, pc, visible_mask, mode)
+        cs = settings_to_c(raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier))
+        args = (gss.xyz.contiguous(), gss.color.contiguous(), gss.opacity.contiguous(), gss.scaling.contiguous(), gss.rot.contiguous())
+        if int(frame.image_width) % 16 == 0:
+            image, radii, state = raster_forward(cs, *args, pair=True)
+        else:   # the two views' tile grids do not mirror: two passes
+            import copy
+            back = copy.copy(frame)
+            back.view_matrix, back.view_matrix_s = frame.view_matrix_s, frame.view_matrix
+            f, radii, state = raster_forward(cs, *args)
+            b, _, _ = raster_forward(settings_to_c(raster_settings_for(back, pc, pipe, bg_color, scaling_modifier)), *args)
+            image = 0.5 * (f + torch.flip(b, dims=(-1,)))
+    return RenderResults(
+        rendered_image=image, viewspace_points=None, visibility_filter=radii > 0, visible_mask=visible_mask, radii=radii,
+        active_gaussains=(radii > 0).sum(), num_rendered=state.counters()[0], selection_mask=gss.mask,
+        neural_opacity=gss.neural_opacity, scaling=gss.scaling, generated_gaussians=gss, time_sub=gss.time_sub)

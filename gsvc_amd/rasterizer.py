@@ -111,10 +111,11 @@ _capacity_hint = {}
 
 
 def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales, rotations, max_instances=None,
-                   sync=True):
+                   sync=True, pair=False):
     """Launch the forward pipeline.  Returns (image, radii, state).  With ``sync`` the instance counters
     are read back (16 B) and the call is repeated with a larger instance capacity if it overflowed; without
-    it the caller must check ``state.counters()[1]`` itself."""
+    it the caller must check ``state.counters()[1]`` itself.  ``pair=True`` returns the two-view frame
+    (render(view) + flip(render(opposite view))) / 2 from one pass (inference only, see gsvc_raster_forward_pair)."""
     L = _lib.lib()
     P = int(means3D.shape[0])
     dev = means3D.device
@@ -131,7 +132,8 @@ def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales,
         image_state = torch.empty(sizes.image_bytes, dtype=torch.uint8, device=dev)
         image = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
-        _lib.check(L.gsvc_raster_forward(C.byref(cs), P, max_instances, _lib.ptr(means3D), _lib.ptr(colors),
+        fn = L.gsvc_raster_forward_pair if pair else L.gsvc_raster_forward
+        _lib.check(fn(C.byref(cs), P, max_instances, _lib.ptr(means3D), _lib.ptr(colors),
                                          _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(image),
                                          _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(binning), _lib.ptr(image_state), stream),
                    "gsvc_raster_forward")

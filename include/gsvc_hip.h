@@ -102,6 +102,17 @@ int gsvc_raster_forward(const gsvc_raster_settings *settings, int64_t P, int64_t
                         const float *rotations, float *image, int32_t *radii, void *geom, void *binning,
                         void *image_state, void *stream);
 
+/* Two-view frame in one pass (no backward): image_pair[3,H,W] = (render(view) + flip_W(render(opposite view))) / 2,
+ * the frame GSVC's evaluation / decoder output (reference utils/report_utils.py:297-319): the opposite view
+ * (frame.view_matrix_s) composites the same Gaussians at the mirrored pixels in reverse depth order, so one binning
+ * and one walk of the tile lists produce both composites.  Same arguments as gsvc_raster_forward with `settings`
+ * holding the forward view; final_T / n_contrib are not produced.  Agrees with two gsvc_raster_forward calls to
+ * < 2e-4 per pixel (the opposite view's own early exit is not replayed). */
+int gsvc_raster_forward_pair(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
+                             const float *means3D, const float *colors, const float *opacities, const float *scales,
+                             const float *rotations, float *image_pair, int32_t *radii, void *geom, void *binning,
+                             void *image_state, void *stream);
+
 /* Backward: dL_dimage[3,H,W] + the forward's inputs and state  ->  gradients (all overwritten):
  * dL_dmeans3D[P,3], dL_dmeans2D[P,3] (screen-space gradient in NDC units, the tensor GSVC's densification
  * reads, reference scene/gaussian_model.py:1311), dL_dcolors[P,3], dL_dopacities[P], dL_dscales[P,3],
