@@ -95,14 +95,25 @@ class _LinearMFMA(torch.autograd.Function):
             else:
                 gx = g @ w
         if ctx.needs_input_grad[1]:
-            if K <= 192:
-                gw = torch.zeros(N, K, device=x.device, dtype=torch.float32)
-                _lib.check(L.gsvc_linear_wgrad(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gw), M, N, K, st), "gsvc_linear_wgrad")
-            else:
-                gw = g.t() @ x
+            gw = _weight_grad(g, x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(dim=0)
         return gx, gw, gb
+
+
+def _weight_grad(g, x, rows_per_slice: int = 4096):
+    """dW = g^T x for tall g [M,N], x [M,K]: the reduction runs over M with a tiny [N,K] output, which a plain GEMM
+    call tiles by OUTPUT (a dozen workgroups on a 256-CU chip: ~500 us at M = 196k).  Splitting M into slices turns
+    it into a batched GEMM that fills the chip (~60 us), followed by a small sum."""
+    M = g.shape[0]
+    S = M // rows_per_slice
+    if S < 2:
+        return g.t() @ x
+    main = S * rows_per_slice
+    gw = torch.bmm(g[:main].view(S, rows_per_slice, -1).transpose(1, 2), x[:main].view(S, rows_per_slice, -1)).sum(dim=0)
+    if main < M:
+        gw = gw + g[main:].t() @ x[main:]
+    return gw
 
 
 class Linear(nn.Linear):

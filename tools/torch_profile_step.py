@@ -1,0 +1,31 @@
+"""torch.profiler view of one fitting step (diagnostic): which ATen ops the GPU time belongs to."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from torch.profiler import ProfilerActivity, profile
+from gsvc_amd.arguments import cfg_20240919
+from gsvc_amd.frame import SyntheticFrameCube
+from gsvc_amd.model import GaussianModel
+from gsvc_amd.train import Trainer
+dev = torch.device("cuda")
+mp_, opt, pipe = cfg_20240919()
+cube = SyntheticFrameCube(1080, 1920, 64, device=dev)
+mp_.threshold = 8.0 / cube.scale
+opt.full_precision_training_total = opt.quantized_training_total = 0
+opt.entropy_constrained_train_total = 10 ** 9
+opt.start_stat, opt.update_until, opt.pause_densification = 0, 10 ** 9, 0
+pc = GaussianModel(mp_, 50, 10, 0.001, 3, 16, 4, False, n_features_per_level=8, log2_hashmap_size=13, log2_hashmap_size_2D=15, device=dev)
+rng = np.random.default_rng(0)
+lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
+pc.create_from_points(rng.uniform(lim, -lim, (220000, 3)), 1.0)
+pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+pc.training_setup(opt)
+tr = Trainer(pc, cube, opt, pipe, mp_)
+for i in range(4):
+    tr.step(i + 1, frame_idx=30)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    for i in range(3):
+        tr.step(10 + i, frame_idx=30)
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=60))
