@@ -2,194 +2,240 @@
 //
 // The generator / deformation / entropy-parameter MLPs of GSVC (reference scene/gaussian_model.py:150-232,
 // 411-501) are chains of nn.Linear with K, N <= 192 applied to ~50k-200k anchor rows per step.  Those GEMMs are
-// tall and skinny (arithmetic intensity ~25 FLOP/B): they are HBM-bound, and the library GEMM reached only ~7 TF
-// (520 us for 196k x 100 x 100).  This kernel streams X once and writes Y once:
-//   one workgroup = 4 waves = 64 rows; W and X are staged through LDS in K-chunks of 64 (row stride 66 dwords:
-//   conflict-free for the MFMA fragment reads); each wave owns 16 rows x all N columns as N/16 accumulators of
-//   v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate — same numerics class as the reference's fp32
-//   GEMM, different summation order).
+// tall and skinny (arithmetic intensity 12-48 FLOP/B): between the HBM and the fp32-MFMA roofs, and the library
+// GEMM reached only 7-30 TF on them.  v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate — same
+// numerics class as the reference's fp32 GEMM, different summation order.
 #include "common.h"
 
 namespace gsvc {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int LIN_KC = 64;          // K chunk staged in LDS
-constexpr int LIN_LD = LIN_KC + 2;  // LDS row stride in dwords
-constexpr int LIN_ROWS = 64;        // rows per workgroup
-constexpr int LIN_NT_MAX = 12;      // N <= 192
-
-// Stage `rows` x `cols_pad` floats of a row-major matrix (leading dimension ld_src, valid columns [c0, c0+cols),
-// valid rows < nrows_valid) into LDS with row stride ld_dst; everything outside is zero-filled.  8-byte loads when
-// the source rows are 8-byte aligned (ld_src and c0 even), 4-byte loads otherwise.
-__device__ __forceinline__ void stage_tile(const float *__restrict__ src, long long row0, long long nrows_valid, int rows,
-                                           int c0, int cols, int cols_pad, int ld_src, float *__restrict__ dst, int ld_dst,
-                                           int tid)
-{
-    if (((ld_src | c0) & 1) == 0) {
-        const int half = cols_pad >> 1;                 // float2 per row
-        for (int i = tid; i < rows * half; i += 256) {
-            const int r = i / half, c = 2 * (i - r * half);
-            const long long gr = row0 + r;
-            float2 v = make_float2(0.f, 0.f);
-            if (gr < nrows_valid) {
-                if (c + 1 < cols) v = *reinterpret_cast<const float2 *>(src + gr * ld_src + c0 + c);
-                else if (c < cols) v.x = src[gr * ld_src + c0 + c];
-            }
-            *reinterpret_cast<float2 *>(dst + r * ld_dst + c) = v;
-        }
-    } else {
-        for (int i = tid; i < rows * cols_pad; i += 256) {
-            const int r = i / cols_pad, c = i - r * cols_pad;
-            const long long gr = row0 + r;
-            dst[r * ld_dst + c] = (gr < nrows_valid && c < cols) ? src[gr * ld_src + c0 + c] : 0.f;
-        }
-    }
-}
-
-template <int NT>
-__global__ void __launch_bounds__(256) k_linear_fwd(const float *__restrict__ X, const float *__restrict__ W,
-                                                    const float *__restrict__ bias, float *__restrict__ Y, long long M,
-                                                    int K, int N)
-{
-    extern __shared__ float lds[];
-    float *sX = lds;                        // [64][LIN_LD]
-    float *sW = lds + LIN_ROWS * LIN_LD;    // [NT*16][LIN_LD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long row0 = (long long)blockIdx.x * LIN_ROWS;
-    const int frag_r = lane & 15, frag_k = lane >> 4;
-    v4f acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-    for (int k0 = 0; k0 < K; k0 += LIN_KC) {
-        const int kc = min(LIN_KC, K - k0);
-        __syncthreads();
-        // stage X[row0:row0+64, k0:k0+kc] and W[0:N, k0:k0+kc]; zero-fill the K tail and the N padding
-        stage_tile(X, row0, M, LIN_ROWS, k0, kc, LIN_KC, K, sX, LIN_LD, tid);
-        stage_tile(W, 0, N, NT * 16, k0, kc, LIN_KC, K, sW, LIN_LD, tid);
-        __syncthreads();
-        const float *xa = sX + (wave * 16 + frag_r) * LIN_LD + frag_k;
-        const float *wb = sW + frag_r * LIN_LD + frag_k;
-        const int kend = (kc + 3) & ~3;
-        for (int kk = 0; kk < kend; kk += 4) {
-            const float a = xa[kk];
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const float b = wb[t * 16 * LIN_LD + kk];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
-            }
-        }
-    }
-    // D fragment: lane holds rows 4*(lane/16)+i (i=0..3) of column lane%16
-    const int col_in = lane & 15, rbase = 4 * (lane >> 4);
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const int col = t * 16 + col_in;
-        if (col < N) {
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const long long gr = row0 + wave * 16 + rbase + i;
-                if (gr < M) Y[gr * N + col] = acc[t][i] + bv;
-            }
-        }
-    }
-}
-
-template <int NT>
-static void launch_linear(const float *X, const float *W, const float *b, float *Y, long long M, int K, int N,
-                          hipStream_t s)
-{
-    const size_t lds = (size_t)(LIN_ROWS + NT * 16) * LIN_LD * sizeof(float);
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_fwd<NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    ProfScope _prof("k_linear_fwd", s);
-    hipLaunchKernelGGL((k_linear_fwd<NT>), dim3((unsigned)((M + LIN_ROWS - 1) / LIN_ROWS)), dim3(256), lds, s, X, W, b, Y,
-                       M, K, N);
-}
+constexpr int LIN_NT_MAX = 12;      // K, N <= 192
 
 // ---------------------------------------------------------------------------------------------------------
-// Weight gradient dW[N,K] += G[M,N]^T X[M,K]: a reduction over the M (anchor) dimension with a tiny output.  The
-// library GEMM tiles the OUTPUT (32x32 tiles -> a dozen workgroups on a 256-CU chip, 520 us at M = 196k); here the
-// workgroups split M instead: each walks its share of the rows in chunks of 64 staged in LDS, keeps the whole
-// N x K product in MFMA accumulators (tiles dealt round-robin to the 4 waves), and adds its partial to dW with
-// contiguous float atomics (64-byte segments).
-constexpr int WG_ROWS = 64;
+// Weight-stationary: the whole zero-padded weight matrix sits in LDS for the life
+// of a persistent workgroup (<= 150 KiB of the 160 KiB), and X never touches LDS: each wave owns 16-row blocks and
+// reads them straight into MFMA A fragments, one 16-byte load per lane per 16 k's, the next row block in flight
+// while the current one is multiplied.  The four k's of an MFMA step may be ANY four k's as long as A and B agree,
+// so lane (r, kq) takes X[r][16g + 4kq .. +3] as one float4 and the matching B fragment is one ds_read_b128 of
+// W[n][16g + 4kq .. +3]; the i-th component of both feeds the i-th MFMA of the group.  The LDS row stride is
+// 8 (mod 64) dwords, which makes those b128 reads conflict-free for the hardware's 16-lane groups.
+// Per 16 rows x 16 k's x 16 columns: one 4-cycle LDS read per four 32-cycle MFMAs -> the kernel is bound by MFMA
+// issue (K, N ~ 192) or by the HBM stream of X and Y (K, N <= 100).
+__host__ __device__ inline int ws_ld(int K) { return ((K + 63) / 64) * 64 + 8; }
 
-template <int TPW>  // accumulator tiles (16x16) per wave
-__global__ void __launch_bounds__(256) k_linear_wgrad(const float *__restrict__ G, const float *__restrict__ X,
-                                                      float *__restrict__ dW, long long M, int N, int K, int ldg, int ldx)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int BUF_OOB = 0x7fffffff;     // a byte offset past any descriptor's range: loads return 0, stores are dropped
+
+// Fragment load through a buffer descriptor that covers exactly the valid rows of one 16-row block: rows past M
+// and (by the explicit offset select) k's past K come back as zeros from the hardware range check — no branches,
+// no clamps, so the compiler counts outstanding loads exactly and the loads can stay in flight across the MFMAs.
+template <int VEC, bool CHECK>
+__device__ __forceinline__ float4 ws_load_a(__amdgpu_buffer_rsrc_t rs, int off, int k0, int K)
+{
+    // off = byte offset of X[row][k0] inside the block; CHECK = this k-group may reach past K (only the last two can)
+    float4 v;
+    if (VEC == 4) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (!CHECK || k0 < K) ? off : BUF_OOB, 0, 0);
+        v = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+    } else if (VEC == 2) {
+        const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rs, (!CHECK || k0 < K) ? off : BUF_OOB, 0, 0);
+        const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rs, (!CHECK || k0 + 2 < K) ? off + 8 : BUF_OOB, 0, 0);
+        v = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y));
+    } else {
+        const unsigned x0 = __builtin_amdgcn_raw_buffer_load_b32(rs, (!CHECK || k0 < K) ? off : BUF_OOB, 0, 0);
+        const unsigned x1 = __builtin_amdgcn_raw_buffer_load_b32(rs, (!CHECK || k0 + 1 < K) ? off + 4 : BUF_OOB, 0, 0);
+        const unsigned x2 = __builtin_amdgcn_raw_buffer_load_b32(rs, (!CHECK || k0 + 2 < K) ? off + 8 : BUF_OOB, 0, 0);
+        const unsigned x3 = __builtin_amdgcn_raw_buffer_load_b32(rs, (!CHECK || k0 + 3 < K) ? off + 12 : BUF_OOB, 0, 0);
+        v = make_float4(__uint_as_float(x0), __uint_as_float(x1), __uint_as_float(x2), __uint_as_float(x3));
+    }
+    return v;
+}
+
+// All KGM fragments of one row block.  Groups 0..KGM-3 are always whole (K > 16 (KGM-2)), so their offsets are
+// one VGPR plus an instruction immediate.
+template <int VEC, int KGM>
+__device__ __forceinline__ float4 ws_load_group(__amdgpu_buffer_rsrc_t rs, int voff, int kq, int K, int g)
+{
+    if (g < KGM - 2) return ws_load_a<VEC, false>(rs, voff + 64 * g, 16 * g + 4 * kq, K);
+    return ws_load_a<VEC, true>(rs, voff + 64 * g, 16 * g + 4 * kq, K);
+}
+
+// Descriptor of the 16-row block `rb` of a row-major [M][ld] float matrix (zero bytes when rb is past the end).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_block_rsrc(const float *base, long long rb, long long RB, long long M, int ld)
+{
+    const long long rows = rb < RB ? min((long long)16, M - rb * 16) : 0;
+    const float *p = base + (rb < RB ? rb : 0) * 16 * ld;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(p) & 0xffffffffu));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(p) >> 32));
+    const int bytes = __builtin_amdgcn_readfirstlane((int)(rows * ld * 4));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+
+// NT = ceil(N/16) column tiles, KGM = compile-time bound on ceil(K/16), VEC = widest aligned load of an X row.
+// THREADS = 1024 (4 waves per SIMD, 128 VGPRs) for the small shapes, 512 (2 waves per SIMD, 256 VGPRs) for the
+// large ones.  Software pipeline without extra registers: as soon as the MFMAs of k-group g have consumed a[g],
+// a[g] is reloaded with the NEXT row block's fragment, so the X stream overlaps the rest of the multiply and the
+// store of the current block.
+// w_in_out != 0: W is given as [K][N] (input-major), i.e. Y = X W — the dX = G W product of the backward pass
+// without a transposed copy of W.
+template <int NT, int KGM, int VEC, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_linear_ws(const float *__restrict__ X, const float *__restrict__ W,
+                                                       const float *__restrict__ bias, float *__restrict__ Y,
+                                                       long long M, int K, int N, int w_in_out, int relu)
 {
     extern __shared__ float lds[];
-    float *sG = lds;                 // [64][ldg]
-    float *sX = lds + WG_ROWS * ldg;  // [64][ldx]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = (N + 15) / 16, kt = (K + 15) / 16, tiles = nt * kt;
-    const int frag_c = lane & 15, frag_r = lane >> 4;
-    v4f acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; t++) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    constexpr int WAVES = THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, kq = lane >> 4;
+    const int ld = ws_ld(K), KG = (K + 15) >> 4, k16 = KG * 16;
+    const long long RB = (M + 15) >> 4, stride = (long long)gridDim.x * WAVES;
+    long long rb = (long long)blockIdx.x * WAVES + wave;
 
-    const long long chunks = (M + WG_ROWS - 1) / WG_ROWS;
-    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
-        const long long row0 = ch * WG_ROWS;
-        __syncthreads();
-        stage_tile(G, row0, M, WG_ROWS, 0, N, nt * 16, N, sG, ldg, tid);
-        stage_tile(X, row0, M, WG_ROWS, 0, K, kt * 16, K, sX, ldx, tid);
-        __syncthreads();
+    // first row block's fragments fly while the weights are staged
+    float4 a[KGM];
+    const int voff = fr * K * 4 + 16 * kq;
+    {
+        const __amdgpu_buffer_rsrc_t rx = ws_block_rsrc(X, rb, RB, M, K);
 #pragma unroll
-        for (int t = 0; t < TPW; t++) {
-            const int tile = wave + 4 * t;          // wave-uniform
-            if (tile < tiles) {
-                const int tn = tile / kt, tk = tile - tn * kt;
-                const float *ga = sG + frag_r * ldg + tn * 16 + frag_c;
-                const float *xb = sX + frag_r * ldx + tk * 16 + frag_c;
-                v4f c = acc[t];
-#pragma unroll 4
-                for (int m4 = 0; m4 < WG_ROWS; m4 += 4)
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[m4 * ldg], xb[m4 * ldx], c, 0, 0, 0);
-                acc[t] = c;
+        for (int g = 0; g < KGM; g++) a[g] = ws_load_group<VEC, KGM>(rx, voff, kq, K, g);
+    }
+    {
+        const int total = k16 * NT * 16;
+        for (int base = tid; base < total; base += THREADS * 8) {
+            float v[8];
+            int dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = base + u * THREADS;
+                int n, k;
+                if (w_in_out) { k = i / (NT * 16); n = i - k * (NT * 16); }
+                else { n = i / k16; k = i - n * k16; }
+                const bool ok = i < total && n < N && k < K;
+                const size_t src = w_in_out ? (size_t)k * N + n : (size_t)n * K + k;
+                v[u] = ok ? W[src] : 0.f;
+                dst[u] = i < total ? n * ld + k : -1;
             }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (dst[u] >= 0) lds[dst[u]] = v[u];
         }
     }
-    const int col_in = lane & 15, rbase = 4 * (lane >> 4);
+    float *sbias = lds + NT * 16 * ld;     // bias (zero-padded) behind the weights: read back with ds_read, not VGPR-resident
+    if (tid < NT * 16) sbias[tid] = (bias && tid < N) ? bias[tid] : 0.f;
+    __syncthreads();
+    // everything loaded so far has landed before the loop starts: inside it the only outstanding memory operations
+    // are the loop's own, which lets the compiler wait for exactly the fragment it needs (vmcnt(n), not vmcnt(0))
 #pragma unroll
-    for (int t = 0; t < TPW; t++) {
-        const int tile = wave + 4 * t;
-        if (tile < tiles) {
-            const int tn = tile / kt, tk = tile - tn * kt;
-            const int k = tk * 16 + col_in;
+    for (int g = 0; g < KGM; g++) asm volatile("" : "+v"(a[g].x), "+v"(a[g].y), "+v"(a[g].z), "+v"(a[g].w));
+
+    const float *wb = lds + fr * ld + 4 * kq;
+    int yoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) yoff[i] = ((4 * kq + i) * N + fr) * 4;
+    for (; rb < RB; rb += stride) {
+        const __amdgpu_buffer_rsrc_t rx = ws_block_rsrc(X, rb + stride, RB, M, K);   // empty past the end
+        v4f acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < KGM; g++) {
+            if (g < KGM - 1 || g < KG) {      // KG is KGM or KGM-1: only the last group is a run-time decision
+                const float4 ag = a[g];
+#pragma unroll
+                for (int t0 = 0; t0 < NT; t0 += 4) {
+                    float4 b[4];
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++)
+                        if (t0 + tt < NT) b[tt] = *reinterpret_cast<const float4 *>(wb + (t0 + tt) * 16 * ld + 16 * g);
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++)
+                        if (t0 + tt < NT) acc[t0 + tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag.x, b[tt].x, acc[t0 + tt], 0, 0, 0);
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++)
+                        if (t0 + tt < NT) acc[t0 + tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag.y, b[tt].y, acc[t0 + tt], 0, 0, 0);
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++)
+                        if (t0 + tt < NT) acc[t0 + tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag.z, b[tt].z, acc[t0 + tt], 0, 0, 0);
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++)
+                        if (t0 + tt < NT) acc[t0 + tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag.w, b[tt].w, acc[t0 + tt], 0, 0, 0);
+                }
+                a[g] = ws_load_group<VEC, KGM>(rx, voff, kq, K, g);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the groups in order: hoisting every B read blows the VGPR budget
+        }
+        // D fragment: lane holds rows 4*(lane/16)+i (i=0..3) of column lane%16; rows past M fall outside the
+        // descriptor and are dropped by the range check, padded columns are sent out of range explicitly
+        const __amdgpu_buffer_rsrc_t ry = ws_block_rsrc(Y, rb, RB, M, N);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const bool in = t < NT - 1 || t * 16 + fr < N;
+            const float bvt = sbias[t * 16 + fr];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int n = tn * 16 + rbase + i;
-                if (n < N && k < K) atomicAdd(dW + (size_t)n * K + k, acc[t][i]);
+                float v = acc[t][i] + bvt;
+                if (relu) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, in ? yoff[i] + 64 * t : BUF_OOB, 0, 0);
             }
         }
     }
 }
 
-template <int TPW>
-static void launch_wgrad(const float *G, const float *X, float *dW, long long M, int N, int K, hipStream_t s)
+template <int NT, int KGM, int VEC, int THREADS>
+static void launch_ws4(const float *X, const float *W, const float *b, float *Y, long long M, int K, int N, int w_in_out,
+                       int relu, hipStream_t s)
 {
-    const int nt = (N + 15) / 16, kt = (K + 15) / 16;
-    const int ldg = nt * 16 + ((nt & 1) ? 0 : 16);  // row stride = 16 (mod 32) dwords: conflict-free fragment reads
-    const int ldx = kt * 16 + ((kt & 1) ? 0 : 16);
-    const size_t lds = (size_t)WG_ROWS * (ldg + ldx) * sizeof(float);
+    const size_t lds = (size_t)NT * 16 * (ws_ld(K) + 1) * sizeof(float);
     static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_wgrad<TPW>),
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_ws<NT, KGM, VEC, THREADS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const long long chunks = (M + WG_ROWS - 1) / WG_ROWS;
-    const unsigned grid = (unsigned)(chunks < 512 ? chunks : 512);
-    ProfScope _prof("k_linear_wgrad", s);
-    hipLaunchKernelGGL((k_linear_wgrad<TPW>), dim3(grid), dim3(256), lds, s, G, X, dW, M, N, K, ldg, ldx);
+    constexpr int WAVES = THREADS / 64;
+    const long long RB = (M + 15) / 16, want = (RB + WAVES - 1) / WAVES;
+    const unsigned grid = (unsigned)(want < 256 ? want : 256);      // persistent: one workgroup per CU
+    ProfScope _prof("k_linear_ws", s);
+    hipLaunchKernelGGL((k_linear_ws<NT, KGM, VEC, THREADS>), dim3(grid), dim3(THREADS), lds, s, X, W, b, Y, M, K, N,
+                       w_in_out, relu);
+}
+
+template <int NT, int KGM, int VEC>
+static void launch_ws3(const float *X, const float *W, const float *b, float *Y, long long M, int K, int N, int w_in_out,
+                       int relu, hipStream_t s)
+{
+    // 1024 threads leave 128 VGPRs per lane: accumulators + A fragments + addressing must fit without spilling
+    constexpr int budget = (VEC == 4 ? 60 : (VEC == 2 ? 52 : 40)) - (NT > 8 ? 8 : 0);
+    if constexpr (NT * 4 + KGM * 4 <= budget) launch_ws4<NT, KGM, VEC, 1024>(X, W, b, Y, M, K, N, w_in_out, relu, s);
+    else launch_ws4<NT, KGM, VEC, 512>(X, W, b, Y, M, K, N, w_in_out, relu, s);
+}
+
+template <int NT, int KGM>
+static void launch_ws2(const float *X, const float *W, const float *b, float *Y, long long M, int K, int N, int w_in_out,
+                       int relu, hipStream_t s)
+{
+    const bool a16 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const bool a8 = (K % 2 == 0) && ((reinterpret_cast<uintptr_t>(X) & 7) == 0);
+    if (a16) launch_ws3<NT, KGM, 4>(X, W, b, Y, M, K, N, w_in_out, relu, s);
+    else if (a8) launch_ws3<NT, KGM, 2>(X, W, b, Y, M, K, N, w_in_out, relu, s);
+    else launch_ws3<NT, KGM, 1>(X, W, b, Y, M, K, N, w_in_out, relu, s);
+}
+
+template <int NT>
+static void launch_ws(const float *X, const float *W, const float *b, float *Y, long long M, int K, int N, int w_in_out,
+                      int relu, hipStream_t s)
+{
+    const int kg = (K + 15) / 16;
+    if (kg <= 2) launch_ws2<NT, 2>(X, W, b, Y, M, K, N, w_in_out, relu, s);
+    else if (kg <= 4) launch_ws2<NT, 4>(X, W, b, Y, M, K, N, w_in_out, relu, s);
+    else if (kg <= 6) launch_ws2<NT, 6>(X, W, b, Y, M, K, N, w_in_out, relu, s);
+    else if (kg <= 8) launch_ws2<NT, 8>(X, W, b, Y, M, K, N, w_in_out, relu, s);
+    else if (kg <= 10) launch_ws2<NT, 10>(X, W, b, Y, M, K, N, w_in_out, relu, s);
+    else launch_ws2<NT, 12>(X, W, b, Y, M, K, N, w_in_out, relu, s);
 }
 
 }  // namespace gsvc
@@ -197,50 +243,29 @@ static void launch_wgrad(const float *G, const float *X, float *dW, long long M,
 using namespace gsvc;
 
 extern "C" int gsvc_linear_forward(const float *X, const float *W, const float *bias, float *Y, int64_t M, int32_t K,
-                                   int32_t N, void *stream)
+                                      int32_t N, int32_t w_in_out, int32_t relu, void *stream)
 {
     GSVC_REQUIRE(M >= 0 && K > 0 && N > 0, "linear_forward: bad shape");
-    if (N > LIN_NT_MAX * 16) {
-        set_error("linear_forward: N=%d exceeds %d", N, LIN_NT_MAX * 16);
+    if (N > LIN_NT_MAX * 16 || K > LIN_NT_MAX * 16) {
+        set_error("linear_forward: N=%d / K=%d exceed %d", N, K, LIN_NT_MAX * 16);
         return GSVC_E_UNSUPPORTED;
     }
     if (M == 0) return GSVC_OK;
     GSVC_REQUIRE(X && W && Y, "linear_forward: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int nt = (N + 15) / 16;
-    switch (nt) {
-        case 1: launch_linear<1>(X, W, bias, Y, M, K, N, s); break;
-        case 2: launch_linear<2>(X, W, bias, Y, M, K, N, s); break;
-        case 3: launch_linear<3>(X, W, bias, Y, M, K, N, s); break;
-        case 4: launch_linear<4>(X, W, bias, Y, M, K, N, s); break;
-        case 5: launch_linear<5>(X, W, bias, Y, M, K, N, s); break;
-        case 6: launch_linear<6>(X, W, bias, Y, M, K, N, s); break;
-        case 7: launch_linear<7>(X, W, bias, Y, M, K, N, s); break;
-        case 8: launch_linear<8>(X, W, bias, Y, M, K, N, s); break;
-        case 9: launch_linear<9>(X, W, bias, Y, M, K, N, s); break;
-        case 10: launch_linear<10>(X, W, bias, Y, M, K, N, s); break;
-        case 11: launch_linear<11>(X, W, bias, Y, M, K, N, s); break;
-        default: launch_linear<12>(X, W, bias, Y, M, K, N, s); break;
+    switch ((N + 15) / 16) {
+        case 1: launch_ws<1>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
+        case 2: launch_ws<2>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
+        case 3: launch_ws<3>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
+        case 4: launch_ws<4>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
+        case 5: launch_ws<5>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
+        case 6: launch_ws<6>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
+        case 7: launch_ws<7>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
+        case 8: launch_ws<8>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
+        case 9: launch_ws<9>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
+        case 10: launch_ws<10>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
+        case 11: launch_ws<11>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
+        default: launch_ws<12>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
     }
     return check_launch("linear_forward");
-}
-
-extern "C" int gsvc_linear_wgrad(const float *G, const float *X, float *dW, int64_t M, int32_t N, int32_t K, void *stream)
-{
-    GSVC_REQUIRE(M >= 0 && K > 0 && N > 0, "linear_wgrad: bad shape");
-    if (N > LIN_NT_MAX * 16 || K > LIN_NT_MAX * 16) {
-        set_error("linear_wgrad: N=%d / K=%d exceed %d", N, K, LIN_NT_MAX * 16);
-        return GSVC_E_UNSUPPORTED;
-    }
-    if (M == 0) return GSVC_OK;
-    GSVC_REQUIRE(G && X && dW, "linear_wgrad: NULL pointer");
-    hipStream_t s = (hipStream_t)stream;
-    const int tiles = ((N + 15) / 16) * ((K + 15) / 16);
-    const int tpw = (tiles + 3) / 4;
-    if (tpw <= 4) launch_wgrad<4>(G, X, dW, M, N, K, s);
-    else if (tpw <= 9) launch_wgrad<9>(G, X, dW, M, N, K, s);
-    else if (tpw <= 16) launch_wgrad<16>(G, X, dW, M, N, K, s);
-    else if (tpw <= 25) launch_wgrad<25>(G, X, dW, M, N, K, s);
-    else launch_wgrad<36>(G, X, dW, M, N, K, s);
-    return check_launch("linear_wgrad");
 }

@@ -61,44 +61,47 @@ class Mix3d2dEncoding(nn.Module):
         return torch.cat([self.encoding_xyz(x), self.encoding_xy(xy), self.encoding_xz(xz), self.encoding_yz(yz)], dim=-1)
 
 
+MFMA_MAX_DIM = 192      # csrc/linear.hip keeps the whole weight matrix in LDS: in/out features <= 192
+
+
 class _LinearMFMA(torch.autograd.Function):
-    """y = x W^T + b through csrc/linear.hip (tall-skinny fp32 MFMA); backward with the library GEMMs."""
+    """y = x W^T + b (optionally followed by ReLU) through the weight-stationary MFMA kernel of csrc/linear.hip.
+    Backward: dX = G W through the same kernel (W read input-major, no transposed copy), dW by the M-split batched
+    GEMM of ``_weight_grad``, db by a column sum."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, relu=False):
         from . import _lib
         x, w = x.contiguous(), weight.contiguous()
         M, K = x.shape
         N = w.shape[0]
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
         b = bias.contiguous() if bias is not None else None
-        _lib.check(_lib.lib().gsvc_linear_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, K, N,
-                                                  _lib.current_stream(x.device)), "gsvc_linear_forward")
-        ctx.save_for_backward(x, w)
+        _lib.check(_lib.lib().gsvc_linear_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, K, N, 0, int(relu),
+                                                     _lib.current_stream(x.device)), "gsvc_linear_forward")
+        ctx.save_for_backward(x, w, y if relu else None)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, g):
         from . import _lib
-        x, w = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
+        if y is not None:
+            g = torch.ops.aten.threshold_backward(g, y, 0.0)     # ReLU': pass where the output was > 0
         g = g.contiguous()
         M, K = x.shape
         N = w.shape[0]
-        L, st = _lib.lib(), _lib.current_stream(x.device)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            if K <= 192:      # dX = G W = linear(G, W^T)
-                gx = torch.empty(M, K, device=x.device, dtype=torch.float32)
-                wt = w.t().contiguous()
-                _lib.check(L.gsvc_linear_forward(_lib.ptr(g), _lib.ptr(wt), None, _lib.ptr(gx), M, N, K, st), "gsvc_linear_forward")
-            else:
-                gx = g @ w
+            gx = torch.empty(M, K, device=x.device, dtype=torch.float32)
+            _lib.check(_lib.lib().gsvc_linear_forward(_lib.ptr(g), _lib.ptr(w), None, _lib.ptr(gx), M, N, K, 1, 0,
+                                                         _lib.current_stream(x.device)), "gsvc_linear_forward")
         if ctx.needs_input_grad[1]:
             gw = _weight_grad(g, x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(dim=0)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 def _weight_grad(g, x, rows_per_slice: int = 4096):
@@ -121,11 +124,38 @@ class Linear(nn.Linear):
 
     MIN_ROWS = 4096
 
+    def _use_mfma(self, x):
+        return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= self.MIN_ROWS
+                and self.out_features <= MFMA_MAX_DIM and self.in_features <= MFMA_MAX_DIM)
+
     def forward(self, x):
-        if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= self.MIN_ROWS
-                and self.out_features <= 192):
+        if self._use_mfma(x):
             return _LinearMFMA.apply(x, self.weight, self.bias)
         return super().forward(x)
+
+    def forward_relu(self, x):
+        """relu(linear(x)) with the ReLU fused into the kernel's store."""
+        if self._use_mfma(x):
+            return _LinearMFMA.apply(x, self.weight, self.bias, True)
+        return torch.relu(super().forward(x))
+
+
+class Sequential(nn.Sequential):
+    """nn.Sequential (same child names, hence the reference's state_dict keys) that runs each Linear -> ReLU pair
+    as one fused call."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                x = m.forward_relu(x)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 class FiLM(nn.Module):
@@ -140,8 +170,8 @@ class FiLM(nn.Module):
         self.act = nn.ReLU()
 
     def forward(self, x, condition):
-        gamma = self.fc_gamma1(self.act(self.fc_gamma0(condition)))
-        beta = self.fc_beta1(self.act(self.fc_beta0(condition)))
+        gamma = self.fc_gamma1(self.fc_gamma0.forward_relu(condition))
+        beta = self.fc_beta1(self.fc_beta0.forward_relu(condition))
         return gamma * x + beta
 
 

@@ -191,13 +191,12 @@ int gsvc_ssim_l1_backward(const float *img1, const float *img2, int32_t C, int32
  * 150-232: every nn.Linear applied to the [anchors, features] matrix)
  * ---------------------------------------------------------------------------------------------------- */
 
-/* Y[M,N] = X[M,K] W[N,K]^T + bias[N] (bias may be NULL); fp32 MFMA, N <= 192.  torch.nn.Linear layout. */
+/* Y[M,N] = X[M,K] W[N,K]^T + bias[N] (bias may be NULL; torch.nn.Linear layout), fp32 MFMA, weight matrix resident
+ * in LDS and X streamed through registers: K, N <= 192 (GSVC_E_UNSUPPORTED beyond).
+ * w_in_out != 0: W is [K][N] (input-major), so Y = X W — the backward's dX = G W without a transposed copy.
+ * relu != 0: Y = max(Y, 0) fused into the store (the Linear -> ReLU pairs of the reference's nn.Sequential MLPs). */
 int gsvc_linear_forward(const float *X, const float *W, const float *bias, float *Y, int64_t M, int32_t K, int32_t N,
-                        void *stream);
-
-/* dW[N,K] += G[M,N]^T X[M,K] (weight gradient; dW is accumulated into with float atomics, caller zero-fills).
- * N, K <= 192.  The input gradient dX = G W is gsvc_linear_forward(G, W^T, NULL, dX, M, N, K). */
-int gsvc_linear_wgrad(const float *G, const float *X, float *dW, int64_t M, int32_t N, int32_t K, void *stream);
+                        int32_t w_in_out, int32_t relu, void *stream);
 
 #ifdef __cplusplus
 }

@@ -325,7 +325,8 @@ def test_fused_ssim_l1_matches_torch_and_reference(H, W):
 
 
 @pytest.mark.parametrize("M,K,N", [(5000, 50, 100), (4097, 116, 100), (8192, 192, 150), (4096, 100, 10), (6000, 66, 66),
-                                    (4500, 50, 1), (4096, 8, 16), (70000, 100, 70)])
+                                    (4500, 50, 1), (4096, 8, 16), (70000, 100, 70), (4103, 51, 37), (9001, 192, 192),
+                                    (5000, 3, 100), (4099, 150, 192), (4111, 177, 33), (300000, 100, 100)])
 def test_mfma_linear_matches_torch(M, K, N):
     """csrc/linear.hip (fp32 MFMA, tall-skinny) vs torch.nn.functional.linear in fp32 on the same GPU: fp32
     products and accumulation on both sides, only the summation order differs -> 1e-5 relative to the row scale."""
@@ -349,3 +350,18 @@ def test_mfma_linear_matches_torch(M, K, N):
     assert torch.allclose(gb, lin.bias.grad, rtol=1e-3, atol=1e-3 * lin.bias.grad.abs().max().item())
     # small batches and CPU tensors keep the library path
     assert torch.equal(lin(x[:10]), F.linear(x[:10], lin.weight, lin.bias))
+    # Linear -> ReLU fused into the store, and its backward
+    x.grad = None
+    lin.zero_grad()
+    yr = lin.forward_relu(x)
+    assert torch.equal(yr, torch.relu(y.detach()))
+    (yr * g).sum().backward()
+    gx2, gw2 = x.grad.clone(), lin.weight.grad.clone()
+    x.grad = None
+    lin.zero_grad()
+    # a pre-activation within rounding of 0 may land on either side of the ReLU in the two summation orders, so
+    # the reference applies the mask of the fused output
+    gm = g * (yr.detach() > 0)
+    (F.linear(x, lin.weight, lin.bias) * gm).sum().backward()
+    assert torch.allclose(gx2, x.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(gw2, lin.weight.grad, rtol=1e-3, atol=1e-3 * lin.weight.grad.abs().max().item())
