@@ -24,3 +24,7 @@ class RenderResults:
     bit_per_offsets_param: typing.Union[torch.Tensor, None] = None
     generated_gaussians: typing.Any = None
     entropy_constrained: bool = False
+    # extras of the un-compacted ("dense") batched path (render_many(dense=True)); unset otherwise
+    dense: bool = False                      # Gaussians = all K slots of every visible anchor; selection_mask marks opacity > 0
+    visible_index: typing.Union[torch.Tensor, None] = None    # int64 indices of the visible anchors
+    raster_state: typing.Any = None          # rasterizer state whose instance counters have not been read back yet

@@ -99,9 +99,15 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
     int bx0 = 0, bx1 = 0;   // x range of the binning rectangle (pair mode: union of the two views)
     bool listed = false;
     if (i < P) {
-        const float4 q = reinterpret_cast<const float4 *>(rotations)[i];
-        radius = preprocess_gaussian(st, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], scales[3 * i],
-                                     scales[3 * i + 1], scales[3 * i + 2], q.x, q.y, q.z, q.w, o);
+        // a Gaussian with opacity <= 0 can never reach alpha >= 1/255: culled here (radius 0), which lets callers
+        // pass un-compacted Gaussian sets (GSVC's "opacity > 0" selection) without a host-side compaction
+        const float op = opacities[i];
+        o.radius_raw = 0;
+        if (op > 0.0f) {
+            const float4 q = reinterpret_cast<const float4 *>(rotations)[i];
+            radius = preprocess_gaussian(st, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], scales[3 * i],
+                                         scales[3 * i + 1], scales[3 * i + 2], q.x, q.y, q.z, q.w, o);
+        }
         radii[i] = radius;
         GeomRec rec;
         BinRec br;
@@ -123,7 +129,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         }
         if (listed) {
             rec.u = o.u; rec.v = o.v; rec.A = o.A; rec.B = o.B;
-            rec.C = o.C; rec.opacity = opacities[i];
+            rec.C = o.C; rec.opacity = op;
             rec.r = colors[3 * i + 0]; rec.g = colors[3 * i + 1]; rec.b = colors[3 * i + 2];
             rec.depth = o.depth;
             alpha_bbox(o.u, o.v, o.A, o.B, o.C, rec.opacity, rec.bbox_x, rec.bbox_y);

@@ -53,6 +53,9 @@ class GeneratedGaussians:
     bit_per_offsets_param: torch.Tensor = None
     concatenated_all: torch.Tensor = None
     time_sub: float = None
+    # extras of the un-compacted ("dense") batched path, None otherwise
+    visible_index: torch.Tensor = None   # int64 indices of the visible anchors (what visable_mask.nonzero() gives)
+    world_xyz: torch.Tensor = None       # anchor + offsets * scaling[:, :3] before the bound clamp, per Gaussian
 
 
 BASE_Q_FEAT, BASE_Q_SCALING, BASE_Q_OFFSETS = 1, 0.001, 0.2
@@ -280,8 +283,14 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
                      bit_per_scaling_param=(ss / ns * kr)[r], bit_per_offsets_param=(so / no * kr)[r]) for r in range(seg.R)]
 
 
-def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.TRAINING_FULL_PRECISION):
-    """`generate_neural_gaussians` for R renders at once; returns a list of R GeneratedGaussians."""
+def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False):
+    """`generate_neural_gaussians` for R renders at once; returns a list of R GeneratedGaussians.
+
+    ``dense=True`` skips the "opacity > 0" compaction: every visible anchor contributes all K Gaussians, ``mask``
+    still marks the ones with opacity > 0, and the rasterizer culls the rest itself (csrc/raster_fwd.hip K1) — the
+    image, the gradients and every masked statistic are the same, but no tensor shape depends on device data, so
+    the step runs without a host synchronisation between the visibility test and the optimizer.
+    ``concatenated_all`` is not materialised in that form (``world_xyz`` carries what the optical-flow loss reads)."""
     R = len(frames)
     K = pc.n_offsets
     vis_list = [_as_index(m) for m in visible_masks]
@@ -333,6 +342,21 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     scale_rot = pc.get_cov_mlp(feat, pe).reshape(rows * K, 7)
     neural_offset = pc.get_deform_mlp(torch.cat([feat, pe], dim=1)).reshape(rows * K, 3)
     offsets = grid_offsets.view(-1, 3) + neural_offset
+    if dense:
+        gs3 = grid_scaling.view(rows, 1, 6)
+        scaling = (gs3[:, :, 3:] * torch.sigmoid(scale_rot[:, :3]).view(rows, K, 3)).reshape(rows * K, 3)
+        rot = pc.rotation_activation(scale_rot[:, 3:7])
+        world = (anchor.view(rows, 1, 3) + offsets.view(rows, K, 3) * gs3[:, :, :3]).reshape(rows * K, 3)
+        xyz = torch.clamp(world, pc.x_bound_min, pc.x_bound_max)
+        out = []
+        for r, (rs, gs) in enumerate(zip(seg.slices(), seg.slices(K))):
+            out.append(GeneratedGaussians(
+                xyz=xyz[gs], color=color[gs], opacity=neural_opacity[gs], scaling=scaling[gs], rot=rot[gs],
+                neural_opacity=neural_opacity[gs], visable_mask=visible_masks[r], mask=mask[gs],
+                bit_per_param=rates[r].bit_per_param, bit_per_feat_param=rates[r].bit_per_feat_param,
+                bit_per_scaling_param=rates[r].bit_per_scaling_param, bit_per_offsets_param=rates[r].bit_per_offsets_param,
+                concatenated_all=None, time_sub=time_sub, visible_index=vis_list[r], world_xyz=world[gs]))
+        return out
     per_anchor = torch.cat([grid_scaling, anchor], dim=-1)
     concatenated_all = torch.cat([per_anchor.repeat_interleave(K, dim=0), color, scale_rot, offsets], dim=-1)
     alive_idx = mask.nonzero(as_tuple=False).squeeze(1)

@@ -137,8 +137,38 @@ def calc_optical_loss_one_frame(render_results1, render_results2, optical_flow, 
     return (d - uv).abs().mean(), pix, d * scale
 
 
+def _optical_loss_dense(r1, r2, optical_flow, x_min, y_min, scale, x_pix_max: int, y_pix_max: int, n_offsets=10):
+    """calc_optical_loss_one_frame for un-compacted results (render_many(dense=True)): the "alive in both renders"
+    intersection and the pairing of the two renders' Gaussians go through [anchors, K] tables indexed by anchor
+    row, and membership becomes a 0/1 weight — the same mean over the same pairs, with no compaction and therefore
+    no host synchronisation."""
+    K = n_offsets
+    dev = r1.visible_mask.device
+    A = r1.visible_mask.shape[0]
+    v1, v2 = r1.visible_index, r2.visible_index
+    m1 = r1.generated_gaussians.mask.view(-1, K)
+    m2 = r2.generated_gaussians.mask.view(-1, K)
+    alive2 = torch.zeros(A, K, dtype=torch.bool, device=dev).index_put_((v2,), m2)
+    xy2_table = torch.zeros(A, K, 2, dtype=r2.generated_gaussians.world_xyz.dtype, device=dev)
+    xy2_table = xy2_table.index_put((v2,), r2.generated_gaussians.world_xyz.view(-1, K, 3)[:, :, :2])
+    keep = (m1 & alive2.index_select(0, v1)).view(-1)                      # per Gaussian of render 1
+    xy1 = r1.generated_gaussians.world_xyz[:, :2]
+    xy2 = xy2_table.index_select(0, v1).view(-1, 2)
+    pix = ((xy1 - torch.tensor([[x_min, y_min]], dtype=xy1.dtype, device=dev)) * scale).round().long()
+    ok = (pix[:, 0] >= 0) & (pix[:, 1] >= 0) & (pix[:, 0] < x_pix_max) & (pix[:, 1] < y_pix_max)
+    w = (keep & ok).to(xy1.dtype).unsqueeze(1)
+    flow = optical_flow.permute(2, 1, 0).to(dev)
+    uv = flow[pix[:, 0].clamp(0, x_pix_max - 1), pix[:, 1].clamp(0, y_pix_max - 1), ...] / scale
+    d = xy2 - xy1
+    return ((d - uv).abs() * w).sum() / (2.0 * w.sum())
+
+
 def calc_optical_loss(render_results1_f, render_results1_b, render_results2_f, render_results2_b, optical_flow,
                       x_min, y_min, scale, x_pix_max: int, y_pix_max: int, n_offsets=10):
+    if render_results1_f.dense:
+        args = (optical_flow, x_min, y_min, scale, x_pix_max, y_pix_max, n_offsets)
+        return (_optical_loss_dense(render_results1_f, render_results2_f, *args)
+                + _optical_loss_dense(render_results1_b, render_results2_b, *args))
     lf, _, _ = calc_optical_loss_one_frame(render_results1_f, render_results2_f, optical_flow, x_min, y_min, scale,
                                            x_pix_max, y_pix_max, n_offsets)
     lb, _, _ = calc_optical_loss_one_frame(render_results1_b, render_results2_b, optical_flow, x_min, y_min, scale,

@@ -459,8 +459,20 @@ class GaussianModel(nn.Module):
         """Accumulate, through the nested masks visible anchor -> opacity>0 -> radius>0: per-anchor positive
         opacity sums and visit counts, per-offset screen-gradient norms and counts."""
         K = self.n_offsets
-        vis = render_results.visible_mask
         op = render_results.neural_opacity.detach().view(-1).clamp_min(0).view(-1, K)
+        if render_results.dense:
+            # un-compacted results: every visible anchor carries its K slots, so the nested masks become weights and
+            # the scatter is by anchor row — no boolean indexing, no host synchronisation
+            vi = render_results.visible_index
+            A = self.opacity_accum.shape[0]
+            self.opacity_accum.index_add_(0, vi, op.sum(dim=1, keepdim=True))
+            self.anchor_demon.index_add_(0, vi, torch.ones(vi.shape[0], 1, device=vi.device, dtype=self.anchor_demon.dtype))
+            w = render_results.visibility_filter.to(self.offset_denom.dtype).view(-1, K)
+            gn = torch.norm(render_results.viewspace_points.grad[:, :2], dim=-1).view(-1, K) * w
+            self.offset_gradient_accum.view(A, K).index_add_(0, vi, gn.to(self.offset_gradient_accum.dtype))
+            self.offset_denom.view(A, K).index_add_(0, vi, w)
+            return
+        vis = render_results.visible_mask
         self.opacity_accum[vis] += op.sum(dim=1, keepdim=True)
         self.anchor_demon[vis] += 1
         # flat (anchor*K + slot) index of every rasterised Gaussian that ended up with radius > 0

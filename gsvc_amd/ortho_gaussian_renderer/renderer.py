@@ -37,12 +37,18 @@ def render(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain
 
 
 def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain_grad=False,
-                mode=GenerateMode.TRAINING_FULL_PRECISION):
+                mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False):
     """`render` for several frames/views of one step: the anchor -> Gaussian generation of all of them runs as
     one batch (gsvc_amd.generate.generate_neural_gaussians_many), then each view is rasterized.  Returns a list
-    of RenderResults with the same fields `render` fills."""
+    of RenderResults with the same fields `render` fills.
+
+    ``dense=True``: no "opacity > 0" compaction and no read-back of the rasterizer's counters — the per-Gaussian
+    fields (viewspace_points, radii, visibility_filter, scaling) cover all K slots of every visible anchor,
+    ``selection_mask`` marks the slots with opacity > 0 (the others get radius 0), ``num_rendered`` is None until
+    ``gsvc_amd.rasterizer.resolve_deferred([r.raster_state ...])`` is called, which the caller MUST do (it is the
+    overflow check) before trusting the images."""
     visible = [prefilter_voxel(f, pc, pipe, bg_color) for f in frames]
-    gss_list = generate_neural_gaussians_many(frames, pc, visible, mode)
+    gss_list = generate_neural_gaussians_many(frames, pc, visible, mode, dense=dense)
     results = []
     for frame, visible_mask, gss in zip(frames, visible, gss_list):
         screenspace_points = torch.zeros_like(gss.xyz, dtype=pc.get_anchor.dtype, requires_grad=True) + 0
@@ -52,16 +58,19 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
             except Exception:
                 pass
         rasterizer = GaussianRasterizer(raster_settings=raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier))
+        rasterizer.deferred = dense
         rendered_image, radii, num_rendered = rasterizer(
             means3D=gss.xyz, means2D=screenspace_points, shs=None, colors_precomp=gss.color, opacities=gss.opacity,
             scales=gss.scaling, rotations=gss.rot, cov3D_precomp=None)
         results.append(RenderResults(
             rendered_image=rendered_image, viewspace_points=screenspace_points, visibility_filter=radii > 0,
-            visible_mask=visible_mask, radii=radii, active_gaussains=(radii > 0).sum(), num_rendered=num_rendered,
+            visible_mask=visible_mask, radii=radii, active_gaussains=(radii > 0).sum(),
+            num_rendered=None if dense else num_rendered,
             selection_mask=gss.mask, neural_opacity=gss.neural_opacity, scaling=gss.scaling,
             bit_per_param=gss.bit_per_param, bit_per_feat_param=gss.bit_per_feat_param,
             bit_per_scaling_param=gss.bit_per_scaling_param, bit_per_offsets_param=gss.bit_per_offsets_param,
-            entropy_constrained=(gss.bit_per_param is not None), generated_gaussians=gss, time_sub=gss.time_sub))
+            entropy_constrained=(gss.bit_per_param is not None), generated_gaussians=gss, time_sub=gss.time_sub,
+            dense=dense, visible_index=gss.visible_index, raster_state=num_rendered if dense else None))
     return results
 
 

@@ -147,12 +147,28 @@ def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales,
         max_instances = int(n * 1.25) + 1024
 
 
+def resolve_deferred(states):
+    """Read back, with ONE host synchronisation, the instance counters of forwards launched with ``sync=False``.
+    Returns (num_rendered list, overflowed: bool); on overflow the capacity hint is raised so that repeating the
+    forwards succeeds — their images (and anything computed from them) must be discarded."""
+    if not states:
+        return [], False
+    host = torch.stack([st.binning[:16].view(torch.int32) for st in states]).tolist()
+    over = False
+    for st, c in zip(states, host):
+        st._counters = tuple(int(v) for v in c)
+        key = (st.cs.image_height, st.cs.image_width)
+        _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(c[0] * 1.25) + 1024)
+        over = over or bool(c[1])
+    return [c[0] for c in host], over
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, cs, holder):
+    def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, cs, holder, sync=True):
         means3D, colors = _as_f32(means3D, "means3D"), _as_f32(colors, "colors_precomp")
         opacities, scales, rotations = _as_f32(opacities, "opacities"), _as_f32(scales, "scales"), _as_f32(rotations, "rotations")
-        image, radii, state = raster_forward(cs, means3D, colors, opacities, scales, rotations)
+        image, radii, state = raster_forward(cs, means3D, colors, opacities, scales, rotations, sync=sync)
         ctx.state = state
         ctx.save_for_backward(means3D, colors, opacities, scales, rotations)
         ctx.mark_non_differentiable(radii)
@@ -178,7 +194,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(st.radii), _lib.ptr(st.geom), _lib.ptr(st.binning),
             _lib.ptr(st.image_state), _lib.ptr(g), _lib.ptr(d3), _lib.ptr(d2), _lib.ptr(dc), _lib.ptr(do), _lib.ptr(ds),
             _lib.ptr(dq), _lib.ptr(scratch), _lib.current_stream(dev)), "gsvc_raster_backward")
-        return d3, d2, dc, do, ds, dq, None, None
+        return d3, d2, dc, do, ds, dq, None, None, None
 
 
 class GaussianRasterizer(nn.Module):
@@ -187,6 +203,7 @@ class GaussianRasterizer(nn.Module):
         self.raster_settings = raster_settings
         self._cs = None
         self.last_state: Optional[RasterState] = None
+        self.deferred = False   # True: forward() does not read the counters back (third return value = RasterState)
 
     def _c_settings(self):
         if self._cs is None:
@@ -219,7 +236,9 @@ class GaussianRasterizer(nn.Module):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         holder = {}
         image, radii = _RasterizeGaussians.apply(means3D, means2D, colors_precomp, opacities, scales, rotations,
-                                                 self._c_settings(), holder)
+                                                 self._c_settings(), holder, not self.deferred)
         self.last_state = holder["state"]
+        if self.deferred:      # counters stay on the device: the caller resolves them with resolve_deferred()
+            return image, radii, self.last_state
         num_rendered = self.last_state.counters()[0]
         return image, radii, num_rendered

@@ -20,6 +20,7 @@ from .encodings import get_binary_vxl_size
 from .generate import GenerateMode
 from .loss_utils import calc_optical_loss, ssim_l1
 from .ortho_gaussian_renderer import render, render_many
+from .rasterizer import resolve_deferred
 from .train_util import TrainingController
 
 
@@ -45,6 +46,15 @@ def get_binary_vxl_size_device(binary_vxl):
     return ones * (-torch.log2(p)) + (total - ones) * (-torch.log2(1 - p)) + 32
 
 
+def _mean_over_selected(values, r):
+    """Mean over the Gaussians a render generated (opacity > 0): all rows of a compacted result, the rows marked
+    by ``selection_mask`` of an un-compacted one."""
+    if not r.dense:
+        return values.mean()
+    w = r.selection_mask.to(values.dtype)
+    return (values * w).sum() / w.sum()
+
+
 class Trainer:
     def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0, batched: bool = True):
         self.batched = batched
@@ -64,6 +74,16 @@ class Trainer:
         return f, b, image
 
     def step(self, iteration: int, frame_idx: int | None = None) -> StepOutput:
+        out = self._step(iteration, frame_idx)
+        if out is None:      # a rasterizer instance buffer overflowed (capacity now raised): repeat the step
+            self.pc.optimizer.zero_grad(set_to_none=True)
+            out = self._step(iteration, frame_idx)
+            if out is None:
+                raise RuntimeError("rasterizer instance buffer overflowed twice in a row")
+        self.controller.step()
+        return out
+
+    def _step(self, iteration: int, frame_idx: int | None = None):
         opt, pc = self.opt, self.pc
         dev = pc.device
         pc.update_learning_rate(iteration)
@@ -81,7 +101,8 @@ class Trainer:
                 back = copy.copy(fr)
                 back.view_matrix, back.view_matrix_s = fr.view_matrix_s, fr.view_matrix
                 views += [fr, back]
-            r1f, r1b, r2f, r2b = render_many(views, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode)
+            r1f, r1b, r2f, r2b = render_many(views, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode,
+                                             dense=True)
             image1 = (r1f.rendered_image + torch.flip(r1b.rendered_image, dims=(-1,))) / 2
             image2 = (r2f.rendered_image + torch.flip(r2b.rendered_image, dims=(-1,))) / 2
         else:
@@ -94,7 +115,7 @@ class Trainer:
         ssim2, l1_2 = ssim_l1(image2, gt2.contiguous())
         Ll1 = l1_1 + l1_2
         ssim_loss = (1.0 - ssim1) + (1.0 - ssim2)
-        scaling_reg = sum(r.scaling.prod(dim=1).mean() for r in renders)
+        scaling_reg = sum(_mean_over_selected(r.scaling.prod(dim=1), r) for r in renders)
         opacity_reg = sum((1 - r.neural_opacity).mean() for r in renders)
         if opt.optical_lambda == 0:
             optical_loss = 0
@@ -113,6 +134,13 @@ class Trainer:
         loss.backward()
         gdist.allreduce_gradients([p for g in pc.optimizer.param_groups for p in g["params"]])
 
+        if self.batched:
+            # the only host synchronisation of the step after the visibility test: the 4 renders' instance counters
+            _, overflowed = resolve_deferred([r.raster_state for r in renders])
+            if overflowed:
+                return None
+            for r in renders:
+                r.num_rendered = r.raster_state.counters()[0]
         with torch.no_grad():
             if self.controller.gaussian_statis:
                 for r in renders:
@@ -120,7 +148,6 @@ class Trainer:
             if iteration < opt.iterations:
                 pc.optimizer.step()
                 pc.optimizer.zero_grad(set_to_none=True)
-        self.controller.step()
         active = sum(r.active_gaussains for r in renders)
         return StepOutput(loss=loss.detach(), image1=image1.detach(), image2=image2.detach(), renders=renders,
                           active_gaussians=active, frame_idx=frame_idx)

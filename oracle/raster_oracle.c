@@ -207,7 +207,10 @@ int64_t gsvc_oracle_raster_forward(const oracle_raster_settings *st, int64_t P, 
     pre_t *pre = (pre_t *)malloc(sizeof(pre_t) * (size_t)(P > 0 ? P : 1));
     int64_t total = 0;
     for (int64_t i = 0; i < P; i++) {
-        int r = preprocess_one(st, means3D + 3 * i, scales + 3 * i, rotations + 4 * i, gx, gy, &pre[i]);
+        /* opacity <= 0 can never reach alpha >= 1/255: culled (radius 0), so un-compacted sets may be passed */
+        int r = 0;
+        if (opacities[i] > 0.0f) r = preprocess_one(st, means3D + 3 * i, scales + 3 * i, rotations + 4 * i, gx, gy, &pre[i]);
+        else memset(&pre[i], 0, sizeof(pre_t));
         radii[i] = r;
         int t = r ? (pre[i].rect[2] - pre[i].rect[0]) * (pre[i].rect[3] - pre[i].rect[1]) : 0;
         total += t;

@@ -93,6 +93,18 @@ def test_batched_generation_equals_per_render():
     with torch.no_grad():
         many = render_many(frames, pc, pipe, bg, mode=GenerateMode.TRAINING_FULL_PRECISION)
         single = [render(f, pc, pipe, bg, mode=GenerateMode.TRAINING_FULL_PRECISION) for f in frames]
+        dense = render_many(frames, pc, pipe, bg, mode=GenerateMode.TRAINING_FULL_PRECISION, dense=True)
+    # un-compacted form: same image; per-Gaussian outputs agree on the "opacity > 0" rows, the other rows are culled
+    from gsvc_amd.rasterizer import resolve_deferred
+    counts, overflowed = resolve_deferred([d.raster_state for d in dense])
+    assert not overflowed
+    for d, b, n in zip(dense, single, counts):
+        assert d.dense and d.num_rendered is None and n == b.num_rendered
+        assert torch.equal(d.selection_mask, b.selection_mask) and torch.equal(d.visible_index, b.visible_mask.nonzero().squeeze(1))
+        assert torch.equal(d.radii[d.selection_mask], b.radii) and int(d.radii[~d.selection_mask].abs().sum()) == 0
+        assert torch.allclose(d.rendered_image, b.rendered_image, atol=2e-5)
+        assert torch.allclose(d.scaling[d.selection_mask], b.scaling, atol=1e-6)
+        assert int(d.active_gaussains) == int(b.active_gaussains)
     for a, b in zip(many, single):
         assert torch.equal(a.visible_mask, b.visible_mask) and torch.equal(a.selection_mask, b.selection_mask)
         assert a.num_rendered == b.num_rendered and torch.equal(a.radii, b.radii)
@@ -115,3 +127,40 @@ def test_batched_generation_equals_per_render():
         for nm in ("bit_per_param", "bit_per_feat_param", "bit_per_scaling_param", "bit_per_offsets_param"):
             assert abs(float(getattr(a, nm)) - float(getattr(b, nm))) < 1e-4 * max(1.0, abs(float(getattr(b, nm)))), nm
         assert torch.allclose(a.rendered_image, b.rendered_image, atol=2e-5)
+
+
+@pytest.mark.parametrize("entropy", [False, True])
+def test_dense_step_equals_per_render_step(entropy):
+    """Trainer(batched=True) — one un-compacted generation pass, sync-free statistics and optical-flow loss, deferred
+    rasterizer counters — against Trainer(batched=False) — 4 reference-style render() calls with compaction and
+    boolean-mask indexing — from the same parameters: same loss, same gradients, same densification statistics.
+    (Deterministic modes only: the noise modes draw per call.)"""
+    res = []
+    for batched in (True, False):
+        pc, cube, opt, pipe, mp, Trainer = _setup(anchors=5000, seed=3)
+        if entropy:      # STE entropy mode: deterministic, rate term and hash-grid context active
+            opt.full_precision_training_total = opt.quantized_training_total = opt.entropy_constrained_train_total = 0
+            opt.ste_entropy_constrained_train_total = 100
+        else:
+            opt.full_precision_training_total = 100
+        opt.start_stat, opt.pause_densification, opt.iterations = 0, 0, 1      # iteration 1 == iterations: no Adam step
+        pc.training_setup(opt)
+        import gsvc_amd.generate as G
+        old = G.SAMPLE_RATE
+        G.SAMPLE_RATE = 2.0         # rate over every visible anchor (the 5 % sample is a random draw)
+        try:
+            out = Trainer(pc, cube, opt, pipe, mp, batched=batched).step(1, frame_idx=5)
+        finally:
+            G.SAMPLE_RATE = old
+        grads = {n: p.grad.clone() for n, p in pc.named_parameters() if p.grad is not None}
+        res.append((float(out.loss), grads, pc.opacity_accum.clone(), pc.anchor_demon.clone(), pc.offset_gradient_accum.clone(),
+                    pc.offset_denom.clone(), out.image1.clone(), [r.num_rendered for r in out.renders]))
+    (la, ga, oa, da, ofa, oda, ia, na), (lb, gb, ob, db, ofb, odb, ib, nb) = res
+    assert na == nb and abs(la - lb) < 1e-5 * max(1.0, abs(lb))
+    assert torch.allclose(ia, ib, atol=2e-5)
+    assert torch.equal(da, db) and torch.equal(oda, odb)
+    assert torch.allclose(oa, ob, rtol=1e-5, atol=1e-6) and torch.allclose(ofa, ofb, rtol=1e-3, atol=1e-9)
+    assert ga.keys() == gb.keys() and len(ga) > 20
+    for n in ga:
+        scale = gb[n].abs().max().item()
+        assert (ga[n] - gb[n]).abs().max().item() <= 2e-3 * scale + 1e-12, n

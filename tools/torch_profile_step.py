@@ -24,8 +24,19 @@ tr = Trainer(pc, cube, opt, pipe, mp_)
 for i in range(4):
     tr.step(i + 1, frame_idx=30)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=bool(os.environ.get('STACKS'))) as prof:
     for i in range(3):
         tr.step(10 + i, frame_idx=30)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=60))
+if os.environ.get('STACKS'):
+    want = os.environ['STACKS'].split(',')
+    from collections import Counter
+    cnt = Counter()
+    for ev in prof.events():
+        if ev.name in want:
+            st = [f for f in ev.stack if '/gsvc_amd/' in f or 'bench' in f][:3]
+            cnt[(ev.name, ' <- '.join(x.split('/gsvc_amd/')[-1] for x in st))] += 1
+    for k, v in sorted(cnt.items(), key=lambda kv: -kv[1])[:60]:
+        print(v, k[0], k[1])
+else:
+    print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=60))
