@@ -57,7 +57,7 @@ class Mix3d2dEncoding(nn.Module):
         self.output_dim = sum(e.output_dim for e in (self.encoding_xyz, self.encoding_xy, self.encoding_xz, self.encoding_yz))
 
     def forward(self, x):
-        xy, xz, yz = x[..., [0, 1]], x[..., [0, 2]], x[..., [1, 2]]
+        xy, xz, yz = x[..., 0:2], x[..., 0::2], x[..., 1:3]     # slices, not list indices: their backward is a strided add, not a sort-based index_put
         return torch.cat([self.encoding_xyz(x), self.encoding_xy(xy), self.encoding_xz(xz), self.encoding_yz(yz)], dim=-1)
 
 

@@ -34,6 +34,14 @@ def has_bool(idx):
         return any(has_bool(i) for i in idx)
     return False
 
+def has_long(idx):
+    if isinstance(idx, torch.Tensor):
+        return idx.dtype == torch.long and idx.dim() > 0
+    if isinstance(idx, (tuple, list)):
+        return any(has_long(i) for i in idx)
+    return False
+
+
 class Spy(TorchFunctionMode):
     def __torch_function__(self, func, types, args=(), kwargs=None):
         name = getattr(func, "__name__", str(func))
@@ -42,6 +50,10 @@ class Spy(TorchFunctionMode):
             hit = name
         elif name in ("__getitem__", "__setitem__") and len(args) > 1 and has_bool(args[1]):
             hit = name + "[bool]"
+        elif name in ("__getitem__", "__setitem__") and len(args) > 1 and has_long(args[1]):
+            hit = name + "[long] grad=%s shape=%s" % (getattr(args[0], "requires_grad", None), tuple(args[0].shape))
+        elif name in ("index_put", "index_put_", "index_add_", "index_add"):
+            hit = name + " shape=%s" % (tuple(args[0].shape),)
         if hit:
             fr = [f for f in traceback.extract_stack() if "/gsvc_amd/" in f.filename][-2:]
             cnt[(hit, " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(fr)))] += 1

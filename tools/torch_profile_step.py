@@ -24,11 +24,13 @@ tr = Trainer(pc, cube, opt, pipe, mp_)
 for i in range(4):
     tr.step(i + 1, frame_idx=30)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=bool(os.environ.get('STACKS'))) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=bool(os.environ.get('STACKS')), record_shapes=bool(os.environ.get('SHAPES'))) as prof:
     for i in range(3):
         tr.step(10 + i, frame_idx=30)
     torch.cuda.synchronize()
-if os.environ.get('STACKS'):
+if os.environ.get('SHAPES'):
+    print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=int(os.environ['SHAPES']), max_name_column_width=50))
+elif os.environ.get('STACKS'):
     want = os.environ['STACKS'].split(',')
     from collections import Counter
     cnt = Counter()
