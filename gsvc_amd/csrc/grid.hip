@@ -10,8 +10,7 @@
 //
 // Mapping to the hardware: one lane per (point, level); a corner's C features are one 4*C-byte row, read
 // with 16-byte loads; the [L,N,C] output row of a lane is contiguous so a wave writes 64*4*C contiguous
-// bytes.  The table backward reduces nothing on chip (corners of neighbouring points differ); it gives C
-// consecutive lanes to a point so that every corner costs one contiguous 4*C-byte atomic segment.
+// bytes.  The table backward accumulates table slices in LDS (k_grid_bwd_lds below).
 #include "common.h"
 
 namespace gsvc {
@@ -158,15 +157,23 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inpu
     }
     Cell<D> c;
     locate<D>(x, resolution, hashmap_size, c);
+    // the 2^D corner rows are read once and kept: the interpolation and all D finite differences use the same rows
+    // (a corner is dropped by both exactly when one of its coordinates lies on the border)
+    float g[1 << D][C];
 #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
         if (c.valid & (1u << idx)) {
-            float g[C];
-            load_row<C>(grid + (size_t)c.row[idx] * C, g);
-            const float w = c.w[idx] * c.wn_re;
+            load_row<C>(grid + (size_t)c.row[idx] * C, g[idx]);
+        } else {
 #pragma unroll
-            for (uint32_t ch = 0; ch < C; ch++) res[ch] += w * g[ch];
+            for (uint32_t ch = 0; ch < C; ch++) g[idx][ch] = 0.f;
         }
+    }
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        const float w = c.w[idx] * c.wn_re;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) res[ch] += (c.valid & (1u << idx)) ? w * g[idx][ch] : 0.f;
     }
     store_row<C>(out, res);
     if (!dd) return;
@@ -178,68 +185,110 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inpu
 #pragma unroll
         for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
             float w = (float)(resolution - 2);
-            uint32_t pl[D];
+            uint32_t lo = 0;      // corner index with bit gd clear
 #pragma unroll
             for (uint32_t nd = 0; nd + 1 < D; nd++) {
                 const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
                 if ((idx & (1u << nd)) == 0) {
                     w *= 1.f - c.frac[d];
-                    pl[d] = c.cell[d];
                 } else {
                     w *= c.frac[d];
-                    pl[d] = min(c.cell[d] + 1, resolution - 1);
+                    lo |= 1u << d;
                 }
             }
-            bool other_border = false;
+            const uint32_t hi = lo | (1u << gd);
 #pragma unroll
-            for (uint32_t d = 0; d < D; d++)
-                if (d != gd) other_border |= (pl[d] == 0) | (pl[d] == resolution - 1);
-            float gl[C], gr[C];
-#pragma unroll
-            for (uint32_t ch = 0; ch < C; ch++) { gl[ch] = 0.f; gr[ch] = 0.f; }
-            pl[gd] = c.cell[gd];
-            if (!(other_border || pl[gd] == 0 || pl[gd] == resolution - 1))
-                load_row<C>(grid + (size_t)grid_row<D>(pl, hashmap_size, resolution) * C, gl);
-            pl[gd] = min(c.cell[gd] + 1, resolution - 1);
-            if (!(other_border || pl[gd] == 0 || pl[gd] == resolution - 1))
-                load_row<C>(grid + (size_t)grid_row<D>(pl, hashmap_size, resolution) * C, gr);
-#pragma unroll
-            for (uint32_t ch = 0; ch < C; ch++) rg[ch] += w * (gr[ch] - gl[ch]);
+            for (uint32_t ch = 0; ch < C; ch++) rg[ch] += w * (g[hi][ch] - g[lo][ch]);
         }
         store_row<C>(dd + gd * C, rg);
     }
 }
 
-// table backward: C consecutive lanes per (point, level), lane c owns feature c.  A corner's C atomics then
-// sit in one wave-instruction on one 4*C-byte row segment (one memory-side request per corner and point
-// instead of one per feature: float atomics on MI355X are priced per 64-byte request, not per lane).
+// Table backward with the level's table privatised in LDS.  GSVC's tables are small (2^13 rows per 3-D level, 2^15
+// per 2-D level in cfg_20240919) and every visible anchor adds into 2^D rows of every level: with global atomics
+// that is N*L*2^D scattered memory-side requests (~17 G requests/s on MI355X: 1.0 ms for 181k points x 12 levels;
+// measured with C consecutive lanes per point so that a corner is one 4*C-byte request).
+// Here a workgroup owns (level, table slice of BWD_SLICE_FLOATS/C rows, chunk of points): it accumulates the chunk's
+// contributions to its slice with LDS atomics and then adds the slice to the gradient table with contiguous
+// atomics (zeros skipped).  A level that needs more than gridDim.z slices falls back to global atomics in its
+// z == 0 workgroups, so one launch covers every table size without the host knowing the (device-resident) offsets.
+constexpr uint32_t BWD_SLICE_FLOATS = 32768;       // 128 KiB of LDS
+constexpr uint32_t BWD_THREADS = 1024;
+constexpr uint32_t BWD_MAX_SLICES = 16;
+
 template <uint32_t D, uint32_t C>
-__global__ void __launch_bounds__(256) k_grid_bwd(const float *__restrict__ grad, const float *__restrict__ inputs,
-                                                  const int32_t *__restrict__ offsets,
-                                                  const int32_t *__restrict__ resolutions,
-                                                  float *__restrict__ grad_grid, uint32_t N)
+__global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__restrict__ grad, const float *__restrict__ inputs,
+                                                              const int32_t *__restrict__ offsets,
+                                                              const int32_t *__restrict__ resolutions,
+                                                              float *__restrict__ grad_grid, uint32_t N, uint32_t chunk)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t b = t / C, ch = t - b * C;
-    if (b >= N) return;
-    const uint32_t level = blockIdx.y;
-    grad_grid += (size_t)(uint32_t)offsets[level] * C;
+    extern __shared__ float acc[];
+    constexpr uint32_t SLICE_ROWS = BWD_SLICE_FLOATS / C;
+    const uint32_t level = blockIdx.y, slice = blockIdx.z, tid = threadIdx.x;
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
     const uint32_t resolution = (uint32_t)resolutions[level];
-    float x[D];
-    bool oob = false;
+    const uint32_t slices = (hashmap_size + SLICE_ROWS - 1) / SLICE_ROWS;
+    const bool fallback = slices > gridDim.z;
+    if (fallback ? slice != 0 : slice >= slices) return;         // block-uniform
+    grad_grid += (size_t)(uint32_t)offsets[level] * C;
+    const uint32_t p0 = blockIdx.x * chunk, p1 = min(N, p0 + chunk);
+    if (fallback) {
+        // C consecutive lanes per point: one contiguous 4*C-byte atomic segment per corner
+        for (uint32_t t = p0 * C + tid; t < p1 * C; t += BWD_THREADS) {
+            const uint32_t b = t / C, ch = t - b * C;
+            float x[D];
+            bool oob = false;
 #pragma unroll
-    for (uint32_t d = 0; d < D; d++) {
-        x[d] = inputs[(size_t)b * D + d];
-        oob |= (x[d] < 0.f) | (x[d] > 1.f);
+            for (uint32_t d = 0; d < D; d++) {
+                x[d] = inputs[(size_t)b * D + d];
+                oob |= (x[d] < 0.f) | (x[d] > 1.f);
+            }
+            if (oob) continue;
+            const float g = grad[((size_t)level * N + b) * C + ch];
+            Cell<D> c;
+            locate<D>(x, resolution, hashmap_size, c);
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << D); idx++)
+                if (c.valid & (1u << idx)) atomicAdd(grad_grid + (size_t)c.row[idx] * C + ch, c.w[idx] * c.wn_re * g);
+        }
+        return;
     }
-    if (oob) return;
-    const float g = grad[((size_t)level * N + b) * C + ch];
-    Cell<D> c;
-    locate<D>(x, resolution, hashmap_size, c);
+    const uint32_t row_lo = slice * SLICE_ROWS, rows = min(SLICE_ROWS, hashmap_size - row_lo);
+    for (uint32_t i = tid; i < rows * C; i += BWD_THREADS) acc[i] = 0.f;
+    __syncthreads();
+    for (uint32_t b = p0 + tid; b < p1; b += BWD_THREADS) {
+        float x[D];
+        bool oob = false;
 #pragma unroll
-    for (uint32_t idx = 0; idx < (1u << D); idx++) {
-        if (c.valid & (1u << idx)) atomicAdd(grad_grid + (size_t)c.row[idx] * C + ch, c.w[idx] * c.wn_re * g);
+        for (uint32_t d = 0; d < D; d++) {
+            x[d] = inputs[(size_t)b * D + d];
+            oob |= (x[d] < 0.f) | (x[d] > 1.f);
+        }
+        if (oob) continue;
+        Cell<D> c;
+        locate<D>(x, resolution, hashmap_size, c);
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++)
+            if ((c.valid & (1u << idx)) && c.row[idx] - row_lo < rows) mine |= 1u << idx;
+        if (!mine) continue;
+        float g[C];
+        load_row<C>(grad + ((size_t)level * N + b) * C, g);
+#pragma unroll
+        for (uint32_t idx = 0; idx < (1u << D); idx++) {
+            if (mine & (1u << idx)) {
+                const float w = c.w[idx] * c.wn_re;
+                float *dst = acc + (c.row[idx] - row_lo) * C;
+#pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++) atomicAdd(dst + ch, w * g[ch]);
+            }
+        }
+    }
+    __syncthreads();
+    float *out = grad_grid + (size_t)row_lo * C;
+    for (uint32_t i = tid; i < rows * C; i += BWD_THREADS) {
+        const float v = acc[i];
+        if (v != 0.f) atomicAdd(out + i, v);
     }
 }
 
@@ -275,7 +324,22 @@ template <uint32_t D, uint32_t C>
 static void launch_bwd(const float *grad, const float *inputs, const int32_t *off, const int32_t *res, float *gemb,
                        uint32_t N, uint32_t L, const float *dy_dx, float *ginp, hipStream_t s)
 {
-    { ProfScope _prof("k_grid_bwd", s); hipLaunchKernelGGL((k_grid_bwd<D, C>), dim3((unsigned)(((uint64_t)N * C + 255) / 256), L), dim3(256), 0, s, grad, inputs, off, res, gemb, N); }
+    {
+        // ~512 resident workgroups: chunk the points so that (chunks x L x typical slices) fills the chip
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_bwd_lds<D, C>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BWD_SLICE_FLOATS * sizeof(float)));
+            attr_set = true;
+        }
+        uint32_t chunks = (512 + L - 1) / L;
+        if (chunks > (N + 2047) / 2048) chunks = (N + 2047) / 2048;      // at least 2048 points per workgroup
+        if (chunks == 0) chunks = 1;
+        const uint32_t chunk = (N + chunks - 1) / chunks;
+        ProfScope _prof("k_grid_bwd", s);
+        hipLaunchKernelGGL((k_grid_bwd_lds<D, C>), dim3(chunks, L, BWD_MAX_SLICES), dim3(BWD_THREADS),
+                           BWD_SLICE_FLOATS * sizeof(float), s, grad, inputs, off, res, gemb, N, chunk);
+    }
     if (dy_dx && ginp)
         { ProfScope _prof("k_grid_input_bwd", s); hipLaunchKernelGGL((k_grid_input_bwd<D, C>), dim3((N * D + 255) / 256), dim3(256), 0, s, grad, dy_dx, ginp, N, L); }
 }

@@ -1,2 +1,6 @@
-python -m pytest tests/test_grid_rate_gpu.py tests/test_train_gpu.py -q -m gpu --tb=short -x 2>&1 | tail -3 | cut -c1-250
-python bench.py --workload train_step --steps 8 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['gsvc_kernel_us_per_step'])"
+python tools/bench_grid.py
+GSVC_GRID_DBG=1 python tools/bench_grid.py
+GSVC_GRID_DBG=2 python tools/bench_grid.py
+GSVC_GRID_DBG=3 python tools/bench_grid.py
+GSVC_GRID_WGS=256 python tools/bench_grid.py
+GSVC_GRID_WGS=1024 python tools/bench_grid.py
