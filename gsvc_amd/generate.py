@@ -112,6 +112,15 @@ def _as_index(mask_or_index):
     return mask_or_index
 
 
+def region(name):
+    """Named range for torch.profiler when GSVC_REGIONS=1 (diagnostics), otherwise a no-op context."""
+    import contextlib
+    import os
+    if os.environ.get("GSVC_REGIONS"):
+        return torch.profiler.record_function(name)
+    return contextlib.nullcontext()
+
+
 def _sync(t):
     if t.is_cuda:
         torch.cuda.synchronize()
@@ -283,25 +292,29 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
                      bit_per_scaling_param=(ss / ns * kr)[r], bit_per_offsets_param=(so / no * kr)[r]) for r in range(seg.R)]
 
 
-def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False):
+def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False,
+                                   anchors=None):
     """`generate_neural_gaussians` for R renders at once; returns a list of R GeneratedGaussians.
 
     ``dense=True`` skips the "opacity > 0" compaction: every visible anchor contributes all K Gaussians, ``mask``
     still marks the ones with opacity > 0, and the rasterizer culls the rest itself (csrc/raster_fwd.hip K1) — the
     image, the gradients and every masked statistic are the same, but no tensor shape depends on device data, so
     the step runs without a host synchronisation between the visibility test and the optimizer.
-    ``concatenated_all`` is not materialised in that form (``world_xyz`` carries what the optical-flow loss reads)."""
+    ``concatenated_all`` is not materialised in that form (``world_xyz`` carries what the optical-flow loss reads).
+    ``anchors``: precomputed ``pc.get_anchor`` without autograd (anchor positions then receive no gradient)."""
     R = len(frames)
     K = pc.n_offsets
-    vis_list = [_as_index(m) for m in visible_masks]
+    with region('gen.visible_index'):
+        vis_list = [_as_index(m) for m in visible_masks]
     dev = vis_list[0].device
     seg = _Segments([v.shape[0] for v in vis_list], dev)
-    vis = torch.cat(vis_list)
-    anchor = pc.get_anchor.index_select(0, vis)
-    feat = pc._anchor_feat.index_select(0, vis)
-    grid_offsets = pc._offset.index_select(0, vis)
-    grid_scaling = _visible_scaling(pc, vis)
-    offset_masks = _visible_mask(pc, vis)
+    with region('gen.gather'):
+        vis = torch.cat(vis_list)
+        anchor = (pc.get_anchor if anchors is None else anchors).index_select(0, vis)
+        feat = pc._anchor_feat.index_select(0, vis)
+        grid_offsets = pc._offset.index_select(0, vis)
+        grid_scaling = _visible_scaling(pc, vis)
+        offset_masks = _visible_mask(pc, vis)
     rates = [RatePack() for _ in range(R)]
     Q_feat, Q_scaling, Q_offsets = BASE_Q_FEAT, BASE_Q_SCALING, BASE_Q_OFFSETS
     time_sub = 0
@@ -313,12 +326,15 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
         grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets, seg)
     elif mode == GenerateMode.TRAINING_ENTROPY:
-        ec = pc.calc_entropy_context(anchor)
-        Q_feat, Q_scaling, Q_offsets = Q_feat * ec.Q_feat_adj, Q_scaling * ec.Q_scaling_adj, Q_offsets * ec.Q_offsets_adj
-        feat = _seg_noise_quant(feat, Q_feat, seg)
-        grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
-        grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets.unsqueeze(1), seg)
-        rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec)
+        with region('gen.entropy_context'):
+            ec = pc.calc_entropy_context(anchor)
+        with region('gen.noise_quant'):
+            Q_feat, Q_scaling, Q_offsets = Q_feat * ec.Q_feat_adj, Q_scaling * ec.Q_scaling_adj, Q_offsets * ec.Q_offsets_adj
+            feat = _seg_noise_quant(feat, Q_feat, seg)
+            grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
+            grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets.unsqueeze(1), seg)
+        with region('gen.rate'):
+            rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec)
     elif mode == GenerateMode.TRAININ_STE_ENTROPY:
         ec = pc.calc_entropy_context(anchor)
         Q_feat, Q_scaling, Q_offsets = (Q_feat * ec.Q_feat_adj.detach(), Q_scaling * ec.Q_scaling_adj.detach(),
@@ -330,32 +346,38 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     else:
         raise ValueError(f"Unknown mode {mode}")
 
-    cam_z = torch.tensor([float(f.cam_pos[-1]) for f in frames], device=dev, dtype=anchor.dtype)
-    cam_z_row = cam_z.index_select(0, seg.seg_id).unsqueeze(1)
-    ob_view = anchor[:, 2:] - cam_z_row
-    pe = torch.cat([pc.embed_time_fn(cam_z_row), pc.embed_fn(ob_view)], dim=1)
+    with region('gen.embed'):
+        cam_z = torch.tensor([float(f.cam_pos[-1]) for f in frames], device=dev, dtype=anchor.dtype)
+        cam_z_row = cam_z.index_select(0, seg.seg_id).unsqueeze(1)
+        ob_view = anchor[:, 2:] - cam_z_row
+        pe = torch.cat([pc.embed_time_fn(cam_z_row), pc.embed_fn(ob_view)], dim=1)
 
     rows = seg.rows
-    neural_opacity = pc.get_opacity_mlp(feat, pe).reshape(-1, 1) * offset_masks.view(-1, 1)
-    mask = (neural_opacity > 0.0).view(-1)
-    color = pc.get_color_mlp(feat, pe).reshape(rows * K, 3)
-    scale_rot = pc.get_cov_mlp(feat, pe).reshape(rows * K, 7)
-    neural_offset = pc.get_deform_mlp(torch.cat([feat, pe], dim=1)).reshape(rows * K, 3)
-    offsets = grid_offsets.view(-1, 3) + neural_offset
+    with region('gen.mlps'):
+        neural_opacity = pc.get_opacity_mlp(feat, pe).reshape(-1, 1) * offset_masks.view(-1, 1)
+        mask = (neural_opacity > 0.0).view(-1)
+        color = pc.get_color_mlp(feat, pe).reshape(rows * K, 3)
+        scale_rot = pc.get_cov_mlp(feat, pe).reshape(rows * K, 7)
+        neural_offset = pc.get_deform_mlp(torch.cat([feat, pe], dim=1)).reshape(rows * K, 3)
+        offsets = grid_offsets.view(-1, 3) + neural_offset
     if dense:
-        gs3 = grid_scaling.view(rows, 1, 6)
-        scaling = (gs3[:, :, 3:] * torch.sigmoid(scale_rot[:, :3]).view(rows, K, 3)).reshape(rows * K, 3)
-        rot = pc.rotation_activation(scale_rot[:, 3:7])
-        world = (anchor.view(rows, 1, 3) + offsets.view(rows, K, 3) * gs3[:, :, :3]).reshape(rows * K, 3)
+        gs_lo, gs_hi = grid_scaling.view(rows, 1, 6).split([3, 3], dim=2)
+        sr_scale, sr_rot = scale_rot.split([3, 4], dim=1)
+        scaling = (gs_hi * torch.sigmoid(sr_scale).view(rows, K, 3)).reshape(rows * K, 3)
+        rot = pc.rotation_activation(sr_rot)
+        world = (anchor.view(rows, 1, 3) + offsets.view(rows, K, 3) * gs_lo).reshape(rows * K, 3)
         xyz = torch.clamp(world, pc.x_bound_min, pc.x_bound_max)
+        # per-render pieces by split (one cat in backward per tensor, instead of a zero-fill + copy + add per slice)
+        sizes = [c * K for c in seg.counts]
+        parts = [t.split(sizes, dim=0) for t in (xyz, color, neural_opacity, scaling, rot, world)]
         out = []
-        for r, (rs, gs) in enumerate(zip(seg.slices(), seg.slices(K))):
+        for r, gs in enumerate(seg.slices(K)):
             out.append(GeneratedGaussians(
-                xyz=xyz[gs], color=color[gs], opacity=neural_opacity[gs], scaling=scaling[gs], rot=rot[gs],
-                neural_opacity=neural_opacity[gs], visable_mask=visible_masks[r], mask=mask[gs],
+                xyz=parts[0][r], color=parts[1][r], opacity=parts[2][r], scaling=parts[3][r], rot=parts[4][r],
+                neural_opacity=parts[2][r], visable_mask=visible_masks[r], mask=mask[gs],
                 bit_per_param=rates[r].bit_per_param, bit_per_feat_param=rates[r].bit_per_feat_param,
                 bit_per_scaling_param=rates[r].bit_per_scaling_param, bit_per_offsets_param=rates[r].bit_per_offsets_param,
-                concatenated_all=None, time_sub=time_sub, visible_index=vis_list[r], world_xyz=world[gs]))
+                concatenated_all=None, time_sub=time_sub, visible_index=vis_list[r], world_xyz=parts[5][r]))
         return out
     per_anchor = torch.cat([grid_scaling, anchor], dim=-1)
     concatenated_all = torch.cat([per_anchor.repeat_interleave(K, dim=0), color, scale_rot, offsets], dim=-1)

@@ -204,7 +204,8 @@ class EntropyParamsNet(nn.Module):
     def forward(self, x):
         params = self.dist_net(x)
         half = params.shape[1] // 2
-        return params[:, :half], params[:, half:], self.quant_step_net(x)
+        mean, scale = params.split([half, params.shape[1] - half], dim=1)     # split: one cat in backward
+        return mean, scale, self.quant_step_net(x)
 
 
 def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000, step_sub=0):

@@ -22,11 +22,18 @@ def raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier=1.0):
         prefiltered=False, debug=getattr(pipe, "debug", False))
 
 
-def prefilter_voxel(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+def prefilter_geometry(pc):
+    """(anchors, scales[:, :3], rotations) of all anchors as the visibility test reads them, without autograd.
+    They do not change within a step, so a step that tests several views evaluates the getters once."""
+    with torch.no_grad():
+        return pc.get_anchor.contiguous(), pc.get_scaling[:, :3].contiguous(), pc.get_rotation.contiguous()
+
+
+def prefilter_voxel(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, geometry=None):
     if getattr(pipe, "compute_cov3D_python", False):
         raise NotImplementedError("compute_cov3D_python is False in GSVC")
     rasterizer = GaussianRasterizer(raster_settings=raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier))
     with torch.no_grad():
-        radii_pure = rasterizer.visible_filter(means3D=pc.get_anchor, scales=pc.get_scaling[:, :3],
-                                               rotations=pc.get_rotation, cov3D_precomp=None)
+        means3D, scales, rotations = geometry if geometry is not None else prefilter_geometry(pc)
+        radii_pure = rasterizer.visible_filter(means3D=means3D, scales=scales, rotations=rotations, cov3D_precomp=None)
     return radii_pure > 0

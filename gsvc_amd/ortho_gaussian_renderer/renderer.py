@@ -9,7 +9,7 @@ import torch
 from ..common.base import RenderResults
 from ..generate import GenerateMode, generate_neural_gaussians, generate_neural_gaussians_many
 from ..rasterizer import GaussianRasterizer, raster_forward, settings_to_c
-from .preprocess import prefilter_voxel, raster_settings_for
+from .preprocess import prefilter_geometry, prefilter_voxel, raster_settings_for
 
 
 def render(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain_grad=False,
@@ -37,7 +37,7 @@ def render(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain
 
 
 def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain_grad=False,
-                mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False):
+                mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False, anchor_grad=True):
     """`render` for several frames/views of one step: the anchor -> Gaussian generation of all of them runs as
     one batch (gsvc_amd.generate.generate_neural_gaussians_many), then each view is rasterized.  Returns a list
     of RenderResults with the same fields `render` fills.
@@ -46,9 +46,15 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
     fields (viewspace_points, radii, visibility_filter, scaling) cover all K slots of every visible anchor,
     ``selection_mask`` marks the slots with opacity > 0 (the others get radius 0), ``num_rendered`` is None until
     ``gsvc_amd.rasterizer.resolve_deferred([r.raster_state ...])`` is called, which the caller MUST do (it is the
-    overflow check) before trusting the images."""
-    visible = [prefilter_voxel(f, pc, pipe, bg_color) for f in frames]
-    gss_list = generate_neural_gaussians_many(frames, pc, visible, mode, dense=dense)
+    overflow check) before trusting the images.
+
+    ``anchor_grad=False``: the anchor positions enter the generation pass detached (no gradient w.r.t. ``_anchor``:
+    GSVC trains them with learning rate 0, `arguments/__init__.py` position_lr_*), which removes the backward
+    through the positional embedding, the hash-grid input gradient and dy_dx."""
+    geometry = prefilter_geometry(pc)
+    visible = [prefilter_voxel(f, pc, pipe, bg_color, geometry=geometry) for f in frames]
+    gss_list = generate_neural_gaussians_many(frames, pc, visible, mode, dense=dense,
+                                              anchors=None if anchor_grad else geometry[0])
     results = []
     for frame, visible_mask, gss in zip(frames, visible, gss_list):
         screenspace_points = torch.zeros_like(gss.xyz, dtype=pc.get_anchor.dtype, requires_grad=True) + 0

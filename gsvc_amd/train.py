@@ -17,7 +17,7 @@ import torch
 
 from . import dist as gdist
 from .encodings import get_binary_vxl_size
-from .generate import GenerateMode
+from .generate import GenerateMode, region
 from .loss_utils import calc_optical_loss, ssim_l1
 from .ortho_gaussian_renderer import render, render_many
 from .rasterizer import resolve_deferred
@@ -65,6 +65,9 @@ class Trainer:
         self.lo, self.hi = gdist.frame_shard(dataset.len_z_frames)
         bg = [1, 1, 1] if model_params.white_background else [0, 0, 0]
         self.background = torch.tensor(bg, dtype=torch.float32)  # host tensor: the kernels take bg by value
+        # anchors are trained with learning rate 0 in GSVC (position_lr_init = position_lr_final = 0): their gradient
+        # changes nothing, so the batched step does not compute it unless a non-zero rate is configured
+        self.anchor_grad = bool(getattr(opt, "position_lr_init", 0.0) or getattr(opt, "position_lr_final", 0.0))
 
     def _two_views(self, frame, mode, retain_grad):
         f = render(frame, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode)
@@ -102,7 +105,7 @@ class Trainer:
                 back.view_matrix, back.view_matrix_s = fr.view_matrix_s, fr.view_matrix
                 views += [fr, back]
             r1f, r1b, r2f, r2b = render_many(views, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode,
-                                             dense=True)
+                                             dense=True, anchor_grad=self.anchor_grad)
             image1 = (r1f.rendered_image + torch.flip(r1b.rendered_image, dims=(-1,))) / 2
             image2 = (r2f.rendered_image + torch.flip(r2b.rendered_image, dims=(-1,))) / 2
         else:
@@ -131,7 +134,8 @@ class Trainer:
             denom = pc._anchor.shape[0] * (pc.feat_dim + 6 + 3 * pc.n_offsets)
             loss = loss + opt.lmbda * (bit_per_param + hash_grid_bits(pc) / denom)
             loss = loss + 5e-4 * torch.mean(torch.sigmoid(pc._mask))
-        loss.backward()
+        with region('step.backward'):
+            loss.backward()
         gdist.allreduce_gradients([p for g in pc.optimizer.param_groups for p in g["params"]])
 
         if self.batched:

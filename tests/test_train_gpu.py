@@ -157,10 +157,18 @@ def test_dense_step_equals_per_render_step(entropy):
                     pc.offset_denom.clone(), out.image1.clone(), [r.num_rendered for r in out.renders]))
     (la, ga, oa, da, ofa, oda, ia, na), (lb, gb, ob, db, ofb, odb, ib, nb) = res
     assert na == nb and abs(la - lb) < 1e-5 * max(1.0, abs(lb))
+    # with a non-zero anchor learning rate the batched step keeps the anchor gradient
+    pc, cube, opt, pipe, mp, Trainer = _setup(anchors=3000, seed=3)
+    opt.position_lr_init = 1e-4
+    opt.full_precision_training_total, opt.iterations = 100, 1
+    pc.training_setup(opt)
+    Trainer(pc, cube, opt, pipe, mp, batched=True).step(1, frame_idx=5)
+    assert pc._anchor.grad is not None and float(pc._anchor.grad.abs().sum()) > 0
     assert torch.allclose(ia, ib, atol=2e-5)
     assert torch.equal(da, db) and torch.equal(oda, odb)
     assert torch.allclose(oa, ob, rtol=1e-5, atol=1e-6) and torch.allclose(ofa, ofb, rtol=1e-3, atol=1e-9)
-    assert ga.keys() == gb.keys() and len(ga) > 20
+    # the batched step skips the gradient of the anchor positions (trained with learning rate 0)
+    assert set(gb) - set(ga) == {"_anchor"} and set(ga) <= set(gb) and len(ga) > 20
     for n in ga:
         scale = gb[n].abs().max().item()
         assert (ga[n] - gb[n]).abs().max().item() <= 2e-3 * scale + 1e-12, n

@@ -1,4 +1,2 @@
-python -m pytest tests -q -m gpu --tb=short 2>&1 | tail -3 | cut -c1-200
-python bench.py > gpurun_out/bench_headline_v5.json 2> gpurun_out/bench_headline_v5.err; tail -c 3000 gpurun_out/bench_headline_v5.json
-python bench.py --workload raster_fwdbwd --no-cpu-baseline | tail -1 > gpurun_out/bench_fwdbwd_v5.json
-python bench.py --workload train_step --no-cpu-baseline | tail -1 > gpurun_out/bench_train_v6.json
+python -m pytest tests/test_train_gpu.py tests/test_grid_rate_gpu.py -q -m gpu --tb=short -x 2>&1 | tail -8 | cut -c1-250
+python bench.py --workload train_step --steps 8 --warmup 4 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['gsvc_kernel_us_per_step'])"

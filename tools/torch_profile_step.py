@@ -28,7 +28,10 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     for i in range(3):
         tr.step(10 + i, frame_idx=30)
     torch.cuda.synchronize()
-if os.environ.get('SHAPES'):
+if os.environ.get('GSVC_REGIONS'):
+    for ev in sorted([e for e in prof.key_averages() if e.key.startswith(('gen.', 'step.'))], key=lambda e: e.key):
+        print(f"{ev.key:24s} cpu_total {ev.cpu_time_total / 3e3:8.2f} ms/step   cuda_total {ev.device_time_total / 3e3:8.2f} ms/step")
+elif os.environ.get('SHAPES'):
     print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=int(os.environ['SHAPES']), max_name_column_width=50))
 elif os.environ.get('STACKS'):
     want = os.environ['STACKS'].split(',')
