@@ -238,6 +238,206 @@ static void launch_ws(const float *X, const float *W, const float *b, float *Y, 
     else launch_ws2<NT, 12>(X, W, b, Y, M, K, N, w_in_out, relu, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient dW[N,K] = G[M,N]^T X[M,K] (+ db[N] = column sums of G): a reduction over the ~180k anchor rows
+// with a tiny output.  A library GEMM tiles the OUTPUT (a dozen workgroups on 256 CUs); here the rows are split:
+// one persistent workgroup per CU, one wave per (64 x 64 output block, row split).  Both operands stream from HBM
+// exactly once, straight into MFMA fragments, no LDS staging:
+//   * an MFMA step reduces 4 rows; lane (j, mq) reads row m0+mq.  A = G^T, so lane j supplies output row n and
+//     its natural load is VEC consecutive columns n..n+VEC-1 of one G row: component i of that vector is the A
+//     operand of a *strided* tile (rows {16 VEC p + VEC j + i}), so one 16-byte load feeds 4 tiles; same for X/B.
+//     A wave-instruction reads 4 rows x 256 contiguous bytes.
+//   * 16 MFMAs per 8 operand registers; the operand registers of step s are reloaded with the next 16-row chunk
+//     right after its MFMAs (register-neutral prefetch, as in k_linear_ws).
+//   * the waves of a block's row splits are summed in LDS, then the workgroup adds its 64 x 64 blocks to dW with
+//     contiguous 256-byte atomic segments (256 workgroups x N x K floats in total).
+constexpr int WG_MAX_WAVES = 12;
+
+template <int VEC>
+__device__ __forceinline__ void wg_load(__amdgpu_buffer_rsrc_t rs, int off, bool valid, float (&dst)[4], int p)
+{
+    // piece p of a 64-column block: VEC floats at byte offset off (+ the piece's immediate), zeros when !valid
+    const int o = valid ? off : BUF_OOB;
+    if (VEC == 4) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+        dst[0] = __uint_as_float(t.x); dst[1] = __uint_as_float(t.y); dst[2] = __uint_as_float(t.z); dst[3] = __uint_as_float(t.w);
+    } else if (VEC == 2) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, o, 0, 0);
+        dst[2 * p] = __uint_as_float(t.x); dst[2 * p + 1] = __uint_as_float(t.y);
+    } else {
+        dst[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
+    }
+}
+
+// operands of one 4-row step for a 64-column block starting at column c0 of a [rows][ld] matrix
+template <int VEC>
+__device__ __forceinline__ void wg_load_step(__amdgpu_buffer_rsrc_t rs, int row_off, int c0, int j, int ld, float (&dst)[4])
+{
+#pragma unroll
+    for (int p = 0; p < 4 / VEC; p++) {
+        const int col = c0 + 16 * VEC * p + VEC * j;
+        wg_load<VEC>(rs, row_off + col * 4, col < ld, dst, p);
+    }
+}
+
+template <int VG, int VX>
+__global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad(const float *__restrict__ G, const float *__restrict__ X,
+                                                                   float *__restrict__ part, int want_db,
+                                                                   long long M, int N, int K, int BN, int BK, int RS)
+{
+    extern __shared__ float sm[];      // [BN*BK][64][64]
+    __shared__ float sdb[LIN_NT_MAX * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pairs = BN * BK;
+    const int pair = wave % pairs, rs = wave / pairs;
+    const int bn = pair / BK, bk = pair - bn * BK;
+    const int j = lane & 15, mq = lane >> 4;
+    const long long RB = (M + 15) >> 4;
+    const long long workers = (long long)gridDim.x * RS;
+    long long rb = (long long)blockIdx.x * RS + rs;
+    if (tid < LIN_NT_MAX * 16) sdb[tid] = 0.f;
+    __syncthreads();
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float fa[4][4], fb[4][4];          // [step][tile]
+    {
+        const __amdgpu_buffer_rsrc_t rg = ws_block_rsrc(G, rb, RB, M, N), rx = ws_block_rsrc(X, rb, RB, M, K);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            wg_load_step<VG>(rg, (4 * s + mq) * N * 4, 64 * bn, j, N, fa[s]);
+            wg_load_step<VX>(rx, (4 * s + mq) * K * 4, 64 * bk, j, K, fb[s]);
+        }
+    }
+    // the first chunk has landed before the loop: inside it only the loop's own loads are outstanding, so the wait
+    // in front of step s is vmcnt(6) (the three later steps' reloads stay in flight), not vmcnt(0)
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) asm volatile("" : "+v"(fa[s][t]), "+v"(fb[s][t]));
+    for (; rb < RB; rb += workers) {
+        const __amdgpu_buffer_rsrc_t rg = ws_block_rsrc(G, rb + workers, RB, M, N);      // empty past the end
+        const __amdgpu_buffer_rsrc_t rx = ws_block_rsrc(X, rb + workers, RB, M, K);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                gsum[tn] += fa[s][tn];
+#pragma unroll
+                for (int tk = 0; tk < 4; tk++)
+                    acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][tn], fb[s][tk], acc[tn][tk], 0, 0, 0);
+            }
+            wg_load_step<VG>(rg, (4 * s + mq) * N * 4, 64 * bn, j, N, fa[s]);
+            wg_load_step<VX>(rx, (4 * s + mq) * K * 4, 64 * bk, j, K, fb[s]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // bias gradient: column sums of G (waves of the first k-block; the row splits meet in LDS)
+    if (want_db && bk == 0) {
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++) {
+            float v = gsum[tn];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int n = 64 * bn + 16 * VG * (tn / VG) + VG * j + (tn % VG);
+            if (mq == 0 && n < N) atomicAdd(sdb + n, v);
+        }
+    }
+    // sum the row splits of each 64 x 64 block in LDS (one wave per block and round), then write this workgroup's
+    // partial dW (and db) to its slot of `part`; k_linear_wgrad_reduce adds the slots (no global atomics: 256
+    // workgroups adding into the same 40 KB serialise on a handful of memory channels, measured +80 us)
+    float *blk = sm + pair * 4096;
+    for (int round = 0; round < RS; round++) {
+        if (rs == round) {
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++)
+#pragma unroll
+                for (int tk = 0; tk < 4; tk++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int nl = 16 * VG * (tn / VG) + VG * (4 * mq + r) + (tn % VG);
+                        const int kl = 16 * VX * (tk / VX) + VX * j + (tk % VX);
+                        float *d = blk + nl * 64 + kl;
+                        *d = (round == 0) ? acc[tn][tk][r] : *d + acc[tn][tk][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *out = part + (size_t)blockIdx.x * ((size_t)N * K + (want_db ? N : 0));
+    for (int i = tid; i < pairs * 4096; i += blockDim.x) {
+        const int pr = i >> 12, nl = (i >> 6) & 63, kl = i & 63;
+        const int n = 64 * (pr / BK) + nl, k = 64 * (pr % BK) + kl;
+        if (n < N && k < K) out[(size_t)n * K + k] = sm[i];
+    }
+    if (want_db)
+        for (int n = tid; n < N; n += blockDim.x) out[(size_t)N * K + n] = sdb[n];
+}
+
+// dst[i] = sum over the workgroup slots of part[slot][i]: 64 outputs per workgroup, the slots dealt to its 4 waves
+__global__ void __launch_bounds__(256) k_linear_wgrad_reduce(const float *__restrict__ part, int slots, int n, float *__restrict__ dW,
+                                                            int nk, float *__restrict__ db)
+{
+    __shared__ float red[4][64];
+    const int li = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + li;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        int s = sg;
+        for (; s + 12 < slots; s += 16) {
+            a0 += part[(size_t)s * n + i];
+            a1 += part[(size_t)(s + 4) * n + i];
+            a2 += part[(size_t)(s + 8) * n + i];
+            a3 += part[(size_t)(s + 12) * n + i];
+        }
+        for (; s < slots; s += 4) a0 += part[(size_t)s * n + i];
+    }
+    red[sg][li] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sg == 0 && i < n) {
+        const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
+        if (i < nk) dW[i] = v;
+        else db[i - nk] = v;
+    }
+}
+
+template <int VG, int VX>
+static void launch_wgrad2(const float *G, const float *X, float *dW, float *db, float *part, int slots, long long M, int N,
+                          int K, hipStream_t s)
+{
+    const int BN = (N + 63) / 64, BK = (K + 63) / 64, pairs = BN * BK;
+    const int RS = pairs >= WG_MAX_WAVES ? 1 : WG_MAX_WAVES / pairs;
+    const size_t lds = (size_t)pairs * 4096 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_wgrad<VG, VX>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    const long long RB = (M + 15) / 16, want = (RB + RS - 1) / RS;
+    const int grid = (int)(want < slots ? want : slots);
+    {
+        ProfScope _prof("k_linear_wgrad", s);
+        hipLaunchKernelGGL((k_linear_wgrad<VG, VX>), dim3(grid), dim3(64 * pairs * RS), lds, s, G, X, part, db ? 1 : 0, M, N, K,
+                           BN, BK, RS);
+    }
+    const int n = N * K + (db ? N : 0);
+    ProfScope _prof("k_linear_wgrad_reduce", s);
+    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3((n + 63) / 64), dim3(256), 0, s, part, grid, n, dW, N * K, db);
+}
+
+static int vec_of(const float *p, int ld)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    if (ld % 4 == 0 && (a & 15) == 0) return 4;
+    if (ld % 2 == 0 && (a & 7) == 0) return 2;
+    return 1;
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -268,4 +468,35 @@ extern "C" int gsvc_linear_forward(const float *X, const float *W, const float *
         default: launch_ws<12>(X, W, bias, Y, M, K, N, w_in_out, relu, s); break;
     }
     return check_launch("linear_forward");
+}
+
+extern "C" int64_t gsvc_linear_wgrad_workspace(int32_t N, int32_t K)
+{
+    return (int64_t)256 * ((int64_t)N * K + N);      // one slot per workgroup (one per CU), floats
+}
+
+extern "C" int gsvc_linear_wgrad(const float *G, const float *X, float *dW, float *db, int64_t M, int32_t N, int32_t K,
+                                 float *workspace, int64_t workspace_floats, void *stream)
+{
+    GSVC_REQUIRE(M >= 0 && K > 0 && N > 0, "linear_wgrad: bad shape");
+    if (N > LIN_NT_MAX * 16 || K > LIN_NT_MAX * 16) {
+        set_error("linear_wgrad: N=%d / K=%d exceed %d", N, K, LIN_NT_MAX * 16);
+        return GSVC_E_UNSUPPORTED;
+    }
+    GSVC_REQUIRE(G && X && dW && workspace, "linear_wgrad: NULL pointer");
+    const int64_t per_slot = (int64_t)N * K + (db ? N : 0);
+    int64_t slots = workspace_floats / per_slot;
+    GSVC_REQUIRE(slots >= 1, "linear_wgrad: workspace smaller than one slot (N*K + N floats)");
+    if (slots > 256) slots = 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) {
+        (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, s);
+        if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s);
+        return GSVC_OK;
+    }
+    const int vg = vec_of(G, N), vx = vec_of(X, K);
+#define WG_CASE(a, b) if (vg == a && vx == b) launch_wgrad2<a, b>(G, X, dW, db, workspace, (int)slots, M, N, K, s)
+    WG_CASE(4, 4); WG_CASE(4, 2); WG_CASE(4, 1); WG_CASE(2, 4); WG_CASE(2, 2); WG_CASE(2, 1); WG_CASE(1, 4); WG_CASE(1, 2); WG_CASE(1, 1);
+#undef WG_CASE
+    return check_launch("linear_wgrad");
 }

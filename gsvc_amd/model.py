@@ -66,8 +66,8 @@ MFMA_MAX_DIM = 192      # csrc/linear.hip keeps the whole weight matrix in LDS: 
 
 class _LinearMFMA(torch.autograd.Function):
     """y = x W^T + b (optionally followed by ReLU) through the weight-stationary MFMA kernel of csrc/linear.hip.
-    Backward: dX = G W through the same kernel (W read input-major, no transposed copy), dW by the M-split batched
-    GEMM of ``_weight_grad``, db by a column sum."""
+    Backward: dX = G W through the same kernel (W read input-major, no transposed copy); dW = G^T X and db through
+    the row-split MFMA kernel ``gsvc_linear_wgrad``."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu=False):
@@ -98,25 +98,19 @@ class _LinearMFMA(torch.autograd.Function):
             _lib.check(_lib.lib().gsvc_linear_forward(_lib.ptr(g), _lib.ptr(w), None, _lib.ptr(gx), M, N, K, 1, 0,
                                                          _lib.current_stream(x.device)), "gsvc_linear_forward")
         if ctx.needs_input_grad[1]:
-            gw = _weight_grad(g, x)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            # dW = G^T X and db = column sums of G in one pass over G and X (rows split over the chip)
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            L = _lib.lib()
+            ws_floats = int(L.gsvc_linear_wgrad_workspace(N, K))
+            buf = torch.empty(N * K + N + ws_floats, device=x.device, dtype=torch.float32)
+            gw = buf[:N * K].view(N, K)
+            gb = buf[N * K:N * K + N] if want_b else None
+            ws = buf[N * K + N:]
+            _lib.check(L.gsvc_linear_wgrad(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gw), _lib.ptr(gb), M, N, K, _lib.ptr(ws), ws_floats,
+                                           _lib.current_stream(x.device)), "gsvc_linear_wgrad")
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(dim=0)
         return gx, gw, gb, None
-
-
-def _weight_grad(g, x, rows_per_slice: int = 4096):
-    """dW = g^T x for tall g [M,N], x [M,K]: the reduction runs over M with a tiny [N,K] output, which a plain GEMM
-    call tiles by OUTPUT (a dozen workgroups on a 256-CU chip: ~500 us at M = 196k).  Splitting M into slices turns
-    it into a batched GEMM that fills the chip (~60 us), followed by a small sum."""
-    M = g.shape[0]
-    S = M // rows_per_slice
-    if S < 2:
-        return g.t() @ x
-    main = S * rows_per_slice
-    gw = torch.bmm(g[:main].view(S, rows_per_slice, -1).transpose(1, 2), x[:main].view(S, rows_per_slice, -1)).sum(dim=0)
-    if main < M:
-        gw = gw + g[main:].t() @ x[main:]
-    return gw
 
 
 class Linear(nn.Linear):

@@ -198,6 +198,14 @@ int gsvc_ssim_l1_backward(const float *img1, const float *img2, int32_t C, int32
 int gsvc_linear_forward(const float *X, const float *W, const float *bias, float *Y, int64_t M, int32_t K, int32_t N,
                         int32_t w_in_out, int32_t relu, void *stream);
 
+/* dW[N,K] = G[M,N]^T X[M,K] and (db != NULL) db[N] = column sums of G: the weight / bias gradients of the same
+ * layers.  Rows are split over the chip instead of the tiny output; every workgroup writes its partial sums to its
+ * slot of `workspace` ((N*K + N) floats per slot, gsvc_linear_wgrad_workspace() = 256 slots) and a second small
+ * kernel adds the slots, so the result is deterministic (no atomics).  K, N <= 192. */
+int64_t gsvc_linear_wgrad_workspace(int32_t N, int32_t K);
+int gsvc_linear_wgrad(const float *G, const float *X, float *dW, float *db, int64_t M, int32_t N, int32_t K,
+                      float *workspace, int64_t workspace_floats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
