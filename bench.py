@@ -99,7 +99,8 @@ def run_train_step(args, rank, world, local_rank, dev):
 
     H, W, T = args.height, args.width, args.train_frames
     mp_, opt, pipe = cfg_20240919()
-    cube = SyntheticFrameCube(H, W, T, seed=1234, device=dev)
+    # the whole synthetic video resident on the device before the timed region (as the reference holds its video in memory)
+    cube = SyntheticFrameCube(H, W, T, seed=1234, device=dev).materialize()
     mp_.threshold = 8.0 / cube.scale                      # 16-frame sliding window
     # jump straight to the entropy-constrained phase (lambda = 0.004, noise quantisation + sampled rate)
     opt.full_precision_training_total, opt.quantized_training_total = 0, 0

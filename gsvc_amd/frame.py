@@ -73,6 +73,16 @@ class SyntheticFrameCube:
         self._sig = rng.uniform(0.03, 0.12, blobs) * min(height, width)
         self._col = rng.uniform(0.1, 1.0, (blobs, 3))
         self._cache = {}
+        self._cache_limit = 64
+
+    def materialize(self):
+        """Generate and keep every frame and flow field on the device (the reference's FrameCubeDataset also holds the
+        whole video in memory, frame_cube/frame.py:141-152), so that fetching a frame launches no kernel."""
+        self._cache_limit = 2 * self.len + 2
+        for t in range(self.len):
+            self._image(t)
+            self.get_optical_flow(t)
+        return self
 
     def __len__(self):
         return self.len
@@ -93,7 +103,7 @@ class SyntheticFrameCube:
             g = torch.exp(-((xs - float(cx) % W) ** 2 + (ys - float(cy) % H) ** 2) / (2 * float(self._sig[k]) ** 2))
             img = img + g[None] * torch.tensor(self._col[k], dtype=torch.float32, device=self.device)[:, None, None] * 0.5
         img = img.clamp(0, 1)
-        if len(self._cache) < 64:
+        if len(self._cache) < self._cache_limit:
             self._cache[t] = img
         return img
 
@@ -127,6 +137,6 @@ class SyntheticFrameCube:
             num += g[None] * torch.tensor(self._vel[k], dtype=torch.float32, device=self.device)[:, None, None]
             den += g
         flow = num / den
-        if len(self._cache) < 64:
+        if len(self._cache) < self._cache_limit:
             self._cache[key] = flow
         return flow
