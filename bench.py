@@ -49,7 +49,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--anchors", type=int, default=220_000, help="train_step: anchors in the 64-frame cube")
     ap.add_argument("--train-frames", type=int, default=64, help="train_step: frames of the synthetic video")
-    ap.add_argument("--pretrain", type=int, default=0, help="train_step: extra untimed steps before warmup")
+    ap.add_argument("--pretrain", type=int, default=30,
+                    help="train_step: extra untimed steps before the warmup (the per-step tensor sizes vary with the visible set; "
+                         "until the caching allocator has seen them, steps pay hipMalloc calls that synchronise the device)")
     return ap.parse_args()
 
 
@@ -375,7 +377,7 @@ def main():
         try:
             import copy
             a2 = copy.copy(args)
-            a2.steps, a2.warmup, a2.no_cpu_baseline = min(args.steps, 10), min(args.warmup, 4), True
+            a2.steps, a2.warmup, a2.no_cpu_baseline = min(args.steps, 20), min(args.warmup, 4), True
             del d, dL, grads, scratch
             torch.cuda.empty_cache()
             ts = run_train_step(a2, rank, world, local_rank, dev)

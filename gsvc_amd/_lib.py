@@ -57,6 +57,12 @@ _SIGNATURES = {
     "gsvc_rate_forward": (C.c_int, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_int32, _i64, _i64, _vp, _vp, _vp]),
     "gsvc_ssim_l1_forward": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_ssim_l1_backward": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_optical_forward": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, C.c_int32, _i64, _vp, C.c_int32, C.c_int32,
+                                       C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_optical_backward": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_regs_partial_floats": (_i64, [C.POINTER(C.c_int64), C.c_int32]),
+    "gsvc_regs_forward": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, _vp, _vp, _vp]),
+    "gsvc_regs_backward": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_linear_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "gsvc_linear_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, _vp, _i64, _vp]),
     "gsvc_linear_wgrad_workspace": (_i64, [C.c_int32, C.c_int32]),

@@ -56,6 +56,7 @@ class GeneratedGaussians:
     # extras of the un-compacted ("dense") batched path, None otherwise
     visible_index: torch.Tensor = None   # int64 indices of the visible anchors (what visable_mask.nonzero() gives)
     world_xyz: torch.Tensor = None       # anchor + offsets * scaling[:, :3] before the bound clamp, per Gaussian
+    batch: object = None                 # the renders' shared un-split tensors (scaling, neural_opacity, mask, seg_offsets)
 
 
 BASE_Q_FEAT, BASE_Q_SCALING, BASE_Q_OFFSETS = 1, 0.001, 0.2
@@ -370,6 +371,8 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         # per-render pieces by split (one cat in backward per tensor, instead of a zero-fill + copy + add per slice)
         sizes = [c * K for c in seg.counts]
         parts = [t.split(sizes, dim=0) for t in (xyz, color, neural_opacity, scaling, rot, world)]
+        from types import SimpleNamespace
+        batch = SimpleNamespace(scaling=scaling, neural_opacity=neural_opacity, mask=mask, seg_offsets=[b * K for b in seg.bounds])
         out = []
         for r, gs in enumerate(seg.slices(K)):
             out.append(GeneratedGaussians(
@@ -377,7 +380,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
                 neural_opacity=parts[2][r], visable_mask=visible_masks[r], mask=mask[gs],
                 bit_per_param=rates[r].bit_per_param, bit_per_feat_param=rates[r].bit_per_feat_param,
                 bit_per_scaling_param=rates[r].bit_per_scaling_param, bit_per_offsets_param=rates[r].bit_per_offsets_param,
-                concatenated_all=None, time_sub=time_sub, visible_index=vis_list[r], world_xyz=parts[5][r]))
+                concatenated_all=None, time_sub=time_sub, visible_index=vis_list[r], world_xyz=parts[5][r], batch=batch))
         return out
     per_anchor = torch.cat([grid_scaling, anchor], dim=-1)
     concatenated_all = torch.cat([per_anchor.repeat_interleave(K, dim=0), color, scale_rot, offsets], dim=-1)

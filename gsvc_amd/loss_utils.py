@@ -137,30 +137,92 @@ def calc_optical_loss_one_frame(render_results1, render_results2, optical_flow, 
     return (d - uv).abs().mean(), pix, d * scale
 
 
+class _OpticalPair(torch.autograd.Function):
+    """Optical-flow consistency of one adjacent-frame pair over un-compacted renders (csrc/losses.hip)."""
+
+    @staticmethod
+    def forward(ctx, world1, world2, mask1, mask2, vis1, vis2, flow, K, anchors, x_min, y_min, scale, x_pix_max, y_pix_max):
+        from . import _lib
+        dev = world1.device
+        world1, world2 = world1.contiguous(), world2.contiguous()
+        m1, m2 = mask1.contiguous().view(torch.uint8), mask2.contiguous().view(torch.uint8)
+        flow = flow.contiguous()
+        n1, n2 = world1.shape[0], world2.shape[0]
+        table = torch.empty(anchors * K, dtype=torch.int32, device=dev)
+        partner = torch.empty(max(n1, 1), dtype=torch.int32, device=dev)
+        sums = torch.empty(2, dtype=torch.float32, device=dev)
+        partial = torch.empty(2 * max((n1 + 255) // 256, 1), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().gsvc_optical_forward(
+            _lib.ptr(world1), _lib.ptr(m1), _lib.ptr(vis1.contiguous()), n1, _lib.ptr(world2), _lib.ptr(m2), _lib.ptr(vis2.contiguous()),
+            n2, K, anchors, _lib.ptr(flow), flow.shape[1], flow.shape[2], float(x_min), float(y_min), float(scale), int(x_pix_max),
+            int(y_pix_max), _lib.ptr(table), _lib.ptr(partner), _lib.ptr(sums), _lib.ptr(partial), _lib.current_stream(dev)),
+            "gsvc_optical_forward")
+        ctx.save_for_backward(partner, sums)
+        ctx.n = (n1, n2)
+        return sums[0] / (2.0 * sums[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        partner, sums = ctx.saved_tensors
+        n1, n2 = ctx.n
+        dev = partner.device
+        g1 = torch.empty(n1, 3, dtype=torch.float32, device=dev)
+        g2 = torch.empty(n2, 3, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().gsvc_optical_backward(_lib.ptr(partner), n1, n2, _lib.ptr(sums), _lib.ptr(g.contiguous().float()),
+                                                    _lib.ptr(g1), _lib.ptr(g2), _lib.current_stream(dev)), "gsvc_optical_backward")
+        return (g1, g2) + (None,) * 12
+
+
 def _optical_loss_dense(r1, r2, optical_flow, x_min, y_min, scale, x_pix_max: int, y_pix_max: int, n_offsets=10):
     """calc_optical_loss_one_frame for un-compacted results (render_many(dense=True)): the "alive in both renders"
-    intersection and the pairing of the two renders' Gaussians go through [anchors, K] tables indexed by anchor
-    row, and membership becomes a 0/1 weight — the same mean over the same pairs, with no compaction and therefore
-    no host synchronisation."""
-    K = n_offsets
-    dev = r1.visible_mask.device
-    A = r1.visible_mask.shape[0]
-    v1, v2 = r1.visible_index, r2.visible_index
-    m1 = r1.generated_gaussians.mask.view(-1, K)
-    m2 = r2.generated_gaussians.mask.view(-1, K)
-    alive2 = torch.zeros(A, K, dtype=torch.bool, device=dev).index_put_((v2,), m2)
-    xy2_table = torch.zeros(A, K, 2, dtype=r2.generated_gaussians.world_xyz.dtype, device=dev)
-    xy2_table = xy2_table.index_put((v2,), r2.generated_gaussians.world_xyz.view(-1, K, 3)[:, :, :2])
-    keep = (m1 & alive2.index_select(0, v1)).view(-1)                      # per Gaussian of render 1
-    xy1 = r1.generated_gaussians.world_xyz[:, :2]
-    xy2 = xy2_table.index_select(0, v1).view(-1, 2)
-    pix = ((xy1 - torch.tensor([[x_min, y_min]], dtype=xy1.dtype, device=dev)) * scale).round().long()
-    ok = (pix[:, 0] >= 0) & (pix[:, 1] >= 0) & (pix[:, 0] < x_pix_max) & (pix[:, 1] < y_pix_max)
-    w = (keep & ok).to(xy1.dtype).unsqueeze(1)
-    flow = optical_flow.permute(2, 1, 0).to(dev)
-    uv = flow[pix[:, 0].clamp(0, x_pix_max - 1), pix[:, 1].clamp(0, y_pix_max - 1), ...] / scale
-    d = xy2 - xy1
-    return ((d - uv).abs() * w).sum() / (2.0 * w.sum())
+    intersection and the pairing of the two renders' Gaussians go through an [anchors*K] slot table inside the fused
+    kernels of csrc/losses.hip — the same mean over the same pairs, with no compaction and no host synchronisation."""
+    g1, g2 = r1.generated_gaussians, r2.generated_gaussians
+    return _OpticalPair.apply(g1.world_xyz, g2.world_xyz, g1.mask, g2.mask, r1.visible_index, r2.visible_index,
+                              optical_flow.to(g1.world_xyz.device), n_offsets, r1.visible_mask.shape[0], x_min, y_min, scale,
+                              x_pix_max, y_pix_max)
+
+
+class _RenderRegs(torch.autograd.Function):
+    """(sum_r mean over opacity>0 of prod(scaling), sum_r mean(1 - neural_opacity)) over the concatenated
+    un-compacted Gaussians of R renders (csrc/losses.hip)."""
+
+    @staticmethod
+    def forward(ctx, scaling, neural_opacity, mask, seg_offsets):
+        import ctypes as C
+        from . import _lib
+        dev = scaling.device
+        scaling, op = scaling.contiguous(), neural_opacity.contiguous()
+        m = mask.contiguous().view(torch.uint8)
+        R = len(seg_offsets) - 1
+        seg = (C.c_int64 * (R + 1))(*[int(v) for v in seg_offsets])
+        L = _lib.lib()
+        sums = torch.empty(3 * R, dtype=torch.float32, device=dev)
+        partial = torch.empty(int(L.gsvc_regs_partial_floats(seg, R)), dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        _lib.check(L.gsvc_regs_forward(_lib.ptr(scaling), _lib.ptr(op), _lib.ptr(m), seg, R, _lib.ptr(sums), _lib.ptr(partial),
+                                       _lib.ptr(out), _lib.current_stream(dev)), "gsvc_regs_forward")
+        ctx.save_for_backward(scaling, m, sums)
+        ctx.seg, ctx.R, ctx.op_shape = seg, R, neural_opacity.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        scaling, m, sums = ctx.saved_tensors
+        dev = scaling.device
+        gs = torch.empty_like(scaling)
+        go = torch.empty(scaling.shape[0], dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().gsvc_regs_backward(_lib.ptr(scaling), _lib.ptr(m), ctx.seg, ctx.R, _lib.ptr(sums),
+                                                 _lib.ptr(g.contiguous().float()), _lib.ptr(gs), _lib.ptr(go),
+                                                 _lib.current_stream(dev)), "gsvc_regs_backward")
+        return gs, go.view(ctx.op_shape), None, None
+
+
+def render_regs(scaling, neural_opacity, mask, seg_offsets):
+    """Returns the 2-vector (scaling regulariser, opacity regulariser) summed over the renders delimited by seg_offsets."""
+    return _RenderRegs.apply(scaling, neural_opacity, mask, seg_offsets)
 
 
 def calc_optical_loss(render_results1_f, render_results1_b, render_results2_f, render_results2_b, optical_flow,

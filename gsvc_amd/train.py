@@ -18,7 +18,7 @@ import torch
 from . import dist as gdist
 from .encodings import get_binary_vxl_size
 from .generate import GenerateMode, region
-from .loss_utils import calc_optical_loss, ssim_l1
+from .loss_utils import calc_optical_loss, render_regs, ssim_l1
 from .ortho_gaussian_renderer import render, render_many
 from .rasterizer import resolve_deferred
 from .train_util import TrainingController
@@ -116,24 +116,32 @@ class Trainer:
         gt2 = frame2.image.to(dev).permute(0, 2, 1)
         ssim1, l1_1 = ssim_l1(image1, gt1.contiguous())
         ssim2, l1_2 = ssim_l1(image2, gt2.contiguous())
-        Ll1 = l1_1 + l1_2
-        ssim_loss = (1.0 - ssim1) + (1.0 - ssim2)
-        scaling_reg = sum(_mean_over_selected(r.scaling.prod(dim=1), r) for r in renders)
-        opacity_reg = sum((1 - r.neural_opacity).mean() for r in renders)
-        if opt.optical_lambda == 0:
-            optical_loss = 0
+        # the loss is a weighted sum of scalar terms: they are collected and combined with one stack + dot (instead of
+        # one tiny kernel per +, *, and their backward nodes)
+        terms, weights, const = [l1_1, l1_2, ssim1, ssim2], [1.0 - opt.lambda_dssim] * 2 + [-opt.lambda_dssim] * 2, 2.0 * opt.lambda_dssim
+        batch = getattr(r1f.generated_gaussians, "batch", None) if self.batched else None
+        if batch is not None:
+            regs = render_regs(batch.scaling, batch.neural_opacity, batch.mask, batch.seg_offsets)
+            terms += [regs[0], regs[1]]
         else:
+            terms += [sum(_mean_over_selected(r.scaling.prod(dim=1), r) for r in renders),
+                      sum((1 - r.neural_opacity).mean() for r in renders)]
+        weights += [opt.scaling_reg, opt.opacity_reg]
+        if opt.optical_lambda != 0:
             flow = self.dataset.get_optical_flow(frame_idx)
-            optical_loss = calc_optical_loss(r1f, r1b, r2f, r2b, flow, self.dataset.x_min, self.dataset.y_min,
-                                             self.dataset.scale, self.dataset.width, self.dataset.height, pc.n_offsets)
-        loss = ((1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * ssim_loss + opt.scaling_reg * scaling_reg
-                + opt.opacity_reg * opacity_reg + opt.optical_lambda * optical_loss)
+            terms.append(calc_optical_loss(r1f, r1b, r2f, r2b, flow, self.dataset.x_min, self.dataset.y_min,
+                                           self.dataset.scale, self.dataset.width, self.dataset.height, pc.n_offsets))
+            weights.append(opt.optical_lambda)
         if self.controller.entropy_constrained:
             assert all(r.entropy_constrained for r in renders)
-            bit_per_param = sum(r.bit_per_param for r in renders)
             denom = pc._anchor.shape[0] * (pc.feat_dim + 6 + 3 * pc.n_offsets)
-            loss = loss + opt.lmbda * (bit_per_param + hash_grid_bits(pc) / denom)
-            loss = loss + 5e-4 * torch.mean(torch.sigmoid(pc._mask))
+            terms += [r.bit_per_param for r in renders] + [hash_grid_bits(pc), torch.mean(torch.sigmoid(pc._mask))]
+            weights += [opt.lmbda] * 4 + [opt.lmbda / denom, 5e-4]
+        key = tuple(weights)
+        if getattr(self, "_w_key", None) != key:      # the weights change only with the training phase
+            self._w_key, self._w = key, torch.tensor(weights, dtype=torch.float32, device=dev)
+        w = self._w
+        loss = torch.dot(torch.stack([t.reshape(()) for t in terms]), w) + const
         with region('step.backward'):
             loss.backward()
         gdist.allreduce_gradients([p for g in pc.optimizer.param_groups for p in g["params"]])

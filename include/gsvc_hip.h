@@ -187,6 +187,36 @@ int gsvc_ssim_l1_backward(const float *img1, const float *img2, int32_t C, int32
                           void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Per-Gaussian loss terms of the fitting step over UN-COMPACTED renders (every visible anchor contributes its K
+ * Gaussians; mask[i] = opacity_i > 0)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Optical-flow consistency of one adjacent-frame pair (reference utils/loss_utils.py:76-135,
+ * calc_optical_loss_one_frame): over the Gaussians alive in both renders (same anchor, same offset slot) whose
+ * frame-t pixel round((xy1 - (x_min, y_min)) * scale) lies inside [0, x_pix_max) x [0, y_pix_max):
+ *   sums[0] = sum |(xy2 - xy1) - flow[:, py, px] / scale|_1,  sums[1] = number of such Gaussians;  loss = sums[0] / (2 sums[1]).
+ * world{1,2}: [n,3] positions before the bound clamp; vis{1,2}: int64 anchor index of each row of K Gaussians;
+ * flow: [2, flow_h, flow_w].  Scratch (caller-allocated): table int32[anchors*K], partner int32[n1] (kept for backward),
+ * partial float[2*ceil(n1/256)] (per-workgroup sums; a second small kernel adds them — no atomics, deterministic). */
+int gsvc_optical_forward(const float *world1, const uint8_t *mask1, const int64_t *vis1, int64_t n1, const float *world2,
+                         const uint8_t *mask2, const int64_t *vis2, int64_t n2, int32_t K, int64_t anchors, const float *flow,
+                         int32_t flow_h, int32_t flow_w, float x_min, float y_min, float scale, int32_t x_pix_max,
+                         int32_t y_pix_max, int32_t *table, int32_t *partner, float *sums, float *partial, void *stream);
+/* grad_world{1,2}[n,3] = d(loss)/d(world) * grad_out[0] (device scalar); both are overwritten. */
+int gsvc_optical_backward(const int32_t *partner, int64_t n1, int64_t n2, const float *sums, const float *grad_out,
+                          float *grad_world1, float *grad_world2, void *stream);
+
+/* Regularisers of the R renders of one step (reference pipeline/train.py:417-424) over their concatenated Gaussians
+ * (render r = [seg_offsets[r], seg_offsets[r+1]), host array of R+1 entries, R <= 8):
+ *   out[0] = sum_r mean_{i in r, mask_i}(scaling_i0 scaling_i1 scaling_i2),  out[1] = sum_r mean_{i in r}(1 - neural_opacity_i).
+ * sums: float[3R] kept for backward; partial: float[gsvc_regs_partial_floats()] scratch (per-workgroup sums). */
+int64_t gsvc_regs_partial_floats(const int64_t *seg_offsets_host, int32_t R);
+int gsvc_regs_forward(const float *scaling, const float *neural_opacity, const uint8_t *mask, const int64_t *seg_offsets_host,
+                      int32_t R, float *sums, float *partial, float *out, void *stream);
+int gsvc_regs_backward(const float *scaling, const uint8_t *mask, const int64_t *seg_offsets_host, int32_t R, const float *sums,
+                       const float *grad_out, float *grad_scaling, float *grad_opacity, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Linear layers of the generator / deformation / entropy-parameter MLPs (reference scene/gaussian_model.py:
  * 150-232: every nn.Linear applied to the [anchors, features] matrix)
  * ---------------------------------------------------------------------------------------------------- */

@@ -172,3 +172,74 @@ def test_dense_step_equals_per_render_step(entropy):
     for n in ga:
         scale = gb[n].abs().max().item()
         assert (ga[n] - gb[n]).abs().max().item() <= 2e-3 * scale + 1e-12, n
+
+
+def test_fused_loss_terms_match_torch():
+    """csrc/losses.hip against plain torch statements of the same terms: the regularisers over un-compacted per-render
+    segments (values and gradients), and the optical-flow pair loss against the reference-style
+    calc_optical_loss_one_frame run on compacted copies of the same renders."""
+    from types import SimpleNamespace
+    from gsvc_amd import loss_utils as LU
+    g = torch.Generator().manual_seed(5)
+    K, A = 4, 900
+    # ---- regularisers
+    counts = [37, 0, 250, 411]
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c * K)
+    n = offs[-1]
+    scaling = (torch.rand(n, 3, generator=g) * 0.1).cuda().requires_grad_(True)
+    op = (torch.rand(n, 1, generator=g) * 2 - 1).cuda().requires_grad_(True)
+    mask = (op.detach().view(-1) > 0)
+    out = LU.render_regs(scaling, op, mask, offs)
+    ref0 = sum((scaling[a:b].prod(1) * mask[a:b]).sum() / mask[a:b].sum() for a, b in zip(offs[:-1], offs[1:]) if b > a)
+    ref1 = sum((1 - op[a:b]).mean() for a, b in zip(offs[:-1], offs[1:]) if b > a)
+    # an empty render contributes 0/0 = nan in both statements (mean of an empty selection): compare without it
+    offs2 = [o for i, o in enumerate(offs) if i == 0 or offs[i] != offs[i - 1]]
+    out = LU.render_regs(scaling, op, mask, offs2)
+    assert abs(float(out[0]) - float(ref0)) < 1e-6 * max(1.0, abs(float(ref0))) and abs(float(out[1]) - float(ref1)) < 1e-5
+    (out[0] * 3.0 + out[1] * 0.5).backward()
+    gs, go = scaling.grad.clone(), op.grad.clone()
+    scaling.grad = op.grad = None
+    (ref0 * 3.0 + ref1 * 0.5).backward()
+    assert torch.allclose(gs, scaling.grad, rtol=1e-4, atol=1e-9) and torch.allclose(go, op.grad, rtol=1e-5, atol=1e-9)
+
+    # ---- optical-flow pair
+    H, W, scale = 48, 64, 32.0
+    x_min, y_min = -W / 2 / scale, -H / 2 / scale
+    flow = (torch.randn(2, H, W, generator=g) * 2).cuda()
+
+    def fake_render(seed):
+        gg = torch.Generator().manual_seed(seed)
+        vis_mask = torch.rand(A, generator=gg) < 0.6
+        vis = vis_mask.nonzero().squeeze(1).cuda()
+        rows = vis.shape[0]
+        world = torch.stack([torch.rand(rows * K, generator=gg) * 2.4 - 1.2, torch.rand(rows * K, generator=gg) * 1.8 - 0.9,
+                             torch.rand(rows * K, generator=gg)], 1).cuda().requires_grad_(True)
+        m = (torch.rand(rows * K, generator=gg) < 0.7).cuda()
+        gsd = SimpleNamespace(world_xyz=world, mask=m)
+        return SimpleNamespace(visible_mask=vis_mask.cuda(), visible_index=vis, generated_gaussians=gsd, dense=True), world, m
+
+    r1, w1, m1 = fake_render(11)
+    r2, w2, m2 = fake_render(12)
+    w2.data[:, :2] = 0.0
+    # make render 2 a displaced copy of render 1 where both exist, so that |d - uv| is informative
+    loss = LU._optical_loss_dense(r1, r2, flow, x_min, y_min, scale, W, H, K)
+    loss.backward()
+    g1, g2 = w1.grad.clone(), w2.grad.clone()
+
+    def compact(r, world, m):
+        # reference-style result: concatenated_all rows = all K slots of the visible anchors; columns 0:6 scaling (ones),
+        # 6:9 anchor (zeros), 19:22 offsets -> anchor + offsets * scaling[:, :3] = world
+        n = world.shape[0]
+        ca = torch.cat([torch.ones(n, 6, device="cuda"), torch.zeros(n, 13, device="cuda"), world], dim=1)
+        return SimpleNamespace(visible_mask=r.visible_mask, generated_gaussians=SimpleNamespace(mask=m, concatenated_all=ca)), None
+
+    w1.grad = w2.grad = None
+    c1, _ = compact(r1, w1, m1)
+    c2, _ = compact(r2, w2, m2)
+    ref, pix, _ = LU.calc_optical_loss_one_frame(c1, c2, flow, x_min, y_min, scale, W, H, K)
+    assert pix.shape[0] > 50
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    ref.backward()
+    assert torch.allclose(g1, w1.grad, rtol=1e-4, atol=1e-8) and torch.allclose(g2, w2.grad, rtol=1e-4, atol=1e-8)

@@ -9,7 +9,7 @@ from gsvc_amd.model import GaussianModel
 from gsvc_amd.train import Trainer
 dev = torch.device("cuda")
 mp_, opt, pipe = cfg_20240919()
-cube = SyntheticFrameCube(1080, 1920, 64, device=dev)
+cube = SyntheticFrameCube(1080, 1920, 64, device=dev).materialize()
 mp_.threshold = 8.0 / cube.scale
 opt.full_precision_training_total = opt.quantized_training_total = 0
 opt.entropy_constrained_train_total = 10 ** 9
@@ -44,4 +44,4 @@ elif os.environ.get('STACKS'):
     for k, v in sorted(cnt.items(), key=lambda kv: -kv[1])[:60]:
         print(v, k[0], k[1])
 else:
-    print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=60))
+    print(prof.key_averages().table(sort_by=os.environ.get("SORT", "self_cuda_time_total"), row_limit=45, max_name_column_width=60))
