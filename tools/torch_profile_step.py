@@ -21,8 +21,8 @@ pc.create_from_points(rng.uniform(lim, -lim, (220000, 3)), 1.0)
 pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
 pc.training_setup(opt)
 tr = Trainer(pc, cube, opt, pipe, mp_)
-for i in range(4):
-    tr.step(i + 1, frame_idx=30)
+for i in range(30):
+    tr.step(i + 1)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=bool(os.environ.get('STACKS')), record_shapes=bool(os.environ.get('SHAPES'))) as prof:
     for i in range(3):
