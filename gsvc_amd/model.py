@@ -448,6 +448,27 @@ class GaussianModel(nn.Module):
         for group in self.optimizer.param_groups:
             group["lr"] = self.scheduler_registry[group["name"]](iteration)
 
+    # ------------------------------------------------------------------ densification / pruning (:1242-1505, gsvc_amd/densify.py)
+    def replace_tensor_to_optimizer(self, tensor, name):
+        from . import densify
+        return densify.replace_tensor_to_optimizer(self, tensor, name)
+
+    def cat_tensors_to_optimizer(self, tensors_dict):
+        from . import densify
+        return densify.cat_tensors_to_optimizer(self, tensors_dict)
+
+    def prune_anchor(self, mask):
+        from . import densify
+        return densify.prune_anchor(self, mask)
+
+    def anchor_growing(self, grads, threshold, offset_mask):
+        from . import densify
+        return densify.anchor_growing(self, grads, threshold, offset_mask)
+
+    def adjust_anchor(self, check_interval=100, success_threshold=0.8, grad_threshold=0.0002, min_opacity=0.005):
+        from . import densify
+        return densify.adjust_anchor(self, check_interval, success_threshold, grad_threshold, min_opacity)
+
     # ------------------------------------------------------------------ densification statistics (:1281-1314)
     @torch.no_grad()
     def training_statis(self, render_results):

@@ -5,8 +5,7 @@ Same loss and order of operations as the step body of reference pipeline/train.p
 evaluation, tensorboard and the codec calls around it are out of scope.  Differences in mechanism: no per-step
 `.item()` / synchronize (the reference syncs ~10x per step for logging), the hash-table bit count stays on the
 device, and under torch.distributed each rank steps on its own frame pair and gradients are averaged with one
-collective (gsvc_amd/dist.py).  Anchor growing/pruning (adjust_anchor) is the next row of SURVEY.md section 8f
-and is not performed here.
+collective (gsvc_amd/dist.py).  Anchor growing/pruning runs at the reference's cadence (gsvc_amd/densify.py).
 """
 from __future__ import annotations
 
@@ -86,6 +85,21 @@ class Trainer:
         self.controller.step()
         return out
 
+    def _adjust_anchor(self, iteration):
+        """Densify / prune (reference pipeline/train.py:567-569).  Under data parallelism every rank must take the same
+        decisions: the statistics are summed over ranks first and the random thinning uses a per-iteration seed."""
+        opt, pc = self.opt, self.pc
+        if gdist.world_size() > 1:
+            gdist.allreduce_statistics(pc)
+            devices = [pc.device] if pc.device.type == "cuda" else []
+            with torch.random.fork_rng(devices=devices):
+                torch.manual_seed(977 + iteration)
+                pc.adjust_anchor(check_interval=opt.update_interval, success_threshold=opt.success_threshold,
+                                 grad_threshold=opt.densify_grad_threshold, min_opacity=opt.min_opacity)
+        else:
+            pc.adjust_anchor(check_interval=opt.update_interval, success_threshold=opt.success_threshold,
+                             grad_threshold=opt.densify_grad_threshold, min_opacity=opt.min_opacity)
+
     def _step(self, iteration: int, frame_idx: int | None = None):
         opt, pc = self.opt, self.pc
         dev = pc.device
@@ -157,6 +171,10 @@ class Trainer:
             if self.controller.gaussian_statis:
                 for r in renders:
                     pc.training_statis(r)
+            if self.controller.gaussian_adjust_anchor:
+                self._adjust_anchor(iteration)
+            if self.controller.clean_denorm:
+                pc.opacity_accum = pc.offset_gradient_accum = pc.offset_denom = None
             if iteration < opt.iterations:
                 pc.optimizer.step()
                 pc.optimizer.zero_grad(set_to_none=True)

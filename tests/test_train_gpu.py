@@ -243,3 +243,29 @@ def test_fused_loss_terms_match_torch():
     assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
     ref.backward()
     assert torch.allclose(g1, w1.grad, rtol=1e-4, atol=1e-8) and torch.allclose(g2, w2.grad, rtol=1e-4, atol=1e-8)
+
+
+def test_training_crosses_densification_steps():
+    """The step keeps running through adjust_anchor (grow + prune every update_interval steps): parameter, statistic
+    and Adam-state shapes stay consistent, the loss stays finite, the number of anchors changes."""
+    pc, cube, opt, pipe, mp, Trainer = _setup(anchors=3000)
+    opt.full_precision_training_total = 1000
+    opt.start_stat, opt.update_from, opt.update_interval, opt.update_until, opt.pause_densification = 2, 6, 5, 40, 0
+    opt.densify_grad_threshold, opt.success_threshold = 1e-7, 0.2
+    pc.training_setup(opt)
+    tr = Trainer(pc, cube, opt, pipe, mp)
+    a0 = pc._anchor.shape[0]
+    counts = []
+    for it in range(1, 24):
+        out = tr.step(it, frame_idx=4 + it % 3)
+        assert np.isfinite(float(out.loss))
+        counts.append(pc._anchor.shape[0])
+    A, K = pc._anchor.shape[0], pc.n_offsets
+    assert len(set(counts)) > 1 and A != a0
+    assert pc._offset.shape == (A, K, 3) and pc._mask.shape == (A, K, 1) and pc._anchor_feat.shape[0] == A
+    assert pc.opacity_accum.shape == (A, 1) and pc.anchor_demon.shape == (A, 1)
+    assert pc.offset_gradient_accum.shape == (A * K, 1) and pc.offset_denom.shape == (A * K, 1)
+    grp = [g for g in pc.optimizer.param_groups if g["name"] == "anchor_feat"][0]
+    assert grp["params"][0] is pc._anchor_feat and pc.optimizer.state[pc._anchor_feat]["exp_avg"].shape == pc._anchor_feat.shape
+    for n, p in pc.named_parameters():
+        assert torch.isfinite(p).all(), n
