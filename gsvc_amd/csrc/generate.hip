@@ -1,0 +1,164 @@
+// gsvc_amd/csrc/generate.hip — tail of the anchor -> neural-Gaussian generation as one kernel each way, gfx950.
+//
+// After the MLPs, reference ortho_gaussian_renderer/guassian.py:262-296 turns their raw outputs into the rasterizer's
+// inputs with a dozen elementwise launches (and ~30 more in backward).  For un-compacted renders (all K slots of every
+// visible anchor, n = rows*K Gaussians) this is, per Gaussian i of anchor row r = i / K:
+//     neural_opacity = opacity_raw * offset_mask                 mask = neural_opacity > 0
+//     scaling        = grid_scaling[r, 3:6] * sigmoid(scale_rot[i, 0:3])
+//     rot            = scale_rot[i, 3:7] / max(|scale_rot[i, 3:7]|, 1e-12)            (F.normalize)
+//     world          = anchor[r] + (grid_offsets[i] + neural_offset[i]) * grid_scaling[r, 0:3]
+//     xyz            = clamp(world, bound_min, bound_max)
+// One lane per Gaussian both ways; in backward a block takes whole anchor rows and the gradients of grid_scaling /
+// anchor (sums over the row's K Gaussians) meet in LDS: no atomics, deterministic.
+#include "common.h"
+
+namespace gsvc {
+
+struct Bounds3 {
+    float lo[3], hi[3];
+};
+
+__global__ void __launch_bounds__(256) k_gen_tail_fwd(const float *__restrict__ op_raw, const float *__restrict__ offset_mask,
+                                                      const float *__restrict__ grid_offsets, const float *__restrict__ neural_offset,
+                                                      const float *__restrict__ scale_rot, const float *__restrict__ grid_scaling,
+                                                      const float *__restrict__ anchor, Bounds3 bd, int64_t n, int K,
+                                                      float *__restrict__ neural_opacity, uint8_t *__restrict__ mask,
+                                                      float *__restrict__ scaling, float *__restrict__ rot,
+                                                      float *__restrict__ world, float *__restrict__ xyz)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = i / K;
+    const float no = op_raw[i] * offset_mask[i];
+    neural_opacity[i] = no;
+    mask[i] = no > 0.0f ? 1 : 0;
+    const float *sr = scale_rot + 7 * i;
+    const float *gs = grid_scaling + 6 * r;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float sg = 1.0f / (1.0f + expf(-sr[c]));
+        scaling[3 * i + c] = gs[3 + c] * sg;
+        const float w = anchor[3 * r + c] + (grid_offsets[3 * i + c] + neural_offset[3 * i + c]) * gs[c];
+        world[3 * i + c] = w;
+        xyz[3 * i + c] = fminf(fmaxf(w, bd.lo[c]), bd.hi[c]);
+    }
+    const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
+    const float inv = 1.0f / fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
+    rot[4 * i] = q0 * inv; rot[4 * i + 1] = q1 * inv; rot[4 * i + 2] = q2 * inv; rot[4 * i + 3] = q3 * inv;
+}
+
+// any of the incoming gradients may be NULL (that output was not used).  A block takes rpb = 256 / K whole anchor rows
+// (rpb * K lanes, one per Gaussian, coalesced accesses); the per-row sums (grid_scaling / anchor gradients) meet in LDS.
+__global__ void __launch_bounds__(256) k_gen_tail_bwd(const float *__restrict__ op_raw, const float *__restrict__ offset_mask,
+                                                      const float *__restrict__ grid_offsets, const float *__restrict__ neural_offset,
+                                                      const float *__restrict__ scale_rot, const float *__restrict__ grid_scaling,
+                                                      const float *__restrict__ world, Bounds3 bd, int64_t rows, int K, int rpb,
+                                                      const float *__restrict__ g_no, const float *__restrict__ g_scaling,
+                                                      const float *__restrict__ g_rot, const float *__restrict__ g_world,
+                                                      const float *__restrict__ g_xyz, float *__restrict__ d_op_raw,
+                                                      float *__restrict__ d_offset_mask, float *__restrict__ d_offsets,
+                                                      float *__restrict__ d_scale_rot, float *__restrict__ d_grid_scaling,
+                                                      float *__restrict__ d_anchor)
+{
+    __shared__ float part[256][9];      // per Gaussian: gw*offset (3), g_scaling*sigmoid (3), gw (3)
+    const int t = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * rpb;
+    const int lr = t / K;                                   // row inside the block
+    const int64_t r = row0 + lr, i = r * K + (t - lr * K);
+    const bool live = lr < rpb && r < rows;
+    float c9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float gno = g_no ? g_no[i] : 0.f;
+        d_op_raw[i] = gno * offset_mask[i];
+        d_offset_mask[i] = gno * op_raw[i];
+        const float *sr = scale_rot + 7 * i;
+        const float *gs = grid_scaling + 6 * r;
+        float *dsr = d_scale_rot + 7 * i;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float w = world[3 * i + c];
+            float gw = g_world ? g_world[3 * i + c] : 0.f;
+            if (g_xyz && w >= bd.lo[c] && w <= bd.hi[c]) gw += g_xyz[3 * i + c];
+            d_offsets[3 * i + c] = gw * gs[c];
+            const float sg = 1.0f / (1.0f + expf(-sr[c]));
+            const float gsc = g_scaling ? g_scaling[3 * i + c] : 0.f;
+            dsr[c] = gsc * gs[3 + c] * sg * (1.0f - sg);
+            c9[c] = gw * (grid_offsets[3 * i + c] + neural_offset[3 * i + c]);
+            c9[3 + c] = gsc * sg;
+            c9[6 + c] = gw;
+        }
+        const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
+        const float nrm = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+        if (g_rot) { g0 = g_rot[4 * i]; g1 = g_rot[4 * i + 1]; g2 = g_rot[4 * i + 2]; g3 = g_rot[4 * i + 3]; }
+        if (nrm > 1e-12f) {
+            const float inv = 1.0f / nrm;
+            const float y0 = q0 * inv, y1 = q1 * inv, y2 = q2 * inv, y3 = q3 * inv;
+            const float dot = y0 * g0 + y1 * g1 + y2 * g2 + y3 * g3;
+            dsr[3] = (g0 - y0 * dot) * inv; dsr[4] = (g1 - y1 * dot) * inv;
+            dsr[5] = (g2 - y2 * dot) * inv; dsr[6] = (g3 - y3 * dot) * inv;
+        } else {
+            dsr[3] = g0 * 1e12f; dsr[4] = g1 * 1e12f; dsr[5] = g2 * 1e12f; dsr[6] = g3 * 1e12f;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 9; c++) part[t][c] = c9[c];
+    __syncthreads();
+    // lane (row, component): 9 components x rpb rows
+    for (int v = t; v < rpb * 9; v += 256) {
+        const int rr = v / 9, c = v - rr * 9;
+        const int64_t gr = row0 + rr;
+        if (gr >= rows) continue;
+        float a = 0.f;
+        for (int k = 0; k < K; k++) a += part[rr * K + k][c];
+        if (c < 6) d_grid_scaling[6 * gr + c] = a;
+        else if (d_anchor) d_anchor[3 * gr + (c - 6)] = a;
+    }
+}
+
+}  // namespace gsvc
+
+using namespace gsvc;
+
+extern "C" int gsvc_gen_tail_forward(const float *op_raw, const float *offset_mask, const float *grid_offsets,
+                                     const float *neural_offset, const float *scale_rot, const float *grid_scaling,
+                                     const float *anchor, const float *bound_min3_host, const float *bound_max3_host, int64_t rows,
+                                     int32_t K, float *neural_opacity, uint8_t *mask, float *scaling, float *rot, float *world,
+                                     float *xyz, void *stream)
+{
+    GSVC_REQUIRE(rows >= 0 && K > 0 && bound_min3_host && bound_max3_host, "gen_tail_forward: bad arguments");
+    if (rows == 0) return GSVC_OK;
+    GSVC_REQUIRE(op_raw && offset_mask && grid_offsets && neural_offset && scale_rot && grid_scaling && anchor && neural_opacity &&
+                 mask && scaling && rot && world && xyz, "gen_tail_forward: NULL pointer");
+    Bounds3 bd;
+    for (int c = 0; c < 3; c++) { bd.lo[c] = bound_min3_host[c]; bd.hi[c] = bound_max3_host[c]; }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = rows * K;
+    ProfScope _p("k_gen_tail_fwd", s);
+    hipLaunchKernelGGL(k_gen_tail_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, op_raw, offset_mask, grid_offsets,
+                       neural_offset, scale_rot, grid_scaling, anchor, bd, n, K, neural_opacity, mask, scaling, rot, world, xyz);
+    return check_launch("gen_tail_forward");
+}
+
+extern "C" int gsvc_gen_tail_backward(const float *op_raw, const float *offset_mask, const float *grid_offsets,
+                                      const float *neural_offset, const float *scale_rot, const float *grid_scaling,
+                                      const float *world, const float *bound_min3_host, const float *bound_max3_host, int64_t rows,
+                                      int32_t K, const float *g_neural_opacity, const float *g_scaling, const float *g_rot,
+                                      const float *g_world, const float *g_xyz, float *d_op_raw, float *d_offset_mask,
+                                      float *d_offsets, float *d_scale_rot, float *d_grid_scaling, float *d_anchor, void *stream)
+{
+    GSVC_REQUIRE(rows >= 0 && K > 0 && bound_min3_host && bound_max3_host, "gen_tail_backward: bad arguments");
+    if (rows == 0) return GSVC_OK;
+    GSVC_REQUIRE(op_raw && offset_mask && grid_offsets && neural_offset && scale_rot && grid_scaling && world && d_op_raw &&
+                 d_offset_mask && d_offsets && d_scale_rot && d_grid_scaling, "gen_tail_backward: NULL pointer");
+    Bounds3 bd;
+    for (int c = 0; c < 3; c++) { bd.lo[c] = bound_min3_host[c]; bd.hi[c] = bound_max3_host[c]; }
+    hipStream_t s = (hipStream_t)stream;
+    GSVC_REQUIRE(K <= 256, "gen_tail_backward: K > 256");
+    const int rpb = 256 / K;
+    ProfScope _p("k_gen_tail_bwd", s);
+    hipLaunchKernelGGL(k_gen_tail_bwd, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, op_raw, offset_mask, grid_offsets,
+                       neural_offset, scale_rot, grid_scaling, world, bd, rows, K, rpb, g_neural_opacity, g_scaling, g_rot, g_world,
+                       g_xyz, d_op_raw, d_offset_mask, d_offsets, d_scale_rot, d_grid_scaling, d_anchor);
+    return check_launch("gen_tail_backward");
+}

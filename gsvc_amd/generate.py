@@ -122,6 +122,53 @@ def region(name):
     return contextlib.nullcontext()
 
 
+class _GenTail(torch.autograd.Function):
+    """Tail of the generation for un-compacted renders (csrc/generate.hip): returns
+    (neural_opacity[n,1], mask[n], scaling[n,3], rot[n,4], world[n,3], xyz[n,3])."""
+
+    @staticmethod
+    def forward(ctx, op_raw, offset_mask, grid_offsets, neural_offset, scale_rot, grid_scaling, anchor, K, bmin, bmax):
+        import ctypes as C
+        from . import _lib
+        dev = op_raw.device
+        op_raw, offset_mask = op_raw.contiguous().view(-1), offset_mask.contiguous().view(-1)
+        grid_offsets, neural_offset = grid_offsets.contiguous().view(-1, 3), neural_offset.contiguous().view(-1, 3)
+        scale_rot, grid_scaling, anchor = scale_rot.contiguous(), grid_scaling.contiguous(), anchor.contiguous()
+        rows = grid_scaling.shape[0]
+        n = rows * K
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)  # noqa: E731
+        no, scaling, rot, world, xyz = f(n, 1), f(n, 3), f(n, 4), f(n, 3), f(n, 3)
+        mask = torch.empty(n, dtype=torch.bool, device=dev)
+        lo, hi = (C.c_float * 3)(*bmin), (C.c_float * 3)(*bmax)
+        _lib.check(_lib.lib().gsvc_gen_tail_forward(
+            _lib.ptr(op_raw), _lib.ptr(offset_mask), _lib.ptr(grid_offsets), _lib.ptr(neural_offset), _lib.ptr(scale_rot),
+            _lib.ptr(grid_scaling), _lib.ptr(anchor), lo, hi, rows, K, _lib.ptr(no), _lib.ptr(mask), _lib.ptr(scaling), _lib.ptr(rot),
+            _lib.ptr(world), _lib.ptr(xyz), _lib.current_stream(dev)), "gsvc_gen_tail_forward")
+        ctx.save_for_backward(op_raw, offset_mask, grid_offsets, neural_offset, scale_rot, grid_scaling, world)
+        ctx.K, ctx.bounds, ctx.anchor_grad = K, (lo, hi), anchor.requires_grad
+        ctx.mark_non_differentiable(mask)
+        return no, mask, scaling, rot, world, xyz
+
+    @staticmethod
+    def backward(ctx, g_no, _g_mask, g_scaling, g_rot, g_world, g_xyz):
+        from . import _lib
+        op_raw, offset_mask, grid_offsets, neural_offset, scale_rot, grid_scaling, world = ctx.saved_tensors
+        dev = op_raw.device
+        rows, K = grid_scaling.shape[0], ctx.K
+        n = rows * K
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)  # noqa: E731
+        d_op, d_om, d_off, d_sr, d_gs = f(n), f(n), f(n, 3), f(n, 7), f(rows, 6)
+        d_anchor = f(rows, 3) if ctx.anchor_grad else None
+        c = lambda t: t.contiguous() if t is not None else None  # noqa: E731
+        g_no, g_scaling, g_rot, g_world, g_xyz = c(g_no), c(g_scaling), c(g_rot), c(g_world), c(g_xyz)
+        _lib.check(_lib.lib().gsvc_gen_tail_backward(
+            _lib.ptr(op_raw), _lib.ptr(offset_mask), _lib.ptr(grid_offsets), _lib.ptr(neural_offset), _lib.ptr(scale_rot),
+            _lib.ptr(grid_scaling), _lib.ptr(world), ctx.bounds[0], ctx.bounds[1], rows, K, _lib.ptr(g_no), _lib.ptr(g_scaling),
+            _lib.ptr(g_rot), _lib.ptr(g_world), _lib.ptr(g_xyz), _lib.ptr(d_op), _lib.ptr(d_om), _lib.ptr(d_off), _lib.ptr(d_sr),
+            _lib.ptr(d_gs), _lib.ptr(d_anchor), _lib.current_stream(dev)), "gsvc_gen_tail_backward")
+        return d_op, d_om, d_off, d_off, d_sr, d_gs, d_anchor, None, None, None
+
+
 def _sync(t):
     if t.is_cuda:
         torch.cuda.synchronize()
@@ -355,19 +402,15 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
 
     rows = seg.rows
     with region('gen.mlps'):
-        neural_opacity = pc.get_opacity_mlp(feat, pe).reshape(-1, 1) * offset_masks.view(-1, 1)
-        mask = (neural_opacity > 0.0).view(-1)
+        op_raw = pc.get_opacity_mlp(feat, pe)
         color = pc.get_color_mlp(feat, pe).reshape(rows * K, 3)
         scale_rot = pc.get_cov_mlp(feat, pe).reshape(rows * K, 7)
         neural_offset = pc.get_deform_mlp(torch.cat([feat, pe], dim=1)).reshape(rows * K, 3)
-        offsets = grid_offsets.view(-1, 3) + neural_offset
     if dense:
-        gs_lo, gs_hi = grid_scaling.view(rows, 1, 6).split([3, 3], dim=2)
-        sr_scale, sr_rot = scale_rot.split([3, 4], dim=1)
-        scaling = (gs_hi * torch.sigmoid(sr_scale).view(rows, K, 3)).reshape(rows * K, 3)
-        rot = pc.rotation_activation(sr_rot)
-        world = (anchor.view(rows, 1, 3) + offsets.view(rows, K, 3) * gs_lo).reshape(rows * K, 3)
-        xyz = torch.clamp(world, pc.x_bound_min, pc.x_bound_max)
+        # opacity mask, sigmoid scaling, normalised rotation, world position, bound clamp: one kernel (csrc/generate.hip)
+        neural_opacity, mask, scaling, rot, world, xyz = _GenTail.apply(
+            op_raw.reshape(-1), offset_masks.reshape(-1), grid_offsets.reshape(-1, 3), neural_offset, scale_rot, grid_scaling,
+            anchor, K, pc.bound_min_host, pc.bound_max_host)
         # per-render pieces by split (one cat in backward per tensor, instead of a zero-fill + copy + add per slice)
         sizes = [c * K for c in seg.counts]
         parts = [t.split(sizes, dim=0) for t in (xyz, color, neural_opacity, scaling, rot, world)]
@@ -382,6 +425,9 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
                 bit_per_scaling_param=rates[r].bit_per_scaling_param, bit_per_offsets_param=rates[r].bit_per_offsets_param,
                 concatenated_all=None, time_sub=time_sub, visible_index=vis_list[r], world_xyz=parts[5][r], batch=batch))
         return out
+    neural_opacity = op_raw.reshape(-1, 1) * offset_masks.view(-1, 1)
+    mask = (neural_opacity > 0.0).view(-1)
+    offsets = grid_offsets.view(-1, 3) + neural_offset
     per_anchor = torch.cat([grid_scaling, anchor], dim=-1)
     concatenated_all = torch.cat([per_anchor.repeat_interleave(K, dim=0), color, scale_rot, offsets], dim=-1)
     alive_idx = mask.nonzero(as_tuple=False).squeeze(1)

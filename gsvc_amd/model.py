@@ -251,6 +251,7 @@ class GaussianModel(nn.Module):
         self.use_feat_bank = use_feat_bank
         self.x_bound_min = torch.zeros(1, 3, device=self.device)
         self.x_bound_max = torch.ones(1, 3, device=self.device)
+        self.bound_min_host, self.bound_max_host = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
         self.n_features_per_level = n_features_per_level
         self.log2_hashmap_size, self.log2_hashmap_size_2D = log2_hashmap_size, log2_hashmap_size_2D
         self.resolutions_list, self.resolutions_list_2D = resolutions_list, resolutions_list_2D
@@ -359,6 +360,9 @@ class GaussianModel(nn.Module):
         lim = [x_lim * (1 + bleed), y_lim * (1 + bleed), z_lim * (1 + bleed)]  # python floats, rounded once to fp32
         self.x_bound_min = torch.tensor([lim], dtype=torch.float32, device=self.device)
         self.x_bound_max = torch.tensor([[-v for v in lim]], dtype=torch.float32, device=self.device)
+        # the same fp32 values on the host (kernels take the bounds by value)
+        self.bound_min_host = tuple(float(np.float32(v)) for v in lim)
+        self.bound_max_host = tuple(float(np.float32(-v)) for v in lim)
 
     def calc_interp_feat(self, x):
         assert x.dim() == 2 and x.shape[1] == 3

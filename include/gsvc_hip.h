@@ -216,6 +216,24 @@ int gsvc_regs_forward(const float *scaling, const float *neural_opacity, const u
 int gsvc_regs_backward(const float *scaling, const uint8_t *mask, const int64_t *seg_offsets_host, int32_t R, const float *sums,
                        const float *grad_out, float *grad_scaling, float *grad_opacity, void *stream);
 
+/* Tail of the anchor -> neural-Gaussian generation for un-compacted renders (reference
+ * ortho_gaussian_renderer/guassian.py:262-296: opacity mask, sigmoid scaling, normalised rotation, world position, bound
+ * clamp), n = rows*K Gaussians, Gaussian i belongs to anchor row i / K.  Inputs: opacity_raw[n], offset_mask[n],
+ * grid_offsets[n,3], neural_offset[n,3], scale_rot[n,7], grid_scaling[rows,6], anchor[rows,3]; bounds: 3 host floats each.
+ * Outputs: neural_opacity[n], mask[n] (opacity > 0), scaling[n,3], rot[n,4], world[n,3], xyz[n,3]. */
+int gsvc_gen_tail_forward(const float *opacity_raw, const float *offset_mask, const float *grid_offsets,
+                          const float *neural_offset, const float *scale_rot, const float *grid_scaling, const float *anchor,
+                          const float *bound_min3_host, const float *bound_max3_host, int64_t rows, int32_t K,
+                          float *neural_opacity, uint8_t *mask, float *scaling, float *rot, float *world, float *xyz, void *stream);
+/* Incoming gradients g_* may be NULL (output unused).  d_offsets is the gradient of both grid_offsets and neural_offset;
+ * d_anchor may be NULL.  All d_* are overwritten. */
+int gsvc_gen_tail_backward(const float *opacity_raw, const float *offset_mask, const float *grid_offsets,
+                           const float *neural_offset, const float *scale_rot, const float *grid_scaling, const float *world,
+                           const float *bound_min3_host, const float *bound_max3_host, int64_t rows, int32_t K,
+                           const float *g_neural_opacity, const float *g_scaling, const float *g_rot, const float *g_world,
+                           const float *g_xyz, float *d_opacity_raw, float *d_offset_mask, float *d_offsets, float *d_scale_rot,
+                           float *d_grid_scaling, float *d_anchor, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Linear layers of the generator / deformation / entropy-parameter MLPs (reference scene/gaussian_model.py:
  * 150-232: every nn.Linear applied to the [anchors, features] matrix)
