@@ -107,7 +107,8 @@ def run_train_step(args, rank, world, local_rank, dev):
     # jump straight to the entropy-constrained phase (lambda = 0.004, noise quantisation + sampled rate)
     opt.full_precision_training_total, opt.quantized_training_total = 0, 0
     opt.entropy_constrained_train_total = 10 ** 9
-    opt.start_stat, opt.update_until = 0, 10 ** 9         # densification statistics on; growing itself is out of scope
+    opt.start_stat, opt.update_until = 0, 10 ** 9         # densification statistics on (adjust_anchor itself runs from
+                                                          # iteration 1500 every 100 steps: not reached by this short run)
     opt.pause_densification = 0
     torch.manual_seed(0)
     np.random.seed(0)
@@ -120,6 +121,9 @@ def run_train_step(args, rank, world, local_rank, dev):
     pc.create_from_points(pts, spatial_lr_scale=1.0)
     pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
     pc.training_setup(opt)
+    if world > 1:
+        from gsvc_amd import dist as gdist
+        gdist.broadcast_parameters(pc)       # replicas start identical (they are built from the same seeds anyway)
     trainer = Trainer(pc, cube, opt, pipe, mp_, seed=0)
     it = [0]
 
