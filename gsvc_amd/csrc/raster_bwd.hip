@@ -296,12 +296,23 @@ __global__ void __launch_bounds__(64, 5) k_blend_bwd_tile(RasterParams st, const
                 if (rel < wl[q] && bbox_hits_b(bb, tx0 + 8 * (q & 1), ty0 + 8 * (q >> 1))) qm |= 1 << q;
         }
         s_id[lane] = id;
+        if (__ballot(qm != 0) == 0ull) continue;
+        // exact ellipse-vs-quadrant test on the bbox survivors (same rule as the forward: raster_common.h)
+        float4 r0, r1;
+        const float4 *rec = reinterpret_cast<const float4 *>(geom + (id < 0 ? 0 : id));
+        if (qm != 0) {
+            r0 = rec[0];
+            r1 = rec[1];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if ((qm & (1 << q)) && !ellipse_hits_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)(tx0 + 8 * (q & 1)),
+                                                          (float)(ty0 + 8 * (q >> 1))))
+                    qm &= ~(1 << q);
+        }
         const unsigned long long mask = __ballot(qm != 0);
         if (mask == 0ull) continue;
         if (qm != 0) {
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-            const float4 *rec = reinterpret_cast<const float4 *>(geom + id);
-            const float4 r0 = rec[0], r1 = rec[1];
             s_f0[pos] = make_float4(r0.x, r0.y, (0.5f * 1.44269504088896340736f) * r0.z, 1.44269504088896340736f * r0.w);
             s_f1[pos] = make_float4((0.5f * 1.44269504088896340736f) * r1.x, r1.y, r1.z, r1.w);
             s_f2[pos] = make_float2(rec[2].x, __int_as_float(lane | (qm << 8) | ((k - beg + 1) << 12)));

@@ -121,6 +121,37 @@ struct PreOut {
     int x0, y0, x1, y1;
 };
 
+// Can the Gaussian (centre (u,v), conic A,B,C, opacity o) reach alpha >= 1/255 at any pixel centre of the 8x8 quadrant whose
+// first pixel is (x0, y0)?  alpha = o exp(-q/2) with q(d) = A dx^2 + 2 B dx dy + C dy^2, so the question is whether the
+// minimum of the convex quadratic q over the square [x0, x0+7] x [y0, y0+7] is <= 2 ln(255 o): 0 if the centre is inside,
+// else the smallest of the four edge minima (each a clamped 1-D parabola).  Tighter than the axis-aligned alpha bbox for
+// rotated / elongated footprints; conservative (margins, NaN keeps), so the composited result is unchanged.
+__device__ __forceinline__ bool ellipse_hits_quad(float u, float v, float A, float B, float C, float o, float x0, float y0)
+{
+    const float lx = x0 - u, hx = x0 + 7.0f - u, ly = y0 - v, hy = y0 + 7.0f - v;
+    if (lx <= 0.f && hx >= 0.f && ly <= 0.f && hy >= 0.f) return true;
+    const float tau2 = 2.0f * (__logf(255.0f * o) + 1e-3f);
+    const float mbc = -B / C, mba = -B / A;
+    float qmin;
+    {
+        const float dy = fminf(fmaxf(mbc * lx, ly), hy);
+        qmin = A * lx * lx + 2.0f * B * lx * dy + C * dy * dy;
+    }
+    {
+        const float dy = fminf(fmaxf(mbc * hx, ly), hy);
+        qmin = fminf(qmin, A * hx * hx + 2.0f * B * hx * dy + C * dy * dy);
+    }
+    {
+        const float dx = fminf(fmaxf(mba * ly, lx), hx);
+        qmin = fminf(qmin, A * dx * dx + 2.0f * B * dx * ly + C * ly * ly);
+    }
+    {
+        const float dx = fminf(fmaxf(mba * hy, lx), hx);
+        qmin = fminf(qmin, A * dx * dx + 2.0f * B * dx * hy + C * hy * hy);
+    }
+    return !(qmin > tau2 * 1.0005f + 2e-3f);
+}
+
 // Steps 1-7 of the raster spec.  Every operation here decides an integer downstream (radius, tile
 // rectangle, depth key), so it is plain IEEE binary32 in a fixed order with no FMA contraction — the CPU
 // oracle repeats it bit for bit.  sqrt and division are the correctly rounded forms.

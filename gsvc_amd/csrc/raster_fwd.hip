@@ -561,12 +561,19 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
             hit = bbox_hits(inst_bbox[k], qx0, qy0);
             id = point_list[k];
         }
+        if (__ballot(hit) == 0ull) continue;
+        // second, exact test on the bbox survivors: does the alpha >= 1/255 ellipse reach this quadrant at all?
+        float4 r0, r1;
+        const float4 *rec = reinterpret_cast<const float4 *>(geom + (PAIR ? (id >> 2) : id));
+        if (hit) {
+            r0 = rec[0];
+            r1 = rec[1];
+            hit = ellipse_hits_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)qx0, (float)qy0);
+        }
         const unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
         if (hit) {
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-            const float4 *rec = reinterpret_cast<const float4 *>(geom + (PAIR ? (id >> 2) : id));
-            const float4 r0 = rec[0], r1 = rec[1];
             w_f0[pos] = make_float4(r0.x, r0.y, (0.5f * LOG2E) * r0.z, LOG2E * r0.w);
             w_f1[pos] = make_float4((0.5f * LOG2E) * r1.x, r1.y, r1.z, r1.w);
             // PAIR: the slot's tag carries the two view-membership flags instead of the list position
