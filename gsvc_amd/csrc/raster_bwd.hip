@@ -49,6 +49,51 @@ __device__ __forceinline__ void wave_sum9_to_lane63(float &a0, float &a1, float 
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
 }
 
+// Same nine sums in 24 cross-lane instructions instead of 54: values 0..7 are reduced "transposed" — every halving step
+// also halves the number of live registers (v_permlane32_swap / v_permlane16_swap move half of one register into the
+// idle half of its partner, one add then reduces two values at once) — so that afterwards a0 holds, in lane group
+// g = lane / 8, the wave total of value g; the ninth value is reduced the classic way into lane 63.
+__device__ __forceinline__ void wave_sum9_spread(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
+                                                 float &a6, float &a7, float &a8)
+{
+    const unsigned long long odd_half_rows = 0xFF00FF00FF00FF00ull;
+    asm volatile("s_nop 1\n"
+                 "v_permlane32_swap_b32 %0, %4\n"
+                 "v_permlane32_swap_b32 %1, %5\n"
+                 "v_permlane32_swap_b32 %2, %6\n"
+                 "v_permlane32_swap_b32 %3, %7\n"
+                 "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32 %0, %0, %4\n"
+                 "v_add_f32 %1, %1, %5\n"
+                 "v_add_f32 %2, %2, %6\n"
+                 "v_add_f32 %3, %3, %7\n"
+                 "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_permlane16_swap_b32 %0, %2\n"
+                 "v_permlane16_swap_b32 %1, %3\n"
+                 "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32 %0, %0, %2\n"
+                 "v_add_f32 %1, %1, %3\n"
+                 "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_cndmask_b32_e64 %0, %0, %1, %9\n"
+                 "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8)
+                 : "s"(odd_half_rows));
+}
+
 __device__ __forceinline__ int sext16b(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 
 __device__ __forceinline__ bool bbox_hits_b(uint2 bb, int qx0, int qy0)
@@ -335,13 +380,11 @@ __global__ void __launch_bounds__(64, 5) k_blend_bwd_tile(RasterParams st, const
                 if (quads & (1 << q))
                     bwd_pixel(ps[q], inq[q], dxb - (float)(8 * (q & 1)), dyb - (float)(8 * (q >> 1)), a, b, c.x, contributor,
                               s_h, s_x, s_y, s_xx, s_xy, s_yy, s_r, s_g, s_b);
-            wave_sum9_to_lane63(s_h, s_x, s_y, s_xx, s_xy, s_yy, s_r, s_g, s_b);
+            wave_sum9_spread(s_h, s_x, s_y, s_xx, s_xy, s_yy, s_r, s_g, s_b);
             touched |= 1ull << e;
-            if (lane == 63) {
-                float *dst = s_out[e];
-                dst[0] = s_h; dst[1] = s_x; dst[2] = s_y; dst[3] = s_xx; dst[4] = s_xy; dst[5] = s_yy;
-                dst[6] = s_r; dst[7] = s_g; dst[8] = s_b;
-            }
+            // lane 8g holds the total of value g (g < 8) in s_h's register, lane 63 the total of the ninth
+            if ((lane & 7) == 0) s_out[e][lane >> 3] = s_h;
+            if (lane == 63) s_out[e][8] = s_b;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
