@@ -69,6 +69,103 @@ __global__ void __launch_bounds__(256) k_visible_filter(RasterParams st, int P, 
                                    scales[3 * i + 1], scales[3 * i + 2], q.x, q.y, q.z, q.w, o);
 }
 
+// ------------------------------------------------------------------------------------------------- K2
+// tile_offsets = exclusive scan of (tile_count + tile_extra); tile_extra is zeroed (K3's cursor for the
+// instances beyond BIN_SLOTS, which sit behind the tile_count[t] slotted ones).  One workgroup; rounds of 8192
+// tiles staged through LDS so that every global access is a coalesced 4-byte-per-lane stream.  Tiles whose list
+// is too long for the one-wave sort are appended to big_list for the workgroup sort.
+constexpr int SCAN_CHUNK = 8192;
+constexpr int SORT_RANK_MAX = 256;    // entries one wave rank-sorts (4 keys per lane)
+constexpr int SORT_WAVE_MAX = 1024;   // entries one wave sorts in LDS (8 KiB)
+
+// s_v: SCAN_CHUNK ints of LDS; called by all 1024 threads of one workgroup.
+__device__ __forceinline__ void scan_tiles_body(int T, const int32_t *__restrict__ tile_count, int32_t *__restrict__ tile_extra,
+                                                int32_t *__restrict__ tile_offsets, int32_t *__restrict__ big_list,
+                                                gsvc_raster_counters *__restrict__ counters, long long max_instances,
+                                                int *__restrict__ s_v)
+{
+    __shared__ int wave_sum[16];
+    __shared__ int wave_max[16];
+    __shared__ int s_big;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_big = 0;
+    int carry = 0, local_max = 0;
+    for (int base = 0; base < T; base += SCAN_CHUNK) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int idx = base + k * 1024 + tid;
+            s_v[k * 1024 + tid] = idx < T ? __hip_atomic_load(tile_count + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                                                __hip_atomic_load(tile_extra + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : 0;
+        }
+        __syncthreads();
+        int v[8];
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            v[k] = s_v[tid * 8 + k];
+            local_max = max(local_max, v[k]);
+            sum += v[k];
+            if (v[k] > SORT_WAVE_MAX) big_list[atomicAdd(&s_big, 1)] = base + tid * 8 + k;
+        }
+        int x = sum;  // inclusive wave scan of the per-lane sums
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wave_sum[wave] = x;
+        __syncthreads();
+        int prefix = carry, total = 0;
+        for (int w = 0; w < 16; w++) {
+            const int ws = wave_sum[w];
+            if (w < wave) prefix += ws;
+            total += ws;
+        }
+        int run = prefix + x - sum;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            s_v[tid * 8 + k] = run;
+            run += v[k];
+        }
+        carry += total;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int idx = base + k * 1024 + tid;
+            if (idx < T) {
+                tile_offsets[idx] = s_v[k * 1024 + tid];
+                tile_extra[idx] = 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) local_max = max(local_max, __shfl_xor(local_max, m, 64));
+    if (lane == 0) wave_max[wave] = local_max;
+    __syncthreads();
+    if (tid == 0) {
+        int mx = 0;
+        for (int w = 0; w < 16; w++) mx = max(mx, wave_max[w]);
+        tile_offsets[T] = carry;
+        counters->num_rendered = carry;
+        counters->overflow = ((long long)carry > max_instances) ? 1 : 0;
+        counters->max_tile_len = mx;
+        counters->num_big_tiles = s_big;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_scan_tiles(int T, const int32_t *__restrict__ tile_count,
+                                                     int32_t *__restrict__ tile_extra,
+                                                     int32_t *__restrict__ tile_offsets,
+                                                     int32_t *__restrict__ big_list,
+                                                     gsvc_raster_counters *__restrict__ counters,
+                                                     long long max_instances)
+{
+    __shared__ int s_v[SCAN_CHUNK];
+    scan_tiles_body(T, tile_count, tile_extra, tile_offsets, big_list, counters, max_instances, s_v);
+}
+
 // ------------------------------------------------------------------------------------------------- K1
 // USE_LDS: per-workgroup histogram of the whole tile grid in dynamic LDS (4*T bytes).  Otherwise (grids too
 // large for LDS) every instance does its own global atomic.
@@ -83,7 +180,9 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
                                                      const float *__restrict__ rotations, int32_t *__restrict__ radii,
                                                      GeomRec *__restrict__ geom, BinRec *__restrict__ bins,
                                                      int32_t *__restrict__ tile_count, int32_t *__restrict__ tile_extra,
-                                                     gsvc_raster_counters *__restrict__ counters)
+                                                     gsvc_raster_counters *__restrict__ counters,
+                                                     int32_t *__restrict__ tile_offsets, int32_t *__restrict__ big_list,
+                                                     long long max_instances)
 {
     extern __shared__ int hist[];
     const int T = st.gx * st.gy;
@@ -215,91 +314,19 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
             }
         reinterpret_cast<int4 *>(bins + i)[1] = make_int4(slot[0], slot[1], slot[2], slot[3]);
     }
-}
-
-// ------------------------------------------------------------------------------------------------- K2
-// tile_offsets = exclusive scan of (tile_count + tile_extra); tile_extra is zeroed (K3's cursor for the
-// instances beyond BIN_SLOTS, which sit behind the tile_count[t] slotted ones).  One workgroup; rounds of 8192
-// tiles staged through LDS so that every global access is a coalesced 4-byte-per-lane stream.  Tiles whose list
-// is too long for the one-wave sort are appended to big_list for the workgroup sort.
-constexpr int SCAN_CHUNK = 8192;
-constexpr int SORT_RANK_MAX = 256;    // entries one wave rank-sorts (4 keys per lane)
-constexpr int SORT_WAVE_MAX = 1024;   // entries one wave sorts in LDS (8 KiB)
-
-__global__ void __launch_bounds__(1024) k_scan_tiles(int T, const int32_t *__restrict__ tile_count,
-                                                     int32_t *__restrict__ tile_extra,
-                                                     int32_t *__restrict__ tile_offsets,
-                                                     int32_t *__restrict__ big_list,
-                                                     gsvc_raster_counters *__restrict__ counters,
-                                                     long long max_instances)
-{
-    __shared__ int s_v[SCAN_CHUNK];
-    __shared__ int wave_sum[16];
-    __shared__ int wave_max[16];
-    __shared__ int s_big;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_big = 0;
-    int carry = 0, local_max = 0;
-    for (int base = 0; base < T; base += SCAN_CHUNK) {
+    // K2 fused: the workgroup that finishes last runs the tile scan (release / acquire through the ticket counter),
+    // which saves a launch and the dependent-kernel gap; hist (>= SCAN_CHUNK ints) is free by now
+    {
+        // tile_count / tile_extra are only ever modified by device-scope atomics (performed at the memory side, never
+        // dirty in an XCD's L2), so "release" = wait until this lane's atomics have been acknowledged, and the scan
+        // reads them with agent-scope loads.  (A full __threadfence() here costs an L2 write-back per workgroup: 5x.)
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int idx = base + k * 1024 + tid;
-            s_v[k * 1024 + tid] = idx < T ? tile_count[idx] + tile_extra[idx] : 0;
-        }
+        if (tid == 0) s_last = (atomicAdd(&counters->reserved[0], 1) == (int)gridDim.x - 1) ? 1 : 0;
         __syncthreads();
-        int v[8];
-        int sum = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            v[k] = s_v[tid * 8 + k];
-            local_max = max(local_max, v[k]);
-            sum += v[k];
-            if (v[k] > SORT_WAVE_MAX) big_list[atomicAdd(&s_big, 1)] = base + tid * 8 + k;
-        }
-        int x = sum;  // inclusive wave scan of the per-lane sums
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int y = __shfl_up(x, d, 64);
-            if (lane >= d) x += y;
-        }
-        if (lane == 63) wave_sum[wave] = x;
-        __syncthreads();
-        int prefix = carry, total = 0;
-        for (int w = 0; w < 16; w++) {
-            const int ws = wave_sum[w];
-            if (w < wave) prefix += ws;
-            total += ws;
-        }
-        int run = prefix + x - sum;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            s_v[tid * 8 + k] = run;
-            run += v[k];
-        }
-        carry += total;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int idx = base + k * 1024 + tid;
-            if (idx < T) {
-                tile_offsets[idx] = s_v[k * 1024 + tid];
-                tile_extra[idx] = 0;
-            }
-        }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) local_max = max(local_max, __shfl_xor(local_max, m, 64));
-    if (lane == 0) wave_max[wave] = local_max;
-    __syncthreads();
-    if (tid == 0) {
-        int mx = 0;
-        for (int w = 0; w < 16; w++) mx = max(mx, wave_max[w]);
-        tile_offsets[T] = carry;
-        counters->num_rendered = carry;
-        counters->overflow = ((long long)carry > max_instances) ? 1 : 0;
-        counters->max_tile_len = mx;
-        counters->num_big_tiles = s_big;
+        if (!s_last) return;
+        scan_tiles_body(T, tile_count, tile_extra, tile_offsets, big_list, counters, max_instances, hist);
     }
 }
 
@@ -734,20 +761,22 @@ static int raster_forward_impl(const gsvc_raster_settings *settings, int64_t P, 
         const unsigned blocks = (unsigned)((P + 1023) / 1024);
         ProfScope _prof("k_preprocess", s);
         const bool use_lds = L.tiles <= LDS_HIST_MAX_TILES;
-        const size_t lds = use_lds ? (size_t)L.tiles * sizeof(int) : 0;
+        // the fused scan stages SCAN_CHUNK tile counts in the same LDS
+        const size_t lds = use_lds ? (size_t)(L.tiles > SCAN_CHUNK ? L.tiles : SCAN_CHUNK) * sizeof(int) : 0;
         auto launch = [&](auto kernel) {
             if (lds > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           LDS_HIST_MAX_TILES * 4);
             hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds, s, p, (int)P, means3D, colors, opacities, scales,
-                               rotations, radii, grec, brec, tile_count, tile_extra, counters);
+                               rotations, radii, grec, brec, tile_count, tile_extra, counters, tile_offsets, big_list,
+                               (long long)max_instances);
         };
         if (use_lds && pair) launch(&k_preprocess<true, true>);
         else if (use_lds) launch(&k_preprocess<true, false>);
         else if (pair) launch(&k_preprocess<false, true>);
         else launch(&k_preprocess<false, false>);
     }
-    {
+    if (P == 0 || L.tiles > LDS_HIST_MAX_TILES) {      // otherwise the scan ran inside k_preprocess (last workgroup)
         ProfScope _prof("k_scan_tiles", s);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, L.tiles, tile_count, tile_extra, tile_offsets,
                            big_list, counters, (long long)max_instances);
