@@ -214,3 +214,54 @@ def test_two_view_pair_kernel_matches_two_renders(oracle_lib, P, H, W, seed):
     with pytest.raises(_lib.GsvcError, match="image_width"):
         rasterizer.raster_forward(r2._c_settings(), d2["means3D"], d2["colors"], d2["opacities"].view(-1).contiguous(),
                                   d2["scales"], d2["rotations"], pair=True)
+
+
+def test_full_size_cfg2_parity_and_properties(oracle_lib):
+    """BASELINE.json configs[1] at full size (1080p, 200 000 Gaussians): bit-exact integers and 1e-4 pixels against the
+    oracle, plus size-independent properties of the forward / backward pair:
+      * determinism: two forwards give identical images and tile lists (no float atomics in the forward);
+      * sortedness: inside every tile the list is ordered by (depth, Gaussian index);
+      * linearity in the colours: render(c1 + c2) = render(c1) + render(c2) with a black background;
+      * conservation: with dL/dimage = 1, sum_i dL/dcolour_i (per channel) = sum_pixels (1 - final_T), and the
+        opacity<=0 Gaussians added to the set change nothing (they are culled)."""
+    sc = synthetic.raster_scene(200_000, seed=11)
+    r, ref, d = _compare_forward(oracle_lib, sc)
+    s = sc["settings"]
+    means2D = torch.zeros_like(d["means3D"])
+    args = dict(means3D=d["means3D"], means2D=means2D, shs=None, opacities=d["opacities"], scales=d["scales"],
+                rotations=d["rotations"], cov3D_precomp=None)
+    img1, radii1, n1 = r(colors_precomp=d["colors"], **args)
+    off1, pl1 = [t.clone() for t in r.last_state.tile_lists()]
+    img2, radii2, n2 = r(colors_precomp=d["colors"], **args)
+    off2, pl2 = r.last_state.tile_lists()
+    assert n1 == n2 and torch.equal(img1, img2) and torch.equal(off1, off2) and torch.equal(pl1, pl2)
+    # sortedness by (depth, id) inside each tile; depth = float 11 of the 12-float GeomRec
+    P = d["means3D"].shape[0]
+    depth = r.last_state.geom[:48 * P].view(torch.float32).view(P, 12)[:, 11]
+    pl = pl2.long()
+    key_d, key_i = depth[pl], pl
+    same_tile = torch.ones(pl.shape[0] - 1, dtype=torch.bool, device="cuda")
+    same_tile[(off2[1:-1].long() - 1).clamp(0, pl.shape[0] - 2)[(off2[1:-1] > 0) & (off2[1:-1] < pl.shape[0])]] = False
+    ordered = (key_d[1:] > key_d[:-1]) | ((key_d[1:] == key_d[:-1]) & (key_i[1:] > key_i[:-1]))
+    assert bool((ordered | ~same_tile).all())
+    # linearity in the colours
+    c2 = torch.rand_like(d["colors"])
+    ia, _, _ = r(colors_precomp=d["colors"], **args)
+    ib, _, _ = r(colors_precomp=c2, **args)
+    iab, _, _ = r(colors_precomp=d["colors"] + c2, **args)
+    assert (iab - (ia + ib)).abs().max().item() < 2e-5
+    # conservation through the backward
+    colors = d["colors"].clone().requires_grad_(True)
+    image, _, _ = r(colors_precomp=colors, **args)
+    fT, _ = r.last_state.image_aux()
+    expected = float((1.0 - fT).double().sum())
+    image.sum().backward()
+    got = colors.grad.double().sum(dim=0)
+    assert torch.allclose(got, torch.full((3,), expected, dtype=torch.float64, device="cuda"), rtol=2e-4)
+    # appending Gaussians with opacity <= 0 changes neither the image nor num_rendered
+    k = 5000
+    ext = {n: torch.cat([d[n], d[n][:k]]) for n in ("means3D", "colors", "scales", "rotations")}
+    ext_op = torch.cat([d["opacities"], -torch.rand(k, 1, device="cuda")])
+    img3, radii3, n3 = r(means3D=ext["means3D"], means2D=torch.zeros_like(ext["means3D"]), shs=None, colors_precomp=ext["colors"],
+                         opacities=ext_op, scales=ext["scales"], rotations=ext["rotations"], cov3D_precomp=None)
+    assert n3 == n1 and torch.equal(img3, img1) and int(radii3[P:].abs().sum()) == 0
