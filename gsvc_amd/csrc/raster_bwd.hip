@@ -3,54 +3,21 @@
 // Replaces the implicit autograd backward of the external CUDA extension (consumers: reference
 // pipeline/train.py:462 `loss.backward()`, scene/gaussian_model.py:1311 `viewspace_points.grad`).
 //
-//   B1 blend_bwd     one 256-lane workgroup per 16x16 tile walks the tile's sorted list back to front
-//                    (LDS-staged batches), replays alpha compositing per pixel and produces, per Gaussian,
-//                    nine partial sums (d/du, d/dv, d/dA, d/dB, d/dC, d/dopacity, d/drgb).  Each wave
-//                    reduces its 64 pixels in registers and issues ONE atomic wave-instruction (9 lanes,
-//                    36 contiguous bytes) into the per-Gaussian accumulator; waves none of whose pixels
-//                    touched the Gaussian skip both.
+//   B1 blend_bwd     one wave per 16x16 tile (lane l owns pixel l of each 8x8 quadrant) walks the tile's sorted list
+//                    back to front in chunks of 64 entries: bbox + exact ellipse test per quadrant, replay of the alpha
+//                    compositing per pixel, per Gaussian nine sums (moments of h = G dL/dalpha and the colour
+//                    gradients) reduced over the wave with permlane swaps + DPP, flushed per chunk with 36-byte
+//                    atomic segments into the per-Gaussian accumulator.
 //   B2 gaussian_bwd  one lane per Gaussian: conic -> 2-D covariance -> 3-D covariance -> (scale, quaternion),
 //                    screen-space -> world mean (constant orthographic Jacobian, no covariance->mean term).
 #include "raster_common.h"
-
-#include <cstdlib>
 
 namespace gsvc {
 
 constexpr int ACC_STRIDE = 16;  // floats per Gaussian in the accumulator (9 used, 64-B rows)
 
-// DPP wave reduction of nine values at once (sums of the 64 lanes land in lane 63): two quad_perm steps and
-// row_shr:4 / row_shr:8 inside each 16-lane row, then row_bcast:15 / row_bcast:31 across rows.  VALU only (no
-// LDS traffic, unlike ds_bpermute shuffles).  Written as one asm block of 54 v_add_f32_dpp so hipcc neither
-// splits them into v_mov_dpp + packed adds nor reorders them; the nine chains are interleaved, which also
-// keeps every DPP read >= 2 instructions behind the write of its source (the DPP wait-state rule; the
-// leading s_nop covers the compiler-scheduled producer of the inputs).  EXEC must be all ones.
-#define GSVC_DPP9(CTRL)                                  \
-    "v_add_f32_dpp %0, %0, %0 " CTRL "\n"                \
-    "v_add_f32_dpp %1, %1, %1 " CTRL "\n"                \
-    "v_add_f32_dpp %2, %2, %2 " CTRL "\n"                \
-    "v_add_f32_dpp %3, %3, %3 " CTRL "\n"                \
-    "v_add_f32_dpp %4, %4, %4 " CTRL "\n"                \
-    "v_add_f32_dpp %5, %5, %5 " CTRL "\n"                \
-    "v_add_f32_dpp %6, %6, %6 " CTRL "\n"                \
-    "v_add_f32_dpp %7, %7, %7 " CTRL "\n"                \
-    "v_add_f32_dpp %8, %8, %8 " CTRL "\n"
-
-__device__ __forceinline__ void wave_sum9_to_lane63(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
-                                                    float &a6, float &a7, float &a8)
-{
-    asm volatile("s_nop 1\n"
-                 GSVC_DPP9("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 GSVC_DPP9("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 GSVC_DPP9("row_shr:4 row_mask:0xf bank_mask:0xf")
-                 GSVC_DPP9("row_shr:8 row_mask:0xf bank_mask:0xf")
-                 GSVC_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 GSVC_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf")
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
-}
-
-// Same nine sums in 24 cross-lane instructions instead of 54: values 0..7 are reduced "transposed" — every halving step
-// also halves the number of live registers (v_permlane32_swap / v_permlane16_swap move half of one register into the
+// Nine per-Gaussian sums over the wave in 24 cross-lane instructions (a plain DPP butterfly needs 54): values 0..7 are
+// reduced "transposed" — every halving step also halves the number of live registers (v_permlane32_swap / v_permlane16_swap move half of one register into the
 // idle half of its partner, one add then reduces two values at once) — so that afterwards a0 holds, in lane group
 // g = lane / 8, the wave total of value g; the ninth value is reduced the classic way into lane 63.
 __device__ __forceinline__ void wave_sum9_spread(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
@@ -101,152 +68,7 @@ __device__ __forceinline__ bool bbox_hits_b(uint2 bb, int qx0, int qy0)
     return !(sext16b(bb.x) > qx0 + 7 || sext16b(bb.x >> 16) < qx0 || sext16b(bb.y) > qy0 + 7 || sext16b(bb.y >> 16) < qy0);
 }
 
-// One workgroup per 16x16 tile, one wave per 8x8 quadrant.  The tile list is walked back to front in chunks
-// of 64 entries; per chunk each wave keeps only the entries whose alpha bounding box touches its quadrant
-// (one vector test for 64 entries), replays the compositing for those, reduces the nine per-Gaussian sums
-// over its 64 pixels with DPP, and adds them to a per-chunk LDS accumulator shared by the four waves.
-// The accumulator is flushed with one 36-byte atomic segment per touched entry.
-__global__ void __launch_bounds__(256) k_blend_bwd(RasterParams st, const int32_t *__restrict__ tile_offsets,
-                                                   const int32_t *__restrict__ point_list,
-                                                   const uint2 *__restrict__ inst_bbox,
-                                                   const GeomRec *__restrict__ geom,
-                                                   const float *__restrict__ final_T,
-                                                   const int32_t *__restrict__ n_contrib,
-                                                   const float *__restrict__ dL_dimage, float *__restrict__ acc,
-                                                   const gsvc_raster_counters *__restrict__ counters)
-{
-    __shared__ float4 s_f0[4][64];   // u v A B
-    __shared__ float4 s_f1[4][64];   // C opacity r g
-    __shared__ float2 s_f2[4][64];   // b, (chunk-local entry index | list position << 8) as int bits
-    __shared__ float s_part[4][64][9];   // per wave, per chunk entry: du dv dA dB dC dopacity dr dg db
-    __shared__ int s_id[64];
-    __shared__ unsigned long long s_touched[4];  // per wave: chunk entries it wrote partial sums for
-    __shared__ int s_last[4];
-    if (counters->overflow) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qx0 = blockIdx.x * TILE + 8 * (wave & 1), qy0 = blockIdx.y * TILE + 8 * (wave >> 1);
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = px < st.W && py < st.H;
-    const int tile = blockIdx.y * st.gx + blockIdx.x;
-    const int beg = tile_offsets[tile];
-    const float fx = (float)px, fy = (float)py;
-    const int HW = st.H * st.W, pix = py * st.W + px;
-    float4 *w_f0 = s_f0[wave];
-    float4 *w_f1 = s_f1[wave];
-    float2 *w_f2 = s_f2[wave];
-
-    const float Tf = inside ? final_T[pix] : 0.f;
-    const int last = inside ? n_contrib[pix] : 0;
-    const float d0 = inside ? dL_dimage[pix] : 0.f;
-    const float d1 = inside ? dL_dimage[HW + pix] : 0.f;
-    const float d2 = inside ? dL_dimage[2 * HW + pix] : 0.f;
-    const float bg_dot = st.bg0 * d0 + st.bg1 * d1 + st.bg2 * d2;
-    float T = Tf;
-    float behind0 = 0.f, behind1 = 0.f, behind2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
-
-    // nobody in the workgroup reaches list entries past the largest n_contrib
-    int wl = last;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) wl = max(wl, __shfl_xor(wl, m, 64));
-    if (lane == 0) s_last[wave] = wl;
-    __syncthreads();
-    const int wg_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-
-    for (int c1 = beg + wg_last; c1 > beg; c1 -= 64) {
-        // chunk = list entries [c1-64, c1) ∩ [beg, c1); chunk-local index e = c1 - 1 - k (back to front)
-        if (tid < 64) {
-            const int k = c1 - 1 - tid;
-            s_id[tid] = k >= beg ? point_list[k] : -1;
-        }
-        __syncthreads();
-        {
-            unsigned long long touched = 0ull;
-            const int k = c1 - 1 - lane;
-            bool hit = false;
-            if (k >= beg && (k - beg) < wl) hit = bbox_hits_b(inst_bbox[k], qx0, qy0);
-            const unsigned long long mask = __ballot(hit);
-            if (mask != 0ull) {
-                if (hit) {
-                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                    const float4 *rec = reinterpret_cast<const float4 *>(geom + s_id[lane]);
-                    w_f0[pos] = rec[0];
-                    w_f1[pos] = rec[1];
-                    w_f2[pos] = make_float2(rec[2].x, __int_as_float(lane | ((k - beg + 1) << 8)));
-                }
-                const int cnt = __popcll(mask);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int j = 0; j < cnt; j++) {
-                    const float4 a = w_f0[j];
-                    const float4 b = w_f1[j];
-                    const float2 c = w_f2[j];
-                    const int tag = __float_as_int(c.y);
-                    const int contributor = tag >> 8;
-                    const float dx = a.x - fx, dy = a.y - fy;
-                    const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                    const float G = __expf(power);
-                    const float alpha = fminf(ALPHA_MAX, b.y * G);
-                    const bool valid = (contributor <= last) && (power <= 0.0f) && (alpha >= ALPHA_MIN);
-                    if (__ballot(valid) == 0ull) continue;  // wave-uniform
-                    float v_du = 0.f, v_dv = 0.f, v_dA = 0.f, v_dB = 0.f, v_dC = 0.f, v_do = 0.f, v_r = 0.f, v_g = 0.f, v_b = 0.f;
-                    if (valid) {
-                        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
-                        T = T * inv;
-                        const float w = alpha * T;
-                        behind0 = last_alpha * lc0 + (1.0f - last_alpha) * behind0;
-                        behind1 = last_alpha * lc1 + (1.0f - last_alpha) * behind1;
-                        behind2 = last_alpha * lc2 + (1.0f - last_alpha) * behind2;
-                        lc0 = b.z; lc1 = b.w; lc2 = c.x;
-                        float dL_dalpha = (b.z - behind0) * d0 + (b.w - behind1) * d1 + (c.x - behind2) * d2;
-                        v_r = w * d0; v_g = w * d1; v_b = w * d2;
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha -= Tf * inv * bg_dot;
-                        const float dL_dG = b.y * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        v_du = dL_dG * (-gdx * a.z - gdy * a.w);
-                        v_dv = dL_dG * (-gdy * b.x - gdx * a.w);
-                        v_dA = -0.5f * gdx * dx * dL_dG;
-                        v_dB = -gdx * dy * dL_dG;
-                        v_dC = -0.5f * gdy * dy * dL_dG;
-                        v_do = G * dL_dalpha;
-                    }
-                    wave_sum9_to_lane63(v_du, v_dv, v_dA, v_dB, v_dC, v_do, v_r, v_g, v_b);
-                    const int e = tag & 0xff;
-                    touched |= 1ull << e;
-                    if (lane == 63) {
-                        float *dst = s_part[wave][e];
-                        dst[0] = v_du; dst[1] = v_dv; dst[2] = v_dA; dst[3] = v_dB; dst[4] = v_dC; dst[5] = v_do;
-                        dst[6] = v_r; dst[7] = v_g; dst[8] = v_b;
-                    }
-                }
-            }
-            if (lane == 0) s_touched[wave] = touched;
-        }
-        __syncthreads();
-        // flush: 9 consecutive lanes per touched entry -> one 36-byte atomic segment in the entry's 64-byte row
-        {
-            const unsigned long long t0 = s_touched[0], t1 = s_touched[1], t2 = s_touched[2], t3 = s_touched[3];
-            const unsigned long long any = t0 | t1 | t2 | t3;
-            for (int v = tid; v < 64 * 9; v += 256) {
-                const int e = v / 9, comp = v - e * 9;
-                if ((any >> e) & 1ull) {
-                    float sum = 0.f;
-                    if ((t0 >> e) & 1ull) sum += s_part[0][e][comp];
-                    if ((t1 >> e) & 1ull) sum += s_part[1][e][comp];
-                    if ((t2 >> e) & 1ull) sum += s_part[2][e][comp];
-                    if ((t3 >> e) & 1ull) sum += s_part[3][e][comp];
-                    atomicAdd(acc + (size_t)s_id[e] * ACC_STRIDE + comp, sum);
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---- variant T (default): ONE wave per 16x16 tile; lane l owns pixel l of each of the four 8x8 quadrants and
+// ONE wave per 16x16 tile; lane l owns pixel l of each of the four 8x8 quadrants and
 // walks the quadrants a Gaussian can reach one after the other (wave-uniform 4-bit mask from the bbox test), adding
 // its nine partial sums in registers.  One DPP reduction per (tile, Gaussian) instead of one per (quadrant,
 // Gaussian), no cross-wave combine, no barriers; a chunk's 64 x 9 sums are flushed with nine 64-lane atomic
@@ -400,7 +222,6 @@ __global__ void __launch_bounds__(64, 5) k_blend_bwd_tile(RasterParams st, const
     }
 }
 
-template <bool MOMENTS>
 __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, const float *__restrict__ means3D,
                                                       const float *__restrict__ scales,
                                                       const float *__restrict__ rotations,
@@ -422,19 +243,14 @@ __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, co
         preprocess_gaussian(st, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], scales[3 * i], scales[3 * i + 1],
                             scales[3 * i + 2], rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2],
                             rotations[4 * i + 3], o);
-        if (MOMENTS) {
-            // accumulator holds moments of h = G dL/dalpha: (sum h, h dx, h dy, h dx^2, h dx dy, h dy^2, colour grads)
-            const float op = opacities[i];
-            const float sh = a0.x, sx = a0.y, sy = a0.z, sxx = a0.w, sxy = a1.x, syy = a1.y;
-            go = sh;
-            du = -op * (o.A * sx + o.B * sy);
-            dv = -op * (o.C * sy + o.B * sx);
-            dA = -0.5f * op * sxx; dB = -op * sxy; dC = -0.5f * op * syy;
-            gc[0] = a1.z; gc[1] = a1.w; gc[2] = a2;
-        } else {
-            du = a0.x; dv = a0.y; dA = a0.z; dB = a0.w; dC = a1.x;
-            go = a1.y; gc[0] = a1.z; gc[1] = a1.w; gc[2] = a2;
-        }
+        // accumulator holds moments of h = G dL/dalpha: (sum h, h dx, h dy, h dx^2, h dx dy, h dy^2, colour grads)
+        const float op = opacities[i];
+        const float sh = a0.x, sx = a0.y, sy = a0.z, sxx = a0.w, sxy = a1.x, syy = a1.y;
+        go = sh;
+        du = -op * (o.A * sx + o.B * sy);
+        dv = -op * (o.C * sy + o.B * sx);
+        dA = -0.5f * op * sxx; dB = -op * sxy; dC = -0.5f * op * syy;
+        gc[0] = a1.z; gc[1] = a1.w; gc[2] = a2;
         g2[0] = du * 0.5f * (float)st.W;
         g2[1] = dv * 0.5f * (float)st.H;
         const float *M = st.m;
@@ -522,27 +338,16 @@ extern "C" int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_
         set_error("raster_backward: hipMemsetAsync failed");
         return GSVC_E_LAUNCH;
     }
-    static const char *variant = getenv("GSVC_BWD_VARIANT");
-    const bool quad = variant && variant[0] == 'q';
     {
         ProfScope _prof("k_blend_bwd", s);
-        if (quad)
-            hipLaunchKernelGGL(k_blend_bwd, dim3(L.gx, L.gy), dim3(256), 0, s, p, tile_offsets, point_list, inst_bbox,
-                               (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters);
-        else
-            hipLaunchKernelGGL(k_blend_bwd_tile, dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, inst_bbox,
-                               (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters);
+        hipLaunchKernelGGL(k_blend_bwd_tile, dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, inst_bbox,
+                           (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters);
     }
     {
         ProfScope _prof("k_gaussian_bwd", s);
-        if (quad)
-            hipLaunchKernelGGL(k_gaussian_bwd<false>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
-                               scales, rotations, opacities, radii, (const float *)scratch, dL_dmeans3D, dL_dmeans2D,
-                               dL_dcolors, dL_dopacities, dL_dscales, dL_drotations);
-        else
-            hipLaunchKernelGGL(k_gaussian_bwd<true>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
-                               scales, rotations, opacities, radii, (const float *)scratch, dL_dmeans3D, dL_dmeans2D,
-                               dL_dcolors, dL_dopacities, dL_dscales, dL_drotations);
+        hipLaunchKernelGGL(k_gaussian_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
+                           scales, rotations, opacities, radii, (const float *)scratch, dL_dmeans3D, dL_dmeans2D,
+                           dL_dcolors, dL_dopacities, dL_dscales, dL_drotations);
     }
     return check_launch("raster_backward");
 }
