@@ -31,6 +31,11 @@ class RasterSettingsC(C.Structure):
     ]
 
 
+class AdamTensorC(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_float), ("bias_correction1", C.c_float), ("bias_correction2", C.c_float)]
+
+
 class RasterSizesC(C.Structure):
     _fields_ = [("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)]
 
@@ -57,6 +62,7 @@ _SIGNATURES = {
     "gsvc_rate_forward": (C.c_int, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_int32, _i64, _i64, _vp, _vp, _vp]),
     "gsvc_ssim_l1_forward": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_ssim_l1_backward": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_adam_step": (C.c_int, [C.c_int32, C.POINTER(AdamTensorC), C.c_double, C.c_double, C.c_double, _vp]),
     "gsvc_gen_tail_forward": (C.c_int, [_vp] * 7 + [C.POINTER(C.c_float), C.POINTER(C.c_float), _i64, C.c_int32] + [_vp] * 7),
     "gsvc_gen_tail_backward": (C.c_int, [_vp] * 7 + [C.POINTER(C.c_float), C.POINTER(C.c_float), _i64, C.c_int32] + [_vp] * 12),
     "gsvc_optical_forward": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, C.c_int32, _i64, _vp, C.c_int32, C.c_int32,

@@ -444,9 +444,12 @@ class GaussianModel(nn.Module):
         reg("mlp_deform", self.mlp_deform, ta.mlp_deform_lr_init, sched("mlp_deform"))
         for name in ("mlp_feature_enet", "mlp_scaling_enet", "mlp_offset_enet"):
             reg(name, getattr(self, name), ta.mlp_entropy_net_lr_init, sched("mlp_entropy_net"))
-        # fused=True: one multi-tensor kernel per group on the GPU (same update rule as the reference's default Adam)
-        self.optimizer = torch.optim.Adam(self.net_params_registry.values(), lr=0.0, eps=1e-15,
-                                          fused=bool(self._anchor.is_cuda))
+        # on the GPU: one launch updates every tensor (gsvc_amd/optim.py, csrc/adam.hip); same rule as the reference's Adam
+        if self._anchor.is_cuda:
+            from .optim import FusedAdam
+            self.optimizer = FusedAdam(self.net_params_registry.values(), lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(self.net_params_registry.values(), lr=0.0, eps=1e-15)
 
     def update_learning_rate(self, iteration):
         for group in self.optimizer.param_groups:

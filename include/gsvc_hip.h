@@ -235,6 +235,23 @@ int gsvc_gen_tail_backward(const float *opacity_raw, const float *offset_mask, c
                            float *d_grid_scaling, float *d_anchor, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Optimizer (reference scene/gaussian_model.py:1034-1058: torch.optim.Adam(eps=1e-15), 15 parameter groups)
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct gsvc_adam_tensor {
+    float *param;             /* updated in place */
+    const float *grad;
+    float *exp_avg;           /* first / second moment, updated in place */
+    float *exp_avg_sq;
+    int64_t n;                /* elements */
+    float lr;
+    float bias_correction1;   /* 1 - beta1^t, t = number of updates of this tensor including this one */
+    float bias_correction2;   /* 1 - beta2^t */
+} gsvc_adam_tensor;
+
+/* One Adam update (no weight decay, no amsgrad) of every tensor in the host array, in one launch per 64 tensors. */
+int gsvc_adam_step(int32_t n_tensors, const gsvc_adam_tensor *tensors_host, double beta1, double beta2, double eps, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Linear layers of the generator / deformation / entropy-parameter MLPs (reference scene/gaussian_model.py:
  * 150-232: every nn.Linear applied to the [anchors, features] matrix)
  * ---------------------------------------------------------------------------------------------------- */

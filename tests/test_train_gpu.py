@@ -269,3 +269,34 @@ def test_training_crosses_densification_steps():
     assert grp["params"][0] is pc._anchor_feat and pc.optimizer.state[pc._anchor_feat]["exp_avg"].shape == pc._anchor_feat.shape
     for n, p in pc.named_parameters():
         assert torch.isfinite(p).all(), n
+
+
+def test_fused_adam_matches_torch_adam():
+    """gsvc_amd.optim.FusedAdam (csrc/adam.hip, one launch for all tensors) against torch.optim.Adam over several steps with
+    per-group learning rates, parameters that skip steps (no grad) and odd sizes."""
+    from gsvc_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(9)
+    shapes = [(1000, 50), (7,), (333, 10, 3), (1,), (4099,), (64, 64)]
+    pa = [torch.randn(*s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    groups = lambda ps: [{"params": [ps[0], ps[1]], "lr": 1e-2, "name": "a"}, {"params": [ps[2]], "lr": 3e-4, "name": "b"},
+                         {"params": ps[3:], "lr": 0.0, "name": "c"}]  # noqa: E731
+    oa, ob = FusedAdam(groups(pa), lr=0.0, eps=1e-15), torch.optim.Adam(groups(pb), lr=0.0, eps=1e-15)
+    for it in range(6):
+        for k, (x, y) in enumerate(zip(pa, pb)):
+            if k == 1 and it % 2 == 0:
+                x.grad = y.grad = None          # a parameter without gradient keeps its own step count
+                continue
+            gr = torch.randn(x.shape, generator=g).cuda() * (10.0 ** (k - 3))
+            x.grad, y.grad = gr.clone(), gr.clone()
+        for grp_a, grp_b in zip(oa.param_groups, ob.param_groups):
+            grp_a["lr"] = grp_b["lr"] = grp_b["lr"] * 0.9 + 1e-5
+        oa.step()
+        ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=1e-5, atol=2e-6)
+        if y in ob.state:
+            for key in ("exp_avg", "exp_avg_sq"):
+                a, b = oa.state[x][key], ob.state[y][key]
+                assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item(), key
+            assert float(oa.state[x]["step"]) == float(ob.state[y]["step"])
