@@ -133,8 +133,9 @@ def raster_forward(st: RasterSettings, means3D, colors, opacities, scales, rotat
         C.byref(st), C.c_int64(P), _p(means3D), _p(colors), _p(opacities), _p(scales), _p(rotations),
         _p(image), _p(radii, C.c_int32), _p(final_T), _p(n_contrib, C.c_int32), _p(ranges, C.c_int32),
         C.c_int64(total), _p(plist, C.c_int32), _p(geom), _p(border, C.c_uint8), C.c_int(num_threads))
-    assert n == total
-    return RasterForward(image, radii, int(n), final_T, n_contrib, ranges, plist[:total], geom, border)
+    # `total` counts every Gaussian the geometric test keeps; the forward also culls opacity <= 0, so n <= total
+    assert 0 <= n <= total
+    return RasterForward(image, radii, int(n), final_T, n_contrib, ranges, plist[:n], geom, border)
 
 
 @dataclass
