@@ -266,3 +266,10 @@ def test_full_size_cfg2_parity_and_properties(oracle_lib):
     img3, radii3, n3 = r(means3D=ext["means3D"], means2D=torch.zeros_like(ext["means3D"]), shs=None, colors_precomp=ext["colors"],
                          opacities=ext_op, scales=ext["scales"], rotations=ext["rotations"], cov3D_precomp=None)
     assert n3 == n1 and torch.equal(img3, img1) and int(radii3[P:].abs().sum()) == 0
+
+
+def test_randomised_scenes_forward_and_backward(oracle_lib):
+    """A fixed-seed slice of tools/stress_raster.py (random image sizes, counts, footprints up to ~50 px, both views,
+    off-screen / out-of-slab / opacity <= 0 Gaussians, random backgrounds): forward and all six gradients."""
+    from tools import stress_raster
+    assert stress_raster.run(12, seed=5, verbose=False) == 0
