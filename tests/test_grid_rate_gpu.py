@@ -30,7 +30,9 @@ def _levels(D, res, log2):
 
 @pytest.mark.parametrize("D,Cf,res,log2,N", [(3, 8, (18, 24, 33, 44, 59, 80), 13, 5000), (2, 8, (130, 258, 514), 15, 4097),
                                               (3, 2, (6, 9, 14), 9, 333), (2, 4, (10, 18), 8, 64), (1, 1, (16, 64), 5, 100),
-                                              (3, 16, (18, 40), 11, 257), (2, 32, (20,), 7, 65)])
+                                              (3, 16, (18, 40), 11, 257), (2, 32, (20,), 7, 65),
+                                              # tables too large for 16 LDS slices: the global-atomic fallback of k_grid_bwd_lds
+                                              (3, 2, (64, 128, 256), 19, 20000), (2, 1, (1026, 2050), 21, 5000)])
 def test_grid_kernels_match_oracle(oracle_lib, D, Cf, res, log2, N):
     from gsvc_amd import gridencoder_backend as be
     rng = np.random.default_rng(D * 100 + Cf)
