@@ -83,6 +83,16 @@ def allreduce_statistics(pc):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+def any_rank(flag: bool, device) -> bool:
+    """True on every rank if `flag` is True on at least one (a one-element MAX all-reduce; identity on one rank).
+    Used for decisions all replicas must take together, e.g. repeating a step whose rasterizer buffer overflowed."""
+    if world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0)
+
+
 def broadcast_parameters(module, src: int = 0):
     """Make every rank start from rank `src`'s parameters and buffers."""
     if world_size() == 1:

@@ -163,7 +163,7 @@ class Trainer:
         if self.batched:
             # the only host synchronisation of the step after the visibility test: the 4 renders' instance counters
             _, overflowed = resolve_deferred([r.raster_state for r in renders])
-            if overflowed:
+            if gdist.any_rank(overflowed, dev):      # replicas repeat the step together (their collectives must pair up)
                 return None
             for r in renders:
                 r.num_rendered = r.raster_state.counters()[0]
