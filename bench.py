@@ -194,6 +194,27 @@ def run_train_step(args, rank, world, local_rank, dev):
         "gsvc_kernel_us_per_step": kernel_us,
         "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] / args.steps} for k, v in kern.items()},
     }
+    # end-to-end frame rate of the decoder's render loop (reference utils/report_utils.py:297-319: per frame the visibility
+    # test, the anchor -> Gaussian generation with the MLPs, and the two-view frame), on the model just fitted
+    from gsvc_amd.generate import GenerateMode
+    from gsvc_amd.ortho_gaussian_renderer import render_pair
+    frames_e2e = [cube.get_dummy_frame(i) for i in range(trainer.lo, max(trainer.lo + 1, min(trainer.hi, trainer.lo + 48)))]
+    for fr in frames_e2e[:4]:
+        render_pair(fr, pc, pipe, trainer.background, mode=GenerateMode.DECODING_AS_IS)
+    torch.cuda.synchronize()
+    te0 = time.perf_counter()
+    for fr in frames_e2e:
+        render_pair(fr, pc, pipe, trainer.background, mode=GenerateMode.DECODING_AS_IS)
+    torch.cuda.synchronize()
+    res["render_pair_fps_end_to_end"] = len(frames_e2e) / (time.perf_counter() - te0) * world
+    from gsvc_amd.ortho_gaussian_renderer import render_frames
+    for _ in render_frames(frames_e2e[:8], pc, pipe, trainer.background):
+        pass
+    torch.cuda.synchronize()
+    te0 = time.perf_counter()
+    n_img = sum(1 for _ in render_frames(frames_e2e, pc, pipe, trainer.background))
+    torch.cuda.synchronize()
+    res["render_frames_fps_end_to_end"] = n_img / (time.perf_counter() - te0) * world
     if world == 1 and not args.no_cpu_baseline:
         import oracle
         oracle.build()
@@ -408,7 +429,8 @@ def main():
     if rank == 0:
         if ts is not None:
             out["train_step"] = {k: ts[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "gsvc_kernel_us_per_step",
-                                                     "kernels", "roofline") if k in ts} if "error" not in ts else ts
+                                                     "kernels", "roofline", "render_pair_fps_end_to_end", "render_frames_fps_end_to_end") if k in ts} \
+                if "error" not in ts else ts
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

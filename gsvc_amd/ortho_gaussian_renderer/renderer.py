@@ -104,3 +104,34 @@ def render_pair(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, m
         rendered_image=image, viewspace_points=None, visibility_filter=radii > 0, visible_mask=visible_mask, radii=radii,
         active_gaussains=(radii > 0).sum(), num_rendered=state.counters()[0], selection_mask=gss.mask,
         neural_opacity=gss.neural_opacity, scaling=gss.scaling, generated_gaussians=gss, time_sub=gss.time_sub)
+
+
+def render_frames(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, mode=GenerateMode.DECODING_AS_IS, batch: int = 8):
+    """The decoder's render loop (reference utils/report_utils.py:297-319 / stream decoding: one two-view frame per video
+    frame) over a list of frames: the anchor -> Gaussian generation of `batch` frames runs as one un-compacted batch
+    (frames of a video are independent), each frame is then composited by one gsvc_raster_forward_pair pass, and the
+    instance counters of a batch are read back together.  Yields the images [3, H, W] in order.  Inference only."""
+    if mode not in (GenerateMode.DECODING_AS_IS, GenerateMode.TRAINING_FULL_PRECISION, GenerateMode.TRAININ_STE_ENTROPY):
+        raise ValueError("render_frames needs a deterministic GenerateMode")
+    from ..rasterizer import resolve_deferred
+    frames = list(frames)
+    for f in frames:
+        if int(f.image_width) % 16 != 0:
+            raise ValueError("render_frames: the two-view pass needs an image width that is a multiple of 16 (use render_pair)")
+    with torch.no_grad():
+        for i in range(0, len(frames), batch):
+            chunk = frames[i:i + batch]
+            while True:
+                geometry = prefilter_geometry(pc)
+                visible = [prefilter_voxel(f, pc, pipe, bg_color, geometry=geometry) for f in chunk]
+                gss_list = generate_neural_gaussians_many(chunk, pc, visible, mode, dense=True, anchors=geometry[0])
+                images, states = [], []
+                for f, gss in zip(chunk, gss_list):
+                    cs = settings_to_c(raster_settings_for(f, pc, pipe, bg_color, scaling_modifier))
+                    image, _, state = raster_forward(cs, gss.xyz.contiguous(), gss.color.contiguous(), gss.opacity.contiguous(),
+                                                     gss.scaling.contiguous(), gss.rot.contiguous(), pair=True, sync=False)
+                    images.append(image)
+                    states.append(state)
+                if not resolve_deferred(states)[1]:
+                    break              # else: an instance buffer overflowed, the capacity hint is raised: once more
+            yield from images
