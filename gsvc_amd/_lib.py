@@ -63,6 +63,10 @@ _SIGNATURES = {
     "gsvc_ssim_l1_forward": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_ssim_l1_backward": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_adam_step": (C.c_int, [C.c_int32, C.POINTER(AdamTensorC), C.c_double, C.c_double, C.c_double, _vp]),
+    "gsvc_noise_quant_scratch_floats": (_i64, [C.POINTER(C.c_int64), C.c_int32]),
+    "gsvc_noise_quant_forward": (C.c_int, [_vp, _vp, C.c_float, _vp, C.POINTER(C.c_int64), C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
+    "gsvc_noise_quant_backward": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, _vp, C.POINTER(C.c_int64), C.c_int32, C.c_int32, _vp, _vp,
+                                            _vp]),
     "gsvc_gen_tail_forward": (C.c_int, [_vp] * 7 + [C.POINTER(C.c_float), C.POINTER(C.c_float), _i64, C.c_int32] + [_vp] * 7),
     "gsvc_gen_tail_backward": (C.c_int, [_vp] * 7 + [C.POINTER(C.c_float), C.POINTER(C.c_float), _i64, C.c_int32] + [_vp] * 12),
     "gsvc_optical_forward": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, C.c_int32, _i64, _vp, C.c_int32, C.c_int32,

@@ -1,0 +1,202 @@
+// gsvc_amd/csrc/quant.hip — training-time noise quantisation of the per-anchor attributes, fused, gfx950.
+//
+// Reference utils/encodings.py:395-409 (UniformQuantizer) as the batched step applies it to R renders at once: for every
+// row m of render r (rows [off[r], off[r+1])), with a per-row step Q_m (or one scalar Q),
+//     centre_r = mean(x over render r) / mean(Q over render r)          (no gradient)
+//     y = clamp(x / Q_m, centre_r - 15000, centre_r + 15000) * Q_m + noise * Q_m,   noise ~ U(-1/2, 1/2) drawn by the caller
+// In PyTorch that is ~25 small launches per tensor and direction (segment means through index_add, broadcasts, clamp with
+// tensor bounds); here: one reduction (+ a one-block finalize), one elementwise forward, one backward.
+#include "common.h"
+
+namespace gsvc {
+
+constexpr int Q_MAX_RENDERS = 8;
+constexpr float Q_CLAMP_STEPS = 15000.0f;
+
+struct QSeg {
+    long long off[Q_MAX_RENDERS + 1];   // first row of render r
+    int R;
+};
+
+__device__ __forceinline__ int q_render_of(const QSeg &seg, long long row)
+{
+    int r = 0;
+    while (r + 1 < seg.R && row >= seg.off[r + 1]) r++;
+    return r;
+}
+
+__device__ __forceinline__ float q_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float q_block_sum(float v, float *red)
+{
+    v = q_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// part[(r*nbx + bx)*2 + {0,1}] = block sums of x (all columns) and of q over 64-row slabs of render r
+__global__ void __launch_bounds__(256) k_quant_sums(const float *__restrict__ x, const float *__restrict__ q, QSeg seg, int C,
+                                                    float *__restrict__ part)
+{
+    __shared__ float red[4];
+    const int r = blockIdx.y;
+    const long long row0 = seg.off[r] + (long long)blockIdx.x * 64, row1 = min(seg.off[r + 1], row0 + 64);
+    float sx = 0.f, sq = 0.f;
+    if (row0 < row1) {
+        const long long e0 = row0 * C, e1 = row1 * C;
+        for (long long e = e0 + threadIdx.x; e < e1; e += 256) sx += x[e];
+        if (q && row0 + threadIdx.x < row1) sq = q[row0 + threadIdx.x];
+    }
+    sx = q_block_sum(sx, red);
+    sq = q_block_sum(sq, red);
+    if (threadIdx.x == 0) {
+        float *d = part + ((size_t)r * gridDim.x + blockIdx.x) * 2;
+        d[0] = sx; d[1] = sq;
+    }
+}
+
+// centre[r] = (sum x / (rows_r C)) / (sum q / rows_r)   or   / q_scalar
+__global__ void __launch_bounds__(256) k_quant_centre(const float *__restrict__ part, int nbx, QSeg seg, int C, int has_q,
+                                                      float q_scalar, float *__restrict__ centre)
+{
+    __shared__ float red[4];
+    for (int r = 0; r < seg.R; r++) {
+        float sx = 0.f, sq = 0.f;
+        for (int b = threadIdx.x; b < nbx; b += 256) {
+            sx += part[((size_t)r * nbx + b) * 2];
+            sq += part[((size_t)r * nbx + b) * 2 + 1];
+        }
+        sx = q_block_sum(sx, red);
+        sq = q_block_sum(sq, red);
+        if (threadIdx.x == 0) {
+            const float rows = (float)(seg.off[r + 1] - seg.off[r]);
+            const float xm = sx / fmaxf(rows * (float)C, 1.f);
+            const float qm = has_q ? sq / fmaxf(rows, 1.f) : q_scalar;
+            centre[r] = xm / qm;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_quant_fwd(const float *__restrict__ x, const float *__restrict__ q, float q_scalar,
+                                                   const float *__restrict__ noise, const float *__restrict__ centre, QSeg seg,
+                                                   int C, float *__restrict__ y)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = seg.off[seg.R] * C;
+    if (e >= n) return;
+    const long long row = e / C;
+    const float c = centre[q_render_of(seg, row)];
+    const float Q = q ? q[row] : q_scalar;
+    const float t = fminf(fmaxf(x[e] / Q, c - Q_CLAMP_STEPS), c + Q_CLAMP_STEPS);
+    y[e] = t * Q + noise[e] * Q;
+}
+
+// dx = g where the clamp is inactive; dq[row] = sum_c g * (clamped value if the clamp is active, else 0, + noise).
+// A block takes rpb = 256 / C whole rows (one lane per element), the row sums meet in LDS.
+__global__ void __launch_bounds__(256) k_quant_bwd(const float *__restrict__ g, const float *__restrict__ x,
+                                                   const float *__restrict__ q, float q_scalar, const float *__restrict__ noise,
+                                                   const float *__restrict__ centre, QSeg seg, int C, int rpb,
+                                                   float *__restrict__ dx, float *__restrict__ dq)
+{
+    __shared__ float part[256];
+    const int t = threadIdx.x, lr = t / C;
+    const long long rows = seg.off[seg.R];
+    const long long row = (long long)blockIdx.x * rpb + lr;
+    const bool live = lr < rpb && row < rows;
+    float contrib = 0.f;
+    if (live) {
+        const long long e = row * C + (t - lr * C);
+        const float c = centre[q_render_of(seg, row)];
+        const float Q = q ? q[row] : q_scalar;
+        const float v = x[e] / Q, lo = c - Q_CLAMP_STEPS, hi = c + Q_CLAMP_STEPS;
+        const bool inside = v >= lo && v <= hi;
+        const float ge = g[e];
+        dx[e] = inside ? ge : 0.f;
+        contrib = ge * ((inside ? 0.f : fminf(fmaxf(v, lo), hi)) + noise[e]);
+    }
+    part[t] = contrib;
+    __syncthreads();
+    if (dq && t < rpb) {
+        const long long r2 = (long long)blockIdx.x * rpb + t;
+        if (r2 < rows) {
+            float a = 0.f;
+            for (int c = 0; c < C; c++) a += part[t * C + c];
+            dq[r2] = a;
+        }
+    }
+}
+
+static bool q_fill(const int64_t *off_host, int R, QSeg &seg)
+{
+    if (R < 1 || R > Q_MAX_RENDERS) return false;
+    seg.R = R;
+    for (int r = 0; r <= R; r++) seg.off[r] = off_host[r];
+    for (int r = R + 1; r <= Q_MAX_RENDERS; r++) seg.off[r] = off_host[R];
+    return true;
+}
+
+static int q_nbx(const QSeg &seg)
+{
+    long long longest = 1;
+    for (int r = 0; r < seg.R; r++) longest = seg.off[r + 1] - seg.off[r] > longest ? seg.off[r + 1] - seg.off[r] : longest;
+    return (int)((longest + 63) / 64);
+}
+
+}  // namespace gsvc
+
+using namespace gsvc;
+
+extern "C" int64_t gsvc_noise_quant_scratch_floats(const int64_t *row_offsets_host, int32_t R)
+{
+    QSeg seg;
+    if (!row_offsets_host || !q_fill(row_offsets_host, R, seg)) return -1;
+    return (int64_t)2 * R * q_nbx(seg);
+}
+
+extern "C" int gsvc_noise_quant_forward(const float *x, const float *q_rows, float q_scalar, const float *noise,
+                                        const int64_t *row_offsets_host, int32_t R, int32_t C, float *scratch, float *centre,
+                                        float *y, void *stream)
+{
+    QSeg seg;
+    GSVC_REQUIRE(row_offsets_host && q_fill(row_offsets_host, R, seg) && C > 0, "noise_quant_forward: 1..8 renders, C > 0");
+    GSVC_REQUIRE(scratch && centre, "noise_quant_forward: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const long long rows = seg.off[R];
+    GSVC_REQUIRE(rows == 0 || (x && noise && y), "noise_quant_forward: NULL pointer");
+    const int nbx = q_nbx(seg);
+    {
+        ProfScope _p("k_quant_sums", s);
+        hipLaunchKernelGGL(k_quant_sums, dim3(nbx, R), dim3(256), 0, s, x, q_rows, seg, C, scratch);
+    }
+    hipLaunchKernelGGL(k_quant_centre, dim3(1), dim3(256), 0, s, scratch, nbx, seg, C, q_rows ? 1 : 0, q_scalar, centre);
+    if (rows) {
+        ProfScope _p("k_quant_fwd", s);
+        hipLaunchKernelGGL(k_quant_fwd, dim3((unsigned)((rows * C + 255) / 256)), dim3(256), 0, s, x, q_rows, q_scalar, noise, centre,
+                           seg, C, y);
+    }
+    return check_launch("noise_quant_forward");
+}
+
+extern "C" int gsvc_noise_quant_backward(const float *grad_y, const float *x, const float *q_rows, float q_scalar,
+                                         const float *noise, const float *centre, const int64_t *row_offsets_host, int32_t R,
+                                         int32_t C, float *grad_x, float *grad_q_rows, void *stream)
+{
+    QSeg seg;
+    GSVC_REQUIRE(row_offsets_host && q_fill(row_offsets_host, R, seg) && C > 0 && C <= 256, "noise_quant_backward: 1..8 renders, 0 < C <= 256");
+    const long long rows = seg.off[R];
+    if (rows == 0) return GSVC_OK;
+    GSVC_REQUIRE(grad_y && x && noise && centre && grad_x, "noise_quant_backward: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = 256 / C;
+    ProfScope _p("k_quant_bwd", s);
+    hipLaunchKernelGGL(k_quant_bwd, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, grad_y, x, q_rows, q_scalar, noise, centre,
+                       seg, C, rpb, grad_x, grad_q_rows);
+    return check_launch("noise_quant_backward");
+}

@@ -292,7 +292,53 @@ def _seg_bounds(x, Q, seg, x_mean=None):
     return centre - 15_000, centre + 15_000
 
 
+class _NoiseQuant(torch.autograd.Function):
+    """clamp(x / Q, centre_r -+ 15000) * Q + U(-1/2, 1/2) * Q per render r, fused (csrc/quant.hip)."""
+
+    @staticmethod
+    def forward(ctx, x2, q_rows, q_scalar, noise, offsets):
+        import ctypes as C
+        from . import _lib
+        dev = x2.device
+        x2, noise = x2.contiguous(), noise.contiguous()
+        q = q_rows.contiguous() if q_rows is not None else None
+        R = len(offsets) - 1
+        seg = (C.c_int64 * (R + 1))(*[int(v) for v in offsets])
+        L = _lib.lib()
+        scratch = torch.empty(max(int(L.gsvc_noise_quant_scratch_floats(seg, R)), 1), dtype=torch.float32, device=dev)
+        centre = torch.empty(R, dtype=torch.float32, device=dev)
+        y = torch.empty_like(x2)
+        _lib.check(L.gsvc_noise_quant_forward(_lib.ptr(x2), _lib.ptr(q), float(q_scalar), _lib.ptr(noise), seg, R, x2.shape[1],
+                                              _lib.ptr(scratch), _lib.ptr(centre), _lib.ptr(y), _lib.current_stream(dev)),
+                   "gsvc_noise_quant_forward")
+        ctx.save_for_backward(x2, q, noise, centre)
+        ctx.seg, ctx.R, ctx.q_scalar = seg, R, float(q_scalar)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        x2, q, noise, centre = ctx.saved_tensors
+        dev = x2.device
+        dx = torch.empty_like(x2)
+        dq = torch.empty(x2.shape[0], dtype=torch.float32, device=dev) if q is not None else None
+        _lib.check(_lib.lib().gsvc_noise_quant_backward(_lib.ptr(g.contiguous()), _lib.ptr(x2), _lib.ptr(q), ctx.q_scalar,
+                                                        _lib.ptr(noise), _lib.ptr(centre), ctx.seg, ctx.R, x2.shape[1],
+                                                        _lib.ptr(dx), _lib.ptr(dq), _lib.current_stream(dev)),
+                   "gsvc_noise_quant_backward")
+        return dx, dq, None, None, None
+
+
 def _seg_noise_quant(x, Q, seg):
+    if x.is_cuda and x.shape[0] > 0 and x[0].numel() <= 256:
+        # fused path: x viewed as [rows, C]; Q is a python number or one step per row
+        x2 = x.reshape(x.shape[0], -1)
+        noise = torch.empty_like(x2).uniform_(-0.5, 0.5)
+        if isinstance(Q, torch.Tensor):
+            y = _NoiseQuant.apply(x2, Q.reshape(-1), 0.0, noise, seg.bounds)
+        else:
+            y = _NoiseQuant.apply(x2, None, float(Q), noise, seg.bounds)
+        return y.view(x.shape)
     lo, hi = _seg_bounds(x, Q, seg)
     x = torch.clamp(x / Q, min=lo, max=hi) * Q
     return x + torch.empty_like(x).uniform_(-0.5, 0.5) * Q

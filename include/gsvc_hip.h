@@ -216,6 +216,20 @@ int gsvc_regs_forward(const float *scaling, const float *neural_opacity, const u
 int gsvc_regs_backward(const float *scaling, const uint8_t *mask, const int64_t *seg_offsets_host, int32_t R, const float *sums,
                        const float *grad_out, float *grad_scaling, float *grad_opacity, void *stream);
 
+/* Training-time noise quantisation (reference utils/encodings.py:395-409 UniformQuantizer) of x[rows, C] for R renders
+ * at once (render r = rows [row_offsets[r], row_offsets[r+1]), host array, R <= 8):
+ *   y = clamp(x / Q, c_r - 15000, c_r + 15000) * Q + noise * Q,   c_r = mean(x over render r) / mean(Q over render r),
+ * Q = q_rows[row] (per-row step, device) or q_scalar when q_rows is NULL; noise[rows, C] ~ U(-1/2, 1/2) is drawn by the
+ * caller.  centre: float[R] (kept for backward); scratch: float[gsvc_noise_quant_scratch_floats()]. */
+int64_t gsvc_noise_quant_scratch_floats(const int64_t *row_offsets_host, int32_t R);
+int gsvc_noise_quant_forward(const float *x, const float *q_rows, float q_scalar, const float *noise,
+                             const int64_t *row_offsets_host, int32_t R, int32_t C, float *scratch, float *centre, float *y,
+                             void *stream);
+/* grad_x[rows, C] and grad_q_rows[rows] (may be NULL) are overwritten; the centre carries no gradient (C <= 256). */
+int gsvc_noise_quant_backward(const float *grad_y, const float *x, const float *q_rows, float q_scalar, const float *noise,
+                              const float *centre, const int64_t *row_offsets_host, int32_t R, int32_t C, float *grad_x,
+                              float *grad_q_rows, void *stream);
+
 /* Tail of the anchor -> neural-Gaussian generation for un-compacted renders (reference
  * ortho_gaussian_renderer/guassian.py:262-296: opacity mask, sigmoid scaling, normalised rotation, world position, bound
  * clamp), n = rows*K Gaussians, Gaussian i belongs to anchor row i / K.  Inputs: opacity_raw[n], offset_mask[n],

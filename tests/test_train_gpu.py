@@ -318,3 +318,37 @@ def test_render_frames_equals_render_pair():
         # alpha >= 1/255 / T < 1e-4 decision: allow a handful of such pixels
         d = (img - ref).abs()
         assert (d > 2e-5).float().mean().item() < 2e-4 and d.max().item() < 5e-3
+
+
+@pytest.mark.parametrize("per_row_q", [True, False])
+def test_fused_noise_quant_matches_torch(per_row_q):
+    """csrc/quant.hip against the PyTorch statement of the per-render UniformQuantizer (same noise tensor): values, the
+    gradient w.r.t. x (1 where the clamp is inactive) and w.r.t. the per-row step Q."""
+    import gsvc_amd.generate as G
+    g = torch.Generator().manual_seed(21)
+    counts = [300, 0, 1111, 64]
+    seg = G._Segments(counts, torch.device("cuda"))
+    rows = sum(counts)
+    x = (torch.randn(rows, 10, 3, generator=g) * 3).cuda().requires_grad_(True)
+    # a few rows far outside the +-15000-step window so that the clamp (and its dQ branch) is exercised
+    x.data[5] = 4000.0
+    x.data[700] = -3500.0
+    Q = ((torch.rand(rows, 1, 1, generator=g) * 0.2 + 0.05).cuda().requires_grad_(True)) if per_row_q else 0.2
+    noise = (torch.rand(rows, 30, generator=g) - 0.5).cuda()
+    q_rows = Q.reshape(-1) if per_row_q else None
+    y = G._NoiseQuant.apply(x.reshape(rows, 30), q_rows, 0.0 if per_row_q else Q, noise, seg.bounds).view(x.shape)
+    lo, hi = G._seg_bounds(x, Q, seg)
+    ref = torch.clamp(x / Q, min=lo, max=hi) * Q + noise.view(x.shape) * Q
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
+    w = torch.randn(x.shape, generator=g).cuda()
+    (y * w).sum().backward()
+    gx = x.grad.clone()
+    gq = Q.grad.clone() if per_row_q else None
+    x.grad = None
+    if per_row_q:
+        Q.grad = None
+    (ref * w).sum().backward()
+    assert torch.allclose(gx, x.grad, rtol=1e-5, atol=1e-6)
+    if per_row_q:
+        # inside the window autograd's dQ is a rounding residue of x/Q - x/Q: compare on the scale of the noise term
+        assert (gq - Q.grad).abs().max().item() <= 1e-3 * Q.grad.abs().max().item()
