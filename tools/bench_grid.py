@@ -1,6 +1,7 @@
 """Microbenchmark of the hash-grid kernels at the train-step shapes."""
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gsvc_amd.encodings import GridEncoder
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 181585

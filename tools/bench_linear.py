@@ -1,6 +1,7 @@
 """Microbenchmark: library F.linear vs k_linear_fwd vs k_linear_ws on the MLP shapes of the train step."""
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gsvc_amd import _lib
 import torch.nn.functional as F
 L = _lib.lib()

@@ -1,6 +1,7 @@
 """Microbenchmark: dW = G^T X through gsvc_linear_wgrad vs the library (plain and M-split batched)."""
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gsvc_amd import _lib
 L = _lib.lib()
 dev = torch.device("cuda:0")
