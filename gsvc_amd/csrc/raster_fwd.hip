@@ -338,7 +338,8 @@ __global__ void __launch_bounds__(256) k_scatter(int P, int gx, const BinRec *__
                                                  int32_t *__restrict__ tile_extra, uint64_t *__restrict__ keys,
                                                  const gsvc_raster_counters *__restrict__ counters)
 {
-    if (counters->overflow) return;
+    // the overflow flag (set by the scan) is only needed before the first store: its load travels with the record loads
+    const int overflow = counters->overflow;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const float4 b0 = reinterpret_cast<const float4 *>(bins + i)[0];
@@ -369,6 +370,7 @@ __global__ void __launch_bounds__(256) k_scatter(int P, int gx, const BinRec *__
         tl[j] = (y0 + jy) * gx + x0 + jx;
         off[j] = j < ntiles ? tile_offsets[tl[j]] : 0;
     }
+    if (overflow) return;
 #pragma unroll
     for (int j = 0; j < BIN_SLOTS; j++)
         if (j < ntiles) keys[off[j] + slots[j]] = make_key(tl[j] % gx);
@@ -450,7 +452,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
                                                     const gsvc_raster_counters *__restrict__ counters, int id_shift)
 {
     __shared__ uint64_t s_all[4 * SORT_WAVE_MAX];   // 32 KiB: one 8-KiB strip per wave
-    if (counters->overflow) return;
+    const int overflow = counters->overflow;   // loaded together with the segment bounds (one scalar round trip, not two)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint64_t *s = s_all + wave * SORT_WAVE_MAX;
@@ -460,6 +462,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
         beg = tile_offsets[t];
         n = tile_offsets[t + 1] - beg;
     }
+    if (overflow) n = 0;
     if (n > 0 && n <= SORT_RANK_MAX) {
         uint64_t k[4];
         uint2 bb[4];
@@ -507,7 +510,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
         for (int i = lane; i < n; i += 64) emit_entry(beg + i, s[i], geom, point_list, inst_bbox, id_shift);
     }
     // long lists: whole workgroups (uniform loop bounds; usually zero iterations)
-    const int nbig = counters->num_big_tiles;
+    const int nbig = overflow ? 0 : counters->num_big_tiles;
     for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
         const int bt = big_list[w];
         const int bbeg = tile_offsets[bt], bn = tile_offsets[bt + 1] - bbeg;
@@ -578,7 +581,11 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     float Tb = 1.0f, B0 = 0.f, B1 = 0.f, B2 = 0.f;   // PAIR: back-to-front composite of the same list
     int last = 0;
-    bool done = !inside;
+    // pixel position relative to the quadrant centre, and its products: the lane's side of the polynomial form
+    const float xl = (float)(lane & 7) - 3.5f, yl = (float)(lane >> 3) - 3.5f;
+    const float xl2 = xl * xl, yl2 = yl * yl, xyl = xl * yl;
+    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;
+    unsigned long long done_m = __ballot(!inside);    // lanes that take no further entries (uniform mask, in SGPRs)
     for (int c0 = beg; c0 < end; c0 += 64) {
         // phase 1: 64 list entries per wave-instruction against this wave's quadrant
         const int k = c0 + lane;
@@ -592,54 +599,109 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
         // second, exact test on the bbox survivors: does the alpha >= 1/255 ellipse reach this quadrant at all?
         float4 r0, r1;
         const float4 *rec = reinterpret_cast<const float4 *>(geom + (PAIR ? (id >> 2) : id));
+        bool safe = true;
         if (hit) {
             r0 = rec[0];
             r1 = rec[1];
             hit = ellipse_hits_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)qx0, (float)qy0);
+            // conic positive definite with a margin and opacity > 0: "power > 0" (spec step 6) cannot happen for this
+            // entry, in exact or in rounded arithmetic, so the composite loop need not test for it
+            safe = r0.z > 0.f && r1.x > 0.f && r0.z * r1.x >= 1.002f * (r0.w * r0.w) && r1.y > 0.f;
         }
         const unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
+        const bool generic = __ballot(hit && !safe) != 0ull;    // NaN / indefinite conics: the literal loop
         if (hit) {
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-            w_f0[pos] = make_float4(r0.x, r0.y, (0.5f * LOG2E) * r0.z, LOG2E * r0.w);
-            w_f1[pos] = make_float4((0.5f * LOG2E) * r1.x, r1.y, r1.z, r1.w);
+            const float Ap = (0.5f * LOG2E) * r0.z, Bp = LOG2E * r0.w, Cp = (0.5f * LOG2E) * r1.x;
             // PAIR: the slot's tag carries the two view-membership flags instead of the list position
-            w_f2[pos] = make_float2(rec[2].x, __int_as_float(PAIR ? (id & 3) : (k - beg + 1)));
+            const float tagf = __int_as_float(PAIR ? (id & 3) : (k - beg + 1));
+            if (generic) {
+                w_f0[pos] = make_float4(r0.x, r0.y, Ap, Bp);
+                w_f1[pos] = make_float4(Cp, r1.y, r1.z, r1.w);
+            } else {
+                // -log2(alpha) of pixel (qcx + x, qcy + y) as a polynomial in the lane's (x, y), |x|, |y| <= 3.5:
+                //   A'(U-x)^2 + C'(V-y)^2 + B'(U-x)(V-y) - log2(o),  U = u - qcx, V = v - qcy;  stored negated
+                const float U = r0.x - qcx, V = r0.y - qcy;
+                const float n0 = __builtin_amdgcn_logf(r1.y) - (Ap * U * U + Cp * V * V + Bp * U * V);
+                w_f0[pos] = make_float4(n0, 2.0f * Ap * U + Bp * V, 2.0f * Cp * V + Bp * U, -Ap);
+                w_f1[pos] = make_float4(-Cp, -Bp, r1.z, r1.w);
+            }
+            w_f2[pos] = make_float2(rec[2].x, tagf);
         }
         const int cnt = __popcll(mask);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // phase 2: composite the survivors front to back
-#pragma unroll 4
-        for (int j = 0; j < cnt; j++) {
-            const float4 a = w_f0[j];
-            const float4 b = w_f1[j];
-            const float2 c = w_f2[j];
-            const float dx = a.x - fx, dy = a.y - fy;
-            const float p = a.z * dx * dx + b.x * dy * dy + a.w * dx * dy;   // = -power * log2(e)
-            const float alpha = fminf(ALPHA_MAX, b.y * __builtin_amdgcn_exp2f(-p));
-            const float test_T = T - alpha * T;
-            const int tagv = __float_as_int(c.y);
-            const bool contrib_any = !(p < 0.0f) && !(alpha < ALPHA_MIN);
-            const bool contrib = PAIR ? (contrib_any && (tagv & 1)) : contrib_any;
-            if (PAIR) {
-                const float ab = (contrib_any && inside && (tagv & 2)) ? alpha : 0.0f;
-                const float om = 1.0f - ab;
-                B0 = b.z * ab + om * B0; B1 = b.w * ab + om * B1; B2 = c.x * ab + om * B2;
-                Tb *= om;
+        // phase 2: composite the survivors front to back.  Lane predicates live as uniform 64-bit masks (v_cmp
+        // results in SGPRs, combined by scalar instructions); 17 vector instructions per entry.
+        if (!generic) {
+            auto step = [&](int j) {
+                const float4 a = w_f0[j];
+                const float4 b = w_f1[j];
+                const float2 c = w_f2[j];
+                float t = fmaf(b.y, xyl, a.x);
+                t = fmaf(a.y, xl, t);
+                t = fmaf(a.z, yl, t);
+                t = fmaf(a.w, xl2, t);
+                t = fmaf(b.x, yl2, t);
+                const float alpha = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(t));
+                const float test_T = T - alpha * T;
+                const unsigned long long small_m = __ballot(alpha < ALPHA_MIN), lt_m = __ballot(test_T < T_MIN);
+                const int tagv = __float_as_int(c.y);
+                unsigned long long keep_m = ~done_m & ~small_m;
+                if (PAIR) {
+                    const int fl = __builtin_amdgcn_readfirstlane(tagv);
+                    const bool back = __builtin_amdgcn_inverse_ballot_w64((fl & 2) ? (~small_m & __ballot(inside)) : 0ull);
+                    const float ab = back ? alpha : 0.0f;
+                    const float om = 1.0f - ab;
+                    B0 = b.z * ab + om * B0; B1 = b.w * ab + om * B1; B2 = c.x * ab + om * B2;
+                    Tb *= om;
+                    if (!(fl & 1)) keep_m = 0ull;
+                }
+                const unsigned long long acc_m = keep_m & ~lt_m;
+                done_m |= keep_m & lt_m;
+                const bool acc = __builtin_amdgcn_inverse_ballot_w64(acc_m);
+                const float w = acc ? alpha * T : 0.0f;
+                C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
+                T = acc ? test_T : T;
+                last = acc ? tagv : last;
+            };
+            int j = 0;      // unrolled by hand: the mask intrinsics are convergent, which rules out "#pragma unroll 4"
+            for (; j + 4 <= cnt; j += 4) { step(j); step(j + 1); step(j + 2); step(j + 3); }
+            for (; j < cnt; j++) step(j);
+        } else {
+            bool done = __builtin_amdgcn_inverse_ballot_w64(done_m);
+            for (int j = 0; j < cnt; j++) {
+                const float4 a = w_f0[j];
+                const float4 b = w_f1[j];
+                const float2 c = w_f2[j];
+                const float dx = a.x - fx, dy = a.y - fy;
+                const float p = a.z * dx * dx + b.x * dy * dy + a.w * dx * dy;   // = -power * log2(e)
+                const float alpha = fminf(ALPHA_MAX, b.y * __builtin_amdgcn_exp2f(-p));
+                const float test_T = T - alpha * T;
+                const int tagv = __float_as_int(c.y);
+                const bool contrib_any = !(p < 0.0f) && !(alpha < ALPHA_MIN);
+                const bool contrib = PAIR ? (contrib_any && (tagv & 1)) : contrib_any;
+                if (PAIR) {
+                    const float ab = (contrib_any && inside && (tagv & 2)) ? alpha : 0.0f;
+                    const float om = 1.0f - ab;
+                    B0 = b.z * ab + om * B0; B1 = b.w * ab + om * B1; B2 = c.x * ab + om * B2;
+                    Tb *= om;
+                }
+                const bool keep = !done && contrib;
+                const bool stop = keep && (test_T < T_MIN);
+                const bool acc = keep && !stop;
+                done |= stop;
+                const float w = acc ? alpha * T : 0.0f;
+                C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
+                T = acc ? test_T : T;
+                last = acc ? tagv : last;
             }
-            const bool keep = !done && contrib;
-            const bool stop = keep && (test_T < T_MIN);
-            const bool acc = keep && !stop;
-            done |= stop;
-            const float w = acc ? alpha * T : 0.0f;
-            C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
-            T = acc ? test_T : T;
-            last = acc ? tagv : last;
+            done_m = __ballot(done);
         }
         __builtin_amdgcn_wave_barrier();
-        if (!PAIR && __ballot(!done) == 0ull) break;
+        if (!PAIR && done_m == ~0ull) break;
     }
     if (inside) {
         const int HW = st.H * st.W, pix = py * st.W + px;
