@@ -636,16 +636,21 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
         // phase 2: composite the survivors front to back.  Lane predicates live as uniform 64-bit masks (v_cmp
         // results in SGPRs, combined by scalar instructions); 17 vector instructions per entry.
         if (!generic) {
-            auto step = [&](int j) {
+            // alpha of entry j at this lane's pixel (independent of the pixel state: four of them are evaluated
+            // together so that their dependent FMA -> exp chains interleave)
+            auto alpha_of = [&](int j) -> float {
                 const float4 a = w_f0[j];
-                const float4 b = w_f1[j];
-                const float2 c = w_f2[j];
+                const float2 b = *reinterpret_cast<const float2 *>(&w_f1[j]);
                 float t = fmaf(b.y, xyl, a.x);
                 t = fmaf(a.y, xl, t);
                 t = fmaf(a.z, yl, t);
                 t = fmaf(a.w, xl2, t);
                 t = fmaf(b.x, yl2, t);
-                const float alpha = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(t));
+                return fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(t));
+            };
+            auto apply = [&](int j, float alpha) {
+                const float2 rg = *(reinterpret_cast<const float2 *>(&w_f1[j]) + 1);
+                const float2 c = w_f2[j];
                 const float test_T = T - alpha * T;
                 const unsigned long long small_m = __ballot(alpha < ALPHA_MIN), lt_m = __ballot(test_T < T_MIN);
                 const int tagv = __float_as_int(c.y);
@@ -655,7 +660,7 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
                     const bool back = __builtin_amdgcn_inverse_ballot_w64((fl & 2) ? (~small_m & __ballot(inside)) : 0ull);
                     const float ab = back ? alpha : 0.0f;
                     const float om = 1.0f - ab;
-                    B0 = b.z * ab + om * B0; B1 = b.w * ab + om * B1; B2 = c.x * ab + om * B2;
+                    B0 = rg.x * ab + om * B0; B1 = rg.y * ab + om * B1; B2 = c.x * ab + om * B2;
                     Tb *= om;
                     if (!(fl & 1)) keep_m = 0ull;
                 }
@@ -663,13 +668,16 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
                 done_m |= keep_m & lt_m;
                 const bool acc = __builtin_amdgcn_inverse_ballot_w64(acc_m);
                 const float w = acc ? alpha * T : 0.0f;
-                C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
+                C0 += rg.x * w; C1 += rg.y * w; C2 += c.x * w;
                 T = acc ? test_T : T;
                 last = acc ? tagv : last;
             };
             int j = 0;      // unrolled by hand: the mask intrinsics are convergent, which rules out "#pragma unroll 4"
-            for (; j + 4 <= cnt; j += 4) { step(j); step(j + 1); step(j + 2); step(j + 3); }
-            for (; j < cnt; j++) step(j);
+            for (; j + 4 <= cnt; j += 4) {
+                const float a0 = alpha_of(j), a1 = alpha_of(j + 1), a2 = alpha_of(j + 2), a3 = alpha_of(j + 3);
+                apply(j, a0); apply(j + 1, a1); apply(j + 2, a2); apply(j + 3, a3);
+            }
+            for (; j < cnt; j++) apply(j, alpha_of(j));
         } else {
             bool done = __builtin_amdgcn_inverse_ballot_w64(done_m);
             for (int j = 0; j < cnt; j++) {
