@@ -350,7 +350,8 @@ def _seg_ste(x, Q, seg, x_mean):
     return (x + (torch.round(x / Q) * Q - x).detach()).detach()
 
 
-def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec):
+def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row=None):
+    """``ec_row``: row -> row of ``ec`` when the entropy context was evaluated once per distinct anchor."""
     K = pc.n_offsets
     with torch.no_grad():
         mask_anchor = (torch.sum(offset_masks, dim=1)[:, 0]) > 0
@@ -360,6 +361,8 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
         sel_seg = seg.seg_id.index_select(0, sel)
         n_sel = torch.zeros(seg.R, device=feat.device).index_add_(0, sel_seg, torch.ones_like(sel_seg, dtype=torch.float32))
     take = lambda t: t.index_select(0, sel)  # noqa: E731
+    sel_ec = sel if ec_row is None else ec_row.index_select(0, sel)
+    take_ec = lambda t: t.index_select(0, sel_ec)  # noqa: E731
 
     def seg_mean_sel(q):   # mean of the chosen rows' Q per render, per chosen row
         s = torch.zeros(seg.R, device=q.device).index_add_(0, sel_seg, q.detach().view(-1))
@@ -369,7 +372,7 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
         q = take(Q)
         qm = seg_mean_sel(q)
         lo, hi = x_mean.detach() - 15_000 * qm, x_mean.detach() + 15_000 * qm
-        return pc.entropy_gaussian(take(x), take(mean), take(scale), q, x_mean, row_bounds=(lo, hi))
+        return pc.entropy_gaussian(take(x), take_ec(mean), take_ec(scale), q, x_mean, row_bounds=(lo, hi))
 
     bit_feat = bits_of(feat, ec.mean_feat, ec.scale_feat, Q_feat, pc._anchor_feat.mean())
     bit_scaling = bits_of(grid_scaling, ec.mean_scaling, ec.scale_scaling, Q_scaling, pc.get_scaling.mean())
@@ -384,6 +387,28 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
     kr = torch.stack([keep_rate[seg.bounds[r]] if seg.counts[r] else keep_rate.new_zeros(()) for r in range(seg.R)])
     return [RatePack(bit_per_param=((sf + ss + so) / (nf + ns + no) * kr)[r], bit_per_feat_param=(sf / nf * kr)[r],
                      bit_per_scaling_param=(ss / ns * kr)[r], bit_per_offsets_param=(so / no * kr)[r]) for r in range(seg.R)]
+
+
+def _entropy_context_distinct(pc, anchor_all, vis):
+    """Entropy context of the batch's rows, evaluated once per DISTINCT anchor.
+
+    The context (hash-grid lookup + the three EntropyParamsNets, reference scene/gaussian_model.py:1569-1597) is a
+    function of the anchor position only, and the renders of one step — two adjacent frames x two opposite views —
+    see almost the same anchors: the concatenated rows name each anchor ~4 times.  Evaluating the grid and the nets
+    on the distinct anchors and gathering rows from that (the per-row step sizes) or composing indices (the 5 % rate
+    sample) is the same arithmetic on a quarter of the rows; the gradients of the duplicates meet in the gathers'
+    backward.  Returns (context over the distinct anchors, row -> distinct index), or (context, None) when nothing
+    repeats."""
+    A = anchor_all.shape[0]
+    if vis.numel() == 0:
+        return pc.calc_entropy_context(anchor_all.index_select(0, vis)), None
+    present = torch.zeros(A, dtype=torch.bool, device=vis.device)
+    present[vis] = True
+    distinct = present.nonzero(as_tuple=False).squeeze(1)
+    if distinct.shape[0] == vis.shape[0]:
+        return pc.calc_entropy_context(anchor_all.index_select(0, vis)), None
+    pos = torch.cumsum(present, dim=0) - 1
+    return pc.calc_entropy_context(anchor_all.index_select(0, distinct)), pos.index_select(0, vis)
 
 
 def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False,
@@ -404,7 +429,8 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     seg = _Segments([v.shape[0] for v in vis_list], dev)
     with region('gen.gather'):
         vis = torch.cat(vis_list)
-        anchor = (pc.get_anchor if anchors is None else anchors).index_select(0, vis)
+        anchor_all = pc.get_anchor if anchors is None else anchors
+        anchor = anchor_all.index_select(0, vis)
         feat = pc._anchor_feat.index_select(0, vis)
         grid_offsets = pc._offset.index_select(0, vis)
         grid_scaling = _visible_scaling(pc, vis)
@@ -421,22 +447,25 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets, seg)
     elif mode == GenerateMode.TRAINING_ENTROPY:
         with region('gen.entropy_context'):
-            ec = pc.calc_entropy_context(anchor)
+            ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis)
         with region('gen.noise_quant'):
-            Q_feat, Q_scaling, Q_offsets = Q_feat * ec.Q_feat_adj, Q_scaling * ec.Q_scaling_adj, Q_offsets * ec.Q_offsets_adj
+            rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
+            Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj), Q_scaling * rows_of(ec.Q_scaling_adj),
+                                            Q_offsets * rows_of(ec.Q_offsets_adj))
             feat = _seg_noise_quant(feat, Q_feat, seg)
             grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
             grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets.unsqueeze(1), seg)
         with region('gen.rate'):
-            rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec)
+            rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row)
     elif mode == GenerateMode.TRAININ_STE_ENTROPY:
-        ec = pc.calc_entropy_context(anchor)
-        Q_feat, Q_scaling, Q_offsets = (Q_feat * ec.Q_feat_adj.detach(), Q_scaling * ec.Q_scaling_adj.detach(),
-                                        Q_offsets * ec.Q_offsets_adj.detach())
+        ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis)
+        rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
+        Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj).detach(), Q_scaling * rows_of(ec.Q_scaling_adj).detach(),
+                                        Q_offsets * rows_of(ec.Q_offsets_adj).detach())
         feat = _seg_ste(feat, Q_feat, seg, pc._anchor_feat.mean())
         grid_scaling = _seg_ste(grid_scaling, Q_scaling, seg, pc.get_scaling.mean())
         grid_offsets = _seg_ste(grid_offsets, Q_offsets.unsqueeze(1), seg, pc._offset.mean())
-        rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec)
+        rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row)
     else:
         raise ValueError(f"Unknown mode {mode}")
 
