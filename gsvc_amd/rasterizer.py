@@ -79,6 +79,7 @@ class RasterState:
         self.cs, self.P, self.max_instances = cs, P, max_instances
         self.geom, self.binning, self.image_state, self.radii = geom, binning, image_state, radii
         self._counters = None
+        self._host = self._event = None     # early asynchronous read-back of the counters (raster_forward, sync=False)
 
     def counters(self):
         """(num_rendered, overflow, num_visible, max_tile_len) — one 16-byte D2H copy (synchronises), cached."""
@@ -139,6 +140,13 @@ def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales,
                    "gsvc_raster_forward")
         state = RasterState(cs, P, max_instances, geom, binning, image_state, radii)
         if not sync:
+            # the counters are final once the forward kernels have run: their 16 bytes start travelling to the host
+            # now, behind the forward only, so that resolve_deferred() later waits for THIS copy and not for
+            # everything queued after it (the whole backward of a fitting step)
+            state._host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+            state._host.copy_(binning[:16].view(torch.int32), non_blocking=True)
+            state._event = torch.cuda.Event()
+            state._event.record()
             return image, radii, state
         n, overflow, _, _ = state.counters()
         if not overflow:
@@ -153,7 +161,12 @@ def resolve_deferred(states):
     forwards succeeds — their images (and anything computed from them) must be discarded."""
     if not states:
         return [], False
-    host = torch.stack([st.binning[:16].view(torch.int32) for st in states]).tolist()
+    if all(getattr(st, "_event", None) is not None for st in states):
+        for st in states:
+            st._event.synchronize()
+        host = [st._host.tolist() for st in states]
+    else:
+        host = torch.stack([st.binning[:16].view(torch.int32) for st in states]).tolist()
     over = False
     for st, c in zip(states, host):
         st._counters = tuple(int(v) for v in c)

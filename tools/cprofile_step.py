@@ -8,7 +8,7 @@ from gsvc_amd.model import GaussianModel
 from gsvc_amd.train import Trainer
 dev = torch.device("cuda")
 mp_, opt, pipe = cfg_20240919()
-cube = SyntheticFrameCube(1080, 1920, 64, device=dev)
+cube = SyntheticFrameCube(1080, 1920, 64, device=dev).materialize()
 mp_.threshold = 8.0 / cube.scale
 opt.full_precision_training_total = opt.quantized_training_total = 0
 opt.entropy_constrained_train_total = 10 ** 9

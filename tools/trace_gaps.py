@@ -2,7 +2,7 @@
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
-adam = [i for i, e in enumerate(ev) if 'FusedAdam' in e[2]]
+adam = [i for i, e in enumerate(ev) if 'FusedAdam' in e[2] or 'k_adam' in e[2]]
 ends = [i for j, i in enumerate(adam) if j + 1 == len(adam) or ev[adam[j + 1]][0] - ev[i][1] > 5_000_000]
 def short(n):
     m = re.search(r'(gsvc::k_\w+)', n)
