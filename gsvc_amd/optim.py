@@ -18,19 +18,28 @@ class FusedAdam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        entries, keep = [], []
-        beta_sets = set()
+        # host side kept short (this runs between the end of backward and the launch, with the GPU waiting): the step
+        # counters advance with one foreach call, the per-tensor table is a reused ctypes array written in place
+        keep, steps = [], []
+        beta_key = None
         dev = None
+        n = 0
+        arr = self._table
         for group in self.param_groups:
             if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
                 raise NotImplementedError("FusedAdam: weight_decay / amsgrad / maximize are not used by GSVC")
             b1, b2 = group["betas"]
-            beta_sets.add((float(b1), float(b2), float(group["eps"])))
+            key = (float(b1), float(b2), float(group["eps"]))
+            if beta_key is None:
+                beta_key = key
+            elif key != beta_key:
+                raise NotImplementedError("FusedAdam: one (betas, eps) for all groups")
             lr = float(group["lr"])
             for p in group["params"]:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue
-                if not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse:
+                if not p.is_cuda or p.dtype != torch.float32 or g.is_sparse:
                     raise _lib.GsvcError("FusedAdam updates dense float32 CUDA parameters (csrc/adam.hip)")
                 dev = p.device
                 st = self.state[p]
@@ -38,19 +47,33 @@ class FusedAdam(torch.optim.Adam):
                     st["step"] = torch.zeros((), dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                t = float(st["step"])
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                if not (p.is_contiguous() and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
+                m, v = st["exp_avg"], st["exp_avg_sq"]
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                if not (p.is_contiguous() and m.is_contiguous() and v.is_contiguous()):
                     raise _lib.GsvcError("FusedAdam: parameters and moments must be contiguous")
                 keep.append(g)
-                entries.append(_lib.AdamTensorC(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                                p.numel(), lr, 1.0 - b1 ** t, 1.0 - b2 ** t))
-        if not entries:
+                steps.append(st["step"])
+                if n == len(arr):
+                    arr = self._table = self._grow(arr)
+                e = arr[n]
+                e.param, e.grad, e.exp_avg, e.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+                e.n, e.lr = p.numel(), lr
+                n += 1
+        if n == 0:
             return loss
-        if len(beta_sets) != 1:
-            raise NotImplementedError("FusedAdam: one (betas, eps) for all groups")
-        b1, b2, eps = next(iter(beta_sets))
-        arr = (_lib.AdamTensorC * len(entries))(*entries)
-        _lib.check(_lib.lib().gsvc_adam_step(len(entries), arr, b1, b2, eps, _lib.current_stream(dev)), "gsvc_adam_step")
+        torch._foreach_add_(steps, 1)
+        b1, b2, eps = beta_key
+        for i, t in enumerate(torch.stack(steps).tolist()):     # host tensors: no device synchronisation
+            arr[i].bias_correction1, arr[i].bias_correction2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+        _lib.check(_lib.lib().gsvc_adam_step(n, arr, b1, b2, eps, _lib.current_stream(dev)), "gsvc_adam_step")
         return loss
+
+    _table = (_lib.AdamTensorC * 64)()
+
+    @staticmethod
+    def _grow(arr):
+        new = (_lib.AdamTensorC * (2 * len(arr)))()
+        for i in range(len(arr)):
+            new[i] = arr[i]
+        return new
