@@ -411,8 +411,16 @@ def _entropy_context_distinct(pc, anchor_all, vis):
     return pc.calc_entropy_context(anchor_all.index_select(0, distinct)), pos.index_select(0, vis)
 
 
+def generator_trunks(pc):
+    """Frame-independent half of the three generator MLPs for ALL anchors: ``linear2(GELU(linear1(anchor_feat)))``
+    (reference scene/gaussian_model.py:168-196 evaluates it per render).  Valid while the parameters do not change and
+    the generation mode leaves the features as stored (decoding): the decoder loop computes it once per video."""
+    with torch.no_grad():
+        return {name: getattr(pc, name).trunk(pc._anchor_feat) for name in ("get_opacity_mlp", "get_color_mlp", "get_cov_mlp")}
+
+
 def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False,
-                                   anchors=None):
+                                   anchors=None, trunks=None):
     """`generate_neural_gaussians` for R renders at once; returns a list of R GeneratedGaussians.
 
     ``dense=True`` skips the "opacity > 0" compaction: every visible anchor contributes all K Gaussians, ``mask``
@@ -477,9 +485,16 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
 
     rows = seg.rows
     with region('gen.mlps'):
-        op_raw = pc.get_opacity_mlp(feat, pe)
-        color = pc.get_color_mlp(feat, pe).reshape(rows * K, 3)
-        scale_rot = pc.get_cov_mlp(feat, pe).reshape(rows * K, 7)
+        if trunks is not None:      # decoding: the feature-only half of the generators was evaluated once for all anchors
+            if mode not in (GenerateMode.DECODING_AS_IS, GenerateMode.TRAINING_FULL_PRECISION):
+                raise ValueError("generator trunks are only valid when the features are used as stored")
+            op_raw = pc.get_opacity_mlp.head(trunks["get_opacity_mlp"].index_select(0, vis), pe)
+            color = pc.get_color_mlp.head(trunks["get_color_mlp"].index_select(0, vis), pe).reshape(rows * K, 3)
+            scale_rot = pc.get_cov_mlp.head(trunks["get_cov_mlp"].index_select(0, vis), pe).reshape(rows * K, 7)
+        else:
+            op_raw = pc.get_opacity_mlp(feat, pe)
+            color = pc.get_color_mlp(feat, pe).reshape(rows * K, 3)
+            scale_rot = pc.get_cov_mlp(feat, pe).reshape(rows * K, 7)
         neural_offset = pc.get_deform_mlp(torch.cat([feat, pe], dim=1)).reshape(rows * K, 3)
     if dense:
         # opacity mask, sigmoid scaling, normalised rotation, world position, bound clamp: one kernel (csrc/generate.hip)

@@ -179,9 +179,15 @@ class GeneratorNet(nn.Module):
         self.film = FiLM(condition_dim, inner_dim)
         self.out_act = nn.Identity() if out_act is None else out_act
 
-    def forward(self, feature, condition):
-        h = self.linear2(self.act(self.linear1(feature)))
+    def trunk(self, feature):
+        """The part that only sees the anchor feature (frame independent when the feature carries no noise)."""
+        return self.linear2(self.act(self.linear1(feature)))
+
+    def head(self, h, condition):
         return self.out_act(self.out_linear(self.film(h, condition)))
+
+    def forward(self, feature, condition):
+        return self.head(self.trunk(feature), condition)
 
 
 class EntropyParamsNet(nn.Module):

@@ -7,7 +7,7 @@ from __future__ import annotations
 import torch
 
 from ..common.base import RenderResults
-from ..generate import GenerateMode, generate_neural_gaussians, generate_neural_gaussians_many
+from ..generate import GenerateMode, generate_neural_gaussians, generate_neural_gaussians_many, generator_trunks
 from ..rasterizer import GaussianRasterizer, raster_forward, settings_to_c
 from .preprocess import prefilter_geometry, prefilter_voxel, raster_settings_for
 
@@ -119,12 +119,15 @@ def render_frames(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0
         if int(f.image_width) % 16 != 0:
             raise ValueError("render_frames: the two-view pass needs an image width that is a multiple of 16 (use render_pair)")
     with torch.no_grad():
+        # the generators' feature-only half does not depend on the frame: once per call for all anchors
+        trunks = generator_trunks(pc) if mode in (GenerateMode.DECODING_AS_IS, GenerateMode.TRAINING_FULL_PRECISION) else None
         for i in range(0, len(frames), batch):
             chunk = frames[i:i + batch]
             while True:
                 geometry = prefilter_geometry(pc)
                 visible = [prefilter_voxel(f, pc, pipe, bg_color, geometry=geometry) for f in chunk]
-                gss_list = generate_neural_gaussians_many(chunk, pc, visible, mode, dense=True, anchors=geometry[0])
+                gss_list = generate_neural_gaussians_many(chunk, pc, visible, mode, dense=True, anchors=geometry[0],
+                                                          trunks=trunks)
                 images, states = [], []
                 for f, gss in zip(chunk, gss_list):
                     cs = settings_to_c(raster_settings_for(f, pc, pipe, bg_color, scaling_modifier))
