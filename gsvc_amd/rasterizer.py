@@ -112,10 +112,11 @@ _capacity_hint = {}
 
 
 def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales, rotations, max_instances=None,
-                   sync=True, pair=False):
+                   sync=True, pair=False, readback=False):
     """Launch the forward pipeline.  Returns (image, radii, state).  With ``sync`` the instance counters
     are read back (16 B) and the call is repeated with a larger instance capacity if it overflowed; without
-    it the caller must check ``state.counters()[1]`` itself.  ``pair=True`` returns the two-view frame
+    it the caller must check ``state.counters()[1]`` itself (``readback``: the counters' copy to the host is queued right
+    behind the forward, for resolve_deferred()).  ``pair=True`` returns the two-view frame
     (render(view) + flip(render(opposite view))) / 2 from one pass (inference only, see gsvc_raster_forward_pair)."""
     L = _lib.lib()
     P = int(means3D.shape[0])
@@ -139,7 +140,7 @@ def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales,
                                          _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(binning), _lib.ptr(image_state), stream),
                    "gsvc_raster_forward")
         state = RasterState(cs, P, max_instances, geom, binning, image_state, radii)
-        if not sync:
+        if not sync and readback:
             # the counters are final once the forward kernels have run: their 16 bytes start travelling to the host
             # now, behind the forward only, so that resolve_deferred() later waits for THIS copy and not for
             # everything queued after it (the whole backward of a fitting step)
@@ -147,6 +148,7 @@ def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales,
             state._host.copy_(binning[:16].view(torch.int32), non_blocking=True)
             state._event = torch.cuda.Event()
             state._event.record()
+        if not sync:
             return image, radii, state
         n, overflow, _, _ = state.counters()
         if not overflow:
@@ -181,7 +183,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, cs, holder, sync=True):
         means3D, colors = _as_f32(means3D, "means3D"), _as_f32(colors, "colors_precomp")
         opacities, scales, rotations = _as_f32(opacities, "opacities"), _as_f32(scales, "scales"), _as_f32(rotations, "rotations")
-        image, radii, state = raster_forward(cs, means3D, colors, opacities, scales, rotations, sync=sync)
+        image, radii, state = raster_forward(cs, means3D, colors, opacities, scales, rotations, sync=sync, readback=not sync)
         ctx.state = state
         ctx.save_for_backward(means3D, colors, opacities, scales, rotations)
         ctx.mark_non_differentiable(radii)
