@@ -7,9 +7,9 @@ Mirrors reference utils/entropy_models.py:32-68 (``EntropyGaussian``) and :159-1
 with x first clamped to ``x_mean -+ 15000 * mean(Q)``.  The whole chain (clamp, two normal CDFs, subtract,
 lower bound, -log2) and its analytic backward — including the net Low_bound rule "gradient passes only where
 the likelihood is >= 2^-16", which the reference evaluates through a NumPy round trip on the host — run as
-one fused HIP kernel each way.  ``quantized=True`` (used only by the offline codec's bit accounting) and the
-never-instantiated Entropy_gaussian_clamp / Entropy_bernoulli / Entropy_factorized / UniverseQuant are out
-of scope.
+one fused HIP kernel each way.  ``quantized=True`` (bit accounting of quantised symbols) scales
+the model to symbol units and runs through the same kernel without a clamp.  The never-instantiated
+Entropy_gaussian_clamp / Entropy_bernoulli / Entropy_factorized / UniverseQuant are out of scope.
 """
 from __future__ import annotations
 
@@ -79,10 +79,16 @@ class EntropyGaussian(nn.Module):
     def forward(self, x, mean, scale, Q=None, x_mean=None, quantized=False, row_bounds=None):
         """``row_bounds=(lo[n], hi[n])`` replaces the clamp bounds computed from x_mean / mean(Q) by one pair per
         row (used when several renders are batched into one call; each row carries its own render's bounds)."""
-        if quantized:
-            raise NotImplementedError("quantized=True is only used by the offline codec's bit accounting (out of scope)")
         if Q is None:
             Q = self.Q
+        if quantized:
+            # bit accounting of already quantised symbols (reference utils/entropy_models.py:56-59): the model is scaled
+            # to symbol units, N(mean / Q, scale / Q) over [x - 1/2, x + 1/2], and nothing is clamped
+            if row_bounds is not None:
+                raise ValueError("quantized=True takes no clamp bounds")
+            inf = torch.full((1,), float("inf"), device=x.device)
+            return self.forward(x, mean / Q, scale / Q, Q=1.0, row_bounds=(-inf.expand(x.reshape(-1, x.shape[-1]).shape[0]),
+                                                                           inf.expand(x.reshape(-1, x.shape[-1]).shape[0])))
         if not x.is_cuda:
             raise _lib.GsvcError("EntropyGaussian runs on the HIP kernels of csrc/rate.hip; CPU tensors are not supported")
         shape = x.shape

@@ -43,6 +43,30 @@ class EntropyContext:
     Q_offsets_adj: torch.Tensor
 
 
+@dataclass
+class BitInfo:
+    """Estimated size of the coded model in bits, per stream (reference scene/gaussian_model.py:55-65)."""
+    bit_anchor: int
+    bit_anchor_gpcc: int
+    bit_feat: int
+    bit_scaling: int
+    bit_offsets: int
+    bit_hash: int
+    bit_masks: int
+    bit_mlp: int
+    bit_mlp_encoded: int
+
+
+BIT2MB_SCALE = 8 * 1024 * 1024
+
+
+def calc_symbol_min_max(x_mean, Q, bound=15000):
+    """Symbol range of a quantised attribute: mean / mean step -+ 15000, truncated (reference :236-239)."""
+    x_min = x_mean.mean() / Q.mean() - bound
+    x_max = x_mean.mean() / Q.mean() + bound
+    return int(x_min), int(x_max)
+
+
 class Mix3d2dEncoding(nn.Module):
     """One 3-D hash grid on (x,y,z) plus three 2-D grids on (x,y), (x,z), (y,z); outputs concatenated."""
 
@@ -383,6 +407,48 @@ class GaussianModel(nn.Module):
         adj = lambda q: torch.exp(torch.clamp(q, min=-10, max=10))  # noqa: E731
         return EntropyContext(mean_f, torch.clamp(scale_f, 1e-9), mean_s, torch.clamp(scale_s, 1e-9),
                               mean_o, torch.clamp(scale_o, 1e-9), adj(q_f), adj(q_s), adj(q_o))
+
+    # ------------------------------------------------------------------ bit accounting
+    def get_mlp_size(self, digit=32):
+        n = sum(p.numel() for name, p in self.named_parameters() if "mlp" in name)
+        return n * digit, n * digit / 8 / 1024 / 1024
+
+    @torch.no_grad()
+    def estimate_final_bits(self):
+        """Size the codec would produce, from the entropy model alone: anchors kept by the mask, attributes rounded to
+        their context-scaled steps and priced by the Gaussian model in symbol units, Bernoulli code length of the
+        binarised hash tables and of the offset masks, raw MLP weights.  Same arithmetic and order as reference
+        scene/gaussian_model.py:1599-1725; returns (log line, BitInfo)."""
+        from .encodings import ANCHOR_ROUND_DIGITS, STE_multistep, get_binary_vxl_size
+        K = self.n_offsets
+        keep = self.get_mask_anchor
+        anchor = self.get_anchor[keep]
+        feat, offsets, scaling, mask = self._anchor_feat[keep], self._offset[keep], self.get_scaling[keep], self.get_mask[keep]
+        ec = self.calc_entropy_context(anchor)
+        Q_feat, Q_scaling, Q_offsets = 1 * ec.Q_feat_adj, 0.001 * ec.Q_scaling_adj, 0.2 * ec.Q_offsets_adj
+        feat_min, feat_max = calc_symbol_min_max(ec.mean_feat, Q_feat)
+        scaling_min, scaling_max = calc_symbol_min_max(ec.mean_scaling, Q_scaling)
+        offsets_min, offsets_max = calc_symbol_min_max(ec.mean_offsets, Q_offsets)
+        q_feat = STE_multistep.quantize(feat, Q_feat, feat_min, feat_max)
+        q_scaling = STE_multistep.quantize(scaling, Q_scaling, scaling_min, scaling_max)
+        q_offsets = STE_multistep.quantize(offsets, Q_offsets.unsqueeze(1), offsets_min, offsets_max).view(-1, 3 * K)
+        mask3 = mask.repeat(1, 1, 3).view(-1, 3 * K)
+        bit_feat = self.entropy_gaussian(q_feat, ec.mean_feat, ec.scale_feat, Q_feat, quantized=True)
+        bit_scaling = self.entropy_gaussian(q_scaling, ec.mean_scaling, ec.scale_scaling, Q_scaling, quantized=True)
+        bit_offsets = self.entropy_gaussian(q_offsets, ec.mean_offsets, ec.scale_offsets, Q_offsets, quantized=True) * mask3
+        bit_anchor = anchor.shape[0] * 3 * ANCHOR_ROUND_DIGITS
+        bit_feat, bit_scaling, bit_offsets = bit_feat.sum().item(), bit_scaling.sum().item(), bit_offsets.sum().item()
+        tables = self.get_encoding_params()
+        bit_hash = get_binary_vxl_size((tables + 1) / 2)[1].item() if self.ste_binary else tables.numel() * 32
+        bit_masks = get_binary_vxl_size(mask)[1].item()
+        bit_mlp = self.get_mlp_size()[0]
+        info = BitInfo(bit_anchor, bit_anchor / 2, bit_feat, bit_scaling, bit_offsets, bit_hash, bit_masks, bit_mlp,
+                       int(bit_mlp * 0.3))
+        mb = lambda b: round(b / BIT2MB_SCALE, 4)  # noqa: E731
+        total = bit_anchor + bit_feat + bit_scaling + bit_offsets + bit_hash + bit_masks + bit_mlp
+        log = (f"Estimated sizes in MB: anchor {mb(bit_anchor)}, feat {mb(bit_feat)}, scaling {mb(bit_scaling)}, "
+               f"offsets {mb(bit_offsets)}, hash {mb(bit_hash)}, masks {mb(bit_masks)}, MLPs {mb(bit_mlp)}, Total {mb(total)}")
+        return log, info
 
     # ------------------------------------------------------------------ initialisation (reference :748-800)
     def voxelize_sample(self, data, voxel_size=0.01):

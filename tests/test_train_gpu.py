@@ -352,3 +352,33 @@ def test_fused_noise_quant_matches_torch(per_row_q):
     if per_row_q:
         # inside the window autograd's dQ is a rounding residue of x/Q - x/Q: compare on the scale of the noise term
         assert (gq - Q.grad).abs().max().item() <= 1e-3 * Q.grad.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_estimate_final_bits_matches_reference():
+    """Bit accounting against the reference's own estimate_final_bits on the same tiny model
+    (tests/golden/make_golden_bits.py; the reference ran on CPU with the grid oracle behind it)."""
+    import os
+    import numpy as np
+    from gsvc_amd.arguments import ModelParams
+    from gsvc_amd.model import GaussianModel
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g, b = np.load(os.path.join(here, "tiny_model.npz")), np.load(os.path.join(here, "final_bits.npz"))
+    dev = torch.device("cuda")
+    pc = GaussianModel(ModelParams(), feat_dim=8, n_offsets=4, voxel_size=0.001, update_depth=3, update_init_factor=16,
+                       update_hierachy_factor=4, use_feat_bank=False, n_features_per_level=2, log2_hashmap_size=9,
+                       log2_hashmap_size_2D=11, resolutions_list=(18, 24, 33), resolutions_list_2D=(130, 258), device=dev)
+    sd = {k[4:]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith("sd::")}
+    for nm in ("_anchor", "_offset", "_mask", "_anchor_feat", "_scaling", "_rotation", "_opacity"):
+        sd[nm] = torch.from_numpy(np.array(b["in::" + nm]))
+        setattr(pc, nm, torch.nn.Parameter(sd[nm].clone().to(dev), requires_grad=nm not in ("_rotation", "_opacity")))
+    pc.load_state_dict(sd, strict=True)
+    pc.to(dev)
+    pc.update_anchor_bound(float(g["x_lim"]), float(g["y_lim"]), float(g["z_lim"]))
+    log, info = pc.estimate_final_bits()
+    for f in ("bit_anchor", "bit_anchor_gpcc", "bit_mlp", "bit_mlp_encoded"):
+        assert float(getattr(info, f)) == float(b["bits::" + f]), f
+    for f in ("bit_feat", "bit_scaling", "bit_offsets", "bit_hash", "bit_masks"):
+        ref = float(b["bits::" + f])
+        assert abs(float(getattr(info, f)) - ref) <= 2e-5 * abs(ref) + 1e-3, (f, getattr(info, f), ref)
+    assert log == str(b["log_info"])
