@@ -266,6 +266,29 @@ typedef struct gsvc_adam_tensor {
 int gsvc_adam_step(int32_t n_tensors, const gsvc_adam_tensor *tensors_host, double beta1, double beta2, double eps, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Entropy coding of quantised attributes with the learned Gaussian model (replaces the external
+ * gsvc_cuda_ans.ANSCoder the reference calls through utils/encodings.py:102-245 encoder_gaussian / decoder_gaussian:
+ * integer symbols in [min_symbol, max_symbol], one Normal(mu, sigma) per symbol in symbol units).
+ * rANS, 20-bit frequencies from the model itself (no tables), independent segments of seg_len symbols; the byte layout
+ * is this library's own (the reference's coder is not in its tree): segment k = bytes [seg_offsets[k], seg_offsets[k+1]).
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* number of segments / bytes of encode scratch for n symbols */
+int64_t gsvc_ans_segments(int64_t n, int32_t seg_len);
+int64_t gsvc_ans_scratch_bytes(int64_t n, int32_t seg_len);
+
+/* symbols[n] (device, int32) -> out (device; capacity gsvc_ans_scratch_bytes is always enough), seg_bytes[segments]
+ * (uint32), seg_offsets[segments + 1] (uint64, seg_offsets[segments] = total bytes).  error_flag (device int32, zeroed by
+ * the caller) becomes non-zero if a symbol lies outside [min_symbol, max_symbol]. */
+int gsvc_ans_encode(const int32_t *symbols, const float *mu, const float *sigma, int64_t n, int32_t min_symbol,
+                    int32_t max_symbol, int32_t seg_len, void *scratch, uint32_t *seg_bytes, uint64_t *seg_offsets, uint8_t *out,
+                    int32_t *error_flag, void *stream);
+
+/* inverse: bytes + seg_offsets[segments + 1] + the same mu, sigma -> symbols[n].  error_flag non-zero: corrupt stream. */
+int gsvc_ans_decode(const uint8_t *bytes, const uint64_t *seg_offsets, const float *mu, const float *sigma, int64_t n,
+                    int32_t min_symbol, int32_t max_symbol, int32_t seg_len, int32_t *symbols, int32_t *error_flag, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Linear layers of the generator / deformation / entropy-parameter MLPs (reference scene/gaussian_model.py:
  * 150-232: every nn.Linear applied to the [anchors, features] matrix)
  * ---------------------------------------------------------------------------------------------------- */
