@@ -1,0 +1,236 @@
+"""Stream encoding / decoding of a fitted model: anchors ordered by z and cut into slabs, the
+three attribute streams of every slab entropy-coded with the context model, the offset masks and the binarised hash
+tables coded with their Bernoulli probability.
+
+Follows reference scene/gaussian_model.py:2313-2804 (``conduct_stream_encoding`` / ``conduct_stream_decoding``) and
+utils/encodings.py:827-862 (``reorder_and_split``) in what is coded, in which order and with which model; what differs:
+
+* the entropy coder is this library's rANS (csrc/ans.hip) — the reference's ``gsvc_cuda_ans`` / ``torchac`` are external
+  packages whose sources are not in its tree — and the streams live in one in-memory ``StreamPack`` (``save`` / ``load``
+  write the reference's file names: ``feat_{s}.b``, ``scaling_{s}.b``, ``offsets_{s}.b``, ``masks.b``, ``hash.b``);
+* binary symbols (masks, hash tables) go through the same coder as a two-symbol alphabet whose model is a unit-range
+  Gaussian placed so that P(0) = 1 - p;
+* anchor geometry: the reference hands the 16-bit anchor grid to MPEG G-PCC (``tmc3``, an external executable); here the
+  quantised anchors are stored raw (3 x uint16 per anchor, in the (x, y, z)-sorted order G-PCC would return);
+* MLP weights are carried as they are (the reference's 8-bit weight quantisation + Huffman stage is not built).
+
+Everything runs on the device except the byte containers.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .codec import ans_decode, ans_encode, decoder_gaussian, encoder_gaussian
+from .encodings import ANCHOR_ROUND_DIGITS, Quantize_anchor, STE_multistep
+from .model import calc_symbol_min_max
+
+BASE_Q = (1.0, 0.001, 0.2)      # feature, scaling, offsets (reference scene/gaussian_model.py:2352-2354)
+
+
+def _lexsort(cols):
+    """Indices that sort rows by cols[0], then cols[1], ... (stable sorts from the last key to the first)."""
+    order = torch.arange(cols[0].shape[0], device=cols[0].device)
+    for c in reversed(cols):
+        order = order[torch.sort(c[order], stable=True).indices]
+    return order
+
+
+def reorder_and_split(anchor, interval=0.01):
+    """Order anchors by (z, x, y) and cut the order into z slabs of ``interval`` (reference utils/encodings.py:827-862).
+    Returns (selection, [(start, end), ...]); slabs without an anchor are left out (the reference assumes there are none)."""
+    sel = _lexsort([anchor[:, 2], anchor[:, 0], anchor[:, 1]])
+    z = anchor[sel, 2]
+    z_min, z_max = z.min(), z.max()
+    assert z_min < 0 and z_max > 0
+    # slab k = [lb + k * interval, lb + (k + 1) * interval), lb = -ceil(|z_min| / interval) * interval; the reference steps a
+    # float32 accumulator (lb += interval), whose rounding can end the walk one slab early and drop that slab's
+    # anchors — here the slab index of every anchor is computed directly, so the slabs always cover all anchors
+    lb = -float(torch.ceil(z_min.abs().double() / interval)) * interval
+    k = torch.floor((z.double() - lb) / interval).to(torch.int64)        # non-decreasing along the z order
+    change = torch.ones_like(k, dtype=torch.bool)
+    change[1:] = k[1:] != k[:-1]
+    starts = change.nonzero(as_tuple=False).squeeze(1).tolist()
+    splits = [(a, b) for a, b in zip(starts, starts[1:] + [int(z.shape[0])])]
+    return sel, splits
+
+
+def _bernoulli_model(n, p_one, device):
+    """Unit-range Gaussian whose mass below 1/2 is P(symbol 0) = 1 - p_one (symbols {0, 1}, range [0, 1])."""
+    p0 = min(max(1.0 - float(p_one), 1e-6), 1.0 - 1e-6)
+    z = float(torch.special.ndtri(torch.tensor(p0, dtype=torch.float64)))
+    if abs(z) < 1e-9:
+        mu, sigma = 0.5, 1.0                                   # p = 1/2
+    elif z > 0:
+        mu, sigma = 0.0, 0.5 / z                               # Phi((1/2 - 0) / sigma) = p0
+    else:
+        mu, sigma = 1.0, 0.5 / (-z)                            # Phi((1/2 - 1) / sigma) = Phi(z) = p0
+    return torch.full((n,), mu, device=device), torch.full((n,), sigma, device=device)
+
+
+def encode_binary(x01, p_one):
+    """{0,1} tensor -> stream at ~H(p_one) bits per element (reference utils/encodings.py:265-287 `encode_binary`)."""
+    sym = (x01.reshape(-1) > 0.5).to(torch.int32)      # get_mask's straight-through form can hold 0.99999994 for "one"
+    mu, sigma = _bernoulli_model(sym.numel(), p_one, sym.device)
+    return ans_encode(sym, mu, sigma, 0, 1)
+
+
+def decode_binary(stream, n, p_one, device):
+    mu, sigma = _bernoulli_model(n, p_one, device)
+    return ans_decode(stream, mu, sigma)
+
+
+@dataclass
+class StreamPack:
+    n_full: int
+    n: int
+    anchor_interval: np.ndarray
+    anchor_min: np.ndarray
+    anchors_q: np.ndarray                    # uint16 [n, 3], (x, y, z)-sorted
+    prob_masks: float
+    prob_hash: float
+    slabs: list = field(default_factory=list)            # [(start, end)] in z order
+    feat: list = field(default_factory=list)             # one stream per slab
+    scaling: list = field(default_factory=list)
+    offsets: list = field(default_factory=list)
+    masks: bytes = b""
+    hash: bytes = b""
+
+    def bits(self):
+        """Coded size per stream in bits (same keys as BitInfo where they exist)."""
+        return {"bit_anchor": self.anchors_q.size * ANCHOR_ROUND_DIGITS, "bit_feat": 8 * sum(map(len, self.feat)),
+                "bit_scaling": 8 * sum(map(len, self.scaling)), "bit_offsets": 8 * sum(map(len, self.offsets)),
+                "bit_masks": 8 * len(self.masks), "bit_hash": 8 * len(self.hash)}
+
+    def save(self, path):
+        os.makedirs(path, exist_ok=True)
+        for s in range(len(self.slabs)):
+            for name, streams in (("feat", self.feat), ("scaling", self.scaling), ("offsets", self.offsets)):
+                with open(os.path.join(path, f"{name}_{s}.b"), "wb") as f:
+                    f.write(streams[s])
+        for name, blob in (("masks.b", self.masks), ("hash.b", self.hash)):
+            with open(os.path.join(path, name), "wb") as f:
+                f.write(blob)
+        self.anchors_q.tofile(os.path.join(path, "anchor_q16.bin"))
+        meta = {k: getattr(self, k) for k in ("n_full", "n", "anchor_interval", "anchor_min", "prob_masks", "prob_hash", "slabs")}
+        with open(os.path.join(path, "meta.pkl"), "wb") as f:
+            pickle.dump(meta, f)
+
+    @classmethod
+    def load(cls, path):
+        with open(os.path.join(path, "meta.pkl"), "rb") as f:
+            meta = pickle.load(f)
+        pack = cls(anchors_q=np.fromfile(os.path.join(path, "anchor_q16.bin"), dtype=np.uint16).reshape(-1, 3), **meta)
+        rd = lambda name: open(os.path.join(path, name), "rb").read()  # noqa: E731
+        for s in range(len(pack.slabs)):
+            pack.feat.append(rd(f"feat_{s}.b")); pack.scaling.append(rd(f"scaling_{s}.b")); pack.offsets.append(rd(f"offsets_{s}.b"))
+        pack.masks, pack.hash = rd("masks.b"), rd("hash.b")
+        return pack
+
+
+def _slab_model(pc, anchor):
+    """Context of one slab: per-element mean / scale / step of the three attribute groups."""
+    ec = pc.calc_entropy_context(anchor)
+    Q = [BASE_Q[0] * ec.Q_feat_adj, BASE_Q[1] * ec.Q_scaling_adj, BASE_Q[2] * ec.Q_offsets_adj]
+    means = [ec.mean_feat, ec.mean_scaling, ec.mean_offsets]
+    scales = [ec.scale_feat, ec.scale_scaling, ec.scale_offsets]
+    return [(m.contiguous(), s.contiguous(), q.repeat(1, m.shape[-1])) for m, s, q in zip(means, scales, Q)]
+
+
+@torch.no_grad()
+def conduct_stream_encoding(pc) -> StreamPack:
+    K = pc.n_offsets
+    keep = pc.get_mask_anchor
+    q_anchor, interval, a_min = pc.quantized_anchor
+    q_anchor = q_anchor[keep]
+    # the order a geometry codec returns the points in: sorted by (x, y, z) (reference utils/encodings.py:753-757)
+    sel = _lexsort([q_anchor[:, 0], q_anchor[:, 1], q_anchor[:, 2]])
+    anchors_q = q_anchor[sel].to(torch.int32).cpu().numpy().astype(np.uint16)
+    anchor = pc.get_anchor[keep][sel]
+    feat, offsets = pc._anchor_feat[keep][sel], pc._offset[keep][sel]
+    scaling, mask = pc.get_scaling[keep][sel], pc.get_mask[keep][sel]
+    z_order, slabs = reorder_and_split(anchor)
+    anchor, feat, offsets, scaling, mask = anchor[z_order], feat[z_order], offsets[z_order], scaling[z_order], mask[z_order]
+    # symbol ranges from the context of ALL kept anchors (reference :2356-2364)
+    ec = pc.calc_entropy_context(anchor)
+    ranges = [calc_symbol_min_max(ec.mean_feat, BASE_Q[0] * ec.Q_feat_adj), calc_symbol_min_max(ec.mean_scaling, BASE_Q[1] * ec.Q_scaling_adj),
+              calc_symbol_min_max(ec.mean_offsets, BASE_Q[2] * ec.Q_offsets_adj)]
+    N = anchor.shape[0]
+    tables = pc.get_encoding_params()                          # {-1, +1}
+    prob_hash = float((((tables + 1) / 2).sum() / tables.numel()).item())
+    prob_masks = float((mask.sum() / mask.numel()).item())
+    pack = StreamPack(n_full=int(pc._anchor.shape[0]), n=N, anchor_interval=interval.cpu().numpy(), anchor_min=a_min.cpu().numpy(),
+                      anchors_q=anchors_q, prob_masks=prob_masks, prob_hash=prob_hash, slabs=list(slabs))
+    for a, b in slabs:
+        (mf, sf, qf), (ms, ss, qs), (mo, so, qo) = _slab_model(pc, anchor[a:b])
+        x = STE_multistep.quantize(feat[a:b], qf, *ranges[0])
+        pack.feat.append(encoder_gaussian(x, mf, sf, qf, *ranges[0])[3])
+        x = STE_multistep.quantize(scaling[a:b], qs, *ranges[1])
+        pack.scaling.append(encoder_gaussian(x, ms, ss, qs, *ranges[1])[3])
+        m3 = mask[a:b].repeat(1, 1, 3).view(-1, 3 * K).to(torch.bool)
+        x = STE_multistep.quantize(offsets[a:b].view(-1, 3 * K), qo, *ranges[2])
+        pack.offsets.append(encoder_gaussian(x[m3], mo[m3], so[m3], qo[m3], *ranges[2])[3] if bool(m3.any()) else b"")
+    pack.masks = encode_binary(mask, prob_masks)
+    pack.hash = encode_binary((tables + 1) / 2, prob_hash)
+    return pack
+
+
+@torch.no_grad()
+def conduct_stream_decoding(pc, pack: StreamPack):
+    """Replace the model's anchors, attributes, masks and hash tables by the decoded ones (``decoded_version`` = True);
+    the MLP weights of ``pc`` must be the encoder's."""
+    dev, K = pc._anchor.device, pc.n_offsets
+    q = torch.from_numpy(pack.anchors_q.astype(np.float32)).to(dev)
+    anchor = Quantize_anchor.dequantized(q, torch.from_numpy(pack.anchor_interval).to(dev), torch.from_numpy(pack.anchor_min).to(dev))
+    z_order, slabs = reorder_and_split(anchor)
+    if list(slabs) != [tuple(s) for s in pack.slabs]:
+        raise RuntimeError("stream decoding: the slab split of the decoded anchors differs from the encoder's")
+    anchor = anchor[z_order]
+    N = pack.n
+    mask = decode_binary(pack.masks, N * K, pack.prob_masks, dev).to(torch.float32).view(N, K, 1)
+    tables = pc.get_encoding_params()
+    hash01 = decode_binary(pack.hash, tables.numel(), pack.prob_hash, dev).to(torch.float32)
+    hash_pm = (hash01 * 2 - 1).view(-1, tables.shape[1])
+    _install_tables(pc, hash_pm)                                  # the context model reads the decoded tables
+    feats, scalings, offsets = [], [], []
+    for s, (a, b) in enumerate(slabs):
+        (mf, sf, qf), (ms, ss, qs), (mo, so, qo) = _slab_model(pc, anchor[a:b])
+        feats.append(decoder_gaussian(mf, sf, qf, stream=pack.feat[s]))
+        scalings.append(decoder_gaussian(ms, ss, qs, stream=pack.scaling[s]))
+        m3 = mask[a:b].repeat(1, 1, 3).view(-1, 3 * K).to(torch.bool)
+        off = torch.zeros_like(mo)
+        if bool(m3.any()):
+            off[m3] = decoder_gaussian(mo[m3], so[m3], qo[m3], stream=pack.offsets[s])
+        offsets.append(off.view(-1, K, 3))
+    Nf = pack.n_full
+
+    def full(rows, *shape):
+        t = torch.zeros((Nf,) + shape, device=dev)
+        t[:N] = rows
+        return nn.Parameter(t)
+
+    pc._anchor_feat = full(torch.cat(feats), pc.feat_dim)
+    pc._offset = full(torch.cat(offsets), K, 3)
+    pc.decoded_version = True
+    pc._anchor = full(anchor, 3)
+    pc._scaling = full(torch.cat(scalings), 6)
+    pc._mask = full(mask, K, 1)
+    return pc
+
+
+def _install_tables(pc, hash_pm):
+    enc = pc.encoding_xyz
+    if pc.use_2D:
+        parts = [enc.encoding_xyz, enc.encoding_xy, enc.encoding_xz, enc.encoding_yz]
+    else:
+        parts = [enc]
+    at = 0
+    for g in parts:
+        n = g.params.shape[0]
+        g.params = nn.Parameter(hash_pm[at:at + n].clone())
+        at += n

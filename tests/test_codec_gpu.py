@@ -94,3 +94,99 @@ def test_encoder_decoder_gaussian_interface():
     assert torch.equal(back, x * Q)
     est = EntropyGaussian()(x, mean, scale, Q[:, :1], quantized=True).sum().item()
     assert abs(bits - est) <= 0.015 * est, (bits, est)
+
+
+def _fitted_like_model(dev, anchors=20000):
+    """A model whose attributes, masks and context nets are away from their initial values (no training needed)."""
+    import numpy as np
+    from gsvc_amd.arguments import cfg_20240919
+    from gsvc_amd.frame import SyntheticFrameCube
+    from gsvc_amd.model import GaussianModel
+    mp_, opt, pipe = cfg_20240919()
+    cube = SyntheticFrameCube(256, 256, 64, device=dev)
+    mp_.threshold = 8.0 / cube.scale
+    pc = GaussianModel(mp_, 50, 10, 0.001, 3, 16, 4, False, n_features_per_level=8, log2_hashmap_size=13, log2_hashmap_size_2D=15,
+                       device=dev)
+    rng = np.random.default_rng(5)
+    lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.05
+    pc.create_from_points(rng.uniform(lim, -lim, (anchors, 3)), 1.0)
+    pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+    g = torch.Generator(device=dev).manual_seed(17)
+    with torch.no_grad():
+        pc._anchor_feat.add_(torch.randn(pc._anchor_feat.shape, device=dev, generator=g) * 2.0)
+        pc._offset.add_(torch.randn(pc._offset.shape, device=dev, generator=g) * 0.7)
+        pc._scaling.add_(torch.randn(pc._scaling.shape, device=dev, generator=g) * 0.2)
+        pc._mask.copy_(torch.randn(pc._mask.shape, device=dev, generator=g) * 4.0)
+        pc._mask[::11] = -9.0                       # anchors without a live offset are not coded
+        for net in (pc.mlp_feature_enet, pc.mlp_scaling_enet, pc.mlp_offset_enet):
+            for p in net.parameters():
+                p.add_(torch.randn(p.shape, device=dev, generator=g) * 0.02)
+        # features and offsets drawn from the context model itself (a fitted model is calibrated: without this most
+        # symbols would sit beyond the estimator's 2^-16 likelihood floor, which the coder prices at 20 bits, not 16)
+        ec = pc.calc_entropy_context(pc.get_anchor)
+        pc._anchor_feat.copy_(ec.mean_feat + ec.scale_feat * torch.randn(ec.mean_feat.shape, device=dev, generator=g))
+        off = ec.mean_offsets + ec.scale_offsets * torch.randn(ec.mean_offsets.shape, device=dev, generator=g)
+        pc._offset.copy_(off.view(pc._offset.shape))
+    return pc, cube, pipe
+
+
+def test_stream_encode_decode_round_trip(tmp_path):
+    """Model -> slab streams -> model: anchors, masks and hash tables come back exactly, every attribute comes back as its
+    quantised value, the coded sizes agree with estimate_final_bits, the pack survives its files."""
+    import copy
+    from gsvc_amd.encodings import STE_multistep
+    from gsvc_amd.model import calc_symbol_min_max
+    from gsvc_amd.stream_codec import BASE_Q, StreamPack, conduct_stream_decoding, conduct_stream_encoding, reorder_and_split, _lexsort
+    dev = torch.device("cuda")
+    pc, cube, pipe = _fitted_like_model(dev)
+    log, info = pc.estimate_final_bits()
+    pack = conduct_stream_encoding(pc)
+    pack.save(str(tmp_path))
+    pack = StreamPack.load(str(tmp_path))
+    bits = pack.bits()
+    per_stream = 8 * 128                      # header + size table + final states of a slab's stream, in bits
+    n_streams = {"bit_feat": len(pack.feat), "bit_offsets": len(pack.offsets), "bit_hash": 1, "bit_masks": 1}
+    for k in ("bit_feat", "bit_offsets", "bit_hash", "bit_masks"):
+        est = float(getattr(info, k))
+        assert -0.02 * est - 64 <= bits[k] - est <= 0.02 * est + n_streams[k] * per_stream + 8 * 9 * (est / 8 / 4096 + 1), (k, bits[k], est)
+    # the scalings of this synthetic model are NOT calibrated: symbols beyond the estimator's 2^-16 floor cost the coder
+    # up to 20 bits instead of 16
+    assert 0.98 * float(info.bit_scaling) <= bits["bit_scaling"] <= 1.3 * float(info.bit_scaling) + 4096
+    # expected decoded tensors, from the encoder-side model
+    K = pc.n_offsets
+    with torch.no_grad():
+        keep = pc.get_mask_anchor
+        q_anchor = pc.quantized_anchor[0][keep]
+        sel = _lexsort([q_anchor[:, 0], q_anchor[:, 1], q_anchor[:, 2]])
+        anchor = pc.get_anchor[keep][sel]
+        z_order, slabs = reorder_and_split(anchor)
+        anchor = anchor[z_order]
+        pick = lambda t: t[keep][sel][z_order]  # noqa: E731
+        feat, offsets, scaling, mask = pick(pc._anchor_feat), pick(pc._offset), pick(pc.get_scaling), (pick(pc.get_mask) > 0.5).float()
+        tables = pc.get_encoding_params().clone()
+        ec = pc.calc_entropy_context(anchor)
+        rf = calc_symbol_min_max(ec.mean_feat, BASE_Q[0] * ec.Q_feat_adj)
+        rs = calc_symbol_min_max(ec.mean_scaling, BASE_Q[1] * ec.Q_scaling_adj)
+        ro = calc_symbol_min_max(ec.mean_offsets, BASE_Q[2] * ec.Q_offsets_adj)
+        exp_feat, exp_scaling, exp_off = [], [], []
+        for a, b in slabs:
+            e = pc.calc_entropy_context(anchor[a:b])
+            qf, qs, qo = BASE_Q[0] * e.Q_feat_adj, BASE_Q[1] * e.Q_scaling_adj, BASE_Q[2] * e.Q_offsets_adj
+            exp_feat.append(STE_multistep.quantize(feat[a:b], qf, *rf) * qf)
+            exp_scaling.append(STE_multistep.quantize(scaling[a:b], qs, *rs) * qs)
+            exp_off.append(STE_multistep.quantize(offsets[a:b], qo.unsqueeze(1), *ro) * qo.unsqueeze(1) * mask[a:b])
+    dec = copy.deepcopy(pc)
+    conduct_stream_decoding(dec, pack)
+    N = pack.n
+    assert dec.decoded_version and N == int(keep.sum())
+    assert torch.equal(dec._anchor[:N], anchor)
+    assert torch.equal(dec._mask[:N], mask)
+    assert torch.equal(dec.get_encoding_params(), tables)
+    assert torch.equal(dec._anchor_feat[:N], torch.cat(exp_feat))
+    assert torch.equal(dec._scaling[:N], torch.cat(exp_scaling))
+    assert torch.equal(dec._offset[:N], torch.cat(exp_off))
+    # the decoded model renders through the decoder loop
+    from gsvc_amd.ortho_gaussian_renderer import render_frames
+    frames = [cube.get_dummy_frame(i) for i in (30, 31)]
+    imgs = list(render_frames(frames, dec, pipe, torch.zeros(3)))
+    assert len(imgs) == 2 and all(torch.isfinite(i).all() for i in imgs)
