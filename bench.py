@@ -215,6 +215,27 @@ def run_train_step(args, rank, world, local_rank, dev):
     n_img = sum(1 for _ in render_frames(frames_e2e, pc, pipe, trainer.background))
     torch.cuda.synchronize()
     res["render_frames_fps_end_to_end"] = n_img / (time.perf_counter() - te0) * world
+    if world == 1:
+        # stream codec round trip of the fitted model and the decoder's frame rate INCLUDING the entropy decode
+        import copy
+        from gsvc_amd.stream_codec import conduct_stream_decoding, conduct_stream_encoding
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        pack = conduct_stream_encoding(pc)
+        torch.cuda.synchronize()
+        tc1 = time.perf_counter()
+        dec = conduct_stream_decoding(copy.deepcopy(pc), pack)
+        torch.cuda.synchronize()
+        tc2 = time.perf_counter()
+        n_dec = sum(1 for _ in render_frames(frames_e2e, dec, pipe, trainer.background))
+        torch.cuda.synchronize()
+        tc3 = time.perf_counter()
+        bits = pack.bits()
+        res["stream_codec"] = {"encode_ms": (tc1 - tc0) * 1e3, "decode_ms": (tc2 - tc1) * 1e3, "slabs": len(pack.slabs),
+                               "anchors_coded": pack.n, "megabytes": {k[4:]: round(v / 8 / 2 ** 20, 4) for k, v in bits.items()},
+                               "stream_decode_fps": n_dec / (tc3 - tc1),
+                               "note": f"entropy decode of the whole model + {n_dec} two-view frames rendered from it"}
+        del dec, pack
     if world == 1 and not args.no_cpu_baseline:
         import oracle
         oracle.build()
@@ -429,7 +450,7 @@ def main():
     if rank == 0:
         if ts is not None:
             out["train_step"] = {k: ts[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "gsvc_kernel_us_per_step",
-                                                     "kernels", "roofline", "render_pair_fps_end_to_end", "render_frames_fps_end_to_end") if k in ts} \
+                                                     "kernels", "roofline", "render_pair_fps_end_to_end", "render_frames_fps_end_to_end", "stream_codec") if k in ts} \
                 if "error" not in ts else ts
         print(json.dumps(out))
     if world > 1:
