@@ -253,14 +253,56 @@ def inverse_sigmoid(x):
 
 
 def mean_3nn_dist2(points: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
-    """Mean squared distance to the 3 nearest neighbours (what simple_knn.distCUDA2 returns), by chunked cdist."""
+    """Mean squared distance to the 3 nearest neighbours (what simple_knn.distCUDA2 returns; reference
+    scene/gaussian_model.py:762,784).  CUDA tensors: uniform-grid binning here, exact search in csrc/knn.hip
+    (O(n) for the roughly uniform clouds GSVC starts from).  CPU tensors (host-side tests): chunked brute force."""
     n = points.shape[0]
+    if points.is_cuda:
+        return _mean_3nn_dist2_hip(points.float().contiguous())
     out = torch.empty(n, device=points.device, dtype=points.dtype)
     for s in range(0, n, chunk):
         d = torch.cdist(points[s:s + chunk], points) ** 2
         k = min(4, n)
         near = torch.topk(d, k, dim=1, largest=False).values[:, 1:]
         out[s:s + chunk] = near.mean(dim=1) if k > 1 else 0.0
+    return out
+
+
+def _mean_3nn_dist2_hip(pts: torch.Tensor, per_cell: float = 4.0, max_cells: int = 1 << 25) -> torch.Tensor:
+    import ctypes as C
+    from . import _lib
+    n = pts.shape[0]
+    if n == 0:
+        return torch.empty(0, device=pts.device)
+    lo, hi = pts.min(dim=0).values, pts.max(dim=0).values
+    ext = (hi - lo).clamp_min(1e-12).double().cpu()
+    lo_h = lo.double().cpu()
+    # cell edge for ~per_cell points per cell over the occupied box (flat clouds: the thin axes get one cell)
+    cells = max(1.0, min(n / per_cell, float(max_cells)))
+    edge = float((ext.prod() / cells) ** (1.0 / 3.0))
+    edge = max(edge, float(ext.max()) / 1024.0, 1e-12)
+    dims = [max(1, int(float(e) / edge) + 1) for e in ext]
+    while dims[0] * dims[1] * dims[2] > max_cells:
+        edge *= 1.26
+        dims = [max(1, int(float(e) / edge) + 1) for e in ext]
+    gx, gy, gz = dims
+    edge32 = float(torch.tensor(edge, dtype=torch.float32))
+    origin = (C.c_float * 3)(*[float(v) for v in lo_h])
+    o32 = torch.tensor([origin[0], origin[1], origin[2]], device=pts.device)
+    # the kernel's own cell rule: floor((p - origin) / edge) in float32, clamped
+    cxyz = torch.floor((pts - o32) / edge32).to(torch.int64)
+    cxyz[:, 0].clamp_(0, gx - 1); cxyz[:, 1].clamp_(0, gy - 1); cxyz[:, 2].clamp_(0, gz - 1)
+    cell = (cxyz[:, 2] * gy + cxyz[:, 1]) * gx + cxyz[:, 0]
+    order = torch.argsort(cell)
+    sorted_pts = pts.index_select(0, order).contiguous()
+    counts = torch.bincount(cell, minlength=gx * gy * gz)
+    cell_start = torch.zeros(gx * gy * gz + 1, dtype=torch.int32, device=pts.device)
+    cell_start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    out_sorted = torch.empty(n, device=pts.device)
+    _lib.check(_lib.lib().gsvc_knn3_mean_dist2(_lib.ptr(sorted_pts), _lib.ptr(cell_start), origin, edge32, gx, gy, gz, n,
+                                               _lib.ptr(out_sorted), _lib.current_stream(pts.device)), "gsvc_knn3_mean_dist2")
+    out = torch.empty_like(out_sorted)
+    out[order] = out_sorted
     return out
 
 

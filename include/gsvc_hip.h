@@ -266,6 +266,15 @@ typedef struct gsvc_adam_tensor {
 int gsvc_adam_step(int32_t n_tensors, const gsvc_adam_tensor *tensors_host, double beta1, double beta2, double eps, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Model creation: mean squared distance to the 3 nearest neighbours (replaces
+ * simple_knn._C.distCUDA2, reference simple-knn.zip simple_knn.cu:185-220, call sites scene/gaussian_model.py:762,784).
+ * The caller bins the points into a uniform grid: points_by_cell[n,3] sorted by cell index ((z * gy + y) * gx + x, cell of
+ * a point = floor((p - origin) / cell_edge) clamped to the grid), cell_start[gx*gy*gz + 1].  out[n] in the sorted order.
+ * ---------------------------------------------------------------------------------------------------- */
+int gsvc_knn3_mean_dist2(const float *points_by_cell, const int32_t *cell_start, const float *origin3_host, float cell_edge,
+                         int32_t gx, int32_t gy, int32_t gz, int64_t n, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Entropy coding of quantised attributes with the learned Gaussian model (replaces the external
  * gsvc_cuda_ans.ANSCoder the reference calls through utils/encodings.py:102-245 encoder_gaussian / decoder_gaussian:
  * integer symbols in [min_symbol, max_symbol], one Normal(mu, sigma) per symbol in symbol units).

@@ -367,3 +367,31 @@ def test_mfma_linear_matches_torch(M, K, N):
     (F.linear(x, lin.weight, lin.bias) * gm).sum().backward()
     assert torch.allclose(gx2, x.grad, rtol=1e-4, atol=1e-5)
     assert torch.allclose(gw2, lin.weight.grad, rtol=1e-3, atol=1e-3 * lin.weight.grad.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,shape", [(1, "cube"), (3, "cube"), (4, "cube"), (5000, "cube"), (5000, "flat"), (5000, "clustered"),
+                                     (20000, "slab")])
+def test_knn3_mean_dist2_matches_brute_force(n, shape):
+    """csrc/knn.hip (stands in for simple_knn.distCUDA2): exact 3-NN mean squared distance."""
+    import numpy as np
+    from gsvc_amd.model import mean_3nn_dist2
+    rng = np.random.default_rng(n)
+    if shape == "cube":
+        p = rng.uniform(-1, 1, (n, 3))
+    elif shape == "flat":
+        p = np.concatenate([rng.uniform(-1, 1, (n, 2)), np.zeros((n, 1))], 1)          # zero extent along z
+    elif shape == "clustered":
+        p = np.concatenate([rng.normal(0, 0.01, (n // 2, 3)), rng.uniform(-1, 1, (n - n // 2, 3))])   # very uneven cells
+    else:
+        p = rng.uniform([-1.0, -0.5625, -0.03], [1.0, 0.5625, 0.03], (n, 3))           # GSVC's thin z-slab of anchors
+    p32 = p.astype(np.float32)
+    got = mean_3nn_dist2(torch.from_numpy(p32).cuda()).cpu().numpy()
+    ref = np.empty(n, np.float64)
+    P = p32.astype(np.float64)
+    for s in range(0, n, 2048):
+        d = ((P[s:s + 2048, None, :] - P[None, :, :]) ** 2).sum(-1)
+        d[np.arange(d.shape[0]), np.arange(s, s + d.shape[0])] = np.inf
+        k = min(3, n - 1)
+        ref[s:s + 2048] = np.sort(d, 1)[:, :k].mean(1) if k > 0 else 0.0
+    assert np.allclose(got, ref, rtol=2e-5, atol=1e-12), np.abs(got - ref).max()
