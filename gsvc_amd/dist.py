@@ -93,6 +93,32 @@ def any_rank(flag: bool, device) -> bool:
     return bool(t.item() > 0)
 
 
+def any_rank_start(flags_dev):
+    """Non-blocking form of any_rank for flags that already live on the device (the rasterizers' overflow words): the
+    MAX all-reduce and the copy of its result to the host are queued NOW — behind the kernels that produce the flags, not
+    behind whatever is launched afterwards — and any_rank_finish() waits for that copy only.  None on a single rank."""
+    if world_size() == 1:
+        return None
+    t = torch.stack([f.reshape(-1)[0] for f in flags_dev]).max().to(torch.float32).reshape(1)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if not t.is_cuda:
+        return (t, None)
+    host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return (host, ev)
+
+
+def any_rank_finish(handle, local_flag: bool) -> bool:
+    if handle is None:
+        return bool(local_flag)
+    host, ev = handle
+    if ev is not None:
+        ev.synchronize()
+    return bool(host.item() > 0) or bool(local_flag)
+
+
 def broadcast_parameters(module, src: int = 0):
     """Make every rank start from rank `src`'s parameters and buffers."""
     if world_size() == 1:

@@ -122,6 +122,9 @@ class Trainer:
                                              dense=True, anchor_grad=self.anchor_grad)
             image1 = (r1f.rendered_image + torch.flip(r1b.rendered_image, dims=(-1,))) / 2
             image2 = (r2f.rendered_image + torch.flip(r2b.rendered_image, dims=(-1,))) / 2
+            # replicas: "did any rank's instance buffer overflow" is reduced right behind the forward kernels, so that
+            # the end-of-step check does not have to wait for the backward (overflow word = second int32 of a binning blob)
+            ovf_handle = gdist.any_rank_start([r.raster_state.binning[4:8].view(torch.int32) for r in (r1f, r1b, r2f, r2b)])
         else:
             r1f, r1b, image1 = self._two_views(frame1, mode, retain_grad)
             r2f, r2b, image2 = self._two_views(frame2, mode, retain_grad)
@@ -163,7 +166,7 @@ class Trainer:
         if self.batched:
             # the only host synchronisation of the step after the visibility test: the 4 renders' instance counters
             _, overflowed = resolve_deferred([r.raster_state for r in renders])
-            if gdist.any_rank(overflowed, dev):      # replicas repeat the step together (their collectives must pair up)
+            if gdist.any_rank_finish(ovf_handle, overflowed):      # replicas repeat the step together (their collectives must pair up)
                 return None
             for r in renders:
                 r.num_rendered = r.raster_state.counters()[0]

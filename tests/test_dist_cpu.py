@@ -41,6 +41,12 @@ def _worker(rank, world, port, q):
     pc.offset_denom = torch.ones(6, 1)
     gd.allreduce_statistics(pc)
     assert torch.all(pc.opacity_accum == 3.0) and torch.all(pc.anchor_demon == 2.0) and torch.all(pc.offset_gradient_accum == 1.5)
+    # collective yes/no decisions: blocking form and the early (start / finish) form
+    assert gd.any_rank(rank == 1, torch.device("cpu")) is True and gd.any_rank(False, torch.device("cpu")) is False
+    h = gd.any_rank_start([torch.tensor([0, 0]), torch.tensor([1 if rank == 0 else 0, 7])])
+    assert gd.any_rank_finish(h, False) is True
+    h = gd.any_rank_start([torch.tensor([0]), torch.tensor([0])])
+    assert gd.any_rank_finish(h, False) is False and gd.any_rank_finish(h, True) is True
     q.put((rank, gd.frame_shard(600), [float(p.data.sum()) for p in model.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
