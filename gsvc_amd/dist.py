@@ -73,6 +73,66 @@ def allreduce_gradients(params, average: bool = True):
     return flat.numel()
 
 
+class GradReducer:
+    """Gradient all-reduce that overlaps the backward pass: every large parameter's collective is launched from a
+    post-accumulate-grad hook the moment its gradient is final (the per-anchor offsets / scalings / masks finish early in the
+    backward, right behind the rasterizer), small parameters (the MLP weights) are reduced in one flat bucket at the end.
+    All ranks run the same backward graph, so the hooks fire — and the collectives are issued — in the same order everywhere.
+    On one rank it does nothing."""
+
+    SMALL = 1 << 18     # elements; below this a tensor joins the flat bucket
+
+    def __init__(self, average: bool = True):
+        self.average = average
+        self._hooked = {}           # id(param) -> (param, handle of the hook)
+        self._pending = []          # (work, grad) of the collectives in flight
+        self._armed = False
+
+    def arm(self, params):
+        """Call before backward with the step's parameters (new Parameter objects, e.g. after densification, get hooks;
+        hooks of parameters that are gone are dropped)."""
+        self._params = [p for p in params if p.requires_grad]
+        if world_size() == 1:
+            return
+        live = {id(p) for p in self._params}
+        for k in [k for k in self._hooked if k not in live]:
+            self._hooked.pop(k)[1].remove()
+        for p in self._params:
+            if id(p) not in self._hooked and p.numel() >= self.SMALL:
+                self._hooked[id(p)] = (p, p.register_post_accumulate_grad_hook(self._on_grad))
+        self._pending = []
+        self._armed = True
+
+    def _on_grad(self, p):
+        if self._armed and p.grad is not None:
+            self._pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p.grad))
+
+    def finish(self):
+        """Call after backward: reduces the small parameters, waits for everything, averages.  Returns the number of
+        gradient elements reduced."""
+        w = world_size()
+        if w == 1:
+            return 0
+        self._armed = False
+        done = {id(g) for _, g in self._pending}
+        small = [p.grad for p in self._params if p.grad is not None and id(p.grad) not in done]
+        n = sum(g.numel() for _, g in self._pending)
+        if small:
+            flat = torch.cat([g.reshape(-1) for g in small])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            off = 0
+            for g in small:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+            n += off
+        for work, _ in self._pending:
+            work.wait()
+        if self.average:
+            torch._foreach_div_([g for _, g in self._pending] + small, float(w))
+        self._pending = []
+        return n
+
+
 def allreduce_statistics(pc):
     """Sum the densification accumulators across ranks (each rank only sees its own frames)."""
     if world_size() == 1:

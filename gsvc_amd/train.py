@@ -67,6 +67,7 @@ class Trainer:
         # anchors are trained with learning rate 0 in GSVC (position_lr_init = position_lr_final = 0): their gradient
         # changes nothing, so the batched step does not compute it unless a non-zero rate is configured
         self.anchor_grad = bool(getattr(opt, "position_lr_init", 0.0) or getattr(opt, "position_lr_final", 0.0))
+        self.reducer = gdist.GradReducer()
 
     def _two_views(self, frame, mode, retain_grad):
         f = render(frame, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode)
@@ -159,9 +160,10 @@ class Trainer:
             self._w_key, self._w = key, torch.tensor(weights, dtype=torch.float32, device=dev)
         w = self._w
         loss = torch.dot(torch.stack([t.reshape(()) for t in terms]), w) + const
+        self.reducer.arm([p for g in pc.optimizer.param_groups for p in g["params"]])
         with region('step.backward'):
             loss.backward()
-        gdist.allreduce_gradients([p for g in pc.optimizer.param_groups for p in g["params"]])
+        self.reducer.finish()
 
         if self.batched:
             # the only host synchronisation of the step after the visibility test: the 4 renders' instance counters

@@ -41,6 +41,26 @@ def _worker(rank, world, port, q):
     pc.offset_denom = torch.ones(6, 1)
     gd.allreduce_statistics(pc)
     assert torch.all(pc.opacity_accum == 3.0) and torch.all(pc.anchor_demon == 2.0) and torch.all(pc.offset_gradient_accum == 1.5)
+    # overlapped reducer: large tensors from hooks during backward, small ones in a flat bucket; a second step re-arms it
+    red = gd.GradReducer()
+    red.SMALL = 16
+    big = torch.nn.Parameter(torch.ones(8, 4))
+    tiny = torch.nn.Parameter(torch.ones(3))
+    unused = torch.nn.Parameter(torch.ones(2))
+    for it in range(2):
+        for p in (big, tiny, unused):
+            p.grad = None
+        red.arm([big, tiny, unused])
+        ((big * float(rank + 1)).sum() + (tiny * float(10 * (rank + 1))).sum()).backward()
+        n = red.finish()
+        assert n == big.numel() + tiny.numel() and unused.grad is None
+        assert torch.allclose(big.grad, torch.full_like(big, 1.5)) and torch.allclose(tiny.grad, torch.full_like(tiny, 15.0))
+    big2 = torch.nn.Parameter(torch.ones(8, 4))          # a replaced parameter (densification) gets its own hook
+    red.arm([big2, tiny])
+    big2.grad, tiny.grad = None, None
+    ((big2 * float(rank + 1)).sum() + tiny.sum()).backward()
+    red.finish()
+    assert torch.allclose(big2.grad, torch.full_like(big2, 1.5)) and len(red._hooked) == 1
     # collective yes/no decisions: blocking form and the early (start / finish) form
     assert gd.any_rank(rank == 1, torch.device("cpu")) is True and gd.any_rank(False, torch.device("cpu")) is False
     h = gd.any_rank_start([torch.tensor([0, 0]), torch.tensor([1 if rank == 0 else 0, 7])])
