@@ -15,8 +15,7 @@ from dataclasses import dataclass
 import torch
 
 from . import dist as gdist
-from .encodings import get_binary_vxl_size
-from .generate import GenerateMode, region
+from .generate import region
 from .loss_utils import calc_optical_loss, render_regs, ssim_l1
 from .ortho_gaussian_renderer import render, render_many
 from .rasterizer import resolve_deferred

@@ -3,7 +3,6 @@ import os, sys, traceback
 from collections import Counter
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from torch.overrides import TorchFunctionMode
 from gsvc_amd.arguments import cfg_20240919
 from gsvc_amd.frame import SyntheticFrameCube
 from gsvc_amd.model import GaussianModel
