@@ -26,7 +26,9 @@ struct alignas(16) GeomRec {
 static_assert(sizeof(GeomRec) == 48, "GeomRec must be 48 bytes");
 
 // One Gaussian as the binning kernels read it: 32 B.
-constexpr int BIN_SLOTS = 4;     // instance slots resolved by K1's LDS histogram; further tiles take the atomic path
+constexpr int BIN_SLOTS = 4;     // instance slots resolved by K1's LDS histogram; further tiles ("extras") are placed by K3
+constexpr int BIN_WG = 1024;     // Gaussians per binning workgroup (K1 and K3 use the same partition)
+constexpr int HEAVY_EXTRAS = 2 * BIN_WG;   // a workgroup with more extras than this places them through an LDS histogram in K3
 struct alignas(16) BinRec {
     float depth;
     uint32_t rect_x, rect_y;     // x0 | x1<<16,  y0 | y1<<16 (tile units, upper exclusive); 0 when culled
@@ -40,8 +42,8 @@ struct RasterLayout {
     // geom blob
     uint64_t off_geom, off_bin, geom_bytes;
     // binning blob
-    uint64_t off_counters, off_tile_offsets, off_tile_count, off_tile_extra, off_big_list, off_keys, off_point_list, off_inst_bbox,
-        binning_bytes;
+    uint64_t off_counters, off_tile_offsets, off_tile_count, off_tile_extra, off_big_list, off_wg_extras, off_keys, off_point_list,
+        off_inst_bbox, binning_bytes;
     // image blob
     uint64_t off_final_T, off_n_contrib, image_bytes;
 };
@@ -62,6 +64,7 @@ inline RasterLayout raster_layout(const gsvc_raster_settings &s, int64_t P, int6
     L.off_tile_count = o;    o += align_up((uint64_t)L.tiles * 4, 256);
     L.off_tile_extra = o;    o += align_up((uint64_t)L.tiles * 4, 256);
     L.off_big_list = o;      o += align_up((uint64_t)L.tiles * 4, 256);
+    L.off_wg_extras = o;     o += align_up(((p + BIN_WG - 1) / BIN_WG) * 4, 256);     // per K1 workgroup: instances beyond the slots
     L.off_keys = o;          o += align_up(m * 8, 256);
     L.off_point_list = o;    o += align_up(m * 4, 256);
     L.off_inst_bbox = o;     o += align_up(m * 8, 256);

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
                                                      int32_t *__restrict__ tile_count, int32_t *__restrict__ tile_extra,
                                                      gsvc_raster_counters *__restrict__ counters,
                                                      int32_t *__restrict__ tile_offsets, int32_t *__restrict__ big_list,
-                                                     long long max_instances)
+                                                     int32_t *__restrict__ wg_extras, long long max_instances)
 {
     extern __shared__ int hist[];
     const int T = st.gx * st.gy;
@@ -195,6 +195,8 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
     int radius = 0;
     PreOut o;
     int slot[BIN_SLOTS] = {0, 0, 0, 0};
+    int n_extra = 0;        // this Gaussian's instances beyond BIN_SLOTS
+    bool heavy = false;     // workgroup-uniform: extras go through the LDS histogram
     int bx0 = 0, bx1 = 0;   // x range of the binning rectangle (pair mode: union of the two views)
     bool listed = false;
     if (i < P) {
@@ -235,20 +237,20 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
             br.depth = o.depth;
             br.rect_x = radius > 0 ? ((uint32_t)o.x0 | ((uint32_t)o.x1 << 16)) : 0u;
             br.rect_y = (uint32_t)o.y0 | ((uint32_t)o.y1 << 16);
+            // the first BIN_SLOTS tiles of the rectangle (row-major): rank inside the workgroup from the LDS histogram
+            // (histogram word of a tile: low half = slotted instances of this workgroup, high half = its extras in the
+            // heavy case; at most 1024 each: no carry).  The remaining tiles ("extras") follow below.
             int j = 0;
-            for (int ty = o.y0; ty < o.y1; ty++)
-                for (int tx = bx0; tx < bx1; tx++, j++) {
+            for (int ty = o.y0; ty < o.y1 && j < BIN_SLOTS; ty++)
+                for (int tx = bx0; tx < bx1 && j < BIN_SLOTS; tx++, j++) {
                     const int t = ty * st.gx + tx;
-                    if (j < BIN_SLOTS) {
-                        const int r = USE_LDS ? atomicAdd(&hist[t], 1) : atomicAdd(&tile_count[t], 1);
-                        if (j == 0) slot[0] = r;
-                        if (j == 1) slot[1] = r;
-                        if (j == 2) slot[2] = r;
-                        if (j == 3) slot[3] = r;
-                    } else {
-                        atomicAdd(&tile_extra[t], 1);
-                    }
+                    const int r = USE_LDS ? (atomicAdd(&hist[t], 1) & 0xffff) : atomicAdd(&tile_count[t], 1);
+                    if (j == 0) slot[0] = r;
+                    if (j == 1) slot[1] = r;
+                    if (j == 2) slot[2] = r;
+                    if (j == 3) slot[3] = r;
                 }
+            n_extra = max((bx1 - bx0) * (o.y1 - o.y0) - BIN_SLOTS, 0);
         } else {
             rec.u = rec.v = rec.A = rec.B = rec.C = rec.opacity = rec.r = rec.g = rec.b = rec.depth = 0.f;
             rec.bbox_x = pack_i16(1, 0); rec.bbox_y = pack_i16(1, 0);
@@ -267,16 +269,35 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         }
     }
     {
-        // visible count: one atomic per workgroup
-        __shared__ int s_vis;
-        if (tid == 0) s_vis = 0;
+        // visible count: one atomic per workgroup; the workgroup's extras: one store (K3 picks its path by it)
+        __shared__ int s_vis, s_ext;
+        if (tid == 0) { s_vis = 0; s_ext = 0; }
         __syncthreads();
         const unsigned long long vm = __ballot(radius > 0);
         if ((tid & 63) == 0 && vm != 0ull) atomicAdd(&s_vis, __popcll(vm));
+        int ne = n_extra;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) ne += __shfl_xor(ne, m, 64);
+        if ((tid & 63) == 0 && ne != 0) atomicAdd(&s_ext, ne);
         __syncthreads();
         if (tid == 0 && s_vis != 0) atomicAdd(&counters->num_visible, s_vis);
+        if (tid == 0) wg_extras[blockIdx.x] = s_ext;
+        // extras: a workgroup with many of them (large footprints) counts them in the high half of the LDS histogram and
+        // adds them to the tiles' cursors with the contiguous flush below; otherwise one fire-and-forget global atomic each
+        heavy = USE_LDS && s_ext > HEAVY_EXTRAS;
+    }
+    if (n_extra > 0) {
+        int j = 0;
+        for (int ty = o.y0; ty < o.y1; ty++)
+            for (int tx = bx0; tx < bx1; tx++, j++) {
+                if (j < BIN_SLOTS) continue;
+                const int t = ty * st.gx + tx;
+                if (heavy) atomicAdd(&hist[t], 0x10000);
+                else atomicAdd(&tile_extra[t], 1);
+            }
     }
     if (!USE_LDS) return;
+    if (heavy) __syncthreads();
     // flush: 64 consecutive tiles per wave-instruction = 256 contiguous bytes of returning atomics; a wave's
     // (up to 8) groups are issued back to back and waited for once — a memory-side atomic takes microseconds
     {
@@ -292,7 +313,9 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
             for (int r = 0; r < 8; r++) {
                 const int t = g0 + r * 1024 + lane;
                 base[r] = 0;
-                if (__ballot(v[r] != 0) != 0ull && t < T) base[r] = atomicAdd(&tile_count[t], v[r]);
+                const int lo = v[r] & 0xffff, hi = (int)((unsigned)v[r] >> 16);
+                if (__ballot(lo != 0) != 0ull && t < T) base[r] = atomicAdd(&tile_count[t], lo);
+                if (heavy && __ballot(hi != 0) != 0ull && t < T) atomicAdd(&tile_extra[t], hi);      // no return value needed
             }
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -378,6 +401,123 @@ __global__ void __launch_bounds__(256) k_scatter(int P, int gx, const BinRec *__
         const int jy = j / w, jx = j - jy * w;
         const int t = (y0 + jy) * gx + x0 + jx;
         keys[tile_offsets[t] + tile_count[t] + atomicAdd(&tile_extra[t], 1)] = make_key(x0 + jx);
+    }
+}
+
+// K3 for tile grids that fit the LDS histogram: same 1024-Gaussian partition as K1.  A workgroup whose Gaussians own
+// many instances beyond the slots (large footprints: a fitting step at 4K has ~60 tiles per visible Gaussian) places
+// them the way K1 counts — tile histogram in LDS, ONE contiguous returning atomic wave-instruction per 64 tiles to
+// reserve the workgroup's range behind every tile's slotted instances, then LDS atomics hand out the positions inside
+// the range — instead of one scattered returning global atomic per instance (measured: 5.6 ms -> K3 of a 4K fitting
+// render; per-instance atomics on a tile's cursor serialise).  Workgroups with few extras keep the per-instance path.
+template <bool PAIR>
+__global__ void __launch_bounds__(1024) k_scatter_lds(int P, int gx, int T, const BinRec *__restrict__ bins,
+                                                      const int32_t *__restrict__ tile_offsets,
+                                                      const int32_t *__restrict__ tile_count,
+                                                      int32_t *__restrict__ tile_extra, const int32_t *__restrict__ wg_extras,
+                                                      uint64_t *__restrict__ keys,
+                                                      const gsvc_raster_counters *__restrict__ counters)
+{
+    extern __shared__ int hist[];
+    if (counters->overflow) return;                      // uniform: the whole workgroup leaves
+    const int tid = threadIdx.x;
+    const bool heavy = wg_extras[blockIdx.x] > HEAVY_EXTRAS;
+    if (heavy) {
+        for (int t = tid; t < T; t += 1024) hist[t] = 0;
+        __syncthreads();
+    }
+    const int i = blockIdx.x * 1024 + tid;
+    bool live = false;
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0, fx0 = 0, fx1 = 0, mx0 = 0, mx1 = 0;
+    uint32_t rx = 0, rb = 0;
+    uint64_t key_hi = 0;
+    int w = 1, ntiles = 0;
+    if (i < P) {
+        const float4 b0 = reinterpret_cast<const float4 *>(bins + i)[0];
+        rx = __float_as_uint(b0.y); rb = __float_as_uint(b0.w);
+        const uint32_t ry = __float_as_uint(b0.z);
+        live = !((((PAIR ? (rx | rb) : rx) | ry) == 0u) || ry == 0u);
+        if (live) {
+            fx0 = rx & 0xffff; fx1 = rx >> 16; y0 = ry & 0xffff; y1 = ry >> 16;
+            x0 = fx0; x1 = fx1;
+            mx0 = rb & 0xffff; mx1 = rb >> 16;
+            if (PAIR) {
+                if (rx == 0u) { x0 = mx0; x1 = mx1; }
+                else if (rb != 0u) { x0 = min(fx0, mx0); x1 = max(fx1, mx1); }
+            }
+            key_hi = (uint64_t)order_bits(b0.x) << 32;
+            w = x1 - x0; ntiles = w * (y1 - y0);
+        }
+    }
+    auto make_key = [&](int tx) -> uint64_t {
+        if (!PAIR) return key_hi | (uint32_t)i;
+        const uint32_t fl = ((rx != 0u && tx >= fx0 && tx < fx1) ? 1u : 0u) | ((rb != 0u && tx >= mx0 && tx < mx1) ? 2u : 0u);
+        return key_hi | (((uint32_t)i << 2) | fl);
+    };
+    if (live) {
+        const int4 sl = reinterpret_cast<const int4 *>(bins + i)[1];
+        const int slots[BIN_SLOTS] = {sl.x, sl.y, sl.z, sl.w};
+        int tl[BIN_SLOTS], off[BIN_SLOTS];
+#pragma unroll
+        for (int j = 0; j < BIN_SLOTS; j++) {
+            const int jy = j / w, jx = j - jy * w;
+            tl[j] = (y0 + jy) * gx + x0 + jx;
+            off[j] = j < ntiles ? tile_offsets[tl[j]] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < BIN_SLOTS; j++)
+            if (j < ntiles) keys[off[j] + slots[j]] = make_key(tl[j] % gx);
+    }
+    if (!heavy) {
+        if (live)
+            for (int j = BIN_SLOTS; j < ntiles; j++) {
+                const int jy = j / w, jx = j - jy * w;
+                const int t = (y0 + jy) * gx + x0 + jx;
+                keys[tile_offsets[t] + tile_count[t] + atomicAdd(&tile_extra[t], 1)] = make_key(x0 + jx);
+            }
+        return;
+    }
+    // heavy: (1) count this workgroup's extras per tile
+    if (live && ntiles > BIN_SLOTS) {
+        int j = 0;
+        for (int ty = y0; ty < y1; ty++)
+            for (int tx = x0; tx < x1; tx++, j++)
+                if (j >= BIN_SLOTS) atomicAdd(&hist[ty * gx + tx], 1);
+    }
+    __syncthreads();
+    // (2) reserve the workgroup's range on every tile's cursor: contiguous returning atomics, as in K1's flush
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int g0 = wave * 64; g0 < T; g0 += 8 * 1024) {
+            int v[8], base[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int t = g0 + r * 1024 + lane;
+                v[r] = t < T ? hist[t] : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int t = g0 + r * 1024 + lane;
+                base[r] = 0;
+                if (__ballot(v[r] != 0) != 0ull && t < T) base[r] = atomicAdd(&tile_extra[t], v[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int t = g0 + r * 1024 + lane;
+                if (t < T) hist[t] = base[r];
+            }
+        }
+    }
+    __syncthreads();
+    // (3) positions inside the range from LDS atomics
+    if (live && ntiles > BIN_SLOTS) {
+        int j = 0;
+        for (int ty = y0; ty < y1; ty++)
+            for (int tx = x0; tx < x1; tx++, j++) {
+                if (j < BIN_SLOTS) continue;
+                const int t = ty * gx + tx;
+                keys[tile_offsets[t] + tile_count[t] + atomicAdd(&hist[t], 1)] = make_key(tx);
+            }
     }
 }
 
@@ -814,6 +954,7 @@ static int raster_forward_impl(const gsvc_raster_settings *settings, int64_t P, 
     auto *tile_count = (int32_t *)(bin + L.off_tile_count);
     auto *tile_extra = (int32_t *)(bin + L.off_tile_extra);
     auto *big_list = (int32_t *)(bin + L.off_big_list);
+    auto *wg_extras = (int32_t *)(bin + L.off_wg_extras);
     auto *keys = (uint64_t *)(bin + L.off_keys);
     auto *point_list = (int32_t *)(bin + L.off_point_list);
     auto *inst_bbox = (uint2 *)(bin + L.off_inst_bbox);
@@ -838,7 +979,7 @@ static int raster_forward_impl(const gsvc_raster_settings *settings, int64_t P, 
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           LDS_HIST_MAX_TILES * 4);
             hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds, s, p, (int)P, means3D, colors, opacities, scales,
-                               rotations, radii, grec, brec, tile_count, tile_extra, counters, tile_offsets, big_list,
+                               rotations, radii, grec, brec, tile_count, tile_extra, counters, tile_offsets, big_list, wg_extras,
                                (long long)max_instances);
         };
         if (use_lds && pair) launch(&k_preprocess<true, true>);
@@ -854,7 +995,19 @@ static int raster_forward_impl(const gsvc_raster_settings *settings, int64_t P, 
     if (P > 0) {
         {
             ProfScope _prof("k_scatter", s);
-            if (pair)
+            if (L.tiles <= LDS_HIST_MAX_TILES) {
+                const unsigned blocks = (unsigned)((P + BIN_WG - 1) / BIN_WG);
+                const size_t lds = (size_t)L.tiles * sizeof(int);
+                auto launch = [&](auto kernel) {
+                    if (lds > 48 * 1024)
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  LDS_HIST_MAX_TILES * 4);
+                    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds, s, (int)P, L.gx, L.tiles, brec, tile_offsets, tile_count,
+                                       tile_extra, wg_extras, keys, counters);
+                };
+                if (pair) launch(&k_scatter_lds<true>);
+                else launch(&k_scatter_lds<false>);
+            } else if (pair)
                 hipLaunchKernelGGL(k_scatter<true>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (int)P, L.gx, brec,
                                    tile_offsets, tile_count, tile_extra, keys, counters);
             else
