@@ -166,6 +166,36 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int T, const int32_t *__res
     scan_tiles_body(T, tile_count, tile_extra, tile_offsets, big_list, counters, max_instances, s_v);
 }
 
+// Walk the tiles j >= BIN_SLOTS ("extras") of every lane's binning rectangle (row-major, x0 / w / y0 / nt per lane; nt = 0:
+// nothing).  A lane that walked a 60-tile rectangle alone would keep its 63 neighbours waiting (footprints are very uneven:
+// most Gaussians of a fitting render are culled or small), so rectangles of COOP_MIN_TILES tiles or more are walked by the
+// whole wave, 64 tiles per step; smaller ones by their own lane.  f(owner lane, ty, tx).
+constexpr int COOP_MIN_TILES = 24;
+
+template <typename OWN, typename F>
+__device__ __forceinline__ void for_each_extra(int lane, int nt, int x0, int w, int y0, OWN &&owner, F &&f)
+{
+    // owner(src) fetches what f needs from the rectangle's owner lane; it runs with the whole wave active (cross-lane reads
+    // inside the partially active tile loop could meet an inactive owner)
+    unsigned long long big = __ballot(nt >= COOP_MIN_TILES);
+    while (big != 0ull) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1ull;
+        const int sx0 = __shfl(x0, src, 64), sw = __shfl(w, src, 64), sy0 = __shfl(y0, src, 64), snt = __shfl(nt, src, 64);
+        const auto od = owner(src);
+        for (int j = BIN_SLOTS + lane; j < snt; j += 64) {
+            const int jy = j / sw, jx = j - jy * sw;
+            f(od, sy0 + jy, sx0 + jx);
+        }
+    }
+    const auto own = owner(lane);
+    if (nt < COOP_MIN_TILES)
+        for (int j = BIN_SLOTS; j < nt; j++) {
+            const int jy = j / w, jx = j - jy * w;
+            f(own, y0 + jy, x0 + jx);
+        }
+}
+
 // ------------------------------------------------------------------------------------------------- K1
 // USE_LDS: per-workgroup histogram of the whole tile grid in dynamic LDS (4*T bytes).  Otherwise (grids too
 // large for LDS) every instance does its own global atomic.
@@ -286,15 +316,13 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         // adds them to the tiles' cursors with the contiguous flush below; otherwise one fire-and-forget global atomic each
         heavy = USE_LDS && s_ext > HEAVY_EXTRAS;
     }
-    if (n_extra > 0) {
-        int j = 0;
-        for (int ty = o.y0; ty < o.y1; ty++)
-            for (int tx = bx0; tx < bx1; tx++, j++) {
-                if (j < BIN_SLOTS) continue;
-                const int t = ty * st.gx + tx;
-                if (heavy) atomicAdd(&hist[t], 0x10000);
-                else atomicAdd(&tile_extra[t], 1);
-            }
+    {
+        const int nt = n_extra > 0 ? n_extra + BIN_SLOTS : 0;
+        for_each_extra(tid & 63, nt, bx0, bx1 - bx0, o.y0, [](int) { return 0; }, [&](int, int ty, int tx) {
+            const int t = ty * st.gx + tx;
+            if (heavy) atomicAdd(&hist[t], 0x10000);
+            else atomicAdd(&tile_extra[t], 1);
+        });
     }
     if (!USE_LDS) return;
     if (heavy) __syncthreads();
@@ -468,22 +496,34 @@ __global__ void __launch_bounds__(1024) k_scatter_lds(int P, int gx, int T, cons
         for (int j = 0; j < BIN_SLOTS; j++)
             if (j < ntiles) keys[off[j] + slots[j]] = make_key(tl[j] % gx);
     }
+    // what a tile's key needs from the Gaussian that owns the rectangle (fetched across the wave for shared rectangles)
+    struct Owner { uint32_t khi, i, rx, rb; int fx0, fx1, mx0, mx1; };
+    const int lane = tid & 63;
+    auto owner = [&](int src) -> Owner {
+        Owner o;
+        o.khi = __shfl((uint32_t)(key_hi >> 32), src, 64); o.i = __shfl((uint32_t)i, src, 64);
+        o.rx = o.rb = 0u; o.fx0 = o.fx1 = o.mx0 = o.mx1 = 0;
+        if (PAIR) {
+            o.rx = __shfl(rx, src, 64); o.rb = __shfl(rb, src, 64);
+            o.fx0 = __shfl(fx0, src, 64); o.fx1 = __shfl(fx1, src, 64); o.mx0 = __shfl(mx0, src, 64); o.mx1 = __shfl(mx1, src, 64);
+        }
+        return o;
+    };
+    auto key_of = [&](const Owner &o, int tx) -> uint64_t {
+        if (!PAIR) return ((uint64_t)o.khi << 32) | o.i;
+        const uint32_t fl = ((o.rx != 0u && tx >= o.fx0 && tx < o.fx1) ? 1u : 0u) | ((o.rb != 0u && tx >= o.mx0 && tx < o.mx1) ? 2u : 0u);
+        return ((uint64_t)o.khi << 32) | ((o.i << 2) | fl);
+    };
+    const int nt_x = live ? ntiles : 0;
     if (!heavy) {
-        if (live)
-            for (int j = BIN_SLOTS; j < ntiles; j++) {
-                const int jy = j / w, jx = j - jy * w;
-                const int t = (y0 + jy) * gx + x0 + jx;
-                keys[tile_offsets[t] + tile_count[t] + atomicAdd(&tile_extra[t], 1)] = make_key(x0 + jx);
-            }
+        for_each_extra(lane, nt_x, x0, w, y0, owner, [&](const Owner &od, int ty, int tx) {
+            const int t = ty * gx + tx;
+            keys[tile_offsets[t] + tile_count[t] + atomicAdd(&tile_extra[t], 1)] = key_of(od, tx);
+        });
         return;
     }
     // heavy: (1) count this workgroup's extras per tile
-    if (live && ntiles > BIN_SLOTS) {
-        int j = 0;
-        for (int ty = y0; ty < y1; ty++)
-            for (int tx = x0; tx < x1; tx++, j++)
-                if (j >= BIN_SLOTS) atomicAdd(&hist[ty * gx + tx], 1);
-    }
+    for_each_extra(lane, nt_x, x0, w, y0, [](int) { return 0; }, [&](int, int ty, int tx) { atomicAdd(&hist[ty * gx + tx], 1); });
     __syncthreads();
     // (2) reserve the workgroup's range on every tile's cursor: contiguous returning atomics, as in K1's flush
     {
@@ -510,15 +550,10 @@ __global__ void __launch_bounds__(1024) k_scatter_lds(int P, int gx, int T, cons
     }
     __syncthreads();
     // (3) positions inside the range from LDS atomics
-    if (live && ntiles > BIN_SLOTS) {
-        int j = 0;
-        for (int ty = y0; ty < y1; ty++)
-            for (int tx = x0; tx < x1; tx++, j++) {
-                if (j < BIN_SLOTS) continue;
-                const int t = ty * gx + tx;
-                keys[tile_offsets[t] + tile_count[t] + atomicAdd(&hist[t], 1)] = make_key(tx);
-            }
-    }
+    for_each_extra(lane, nt_x, x0, w, y0, owner, [&](const Owner &od, int ty, int tx) {
+        const int t = ty * gx + tx;
+        keys[tile_offsets[t] + tile_count[t] + atomicAdd(&hist[t], 1)] = key_of(od, tx);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------- K4
