@@ -12,7 +12,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-ALIAS = {"k_blend_bwd_tile": "k_blend_bwd"}      # kernel function name -> the name bench.py's HIP-event profiler uses
+ALIAS = {"k_blend_bwd_tile": "k_blend_bwd", "k_scatter_lds": "k_scatter"}      # kernel function name -> the name bench.py's HIP-event profiler uses
 
 
 def short(name):
