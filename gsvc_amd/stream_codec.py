@@ -18,8 +18,8 @@ Everything runs on the device except the byte containers.
 """
 from __future__ import annotations
 
+import json
 import os
-import pickle
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -117,14 +117,21 @@ class StreamPack:
             with open(os.path.join(path, name), "wb") as f:
                 f.write(blob)
         self.anchors_q.tofile(os.path.join(path, "anchor_q16.bin"))
-        meta = {k: getattr(self, k) for k in ("n_full", "n", "anchor_interval", "anchor_min", "prob_masks", "prob_hash", "slabs")}
-        with open(os.path.join(path, "meta.pkl"), "wb") as f:
-            pickle.dump(meta, f)
+        meta = {"n_full": self.n_full, "n": self.n, "prob_masks": self.prob_masks, "prob_hash": self.prob_hash,
+                "slabs": [list(s) for s in self.slabs],
+                # float32 values survive the trip through JSON doubles exactly
+                "anchor_interval": np.asarray(self.anchor_interval, np.float32).astype(np.float64).tolist(),
+                "anchor_min": np.asarray(self.anchor_min, np.float32).astype(np.float64).tolist()}
+        with open(os.path.join(path, "meta.json"), "w") as f:
+            json.dump(meta, f)
 
     @classmethod
     def load(cls, path):
-        with open(os.path.join(path, "meta.pkl"), "rb") as f:
-            meta = pickle.load(f)
+        with open(os.path.join(path, "meta.json")) as f:
+            meta = json.load(f)
+        meta["anchor_interval"] = np.asarray(meta["anchor_interval"], np.float32)
+        meta["anchor_min"] = np.asarray(meta["anchor_min"], np.float32)
+        meta["slabs"] = [tuple(s) for s in meta["slabs"]]
         pack = cls(anchors_q=np.fromfile(os.path.join(path, "anchor_q16.bin"), dtype=np.uint16).reshape(-1, 3), **meta)
         rd = lambda name: open(os.path.join(path, name), "rb").read()  # noqa: E731
         for s in range(len(pack.slabs)):
