@@ -86,6 +86,7 @@ class GradReducer:
         self.average = average
         self._hooked = {}           # id(param) -> (param, handle of the hook)
         self._pending = []          # (work, grad) of the collectives in flight
+        self._params = []
         self._armed = False
 
     def arm(self, params):

@@ -24,7 +24,9 @@ class FusedAdam(torch.optim.Adam):
         beta_key = None
         dev = None
         n = 0
-        arr = self._table
+        arr = self.__dict__.get("_table")
+        if arr is None:
+            arr = self._table = (_lib.AdamTensorC * 64)()      # per optimizer: the table is scratch for one launch
         for group in self.param_groups:
             if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
                 raise NotImplementedError("FusedAdam: weight_decay / amsgrad / maximize are not used by GSVC")
@@ -68,8 +70,6 @@ class FusedAdam(torch.optim.Adam):
             arr[i].bias_correction1, arr[i].bias_correction2 = 1.0 - b1 ** t, 1.0 - b2 ** t
         _lib.check(_lib.lib().gsvc_adam_step(n, arr, b1, b2, eps, _lib.current_stream(dev)), "gsvc_adam_step")
         return loss
-
-    _table = (_lib.AdamTensorC * 64)()
 
     @staticmethod
     def _grow(arr):
