@@ -248,3 +248,48 @@ def test_grid_oracle_reproduces_fixture(oracle_lib, tag):
     o0, d0 = oracle_lib.grid_forward(xs, emb, g["offsets"], g["resolutions"], calc_dy_dx=True)
     D = xs.shape[1]
     assert d0.shape == (xs.shape[0], L * D * C)
+
+
+def test_ms_ssim_against_independent_numpy():
+    """gsvc_amd.metrics.ms_ssim (restatement of pytorch_msssim's algorithm, parity unpinned) against a
+    NumPy / SciPy implementation written from the same published description."""
+    from scipy.ndimage import correlate1d
+    from gsvc_amd.metrics import MS_WEIGHTS, ms_ssim, msssim_fn
+    rng = np.random.default_rng(3)
+    H, W = 200, 181                                           # odd side: exercises the pooling's padding rule
+    a = rng.random((2, 3, H, W))
+    b = np.clip(a + rng.normal(0, 0.08, a.shape) + 0.05 * np.sin(np.arange(W) / 7.0), 0, 1)
+
+    g = np.exp(-((np.arange(11) - 5) ** 2) / (2 * 1.5 ** 2))
+    g /= g.sum()
+
+    def filt(x):                                              # valid correlation along H then W
+        x = correlate1d(x, g, axis=-2, mode="constant")[..., 5:-5, :]
+        return correlate1d(x, g, axis=-1, mode="constant")[..., :, 5:-5]
+
+    def pool(x):                                              # 2x2 average, zero padding on odd sides, padded cells counted
+        ph, pw = x.shape[-2] % 2, x.shape[-1] % 2
+        x = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
+        h2, w2 = x.shape[-2] // 2, x.shape[-1] // 2
+        return x[..., :2 * h2, :2 * w2].reshape(x.shape[0], x.shape[1], h2, 2, w2, 2).mean((3, 5))
+
+    x, y = a.copy(), b.copy()
+    terms = []
+    for lvl in range(5):
+        mu1, mu2 = filt(x), filt(y)
+        s1, s2, s12 = filt(x * x) - mu1 ** 2, filt(y * y) - mu2 ** 2, filt(x * y) - mu1 * mu2
+        cs = (2 * s12 + 0.03 ** 2) / (s1 + s2 + 0.03 ** 2)
+        ss = (2 * mu1 * mu2 + 0.01 ** 2) / (mu1 ** 2 + mu2 ** 2 + 0.01 ** 2) * cs
+        if lvl < 4:
+            terms.append(np.maximum(cs.mean((-1, -2)), 0))
+            x, y = pool(x), pool(y)
+        else:
+            terms.append(np.maximum(ss.mean((-1, -2)), 0))
+    ref = np.prod(np.stack(terms) ** np.array(MS_WEIGHTS).reshape(-1, 1, 1), axis=0).mean()
+    got = ms_ssim(T(a.astype(np.float32)), T(b.astype(np.float32)))
+    assert abs(float(got) - ref) < 2e-5, (float(got), ref)
+    assert abs(float(msssim_fn(T(a[0].astype(np.float32))[None], T(b[0].astype(np.float32))[None])) -
+               np.prod(np.stack(terms)[:, 0] ** np.array(MS_WEIGHTS).reshape(-1, 1), axis=0).mean()) < 2e-5
+    assert float(ms_ssim(T(a.astype(np.float32)), T(a.astype(np.float32)))) > 0.99999
+    with pytest.raises(ValueError):
+        ms_ssim(torch.zeros(1, 3, 100, 300), torch.zeros(1, 3, 100, 300))
