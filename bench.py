@@ -263,11 +263,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GSVC_SHARE_GPU"):        # test knob: every rank on device 0 (needs GSVC_DIST_BACKEND=gloo; RCCL wants one GPU per rank)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GSVC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if args.workload == "train_step":
         res = run_train_step(args, rank, world, local_rank, dev)
         if rank == 0:

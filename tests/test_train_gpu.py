@@ -382,3 +382,25 @@ def test_estimate_final_bits_matches_reference():
         ref = float(b["bits::" + f])
         assert abs(float(getattr(info, f)) - ref) <= 2e-5 * abs(ref) + 1e-3, (f, getattr(info, f), ref)
     assert log == str(b["log_info"])
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_through_gloo():
+    """The multi-rank fitting step end to end on GPU tensors: two torchrun ranks on device 0 with the gloo backend (RCCL
+    wants one GPU per rank; the driver's multi-GPU runs use it) — parameter broadcast, gradient all-reduce from the
+    backward hooks, the early overflow decision, per-rank frame shards, one JSON line from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSVC_DIST_BACKEND="gloo", GSVC_SHARE_GPU="1")
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "train_step", "--steps", "3",
+           "--warmup", "1", "--pretrain", "2", "--anchors", "20000", "--height", "272", "--width", "480", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
