@@ -404,3 +404,18 @@ def test_two_ranks_share_one_gpu_through_gloo():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_two_ranks_keep_identical_anchors_through_densification():
+    """Data-parallel densification: statistics summed over ranks + a per-iteration seed for the random thinning keep the
+    replicas' anchor sets, parameters and Adam moments identical across adjust_anchor (tests/_dp_densify_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_dp_densify_worker.py")]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DP_DENSIFY_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
