@@ -105,7 +105,7 @@ __device__ __forceinline__ void bwd_pixel(PixState &p, bool inq, float dx, float
     }
 }
 
-__global__ void __launch_bounds__(64, 5) k_blend_bwd_tile(RasterParams st, const int32_t *__restrict__ tile_offsets,
+__global__ void __launch_bounds__(64, 4) k_blend_bwd_tile(RasterParams st, const int32_t *__restrict__ tile_offsets,
                                                        const int32_t *__restrict__ point_list,
                                                        const uint2 *__restrict__ inst_bbox,
                                                        const GeomRec *__restrict__ geom,
