@@ -419,3 +419,36 @@ def test_two_ranks_keep_identical_anchors_through_densification():
            "--master-port", str(port), os.path.join(root, "tests", "_dp_densify_worker.py")]
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "DP_DENSIFY_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
+
+
+@pytest.mark.gpu
+def test_evaluate_and_checkpoint_round_trip(tmp_path):
+    """report.evaluate returns the reference's evaluation quantities; a checkpoint restores a model that renders the same
+    frames bit for bit and keeps training (optimizer state included)."""
+    from gsvc_amd.ortho_gaussian_renderer import render_frames
+    from gsvc_amd.report import evaluate, load_checkpoint, save_checkpoint
+    pc, cube, opt, pipe, mp, Trainer = _setup(anchors=4000, H=192, W=256)
+    opt.full_precision_training_total = 1000
+    pc.training_setup(opt)
+    tr = Trainer(pc, cube, opt, pipe, mp)
+    for it in range(1, 9):
+        tr.step(it)
+    bg = torch.zeros(3)
+    ev = evaluate(pc, cube, pipe, bg, frame_ids=range(2, 8))
+    assert ev["frames"] == 6 and ev["fps"] > 0
+    for k in ("l1", "psnr", "ssim", "msssim"):
+        assert np.isfinite(ev[k]), (k, ev)
+    assert 0.0 <= ev["ssim"] <= 1.0 and 0.0 <= ev["msssim"] <= 1.0 and ev["psnr"] > 0
+    path = str(tmp_path / "ck.pt")
+    save_checkpoint(pc, path, iteration=8)
+    pc2, cube2, opt2, pipe2, mp2, _ = _setup(anchors=4000, H=192, W=256, seed=5)      # different initial values
+    assert load_checkpoint(pc2, path, training_args=opt2) == 8
+    frames = [cube.get_dummy_frame(i) for i in (3, 4)]
+    a = list(render_frames(frames, pc, pipe, bg))
+    b = list(render_frames(frames, pc2, pipe, bg))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    st1, st2 = pc.optimizer.state[pc._anchor_feat], pc2.optimizer.state[pc2._anchor_feat]
+    assert torch.equal(st1["exp_avg"], st2["exp_avg"]) and float(st1["step"]) == float(st2["step"])
+    opt2.full_precision_training_total = 1000
+    out = Trainer(pc2, cube2, opt2, pipe2, mp2).step(9)
+    assert np.isfinite(float(out.loss))
