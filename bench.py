@@ -1,99 +1,156 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the GSVC hot path on MI355X (contract: see the task statement).
 
-    python bench.py --gpus N --steps K --warmup W [--workload raster_fwd|raster_fwdbwd|train_step]
+    python bench.py --gpus N --steps K --warmup W [--workload headline|train_step|raster_fwd|raster_fwdbwd]
 
-A "step" is one pass of the hot path over one synthetic UVG-shaped 1080p frame resident in HBM.
-  raster_fwd     BASELINE.json configs[1]: 1080p single frame, 200k Gaussians, forward raster only
-  raster_fwdbwd  same scene, forward + backward of the rasterizer (dL/dimage random)
-  train_step     BASELINE.json configs[2]: 1080p, 16-frame z-slab, ~50k visible anchors x K=10 (<=500k Gaussians per
-                 render), one full fitting step = 4 renders (2 frames x 2 views) fwd+bwd, hash grid, entropy
-                 loss (lambda 0.004, TRAINING_ENTROPY mode), SSIM/L1/optical losses, Adam
-N > 1: launched by torch.distributed.run, one rank per GPU; frames shard across ranks (each rank rasterizes
-its own frame of the same video; no data-path collective in these workloads) -> weak scaling.
+Workloads (a "step" is one pass of the hot path over synthetic UVG-shaped 1080p input resident in HBM):
+  train_step     BASELINE.json configs[2] (the largest single-GPU configuration of the metric): 1080p, 16-frame z-slab,
+                 ~50k visible anchors x K=10 = ~500k Gaussians submitted per render, one full fitting step = 4 renders
+                 (2 adjacent frames x 2 opposite views) forward + backward, hash grid, entropy loss (lambda 0.004,
+                 TRAINING_ENTROPY mode), L1 / SSIM / optical-flow losses, Adam; 200 untimed fitting steps first
+  raster_fwd     BASELINE.json configs[1]: 1080p single frame, 200k Gaussians, forward raster only (render fps)
+  raster_fwdbwd  same scene, forward + backward of the rasterizer alone
+  headline       (default) train_step as the top-level value / ms_per_step / roofline / cpu_baseline, plus a short
+                 raster_fwd run reported under the side key "raster_fwd" (render fps, single and two-view)
 
-One JSON line on rank 0.  `value` = Gaussians rasterized per second, whole job (sum over ranks of Gaussians
-with radius > 0 per step, x steps, / max-over-ranks wall time).  `roofline` is for the dominant kernel,
-timed with HIP events on its own stream inside this process (second pass of K steps with the library's
-per-kernel event hooks on).  `cpu_baseline` = the CPU oracle (a port, not the product) on the same scene.
+--gpus N > 1: when not already under torch.distributed.run (no WORLD_SIZE in the environment) this process starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD before anything touches the GPU,
+relays its JSON line and exits with its return code.  One rank per GPU over RCCL; frames shard across ranks
+(rank r samples its pairs from its own block of frames), gradients are all-reduced once per step -> weak scaling.
+
+One JSON line on rank 0.  `value` = Gaussians rasterized per second, whole job (sum over ranks and over the 4
+renders of Gaussians with radius > 0, x steps, / max-over-ranks wall time).  `roofline` is for the dominant
+rasterizer kernel, timed with HIP events on its launch stream inside this process (a second pass of K steps with
+the library's per-kernel event hooks on); `roofline.traffic` comes from rocprofv3 PMC passes of this same command
+(they cannot run inside this process): the file and binary version they were taken from are named beside it.
+`cpu_baseline` = the CPU oracle (a port, not the product) on a bounded sample of the same workload.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "train-step Gaussians/sec + render fps @1080p"
+PAIR_NOTE = ("two-view frames come from the fused gsvc_raster_forward_pair pass: the back-to-front composite of the opposite "
+             "view has no T<1e-4 early exit, so pixels agree with two separate renders to 2.5e-3, not to the 1e-4 of "
+             "the single-view path (inference only; training always uses the single-view kernels)")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="headline", choices=["headline", "raster_fwd", "raster_fwdbwd", "train_step"],
-                    help="headline = raster_fwd (BASELINE.json configs[1], the value) + a short train_step (configs[2]) "
-                         "reported in the same JSON line under 'train_step'")
-    ap.add_argument("--gaussians", type=int, default=200_000)
+    ap.add_argument("--workload", default="headline", choices=["headline", "raster_fwd", "raster_fwdbwd", "train_step"])
+    ap.add_argument("--gaussians", type=int, default=200_000, help="raster workloads: Gaussians in the slab")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--frames", type=int, default=600)
+    ap.add_argument("--frames", type=int, default=600, help="raster workloads: frames of the cube")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--anchors", type=int, default=220_000, help="train_step: anchors in the 64-frame cube")
+    ap.add_argument("--no-side", action="store_true", help="headline: skip the raster_fwd side run")
+    ap.add_argument("--anchors", type=int, default=245_000,
+                    help="train_step: anchors in the cube (245k in 64 frames x 1.1 bleed -> ~50k in a 16-frame slab)")
     ap.add_argument("--train-frames", type=int, default=64, help="train_step: frames of the synthetic video")
-    ap.add_argument("--pretrain", type=int, default=30,
-                    help="train_step: extra untimed steps before the warmup (the per-step tensor sizes vary with the visible set; "
-                         "until the caching allocator has seen them, steps pay hipMalloc calls that synchronise the device)")
-    return ap.parse_args()
+    ap.add_argument("--pretrain", type=int, default=200,
+                    help="train_step: untimed fitting steps before the warmup (BASELINE.md section 2: 200, so that opacities "
+                         "and scales are no longer at their initial values; they also let the caching allocator see every "
+                         "tensor size the varying visible set produces)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(sc, workload):
-    """Oracle (CPU port of the same algorithm) on the host cores of this box, same scene, one pass."""
-    import oracle
-    oracle.build()
-    s = sc["settings"]
-    st = oracle.make_settings(s["H"], s["W"], s["x_min"], s["y_min"], s["scale"], s["threshold"], s["viewmatrix"],
-                              bg=s["bg"], scale_modifier=s["scale_modifier"])
-    cores = os.cpu_count() or 1
+# ------------------------------------------------------------------------------------------------ launcher
+def spawn_ranks(args) -> int:
+    """--gpus N without WORLD_SIZE: run N ranks of this script under torch.distributed.run as a child process.
+    Nothing in this (parent) process has touched the GPU: torch.cuda.device_count() does not initialise it."""
+    import socket
+    import torch
+    share = bool(os.environ.get("GSVC_SHARE_GPU"))
+    have = torch.cuda.device_count()
+    if not share and have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); refusing to run fewer "
+                         f"ranks under the same label (GSVC_SHARE_GPU=1 GSVC_DIST_BACKEND=gloo is the single-GPU test knob)\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            sys.stderr.write(out + "\n")
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited without a JSON line\n")
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC extract (tools/pmc_extract.py) + where it came from."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        data = json.load(open(path))
+        val = data.get(workload, {}).get(kernel)
+        src = {"measured_live": False, "file": "profiles/pmc_latest.json",
+               "binary": data.get("_binary", {}).get(workload, "unknown"),
+               "passes": data.get("_source", {}).get(workload, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")}
+        return val, src
+    except Exception:  # noqa: BLE001
+        return None, {"measured_live": False, "file": None}
+
+
+def timed(torch, dist, world, fn, steps):
+    """Barrier + synchronize on both sides, max over ranks."""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    fwd = oracle.raster_forward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"],
-                                num_threads=cores)
-    t_f = time.perf_counter() - t0
-    n_vis = int((fwd.radii > 0).sum())
-    # bounded sample: repeat the pass until ~10 s of CPU work have been timed
-    reps = 1
-    while t_f < 10.0 and reps < 64:
-        t0 = time.perf_counter()
-        oracle.raster_forward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"], num_threads=cores)
-        t_f += time.perf_counter() - t0
-        reps += 1
-    sample = (f"{reps} forward passes of the same {s['H']}x{s['W']} scene ({sc['means3D'].shape[0]} Gaussians); preprocess + "
-              f"sort scalar, blend over {cores} OpenMP threads")
-    used = cores
-    units, t = n_vis * reps, t_f
-    if workload == "raster_fwdbwd":      # one forward+backward pass = mean forward time + one scalar backward
-        dL = np.ones((3, s["H"], s["W"]), np.float32)
-        t0 = time.perf_counter()
-        oracle.raster_backward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"], fwd, dL)
-        units, t = n_vis, t_f / reps + (time.perf_counter() - t0)
-        sample += " (mean) + 1 scalar backward pass"
-    n_vis = units
-    return {"value": n_vis / t, "unit": "Gaussians/s", "cores": used, "kind": "port", "sample": sample,
-            "seconds": round(t, 3)}
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
 
 
-def run_train_step(args, rank, world, local_rank, dev):
-    """BASELINE.json configs[2] on one GPU; frames shard over ranks with one gradient all-reduce per step."""
+def reduce_sum_max(torch, dist, world, dev, total, elapsed):
+    t = torch.tensor([float(total), float(elapsed)], device=dev, dtype=torch.float64)
+    if world > 1:
+        a, b = t[0:1].clone(), t[1:2].clone()
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        dist.all_reduce(b, op=dist.ReduceOp.MAX)
+        return float(a.item()), float(b.item())
+    return float(t[0].item()), float(t[1].item())
+
+
+# ------------------------------------------------------------------------------------------------ train_step
+def run_train_step(args, rank, world, dev):
+    """BASELINE.json configs[2]; frames shard over ranks with one gradient all-reduce per step."""
+    import numpy as np
+    import torch
     import torch.distributed as dist
-    from gsvc_amd import _lib, synthetic
+    from gsvc_amd import _lib
+    from gsvc_amd import dist as gdist
     from gsvc_amd.arguments import cfg_20240919
     from gsvc_amd.frame import SyntheticFrameCube
     from gsvc_amd.model import GaussianModel
@@ -108,7 +165,7 @@ def run_train_step(args, rank, world, local_rank, dev):
     opt.full_precision_training_total, opt.quantized_training_total = 0, 0
     opt.entropy_constrained_train_total = 10 ** 9
     opt.start_stat, opt.update_until = 0, 10 ** 9         # densification statistics on (adjust_anchor itself runs from
-                                                          # iteration 1500 every 100 steps: not reached by this short run)
+                                                          # iteration 1500 every 100 steps: not reached by this run)
     opt.pause_densification = 0
     torch.manual_seed(0)
     np.random.seed(0)
@@ -122,39 +179,43 @@ def run_train_step(args, rank, world, local_rank, dev):
     pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
     pc.training_setup(opt)
     if world > 1:
-        from gsvc_amd import dist as gdist
         gdist.broadcast_parameters(pc)       # replicas start identical (they are built from the same seeds anyway)
     trainer = Trainer(pc, cube, opt, pipe, mp_, seed=0)
     it = [0]
+    last = [None]
 
     def step():
         it[0] += 1
-        return trainer.step(it[0])
+        last[0] = trainer.step(it[0])
+        return last[0]
 
     for _ in range(args.pretrain + args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+        step()
     active = torch.zeros((), device=dev, dtype=torch.float64)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-        active += out.active_gaussians
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    stats = torch.tensor([float(active.item()), elapsed], device=dev, dtype=torch.float64)
-    total_units = stats[0:1].clone()
-    tmax = stats[1:2].clone()
-    if world > 1:
-        dist.all_reduce(total_units, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_units, elapsed = float(total_units.item()), float(tmax.item())
 
+    def counted():
+        nonlocal active
+        active += step().active_gaussians
+
+    elapsed = timed(torch, dist, world, counted, args.steps)
+    total_units, elapsed = reduce_sum_max(torch, dist, world, dev, active.item(), elapsed)
+
+    # exposed communication: the same K steps with the gradient exchange switched off (replicas diverge: last thing
+    # measured on the model's gradients; parameters are re-broadcast afterwards)
+    comm = None
+    if world > 1:
+        trainer.reducer.enabled = False
+        for _ in range(3):
+            step()
+        e2 = timed(torch, dist, world, step, args.steps)
+        trainer.reducer.enabled = True
+        _, e2 = reduce_sum_max(torch, dist, world, dev, 0.0, e2)
+        gdist.broadcast_parameters(pc)
+        comm = {"ms_per_step_without_exchange": 1e3 * e2 / args.steps,
+                "exposed_ms_per_step": 1e3 * (elapsed - e2) / args.steps,
+                "gradient_bytes_per_step": 4 * sum(p.numel() for g in pc.optimizer.param_groups for p in g["params"] if p.requires_grad)}
+
+    # per-kernel pass: same K steps with HIP events around every launch on the launch stream
     _lib.profile_enable(True)
     inst = 0
     for _ in range(args.steps):
@@ -163,8 +224,36 @@ def run_train_step(args, rank, world, local_rank, dev):
     torch.cuda.synchronize()
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
+    out = last[0]
+
+    # decoder loop (reference utils/report_utils.py:297-319: per frame the visibility test, the anchor -> Gaussian
+    # generation with the MLPs, and the two-view frame) on every rank's own frames
+    from gsvc_amd.generate import GenerateMode
+    from gsvc_amd.ortho_gaussian_renderer import render_frames, render_pair
+    frames_e2e = [cube.get_dummy_frame(i) for i in range(trainer.lo, max(trainer.lo + 1, min(trainer.hi, trainer.lo + 48)))]
+    n_fr = len(frames_e2e)
+    for fr in frames_e2e[:4]:
+        render_pair(fr, pc, pipe, trainer.background, mode=GenerateMode.DECODING_AS_IS)
+
+    def pair_loop():
+        for fr in frames_e2e:
+            render_pair(fr, pc, pipe, trainer.background, mode=GenerateMode.DECODING_AS_IS)
+
+    def frames_loop():
+        for _ in render_frames(frames_e2e, pc, pipe, trainer.background):
+            pass
+
+    tp = timed(torch, dist, world, pair_loop, 1)
+    n_all, tp = reduce_sum_max(torch, dist, world, dev, n_fr, tp)
+    pair_fps = n_all / tp
+    for _ in render_frames(frames_e2e[:8], pc, pipe, trainer.background):
+        pass
+    tf = timed(torch, dist, world, frames_loop, 1)
+    n_all, tf = reduce_sum_max(torch, dist, world, dev, n_fr, tf)
+    frames_fps = n_all / tf
     if rank != 0:
         return None
+
     HW = H * W
     n_inst = inst / (4 * args.steps)                      # instances per render
     P = float(sum(r.radii.numel() for r in out.renders)) / 4
@@ -178,43 +267,31 @@ def run_train_step(args, rank, world, local_rank, dev):
     dom_bytes = alg[dom]
     achieved = dom_bytes / (kern[dom]["avg_us"] * 1e-6) / 1e9
     kernel_us = sum(v["avg_us"] * v["launches"] for v in kern.values()) / args.steps
+    traffic, traffic_src = pmc_traffic("train_step", dom)
     res = {
-        "metric": "train-step Gaussians/sec + render fps @1080p", "value": total_units / elapsed, "unit": "Gaussians/s",
+        "metric": METRIC, "value": total_units / elapsed, "unit": "Gaussians/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"train_step: {H}x{W}, {T}-frame synthetic video, {pc._anchor.shape[0]} anchors x K=10, 16-frame "
-                               f"z-slab (BASELINE.json configs[2]); 4 renders/step fwd+bwd + hash grid + entropy loss "
-                               f"(lambda={opt.lmbda}, TRAINING_ENTROPY) + L1/SSIM/optical + Adam; one frame pair per rank",
+        "config": {"workload": f"train_step (BASELINE.json configs[2]): {H}x{W}, {T}-frame synthetic video, {pc._anchor.shape[0]} "
+                               f"anchors x K=10, 16-frame z-slab; 4 renders/step fwd+bwd + hash grid + entropy loss "
+                               f"(lambda={opt.lmbda}, TRAINING_ENTROPY) + L1/SSIM/optical + Adam; one frame pair per rank; "
+                               f"{args.pretrain} untimed fitting steps before the warmup",
                    "gaussians_per_render": P, "active_per_render": n_vis, "instances_per_render": n_inst,
-                   "parallelism": f"frame-shard x{world} + grad all-reduce"},
-        "render_fps": None,
+                   "visible_anchors_per_render": P / pc.n_offsets,
+                   "parallelism": f"frame-shard x{world} + gradient all-reduce" if world > 1 else "single GPU"},
+        "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+        "dist_backend": (dist.get_backend() if world > 1 else None),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": dom_bytes,
-                     "avg_launch_us": kern[dom]["avg_us"]},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": kern[dom]["avg_us"]},
         "gsvc_kernel_us_per_step": kernel_us,
         "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] / args.steps} for k, v in kern.items()},
+        "render_pair_fps_end_to_end": pair_fps,
+        "render_frames_fps_end_to_end": frames_fps,
+        "render_fps_note": PAIR_NOTE,
     }
-    # end-to-end frame rate of the decoder's render loop (reference utils/report_utils.py:297-319: per frame the visibility
-    # test, the anchor -> Gaussian generation with the MLPs, and the two-view frame), on the model just fitted
-    from gsvc_amd.generate import GenerateMode
-    from gsvc_amd.ortho_gaussian_renderer import render_pair
-    frames_e2e = [cube.get_dummy_frame(i) for i in range(trainer.lo, max(trainer.lo + 1, min(trainer.hi, trainer.lo + 48)))]
-    for fr in frames_e2e[:4]:
-        render_pair(fr, pc, pipe, trainer.background, mode=GenerateMode.DECODING_AS_IS)
-    torch.cuda.synchronize()
-    te0 = time.perf_counter()
-    for fr in frames_e2e:
-        render_pair(fr, pc, pipe, trainer.background, mode=GenerateMode.DECODING_AS_IS)
-    torch.cuda.synchronize()
-    res["render_pair_fps_end_to_end"] = len(frames_e2e) / (time.perf_counter() - te0) * world
-    from gsvc_amd.ortho_gaussian_renderer import render_frames
-    for _ in render_frames(frames_e2e[:8], pc, pipe, trainer.background):
-        pass
-    torch.cuda.synchronize()
-    te0 = time.perf_counter()
-    n_img = sum(1 for _ in render_frames(frames_e2e, pc, pipe, trainer.background))
-    torch.cuda.synchronize()
-    res["render_frames_fps_end_to_end"] = n_img / (time.perf_counter() - te0) * world
+    if comm is not None:
+        res["gradient_exchange"] = comm
     if world == 1:
         # stream codec round trip of the fitted model and the decoder's frame rate INCLUDING the entropy decode
         import copy
@@ -250,42 +327,54 @@ def run_train_step(args, rank, world, local_rank, dev):
         oracle.raster_backward(st, *arrs, fwd, np.ones((3, H, W), np.float32))
         tc = time.perf_counter() - t0
         res["cpu_baseline"] = {"value": float((fwd.radii > 0).sum()) / tc, "unit": "Gaussians/s", "cores": cores, "kind": "port",
-                               "sample": "rasterizer forward (OpenMP) + backward (scalar) of ONE of the step's 4 renders; "
-                                         "MLPs/grid/loss not included", "seconds": round(tc, 3)}
+                               "sample": "rasterizer forward (preprocess + sort scalar, blend on all cores with OpenMP) + backward "
+                                         "(scalar) of ONE of the timed step's 4 renders, same Gaussians; the MLPs, hash grid, rate "
+                                         "and image losses of the step are NOT in the CPU sample (it does less work per Gaussian)",
+                               "seconds": round(tc, 3)}
     return res
 
 
-def main():
-    args = parse()
-    headline = args.workload == "headline"
-    if headline:
-        args.workload = "raster_fwd"
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("GSVC_SHARE_GPU"):        # test knob: every rank on device 0 (needs GSVC_DIST_BACKEND=gloo; RCCL wants one GPU per rank)
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        backend = os.environ.get("GSVC_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    if args.workload == "train_step":
-        res = run_train_step(args, rank, world, local_rank, dev)
-        if rank == 0:
-            print(json.dumps(res))
-        if world > 1:
-            import torch.distributed as dist
-            dist.destroy_process_group()
-        return
+# ------------------------------------------------------------------------------------------------ raster
+def cpu_baseline_raster(sc, workload):
+    """Oracle (CPU port of the same algorithm) on the host cores of this box, same scene, bounded sample."""
+    import numpy as np
+    import oracle
+    oracle.build()
+    s = sc["settings"]
+    st = oracle.make_settings(s["H"], s["W"], s["x_min"], s["y_min"], s["scale"], s["threshold"], s["viewmatrix"],
+                              bg=s["bg"], scale_modifier=s["scale_modifier"])
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    fwd = oracle.raster_forward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"],
+                                num_threads=cores)
+    t_f = time.perf_counter() - t0
+    n_vis = int((fwd.radii > 0).sum())
+    reps = 1
+    while t_f < 10.0 and reps < 64:       # bounded sample: repeat the pass until ~10 s of CPU work have been timed
+        t0 = time.perf_counter()
+        oracle.raster_forward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"], num_threads=cores)
+        t_f += time.perf_counter() - t0
+        reps += 1
+    sample = (f"{reps} forward passes of the same {s['H']}x{s['W']} scene ({sc['means3D'].shape[0]} Gaussians); preprocess + "
+              f"sort scalar, blend over {cores} OpenMP threads")
+    units, t = n_vis * reps, t_f
+    if workload == "raster_fwdbwd":      # one forward+backward pass = mean forward time + one scalar backward
+        dL = np.ones((3, s["H"], s["W"]), np.float32)
+        t0 = time.perf_counter()
+        oracle.raster_backward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"], fwd, dL)
+        units, t = n_vis, t_f / reps + (time.perf_counter() - t0)
+        sample += " (mean) + 1 scalar backward pass"
+    return {"value": units / t, "unit": "Gaussians/s", "cores": cores, "kind": "port", "sample": sample, "seconds": round(t, 3)}
+
+
+def run_raster(args, rank, world, dev, workload, cpu_baseline):
+    """BASELINE.json configs[1] (and its forward+backward variant): rank r renders its own frame of the same video."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
     from gsvc_amd import _lib, rasterizer, synthetic
 
     H, W, T, P = args.height, args.width, args.frames, args.gaussians
-    # frames shard across ranks: rank r renders its own frame of the same video
     frame_id = T // 2 + rank
     sc = synthetic.raster_scene(P, H=H, W=W, T=T, seed=2026 + rank, window_frames=16, frame_id=frame_id)
     s = sc["settings"]
@@ -304,14 +393,13 @@ def main():
     cap = int(n_inst * 1.1) + 1024
     grads = [torch.empty(P, 3, device=dev), torch.empty(P, 3, device=dev), torch.empty(P, 3, device=dev),
              torch.empty(P, device=dev), torch.empty(P, 3, device=dev), torch.empty(P, 4, device=dev)]
-    scratch = torch.empty(P * 16, device=dev)
+    scratch = torch.empty(rasterizer.backward_scratch_floats(P, cap), device=dev)
     L = _lib.lib()
-    import ctypes as C
 
     def step():
         image, radii, st = rasterizer.raster_forward(cs, d["means3D"], d["colors"], d["opacities"], d["scales"],
                                                      d["rotations"], max_instances=cap, sync=False)
-        if args.workload == "raster_fwdbwd":
+        if workload == "raster_fwdbwd":
             _lib.check(L.gsvc_raster_backward(
                 C.byref(cs), P, cap, _lib.ptr(d["means3D"]), _lib.ptr(d["colors"]), _lib.ptr(d["opacities"]),
                 _lib.ptr(d["scales"]), _lib.ptr(d["rotations"]), _lib.ptr(radii), _lib.ptr(st.geom), _lib.ptr(st.binning),
@@ -323,142 +411,135 @@ def main():
         return rasterizer.raster_forward(cs, d["means3D"], d["colors"], d["opacities"], d["scales"], d["rotations"],
                                          max_instances=cap, sync=False, pair=True)[0]
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-
-    units = torch.tensor([float(n_vis) * args.steps, elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        import torch.distributed as dist
-        tmax = units[1:2].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tot = units[0:1].clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed, total_units = float(tmax.item()), float(tot.item())
-    else:
-        total_units = float(units[0].item())
+    elapsed = timed(torch, dist, world, step, args.steps)
+    total_units, elapsed = reduce_sum_max(torch, dist, world, dev, float(n_vis) * args.steps, elapsed)
 
     # two-view frames (the reference's fps definition: view + opposite view + flip + average) from the fused pass
     for _ in range(3):
         step_pair()
-    torch.cuda.synchronize()
-    tp0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_pair()
-    torch.cuda.synchronize()
-    pair_fps = args.steps / (time.perf_counter() - tp0)
+    tp = timed(torch, dist, world, step_pair, args.steps)
+    _, tp = reduce_sum_max(torch, dist, world, dev, 0.0, tp)
+    pair_fps = args.steps * world / tp
 
     # the same two-view frames pipelined over two HIP streams (a decoder renders frame after frame: the latency-bound
     # binning kernels of frame i+1 overlap the compositing of frame i); reported beside, never instead of, the
     # single-stream numbers
     pipelined_fps = None
-    if args.workload == "raster_fwd":
+    if workload == "raster_fwd":
         streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-        def pipelined(n):
-            for i in range(n):
-                with torch.cuda.stream(streams[i & 1]):
-                    step_pair()
-        pipelined(4)
-        torch.cuda.synchronize()
-        tq0 = time.perf_counter()
-        pipelined(args.steps)
-        torch.cuda.synchronize()
-        pipelined_fps = args.steps / (time.perf_counter() - tq0)
+        k = [0]
 
-    # per-kernel pass: same K steps with HIP events around every launch on the launch stream
+        def pipelined():
+            k[0] += 1
+            with torch.cuda.stream(streams[k[0] & 1]):
+                step_pair()
+        for _ in range(4):
+            pipelined()
+        tq = timed(torch, dist, world, pipelined, args.steps)
+        _, tq = reduce_sum_max(torch, dist, world, dev, 0.0, tq)
+        pipelined_fps = args.steps * world / tq
+
     _lib.profile_enable(True)
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
+    if rank != 0:
+        return None
+    HW = H * W
+    alg = {  # algorithmic bytes per launch (SURVEY.md section 8d / BASELINE.md section 3)
+        "k_preprocess": 60 * P + 44 * n_vis, "k_blend": 40 * n_inst + 20 * HW, "k_blend_bwd": 40 * n_inst + 20 * HW,
+        "k_gaussian_bwd": 88 * n_vis + 124 * P,
+    }
+    kern = {k: {"launches": n, "avg_us": 1e3 * ms / max(n, 1)} for k, (n, ms) in prof.items()}
+    dom = max(kern, key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
+    dom_bytes = alg.get(dom, 0)
+    achieved = dom_bytes / (kern[dom]["avg_us"] * 1e-6) / 1e9 if dom_bytes else 0.0
+    pipe_bytes = 60 * P + 44 * n_vis + 40 * n_inst + 20 * HW
+    if workload == "raster_fwdbwd":
+        pipe_bytes += 40 * n_inst + 20 * HW + 88 * n_vis + 124 * P
+    kernel_us = sum(v["avg_us"] * v["launches"] for v in kern.values()) / args.steps
+    traffic, traffic_src = pmc_traffic(workload, dom)
+    cfg_name = "BASELINE.json configs[1]" if (H, W, P) == (1080, 1920, 200_000) else "raster set of BASELINE.md section 2"
+    out = {
+        "metric": METRIC, "value": total_units / elapsed, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{workload} ({cfg_name}): {H}x{W} single frame of a {T}-frame cube, {P} Gaussians in a "
+                               f"16-frame z-slab; frames sharded 1 per rank",
+                   "gaussians": P, "visible": n_vis, "instances": n_inst, "max_tile_list": max_tile,
+                   "parallelism": f"frame-shard x{world}"},
+        "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+        "render_fps": args.steps * world / elapsed,
+        "render_fps_two_view": pair_fps,
+        "render_fps_two_view_2streams": pipelined_fps,
+        "render_fps_note": PAIR_NOTE,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": kern[dom]["avg_us"]},
+        "roofline_pipeline": {"algorithmic_bytes_per_step": pipe_bytes, "kernel_us_per_step": kernel_us,
+                              "achieved": pipe_bytes / (kernel_us * 1e-6) / 1e9, "unit": "GB/s",
+                              "achieved_on_wall_ms_per_step": pipe_bytes / (elapsed / args.steps) / 1e9},
+        "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] / args.steps}
+                    for k, v in kern.items()},
+    }
+    if cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_raster(sc, workload)
+    del d, dL, grads, scratch
+    torch.cuda.empty_cache()
+    return out
 
-    if rank == 0:
-        HW = H * W
-        alg = {  # algorithmic bytes per launch (SURVEY.md section 8d / BASELINE.md section 3)
-            "k_preprocess": 60 * P + 44 * n_vis,
-            "k_blend": 40 * n_inst + 20 * HW,
-            "k_blend_bwd": 40 * n_inst + 20 * HW,
-            "k_gaussian_bwd": 88 * n_vis + 124 * P,
-        }
-        kern = {k: {"launches": n, "avg_us": 1e3 * ms / max(n, 1)} for k, (n, ms) in prof.items()}
-        dom = max(kern, key=lambda k: kern[k]["avg_us"] * kern[k]["launches"])
-        dom_bytes = alg.get(dom, 0)
-        achieved = dom_bytes / (kern[dom]["avg_us"] * 1e-6) / 1e9 if dom_bytes else 0.0
-        pipe_bytes = 60 * P + 44 * n_vis + 40 * n_inst + 20 * HW
-        if args.workload == "raster_fwdbwd":
-            pipe_bytes += 40 * n_inst + 20 * HW + 88 * n_vis + 124 * P
-        kernel_us = sum(v["avg_us"] * v["launches"] for v in kern.values()) / args.steps
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus}\n")
+        sys.exit(2)
+    import torch
+    if os.environ.get("GSVC_SHARE_GPU"):        # test knob: every rank on device 0 (needs GSVC_DIST_BACKEND=gloo; RCCL wants one GPU per rank)
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get("GSVC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    cpu = world == 1 and not args.no_cpu_baseline
+    if args.workload in ("headline", "train_step"):
+        res = run_train_step(args, rank, world, dev)
+        if args.workload == "headline" and not args.no_side and world == 1:
+            # second term of the metric: render fps at 1080p on BASELINE.json configs[1]; a failure here must not take
+            # the train-step line down
             try:
-                traffic = json.load(open(pmc_path)).get(args.workload, {}).get(dom)
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "train-step Gaussians/sec + render fps @1080p",
-            "value": total_units / elapsed,
-            "unit": "Gaussians/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {H}x{W} single frame of a {T}-frame cube, {P} Gaussians in a "
-                                   f"16-frame z-slab (BASELINE.json configs[1]); frames sharded 1 per rank",
-                       "gaussians": P, "visible": n_vis, "instances": n_inst, "max_tile_list": max_tile,
-                       "parallelism": f"frame-shard x{world}"},
-            "render_fps": args.steps * world / elapsed,
-            "render_fps_two_view": pair_fps * world,
-            "render_fps_two_view_2streams": pipelined_fps * world if pipelined_fps else None,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": kern[dom]["avg_us"]},
-            "roofline_pipeline": {"algorithmic_bytes_per_step": pipe_bytes, "kernel_us_per_step": kernel_us,
-                                  "achieved": pipe_bytes / (kernel_us * 1e-6) / 1e9, "unit": "GB/s"},
-            "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] / args.steps}
-                        for k, v in kern.items()},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, args.workload)
-    ts = None
-    if headline:
-        # second workload of the headline metric: the full fitting step (BASELINE.json configs[2]); failures here
-        # must not take the raster line down
-        try:
-            import copy
-            a2 = copy.copy(args)
-            a2.steps, a2.warmup, a2.no_cpu_baseline = min(args.steps, 20), min(args.warmup, 4), True
-            del d, dL, grads, scratch
-            torch.cuda.empty_cache()
-            ts = run_train_step(a2, rank, world, local_rank, dev)
-        except Exception as e:  # noqa: BLE001
-            ts = {"error": f"{type(e).__name__}: {e}"}
+                import copy
+                a2 = copy.copy(args)
+                a2.steps, a2.warmup = max(args.steps, 100), max(args.warmup, 10)
+                torch.cuda.empty_cache()
+                side = run_raster(a2, rank, world, dev, "raster_fwd", cpu_baseline=False)
+            except Exception as e:  # noqa: BLE001
+                side = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                keep = ("value", "unit", "ms_per_step", "steps", "config", "render_fps", "render_fps_two_view",
+                        "render_fps_two_view_2streams", "render_fps_note", "roofline", "roofline_pipeline", "kernels", "error")
+                res["raster_fwd"] = {k: side[k] for k in keep if k in side}
+                if "render_fps" in side:
+                    res["render_fps"] = side["render_fps"]
+                    res["render_fps_two_view"] = side["render_fps_two_view"]
+    else:
+        res = run_raster(args, rank, world, dev, args.workload, cpu_baseline=cpu)
     if rank == 0:
-        if ts is not None:
-            out["train_step"] = {k: ts[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "gsvc_kernel_us_per_step",
-                                                     "kernels", "roofline", "render_pair_fps_end_to_end", "render_frames_fps_end_to_end", "stream_codec") if k in ts} \
-                if "error" not in ts else ts
-        print(json.dumps(out))
+        print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgsvc_hip.so")
+LIB_PATH = os.environ.get("GSVC_LIB_PATH") or os.path.join(_HERE, "csrc", "libgsvc_hip.so")   # env: kernel experiments only
 _lib = None
 
 
@@ -54,6 +54,7 @@ _SIGNATURES = {
     "gsvc_raster_visible_filter": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_raster_forward": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64] + [_vp] * 11),
     "gsvc_raster_forward_pair": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64] + [_vp] * 11),
+    "gsvc_raster_backward_scratch_bytes": (_i64, [_i64, _i64]),
     "gsvc_raster_backward": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64] + [_vp] * 18),
     "gsvc_raster_binning_layout": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gsvc_raster_image_layout": (C.c_int, [C.POINTER(RasterSettingsC), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -6,15 +6,17 @@
 //   B1 blend_bwd     one wave per 16x16 tile (lane l owns pixel l of each 8x8 quadrant) walks the tile's sorted list
 //                    back to front in chunks of 64 entries: bbox + exact ellipse test per quadrant, replay of the alpha
 //                    compositing per pixel, per Gaussian nine sums (moments of h = G dL/dalpha and the colour
-//                    gradients) reduced over the wave with permlane swaps + DPP, flushed per chunk with 36-byte
-//                    atomic segments into the per-Gaussian accumulator.
-//   B2 gaussian_bwd  one lane per Gaussian: conic -> 2-D covariance -> 3-D covariance -> (scale, quaternion),
+//                    gradients) reduced over the wave with permlane swaps + DPP (two entries per pass), written per chunk
+//                    as whole 64-byte rows — one per (tile, Gaussian) instance, at the row index the sort kernel left in
+//                    gslot — with plain stores: no atomics, no zero-fill pass, deterministic.
+//   B2 gaussian_bwd  one lane per Gaussian: adds up the Gaussian's rows (contiguous, one per tile of its rectangle), then
+//                    conic -> 2-D covariance -> 3-D covariance -> (scale, quaternion),
 //                    screen-space -> world mean (constant orthographic Jacobian, no covariance->mean term).
 #include "raster_common.h"
 
-namespace gsvc {
+#include <cstdlib>
 
-constexpr int ACC_STRIDE = 16;  // floats per Gaussian in the accumulator (9 used, 64-B rows)
+namespace gsvc {
 
 // Nine per-Gaussian sums over the wave in 24 cross-lane instructions (a plain DPP butterfly needs 54): values 0..7 are
 // reduced "transposed" — every halving step also halves the number of live registers (v_permlane32_swap / v_permlane16_swap move half of one register into the
@@ -61,6 +63,73 @@ __device__ __forceinline__ void wave_sum9_spread(float &a0, float &a1, float &a2
                  : "s"(odd_half_rows));
 }
 
+// The same reduction for TWO list entries at once: the two dependent chains are issued stage by stage side by side, so
+// each chain's cross-lane latency (and the wait states between a VALU write and a DPP read) is covered by the other's
+// instructions.  The two ninth values share one chain: a permlane32 swap + add leaves A's in the lower and B's in the
+// upper 32 lanes of a8, five DPP steps finish both.  Afterwards: a0 / b0 hold, in lane group g = lane / 8, the total
+// of value g of entry A / B; a8 holds A's ninth total in lane 31 and B's in lane 63.  61 instructions for two entries.
+__device__ __forceinline__ void wave_sum9_spread_x2(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
+                                                    float &a6, float &a7, float &a8, float &b0, float &b1, float &b2,
+                                                    float &b3, float &b4, float &b5, float &b6, float &b7, float &b8)
+{
+    const unsigned long long odd_half_rows = 0xFF00FF00FF00FF00ull;
+    asm volatile("s_nop 1\n"
+                 "v_permlane32_swap_b32 %0, %4\n"
+                 "v_permlane32_swap_b32 %1, %5\n"
+                 "v_permlane32_swap_b32 %2, %6\n"
+                 "v_permlane32_swap_b32 %3, %7\n"
+                 "v_permlane32_swap_b32 %9, %13\n"
+                 "v_permlane32_swap_b32 %10, %14\n"
+                 "v_permlane32_swap_b32 %11, %15\n"
+                 "v_permlane32_swap_b32 %12, %16\n"
+                 "v_permlane32_swap_b32 %8, %17\n"
+                 "s_nop 1\n"
+                 "v_add_f32 %0, %0, %4\n"
+                 "v_add_f32 %1, %1, %5\n"
+                 "v_add_f32 %2, %2, %6\n"
+                 "v_add_f32 %3, %3, %7\n"
+                 "v_add_f32 %9, %9, %13\n"
+                 "v_add_f32 %10, %10, %14\n"
+                 "v_add_f32 %11, %11, %15\n"
+                 "v_add_f32 %12, %12, %16\n"
+                 "v_add_f32 %8, %8, %17\n"
+                 "s_nop 1\n"
+                 "v_permlane16_swap_b32 %0, %2\n"
+                 "v_permlane16_swap_b32 %1, %3\n"
+                 "v_permlane16_swap_b32 %9, %11\n"
+                 "v_permlane16_swap_b32 %10, %12\n"
+                 "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32 %0, %0, %2\n"
+                 "v_add_f32 %1, %1, %3\n"
+                 "v_add_f32 %9, %9, %11\n"
+                 "v_add_f32 %10, %10, %12\n"
+                 "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %9, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %10, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_cndmask_b32_e64 %0, %0, %1, %18\n"
+                 "v_cndmask_b32_e64 %9, %9, %10, %18\n"
+                 "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %9, %9, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %9, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(b0),
+                   "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7), "+v"(b8)
+                 : "s"(odd_half_rows));
+}
+
 __device__ __forceinline__ int sext16b(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 
 __device__ __forceinline__ bool bbox_hits_b(uint2 bb, int qx0, int qy0)
@@ -68,81 +137,128 @@ __device__ __forceinline__ bool bbox_hits_b(uint2 bb, int qx0, int qy0)
     return !(sext16b(bb.x) > qx0 + 7 || sext16b(bb.x >> 16) < qx0 || sext16b(bb.y) > qy0 + 7 || sext16b(bb.y >> 16) < qy0);
 }
 
-// ONE wave per 16x16 tile; lane l owns pixel l of each of the four 8x8 quadrants and
-// walks the quadrants a Gaussian can reach one after the other (wave-uniform 4-bit mask from the bbox test), adding
-// its nine partial sums in registers.  One DPP reduction per (tile, Gaussian) instead of one per (quadrant,
-// Gaussian), no cross-wave combine, no barriers; a chunk's 64 x 9 sums are flushed with nine 64-lane atomic
-// wave-instructions (36 contiguous bytes per list entry).
+// Pixel state of the back-to-front replay.  The colours only ever enter through their dot product with dL/dpixel, so the
+// composited-behind colour is kept as ONE number: bd = (colour seen behind the current entry, at unit transmittance) . d
 struct PixState {
-    float T, tb, d0, d1, d2, behind0, behind1, behind2;  // tb = final_T * (bg . dL/dpixel)
-    int last;
+    float T, tb, d0, d1, d2, bd;  // tb = final_T * (bg . dL/dpixel)
+    int last;                     // n_contrib; 0 for a pixel outside the image (no list position is <= 0)
 };
 
-__device__ __forceinline__ void bwd_pixel(PixState &p, bool inq, float dx, float dy, const float4 &a, const float4 &b,
-                                          float cb, int contributor, float &s_h, float &s_x, float &s_y, float &s_xx,
-                                          float &s_xy, float &s_yy, float &s_r, float &s_g, float &s_b)
+struct Sums9 {
+    float h, x, y, xx, xy, yy, r, g, b;
+};
+
+// One list entry at one pixel, straight-line: a pixel the entry did not contribute to (behind the pixel's last
+// contributor, alpha < 1/255, power > 0, outside the image) runs the same instructions with alpha = 0 and G = 0, which
+// leaves T and bd unchanged (rcp(1) = 1, 0 * cd + 1 * bd = bd) and adds zeros.  No EXEC-mask branches: the compiler's
+// branchy form spent a third of its instructions on zero-filling the nine sums on every path.
+__device__ __forceinline__ void bwd_pixel(PixState &p, float dx, float dy, const float4 &a, const float4 &b, float cb,
+                                          int contributor, Sums9 &s)
 {
-    const float pw = a.z * dx * dx + b.x * dy * dy + a.w * dx * dy;   // -power*log2(e), conic pre-scaled
-    const float G = __builtin_amdgcn_exp2f(-pw);
-    const float alpha = fminf(ALPHA_MAX, b.y * G);
-    const bool valid = inq && (contributor <= p.last) && !(pw < 0.0f) && !(alpha < ALPHA_MIN);
-    if (valid) {
-        const float oma = 1.0f - alpha;
-        const float inv = __builtin_amdgcn_rcpf(oma);
-        p.T *= inv;
-        const float w = alpha * p.T;
-        // `behind` = colour composited behind this Gaussian (everything already visited)
-        float dLda = (b.z - p.behind0) * p.d0 + (b.w - p.behind1) * p.d1 + (cb - p.behind2) * p.d2;
-        s_r += w * p.d0; s_g += w * p.d1; s_b += w * p.d2;
-        dLda = dLda * p.T - p.tb * inv;
-        p.behind0 = alpha * b.z + oma * p.behind0;
-        p.behind1 = alpha * b.w + oma * p.behind1;
-        p.behind2 = alpha * cb + oma * p.behind2;
-        // moments of h = G * dL/dalpha; the conic / opacity factors are applied once per Gaussian in B2
-        const float h = G * dLda;
-        const float hx = h * dx, hy = h * dy;
-        s_h += h; s_x += hx; s_y += hy; s_xx += hx * dx; s_xy += hx * dy; s_yy += hy * dy;
-    }
+    float t1 = a.z * dx;                        // -power*log2(e) = A' dx^2 + C' dy^2 + B' dx dy, conic pre-scaled
+    t1 = fmaf(a.w, dy, t1);
+    float pw = (b.x * dy) * dy;
+    pw = fmaf(dx, t1, pw);
+    const float Graw = __builtin_amdgcn_exp2f(-pw);
+    const float araw = fminf(ALPHA_MAX, b.y * Graw);
+    const bool valid = (contributor <= p.last) & !(pw < 0.0f) & !(araw < ALPHA_MIN);
+    const float alpha = valid ? araw : 0.0f;
+    const float G = valid ? Graw : 0.0f;
+    const float cd = fmaf(cb, p.d2, fmaf(b.w, p.d1, b.z * p.d0));   // colour . dL/dpixel
+    const float oma = 1.0f - alpha;
+    const float inv = __builtin_amdgcn_rcpf(oma);
+    p.T *= inv;
+    const float w = alpha * p.T;
+    s.r = fmaf(w, p.d0, s.r); s.g = fmaf(w, p.d1, s.g); s.b = fmaf(w, p.d2, s.b);
+    const float dLda = fmaf(cd - p.bd, p.T, -(p.tb * inv));
+    p.bd = fmaf(alpha, cd, oma * p.bd);
+    // moments of h = G * dL/dalpha; the conic / opacity factors are applied once per Gaussian in B2
+    const float h = G * dLda;
+    const float hx = h * dx, hy = h * dy;
+    s.h += h; s.x += hx; s.y += hy;
+    s.xx = fmaf(hx, dx, s.xx); s.xy = fmaf(hx, dy, s.xy); s.yy = fmaf(hy, dy, s.yy);
 }
 
-__global__ void __launch_bounds__(64, 4) k_blend_bwd_tile(RasterParams st, const int32_t *__restrict__ tile_offsets,
+// ONE wave per 16x16 tile; lane l owns pixel l of each of the four 8x8 quadrants and walks the quadrants a Gaussian can
+// reach one after the other (wave-uniform 4-bit mask from the bbox + ellipse tests), adding its nine partial sums in
+// registers: one cross-lane reduction per (tile, Gaussian), two list entries per reduction pass.  The nine totals of
+// every list entry are written — with plain, whole-line stores, no atomics — to that instance's own 64-byte row of the
+// partial-sum buffer (row index from the sort: gslot); entries nothing reached get a row of zeros.  B2 then adds up
+// each Gaussian's rows (they are contiguous and in tile order: the sum order is fixed, the backward is deterministic).
+#ifndef GSVC_BWD_WAVES
+#define GSVC_BWD_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterParams st, const int32_t *__restrict__ tile_offsets,
                                                        const int32_t *__restrict__ point_list,
                                                        const uint2 *__restrict__ inst_bbox,
+                                                       const int32_t *__restrict__ gslot,
                                                        const GeomRec *__restrict__ geom,
                                                        const float *__restrict__ final_T,
                                                        const int32_t *__restrict__ n_contrib,
-                                                       const float *__restrict__ dL_dimage, float *__restrict__ acc,
-                                                       const gsvc_raster_counters *__restrict__ counters)
+                                                       const float *__restrict__ dL_dimage, float *__restrict__ rows,
+                                                       const gsvc_raster_counters *__restrict__ counters, int dbg)
 {
     __shared__ float4 s_f0[64];     // u v A' B'
     __shared__ float4 s_f1[64];     // C' opacity r g
     __shared__ float2 s_f2[64];     // b, tag = chunk entry | quadrant mask << 8 | list position << 12
     __shared__ float s_out[64][9];  // per chunk entry: sum h, h dx, h dy, h dx^2, h dx dy, h dy^2, w d0, w d1, w d2
-    __shared__ int s_id[64];
-    if (counters->overflow) return;
     const int lane = threadIdx.x;
     const int tx0 = blockIdx.x * TILE, ty0 = blockIdx.y * TILE;
     const int tile = blockIdx.y * st.gx + blockIdx.x;
-    const int beg = tile_offsets[tile];
     const int HW = st.H * st.W;
     PixState ps[4];
     const float fx0 = (float)(tx0 + (lane & 7)), fy0 = (float)(ty0 + (lane >> 3));
-    bool inq[4];
     int wl[4];
+    // every load of the prologue is issued before anything is waited for (one memory round trip): the tile's list bounds,
+    // the forward's per-pixel state (tile-major: coalesced) and dL/dpixel — the latter as one 16-byte load per lane and
+    // channel (lane l: row l / 4 of the tile, pixels 4 (l % 4) .. + 3), handed to the quadrant layout through LDS
+    float Tf[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int px = tx0 + 8 * (q & 1) + (lane & 7), py = ty0 + 8 * (q >> 1) + (lane >> 3);
-        inq[q] = px < st.W && py < st.H;
-        const int pix = py * st.W + px;
+        Tf[q] = final_T[(tile * 4 + q) * 64 + lane];
+        ps[q].last = n_contrib[(tile * 4 + q) * 64 + lane];
+    }
+    const bool wide = (st.W & 3) == 0;
+    if (wide) {
+        const int py = ty0 + (lane >> 2), px = tx0 + 4 * (lane & 3);
+        const bool in = py < st.H && px < st.W;
+        float4 g[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            g[c] = in ? *reinterpret_cast<const float4 *>(dL_dimage + (size_t)c * HW + (size_t)py * st.W + px)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 *t0 = s_f0, *t1 = s_f1, *t2 = reinterpret_cast<float4 *>(&s_out[0][0]);
+        t0[lane] = g[0]; t1[lane] = g[1]; t2[lane] = g[2];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int o = (8 * (q >> 1) + (lane >> 3)) * TILE + 8 * (q & 1) + (lane & 7);
+            ps[q].d0 = reinterpret_cast<const float *>(t0)[o];
+            ps[q].d1 = reinterpret_cast<const float *>(t1)[o];
+            ps[q].d2 = reinterpret_cast<const float *>(t2)[o];
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int px = tx0 + 8 * (q & 1) + (lane & 7), py = ty0 + 8 * (q >> 1) + (lane >> 3);
+            const bool inq = px < st.W && py < st.H;
+            const int pix = py * st.W + px;
+            ps[q].d0 = inq ? dL_dimage[pix] : 0.f;
+            ps[q].d1 = inq ? dL_dimage[HW + pix] : 0.f;
+            ps[q].d2 = inq ? dL_dimage[2 * HW + pix] : 0.f;
+        }
+    }
+    const int beg = tile_offsets[tile], end = tile_offsets[tile + 1];
+    if (counters->overflow || beg == end) return;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
         PixState &p = ps[q];
-        const float Tf = inq[q] ? final_T[pix] : 0.f;
-        p.last = inq[q] ? n_contrib[pix] : 0;
-        p.d0 = inq[q] ? dL_dimage[pix] : 0.f;
-        p.d1 = inq[q] ? dL_dimage[HW + pix] : 0.f;
-        p.d2 = inq[q] ? dL_dimage[2 * HW + pix] : 0.f;
-        p.tb = Tf * (st.bg0 * p.d0 + st.bg1 * p.d1 + st.bg2 * p.d2);
-        p.T = Tf;
-        p.behind0 = p.behind1 = p.behind2 = 0.f;
+        p.tb = Tf[q] * (st.bg0 * p.d0 + st.bg1 * p.d1 + st.bg2 * p.d2);
+        p.T = Tf[q];
+        p.bd = 0.f;
         int m = p.last;
 #pragma unroll
         for (int k = 32; k >= 1; k >>= 1) m = max(m, __shfl_xor(m, k, 64));
@@ -150,26 +266,48 @@ __global__ void __launch_bounds__(64, 4) k_blend_bwd_tile(RasterParams st, const
     }
     const int tile_last = max(max(wl[0], wl[1]), max(wl[2], wl[3]));
 
+    // entries behind the last contributor of every pixel of the tile: nothing to replay, their rows are zero
+    for (int k = beg + tile_last + lane; k < end; k += 64) {
+        float4 *row = reinterpret_cast<float4 *>(rows + (size_t)gslot[k] * ROW_FLOATS);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        row[0] = z; row[1] = z; row[2] = z; row[3] = z;
+    }
+
+    // chunk = list entries [c1-64, c1) from the back; lane e holds entry k = c1 - 1 - e.  The next chunk's list words are
+    // requested while the current chunk is replayed.
+    uint2 bb_n = make_uint2(0u, 0u);
+    int id_n = -1, gs_n = 0;
+    {
+        const int k = beg + tile_last - 1 - lane;
+        if (k >= beg) { bb_n = inst_bbox[k]; id_n = point_list[k]; gs_n = gslot[k]; }
+    }
+    if (dbg & 4) return;                                      // timing experiment only: prologue + zero rows
     for (int c1 = beg + tile_last; c1 > beg; c1 -= 64) {
-        // chunk = list entries [c1-64, c1) from the back; chunk-local index e = c1 - 1 - k
         const int k = c1 - 1 - lane;
-        int qm = 0, id = -1;
+        const uint2 bb = bb_n;
+        const int id = id_n, gs = gs_n;
+        int qm = 0;
         if (k >= beg) {
-            const uint2 bb = inst_bbox[k];
-            id = point_list[k];
             const int rel = k - beg;
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (rel < wl[q] && bbox_hits_b(bb, tx0 + 8 * (q & 1), ty0 + 8 * (q >> 1))) qm |= 1 << q;
         }
-        s_id[lane] = id;
-        if (__ballot(qm != 0) == 0ull) continue;
         // exact ellipse-vs-quadrant test on the bbox survivors (same rule as the forward: raster_common.h)
-        float4 r0, r1;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        float r2x = 0.f;
         const float4 *rec = reinterpret_cast<const float4 *>(geom + (id < 0 ? 0 : id));
         if (qm != 0) {
             r0 = rec[0];
             r1 = rec[1];
+            r2x = rec[2].x;
+        }
+        {
+            const int kn = c1 - 64 - 1 - lane;      // behind the gathers: waiting for them leaves these in flight
+            id_n = -1;
+            if (kn >= beg) { bb_n = inst_bbox[kn]; id_n = point_list[kn]; gs_n = gslot[kn]; }
+        }
+        if (qm != 0) {
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if ((qm & (1 << q)) && !ellipse_hits_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)(tx0 + 8 * (q & 1)),
@@ -177,46 +315,65 @@ __global__ void __launch_bounds__(64, 4) k_blend_bwd_tile(RasterParams st, const
                     qm &= ~(1 << q);
         }
         const unsigned long long mask = __ballot(qm != 0);
-        if (mask == 0ull) continue;
         if (qm != 0) {
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
             s_f0[pos] = make_float4(r0.x, r0.y, (0.5f * 1.44269504088896340736f) * r0.z, 1.44269504088896340736f * r0.w);
             s_f1[pos] = make_float4((0.5f * 1.44269504088896340736f) * r1.x, r1.y, r1.z, r1.w);
-            s_f2[pos] = make_float2(rec[2].x, __int_as_float(lane | (qm << 8) | ((k - beg + 1) << 12)));
+            s_f2[pos] = make_float2(r2x, __int_as_float(lane | (qm << 8) | ((k - beg + 1) << 12)));
         }
-        const int cnt = __popcll(mask);
+        const int cnt = (dbg & 8) ? 0 : __popcll(mask);      // timing experiment only: chunk overhead without entries
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        unsigned long long touched = 0ull;
-        for (int j = 0; j < cnt; j++) {
+        auto replay = [&](int j, Sums9 &s, int &e) {
             const float4 a = s_f0[j];
             const float4 b = s_f1[j];
             const float2 c = s_f2[j];
             const int tag = __builtin_amdgcn_readfirstlane(__float_as_int(c.y));
-            const int contributor = tag >> 12, quads = (tag >> 8) & 0xf, e = tag & 0xff;
-            float s_h = 0.f, s_x = 0.f, s_y = 0.f, s_xx = 0.f, s_xy = 0.f, s_yy = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
+            const int contributor = tag >> 12, quads = (tag >> 8) & 0xf;
+            e = tag & 0xff;
+            s.h = s.x = s.y = s.xx = s.xy = s.yy = s.r = s.g = s.b = 0.f;
             const float dxb = a.x - fx0, dyb = a.y - fy0;
+            if (dbg & 1) { s.h = dxb; s.x = dyb; return; }     // timing experiment only (GSVC_BWD_DEBUG): no replay
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (quads & (1 << q))
-                    bwd_pixel(ps[q], inq[q], dxb - (float)(8 * (q & 1)), dyb - (float)(8 * (q >> 1)), a, b, c.x, contributor,
-                              s_h, s_x, s_y, s_xx, s_xy, s_yy, s_r, s_g, s_b);
-            wave_sum9_spread(s_h, s_x, s_y, s_xx, s_xy, s_yy, s_r, s_g, s_b);
-            touched |= 1ull << e;
-            // lane 8g holds the total of value g (g < 8) in s_h's register, lane 63 the total of the ninth
-            if ((lane & 7) == 0) s_out[e][lane >> 3] = s_h;
-            if (lane == 63) s_out[e][8] = s_b;
+                    bwd_pixel(ps[q], dxb - (float)(8 * (q & 1)), dyb - (float)(8 * (q >> 1)), a, b, c.x, contributor, s);
+        };
+        // after a reduction lane 8g holds the total of value g (g < 8) in the first register, lane 63 the total of the ninth
+        int j = 0;
+        for (; j + 2 <= cnt; j += 2) {
+            Sums9 sa, sb;
+            int ea, eb;
+            replay(j, sa, ea);
+            replay(j + 1, sb, eb);
+            if (!(dbg & 2))                                   // timing experiment only: no reduction
+                wave_sum9_spread_x2(sa.h, sa.x, sa.y, sa.xx, sa.xy, sa.yy, sa.r, sa.g, sa.b, sb.h, sb.x, sb.y, sb.xx, sb.xy,
+                                    sb.yy, sb.r, sb.g, sb.b);
+            if ((lane & 7) == 0) { s_out[ea][lane >> 3] = sa.h; s_out[eb][lane >> 3] = sb.h; }
+            if ((lane & 31) == 31) s_out[lane == 31 ? ea : eb][8] = sa.b;
+        }
+        if (j < cnt) {
+            Sums9 sa;
+            int ea;
+            replay(j, sa, ea);
+            wave_sum9_spread(sa.h, sa.x, sa.y, sa.xx, sa.xy, sa.yy, sa.r, sa.g, sa.b);
+            if ((lane & 7) == 0) s_out[ea][lane >> 3] = sa.h;
+            if (lane == 63) s_out[ea][8] = sa.b;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // flush: lane -> (entry, component); 9 consecutive lanes = one 36-byte atomic segment
+        // flush: every entry of the chunk writes its whole row (replayed entries their sums, the others zeros)
+        if (k >= beg) {
+            float v[9];
 #pragma unroll
-        for (int r = 0; r < 9; r++) {
-            const int v = r * 64 + lane;
-            const int e = v / 9, comp = v - e * 9;
-            if ((touched >> e) & 1ull) atomicAdd(acc + (size_t)s_id[e] * ACC_STRIDE + comp, s_out[e][comp]);
+            for (int c = 0; c < 9; c++) v[c] = qm != 0 ? s_out[lane][c] : 0.f;
+            float4 *row = reinterpret_cast<float4 *>(rows + (size_t)gs * ROW_FLOATS);
+            row[0] = make_float4(v[0], v[1], v[2], v[3]);
+            row[1] = make_float4(v[4], v[5], v[6], v[7]);
+            row[2] = make_float4(v[8], 0.f, 0.f, 0.f);
+            row[3] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -226,7 +383,9 @@ __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, co
                                                       const float *__restrict__ scales,
                                                       const float *__restrict__ rotations,
                                                       const float *__restrict__ opacities,
-                                                      const int32_t *__restrict__ radii, const float *__restrict__ acc,
+                                                      const int32_t *__restrict__ radii, const GeomRec *__restrict__ geom,
+                                                      const float *__restrict__ rows,
+                                                      const gsvc_raster_counters *__restrict__ counters,
                                                       float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
                                                       float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacities,
                                                       float *__restrict__ dL_dscales, float *__restrict__ dL_drotations)
@@ -234,10 +393,22 @@ __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, co
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     float g3[3] = {0, 0, 0}, g2[3] = {0, 0, 0}, gc[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, go = 0.f;
-    if (radii[i] > 0) {
-        const float4 a0 = reinterpret_cast<const float4 *>(acc + (size_t)i * ACC_STRIDE)[0];
-        const float4 a1 = reinterpret_cast<const float4 *>(acc + (size_t)i * ACC_STRIDE)[1];
-        const float a2 = acc[(size_t)i * ACC_STRIDE + 8];
+    if (radii[i] > 0 && !counters->overflow) {
+        // this Gaussian's rows of the partial-sum buffer: one per tile of its rectangle, contiguous, added in tile order
+        const float4 w2 = reinterpret_cast<const float4 *>(geom + i)[2];
+        const float4 w3 = reinterpret_cast<const float4 *>(geom + i)[3];
+        const uint32_t rx = __float_as_uint(w3.x), ry = __float_as_uint(w3.y);
+        const int n_rows = ((int)(rx >> 16) - (int)(rx & 0xffff)) * ((int)(ry >> 16) - (int)(ry & 0xffff));
+        const float4 *row = reinterpret_cast<const float4 *>(rows + (size_t)__float_as_int(w2.w) * ROW_FLOATS);
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        float a2 = 0.f;
+        for (int j = 0; j < n_rows; j++, row += ROW_FLOATS / 4) {
+            const float4 x0 = row[0], x1 = row[1];
+            const float x2 = row[2].x;
+            a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+            a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+            a2 += x2;
+        }
         float du, dv, dA, dB, dC;
         PreOut o;
         preprocess_gaussian(st, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], scales[3 * i], scales[3 * i + 1],
@@ -309,6 +480,12 @@ __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, co
 
 using namespace gsvc;
 
+extern "C" int64_t gsvc_raster_backward_scratch_bytes(int64_t P, int64_t max_instances)
+{
+    (void)P;
+    return (max_instances > 0 ? max_instances : 1) * (int64_t)(ROW_FLOATS * sizeof(float));
+}
+
 extern "C" int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
                                     const float *means3D, const float *colors, const float *opacities,
                                     const float *scales, const float *rotations, const int32_t *radii, const void *geom,
@@ -334,20 +511,18 @@ extern "C" int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_
     auto *inst_bbox = (const uint2 *)(bin + L.off_inst_bbox);
     auto *final_T = (const float *)((const char *)image_state + L.off_final_T);
     auto *n_contrib = (const int32_t *)((const char *)image_state + L.off_n_contrib);
-    if (hipMemsetAsync(scratch, 0, (size_t)P * ACC_STRIDE * sizeof(float), s) != hipSuccess) {
-        set_error("raster_backward: hipMemsetAsync failed");
-        return GSVC_E_LAUNCH;
-    }
+    auto *gslot = (const int32_t *)(bin + L.off_gslot);
+    static const int dbg = getenv("GSVC_BWD_DEBUG") ? atoi(getenv("GSVC_BWD_DEBUG")) : 0;   // kernel-timing experiments
     {
         ProfScope _prof("k_blend_bwd", s);
-        hipLaunchKernelGGL(k_blend_bwd_tile, dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, inst_bbox,
-                           (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters);
+        hipLaunchKernelGGL(k_blend_bwd_tile, dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, inst_bbox, gslot,
+                           (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters, dbg);
     }
     {
         ProfScope _prof("k_gaussian_bwd", s);
         hipLaunchKernelGGL(k_gaussian_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, p, (int)P, means3D,
-                           scales, rotations, opacities, radii, (const float *)scratch, dL_dmeans3D, dL_dmeans2D,
-                           dL_dcolors, dL_dopacities, dL_dscales, dL_drotations);
+                           scales, rotations, opacities, radii, (const GeomRec *)geom, (const float *)scratch, counters,
+                           dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations);
     }
     return check_launch("raster_backward");
 }

@@ -15,15 +15,21 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_MIN = 0.0001f;
 
-// One Gaussian as the blend kernels read it: 48 B, three 16-B (scalar) loads.
+// One Gaussian as the blend / sort kernels read it: 64 B = one cache line (a 48-B record straddles two lines half of the
+// time); the blend kernels load the first three 16-B words, the sort kernel the last two.
 struct alignas(16) GeomRec {
     float u, v, A, B;            // pixel-space centre, conic xx, xy
     float C, opacity, r, g;      // conic yy, opacity, colour
     float b;                     // colour
     uint32_t bbox_x, bbox_y;     // int16 pairs lo|hi<<16: pixels outside can never reach alpha >= 1/255
+    int32_t goff;                // first of this Gaussian's rows in the backward's per-instance partial-sum buffer: the
+                                 // instance in tile j of its rectangle (row-major) owns row goff + j (single-view binning only)
+    uint32_t rect_x, rect_y;     // tile rectangle x0 | x1<<16, y0 | y1<<16 (as BinRec; 0 when culled)
     float depth;                 // view-space z
+    uint32_t pad;
 };
-static_assert(sizeof(GeomRec) == 48, "GeomRec must be 48 bytes");
+static_assert(sizeof(GeomRec) == 64, "GeomRec must be 64 bytes");
+constexpr int ROW_FLOATS = 16;   // one backward partial-sum row: 9 sums + padding = one 64-B line, written whole
 
 // One Gaussian as the binning kernels read it: 32 B.
 constexpr int BIN_SLOTS = 4;     // instance slots resolved by K1's LDS histogram; further tiles ("extras") are placed by K3
@@ -43,7 +49,7 @@ struct RasterLayout {
     uint64_t off_geom, off_bin, geom_bytes;
     // binning blob
     uint64_t off_counters, off_tile_offsets, off_tile_count, off_tile_extra, off_big_list, off_wg_extras, off_keys, off_point_list,
-        off_inst_bbox, binning_bytes;
+        off_inst_bbox, off_gslot, binning_bytes;
     // image blob
     uint64_t off_final_T, off_n_contrib, image_bytes;
 };
@@ -68,8 +74,10 @@ inline RasterLayout raster_layout(const gsvc_raster_settings &s, int64_t P, int6
     L.off_keys = o;          o += align_up(m * 8, 256);
     L.off_point_list = o;    o += align_up(m * 4, 256);
     L.off_inst_bbox = o;     o += align_up(m * 8, 256);
+    L.off_gslot = o;         o += align_up(m * 4, 256);      // per sorted instance: its row in the backward's partial-sum buffer
     L.binning_bytes = o;
-    const uint64_t hw = (uint64_t)s.image_height * (uint64_t)s.image_width;
+    // final_T / n_contrib are stored tile-major: [tile][quadrant][lane] (whole 16x16 tiles, also at the image border)
+    const uint64_t hw = (uint64_t)L.tiles * (TILE * TILE);
     L.off_final_T = 0;
     L.off_n_contrib = align_up(hw * 4, 256);
     L.image_bytes = L.off_n_contrib + align_up(hw * 4, 256);

@@ -215,6 +215,9 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
                                                      int32_t *__restrict__ wg_extras, long long max_instances)
 {
     extern __shared__ int hist[];
+    __shared__ int s_wt[16];
+    __shared__ int s_gbase;
+    int row_excl = 0;
     const int T = st.gx * st.gy;
     const int tid = threadIdx.x;
     if (USE_LDS) {
@@ -229,6 +232,9 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
     bool heavy = false;     // workgroup-uniform: extras go through the LDS histogram
     int bx0 = 0, bx1 = 0;   // x range of the binning rectangle (pair mode: union of the two views)
     bool listed = false;
+    int my_tiles = 0;       // instances of this Gaussian = rows it owns in the backward's partial-sum buffer
+    float rec2_b = 0.f;
+    uint32_t rec2_bx = 0u, rec2_by = 0u;
     if (i < P) {
         // a Gaussian with opacity <= 0 can never reach alpha >= 1/255: culled here (radius 0), which lets callers
         // pass un-compacted Gaussian sets (GSVC's "opacity > 0" selection) without a host-side compaction
@@ -267,6 +273,8 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
             br.depth = o.depth;
             br.rect_x = radius > 0 ? ((uint32_t)o.x0 | ((uint32_t)o.x1 << 16)) : 0u;
             br.rect_y = (uint32_t)o.y0 | ((uint32_t)o.y1 << 16);
+            rec.rect_x = br.rect_x; rec.rect_y = br.rect_y;
+            my_tiles = (bx1 - bx0) * (o.y1 - o.y0);
             // the first BIN_SLOTS tiles of the rectangle (row-major): rank inside the workgroup from the LDS histogram
             // (histogram word of a tile: low half = slotted instances of this workgroup, high half = its extras in the
             // heavy case; at most 1024 each: no carry).  The remaining tiles ("extras") follow below.
@@ -284,11 +292,15 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         } else {
             rec.u = rec.v = rec.A = rec.B = rec.C = rec.opacity = rec.r = rec.g = rec.b = rec.depth = 0.f;
             rec.bbox_x = pack_i16(1, 0); rec.bbox_y = pack_i16(1, 0);
+            rec.rect_x = rec.rect_y = 0u;
             br.depth = 0.f; br.rect_x = br.rect_y = 0u;
         }
+        rec.goff = 0; rec.pad = 0u;
         float4 *dst = reinterpret_cast<float4 *>(geom + i);
         const float4 *src = reinterpret_cast<const float4 *>(&rec);
-        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+        dst[0] = src[0]; dst[1] = src[1]; dst[3] = src[3];
+        // word 2 (blue, alpha box, goff) is stored once the workgroup's row range is known (below)
+        rec2_b = rec.b; rec2_bx = rec.bbox_x; rec2_by = rec.bbox_y;
         if (!USE_LDS || !listed) {
             br.slot[0] = slot[0]; br.slot[1] = slot[1]; br.slot[2] = slot[2]; br.slot[3] = slot[3];
             float4 *bd = reinterpret_cast<float4 *>(bins + i);
@@ -302,6 +314,18 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         // visible count: one atomic per workgroup; the workgroup's extras: one store (K3 picks its path by it)
         __shared__ int s_vis, s_ext;
         if (tid == 0) { s_vis = 0; s_ext = 0; }
+        // rows of the backward's per-instance buffer: exclusive scan of the instance counts inside the workgroup; the
+        // workgroup's base comes from ONE returning atomic on a global cursor (its order among workgroups is irrelevant: a
+        // Gaussian's rows only have to be contiguous and its own)
+        int incl = my_tiles;
+        if (!PAIR) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(incl, d, 64);
+                if ((tid & 63) >= d) incl += y;
+            }
+            if ((tid & 63) == 63) s_wt[tid >> 6] = incl;
+        }
         __syncthreads();
         const unsigned long long vm = __ballot(radius > 0);
         if ((tid & 63) == 0 && vm != 0ull) atomicAdd(&s_vis, __popcll(vm));
@@ -312,6 +336,17 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         __syncthreads();
         if (tid == 0 && s_vis != 0) atomicAdd(&counters->num_visible, s_vis);
         if (tid == 0) wg_extras[blockIdx.x] = s_ext;
+        if (!PAIR) {
+            int before = 0;
+            const int my_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            for (int w = 0; w < my_wave; w++) before += s_wt[w];
+            row_excl = before + incl - my_tiles;
+            // the atomic's round trip hides under the histogram flush; s_gbase is read behind the next barrier
+            if (tid == 1023) {
+                const int total = before + incl;
+                s_gbase = total != 0 ? atomicAdd(&counters->reserved[1], total) : 0;
+            }
+        }
         // extras: a workgroup with many of them (large footprints) counts them in the high half of the LDS histogram and
         // adds them to the tiles' cursors with the contiguous flush below; otherwise one fire-and-forget global atomic each
         heavy = USE_LDS && s_ext > HEAVY_EXTRAS;
@@ -324,7 +359,19 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
             else atomicAdd(&tile_extra[t], 1);
         });
     }
-    if (!USE_LDS) return;
+    auto store_word2 = [&]() {
+        if (i < P) {
+            GeomRec r2;
+            r2.b = rec2_b; r2.bbox_x = rec2_bx; r2.bbox_y = rec2_by;
+            r2.goff = PAIR ? 0 : s_gbase + row_excl;
+            reinterpret_cast<float4 *>(geom + i)[2] = reinterpret_cast<const float4 *>(&r2)[2];
+        }
+    };
+    if (!USE_LDS) {
+        __syncthreads();
+        store_word2();
+        return;
+    }
     if (heavy) __syncthreads();
     // flush: 64 consecutive tiles per wave-instruction = 256 contiguous bytes of returning atomics; a wave's
     // (up to 8) groups are issued back to back and waited for once — a memory-side atomic takes microseconds
@@ -353,6 +400,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         }
     }
     __syncthreads();
+    store_word2();
     if (i < P && listed) {
         int j = 0;
         for (int ty = o.y0; ty < o.y1 && j < BIN_SLOTS; ty++)
@@ -605,13 +653,24 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *a, int n, int tid)
 // one wave per tile, segments of <= SORT_WAVE_MAX entries
 // every sorted entry gets its Gaussian id (point_list) and that Gaussian's alpha bounding box (inst_bbox), so the
 // blend kernels test 64 entries per wave-instruction without touching the Gaussian records
+// Row of the backward's partial-sum buffer that belongs to the instance of Gaussian (words 2, 3 of its record) in tile
+// (tx, ty): goff + row-major index of the tile inside the Gaussian's rectangle.
+__device__ __forceinline__ int32_t row_of_instance(const float4 &f2, const float4 &f3, int tx, int ty)
+{
+    const uint32_t rx = __float_as_uint(f3.x), ry = __float_as_uint(f3.y);
+    const int x0 = rx & 0xffff, w = (int)(rx >> 16) - x0, y0 = ry & 0xffff;
+    return __float_as_int(f2.w) + (ty - y0) * w + (tx - x0);
+}
+
 __device__ __forceinline__ void emit_entry(int pos, uint64_t key, const GeomRec *__restrict__ geom,
-                                           int32_t *__restrict__ point_list, uint2 *__restrict__ inst_bbox, int id_shift)
+                                           int32_t *__restrict__ point_list, uint2 *__restrict__ inst_bbox,
+                                           int32_t *__restrict__ gslot, int tx, int ty, int id_shift)
 {
     const uint32_t low = (uint32_t)key, id = low >> id_shift;   // pair mode keeps the two view flags in the low bits
     point_list[pos] = (int32_t)low;
     const float4 f2 = reinterpret_cast<const float4 *>(geom + id)[2];
     inst_bbox[pos] = make_uint2(__float_as_uint(f2.y), __float_as_uint(f2.z));
+    if (gslot) gslot[pos] = row_of_instance(f2, reinterpret_cast<const float4 *>(geom + id)[3], tx, ty);
 }
 
 // One launch sorts every tile: 256-lane workgroups, each wave takes one tile at a time (tile = 4*block + wave):
@@ -623,7 +682,7 @@ __device__ __forceinline__ void emit_entry(int pos, uint64_t key, const GeomRec 
 __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__restrict__ tile_offsets,
                                                     const int32_t *__restrict__ big_list, uint64_t *__restrict__ keys,
                                                     const GeomRec *__restrict__ geom, int32_t *__restrict__ point_list,
-                                                    uint2 *__restrict__ inst_bbox,
+                                                    uint2 *__restrict__ inst_bbox, int32_t *__restrict__ gslot, int gx,
                                                     const gsvc_raster_counters *__restrict__ counters, int id_shift)
 {
     __shared__ uint64_t s_all[4 * SORT_WAVE_MAX];   // 32 KiB: one 8-KiB strip per wave
@@ -638,14 +697,17 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
         n = tile_offsets[t + 1] - beg;
     }
     if (overflow) n = 0;
+    const int ty = t / gx, tx = t - ty * gx;
     if (n > 0 && n <= SORT_RANK_MAX) {
         uint64_t k[4];
         uint2 bb[4];
+        int32_t row[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int i = lane + 64 * q;
             k[q] = ~0ull;
             bb[q] = make_uint2(0u, 0u);
+            row[q] = 0;
             if (i < n) {
                 k[q] = keys[beg + i];
                 s[i] = k[q];
@@ -654,8 +716,10 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (lane + 64 * q < n) {
-                const float4 f2 = reinterpret_cast<const float4 *>(geom + ((uint32_t)k[q] >> id_shift))[2];
+                const float4 *rec = reinterpret_cast<const float4 *>(geom + ((uint32_t)k[q] >> id_shift));
+                const float4 f2 = rec[2];
                 bb[q] = make_uint2(__float_as_uint(f2.y), __float_as_uint(f2.z));
+                if (gslot) row[q] = row_of_instance(f2, rec[3], tx, ty);
             }
         }
         sort_sync<true>();
@@ -676,30 +740,32 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
             if (lane + 64 * q < n) {
                 point_list[beg + r[q]] = (int32_t)(uint32_t)k[q];
                 inst_bbox[beg + r[q]] = bb[q];
+                if (gslot) gslot[beg + r[q]] = row[q];
             }
         }
     } else if (n > SORT_RANK_MAX && n <= SORT_WAVE_MAX) {
         for (int i = lane; i < n; i += 64) s[i] = keys[beg + i];
         sort_sync<true>();
         bitonic_sort<64>(s, n, lane);
-        for (int i = lane; i < n; i += 64) emit_entry(beg + i, s[i], geom, point_list, inst_bbox, id_shift);
+        for (int i = lane; i < n; i += 64) emit_entry(beg + i, s[i], geom, point_list, inst_bbox, gslot, tx, ty, id_shift);
     }
     // long lists: whole workgroups (uniform loop bounds; usually zero iterations)
     const int nbig = overflow ? 0 : counters->num_big_tiles;
     for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
         const int bt = big_list[w];
         const int bbeg = tile_offsets[bt], bn = tile_offsets[bt + 1] - bbeg;
+        const int bty = bt / gx, btx = bt - bty * gx;
         __syncthreads();
         if (bn <= 4 * SORT_WAVE_MAX) {
             for (int i = tid; i < bn; i += 256) s_all[i] = keys[bbeg + i];
             __syncthreads();
             bitonic_sort<256>(s_all, bn, tid);
-            for (int i = tid; i < bn; i += 256) emit_entry(bbeg + i, s_all[i], geom, point_list, inst_bbox, id_shift);
+            for (int i = tid; i < bn; i += 256) emit_entry(bbeg + i, s_all[i], geom, point_list, inst_bbox, gslot, btx, bty, id_shift);
         } else {
             uint64_t *a = keys + bbeg;
             __threadfence_block();
             bitonic_sort<256>(a, bn, tid);  // __syncthreads() orders the workgroup's own global accesses
-            for (int i = tid; i < bn; i += 256) emit_entry(bbeg + i, a[i], geom, point_list, inst_bbox, id_shift);
+            for (int i = tid; i < bn; i += 256) emit_entry(bbeg + i, a[i], geom, point_list, inst_bbox, gslot, btx, bty, id_shift);
         }
     }
 }
@@ -886,6 +952,13 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
         __builtin_amdgcn_wave_barrier();
         if (!PAIR && done_m == ~0ull) break;
     }
+    if (!PAIR) {
+        // per-pixel state for the backward, TILE-MAJOR (tile, quadrant, lane): one coalesced 256-B store per wave here and
+        // one coalesced load per quadrant there; pixels outside the image hold T = 1, last = 0 (nothing contributes)
+        const int sidx = (tile * 4 + wave) * 64 + lane;
+        final_T[sidx] = T;
+        n_contrib[sidx] = last;
+    }
     if (inside) {
         const int HW = st.H * st.W, pix = py * st.W + px;
         if (PAIR) {
@@ -893,8 +966,6 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
             image[HW + pix] = 0.5f * ((C1 + T * st.bg1) + (B1 + Tb * st.bg1));
             image[2 * HW + pix] = 0.5f * ((C2 + T * st.bg2) + (B2 + Tb * st.bg2));
         } else {
-            final_T[pix] = T;
-            n_contrib[pix] = last;
             image[pix] = C0 + T * st.bg0;
             image[HW + pix] = C1 + T * st.bg1;
             image[2 * HW + pix] = C2 + T * st.bg2;
@@ -993,6 +1064,7 @@ static int raster_forward_impl(const gsvc_raster_settings *settings, int64_t P, 
     auto *keys = (uint64_t *)(bin + L.off_keys);
     auto *point_list = (int32_t *)(bin + L.off_point_list);
     auto *inst_bbox = (uint2 *)(bin + L.off_inst_bbox);
+    auto *gslot = (int32_t *)(bin + L.off_gslot);
     auto *grec = (GeomRec *)((char *)geom + L.off_geom);
     auto *brec = (BinRec *)((char *)geom + L.off_bin);
     auto *final_T = (float *)((char *)image_state + L.off_final_T);
@@ -1052,7 +1124,8 @@ static int raster_forward_impl(const gsvc_raster_settings *settings, int64_t P, 
         {
             ProfScope _prof("k_sort_tiles", s);
             hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)((L.tiles + 3) / 4)), dim3(256), 0, s, L.tiles, tile_offsets,
-                               big_list, keys, grec, point_list, inst_bbox, counters, pair ? 2 : 0);
+                               big_list, keys, grec, point_list, inst_bbox, pair ? (int32_t *)nullptr : gslot, L.gx, counters,
+                               pair ? 2 : 0);
         }
     }
     {

@@ -103,8 +103,13 @@ class RasterState:
         a, b = C.c_uint64(), C.c_uint64()
         _lib.check(_lib.lib().gsvc_raster_image_layout(C.byref(self.cs), C.byref(a), C.byref(b)), "gsvc_raster_image_layout")
         H, W = self.cs.image_height, self.cs.image_width
-        fT = self.image_state[a.value:a.value + 4 * H * W].view(torch.float32).view(H, W)
-        nc = self.image_state[b.value:b.value + 4 * H * W].view(torch.int32).view(H, W)
+        gy, gx = (H + 15) // 16, (W + 15) // 16
+        n = gy * gx * 256
+
+        def rows(t):      # the blob keeps them tile-major [tile_y, tile_x, quad_y, quad_x, lane_y, lane_x]
+            return t.view(gy, gx, 2, 2, 8, 8).permute(0, 2, 4, 1, 3, 5).reshape(gy * 16, gx * 16)[:H, :W].contiguous()
+        fT = rows(self.image_state[a.value:a.value + 4 * n].view(torch.float32))
+        nc = rows(self.image_state[b.value:b.value + 4 * n].view(torch.int32))
         return fT, nc
 
 
@@ -178,6 +183,11 @@ def resolve_deferred(states):
     return [c[0] for c in host], over
 
 
+def backward_scratch_floats(P: int, max_instances: int) -> int:
+    """Floats of scratch gsvc_raster_backward needs (one 64-byte row of partial sums per instance)."""
+    return int(_lib.lib().gsvc_raster_backward_scratch_bytes(int(P), int(max_instances))) // 4
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, cs, holder, sync=True):
@@ -203,7 +213,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         do = torch.empty(P, 1, device=dev)
         ds = torch.empty(P, 3, device=dev)
         dq = torch.empty(P, 4, device=dev)
-        scratch = torch.empty(max(P, 1) * 16, device=dev)
+        scratch = torch.empty(backward_scratch_floats(P, st.max_instances), device=dev)
         _lib.check(_lib.lib().gsvc_raster_backward(
             C.byref(st.cs), P, st.max_instances, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opacities),
             _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(st.radii), _lib.ptr(st.geom), _lib.ptr(st.binning),

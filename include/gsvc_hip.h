@@ -116,7 +116,10 @@ int gsvc_raster_forward_pair(const gsvc_raster_settings *settings, int64_t P, in
 /* Backward: dL_dimage[3,H,W] + the forward's inputs and state  ->  gradients (all overwritten):
  * dL_dmeans3D[P,3], dL_dmeans2D[P,3] (screen-space gradient in NDC units, the tensor GSVC's densification
  * reads, reference scene/gaussian_model.py:1311), dL_dcolors[P,3], dL_dopacities[P], dL_dscales[P,3],
- * dL_drotations[P,4].  `scratch` = P*16*4 bytes, zeroed inside. */
+ * dL_drotations[P,4].  `scratch`: gsvc_raster_backward_scratch_bytes(P, max_instances) bytes (one 64-byte row of
+ * partial sums per (tile, Gaussian) instance; every row that is read is written first, nothing needs zeroing).
+ * No float atomics: two calls on the same inputs return bit-identical gradients. */
+int64_t gsvc_raster_backward_scratch_bytes(int64_t P, int64_t max_instances);
 int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
                          const float *means3D, const float *colors, const float *opacities, const float *scales,
                          const float *rotations, const int32_t *radii, const void *geom, const void *binning,

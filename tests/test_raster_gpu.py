@@ -177,6 +177,17 @@ def test_backward_parity(oracle_lib, P, H, W, seed, view):
     # culled Gaussians get exactly zero
     culled = ref.radii == 0
     assert torch.all(d["means3D"].grad[torch.tensor(culled, device="cuda")] == 0)
+    # no float atomics anywhere in the backward: a second run returns bit-identical gradients
+    first = {k: v.grad.clone() for k, v in d.items()}
+    first["means2D"] = means2D.grad.clone()
+    for v in list(d.values()) + [means2D]:
+        v.grad = None
+    image, radii, _ = r(means3D=d["means3D"], means2D=means2D, shs=None, colors_precomp=d["colors"],
+                        opacities=d["opacities"], scales=d["scales"], rotations=d["rotations"], cov3D_precomp=None)
+    (image * torch.tensor(dL, device="cuda")).sum().backward()
+    for k, v in d.items():
+        assert torch.equal(v.grad, first[k]), k
+    assert torch.equal(means2D.grad, first["means2D"])
 
 
 @pytest.mark.parametrize("P,H,W,seed", [(3000, 128, 192, 0), (20000, 1080, 1920, 1), (1500, 100, 160, 2)])
@@ -236,9 +247,9 @@ def test_full_size_cfg2_parity_and_properties(oracle_lib):
     img2, radii2, n2 = r(colors_precomp=d["colors"], **args)
     off2, pl2 = r.last_state.tile_lists()
     assert n1 == n2 and torch.equal(img1, img2) and torch.equal(off1, off2) and torch.equal(pl1, pl2)
-    # sortedness by (depth, id) inside each tile; depth = float 11 of the 12-float GeomRec
+    # sortedness by (depth, id) inside each tile; depth = float 14 of the 16-float GeomRec
     P = d["means3D"].shape[0]
-    depth = r.last_state.geom[:48 * P].view(torch.float32).view(P, 12)[:, 11]
+    depth = r.last_state.geom[:64 * P].view(torch.float32).view(P, 16)[:, 14]
     pl = pl2.long()
     key_d, key_i = depth[pl], pl
     same_tile = torch.ones(pl.shape[0] - 1, dtype=torch.bool, device="cuda")
