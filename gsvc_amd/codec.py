@@ -65,10 +65,18 @@ def ans_decode(stream: bytes, mu: torch.Tensor, sigma: torch.Tensor) -> torch.Te
     L = _lib.lib()
     dev = mu.device
     off = _HEADER.size
+    # the kernel derives the segment count from (n, seg_len) and reads seg_offsets[seg + 1] for each: a header that
+    # disagrees, or sizes that run past the end of the stream, must never reach the device
+    if seg_len <= 0 or n < 0 or n_seg != int(L.gsvc_ans_segments(n, seg_len)):
+        raise _lib.GsvcError(f"ans_decode: malformed header (n={n}, seg_len={seg_len}, n_seg={n_seg})")
+    if off + 4 * n_seg > len(stream):
+        raise _lib.GsvcError("ans_decode: truncated stream (segment table)")
     sizes = np.frombuffer(stream, dtype="<u4", count=n_seg, offset=off).astype(np.int64)
     off += 4 * n_seg
     offsets = np.zeros(n_seg + 1, dtype=np.int64)
     np.cumsum(sizes, out=offsets[1:])
+    if off + int(offsets[-1]) > len(stream):
+        raise _lib.GsvcError("ans_decode: truncated stream (payload shorter than its segment table says)")
     payload = np.frombuffer(stream, dtype=np.uint8, count=int(offsets[-1]), offset=off)
     bytes_d = torch.from_numpy(payload.copy()).to(dev) if payload.size else torch.empty(1, dtype=torch.uint8, device=dev)
     offs_d = torch.from_numpy(offsets).to(dev)

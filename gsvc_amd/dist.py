@@ -48,6 +48,9 @@ def frame_shard(num_frames: int, rank_: int | None = None, world: int | None = N
     r = rank() if rank_ is None else rank_
     w = world_size() if world is None else world
     pairs = num_frames - 1
+    if w > pairs:
+        raise ValueError(f"frame_shard: {w} ranks but only {pairs} adjacent-frame pairs in a {num_frames}-frame video; "
+                         f"use at most {pairs} ranks (every rank needs at least one pair of its own)")
     base, extra = divmod(pairs, w)
     lo = r * base + min(r, extra)
     hi = lo + base + (1 if r < extra else 0)
@@ -84,6 +87,7 @@ class GradReducer:
 
     def __init__(self, average: bool = True):
         self.average = average
+        self.enabled = True         # False: no exchange at all (bench.py measures the step without it; replicas diverge)
         self._hooked = {}           # id(param) -> (param, handle of the hook)
         self._pending = []          # (work, grad) of the collectives in flight
         self._params = []
@@ -93,7 +97,8 @@ class GradReducer:
         """Call before backward with the step's parameters (new Parameter objects, e.g. after densification, get hooks;
         hooks of parameters that are gone are dropped)."""
         self._params = [p for p in params if p.requires_grad]
-        if world_size() == 1:
+        if world_size() == 1 or not self.enabled:
+            self._armed = False
             return
         live = {id(p) for p in self._params}
         for k in [k for k in self._hooked if k not in live]:
@@ -112,7 +117,7 @@ class GradReducer:
         """Call after backward: reduces the small parameters, waits for everything, averages.  Returns the number of
         gradient elements reduced."""
         w = world_size()
-        if w == 1:
+        if w == 1 or not self.enabled:
             return 0
         self._armed = False
         done = {id(g) for _, g in self._pending}
@@ -142,6 +147,16 @@ def allreduce_statistics(pc):
         t = getattr(pc, name, None)
         if isinstance(t, torch.Tensor) and t.numel():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def keep_statistics_on_rank0(pc):
+    """After an all-reduced adjust_anchor: ranks other than 0 zero their densification accumulators (see Trainer._adjust_anchor)."""
+    if world_size() == 1 or rank() == 0:
+        return
+    for name in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
+        t = getattr(pc, name, None)
+        if isinstance(t, torch.Tensor) and t.numel():
+            t.zero_()
 
 
 def any_rank(flag: bool, device) -> bool:

@@ -53,6 +53,7 @@ def save_checkpoint(pc, path, iteration: int = 0):
     stats = {n: getattr(pc, n) for n in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom", "max_radii2D")}
     torch.save({"iteration": int(iteration), "state_dict": pc.state_dict(), "per_anchor": per_anchor, "stats": stats,
                 "decoded_version": bool(pc.decoded_version), "voxel_size": float(pc.voxel_size),
+                "spatial_lr_scale": float(pc.spatial_lr_scale), "percent_dense": float(getattr(pc, "percent_dense", 0.0) or 0.0),
                 "bounds": (pc.bound_min_host, pc.bound_max_host),
                 "optimizer": pc.optimizer.state_dict() if pc.optimizer is not None else None}, path)
 
@@ -60,7 +61,7 @@ def save_checkpoint(pc, path, iteration: int = 0):
 def load_checkpoint(pc, path, training_args=None) -> int:
     """Restore what save_checkpoint wrote into a model built with the same hyper-parameters; with ``training_args`` the
     optimizer is set up and its state restored.  Returns the stored iteration."""
-    ck = torch.load(path, map_location=pc.device, weights_only=False)
+    ck = torch.load(path, map_location=pc.device, weights_only=True)      # tensors / numbers / tuples only: nothing is unpickled
     for n, t in ck["per_anchor"].items():
         setattr(pc, n, torch.nn.Parameter(t.to(pc.device).clone(), requires_grad=n not in ("_rotation", "_opacity")))
     pc.load_state_dict(ck["state_dict"], strict=True)
@@ -69,10 +70,13 @@ def load_checkpoint(pc, path, training_args=None) -> int:
     pc.bound_min_host, pc.bound_max_host = tuple(lo), tuple(hi)
     pc.x_bound_min = torch.tensor([list(lo)], dtype=torch.float32, device=pc.device)
     pc.x_bound_max = torch.tensor([list(hi)], dtype=torch.float32, device=pc.device)
-    for n, t in ck["stats"].items():
-        setattr(pc, n, t.to(pc.device) if isinstance(t, torch.Tensor) else t)
+    pc.spatial_lr_scale = float(ck.get("spatial_lr_scale", pc.spatial_lr_scale))
     if training_args is not None:
-        pc.training_setup(training_args)
+        pc.training_setup(training_args)      # re-creates (zeroes) the densification statistics: restore them afterwards
         if ck["optimizer"] is not None:
             pc.optimizer.load_state_dict(ck["optimizer"])
+    if ck.get("percent_dense"):
+        pc.percent_dense = float(ck["percent_dense"])
+    for n, t in ck["stats"].items():
+        setattr(pc, n, t.to(pc.device) if isinstance(t, torch.Tensor) else t)
     return ck["iteration"]

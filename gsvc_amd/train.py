@@ -96,6 +96,10 @@ class Trainer:
                 torch.manual_seed(977 + iteration)
                 pc.adjust_anchor(check_interval=opt.update_interval, success_threshold=opt.success_threshold,
                                  grad_threshold=opt.densify_grad_threshold, min_opacity=opt.min_opacity)
+            # the accumulators now hold the GLOBAL sums on every rank, and adjust_anchor keeps the rows that did not cross
+            # its thresholds: only rank 0 carries them into the next interval, the other ranks restart from zero, so that
+            # the next all-reduce yields (old global sum + every rank's new observations) and not world_size copies of it
+            gdist.keep_statistics_on_rank0(pc)
         else:
             pc.adjust_anchor(check_interval=opt.update_interval, success_threshold=opt.success_threshold,
                              grad_threshold=opt.densify_grad_threshold, min_opacity=opt.min_opacity)

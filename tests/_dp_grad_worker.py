@@ -1,0 +1,73 @@
+"""Worker of tests/test_train_gpu.py::test_two_rank_step_averages_gradients (run under torch.distributed.run, 2 ranks):
+one data-parallel fitting step — each rank on a frame pair of its own shard, gradients exchanged by the overlapped
+reducer (gsvc_amd/dist.py) — must leave on every rank the MEAN of the two single-process gradients of those two pairs.
+Backend from GSVC_DIST_BACKEND: "nccl" (= RCCL, one GPU per rank) or "gloo" with GSVC_SHARE_GPU=1 (both ranks on device 0)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    backend = os.environ.get("GSVC_DIST_BACKEND", "nccl")
+    local = 0 if os.environ.get("GSVC_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    from test_train_gpu import _setup
+    from gsvc_amd import dist as gd
+    pc, cube, opt, pipe, mp, Trainer = _setup(anchors=3000)
+    opt.full_precision_training_total = 1000          # no quantisation noise: the step is a deterministic function of the frames
+    pc.training_setup(opt)
+    gd.broadcast_parameters(pc)
+    tr = Trainer(pc, cube, opt, pipe, mp, seed=3)
+    captured = {}
+
+    def capture_instead_of_update():
+        captured.clear()
+        for g in pc.optimizer.param_groups:
+            for i, p in enumerate(g["params"]):
+                if p.grad is not None:
+                    captured[f"{g['name']}.{i}"] = p.grad.detach().clone()
+    pc.optimizer.step = capture_instead_of_update      # parameters stay as they are: every step below sees the same model
+
+    mine = torch.tensor([tr.lo], device="cuda" if backend == "nccl" else "cpu")
+    los = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(los, mine)
+    los = [int(t.item()) for t in los]
+    assert len(set(los)) == len(los), los               # every rank has its own frames
+
+    tr.step(1, frame_idx=tr.lo)
+    dp = dict(captured)
+    assert len(dp) >= 8, sorted(dp)
+
+    tr.reducer.enabled = False                          # single-process reference: the same pairs one after the other
+    ref = {}
+    for f in los:
+        tr.step(1, frame_idx=f)
+        for k, v in captured.items():
+            ref[k] = ref.get(k, 0) + v / len(los)
+    worst = 0.0
+    for k, v in ref.items():
+        scale = float(v.abs().max())
+        if scale == 0.0:
+            assert float(dp[k].abs().max()) == 0.0, k
+            continue
+        err = float((dp[k] - v).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 2e-4, (k, err, scale)
+    if dist.get_rank() == 0:
+        print(f"DP_GRAD_OK backend={dist.get_backend()} ranks={dist.get_world_size()} tensors={len(ref)} worst={worst:.2e}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

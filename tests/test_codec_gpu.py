@@ -76,6 +76,26 @@ def test_symbol_outside_range_is_an_error():
         ans_encode(sym, torch.zeros(3, device=dev), torch.ones(3, device=dev), 0, 10)
 
 
+def test_malformed_streams_are_refused_on_the_host():
+    """A truncated file or a header whose segment count disagrees with (n, seg_len) must raise before any kernel reads
+    through offsets taken from it."""
+    import struct
+    from gsvc_amd import _lib, codec
+    n = 10_000
+    mu = torch.zeros(n, device="cuda")
+    sigma = torch.full((n,), 3.0, device="cuda")
+    sym = torch.randint(-8, 9, (n,), device="cuda", dtype=torch.int32)
+    stream = codec.ans_encode(sym, mu, sigma, -8, 8)
+    assert torch.equal(codec.ans_decode(stream, mu, sigma), sym)
+    with pytest.raises(_lib.GsvcError, match="truncated"):
+        codec.ans_decode(stream[:len(stream) // 2], mu, sigma)
+    hdr = list(codec._HEADER.unpack_from(stream, 0))
+    hdr[-1] -= 1                                           # n_seg smaller than ceil(n / seg_len)
+    bad = codec._HEADER.pack(*hdr) + stream[codec._HEADER.size:]
+    with pytest.raises(_lib.GsvcError, match="malformed header"):
+        codec.ans_decode(bad, mu, sigma)
+
+
 def test_encoder_decoder_gaussian_interface():
     """The reference-shaped pair: quantised features with a per-row step, de-quantised values back; the coded size
     agrees with EntropyGaussian(quantized=True) — the estimate estimate_final_bits is made of."""

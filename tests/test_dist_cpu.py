@@ -41,6 +41,27 @@ def _worker(rank, world, port, q):
     pc.offset_denom = torch.ones(6, 1)
     gd.allreduce_statistics(pc)
     assert torch.all(pc.opacity_accum == 3.0) and torch.all(pc.anchor_demon == 2.0) and torch.all(pc.offset_gradient_accum == 1.5)
+    # two densification intervals: what the ranks hold after the second reduction must equal a single process that saw every
+    # rank's observations — not world_size copies of the rows that survived the first adjust_anchor
+    def observe(step):        # this rank's new observations of interval `step`
+        return torch.arange(1.0, 4.0).view(3, 1) * (rank + 1) * step
+    def adjust(t):            # stand-in for adjust_anchor: rows above the threshold are consumed (zeroed), the rest survive
+        t[t > 5.0] = 0.0
+    pc2 = type("PC", (), {})()
+    for name in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
+        setattr(pc2, name, torch.zeros(3, 1))
+    single = torch.zeros(3, 1)
+    for step in (1, 2):
+        for name in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
+            getattr(pc2, name).add_(observe(step))
+        single += sum(torch.arange(1.0, 4.0).view(3, 1) * (r_ + 1) * step for r_ in range(world))
+        gd.allreduce_statistics(pc2)
+        assert torch.equal(pc2.opacity_accum, single), (step, pc2.opacity_accum.tolist(), single.tolist())
+        adjust(single)
+        for name in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
+            adjust(getattr(pc2, name))
+        gd.keep_statistics_on_rank0(pc2)
+        assert torch.equal(pc2.offset_denom, single if rank == 0 else torch.zeros(3, 1))
     # overlapped reducer: large tensors from hooks during backward, small ones in a flat bucket; a second step re-arms it
     red = gd.GradReducer()
     red.SMALL = 16
@@ -90,6 +111,8 @@ def test_two_rank_gloo():
 
 def test_frame_shard_partitions():
     from gsvc_amd.dist import frame_shard
+    with pytest.raises(ValueError, match="adjacent-frame pairs"):
+        frame_shard(4, 0, 8)              # more ranks than pairs: refused instead of handing out another rank's frames
     for T, W in ((600, 8), (300, 8), (17, 4), (9, 8), (2, 1)):
         blocks = [frame_shard(T, r, W) for r in range(W)]
         assert blocks[0][0] == 0 and blocks[-1][1] == T - 1

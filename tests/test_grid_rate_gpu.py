@@ -32,7 +32,12 @@ def _levels(D, res, log2):
                                               (3, 2, (6, 9, 14), 9, 333), (2, 4, (10, 18), 8, 64), (1, 1, (16, 64), 5, 100),
                                               (3, 16, (18, 40), 11, 257), (2, 32, (20,), 7, 65),
                                               # tables too large for 16 LDS slices: the global-atomic fallback of k_grid_bwd_lds
-                                              (3, 2, (64, 128, 256), 19, 20000), (2, 1, (1026, 2050), 21, 5000)])
+                                              (3, 2, (64, 128, 256), 19, 20000), (2, 1, (1026, 2050), 21, 5000),
+                                              # the production tables of cfg_20240919.yaml in full (reference
+                                              # scene/gaussian_model.py:280-281, arguments/__init__.py:68-70): 12 3-D levels up to
+                                              # resolution 514 with 2^13 rows, 4 2-D levels up to 1026 with 2^15 rows, 8 features
+                                              (3, 8, (18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514), 13, 30000),
+                                              (2, 8, (130, 258, 514, 1026), 15, 30000)])
 def test_grid_kernels_match_oracle(oracle_lib, D, Cf, res, log2, N):
     from gsvc_amd import gridencoder_backend as be
     rng = np.random.default_rng(D * 100 + Cf)

@@ -174,6 +174,63 @@ def test_dense_step_equals_per_render_step(entropy):
         assert (ga[n] - gb[n]).abs().max().item() <= 2e-3 * scale + 1e-12, n
 
 
+def test_dense_step_equals_per_render_step_at_cfg3_size():
+    """The same comparison at BASELINE.json configs[2] size with the production model: 1080p, 245 000 anchors x K = 10 in a
+    64-frame cube (about 48 000 visible anchors / 480 000 Gaussians per render in the 16-frame slab), the 12 + 3 x 4-level
+    hash grids with 8 features (cfg_20240919.yaml), rate term on (deterministic STE mode, rate over every visible
+    anchor): the batched un-compacted step that bench.py times against four reference-style render() calls."""
+    from gsvc_amd.arguments import cfg_20240919
+    from gsvc_amd.frame import SyntheticFrameCube
+    from gsvc_amd.model import GaussianModel
+    from gsvc_amd.train import Trainer
+    import gsvc_amd.generate as G
+    res = []
+    for batched in (True, False):
+        mp_, opt, pipe = cfg_20240919()
+        cube = SyntheticFrameCube(1080, 1920, 64, seed=1234, device="cuda").materialize()
+        mp_.threshold = 8.0 / cube.scale
+        opt.full_precision_training_total = opt.quantized_training_total = opt.entropy_constrained_train_total = 0
+        opt.ste_entropy_constrained_train_total = 100
+        opt.start_stat, opt.pause_densification, opt.iterations = 0, 0, 1
+        torch.manual_seed(0)
+        np.random.seed(0)
+        pc = GaussianModel(mp_, mp_.anchor_feature_dim, mp_.n_offsets, mp_.voxel_size, mp_.update_depth, mp_.update_init_factor,
+                           mp_.update_hierarchy_factor, mp_.use_feat_bank, n_features_per_level=mp_.grid_feature_dim,
+                           log2_hashmap_size=mp_.log2, log2_hashmap_size_2D=mp_.log2_2D, device="cuda")
+        rng = np.random.default_rng(0)
+        lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
+        pc.create_from_points(rng.uniform(lim, -lim, (245_000, 3)), spatial_lr_scale=1.0)
+        pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+        pc.training_setup(opt)
+        old = G.SAMPLE_RATE
+        G.SAMPLE_RATE = 2.0
+        try:
+            out = Trainer(pc, cube, opt, pipe, mp_, batched=batched).step(1, frame_idx=30)
+        finally:
+            G.SAMPLE_RATE = old
+        grads = {n: p.grad.clone() for n, p in pc.named_parameters() if p.grad is not None}
+        res.append((float(out.loss), grads, pc.opacity_accum.clone(), pc.anchor_demon.clone(), pc.offset_gradient_accum.clone(),
+                    pc.offset_denom.clone(), out.image1.clone(), [r.num_rendered for r in out.renders],
+                    [int(r.radii.numel()) for r in out.renders]))
+        del pc, cube, out
+        torch.cuda.empty_cache()
+    (la, ga, oa, da, ofa, oda, ia, na, pa), (lb, gb, ob, db, ofb, odb, ib, nb, pb) = res
+    assert min(pa) > 400_000, pa                       # un-compacted: K Gaussians per visible anchor
+    assert na == nb and abs(la - lb) < 1e-5 * max(1.0, abs(lb)), (na, nb, la, lb)
+    # 300-entry tile lists: a last-ulp difference in one Gaussian (the two paths run their MLPs over different row counts)
+    # moves a pixel by ~1e-5; threshold decisions on the fence (alpha vs 1/255) by up to 1/255 on isolated pixels
+    diff = (ia - ib).abs()
+    assert diff.max().item() < 5e-3 and (diff > 5e-5).float().mean().item() < 1e-4, (diff.max().item(), (diff > 5e-5).float().mean().item())
+    assert torch.equal(da, db) and torch.equal(oda, odb)
+    assert torch.allclose(oa, ob, rtol=1e-5, atol=1e-6)
+    # accumulated screen-space gradient norms: relative to the largest (a Gaussian whose gradient is 1e-6 of it is noise)
+    assert (ofa - ofb).abs().max().item() <= 2e-3 * ofb.abs().max().item(), ((ofa - ofb).abs().max().item(), ofb.abs().max().item())
+    assert set(gb) - set(ga) == {"_anchor"} and len(ga) > 20
+    for n in ga:
+        scale = gb[n].abs().max().item()
+        assert (ga[n] - gb[n]).abs().max().item() <= 2e-3 * scale + 1e-12, n
+
+
 def test_fused_loss_terms_match_torch():
     """csrc/losses.hip against plain torch statements of the same terms: the regularisers over un-compacted per-render
     segments (values and gradients), and the optical-flow pair loss against the reference-style
@@ -384,26 +441,68 @@ def test_estimate_final_bits_matches_reference():
     assert log == str(b["log_info"])
 
 
-@pytest.mark.gpu
-def test_two_ranks_share_one_gpu_through_gloo():
-    """The multi-rank fitting step end to end on GPU tensors: two torchrun ranks on device 0 with the gloo backend (RCCL
-    wants one GPU per rank; the driver's multi-GPU runs use it) — parameter broadcast, gradient all-reduce from the
-    backward hooks, the early overflow decision, per-rank frame shards, one JSON line from rank 0."""
-    import json
+def _run_bench(extra_env, *args, timeout=900):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GSVC_DIST_BACKEND="gloo", GSVC_SHARE_GPU="1")
+    env = dict(os.environ, **extra_env)
+    env.pop("WORLD_SIZE", None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], cwd=root, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (the driver's command form) must run TWO ranks or fail: with the single-GPU test knobs
+    (both ranks on device 0, gloo) it starts torch.distributed.run as a child and relays rank 0's line with n_gpus = 2 —
+    the whole multi-rank fitting step on GPU tensors: parameter broadcast, gradient all-reduce from the backward hooks, the
+    early overflow decision, per-rank frame shards; without the knobs on a box with fewer than 2 GPUs it exits non-zero
+    and prints no JSON line (it used to run one rank and report n_gpus 1)."""
+    import json
+    small = ["--workload", "train_step", "--steps", "3", "--warmup", "1", "--pretrain", "2", "--anchors", "20000",
+             "--height", "272", "--width", "480", "--no-cpu-baseline"]
+    out = _run_bench({"GSVC_DIST_BACKEND": "gloo", "GSVC_SHARE_GPU": "1"}, "--gpus", "2", *small)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["dist_backend"] == "gloo"
+    assert res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["gradient_exchange"]["gradient_bytes_per_step"] > 0 and "exposed_ms_per_step" in res["gradient_exchange"]
+    if torch.cuda.device_count() < 2:
+        out = _run_bench({}, "--gpus", "2", *small)
+        assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert "GPU(s)" in out.stderr
+
+
+def _run_dp_grad_worker(env_extra):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "train_step", "--steps", "3",
-           "--warmup", "1", "--pretrain", "2", "--anchors", "20000", "--height", "272", "--width", "480", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
+           "--master-port", str(port), os.path.join(root, "tests", "_dp_grad_worker.py")]
+    out = subprocess.run(cmd, cwd=root, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "DP_GRAD_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
+    return out.stdout
+
+
+@pytest.mark.gpu
+def test_two_rank_step_averages_gradients():
+    """One data-parallel step leaves on every rank the mean of the two single-process gradients of the ranks' frame pairs
+    (every parameter group; tests/_dp_grad_worker.py).  Both ranks on device 0 through gloo: runs on a 1-GPU box."""
+    assert "backend=gloo ranks=2" in _run_dp_grad_worker({"GSVC_DIST_BACKEND": "gloo", "GSVC_SHARE_GPU": "1"})
+
+
+@pytest.mark.gpu
+def test_two_rank_step_averages_gradients_over_rccl():
+    """The same over RCCL (backend "nccl"), one GPU per rank: the hook-driven asynchronous all-reduces run on RCCL's own
+    streams next to the backward."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs for one rank per GPU over RCCL; this box has {torch.cuda.device_count()}")
+    assert "backend=nccl ranks=2" in _run_dp_grad_worker({"GSVC_DIST_BACKEND": "nccl"})
 
 
 @pytest.mark.gpu
@@ -440,6 +539,7 @@ def test_evaluate_and_checkpoint_round_trip(tmp_path):
         assert np.isfinite(ev[k]), (k, ev)
     assert 0.0 <= ev["ssim"] <= 1.0 and 0.0 <= ev["msssim"] <= 1.0 and ev["psnr"] > 0
     path = str(tmp_path / "ck.pt")
+    pc.spatial_lr_scale = 2.5
     save_checkpoint(pc, path, iteration=8)
     pc2, cube2, opt2, pipe2, mp2, _ = _setup(anchors=4000, H=192, W=256, seed=5)      # different initial values
     assert load_checkpoint(pc2, path, training_args=opt2) == 8
@@ -449,6 +549,12 @@ def test_evaluate_and_checkpoint_round_trip(tmp_path):
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     st1, st2 = pc.optimizer.state[pc._anchor_feat], pc2.optimizer.state[pc2._anchor_feat]
     assert torch.equal(st1["exp_avg"], st2["exp_avg"]) and float(st1["step"]) == float(st2["step"])
+    # resuming keeps the densification statistics (training_setup re-zeroes them: they are restored after it) and the
+    # learning-rate scale of the per-anchor groups
+    assert pc2.spatial_lr_scale == 2.5
+    assert float(pc.opacity_accum.abs().sum()) > 0
+    for name in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
+        assert torch.equal(getattr(pc, name), getattr(pc2, name)), name
     opt2.full_precision_training_total = 1000
     out = Trainer(pc2, cube2, opt2, pipe2, mp2).step(9)
     assert np.isfinite(float(out.loss))
