@@ -38,6 +38,7 @@ def averages(path, counter):
 
 def main():
     workload, fetch_csv, write_csv = sys.argv[1:4]
+    tag = sys.argv[4] if len(sys.argv) > 4 else "unknown"
     fetch, write = averages(fetch_csv, "FETCH_SIZE"), averages(write_csv, "WRITE_SIZE")
     out_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
@@ -46,9 +47,15 @@ def main():
     data[workload] = {k: int(round((2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024)) for k in sorted(set(fetch) | set(write))}
     if workload == "raster_fwdbwd":              # the forward kernels of the same launches
         data["raster_fwd"] = {k: v for k, v in data[workload].items() if "bwd" not in k}
-    data["raw_KiB"] = {}
-    for k in sorted(set(fetch) | set(write)):
-        data["raw_KiB"][k] = {"FETCH_SIZE": fetch.get(k), "WRITE_SIZE": write.get(k)}
+    data.setdefault("_binary", {})[workload] = tag
+    data.setdefault("_source", {})[workload] = (f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python3 bench.py "
+                                                f"--workload {workload}; CSVs: {os.path.basename(fetch_csv)}, {os.path.basename(write_csv)}")
+    if workload == "raster_fwdbwd":
+        data["_binary"]["raster_fwd"], data["_source"]["raster_fwd"] = data["_binary"][workload], data["_source"][workload]
+    raw = data.setdefault("raw_KiB", {})
+    if not isinstance(raw.get(workload), dict) or "FETCH_SIZE" in raw.get(workload, {}):
+        raw = data["raw_KiB"] = {k: v for k, v in raw.items() if isinstance(v, dict) and "FETCH_SIZE" not in v}
+    raw[workload] = {k: {"FETCH_SIZE": fetch.get(k), "WRITE_SIZE": write.get(k)} for k in sorted(set(fetch) | set(write))}
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
     print(json.dumps(data[workload], indent=1))
 
