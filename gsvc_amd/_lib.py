@@ -28,7 +28,14 @@ class RasterSettingsC(C.Structure):
         ("scale_modifier", C.c_float),
         ("bg", C.c_float * 3),
         ("viewmatrix", C.c_float * 16),
+        ("flags", C.c_uint32),
+        ("low_pass", C.c_float),
     ]
+
+
+# gsvc_raster_settings.flags (include/gsvc_hip.h)
+RASTER_SLAB_ONE_SIDED, RASTER_PIXEL_CORNER, RASTER_DEPTH_DESCENDING = 1, 2, 4
+RASTER_MEANS2D_PIXEL_UNITS, RASTER_CLAMP_STOPS_GRADIENT, RASTER_NO_LOW_PASS = 8, 16, 32
 
 
 class AdamTensorC(C.Structure):

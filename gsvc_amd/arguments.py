@@ -39,6 +39,10 @@ class PipelineParams:
     compute_cov3D_python: bool = False
     debug: bool = False
     skip_prefetch: bool = False
+    # not in the reference: rasterizer convention switches handed to every render (gsvc_raster_settings.flags / .low_pass,
+    # include/gsvc_hip.h; 0 = DESIGN.md's raster spec) — how a maintainer matches the real extension, INTEGRATION.md
+    raster_flags: int = 0
+    raster_low_pass: float = 0.0
 
 
 def _lr(init, final, delay_mult=0.01, max_steps=40_000):

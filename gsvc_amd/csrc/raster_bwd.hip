@@ -152,6 +152,7 @@ struct Sums9 {
 // contributor, alpha < 1/255, power > 0, outside the image) runs the same instructions with alpha = 0 and G = 0, which
 // leaves T and bd unchanged (rcp(1) = 1, 0 * cd + 1 * bd = bd) and adds zeros.  No EXEC-mask branches: the compiler's
 // branchy form spent a third of its instructions on zero-filling the nine sums on every path.
+template <bool CLAMP_STOP>
 __device__ __forceinline__ void bwd_pixel(PixState &p, float dx, float dy, const float4 &a, const float4 &b, float cb,
                                           int contributor, Sums9 &s)
 {
@@ -163,7 +164,8 @@ __device__ __forceinline__ void bwd_pixel(PixState &p, float dx, float dy, const
     const float araw = fminf(ALPHA_MAX, b.y * Graw);
     const bool valid = (contributor <= p.last) & !(pw < 0.0f) & !(araw < ALPHA_MIN);
     const float alpha = valid ? araw : 0.0f;
-    const float G = valid ? Graw : 0.0f;
+    // CLAMP_STOP (GSVC_RASTER_CLAMP_STOPS_GRADIENT): where min(0.99, .) is active alpha does not depend on the Gaussian
+    const float G = (CLAMP_STOP ? (valid & !(b.y * Graw > ALPHA_MAX)) : valid) ? Graw : 0.0f;
     const float cd = fmaf(cb, p.d2, fmaf(b.w, p.d1, b.z * p.d0));   // colour . dL/dpixel
     const float oma = 1.0f - alpha;
     const float inv = __builtin_amdgcn_rcpf(oma);
@@ -188,6 +190,7 @@ __device__ __forceinline__ void bwd_pixel(PixState &p, float dx, float dy, const
 #ifndef GSVC_BWD_WAVES
 #define GSVC_BWD_WAVES 4
 #endif
+template <bool CLAMP_STOP>
 __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterParams st, const int32_t *__restrict__ tile_offsets,
                                                        const int32_t *__restrict__ point_list,
                                                        const uint2 *__restrict__ inst_bbox,
@@ -338,7 +341,7 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (quads & (1 << q))
-                    bwd_pixel(ps[q], dxb - (float)(8 * (q & 1)), dyb - (float)(8 * (q >> 1)), a, b, c.x, contributor, s);
+                    bwd_pixel<CLAMP_STOP>(ps[q], dxb - (float)(8 * (q & 1)), dyb - (float)(8 * (q >> 1)), a, b, c.x, contributor, s);
         };
         // after a reduction lane 8g holds the total of value g (g < 8) in the first register, lane 63 the total of the ninth
         int j = 0;
@@ -422,8 +425,9 @@ __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, co
         dv = -op * (o.C * sy + o.B * sx);
         dA = -0.5f * op * sxx; dB = -op * sxy; dC = -0.5f * op * syy;
         gc[0] = a1.z; gc[1] = a1.w; gc[2] = a2;
-        g2[0] = du * 0.5f * (float)st.W;
-        g2[1] = dv * 0.5f * (float)st.H;
+        const bool pixel_units = st.flags & GSVC_RASTER_MEANS2D_PIXEL_UNITS;
+        g2[0] = pixel_units ? du : du * 0.5f * (float)st.W;
+        g2[1] = pixel_units ? dv : dv * 0.5f * (float)st.H;
         const float *M = st.m;
         for (int j = 0; j < 3; j++) g3[j] = st.scale * (M[j] * du + M[4 + j] * dv);
 
@@ -515,8 +519,12 @@ extern "C" int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_
     static const int dbg = getenv("GSVC_BWD_DEBUG") ? atoi(getenv("GSVC_BWD_DEBUG")) : 0;   // kernel-timing experiments
     {
         ProfScope _prof("k_blend_bwd", s);
-        hipLaunchKernelGGL(k_blend_bwd_tile, dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, inst_bbox, gslot,
-                           (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters, dbg);
+        if (p.flags & GSVC_RASTER_CLAMP_STOPS_GRADIENT)
+            hipLaunchKernelGGL(k_blend_bwd_tile<true>, dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, inst_bbox,
+                               gslot, (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters, dbg);
+        else
+            hipLaunchKernelGGL(k_blend_bwd_tile<false>, dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, inst_bbox,
+                               gslot, (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters, dbg);
     }
     {
         ProfScope _prof("k_gaussian_bwd", s);

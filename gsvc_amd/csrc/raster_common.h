@@ -10,7 +10,7 @@
 namespace gsvc {
 
 constexpr int TILE = 16;
-constexpr float LOWPASS = 0.3f;
+constexpr float LOWPASS = 0.3f;   // default of gsvc_raster_settings.low_pass
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_MIN = 0.0001f;
@@ -90,6 +90,9 @@ struct RasterParams {
     float x_min, y_min, scale, threshold, scale_modifier;
     float bg0, bg1, bg2;
     float m[12];  // rows 0..2 of the view matrix
+    uint32_t flags;     // GSVC_RASTER_* convention switches
+    float low_pass;     // resolved value (default 0.3)
+    float pix_off;      // 0.5 (pixel centres on integers) or 0
 };
 
 inline RasterParams make_params(const gsvc_raster_settings &s)
@@ -101,6 +104,9 @@ inline RasterParams make_params(const gsvc_raster_settings &s)
     p.scale_modifier = s.scale_modifier;
     p.bg0 = s.bg[0]; p.bg1 = s.bg[1]; p.bg2 = s.bg[2];
     for (int i = 0; i < 12; i++) p.m[i] = s.viewmatrix[i];
+    p.flags = s.flags;
+    p.low_pass = (s.flags & GSVC_RASTER_NO_LOW_PASS) ? 0.0f : (s.low_pass != 0.0f ? s.low_pass : LOWPASS);
+    p.pix_off = (s.flags & GSVC_RASTER_PIXEL_CORNER) ? 0.0f : 0.5f;
     return p;
 }
 
@@ -178,7 +184,9 @@ __device__ __forceinline__ int preprocess_gaussian(const RasterParams &st, float
     o.radius = 0;
     o.radius_raw = 0;
     o.xv = xv;
-    if (!(fabsf(zv) <= st.threshold)) return 0;
+    if (st.flags & GSVC_RASTER_SLAB_ONE_SIDED) {
+        if (!(zv <= 0.0f && zv >= -st.threshold)) return 0;
+    } else if (!(fabsf(zv) <= st.threshold)) return 0;
 
     float R00 = 1.f - 2.f * (qy * qy + qz * qz);
     float R01 = 2.f * (qx * qy - qr * qz);
@@ -208,9 +216,9 @@ __device__ __forceinline__ int preprocess_gaussian(const RasterParams &st, float
     float U10 = c00 * T10 + c01 * T11 + c02 * T12;
     float U11 = c01 * T10 + c11 * T11 + c12 * T12;
     float U12 = c02 * T10 + c12 * T11 + c22 * T12;
-    float ca = T00 * U00 + T01 * U01 + T02 * U02 + LOWPASS;
+    float ca = T00 * U00 + T01 * U01 + T02 * U02 + st.low_pass;
     float cb = T00 * U10 + T01 * U11 + T02 * U12;
-    float cc = T10 * U10 + T11 * U11 + T12 * U12 + LOWPASS;
+    float cc = T10 * U10 + T11 * U11 + T12 * U12 + st.low_pass;
     float det = ca * cc - cb * cb;
     if (!(det != 0.0f)) return 0;
     float det_inv = (1.0f / det);
@@ -226,8 +234,8 @@ __device__ __forceinline__ int preprocess_gaussian(const RasterParams &st, float
     if (rad_f > 1.0e9f) rad_f = 1.0e9f;
     int radius = (int)rad_f;
 
-    float u = (xv - st.x_min) * st.scale - 0.5f;
-    float v = (yv - st.y_min) * st.scale - 0.5f;
+    float u = (xv - st.x_min) * st.scale - st.pix_off;
+    float v = (yv - st.y_min) * st.scale - st.pix_off;
     float rf = (float)radius;
     int x0 = tile_clamp(((u - rf) / (float)TILE), st.gx);
     int x1 = tile_clamp(((u + rf + (float)(TILE - 1)) / (float)TILE), st.gx);

@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
             bx0 = o.x0; bx1 = o.x1;
         } else if (o.radius_raw > 0) {
             // opposite view: x_view' = -x_view, same y, same radius; rectangle by the same formula, then mirrored
-            const float ub = (-o.xv - st.x_min) * st.scale - 0.5f, rf = (float)o.radius_raw;
+            const float ub = (-o.xv - st.x_min) * st.scale - st.pix_off, rf = (float)o.radius_raw;
             const int xb0 = tile_clamp((ub - rf) / (float)TILE, st.gx), xb1 = tile_clamp((ub + rf + (float)(TILE - 1)) / (float)TILE, st.gx);
             const bool vis_b = (xb1 - xb0) * (o.y1 - o.y0) > 0;
             const int mx0 = st.gx - xb1, mx1 = st.gx - xb0;
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
             rec.r = colors[3 * i + 0]; rec.g = colors[3 * i + 1]; rec.b = colors[3 * i + 2];
             rec.depth = o.depth;
             alpha_bbox(o.u, o.v, o.A, o.B, o.C, rec.opacity, rec.bbox_x, rec.bbox_y);
-            br.depth = o.depth;
+            br.depth = (st.flags & GSVC_RASTER_DEPTH_DESCENDING) ? -o.depth : o.depth;      // the sort key
             br.rect_x = radius > 0 ? ((uint32_t)o.x0 | ((uint32_t)o.x1 << 16)) : 0u;
             br.rect_y = (uint32_t)o.y0 | ((uint32_t)o.y1 << 16);
             rec.rect_x = br.rect_x; rec.rect_y = br.rect_y;
@@ -1047,6 +1047,12 @@ static int raster_forward_impl(const gsvc_raster_settings *settings, int64_t P, 
     GSVC_REQUIRE(image && geom && binning && image_state, "raster_forward: NULL output/state pointer");
     if (pair && (settings->image_width % TILE != 0 || P >= ((int64_t)1 << 29))) {
         set_error("raster_forward_pair: needs image_width %% 16 == 0 (tile grids of the two views must mirror) and P < 2^29");
+        return GSVC_E_UNSUPPORTED;
+    }
+    if (pair && (settings->flags & (GSVC_RASTER_SLAB_ONE_SIDED | GSVC_RASTER_PIXEL_CORNER))) {
+        // a one-sided slab shows the two views different Gaussians, and without the half-pixel offset the mirrored view's
+        // pixel centres fall one pixel beside this view's: the opposite view is then not the reverse composite of this one
+        set_error("raster_forward_pair: not defined under GSVC_RASTER_SLAB_ONE_SIDED / GSVC_RASTER_PIXEL_CORNER (render the two views)");
         return GSVC_E_UNSUPPORTED;
     }
     GSVC_REQUIRE(P == 0 || (means3D && colors && opacities && scales && rotations && radii),

@@ -19,7 +19,8 @@ def raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier=1.0):
         image_height=int(frame.image_height), image_width=int(frame.image_width), x_min=frame.x_min, y_min=frame.y_min,
         scale=frame.scale, threshold=pc.model_config.threshold, bg=bg_color, scale_modifier=scaling_modifier,
         viewmatrix=frame.view_matrix.permute(1, 0), sh_degree=pc.model_config.sh_degree, campos=frame.cam_pos,
-        prefiltered=False, debug=getattr(pipe, "debug", False))
+        prefiltered=False, debug=getattr(pipe, "debug", False), flags=int(getattr(pipe, "raster_flags", 0) or 0),
+        low_pass=float(getattr(pipe, "raster_low_pass", 0.0) or 0.0))
 
 
 def prefilter_geometry(pc):

@@ -91,7 +91,7 @@ def render_pair(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, m
         gss = generate_neural_gaussians(frame, pc, visible_mask, mode)
         cs = settings_to_c(raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier))
         args = (gss.xyz.contiguous(), gss.color.contiguous(), gss.opacity.contiguous(), gss.scaling.contiguous(), gss.rot.contiguous())
-        if int(frame.image_width) % 16 == 0:
+        if int(frame.image_width) % 16 == 0 and not (cs.flags & 3):   # (one-sided slab / pixel-corner: the views do not mirror)
             image, radii, state = raster_forward(cs, *args, pair=True)
         else:   # the two views' tile grids do not mirror: two passes
             import copy
@@ -116,8 +116,9 @@ def render_frames(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0
     from ..rasterizer import resolve_deferred
     frames = list(frames)
     for f in frames:
-        if int(f.image_width) % 16 != 0:
-            raise ValueError("render_frames: the two-view pass needs an image width that is a multiple of 16 (use render_pair)")
+        if int(f.image_width) % 16 != 0 or (int(getattr(pipe, "raster_flags", 0) or 0) & 3):
+            raise ValueError("render_frames: the two-view pass needs an image width that is a multiple of 16 and the symmetric-slab / "
+                             "pixel-centre conventions (use render_pair)")
     with torch.no_grad():
         # the generators' feature-only half does not depend on the frame: once per call for all anchors
         trunks = generator_trunks(pc) if mode in (GenerateMode.DECODING_AS_IS, GenerateMode.TRAINING_FULL_PRECISION) else None

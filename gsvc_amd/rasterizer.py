@@ -42,6 +42,10 @@ class GaussianRasterizationSettings(NamedTuple):
     campos: Optional[torch.Tensor] = None
     prefiltered: bool = False
     debug: bool = False
+    # not fields of the reference's settings: the convention switches of include/gsvc_hip.h (GSVC_RASTER_*, 0 = DESIGN.md's
+    # raster spec) and the low-pass added to the 2-D covariance (0 = the default 0.3), see INTEGRATION.md
+    flags: int = 0
+    low_pass: float = 0.0
 
 
 def _host_floats(t, n):
@@ -61,6 +65,7 @@ def settings_to_c(rs: GaussianRasterizationSettings) -> _lib.RasterSettingsC:
     s.threshold, s.scale_modifier = float(rs.threshold), float(rs.scale_modifier)
     s.bg[:] = _host_floats(rs.bg, 3).tolist()
     s.viewmatrix[:] = _host_floats(rs.viewmatrix, 16).tolist()
+    s.flags, s.low_pass = int(getattr(rs, "flags", 0)), float(getattr(rs, "low_pass", 0.0))
     return s
 
 

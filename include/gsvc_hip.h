@@ -66,7 +66,21 @@ typedef struct gsvc_raster_settings {
     float scale_modifier;
     float bg[3];
     float viewmatrix[16];
+    uint32_t flags;   /* GSVC_RASTER_* convention switches below; 0 = the conventions of DESIGN.md "Raster spec" */
+    float low_pass;   /* added to the diagonal of the 2-D covariance, pixels^2; 0 = the default 0.3 (reference
+                         arguments/__init__.py:55); GSVC_RASTER_NO_LOW_PASS for none */
 } gsvc_raster_settings;
+
+/* Convention switches.  The external CUDA rasterizer's source is not part of the reference tree (README.md:52), so the
+ * conventions its call sites do not pin are kept switchable; INTEGRATION.md "Calibrating the rasterizer conventions" shows
+ * how to find the combination that reproduces the real extension on one small scene.  Every combination is covered by the
+ * oracle <-> dense-float64 cross-check and by HIP <-> oracle parity (tests/test_oracle_raster.py, tests/test_raster_gpu.py). */
+#define GSVC_RASTER_SLAB_ONE_SIDED 1u        /* keep -threshold <= z_view <= 0 instead of |z_view| <= threshold (preprocess.py:108-112) */
+#define GSVC_RASTER_PIXEL_CORNER 2u          /* u = (x_view - x_min) * scale, without the -0.5 that puts pixel centres on integers */
+#define GSVC_RASTER_DEPTH_DESCENDING 4u      /* composite from the largest view-space z to the smallest (ties still by index) */
+#define GSVC_RASTER_MEANS2D_PIXEL_UNITS 8u   /* dL_dmeans2D = (dL/du, dL/dv) in pixels instead of NDC units (x W/2, x H/2) */
+#define GSVC_RASTER_CLAMP_STOPS_GRADIENT 16u /* no gradient to conic / mean / opacity where the alpha <= 0.99 clamp is active */
+#define GSVC_RASTER_NO_LOW_PASS 32u          /* low_pass = 0 exactly */
 
 /* Byte sizes of the three opaque state blobs of one forward call (the 3DGS-lineage "geomBuffer /
  * binningBuffer / imgBuffer" the reference extension hands back to autograd). */

@@ -61,10 +61,13 @@ class RasterSettings(C.Structure):
         ("scale_modifier", C.c_float),
         ("bg", C.c_float * 3),
         ("viewmatrix", C.c_float * 16),
+        ("flags", C.c_uint32),
+        ("low_pass", C.c_float),
     ]
 
 
-def make_settings(H, W, x_min, y_min, scale, threshold, viewmatrix, bg=(0.0, 0.0, 0.0), scale_modifier=1.0):
+def make_settings(H, W, x_min, y_min, scale, threshold, viewmatrix, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, flags=0,
+                  low_pass=0.0):
     s = RasterSettings()
     s.image_height, s.image_width = int(H), int(W)
     s.x_min, s.y_min, s.scale, s.threshold = float(x_min), float(y_min), float(scale), float(threshold)
@@ -72,6 +75,7 @@ def make_settings(H, W, x_min, y_min, scale, threshold, viewmatrix, bg=(0.0, 0.0
     s.bg[:] = [float(b) for b in bg]
     vm = np.asarray(viewmatrix, dtype=np.float32).reshape(16)
     s.viewmatrix[:] = [float(v) for v in vm]
+    s.flags, s.low_pass = int(flags), float(low_pass)
     return s
 
 

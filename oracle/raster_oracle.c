@@ -45,7 +45,21 @@ typedef struct {
     float scale_modifier;
     float bg[3];
     float viewmatrix[16]; /* row-major M: p_view = M[:3,:3] p + M[:3,3] */
+    uint32_t flags;       /* convention switches, same bits as include/gsvc_hip.h GSVC_RASTER_* */
+    float low_pass;       /* 0 = default 0.3 */
 } oracle_raster_settings;
+
+#define F_SLAB_ONE_SIDED 1u
+#define F_PIXEL_CORNER 2u
+#define F_DEPTH_DESCENDING 4u
+#define F_MEANS2D_PIXEL_UNITS 8u
+#define F_CLAMP_STOPS_GRADIENT 16u
+#define F_NO_LOW_PASS 32u
+
+static inline float low_pass_of(const oracle_raster_settings *st)
+{
+    return (st->flags & F_NO_LOW_PASS) ? 0.0f : (st->low_pass != 0.0f ? st->low_pass : LOWPASS);
+}
 
 typedef struct {
     float u, v, depth;
@@ -84,7 +98,9 @@ static int preprocess_one(const oracle_raster_settings *st, const float *p, cons
     float xv = M[0] * p[0] + M[1] * p[1] + M[2] * p[2] + M[3];
     float yv = M[4] * p[0] + M[5] * p[1] + M[6] * p[2] + M[7];
     float zv = M[8] * p[0] + M[9] * p[1] + M[10] * p[2] + M[11];
-    if (!(fabsf(zv) <= st->threshold)) return 0; /* slab cull, NaN culled */
+    if (st->flags & F_SLAB_ONE_SIDED) {
+        if (!(zv <= 0.0f && zv >= -st->threshold)) return 0;
+    } else if (!(fabsf(zv) <= st->threshold)) return 0; /* slab cull, NaN culled */
 
     /* rotation from quaternion (r,x,y,z) used as given (reference utils/general_utils.py:98-119 convention) */
     float r = q[0], x = q[1], y = q[2], z = q[3];
@@ -120,9 +136,10 @@ static int preprocess_one(const oracle_raster_settings *st, const float *p, cons
         U0[a] = C3[a][0] * T0[0] + C3[a][1] * T0[1] + C3[a][2] * T0[2];
         U1[a] = C3[a][0] * T1[0] + C3[a][1] * T1[1] + C3[a][2] * T1[2];
     }
-    float ca = T0[0] * U0[0] + T0[1] * U0[1] + T0[2] * U0[2] + LOWPASS;
+    const float lowpass = low_pass_of(st);
+    float ca = T0[0] * U0[0] + T0[1] * U0[1] + T0[2] * U0[2] + lowpass;
     float cb = T0[0] * U1[0] + T0[1] * U1[1] + T0[2] * U1[2];
-    float cc = T1[0] * U1[0] + T1[1] * U1[1] + T1[2] * U1[2] + LOWPASS;
+    float cc = T1[0] * U1[0] + T1[1] * U1[1] + T1[2] * U1[2] + lowpass;
     float det = ca * cc - cb * cb;
     if (!(det != 0.0f)) return 0; /* det==0 or NaN */
     float det_inv = 1.0f / det;
@@ -138,8 +155,9 @@ static int preprocess_one(const oracle_raster_settings *st, const float *p, cons
     if (rad_f > 1.0e9f) rad_f = 1.0e9f;
     int radius = (int)rad_f;
 
-    float u = (xv - st->x_min) * st->scale - 0.5f;
-    float v = (yv - st->y_min) * st->scale - 0.5f;
+    const float pix_off = (st->flags & F_PIXEL_CORNER) ? 0.0f : 0.5f;
+    float u = (xv - st->x_min) * st->scale - pix_off;
+    float v = (yv - st->y_min) * st->scale - pix_off;
     float rf = (float)radius;
     int x0 = tile_clamp((u - rf) / (float)TILE, gx);
     int x1 = tile_clamp((u + rf + (float)(TILE - 1)) / (float)TILE, gx);
@@ -227,7 +245,7 @@ int64_t gsvc_oracle_raster_forward(const oracle_raster_settings *st, int64_t P, 
     int64_t n = 0;
     for (int64_t i = 0; i < P; i++) {
         if (!radii[i]) continue;
-        uint32_t db = order_bits(pre[i].depth);
+        uint32_t db = order_bits((st->flags & F_DEPTH_DESCENDING) ? -pre[i].depth : pre[i].depth);
         for (int ty = pre[i].rect[1]; ty < pre[i].rect[3]; ty++)
             for (int tx = pre[i].rect[0]; tx < pre[i].rect[2]; tx++) {
                 inst[n].tile = (uint32_t)(ty * gx + tx);
@@ -356,6 +374,10 @@ void gsvc_oracle_raster_backward(const oracle_raster_settings *st, int64_t P, co
                     /* the 0.99 clamp is not special-cased (gradient flows as if unclamped), as in the
                        published algorithm */
                     float dL_dG = o * dL_dalpha;
+                    if ((st->flags & F_CLAMP_STOPS_GRADIENT) && o * G > ALPHA_MAX) {
+                        dL_dG = 0.0f;      /* alpha = 0.99 there: it depends neither on G nor on the opacity */
+                        dL_dalpha = 0.0f;  /* (only its use for dL/dopacity below: the recurrences are done with it) */
+                    }
                     float gdx = G * dx, gdy = G * dy;
                     float dG_du = -gdx * g->conic[0] - gdy * g->conic[1];
                     float dG_dv = -gdy * g->conic[2] - gdx * g->conic[1];
@@ -378,8 +400,13 @@ void gsvc_oracle_raster_backward(const oracle_raster_settings *st, int64_t P, co
         if (!radii[i]) continue;
         const double *a = acc + 9 * i;
         double du = a[0], dv = a[1], dA = a[2], dB = a[3], dC = a[4];
-        gm2[0] = (float)(du * 0.5 * W);
-        gm2[1] = (float)(dv * 0.5 * H);
+        if (st->flags & F_MEANS2D_PIXEL_UNITS) {
+            gm2[0] = (float)du;
+            gm2[1] = (float)dv;
+        } else {
+            gm2[0] = (float)(du * 0.5 * W);
+            gm2[1] = (float)(dv * 0.5 * H);
+        }
         dL_dopacity[i] = (float)a[5];
         gc[0] = (float)a[6]; gc[1] = (float)a[7]; gc[2] = (float)a[8];
         /* means: u = (M0.p + M03 - x_min)*scale - .5 */

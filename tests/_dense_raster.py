@@ -19,7 +19,8 @@ def quat_to_rot(q):
 
 
 def dense_render(settings, means3D, colors, opacities, scales, rotations, radii, uv_delta=None):
-    """settings: dict(H,W,x_min,y_min,scale,threshold,viewmatrix[4,4],bg[3],scale_modifier).
+    """settings: dict(H,W,x_min,y_min,scale,threshold,viewmatrix[4,4],bg[3],scale_modifier[,flags,low_pass]); flags are the
+    GSVC_RASTER_* convention switches of include/gsvc_hip.h (the slab test itself is in `radii`, which the oracle provides).
     radii: int array from the oracle (defines visibility and the tile rectangle, both non-differentiable).
     All tensor inputs float64.  Returns image [3,H,W]."""
     H, W = settings["H"], settings["W"]
@@ -34,13 +35,16 @@ def dense_render(settings, means3D, colors, opacities, scales, rotations, radii,
     cov3 = L @ L.transpose(1, 2)
     T2 = sc * Wm[:2, :]
     cov2 = T2 @ cov3 @ T2.T
-    a = cov2[:, 0, 0] + 0.3
+    flags = int(settings.get("flags", 0))
+    lp = 0.0 if flags & 32 else (settings.get("low_pass", 0.0) or 0.3)
+    off = 0.0 if flags & 2 else 0.5
+    a = cov2[:, 0, 0] + lp
     b = cov2[:, 0, 1]
-    c = cov2[:, 1, 1] + 0.3
+    c = cov2[:, 1, 1] + lp
     det = a * c - b * b
     A, B, Cc = c / det, -b / det, a / det
-    u = (pv[:, 0] - settings["x_min"]) * sc - 0.5
-    v = (pv[:, 1] - settings["y_min"]) * sc - 0.5
+    u = (pv[:, 0] - settings["x_min"]) * sc - off
+    v = (pv[:, 1] - settings["y_min"]) * sc - off
     if uv_delta is not None:
         u = u + uv_delta[:, 0]
         v = v + uv_delta[:, 1]
@@ -52,6 +56,8 @@ def dense_render(settings, means3D, colors, opacities, scales, rotations, radii,
     radii = np.asarray(radii)
     # order: depth ascending (float32 value as the oracle sees it), ties by index
     depth32 = pv[:, 2].detach().numpy().astype(np.float32)
+    if flags & 4:
+        depth32 = -depth32
     order = sorted([i for i in range(P) if radii[i] > 0], key=lambda i: (depth32[i], i))
     T = torch.ones(H, W, dtype=torch.float64)
     C = torch.zeros(3, H, W, dtype=torch.float64)
@@ -73,7 +79,10 @@ def dense_render(settings, means3D, colors, opacities, scales, rotations, radii,
         dy = v[i] - ys
         power = -0.5 * (A[i] * dx * dx + Cc[i] * dy * dy) - B[i] * dx * dy
         raw = opacities[i] * torch.exp(power)
-        alpha = raw + (torch.clamp(raw, max=0.99) - raw).detach()  # clamp value, pass-through gradient
+        if flags & 16:
+            alpha = torch.clamp(raw, max=0.99)                          # a real clamp: no gradient where it is active
+        else:
+            alpha = raw + (torch.clamp(raw, max=0.99) - raw).detach()  # clamp value, pass-through gradient
         valid = member & (power <= 0) & (alpha >= 1.0 / 255.0) & (~done)
         test_T = T * (1 - alpha)
         stop = valid & (test_T < 1e-4)

@@ -19,13 +19,20 @@ def _tiny_scene(P=40, H=40, W=56, seed=0, sigma=(1.0, 5.0)):
 
 def _settings(oracle, s, view="viewmatrix"):
     return oracle.make_settings(s["H"], s["W"], s["x_min"], s["y_min"], s["scale"], s["threshold"], s[view],
-                                bg=s["bg"], scale_modifier=s["scale_modifier"])
+                                bg=s["bg"], scale_modifier=s["scale_modifier"], flags=s.get("flags", 0),
+                                low_pass=s.get("low_pass", 0.0))
 
 
-def test_forward_matches_dense(oracle_lib):
+# every convention switch of include/gsvc_hip.h alone, all of them together, and a non-default low-pass
+FLAG_CASES = [(0, 0.0), (1, 0.0), (2, 0.0), (4, 0.0), (8, 0.0), (16, 0.0), (32, 0.0), (0, 0.1), (1 | 2 | 4 | 8 | 16, 0.55)]
+
+
+@pytest.mark.parametrize("flags,low_pass", FLAG_CASES)
+def test_forward_matches_dense(oracle_lib, flags, low_pass):
     sc = _tiny_scene()
     s = sc["settings"]
     s["bg"] = (0.1, 0.2, 0.3)
+    s["flags"], s["low_pass"] = flags, low_pass
     st = _settings(oracle_lib, s)
     fwd = oracle_lib.raster_forward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"])
     assert fwd.num_rendered > 0 and (fwd.radii > 0).sum() > 10
@@ -36,10 +43,14 @@ def test_forward_matches_dense(oracle_lib):
     assert err.max() < 2e-5, err.max()
 
 
-def test_backward_matches_autograd(oracle_lib):
+@pytest.mark.parametrize("flags,low_pass", FLAG_CASES)
+def test_backward_matches_autograd(oracle_lib, flags, low_pass):
     sc = _tiny_scene(P=30, seed=3)
+    if flags & 16:
+        sc["opacities"][::3] = 0.999          # centres above the 0.99 clamp: the switch must have something to switch
     s = sc["settings"]
     s["bg"] = (0.3, 0.1, 0.6)
+    s["flags"], s["low_pass"] = flags, low_pass
     st = _settings(oracle_lib, s)
     fwd = oracle_lib.raster_forward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"])
     rng = np.random.default_rng(5)
@@ -66,7 +77,7 @@ def test_backward_matches_autograd(oracle_lib):
     close(bwd.means3D, t["means3D"].grad, "means3D")
     close(bwd.scales, t["scales"].grad, "scales")
     close(bwd.rotations, t["rotations"].grad, "rotations")
-    g2 = delta.grad.numpy() * np.array([0.5 * s["W"], 0.5 * s["H"]])
+    g2 = delta.grad.numpy() * (np.array([1.0, 1.0]) if flags & 8 else np.array([0.5 * s["W"], 0.5 * s["H"]]))
     close(bwd.means2D[:, :2], g2, "means2D")
     assert np.all(bwd.means2D[:, 2] == 0)
     # no gradient along view z (orthographic: depth only orders)
@@ -128,3 +139,37 @@ def test_edge_cases(oracle_lib):
     for t0, t1 in f.tile_ranges:
         seg = list(f.point_list[t0:t1])
         assert seg == sorted(seg)
+
+
+def test_convention_switches_change_what_they_name(oracle_lib):
+    """Each switch moves the result in the direction its name says (the cross-checks above would also pass if a flag were
+    ignored by oracle and dense statement alike)."""
+    sc = _tiny_scene(P=60, seed=8)
+    s = sc["settings"]
+    args = (sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"])
+
+    def fwd(flags, low_pass=0.0):
+        s["flags"], s["low_pass"] = flags, low_pass
+        return oracle_lib.raster_forward(_settings(oracle_lib, s), *args)
+    base = fwd(0)
+    one = fwd(1)          # one-sided slab: only the Gaussians at or in front of the camera plane (z_view <= 0) survive
+    zv = sc["means3D"][:, 2] - s["z_cam"]
+    assert (one.radii > 0).sum() < (base.radii > 0).sum() and not np.any((one.radii > 0) & (zv > 0)) and np.all((one.radii > 0)[zv > 0] == 0)
+    assert np.array_equal((one.radii > 0)[zv <= 0], (base.radii > 0)[zv <= 0])
+    corner = fwd(2)       # without the half-pixel offset every centre sits half a pixel further right / down
+    vis = (base.radii > 0) & (corner.radii > 0)
+    assert np.allclose(corner.geom[vis, 0] - base.geom[vis, 0], 0.5, atol=1e-4) and np.allclose(corner.geom[vis, 1] - base.geom[vis, 1], 0.5, atol=1e-4)
+    desc = fwd(4)         # reversed depth order inside every tile (distinct depths in this scene)
+    assert desc.num_rendered == base.num_rendered
+    for (a0, a1), (b0, b1) in zip(base.tile_ranges, desc.tile_ranges):
+        assert list(base.point_list[a0:a1]) == list(desc.point_list[b0:b1][::-1])
+    nolp, lp = fwd(32), fwd(0, 1.5)     # the low-pass widens every footprint
+    assert np.all(nolp.radii[vis] <= base.radii[vis]) and np.all(lp.radii[vis] >= base.radii[vis]) and lp.num_rendered > nolp.num_rendered
+    # backward-only switches
+    dL = np.ones((3, s["H"], s["W"]), np.float32)
+    s["flags"], s["low_pass"] = 0, 0.0
+    b0 = oracle_lib.raster_backward(_settings(oracle_lib, s), *args, base, dL)
+    s["flags"] = 8
+    b8 = oracle_lib.raster_backward(_settings(oracle_lib, s), *args, base, dL)
+    assert np.allclose(b0.means2D[:, 0], b8.means2D[:, 0] * 0.5 * s["W"], rtol=1e-6) and np.allclose(b0.means2D[:, 1], b8.means2D[:, 1] * 0.5 * s["H"], rtol=1e-6)
+    assert np.array_equal(b0.means3D, b8.means3D)
