@@ -300,16 +300,23 @@ def run_train_step(args, rank, world, dev):
         tc0 = time.perf_counter()
         pack = conduct_stream_encoding(pc)
         torch.cuda.synchronize()
+        target = copy.deepcopy(pc)
+        _lib.profile_enable(True)
         tc1 = time.perf_counter()
-        dec = conduct_stream_decoding(copy.deepcopy(pc), pack)
+        dec = conduct_stream_decoding(target, pack)
         torch.cuda.synchronize()
         tc2 = time.perf_counter()
+        kprof = _lib.profile_collect()
+        _lib.profile_enable(False)
         n_dec = sum(1 for _ in render_frames(frames_e2e, dec, pipe, trainer.background))
         torch.cuda.synchronize()
         tc3 = time.perf_counter()
         bits = pack.bits()
         res["stream_codec"] = {"encode_ms": (tc1 - tc0) * 1e3, "decode_ms": (tc2 - tc1) * 1e3, "slabs": len(pack.slabs),
                                "anchors_coded": pack.n, "megabytes": {k[4:]: round(v / 8 / 2 ** 20, 4) for k, v in bits.items()},
+                               "ans_decode_kernel": {"launches": kprof.get("k_ans_decode", (0, 0.0))[0],
+                                                     "sum_ms": kprof.get("k_ans_decode", (0, 0.0))[1],
+                                                     "note": "sum of the launches' own durations; they run side by side on 8 streams"},
                                "stream_decode_fps": n_dec / (tc3 - tc1),
                                "note": f"entropy decode of the whole model + {n_dec} two-view frames rendered from it"}
         del dec, pack

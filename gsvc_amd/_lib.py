@@ -85,9 +85,11 @@ _SIGNATURES = {
     "gsvc_regs_backward": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_knn3_mean_dist2": (C.c_int, [_vp, _vp, C.POINTER(C.c_float), C.c_float, C.c_int32, C.c_int32, C.c_int32, _i64, _vp, _vp]),
     "gsvc_ans_segments": (_i64, [_i64, C.c_int32]),
+    "gsvc_ans_table_checksum": (C.c_uint32, []),
     "gsvc_ans_scratch_bytes": (_i64, [_i64, C.c_int32]),
     "gsvc_ans_encode": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "gsvc_ans_decode": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "gsvc_ans_decode_scratch_bytes": (_i64, [_i64, C.c_int32]),
+    "gsvc_ans_decode": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "gsvc_linear_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "gsvc_linear_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, _vp, _i64, _vp]),
     "gsvc_linear_wgrad_workspace": (_i64, [C.c_int32, C.c_int32]),

@@ -9,12 +9,14 @@
 // Coder: range-ANS, 32-bit state in [2^23, 2^31), byte renormalisation, 20-bit probabilities.  The cumulative
 // frequency of symbol s is  C(s) = floor(Phi((s - 1/2 - mu) / sigma) * (2^20 - R)) + (s - min),  R = max - min + 1, C(min) = 0,
 // C(max + 1) = 2^20: every symbol keeps a frequency >= 1 whatever the model says, and encoder and decoder evaluate the
-// same double-precision expression (no table of R entries per symbol).  The symbols are cut into segments of `seg_len`;
+// same exactly specified expression (Phi from a fixed-point table, see ans_cdf; no table of R entries per symbol).  The symbols are cut into segments of `seg_len`;
 // one lane codes one segment sequentially (rANS is serial), segments are independent streams: [4-byte final state]
 // [renormalisation bytes in the order the decoder reads them].  K1 codes into a fixed-stride scratch (from the end of
-// each slot backwards), K2 packs the segments back to back.  The decoder finds s by bisection on C.
-// This is an offline path (the reference runs it on the CPU): sized for correctness and a bounded run time, not tuned.
+// each slot backwards), K2 packs the segments back to back.  The decoder finds s from a float inverse of the model as a
+// first guess, then an exact bracket + bisection on C (ans_decode_symbol).
 #include "common.h"
+
+#include <cstdlib>
 
 namespace gsvc {
 
@@ -25,19 +27,41 @@ constexpr int ANS_SLOT_BYTES_PER_SYMBOL = 3;     // 20 bits per symbol at most, 
 
 __host__ __device__ inline int64_t ans_slot_bytes(int32_t seg_len) { return (int64_t)seg_len * ANS_SLOT_BYTES_PER_SYMBOL + 8; }
 
-// C(s) for s in [min, max + 1]
-__device__ __forceinline__ uint32_t ans_cdf(int s, double mu, double sigma, int smin, int smax)
+// Phi(z) as a 32-bit fixed-point number from a table of 4097 samples over z in [-8, 8] (step 1/256) and linear
+// interpolation in integer arithmetic: every operation between the model's floats and the frequency is an exactly specified
+// one (IEEE +, -, *, /, float -> integer conversion, integer multiply / shift), so encoder and decoder agree bit for bit on any
+// hardware and any math-library version — a stream no longer depends on how a particular erfc() rounds — and an evaluation
+// costs ~20 instructions instead of a double-precision erfc (~600 cycles; the decoder needs 2-4 of them per symbol).  The
+// interpolation error (< 5e-7) is below the 2^-20 frequency resolution.  The table sits in LDS (16 KiB per workgroup).
+constexpr int PHI_STEPS = 4096;
+constexpr double PHI_ZMAX = 8.0;
+__device__ uint32_t g_phi_table[PHI_STEPS + 1];
+
+__device__ __forceinline__ void load_phi_table(uint32_t *lds, int tid, int nthreads)
+{
+    for (int i = tid; i <= PHI_STEPS; i += nthreads) lds[i] = g_phi_table[i];
+    __syncthreads();
+}
+
+// C(s) for s in [min, max + 1]; inv_sigma = 1.0 / sigma, computed once per symbol by encoder and decoder alike
+__device__ __forceinline__ uint32_t ans_cdf(const uint32_t *__restrict__ phi, int s, double mu, double inv_sigma, int smin, int smax)
 {
 #pragma clang fp contract(off)
     if (s <= smin) return 0u;
     if (s > smax) return ANS_M;
     const uint32_t R = (uint32_t)(smax - smin + 1);
-    const double z = ((double)s - 0.5 - mu) / sigma;
-    double p = 0.5 * erfc(-z * 0.70710678118654752440);
-    p = p < 0.0 ? 0.0 : (p > 1.0 ? 1.0 : p);
-    if (!(p == p)) p = 0.5;                        // NaN model (sigma = 0 with s - 1/2 == mu): any fixed value works
-    uint32_t c = (uint32_t)(p * (double)(ANS_M - R));
-    if (c > ANS_M - R) c = ANS_M - R;
+    const double z = ((double)s - 0.5 - mu) * inv_sigma;
+    const double t = (z + PHI_ZMAX) * ((double)PHI_STEPS / (2.0 * PHI_ZMAX));
+    uint32_t p32;
+    if (!(t > 0.0)) p32 = (z != z) ? 0x80000000u : 0u;            // NaN model (sigma = 0 with s - 1/2 == mu): any fixed value
+    else if (t >= (double)PHI_STEPS) p32 = 0xffffffffu;
+    else {
+        const int i = (int)t;
+        const uint32_t f = (uint32_t)((t - (double)i) * 65536.0);  // 16-bit fraction
+        const uint32_t a = phi[i], b = phi[i + 1];
+        p32 = a + (uint32_t)(((uint64_t)(b - a) * f) >> 16);
+    }
+    const uint32_t c = (uint32_t)(((uint64_t)p32 * (uint64_t)(ANS_M - R)) >> 32);
     return c + (uint32_t)(s - smin);
 }
 
@@ -46,6 +70,8 @@ __global__ void __launch_bounds__(64) k_ans_encode(const int32_t *__restrict__ s
                                                    int64_t n_seg, uint8_t *__restrict__ scratch, uint32_t *__restrict__ seg_bytes,
                                                    int32_t *__restrict__ error_flag)
 {
+    __shared__ uint32_t phi[PHI_STEPS + 1];
+    load_phi_table(phi, threadIdx.x, 64);
     const int64_t seg = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (seg >= n_seg) return;
     const int64_t i0 = seg * seg_len;
@@ -57,8 +83,8 @@ __global__ void __launch_bounds__(64) k_ans_encode(const int32_t *__restrict__ s
     for (int64_t i = i1 - 1; i >= i0; i--) {
         const int s = sym[i];
         if (s < smin || s > smax) { atomicExch(error_flag, 1); continue; }
-        const double m = (double)mu[i], sg = (double)sigma[i];
-        const uint32_t start = ans_cdf(s, m, sg, smin, smax), freq = ans_cdf(s + 1, m, sg, smin, smax) - start;
+        const double m = (double)mu[i], sg = 1.0 / (double)sigma[i];
+        const uint32_t start = ans_cdf(phi, s, m, sg, smin, smax), freq = ans_cdf(phi, s + 1, m, sg, smin, smax) - start;
         if (freq == 0u || freq > ANS_M) { atomicExch(error_flag, 2); continue; }
         const uint64_t x_max = ((uint64_t)(ANS_L >> ANS_SCALE_BITS) << 8) * freq;
         for (int r = 0; r < 4 && (uint64_t)x >= x_max; r++) {     // at most 3 bytes leave per symbol
@@ -105,42 +131,229 @@ __global__ void __launch_bounds__(256) k_ans_pack(const uint8_t *__restrict__ sc
     for (uint32_t i = threadIdx.x; i < nb; i += 256) dst[i] = src[i];
 }
 
-__global__ void __launch_bounds__(64) k_ans_decode(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ seg_offsets,
-                                                   const float *__restrict__ mu, const float *__restrict__ sigma, int64_t n,
-                                                   int smin, int smax, int seg_len, int64_t n_seg, int32_t *__restrict__ sym,
-                                                   int32_t *__restrict__ error_flag)
+struct ByteReader {
+    const uint4 *chunk;       // next aligned 16-byte chunk
+    uint4 buf;
+    int pos;                  // next unread byte of buf
+    __device__ __forceinline__ void open(const uint8_t *p)
+    {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        chunk = reinterpret_cast<const uint4 *>(a & ~(uintptr_t)15);
+        pos = (int)(a & 15);
+        buf = *chunk++;
+    }
+    __device__ __forceinline__ uint32_t next()
+    {
+        if (pos == 16) { buf = *chunk++; pos = 0; }
+        const uint32_t w = pos < 8 ? (pos < 4 ? buf.x : buf.y) : (pos < 12 ? buf.z : buf.w);
+        const uint32_t b = (w >> (8 * (pos & 3))) & 0xffu;
+        pos++;
+        return b;
+    }
+};
+
+// Slow path of the decoder: the symbol is further than one step from the model's mode s0.  Known on entry: either
+// slot >= C(s0 + 2) (`above`, c_edge = C(s0 + 2)) or slot < C(s0 - 1) (c_edge = C(s0 - 1)).  Finds the largest s with
+// C(s) <= slot by doubling steps away from that edge, then bisection; for a broad model (sigma > 4 symbols) the first probe is a
+// float inverse of the model, s ~ mu + 1/2 + sigma * Phi^-1(slot / 2^20), which usually lands within a few symbols.  The guess
+// only orders the search: the result is exact.
+__device__ __forceinline__ int ans_decode_symbol(const uint32_t *__restrict__ phi, uint32_t slot, double m, double inv_sg, float sgf,
+                                                 int smin, int smax, int s0, bool above, uint32_t c_edge, uint32_t &start,
+                                                 uint32_t &freq)
 {
+    int lo, hi;
+    uint32_t c_lo, c_hi1;      // C(lo), C(hi + 1) of the current bracket: C(lo) <= slot < C(hi + 1)
+    int guess = 0;
+    const bool use_guess = sgf > 4.0f;
+    if (use_guess) {
+        const float qf = ((float)slot + 0.5f) * (1.0f / (float)ANS_M);
+        float g = (float)m + 0.5f + sgf * normcdfinvf(qf);
+        g = g == g ? fminf(fmaxf(g, (float)smin), (float)smax) : (float)smin;
+        guess = (int)floorf(g);
+    }
+    if (above) {                           // answer >= s0 + 2: gallop upwards
+        lo = s0 + 2; c_lo = c_edge;
+        if (use_guess && guess > lo) {
+            const uint32_t c = ans_cdf(phi, guess, m, inv_sg, smin, smax);
+            if (c <= slot) { lo = guess; c_lo = c; }
+        }
+        int64_t step = 1;
+        for (;;) {
+            const int64_t t = (int64_t)lo + step;
+            const int probe = t > (int64_t)smax + 1 ? smax + 1 : (int)t;
+            const uint32_t c = ans_cdf(phi, probe, m, inv_sg, smin, smax);       // C(max + 1) = 2^20 > slot ends the loop
+            if (c > slot) { hi = probe - 1; c_hi1 = c; break; }
+            lo = probe; c_lo = c; step <<= 1;
+        }
+    } else {                               // answer <= s0 - 2: gallop downwards (C(min) = 0 <= slot ends the loop)
+        hi = s0 - 2; c_hi1 = c_edge;
+        if (use_guess && guess < hi) {
+            const uint32_t c = ans_cdf(phi, guess + 1, m, inv_sg, smin, smax);
+            if (c > slot) { hi = guess; c_hi1 = c; }
+        }
+        int64_t step = 1;
+        for (;;) {
+            const int64_t t = (int64_t)hi + 1 - step;
+            const int probe = t < (int64_t)smin ? smin : (int)t;
+            const uint32_t c = ans_cdf(phi, probe, m, inv_sg, smin, smax);
+            if (c <= slot) { lo = probe; c_lo = c; break; }
+            hi = probe - 1; c_hi1 = c; step <<= 1;
+        }
+    }
+    for (int it = 0; it < 32 && lo < hi; it++) {
+        const int mid = lo + (int)(((int64_t)hi - lo + 1) >> 1);
+        const uint32_t c = ans_cdf(phi, mid, m, inv_sg, smin, smax);
+        if (c <= slot) { lo = mid; c_lo = c; } else { hi = mid - 1; c_hi1 = c; }
+    }
+    start = c_lo;
+    freq = c_hi1 - c_lo;
+    return lo;
+}
+
+__device__ __forceinline__ int ans_mode(float m, int smin, int smax)
+{
+    float g = floorf(m + 0.5f);
+    g = g == g ? fminf(fmaxf(g, (float)smin), (float)smax) : (float)smin;
+    return (int)g;
+}
+
+// Per symbol, from the model alone (no coder state): the cumulative frequencies around the model's mode s0 = round(mu),
+// (C(s0 - 1), C(s0), C(s0 + 1), C(s0 + 2)), written together with (mu, sigma) as one 32-byte record in the order the decode
+// kernel's lanes walk: record of symbol t of segment g at [(g / 64) * seg_len + t] * 64 + g % 64, so that the 64 lanes of a
+// decode wave — one segment each, 16 KB apart in the model arrays — read ONE contiguous 2-KB piece per step.  Embarrassingly
+// parallel (one lane per symbol over the whole chip) while the decode kernel has one lane per SEGMENT, and a wave of it pays for
+// its slowest lane at every step: with the three symbols around the mode decided by compares, the search (hundreds of cycles)
+// runs only for symbols further out — rare in a fitted model, where a wave would otherwise hit it at most steps through one lane
+// or another.
+__global__ void __launch_bounds__(256) k_ans_model(const float *__restrict__ mu, const float *__restrict__ sigma, int64_t n, int smin,
+                                                   int smax, int seg_len, uint4 *__restrict__ records)
+{
+    __shared__ uint32_t phi[PHI_STEPS + 1];
+    load_phi_table(phi, threadIdx.x, 256);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float m = mu[i], sg = sigma[i];
+    const double inv = 1.0 / (double)sg, md = (double)m;
+    const int s0 = ans_mode(m, smin, smax);
+    const int64_t g = i / seg_len, t = i - g * seg_len;
+    uint4 *dst = records + (((g >> 6) * seg_len + t) * 64 + (g & 63)) * 2;
+    dst[0] = make_uint4(ans_cdf(phi, s0 - 1, md, inv, smin, smax), ans_cdf(phi, s0, md, inv, smin, smax),
+                        ans_cdf(phi, s0 + 1, md, inv, smin, smax), ans_cdf(phi, s0 + 2, md, inv, smin, smax));
+    dst[1] = make_uint4(__float_as_uint(m), __float_as_uint(sg), 0u, 0u);
+}
+
+constexpr int ANS_AHEAD = 16;     // records a decode lane keeps in flight (the stream is coalesced, its latency is not short)
+
+// One lane decodes one segment.  Everything a lane reads from memory is fetched ahead of its use: the byte stream through a
+// 16-byte register buffer (a renormalisation byte used to be a dependent global load of ~1 us each with the few waves a
+// decode launch has), the model records ANS_AHEAD symbols ahead (each record register is reloaded as soon as it is consumed).
+__global__ void __launch_bounds__(64) k_ans_decode(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ seg_offsets,
+                                                   int64_t n, int smin, int smax, int seg_len, int64_t n_seg,
+                                                   int32_t *__restrict__ sym, int32_t *__restrict__ error_flag,
+                                                   const uint4 *__restrict__ records)
+{
+    __shared__ uint32_t phi[PHI_STEPS + 1];
+    load_phi_table(phi, threadIdx.x, 64);
     const int64_t seg = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (seg >= n_seg) return;
     const int64_t i0 = seg * seg_len;
-    const int64_t i1 = i0 + seg_len < n ? i0 + seg_len : n;
-    const uint8_t *p = bytes + seg_offsets[seg], *pend = bytes + seg_offsets[seg + 1];
-    if (pend - p < 4) { atomicExch(error_flag, 3); return; }
-    uint32_t x = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
-    p += 4;
-    for (int64_t i = i0; i < i1; i++) {
-        const double m = (double)mu[i], sg = (double)sigma[i];
-        const uint32_t slot = x & (ANS_M - 1u);
-        // largest s in [min, max] with C(s) <= slot: bisection, at most 32 steps
-        int lo = smin, hi = smax;
-        for (int it = 0; it < 32 && lo < hi; it++) {
-            const int mid = lo + (int)(((int64_t)hi - lo + 1) >> 1);
-            if (ans_cdf(mid, m, sg, smin, smax) <= slot) lo = mid; else hi = mid - 1;
+    const int len = (int)((i0 + seg_len < n ? i0 + seg_len : n) - i0);
+    const uint64_t b0 = seg_offsets[seg], b1 = seg_offsets[seg + 1];
+    if (b1 < b0 + 4) { atomicExch(error_flag, 3); return; }
+    int64_t left = (int64_t)(b1 - b0) - 4;          // renormalisation bytes this segment still holds
+    ByteReader rd;
+    rd.open(bytes + b0);
+    uint32_t x = rd.next() << 24;
+    x |= rd.next() << 16;
+    x |= rd.next() << 8;
+    x |= rd.next();
+    const uint4 *rec = records + ((int64_t)blockIdx.x * seg_len * 64 + threadIdx.x) * 2;      // + 128 per symbol
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    uint4 ra[ANS_AHEAD], rb[ANS_AHEAD];
+#pragma unroll
+    for (int k = 0; k < ANS_AHEAD; k++) {
+        ra[k] = k < len ? rec[(int64_t)k * 128] : zero;
+        rb[k] = k < len ? rec[(int64_t)k * 128 + 1] : zero;
+    }
+    for (int t0 = 0; t0 < len; t0 += ANS_AHEAD) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < ANS_AHEAD; k++) {
+            if (ok && t0 + k < len) {
+                const uint4 c = ra[k];
+                const float m = __uint_as_float(rb[k].x), sg = __uint_as_float(rb[k].y);
+                if (t0 + ANS_AHEAD + k < len) {          // this register pair is free again: the record ANS_AHEAD steps ahead
+                    ra[k] = rec[(int64_t)(t0 + ANS_AHEAD + k) * 128];
+                    rb[k] = rec[(int64_t)(t0 + ANS_AHEAD + k) * 128 + 1];
+                }
+                const int s0 = ans_mode(m, smin, smax);
+                const uint32_t slot = x & (ANS_M - 1u);
+                uint32_t start, freq;
+                int out;
+                if (slot >= c.y && slot < c.z) { out = s0; start = c.y; freq = c.z - c.y; }
+                else if (slot >= c.z && slot < c.w) { out = s0 + 1; start = c.z; freq = c.w - c.z; }
+                else if (slot >= c.x && slot < c.y) { out = s0 - 1; start = c.x; freq = c.y - c.x; }
+                else {
+                    const bool above = slot >= c.w;
+                    out = ans_decode_symbol(phi, slot, (double)m, 1.0 / (double)sg, sg, smin, smax, s0, above, above ? c.w : c.x, start, freq);
+                }
+                sym[i0 + t0 + k] = out;
+                if (freq == 0u || slot < start || slot - start >= freq) {
+                    atomicExch(error_flag, 4);
+                    ok = false;
+                } else {
+                    x = freq * (x >> ANS_SCALE_BITS) + slot - start;
+                    for (int r = 0; r < 4 && x < ANS_L; r++) {
+                        if (--left < 0) { atomicExch(error_flag, 5); ok = false; break; }
+                        x = (x << 8) | rd.next();
+                    }
+                }
+            }
         }
-        const uint32_t start = ans_cdf(lo, m, sg, smin, smax), freq = ans_cdf(lo + 1, m, sg, smin, smax) - start;
-        sym[i] = lo;
-        if (freq == 0u || slot < start || slot - start >= freq) { atomicExch(error_flag, 4); return; }
-        x = freq * (x >> ANS_SCALE_BITS) + slot - start;
-        for (int r = 0; r < 4 && x < ANS_L; r++) {
-            if (p >= pend) { atomicExch(error_flag, 5); return; }
-            x = (x << 8) | (uint32_t)(*p++);
-        }
+        if (!ok) return;
     }
 }
 
 }  // namespace gsvc
 
 using namespace gsvc;
+
+#include <cmath>
+#include <mutex>
+
+// The table is filled once per process from the host's double-precision erfc, rounded to 32-bit fixed point.  Two platforms
+// whose erfc differ in the last place could round one of the 4097 entries differently, so a stream carries the table's
+// checksum (gsvc_ans_table_checksum) and the decoder compares it with its own before decoding.
+static uint32_t g_phi_host[PHI_STEPS + 1];
+static uint32_t g_phi_crc = 0;
+static int ensure_phi_table()
+{
+    static std::once_flag once;
+    static int rc = GSVC_OK;
+    std::call_once(once, [] {
+        uint32_t h = 2166136261u;
+        for (int i = 0; i <= PHI_STEPS; i++) {
+            const double z = -PHI_ZMAX + (double)i * (2.0 * PHI_ZMAX / (double)PHI_STEPS);
+            double p = 0.5 * std::erfc(-z * 0.70710678118654752440) * 4294967296.0;
+            p = std::floor(p + 0.5);
+            g_phi_host[i] = p >= 4294967295.0 ? 0xffffffffu : (p <= 0.0 ? 0u : (uint32_t)p);
+            if (i > 0 && g_phi_host[i] < g_phi_host[i - 1]) g_phi_host[i] = g_phi_host[i - 1];     // monotone by construction
+            for (int b = 0; b < 4; b++) h = (h ^ ((g_phi_host[i] >> (8 * b)) & 0xffu)) * 16777619u;   // FNV-1a
+        }
+        g_phi_crc = h;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phi_table), g_phi_host, sizeof(g_phi_host)) != hipSuccess) {
+            set_error("ans: uploading the Phi table failed");
+            rc = GSVC_E_LAUNCH;
+        }
+    });
+    return rc;
+}
+
+extern "C" uint32_t gsvc_ans_table_checksum(void)
+{
+    ensure_phi_table();
+    return g_phi_crc;
+}
 
 extern "C" int64_t gsvc_ans_segments(int64_t n, int32_t seg_len) { return seg_len > 0 && n > 0 ? (n + seg_len - 1) / seg_len : 0; }
 
@@ -158,6 +371,7 @@ extern "C" int gsvc_ans_encode(const int32_t *symbols, const float *mu, const fl
                  "ans_encode: symbol range [%d, %d] does not fit 20-bit frequencies", min_symbol, max_symbol);
     if (n == 0) return GSVC_OK;
     GSVC_REQUIRE(symbols && mu && sigma && scratch && seg_bytes && seg_offsets && out && error_flag, "ans_encode: NULL pointer");
+    if (int rc = ensure_phi_table()) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int64_t n_seg = gsvc_ans_segments(n, seg_len);
     {
@@ -171,19 +385,33 @@ extern "C" int gsvc_ans_encode(const int32_t *symbols, const float *mu, const fl
     return check_launch("ans_encode");
 }
 
+extern "C" int64_t gsvc_ans_decode_scratch_bytes(int64_t n, int32_t seg_len)
+{
+    // one 32-byte record per symbol, laid out per group of 64 segments (the last group is padded to 64 segments)
+    const int64_t n_seg = gsvc_ans_segments(n, seg_len);
+    return ((n_seg + 63) / 64) * 64 * (int64_t)(seg_len > 0 ? seg_len : 1) * 2 * (int64_t)sizeof(uint4) + 16;
+}
+
 extern "C" int gsvc_ans_decode(const uint8_t *bytes, const uint64_t *seg_offsets, const float *mu, const float *sigma, int64_t n,
                                int32_t min_symbol, int32_t max_symbol, int32_t seg_len, int32_t *symbols, int32_t *error_flag,
-                               void *stream)
+                               void *scratch, void *stream)
 {
     GSVC_REQUIRE(n >= 0 && seg_len > 0 && seg_len <= (1 << 20), "ans_decode: bad sizes");
     GSVC_REQUIRE(max_symbol >= min_symbol && (int64_t)max_symbol - min_symbol + 1 < (int64_t)(ANS_M / 2),
                  "ans_decode: symbol range [%d, %d] does not fit 20-bit frequencies", min_symbol, max_symbol);
     if (n == 0) return GSVC_OK;
-    GSVC_REQUIRE(bytes && seg_offsets && mu && sigma && symbols && error_flag, "ans_decode: NULL pointer");
+    GSVC_REQUIRE(bytes && seg_offsets && mu && sigma && symbols && error_flag && scratch, "ans_decode: NULL pointer");
+    GSVC_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 15) == 0, "ans_decode: scratch must be 16-byte aligned");
+    if (int rc = ensure_phi_table()) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int64_t n_seg = gsvc_ans_segments(n, seg_len);
+    {
+        ProfScope _p("k_ans_model", s);
+        hipLaunchKernelGGL(k_ans_model, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mu, sigma, n, min_symbol, max_symbol, seg_len,
+                           (uint4 *)scratch);
+    }
     ProfScope _p("k_ans_decode", s);
-    hipLaunchKernelGGL(k_ans_decode, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, s, bytes, seg_offsets, mu, sigma, n, min_symbol,
-                       max_symbol, seg_len, n_seg, symbols, error_flag);
+    hipLaunchKernelGGL(k_ans_decode, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, s, bytes, seg_offsets, n, min_symbol, max_symbol,
+                       seg_len, n_seg, symbols, error_flag, (const uint4 *)scratch);
     return check_launch("ans_decode");
 }

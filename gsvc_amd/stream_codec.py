@@ -26,7 +26,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .codec import ans_decode, ans_encode, decoder_gaussian, encoder_gaussian
+from .codec import DeferredChecks, ans_decode, ans_encode, decoder_gaussian, encoder_gaussian, prepare_streams
 from .encodings import ANCHOR_ROUND_DIGITS, Quantize_anchor, STE_multistep
 from .model import calc_symbol_min_max
 
@@ -140,6 +140,9 @@ class StreamPack:
         return pack
 
 
+DECODE_STREAMS = 8
+
+
 def _slab_model(pc, anchor):
     """Context of one slab: per-element mean / scale / step of the three attribute groups."""
     ec = pc.calc_entropy_context(anchor)
@@ -205,15 +208,42 @@ def conduct_stream_decoding(pc, pack: StreamPack):
     hash_pm = (hash01 * 2 - 1).view(-1, tables.shape[1])
     _install_tables(pc, hash_pm)                                  # the context model reads the decoded tables
     feats, scalings, offsets = [], [], []
+    # The slabs' streams are independent and one decode launch is a few waves (one lane per 4 096-symbol segment), so the
+    # launches are spread over a few HIP streams and run side by side.  Nothing inside the loop may synchronise (the host
+    # would wait for one slab's kernels before it can queue the next): every payload is uploaded before the loop with one
+    # copy, the masked offsets are addressed through index lists computed up front (boolean-mask indexing reads a count back),
+    # and the decode kernels' error words are read once at the end.
+    n_slab = len(slabs)
+    prepared = prepare_streams(list(pack.feat) + list(pack.scaling) + list(pack.offsets), dev)
+    m3_all = mask.repeat(1, 1, 3).view(N, 3 * K) > 0
+    nz = m3_all.view(-1).nonzero(as_tuple=False).squeeze(1)                      # flat positions of the coded offsets
+    edges = torch.tensor([a * 3 * K for a, _ in slabs] + [N * 3 * K], device=dev)
+    cuts = torch.searchsorted(nz, edges).tolist()                                # the one read-back before the loop
+    checks = DeferredChecks()
+    main = torch.cuda.current_stream(dev)
+    pool = [torch.cuda.Stream(device=dev) for _ in range(min(DECODE_STREAMS, max(n_slab, 1)))]
     for s, (a, b) in enumerate(slabs):
         (mf, sf, qf), (ms, ss, qs), (mo, so, qo) = _slab_model(pc, anchor[a:b])
-        feats.append(decoder_gaussian(mf, sf, qf, stream=pack.feat[s]))
-        scalings.append(decoder_gaussian(ms, ss, qs, stream=pack.scaling[s]))
-        m3 = mask[a:b].repeat(1, 1, 3).view(-1, 3 * K).to(torch.bool)
-        off = torch.zeros_like(mo)
-        if bool(m3.any()):
-            off[m3] = decoder_gaussian(mo[m3], so[m3], qo[m3], stream=pack.offsets[s])
-        offsets.append(off.view(-1, K, 3))
+        sel = nz[cuts[s]:cuts[s + 1]] - a * 3 * K                                # positions inside this slab's [rows, 3K] block
+        side = pool[s % len(pool)]
+        side.wait_stream(main)                                    # the context (means, scales, steps) is computed on `main`
+        with torch.cuda.stream(side):
+            feats.append(decoder_gaussian(mf, sf, qf, stream=prepared[s], defer=checks))
+            scalings.append(decoder_gaussian(ms, ss, qs, stream=prepared[n_slab + s], defer=checks))
+            off = torch.zeros_like(mo)
+            if prepared[2 * n_slab + s] is not None:
+                vals = decoder_gaussian(mo.view(-1)[sel], so.view(-1)[sel], qo.view(-1)[sel], stream=prepared[2 * n_slab + s],
+                                        defer=checks)
+                off.view(-1)[sel] = vals
+            elif cuts[s + 1] != cuts[s]:
+                raise RuntimeError("stream decoding: a slab has coded offsets but an empty offsets stream")
+            offsets.append(off.view(-1, K, 3))
+        for t in (mf, sf, qf, ms, ss, qs, mo, so, qo, sel, feats[-1], scalings[-1], offsets[-1]):
+            t.record_stream(side)
+            t.record_stream(main)
+    for side in pool:
+        main.wait_stream(side)
+    checks.check()
     Nf = pack.n_full
 
     def full(rows, *shape):

@@ -301,6 +301,9 @@ int gsvc_knn3_mean_dist2(const float *points_by_cell, const int32_t *cell_start,
 
 /* number of segments / bytes of encode scratch for n symbols */
 int64_t gsvc_ans_segments(int64_t n, int32_t seg_len);
+/* checksum of the fixed-point Phi table encoder and decoder build their frequencies from: a stream records it, a decoder
+ * whose own table differs (another platform's erfc rounded an entry the other way) must refuse the stream */
+uint32_t gsvc_ans_table_checksum(void);
 int64_t gsvc_ans_scratch_bytes(int64_t n, int32_t seg_len);
 
 /* symbols[n] (device, int32) -> out (device; capacity gsvc_ans_scratch_bytes is always enough), seg_bytes[segments]
@@ -310,9 +313,15 @@ int gsvc_ans_encode(const int32_t *symbols, const float *mu, const float *sigma,
                     int32_t max_symbol, int32_t seg_len, void *scratch, uint32_t *seg_bytes, uint64_t *seg_offsets, uint8_t *out,
                     int32_t *error_flag, void *stream);
 
-/* inverse: bytes + seg_offsets[segments + 1] + the same mu, sigma -> symbols[n].  error_flag non-zero: corrupt stream. */
+/* inverse: bytes + seg_offsets[segments + 1] + the same mu, sigma -> symbols[n].  error_flag non-zero: corrupt stream.
+ * `bytes` must be readable up to 16 bytes past seg_offsets[segments] (the kernel reads the stream in aligned 16-byte pieces).
+ * `scratch`: gsvc_ans_decode_scratch_bytes(n, seg_len) bytes, 16-byte aligned: the part of the model that does not depend on
+ * the coder state (the cumulative frequencies of every symbol's mode) is computed by a chip-wide parallel kernel first and laid
+ * out so that the serial per-segment lanes of the decode kernel read it as one coalesced stream. */
+int64_t gsvc_ans_decode_scratch_bytes(int64_t n, int32_t seg_len);
 int gsvc_ans_decode(const uint8_t *bytes, const uint64_t *seg_offsets, const float *mu, const float *sigma, int64_t n,
-                    int32_t min_symbol, int32_t max_symbol, int32_t seg_len, int32_t *symbols, int32_t *error_flag, void *stream);
+                    int32_t min_symbol, int32_t max_symbol, int32_t seg_len, int32_t *symbols, int32_t *error_flag, void *scratch,
+                    void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Linear layers of the generator / deformation / entropy-parameter MLPs (reference scene/gaussian_model.py:

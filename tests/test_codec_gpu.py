@@ -41,9 +41,12 @@ def test_round_trip_and_size(n, spread):
     back = ans_decode(stream, mu, sigma)
     assert torch.equal(back, sym)
     ideal = _ideal_bits(sym, mu, sigma, smin, smax)
-    from gsvc_amd.codec import SEG_LEN
-    n_seg = (n + SEG_LEN - 1) // SEG_LEN
-    overhead = 8 * (32 + 4 * n_seg + 5 * n_seg)         # header, size table, final state + flush per segment
+    from gsvc_amd import codec
+    seg_len = codec._HEADER.unpack_from(stream, 0)[3]   # chosen by the encoder from the stream's bits per symbol
+    assert seg_len in (512, 1024, 2048, 4096)
+    n_seg = (n + seg_len - 1) // seg_len
+    overhead = 8 * (36 + 4 * n_seg + 5 * n_seg)         # header, size table, final state + flush per segment
+    assert 8 * 9 * n_seg <= 0.03 * ideal + 8 * 9 * ((n + 4095) // 4096) + 64      # short segments only where they cost <= 3 %
     assert 8 * len(stream) <= ideal * 1.002 + overhead + 64, (8 * len(stream), ideal)
     assert 8 * len(stream) >= ideal * 0.999
 
