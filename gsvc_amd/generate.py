@@ -113,6 +113,65 @@ def _as_index(mask_or_index):
     return mask_or_index
 
 
+class StepPlan:
+    """Every data-dependent index list of one batched generation pass, computed WITHOUT a host synchronisation and read back
+    with one copy: the visible anchors of each of the R views, the distinct anchors of their union (entropy context) and the
+    5 % rate sample.  ``torch.nonzero`` / boolean-mask indexing read a count back per call — six device round trips at the
+    start of a fitting step during which the GPU has nothing queued; a plan is built at the TAIL of the previous step (the
+    kernels queue behind the optimizer, the nine counts travel to pinned host memory behind them), so the next step starts
+    with one wait for that copy instead.  Index lists come from ``torch.nonzero_static`` (capacity = all anchors) and are
+    cut to their true length once the counts are on the host (``resolve``)."""
+
+    def __init__(self, frames, pc, visible_masks, geometry, sample: bool):
+        dev = visible_masks[0].device
+        A = visible_masks[0].shape[0]
+        self.frames, self.visible_masks, self.geometry, self.R = frames, visible_masks, geometry, len(visible_masks)
+        self.key = (A, id(pc._anchor), pc._anchor._version, pc._scaling._version, pc._mask._version)
+        self._idx = [torch.nonzero_static(m, size=A).squeeze(1) for m in visible_masks]
+        counts = [m.sum() for m in visible_masks]
+        present = visible_masks[0]
+        for m in visible_masks[1:]:
+            present = present | m
+        self._distinct = torch.nonzero_static(present, size=A).squeeze(1)
+        self.pos = torch.cumsum(present, dim=0) - 1                      # anchor -> row of the distinct list
+        counts.append(present.sum())
+        self._sel = None
+        if sample:
+            # the rate sample in anchor space: a row is (render r, visible anchor a); its position in the concatenated rows is
+            # (visible anchors of the renders before r) + (rank of a among render r's visible anchors)
+            with torch.no_grad():
+                live = pc.get_mask.reshape(A, -1).sum(dim=1) > 0          # mask_anchor for every anchor
+            cnt_t = torch.stack(counts[:self.R])
+            starts = torch.cumsum(cnt_t, dim=0) - cnt_t
+            self._sel = []
+            for r, m in enumerate(visible_masks):
+                chosen = m & live & (torch.rand(A, device=dev) <= SAMPLE_RATE)
+                rank = torch.cumsum(m, dim=0) - 1
+                anchors_r = torch.nonzero_static(chosen, size=A).squeeze(1)
+                self._sel.append(starts[r] + rank.index_select(0, anchors_r.clamp_min(0)))
+                counts.append(chosen.sum())
+        self._host = torch.empty(len(counts), dtype=torch.int64, pin_memory=True)
+        self._host.copy_(torch.stack(counts), non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self.vis_list = self.distinct = self.sel = None
+
+    def matches(self, pc) -> bool:
+        return self.key == (self.visible_masks[0].shape[0], id(pc._anchor), pc._anchor._version, pc._scaling._version,
+                            pc._mask._version)
+
+    def resolve(self):
+        """The one wait: cut the padded lists to their lengths."""
+        if self.vis_list is None:
+            self._event.synchronize()
+            n = self._host.tolist()
+            self.vis_list = [ix[:c] for ix, c in zip(self._idx, n[:self.R])]
+            self.distinct = self._distinct[:n[self.R]]
+            if self._sel is not None:
+                self.sel = torch.cat([s[:c] for s, c in zip(self._sel, n[self.R + 1:])])
+        return self
+
+
 def region(name):
     """Named range for torch.profiler when GSVC_REGIONS=1 (diagnostics), otherwise a no-op context."""
     import contextlib
@@ -350,14 +409,16 @@ def _seg_ste(x, Q, seg, x_mean):
     return (x + (torch.round(x / Q) * Q - x).detach()).detach()
 
 
-def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row=None):
-    """``ec_row``: row -> row of ``ec`` when the entropy context was evaluated once per distinct anchor."""
+def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row=None, sel=None):
+    """``ec_row``: row -> row of ``ec`` when the entropy context was evaluated once per distinct anchor.  ``sel``: the rate
+    sample's rows when a StepPlan drew it ahead of the step (same rule: Bernoulli(SAMPLE_RATE) and mask_anchor)."""
     K = pc.n_offsets
     with torch.no_grad():
         mask_anchor = (torch.sum(offset_masks, dim=1)[:, 0]) > 0
         keep_rate = seg.mean(mask_anchor.float().unsqueeze(1)).view(-1)          # per row, constant per render
-        chosen = (torch.rand_like(feat[:, 0]) <= SAMPLE_RATE) & mask_anchor
-        sel = chosen.nonzero(as_tuple=False).squeeze(1)
+        if sel is None:
+            chosen = (torch.rand_like(feat[:, 0]) <= SAMPLE_RATE) & mask_anchor
+            sel = chosen.nonzero(as_tuple=False).squeeze(1)
         sel_seg = seg.seg_id.index_select(0, sel)
         n_sel = torch.zeros(seg.R, device=feat.device).index_add_(0, sel_seg, torch.ones_like(sel_seg, dtype=torch.float32))
     take = lambda t: t.index_select(0, sel)  # noqa: E731
@@ -389,7 +450,7 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
                      bit_per_scaling_param=(ss / ns * kr)[r], bit_per_offsets_param=(so / no * kr)[r]) for r in range(seg.R)]
 
 
-def _entropy_context_distinct(pc, anchor_all, vis):
+def _entropy_context_distinct(pc, anchor_all, vis, plan=None):
     """Entropy context of the batch's rows, evaluated once per DISTINCT anchor.
 
     The context (hash-grid lookup + the three EntropyParamsNets, reference scene/gaussian_model.py:1569-1597) is a
@@ -402,6 +463,10 @@ def _entropy_context_distinct(pc, anchor_all, vis):
     A = anchor_all.shape[0]
     if vis.numel() == 0:
         return pc.calc_entropy_context(anchor_all.index_select(0, vis)), None
+    if plan is not None:           # the distinct list and the anchor -> row map were computed with the visibility test
+        if plan.distinct.shape[0] == vis.shape[0]:
+            return pc.calc_entropy_context(anchor_all.index_select(0, vis)), None
+        return pc.calc_entropy_context(anchor_all.index_select(0, plan.distinct)), plan.pos.index_select(0, vis)
     present = torch.zeros(A, dtype=torch.bool, device=vis.device)
     present[vis] = True
     distinct = present.nonzero(as_tuple=False).squeeze(1)
@@ -420,7 +485,7 @@ def generator_trunks(pc):
 
 
 def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False,
-                                   anchors=None, trunks=None):
+                                   anchors=None, trunks=None, plan=None):
     """`generate_neural_gaussians` for R renders at once; returns a list of R GeneratedGaussians.
 
     ``dense=True`` skips the "opacity > 0" compaction: every visible anchor contributes all K Gaussians, ``mask``
@@ -432,7 +497,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     R = len(frames)
     K = pc.n_offsets
     with region('gen.visible_index'):
-        vis_list = [_as_index(m) for m in visible_masks]
+        vis_list = plan.resolve().vis_list if plan is not None else [_as_index(m) for m in visible_masks]
     dev = vis_list[0].device
     seg = _Segments([v.shape[0] for v in vis_list], dev)
     with region('gen.gather'):
@@ -455,7 +520,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets, seg)
     elif mode == GenerateMode.TRAINING_ENTROPY:
         with region('gen.entropy_context'):
-            ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis)
+            ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan)
         with region('gen.noise_quant'):
             rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
             Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj), Q_scaling * rows_of(ec.Q_scaling_adj),
@@ -464,9 +529,10 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
             grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
             grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets.unsqueeze(1), seg)
         with region('gen.rate'):
-            rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row)
+            rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row,
+                               sel=plan.sel if plan is not None else None)
     elif mode == GenerateMode.TRAININ_STE_ENTROPY:
-        ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis)
+        ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan)
         rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
         Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj).detach(), Q_scaling * rows_of(ec.Q_scaling_adj).detach(),
                                         Q_offsets * rows_of(ec.Q_offsets_adj).detach())

@@ -5,4 +5,4 @@
 from ..generate import (GenerateMode, GeneratedGaussians, RatePack, calc_sampled_rate,  # noqa: F401
                         generate_neural_gaussians)
 from .preprocess import prefilter_voxel  # noqa: F401
-from .renderer import render, render_frames, render_many, render_pair  # noqa: F401
+from .renderer import plan_views, render, render_frames, render_many, render_pair  # noqa: F401

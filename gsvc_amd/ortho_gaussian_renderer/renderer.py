@@ -36,8 +36,18 @@ def render(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain
         entropy_constrained=(gss.bit_per_param is not None), generated_gaussians=gss, time_sub=gss.time_sub)
 
 
+def plan_views(frames, pc, pipe, bg_color: torch.Tensor, mode=GenerateMode.TRAINING_FULL_PRECISION):
+    """Visibility test of ``frames`` + every data-dependent index list of their batched generation pass, queued without a host
+    synchronisation (gsvc_amd.generate.StepPlan); hand the result to ``render_many(plan=...)``.  Built at the tail of a
+    fitting step for the next one, it replaces the step's six count read-backs by one wait."""
+    from ..generate import StepPlan
+    geometry = prefilter_geometry(pc)
+    visible = [prefilter_voxel(f, pc, pipe, bg_color, geometry=geometry) for f in frames]
+    return StepPlan(frames, pc, visible, geometry, sample=(mode == GenerateMode.TRAINING_ENTROPY))
+
+
 def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain_grad=False,
-                mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False, anchor_grad=True):
+                mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False, anchor_grad=True, plan=None):
     """`render` for several frames/views of one step: the anchor -> Gaussian generation of all of them runs as
     one batch (gsvc_amd.generate.generate_neural_gaussians_many), then each view is rasterized.  Returns a list
     of RenderResults with the same fields `render` fills.
@@ -51,10 +61,13 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
     ``anchor_grad=False``: the anchor positions enter the generation pass detached (no gradient w.r.t. ``_anchor``:
     GSVC trains them with learning rate 0, `arguments/__init__.py` position_lr_*), which removes the backward
     through the positional embedding, the hash-grid input gradient and dy_dx."""
-    geometry = prefilter_geometry(pc)
-    visible = [prefilter_voxel(f, pc, pipe, bg_color, geometry=geometry) for f in frames]
+    if plan is not None:
+        geometry, visible = plan.geometry, plan.visible_masks
+    else:
+        geometry = prefilter_geometry(pc)
+        visible = [prefilter_voxel(f, pc, pipe, bg_color, geometry=geometry) for f in frames]
     gss_list = generate_neural_gaussians_many(frames, pc, visible, mode, dense=dense,
-                                              anchors=None if anchor_grad else geometry[0])
+                                              anchors=None if anchor_grad else geometry[0], plan=plan)
     results = []
     for frame, visible_mask, gss in zip(frames, visible, gss_list):
         screenspace_points = torch.zeros_like(gss.xyz, dtype=pc.get_anchor.dtype, requires_grad=True) + 0

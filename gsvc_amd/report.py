@@ -46,6 +46,19 @@ def evaluate(pc, dataset, pipe, bg_color, frame_ids=None, batch: int = 8) -> dic
             "msssim": sums["msssim"] / n_ms if n_ms else float("nan"), "fps": len(frames) / elapsed if elapsed > 0 else float("inf")}
 
 
+def _plain(obj):
+    """NumPy scalars -> Python numbers, recursively (the learning-rate schedule leaves np.float64 in the optimizer's groups;
+    a file holding them cannot be read back with ``weights_only=True``)."""
+    import numpy as np
+    if isinstance(obj, dict):
+        return {k: _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_plain(v) for v in obj)
+    if isinstance(obj, np.generic):
+        return obj.item()
+    return obj
+
+
 def save_checkpoint(pc, path, iteration: int = 0):
     """Model parameters (reference-compatible state_dict keys), the per-anchor tensors, the densification statistics and
     the optimizer state in one file."""
@@ -54,8 +67,8 @@ def save_checkpoint(pc, path, iteration: int = 0):
     torch.save({"iteration": int(iteration), "state_dict": pc.state_dict(), "per_anchor": per_anchor, "stats": stats,
                 "decoded_version": bool(pc.decoded_version), "voxel_size": float(pc.voxel_size),
                 "spatial_lr_scale": float(pc.spatial_lr_scale), "percent_dense": float(getattr(pc, "percent_dense", 0.0) or 0.0),
-                "bounds": (pc.bound_min_host, pc.bound_max_host),
-                "optimizer": pc.optimizer.state_dict() if pc.optimizer is not None else None}, path)
+                "bounds": (tuple(float(v) for v in pc.bound_min_host), tuple(float(v) for v in pc.bound_max_host)),
+                "optimizer": _plain(pc.optimizer.state_dict()) if pc.optimizer is not None else None}, path)
 
 
 def load_checkpoint(pc, path, training_args=None) -> int:

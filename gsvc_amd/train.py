@@ -17,7 +17,7 @@ import torch
 from . import dist as gdist
 from .generate import region
 from .loss_utils import calc_optical_loss, render_regs, ssim_l1
-from .ortho_gaussian_renderer import render, render_many
+from .ortho_gaussian_renderer import plan_views, render, render_many
 from .rasterizer import resolve_deferred
 from .train_util import TrainingController
 
@@ -54,8 +54,14 @@ def _mean_over_selected(values, r):
 
 
 class Trainer:
-    def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0, batched: bool = True):
+    def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0, batched: bool = True, prefetch: bool = True):
         self.batched = batched
+        # prefetch: the next step's frame pair is drawn, its visibility test run and every data-dependent index list of its
+        # generation pass queued at the END of a step (gsvc_amd.generate.StepPlan): the next step then starts with one wait
+        # for nine counts instead of six device round trips with an idle GPU
+        import os
+        self.prefetch = prefetch and batched and not os.environ.get("GSVC_NO_PREFETCH")      # env: A/B timing only
+        self._plan = self._plan_idx = self._plan_mode = None
         self.pc, self.dataset, self.opt, self.pipe, self.mp = gaussians, dataset, opt, pipe, model_params
         self.controller = TrainingController(opt)
         self.controller.step()  # iterations are 1-based
@@ -76,14 +82,32 @@ class Trainer:
         return f, b, image
 
     def step(self, iteration: int, frame_idx: int | None = None) -> StepOutput:
+        if frame_idx is None and self._plan_idx is not None:
+            frame_idx = self._plan_idx              # drawn (from the same generator, in the same order) at the end of the last step
         out = self._step(iteration, frame_idx)
         if out is None:      # a rasterizer instance buffer overflowed (capacity now raised): repeat the step
             self.pc.optimizer.zero_grad(set_to_none=True)
-            out = self._step(iteration, frame_idx)
+            out = self._step(iteration, frame_idx if frame_idx is not None else self._last_idx)     # the same frame pair again
             if out is None:
                 raise RuntimeError("rasterizer instance buffer overflowed twice in a row")
         self.controller.step()
+        self._plan = self._plan_idx = None
+        if self.prefetch and self.pc._anchor.is_cuda:
+            with torch.no_grad():
+                self._plan_idx = self.rng.randint(self.lo, max(self.lo, self.hi - 1))
+                self._plan_mode = self.controller.render_mode
+                self._plan = plan_views(self._views(self._plan_idx), self.pc, self.pipe, self.background, self._plan_mode)
         return out
+
+    def _views(self, frame_idx):
+        """The step's four views: (frame, frame seen from the opposite side) of the two adjacent frames."""
+        import copy
+        views = []
+        for fr in (self.dataset[frame_idx], self.dataset[frame_idx + 1]):
+            back = copy.copy(fr)
+            back.view_matrix, back.view_matrix_s = fr.view_matrix_s, fr.view_matrix
+            views += [fr, back]
+        return views
 
     def _adjust_anchor(self, iteration):
         """Densify / prune (reference pipeline/train.py:567-569).  Under data parallelism every rank must take the same
@@ -110,20 +134,19 @@ class Trainer:
         pc.update_learning_rate(iteration)
         if frame_idx is None:
             frame_idx = self.rng.randint(self.lo, max(self.lo, self.hi - 1))
+        self._last_idx = frame_idx
         frame1, frame2 = self.dataset[frame_idx], self.dataset[frame_idx + 1]
         mode = self.controller.render_mode
         retain_grad = opt.update_until > iteration >= 0
 
         if self.batched:
             # one generation pass for the 4 views (frame1 f/b, frame2 f/b), then 4 rasterizations
-            import copy
-            views = []
-            for fr in (frame1, frame2):
-                back = copy.copy(fr)
-                back.view_matrix, back.view_matrix_s = fr.view_matrix_s, fr.view_matrix
-                views += [fr, back]
+            plan = self._plan if (self._plan is not None and self._plan_idx == frame_idx and self._plan_mode == mode and
+                                  self._plan.matches(pc)) else None
+            views = plan.frames if plan is not None else self._views(frame_idx)
+            frame1, frame2 = views[0], views[2]
             r1f, r1b, r2f, r2b = render_many(views, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode,
-                                             dense=True, anchor_grad=self.anchor_grad)
+                                             dense=True, anchor_grad=self.anchor_grad, plan=plan)
             image1 = (r1f.rendered_image + torch.flip(r1b.rendered_image, dims=(-1,))) / 2
             image2 = (r2f.rendered_image + torch.flip(r2b.rendered_image, dims=(-1,))) / 2
             # replicas: "did any rank's instance buffer overflow" is reduced right behind the forward kernels, so that

@@ -528,6 +528,7 @@ def test_evaluate_and_checkpoint_round_trip(tmp_path):
     from gsvc_amd.report import evaluate, load_checkpoint, save_checkpoint
     pc, cube, opt, pipe, mp, Trainer = _setup(anchors=4000, H=192, W=256)
     opt.full_precision_training_total = 1000
+    opt.start_stat = 0                                   # densification statistics from the first step (checked below)
     pc.training_setup(opt)
     tr = Trainer(pc, cube, opt, pipe, mp)
     for it in range(1, 9):
