@@ -54,6 +54,9 @@ def parse(argv=None):
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--frames", type=int, default=600, help="raster workloads: frames of the cube")
+    ap.add_argument("--sigma-px", type=float, nargs=2, default=(0.5, 4.0),
+                    help="raster workloads: range of the Gaussians' per-axis sigma in pixels (log-uniform); BASELINE.md section 2 "
+                         "uses 0.5 .. 4; a fitting render has footprints of ~13 tiles per Gaussian (try 2 .. 12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="headline: skip the raster_fwd side run")
     ap.add_argument("--anchors", type=int, default=245_000,
@@ -383,7 +386,7 @@ def run_raster(args, rank, world, dev, workload, cpu_baseline):
 
     H, W, T, P = args.height, args.width, args.frames, args.gaussians
     frame_id = T // 2 + rank
-    sc = synthetic.raster_scene(P, H=H, W=W, T=T, seed=2026 + rank, window_frames=16, frame_id=frame_id)
+    sc = synthetic.raster_scene(P, H=H, W=W, T=T, seed=2026 + rank, window_frames=16, frame_id=frame_id, sigma_px=tuple(args.sigma_px))
     s = sc["settings"]
     rs = rasterizer.GaussianRasterizationSettings(
         image_height=H, image_width=W, x_min=s["x_min"], y_min=s["y_min"], scale=s["scale"], threshold=s["threshold"],
@@ -470,7 +473,8 @@ def run_raster(args, rank, world, dev, workload, cpu_baseline):
         pipe_bytes += 40 * n_inst + 20 * HW + 88 * n_vis + 124 * P
     kernel_us = sum(v["avg_us"] * v["launches"] for v in kern.values()) / args.steps
     traffic, traffic_src = pmc_traffic(workload, dom)
-    cfg_name = "BASELINE.json configs[1]" if (H, W, P) == (1080, 1920, 200_000) else "raster set of BASELINE.md section 2"
+    cfg_name = ("BASELINE.json configs[1]" if (H, W, P, tuple(args.sigma_px)) == (1080, 1920, 200_000, (0.5, 4.0))
+                else f"raster set of BASELINE.md section 2, sigma {args.sigma_px[0]}..{args.sigma_px[1]} px")
     out = {
         "metric": METRIC, "value": total_units / elapsed, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",

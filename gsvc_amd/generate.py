@@ -410,44 +410,46 @@ def _seg_ste(x, Q, seg, x_mean):
 
 
 def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row=None, sel=None):
-    """``ec_row``: row -> row of ``ec`` when the entropy context was evaluated once per distinct anchor.  ``sel``: the rate
-    sample's rows when a StepPlan drew it ahead of the step (same rule: Bernoulli(SAMPLE_RATE) and mask_anchor)."""
-    K = pc.n_offsets
+    """Sampled rate of the R renders of a batch (reference guassian.py:73-132 per render): 5 % of the visible anchors that have
+    a live offset, bits of their features / scalings / offsets under the entropy context, four normalised means per render.
+    ``ec_row``: row -> row of ``ec`` when the entropy context was evaluated once per distinct anchor.  ``sel``: the sample's
+    rows when a StepPlan drew it ahead of the step (same rule: Bernoulli(SAMPLE_RATE) and mask_anchor).
+
+    Written as a few wide tensor operations: the three attribute groups side by side ([n_sel, 3] steps, [3, n_sel] clamp
+    bounds, [R, 3] sums) instead of one chain of small launches per group and per render — this function used to issue
+    ~120 kernels forward and as many backward to produce sixteen numbers."""
+    from .entropy_models import CLAMP_STEPS, _GaussianBits
+    K, R, dev = pc.n_offsets, seg.R, feat.device
     with torch.no_grad():
-        mask_anchor = (torch.sum(offset_masks, dim=1)[:, 0]) > 0
-        keep_rate = seg.mean(mask_anchor.float().unsqueeze(1)).view(-1)          # per row, constant per render
+        live = (torch.sum(offset_masks, dim=1)[:, 0] > 0)
+        kr = torch.zeros(R, device=dev).index_add_(0, seg.seg_id, live.float()) / seg.counts_t.clamp_min(1)     # keep rate per render
         if sel is None:
-            chosen = (torch.rand_like(feat[:, 0]) <= SAMPLE_RATE) & mask_anchor
+            chosen = (torch.rand_like(feat[:, 0]) <= SAMPLE_RATE) & live
             sel = chosen.nonzero(as_tuple=False).squeeze(1)
         sel_seg = seg.seg_id.index_select(0, sel)
-        n_sel = torch.zeros(seg.R, device=feat.device).index_add_(0, sel_seg, torch.ones_like(sel_seg, dtype=torch.float32))
-    take = lambda t: t.index_select(0, sel)  # noqa: E731
+        n_sel = torch.zeros(R, device=dev).index_add_(0, sel_seg, torch.ones_like(sel_seg, dtype=torch.float32))
     sel_ec = sel if ec_row is None else ec_row.index_select(0, sel)
-    take_ec = lambda t: t.index_select(0, sel_ec)  # noqa: E731
-
-    def seg_mean_sel(q):   # mean of the chosen rows' Q per render, per chosen row
-        s = torch.zeros(seg.R, device=q.device).index_add_(0, sel_seg, q.detach().view(-1))
-        return (s / n_sel.clamp_min(1)).index_select(0, sel_seg)
-
-    def bits_of(x, mean, scale, Q, x_mean):
-        q = take(Q)
-        qm = seg_mean_sel(q)
-        lo, hi = x_mean.detach() - 15_000 * qm, x_mean.detach() + 15_000 * qm
-        return pc.entropy_gaussian(take(x), take_ec(mean), take_ec(scale), q, x_mean, row_bounds=(lo, hi))
-
-    bit_feat = bits_of(feat, ec.mean_feat, ec.scale_feat, Q_feat, pc._anchor_feat.mean())
-    bit_scaling = bits_of(grid_scaling, ec.mean_scaling, ec.scale_scaling, Q_scaling, pc.get_scaling.mean())
-    bit_offsets = bits_of(grid_offsets.view(-1, 3 * K), ec.mean_offsets, ec.scale_offsets, Q_offsets, pc._offset.mean())
-    bit_offsets = bit_offsets * take(offset_masks).repeat(1, 1, 3).view(-1, 3 * K)
-
-    def seg_sum(b):
-        return torch.zeros(seg.R, device=b.device, dtype=b.dtype).index_add_(0, sel_seg, b.sum(dim=1))
-
-    sf, ss, so = seg_sum(bit_feat), seg_sum(bit_scaling), seg_sum(bit_offsets)
-    nf, ns, no = n_sel * bit_feat.shape[1], n_sel * bit_scaling.shape[1], n_sel * bit_offsets.shape[1]
-    kr = torch.stack([keep_rate[seg.bounds[r]] if seg.counts[r] else keep_rate.new_zeros(()) for r in range(seg.R)])
-    return [RatePack(bit_per_param=((sf + ss + so) / (nf + ns + no) * kr)[r], bit_per_feat_param=(sf / nf * kr)[r],
-                     bit_per_scaling_param=(ss / ns * kr)[r], bit_per_offsets_param=(so / no * kr)[r]) for r in range(seg.R)]
+    # steps of the chosen rows, the three groups side by side; clamp bounds = x_mean -+ 15000 * (mean step of the row's render)
+    Q3 = torch.cat([Q_feat.reshape(-1, 1), Q_scaling.reshape(-1, 1), Q_offsets.reshape(-1, 1)], dim=1).index_select(0, sel)
+    Q3T = Q3.t().contiguous()                                                     # [3, n_sel]: one contiguous row per group
+    with torch.no_grad():
+        qm = torch.zeros(R, 3, device=dev).index_add_(0, sel_seg, Q3) / n_sel.clamp_min(1).unsqueeze(1)
+        qmT = qm.index_select(0, sel_seg).t()                                     # [3, n_sel]
+        xm = torch.stack([pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()]).unsqueeze(1)
+        lo, hi = (xm - CLAMP_STEPS * qmT).contiguous(), (xm + CLAMP_STEPS * qmT).contiguous()
+    xs = (feat, grid_scaling, grid_offsets.view(-1, 3 * K))
+    means = (ec.mean_feat, ec.mean_scaling, ec.mean_offsets)
+    scales = (ec.scale_feat, ec.scale_scaling, ec.scale_offsets)
+    bits = [_GaussianBits.apply(xs[g].index_select(0, sel), means[g].index_select(0, sel_ec), scales[g].index_select(0, sel_ec),
+                                Q3T[g], 0.0, lo[g], hi[g], True) for g in range(3)]
+    bits[2] = bits[2] * offset_masks.index_select(0, sel).repeat(1, 1, 3).view(-1, 3 * K)
+    S = torch.zeros(R, 3, device=dev).index_add_(0, sel_seg, torch.stack([b.sum(dim=1) for b in bits], dim=1))   # [R, 3] bit sums
+    dims = torch.tensor([float(bits[0].shape[1]), float(bits[1].shape[1]), float(bits[2].shape[1])], device=dev)
+    N = n_sel.unsqueeze(1) * dims                                                 # coded elements per render and group
+    per = S / N * kr.unsqueeze(1)
+    tot = S.sum(dim=1) / N.sum(dim=1) * kr
+    return [RatePack(bit_per_param=tot[r], bit_per_feat_param=per[r, 0], bit_per_scaling_param=per[r, 1],
+                     bit_per_offsets_param=per[r, 2]) for r in range(R)]
 
 
 def _entropy_context_distinct(pc, anchor_all, vis, plan=None):
