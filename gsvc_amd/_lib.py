@@ -43,6 +43,11 @@ class AdamTensorC(C.Structure):
                 ("n", C.c_int64), ("lr", C.c_float), ("bias_correction1", C.c_float), ("bias_correction2", C.c_float)]
 
 
+class WgradReduceJobC(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("slots", C.c_int32), ("N", C.c_int32),
+                ("K", C.c_int32)]
+
+
 class RasterSizesC(C.Structure):
     _fields_ = [("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)]
 
@@ -91,7 +96,10 @@ _SIGNATURES = {
     "gsvc_ans_decode_scratch_bytes": (_i64, [_i64, C.c_int32]),
     "gsvc_ans_decode": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "gsvc_linear_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "gsvc_linear_forward_ex": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_linear_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, _vp, _i64, _vp]),
+    "gsvc_linear_wgrad_partial": (C.c_int, [_vp, _vp, C.c_int32, _i64, C.c_int32, C.c_int32, _vp, _i64, C.POINTER(C.c_int32), _vp]),
+    "gsvc_linear_wgrad_reduce_many": (C.c_int, [C.POINTER(WgradReduceJobC), C.c_int32, _vp]),
     "gsvc_linear_wgrad_workspace": (_i64, [C.c_int32, C.c_int32]),
     "gsvc_rate_backward": (C.c_int, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_int32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
@@ -113,6 +121,8 @@ def lib():
         import torch  # noqa: F401  (loads the HIP runtime this library links against)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
+            if os.environ.get("GSVC_LIB_PATH") and not hasattr(L, name):
+                continue          # kernel experiments against an older build: entry points it lacks stay unbound
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -1,0 +1,319 @@
+// gsvc_amd/csrc/linear_wgrad.hip — weight / bias gradients of the MLP layers (dW = G^T X over ~200k rows) on MFMA, gfx950.
+#include "linear_ws.h"
+
+namespace gsvc {
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient dW[N,K] = G[M,N]^T X[M,K] (+ db[N] = column sums of G): a reduction over the ~180k anchor rows
+// with a tiny output.  A library GEMM tiles the OUTPUT (a dozen workgroups on 256 CUs); here the rows are split:
+// one persistent workgroup per CU, one wave per (64 x 64 output block, row split).  Both operands stream from HBM
+// exactly once, straight into MFMA fragments, no LDS staging:
+//   * an MFMA step reduces 4 rows; lane (j, mq) reads row m0+mq.  A = G^T, so lane j supplies output row n and
+//     its natural load is VEC consecutive columns n..n+VEC-1 of one G row: component i of that vector is the A
+//     operand of a *strided* tile (rows {16 VEC p + VEC j + i}), so one 16-byte load feeds 4 tiles; same for X/B.
+//     A wave-instruction reads 4 rows x 256 contiguous bytes.
+//   * 16 MFMAs per 8 operand registers; the operand registers of step s are reloaded with the next 16-row chunk
+//     right after its MFMAs (register-neutral prefetch, as in k_linear_ws).
+//   * the waves of a block's row splits are summed in LDS, then the workgroup adds its 64 x 64 blocks to dW with
+//     contiguous 256-byte atomic segments (256 workgroups x N x K floats in total).
+constexpr int WG_MAX_WAVES = 12;
+
+template <int VEC>
+__device__ __forceinline__ void wg_load(__amdgpu_buffer_rsrc_t rs, int off, bool valid, float (&dst)[4], int p)
+{
+    // piece p of a 64-column block: VEC floats at byte offset off (+ the piece's immediate), zeros when !valid
+    const int o = valid ? off : BUF_OOB;
+    if (VEC == 4) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+        dst[0] = __uint_as_float(t.x); dst[1] = __uint_as_float(t.y); dst[2] = __uint_as_float(t.z); dst[3] = __uint_as_float(t.w);
+    } else if (VEC == 2) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, o, 0, 0);
+        dst[2 * p] = __uint_as_float(t.x); dst[2 * p + 1] = __uint_as_float(t.y);
+    } else {
+        dst[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
+    }
+}
+
+// operands of one 4-row step for a 64-column block starting at column c0 of a [rows][ld] matrix
+template <int VEC>
+__device__ __forceinline__ void wg_load_step(__amdgpu_buffer_rsrc_t rs, int row_off, int c0, int j, int ld, float (&dst)[4])
+{
+#pragma unroll
+    for (int p = 0; p < 4 / VEC; p++) {
+        const int col = c0 + 16 * VEC * p + VEC * j;
+        wg_load<VEC>(rs, row_off + col * 4, col < ld, dst, p);
+    }
+}
+
+template <int VG, int VX>
+__global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad(const float *__restrict__ G, const float *__restrict__ X,
+                                                                   float *__restrict__ part, int want_db,
+                                                                   long long M, int N, int K, int BN, int BK, int RS)
+{
+    extern __shared__ float sm[];      // [BN*BK][64][64]
+    __shared__ float sdb[LIN_NT_MAX * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pairs = BN * BK;
+    const int pair = wave % pairs, rs = wave / pairs;
+    const int bn = pair / BK, bk = pair - bn * BK;
+    const int j = lane & 15, mq = lane >> 4;
+    const long long RB = (M + 15) >> 4;
+    const long long workers = (long long)gridDim.x * RS;
+    long long rb = (long long)blockIdx.x * RS + rs;
+    if (tid < LIN_NT_MAX * 16) sdb[tid] = 0.f;
+    __syncthreads();
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float fa[4][4], fb[4][4];          // [step][tile]
+    {
+        const __amdgpu_buffer_rsrc_t rg = ws_block_rsrc(G, rb, RB, M, N), rx = ws_block_rsrc(X, rb, RB, M, K);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            wg_load_step<VG>(rg, (4 * s + mq) * N * 4, 64 * bn, j, N, fa[s]);
+            wg_load_step<VX>(rx, (4 * s + mq) * K * 4, 64 * bk, j, K, fb[s]);
+        }
+    }
+    // the first chunk has landed before the loop: inside it only the loop's own loads are outstanding, so the wait
+    // in front of step s is vmcnt(6) (the three later steps' reloads stay in flight), not vmcnt(0)
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) asm volatile("" : "+v"(fa[s][t]), "+v"(fb[s][t]));
+    for (; rb < RB; rb += workers) {
+        const __amdgpu_buffer_rsrc_t rg = ws_block_rsrc(G, rb + workers, RB, M, N);      // empty past the end
+        const __amdgpu_buffer_rsrc_t rx = ws_block_rsrc(X, rb + workers, RB, M, K);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                gsum[tn] += fa[s][tn];
+#pragma unroll
+                for (int tk = 0; tk < 4; tk++)
+                    acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][tn], fb[s][tk], acc[tn][tk], 0, 0, 0);
+            }
+            wg_load_step<VG>(rg, (4 * s + mq) * N * 4, 64 * bn, j, N, fa[s]);
+            wg_load_step<VX>(rx, (4 * s + mq) * K * 4, 64 * bk, j, K, fb[s]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // bias gradient: column sums of G (waves of the first k-block; the row splits meet in LDS)
+    if (want_db && bk == 0) {
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++) {
+            float v = gsum[tn];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int n = 64 * bn + 16 * VG * (tn / VG) + VG * j + (tn % VG);
+            if (mq == 0 && n < N) atomicAdd(sdb + n, v);
+        }
+    }
+    // sum the row splits of each 64 x 64 block in LDS (one wave per block and round), then write this workgroup's
+    // partial dW (and db) to its slot of `part`; k_linear_wgrad_reduce adds the slots (no global atomics: 256
+    // workgroups adding into the same 40 KB serialise on a handful of memory channels, measured +80 us)
+    float *blk = sm + pair * 4096;
+    for (int round = 0; round < RS; round++) {
+        if (rs == round) {
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++)
+#pragma unroll
+                for (int tk = 0; tk < 4; tk++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int nl = 16 * VG * (tn / VG) + VG * (4 * mq + r) + (tn % VG);
+                        const int kl = 16 * VX * (tk / VX) + VX * j + (tk % VX);
+                        float *d = blk + nl * 64 + kl;
+                        *d = (round == 0) ? acc[tn][tk][r] : *d + acc[tn][tk][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *out = part + (size_t)blockIdx.x * ((size_t)N * K + (want_db ? N : 0));
+    for (int i = tid; i < pairs * 4096; i += blockDim.x) {
+        const int pr = i >> 12, nl = (i >> 6) & 63, kl = i & 63;
+        const int n = 64 * (pr / BK) + nl, k = 64 * (pr % BK) + kl;
+        if (n < N && k < K) out[(size_t)n * K + k] = sm[i];
+    }
+    if (want_db)
+        for (int n = tid; n < N; n += blockDim.x) out[(size_t)N * K + n] = sdb[n];
+}
+
+// dst[i] = sum over the workgroup slots of part[slot][i]: 64 outputs per workgroup, the slots dealt to its 4 waves
+__global__ void __launch_bounds__(256) k_linear_wgrad_reduce(const float *__restrict__ part, int slots, int n, float *__restrict__ dW,
+                                                            int nk, float *__restrict__ db)
+{
+    __shared__ float red[4][64];
+    const int li = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + li;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        int s = sg;
+        for (; s + 12 < slots; s += 16) {
+            a0 += part[(size_t)s * n + i];
+            a1 += part[(size_t)(s + 4) * n + i];
+            a2 += part[(size_t)(s + 8) * n + i];
+            a3 += part[(size_t)(s + 12) * n + i];
+        }
+        for (; s < slots; s += 4) a0 += part[(size_t)s * n + i];
+    }
+    red[sg][li] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sg == 0 && i < n) {
+        const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
+        if (i < nk) dW[i] = v;
+        else db[i - nk] = v;
+    }
+}
+
+// The same sum for up to 8 weight gradients in one launch (the layers of one network's backward pass): a block finds its
+// job through the by-value table of first blocks.
+struct WgReduceJobs {
+    const float *part[8];
+    float *dW[8], *db[8];
+    int slots[8], n[8], nk[8], first_block[9];
+};
+
+__global__ void __launch_bounds__(256) k_linear_wgrad_reduce_many(WgReduceJobs t, int jobs)
+{
+    __shared__ float red[4][64];
+    int job = 0;
+    while (job + 1 < jobs && (int)blockIdx.x >= t.first_block[job + 1]) job++;
+    const float *__restrict__ part = t.part[job];
+    const int slots = t.slots[job], n = t.n[job];
+    const int li = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int i = ((int)blockIdx.x - t.first_block[job]) * 64 + li;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        int s = sg;
+        for (; s + 12 < slots; s += 16) {
+            a0 += part[(size_t)s * n + i];
+            a1 += part[(size_t)(s + 4) * n + i];
+            a2 += part[(size_t)(s + 8) * n + i];
+            a3 += part[(size_t)(s + 12) * n + i];
+        }
+        for (; s < slots; s += 4) a0 += part[(size_t)s * n + i];
+    }
+    red[sg][li] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sg == 0 && i < n) {
+        const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
+        if (i < t.nk[job]) t.dW[job][i] = v;
+        else t.db[job][i - t.nk[job]] = v;
+    }
+}
+
+template <int VG, int VX>
+static int launch_wgrad2(const float *G, const float *X, float *dW, float *db, bool want_db, float *part, int slots, long long M,
+                         int N, int K, hipStream_t s)
+{
+    const int BN = (N + 63) / 64, BK = (K + 63) / 64, pairs = BN * BK;
+    const int RS = pairs >= WG_MAX_WAVES ? 1 : WG_MAX_WAVES / pairs;
+    const size_t lds = (size_t)pairs * 4096 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_wgrad<VG, VX>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    const long long RB = (M + 15) / 16, want = (RB + RS - 1) / RS;
+    const int grid = (int)(want < slots ? want : slots);
+    {
+        ProfScope _prof("k_linear_wgrad", s);
+        hipLaunchKernelGGL((k_linear_wgrad<VG, VX>), dim3(grid), dim3(64 * pairs * RS), lds, s, G, X, part, want_db ? 1 : 0, M, N, K,
+                           BN, BK, RS);
+    }
+    if (!dW) return grid;      // partial sums only: the caller adds the slots later (gsvc_linear_wgrad_reduce_many)
+    const int n = N * K + (want_db ? N : 0);
+    ProfScope _prof("k_linear_wgrad_reduce", s);
+    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3((n + 63) / 64), dim3(256), 0, s, part, grid, n, dW, N * K, db);
+    return grid;
+}
+
+static int vec_of(const float *p, int ld)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    if (ld % 4 == 0 && (a & 15) == 0) return 4;
+    if (ld % 2 == 0 && (a & 7) == 0) return 2;
+    return 1;
+}
+
+}  // namespace gsvc
+
+using namespace gsvc;
+
+extern "C" int64_t gsvc_linear_wgrad_workspace(int32_t N, int32_t K)
+{
+    return (int64_t)256 * ((int64_t)N * K + N);      // one slot per workgroup (one per CU), floats
+}
+
+static int wgrad_launch(const float *G, const float *X, float *dW, float *db, bool want_db, int64_t M, int32_t N, int32_t K,
+                        float *workspace, int64_t workspace_floats, hipStream_t s, const char *what, int *slots_used)
+{
+    GSVC_REQUIRE(M > 0 && K > 0 && N > 0, "%s: bad shape", what);
+    if (N > LIN_NT_MAX * 16 || K > LIN_NT_MAX * 16) {
+        set_error("%s: N=%d / K=%d exceed %d", what, N, K, LIN_NT_MAX * 16);
+        return GSVC_E_UNSUPPORTED;
+    }
+    GSVC_REQUIRE(G && X && workspace, "%s: NULL pointer", what);
+    const int64_t per_slot = (int64_t)N * K + (want_db ? N : 0);
+    int64_t slots = workspace_floats / per_slot;
+    GSVC_REQUIRE(slots >= 1, "%s: workspace smaller than one slot (N*K + N floats)", what);
+    if (slots > 256) slots = 256;
+    const int vg = vec_of(G, N), vx = vec_of(X, K);
+    int used = 0;
+#define WG_CASE(a, b) if (vg == a && vx == b) used = launch_wgrad2<a, b>(G, X, dW, db, want_db, workspace, (int)slots, M, N, K, s)
+    WG_CASE(4, 4); WG_CASE(4, 2); WG_CASE(4, 1); WG_CASE(2, 4); WG_CASE(2, 2); WG_CASE(2, 1); WG_CASE(1, 4); WG_CASE(1, 2); WG_CASE(1, 1);
+#undef WG_CASE
+    if (slots_used) *slots_used = used;
+    return check_launch(what);
+}
+
+extern "C" int gsvc_linear_wgrad(const float *G, const float *X, float *dW, float *db, int64_t M, int32_t N, int32_t K,
+                                 float *workspace, int64_t workspace_floats, void *stream)
+{
+    GSVC_REQUIRE(M >= 0 && K > 0 && N > 0, "linear_wgrad: bad shape");
+    GSVC_REQUIRE(dW, "linear_wgrad: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) {
+        (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, s);
+        if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s);
+        return GSVC_OK;
+    }
+    return wgrad_launch(G, X, dW, db, db != nullptr, M, N, K, workspace, workspace_floats, s, "linear_wgrad", nullptr);
+}
+
+extern "C" int gsvc_linear_wgrad_partial(const float *G, const float *X, int32_t want_db, int64_t M, int32_t N, int32_t K,
+                                         float *workspace, int64_t workspace_floats, int32_t *slots_used, void *stream)
+{
+    GSVC_REQUIRE(slots_used, "linear_wgrad_partial: NULL pointer");
+    return wgrad_launch(G, X, nullptr, nullptr, want_db != 0, M, N, K, workspace, workspace_floats, (hipStream_t)stream,
+                        "linear_wgrad_partial", slots_used);
+}
+
+extern "C" int gsvc_linear_wgrad_reduce_many(const gsvc_wgrad_reduce_job *jobs, int32_t n_jobs, void *stream)
+{
+    GSVC_REQUIRE(jobs && n_jobs >= 0, "linear_wgrad_reduce_many: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    for (int j0 = 0; j0 < n_jobs; j0 += 8) {
+        WgReduceJobs t;
+        const int nj = n_jobs - j0 < 8 ? n_jobs - j0 : 8;
+        int blocks = 0;
+        for (int j = 0; j < nj; j++) {
+            const gsvc_wgrad_reduce_job &q = jobs[j0 + j];
+            GSVC_REQUIRE(q.partial && q.dW && q.slots > 0 && q.N > 0 && q.K > 0, "linear_wgrad_reduce_many: bad job %d", j0 + j);
+            t.part[j] = q.partial; t.dW[j] = q.dW; t.db[j] = q.db; t.slots[j] = q.slots;
+            t.nk[j] = q.N * q.K; t.n[j] = t.nk[j] + (q.db ? q.N : 0);
+            t.first_block[j] = blocks;
+            blocks += (t.n[j] + 63) / 64;
+        }
+        t.first_block[nj] = blocks;
+        ProfScope _prof("k_linear_wgrad_reduce", s);
+        hipLaunchKernelGGL(k_linear_wgrad_reduce_many, dim3(blocks), dim3(256), 0, s, t, nj);
+    }
+    return check_launch("linear_wgrad_reduce_many");
+}

@@ -1,0 +1,229 @@
+"""Whole-MLP autograd functions for the generator / deformation / entropy-parameter networks.
+
+The reference evaluates these networks layer by layer (scene/gaussian_model.py:150-232, 411-501: ``nn.Linear`` ->
+``nn.GELU`` -> ..., FiLM = two 2-layer ReLU nets + ``gamma * x + beta``).  Layer-by-layer autograd costs one Python
+autograd function per Linear plus one graph node per activation / product / sum: ~70 functions and ~450 backward nodes per
+fitting step, i.e. more host time than the GPU needs for the kernels.  Here a network is ONE autograd function: its forward
+launches the MFMA kernels of csrc/linear.hip and the elementwise pieces back to back and keeps the intermediates it needs,
+its backward walks the layers in reverse — the same arithmetic in the same order (tested against the layer-by-layer modules:
+outputs and every gradient), without the graph bookkeeping in between.
+
+Activations ride on the GEMM kernels' epilogue (gsvc_linear_forward_ex):
+  forward   ReLU in place; GELU stores the pre-activation and the activated value side by side (the backward needs the
+            former, the next layer and its weight gradient the latter); tanh / sigmoid at the output; FiLM's
+            ``gamma * h + beta`` in the epilogue of the GEMM that produces gamma
+  backward  dX = (G W) * f'(saved) — the derivative of the PREVIOUS layer's activation is applied where dX is produced
+            (GELU' from the saved pre-activation, ReLU' from the saved output), and the FiLM product rule
+            (d gamma = g * h, d h = g * gamma) is the epilogue of the GEMM that produces g.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+MFMA_MAX_DIM = 192
+MIN_ROWS = 4096
+
+# epilogue codes of gsvc_linear_forward_ex (include/gsvc_hip.h)
+EPI_NONE, EPI_RELU, EPI_GELU_DUAL, EPI_TANH, EPI_SIGMOID, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK, EPI_FILM, EPI_FILM_GRAD = range(9)
+
+_workspaces = {}
+
+
+def _workspace(dev, floats):
+    """One weight-gradient workspace per device, grown on demand (the launches of a stream run in order, so they can
+    share it)."""
+    key = (dev.type, dev.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(max(floats, 1 << 22), device=dev, dtype=torch.float32)
+        _workspaces[key] = ws
+    return ws
+
+
+def linear_ex(x, w, b=None, epi=EPI_NONE, aux1=None, aux2=None, y2=None, y3=None, w_in_out=False, out=None):
+    """Y = epilogue(X W^T + b) through gsvc_linear_forward_ex; returns Y (and fills y2 / y3 where the epilogue has them).
+    w_in_out: W is [K, N] (the dX = G W product of a backward pass)."""
+    M, K = x.shape
+    N = w.shape[1] if w_in_out else w.shape[0]
+    y = out if out is not None else torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().gsvc_linear_forward_ex(
+        _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, K, N, int(w_in_out), int(epi), _lib.ptr(aux1), _lib.ptr(aux2),
+        _lib.ptr(y2), _lib.ptr(y3), _lib.current_stream(x.device)), "gsvc_linear_forward_ex")
+    return y
+
+
+class WgradBatch:
+    """Weight gradients of one network's backward pass: every layer's row-split kernel runs at once (its partial sums go to
+    its own region of the workspace), ONE small launch adds up the slots of all layers at the end (``flush``)."""
+
+    ARENA = 1 << 24     # floats
+
+    def __init__(self, dev):
+        import ctypes as C
+        self.dev, self.C = dev, C
+        self.ws = _workspace(dev, self.ARENA)
+        self.off, self.jobs, self.keep = 0, [], []
+        self.stream = _lib.current_stream(dev)
+
+    def add(self, g, x, want_b=True):
+        """dW = G^T X [N, K] and db = column sums of G [N]; the tensors are complete after flush()."""
+        M, N = g.shape
+        K = x.shape[1]
+        L, C = _lib.lib(), self.C
+        need = int(L.gsvc_linear_wgrad_workspace(N, K))
+        if self.off + need > self.ws.numel():
+            self.flush()
+        buf = torch.empty(N * K + N, device=self.dev, dtype=torch.float32)
+        gw = buf[:N * K].view(N, K)
+        gb = buf[N * K:] if want_b else None
+        if M == 0:
+            buf.zero_()
+            return gw, gb
+        region = self.ws[self.off:self.off + need]
+        slots = C.c_int32(0)
+        _lib.check(L.gsvc_linear_wgrad_partial(_lib.ptr(g), _lib.ptr(x), int(want_b), M, N, K, _lib.ptr(region), need,
+                                               C.byref(slots), self.stream), "gsvc_linear_wgrad_partial")
+        self.jobs.append(_lib.WgradReduceJobC(region.data_ptr(), gw.data_ptr(), gb.data_ptr() if want_b else None, slots.value, N, K))
+        self.keep.append(buf)
+        self.off += need
+        return gw, gb
+
+    def flush(self):
+        if self.jobs:
+            arr = (_lib.WgradReduceJobC * len(self.jobs))(*self.jobs)
+            _lib.check(_lib.lib().gsvc_linear_wgrad_reduce_many(arr, len(self.jobs), self.stream), "gsvc_linear_wgrad_reduce_many")
+        self.off, self.jobs, self.keep = 0, [], []
+
+
+def usable(x, *linears):
+    """The fused path needs a tall fp32 CUDA matrix and layers that fit the weight-stationary kernel."""
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= MIN_ROWS and
+            all(l.in_features <= MFMA_MAX_DIM and l.out_features <= MFMA_MAX_DIM and l.bias is not None for l in linears))
+
+
+class _SeqGelu(torch.autograd.Function):
+    """Linear -> GELU -> Linear -> GELU ... -> Linear (no activation after the last layer): mlp_deform and the two
+    sub-networks of every EntropyParamsNet.  params = (W0, b0, W1, b1, ...)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        x = x.contiguous()
+        n = len(params) // 2
+        acts, zs = [x], []
+        h = x
+        for i in range(n):
+            w, b = params[2 * i].contiguous(), params[2 * i + 1].contiguous()
+            if i + 1 < n:
+                a = torch.empty(h.shape[0], w.shape[0], device=h.device, dtype=torch.float32)
+                z = linear_ex(h, w, b, EPI_GELU_DUAL, y2=a)
+                zs.append(z)
+                acts.append(a)
+                h = a
+            else:
+                h = linear_ex(h, w, b)
+        ctx.n = n
+        ctx.save_for_backward(*acts, *zs, *[params[2 * i] for i in range(n)])
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        acts, zs, ws = saved[:n], saved[n:2 * n - 1], saved[2 * n - 1:]
+        g = g.contiguous()
+        grads = [None] * (2 * n)
+        wg = WgradBatch(g.device)
+        for i in range(n - 1, -1, -1):
+            w = ws[i].contiguous()
+            if ctx.needs_input_grad[1 + 2 * i]:
+                grads[2 * i], grads[2 * i + 1] = wg.add(g, acts[i])
+            if i > 0:
+                g = linear_ex(g, w, None, EPI_MUL_GELU_GRAD, aux1=zs[i - 1], w_in_out=True)      # through layer i and GELU i-1
+            elif ctx.needs_input_grad[0]:
+                g = linear_ex(g, w, None, w_in_out=True)
+            else:
+                g = None
+        wg.flush()
+        return (g, *grads)
+
+
+ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
+
+
+class _Generator(torch.autograd.Function):
+    """GeneratorNet: out_act(out_linear(FiLM(linear2(GELU(linear1(feature))), condition))) (reference
+    scene/gaussian_model.py:150-196).  params = linear1 (W, b), linear2, fc_gamma0, fc_gamma1, fc_beta0, fc_beta1, out_linear."""
+
+    @staticmethod
+    def forward(ctx, feature, condition, act, *params):
+        feature, condition = feature.contiguous(), condition.contiguous()
+        W1, b1, W2, b2, Wg0, bg0, Wg1, bg1, Wb0, bb0, Wb1, bb1, W3, b3 = [p.contiguous() for p in params]
+        M, dev = feature.shape[0], feature.device
+        f = lambda n: torch.empty(M, n, device=dev, dtype=torch.float32)  # noqa: E731
+        a1 = f(W1.shape[0])
+        z1 = linear_ex(feature, W1, b1, EPI_GELU_DUAL, y2=a1)
+        h = linear_ex(a1, W2, b2)
+        cb = linear_ex(condition, Wb0, bb0, EPI_RELU)
+        beta = linear_ex(cb, Wb1, bb1)
+        cg = linear_ex(condition, Wg0, bg0, EPI_RELU)
+        x3 = f(Wg1.shape[0])
+        gamma = linear_ex(cg, Wg1, bg1, EPI_FILM, aux1=h, aux2=beta, y2=x3)            # gamma and x3 = gamma * h + beta
+        y = linear_ex(x3, W3, b3, (EPI_NONE, EPI_TANH, EPI_SIGMOID)[act])
+        ctx.act = act
+        ctx.save_for_backward(feature, condition, z1, a1, h, cb, cg, gamma, x3, y, W1, W2, Wg0, Wg1, Wb0, Wb1, W3)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        feature, condition, z1, a1, h, cb, cg, gamma, x3, y, W1, W2, Wg0, Wg1, Wb0, Wb1, W3 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        gy = gy.contiguous()
+        if ctx.act == ACT_TANH:
+            go = torch.ops.aten.tanh_backward(gy, y)
+        elif ctx.act == ACT_SIGMOID:
+            go = torch.ops.aten.sigmoid_backward(gy, y)
+        else:
+            go = gy
+        P = [None] * 14
+        wg = WgradBatch(gy.device)
+        P[12], P[13] = wg.add(go, x3)
+        # g x3 = go W3 is d beta; the same GEMM's epilogue leaves d gamma = g x3 * h and d h = g x3 * gamma
+        M, dev = feature.shape[0], feature.device
+        gg = torch.empty(M, h.shape[1], device=dev, dtype=torch.float32)
+        gh = torch.empty_like(gg)
+        gbeta = linear_ex(go, W3, None, EPI_FILM_GRAD, aux1=h, aux2=gamma, y2=gg, y3=gh, w_in_out=True)
+        P[10], P[11] = wg.add(gbeta, cb)
+        gcb = linear_ex(gbeta, Wb1, None, EPI_MUL_RELU_MASK, aux1=cb, w_in_out=True)
+        P[8], P[9] = wg.add(gcb, condition)
+        P[6], P[7] = wg.add(gg, cg)
+        gcg = linear_ex(gg, Wg1, None, EPI_MUL_RELU_MASK, aux1=cg, w_in_out=True)
+        P[4], P[5] = wg.add(gcg, condition)
+        gcond = None
+        if need[1]:
+            gcond = linear_ex(gcb, Wb0, None, w_in_out=True)
+            gcond += linear_ex(gcg, Wg0, None, w_in_out=True)
+        P[2], P[3] = wg.add(gh, a1)
+        gz1 = linear_ex(gh, W2, None, EPI_MUL_GELU_GRAD, aux1=z1, w_in_out=True)
+        P[0], P[1] = wg.add(gz1, feature)
+        gfeat = linear_ex(gz1, W1, None, w_in_out=True) if need[0] else None
+        wg.flush()
+        return (gfeat, gcond, None, *P)
+
+
+def seq_gelu(x, linears):
+    params = []
+    for l in linears:
+        params += [l.weight, l.bias]
+    return _SeqGelu.apply(x, *params)
+
+
+def generator(net, feature, condition):
+    act = {"Tanh": ACT_TANH, "Sigmoid": ACT_SIGMOID, "Identity": ACT_NONE}[type(net.out_act).__name__]
+    film = net.film
+    ls = (net.linear1, net.linear2, film.fc_gamma0, film.fc_gamma1, film.fc_beta0, film.fc_beta1, net.out_linear)
+    params = []
+    for l in ls:
+        params += [l.weight, l.bias]
+    return _Generator.apply(feature, condition, act, *params)

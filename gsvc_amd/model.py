@@ -18,6 +18,7 @@ per access; the 3-NN initial scale uses chunked torch.cdist instead of simple_kn
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 
@@ -176,6 +177,20 @@ class Sequential(nn.Sequential):
         return x
 
 
+class GeluSequential(nn.Sequential):
+    """nn.Sequential of Linear -> GELU -> ... -> Linear (same child names, hence the reference's state_dict keys).  A tall CUDA
+    matrix runs the whole chain as ONE autograd function with the GELUs on the GEMM epilogues (gsvc_amd/mlp.py)."""
+
+    def forward(self, x):
+        from . import mlp
+        mods = list(self)
+        linears = mods[0::2]
+        if (all(isinstance(m, nn.Linear) for m in linears) and all(isinstance(m, nn.GELU) for m in mods[1::2])
+                and len(mods) % 2 == 1 and mlp.usable(x, *linears) and not os.environ.get("GSVC_NO_MLP_CHAIN")):
+            return mlp.seq_gelu(x, linears)
+        return super().forward(x)
+
+
 class FiLM(nn.Module):
     """gamma(cond) * x + beta(cond), both from 2-layer ReLU MLPs."""
 
@@ -211,6 +226,12 @@ class GeneratorNet(nn.Module):
         return self.out_act(self.out_linear(self.film(h, condition)))
 
     def forward(self, feature, condition):
+        from . import mlp
+        f = self.film
+        if (type(self.out_act).__name__ in ("Tanh", "Sigmoid", "Identity") and not os.environ.get("GSVC_NO_MLP_CHAIN")
+                and mlp.usable(feature, self.linear1, self.linear2, self.out_linear)
+                and mlp.usable(condition, f.fc_gamma0, f.fc_gamma1, f.fc_beta0, f.fc_beta1)):
+            return mlp.generator(self, feature, condition)      # the whole network as one autograd function
         return self.head(self.trunk(feature), condition)
 
 
@@ -218,12 +239,12 @@ class EntropyParamsNet(nn.Module):
     def __init__(self, input_dim, inner_dim, inner_dim2, output_dim, layer=2):
         super().__init__()
         if layer == 2:
-            self.dist_net = nn.Sequential(Linear(input_dim, inner_dim), nn.GELU(), Linear(inner_dim, output_dim * 2))
+            self.dist_net = GeluSequential(Linear(input_dim, inner_dim), nn.GELU(), Linear(inner_dim, output_dim * 2))
         else:
             assert layer == 3
-            self.dist_net = nn.Sequential(Linear(input_dim, inner_dim), nn.GELU(), Linear(inner_dim, inner_dim),
-                                          nn.GELU(), Linear(inner_dim, output_dim * 2))
-        self.quant_step_net = nn.Sequential(Linear(input_dim, inner_dim2), nn.GELU(), Linear(inner_dim2, 1))
+            self.dist_net = GeluSequential(Linear(input_dim, inner_dim), nn.GELU(), Linear(inner_dim, inner_dim),
+                                           nn.GELU(), Linear(inner_dim, output_dim * 2))
+        self.quant_step_net = GeluSequential(Linear(input_dim, inner_dim2), nn.GELU(), Linear(inner_dim2, 1))
 
     def forward(self, x):
         params = self.dist_net(x)
@@ -357,7 +378,7 @@ class GaussianModel(nn.Module):
         self.mlp_opacity = GeneratorNet(feat_dim, n_offsets, inner, cond, out_act=nn.Tanh())
         self.mlp_cov = GeneratorNet(feat_dim, 7 * n_offsets, inner, cond)
         self.mlp_color = GeneratorNet(feat_dim, 3 * n_offsets, inner, cond, out_act=nn.Sigmoid())
-        self.mlp_deform = nn.Sequential(
+        self.mlp_deform = GeluSequential(
             Linear(feat_dim + cond, inner), nn.GELU(), Linear(inner, inner), nn.GELU(),
             Linear(inner, inner), nn.GELU(), Linear(inner, inner), nn.GELU(), Linear(inner, 3 * n_offsets))
         gdim = self.encoding_xyz.output_dim

@@ -335,6 +335,24 @@ int gsvc_ans_decode(const uint8_t *bytes, const uint64_t *seg_offsets, const flo
 int gsvc_linear_forward(const float *X, const float *W, const float *bias, float *Y, int64_t M, int32_t K, int32_t N,
                         int32_t w_in_out, int32_t relu, void *stream);
 
+/* The same product with an epilogue program (the activations of the MLPs ride on the GEMM that produces their operand;
+ * gsvc_amd/mlp.py runs every network of scene/gaussian_model.py:150-232 as one chain of these calls).  aux1 / aux2 / Y2 / Y3
+ * have Y's shape [M,N]; v = X W^T + bias:
+ *   GSVC_LIN_NONE / _RELU       as gsvc_linear_forward
+ *   GSVC_LIN_GELU_DUAL          Y = v (the pre-activation the backward needs), Y2 = GELU(v) (exact, erf form)
+ *   GSVC_LIN_TANH / _SIGMOID    Y = tanh(v) / sigmoid(v)
+ *   GSVC_LIN_MUL_GELU_GRAD      Y = v * GELU'(aux1)            (dX of a layer behind a GELU: aux1 = its pre-activation)
+ *   GSVC_LIN_MUL_RELU_MASK      Y = aux1 > 0 ? v : 0           (dX of a layer behind a ReLU: aux1 = its output)
+ *   GSVC_LIN_FILM               Y = v (gamma), Y2 = v * aux1 + aux2          (FiLM: aux1 = h, aux2 = beta)
+ *   GSVC_LIN_FILM_GRAD          Y = v (d beta), Y2 = v * aux1 (d gamma, aux1 = h), Y3 = v * aux2 (d h, aux2 = gamma) */
+enum {
+    GSVC_LIN_NONE = 0, GSVC_LIN_RELU = 1, GSVC_LIN_GELU_DUAL = 2, GSVC_LIN_TANH = 3, GSVC_LIN_SIGMOID = 4,
+    GSVC_LIN_MUL_GELU_GRAD = 5, GSVC_LIN_MUL_RELU_MASK = 6, GSVC_LIN_FILM = 7, GSVC_LIN_FILM_GRAD = 8
+};
+int gsvc_linear_forward_ex(const float *X, const float *W, const float *bias, float *Y, int64_t M, int32_t K, int32_t N,
+                           int32_t w_in_out, int32_t epilogue, const float *aux1, const float *aux2, float *Y2, float *Y3,
+                           void *stream);
+
 /* dW[N,K] = G[M,N]^T X[M,K] and (db != NULL) db[N] = column sums of G: the weight / bias gradients of the same
  * layers.  Rows are split over the chip instead of the tiny output; every workgroup writes its partial sums to its
  * slot of `workspace` ((N*K + N) floats per slot, gsvc_linear_wgrad_workspace() = 256 slots) and a second small
@@ -342,6 +360,19 @@ int gsvc_linear_forward(const float *X, const float *W, const float *bias, float
 int64_t gsvc_linear_wgrad_workspace(int32_t N, int32_t K);
 int gsvc_linear_wgrad(const float *G, const float *X, float *dW, float *db, int64_t M, int32_t N, int32_t K,
                       float *workspace, int64_t workspace_floats, void *stream);
+
+/* The two halves of gsvc_linear_wgrad apart, so that one small launch adds up the partial sums of every layer of a network's
+ * backward pass: _partial runs the row-split kernel only (workspace as above, one region per pending layer; *slots_used = the
+ * slots it filled), _reduce_many adds the slots of n_jobs layers (db may be NULL when the partials were taken without it;
+ * `partial` must then have been produced with want_db = 0). */
+typedef struct gsvc_wgrad_reduce_job {
+    const float *partial;
+    float *dW, *db;
+    int32_t slots, N, K;
+} gsvc_wgrad_reduce_job;
+int gsvc_linear_wgrad_partial(const float *G, const float *X, int32_t want_db, int64_t M, int32_t N, int32_t K,
+                              float *workspace, int64_t workspace_floats, int32_t *slots_used, void *stream);
+int gsvc_linear_wgrad_reduce_many(const gsvc_wgrad_reduce_job *jobs, int32_t n_jobs, void *stream);
 
 #ifdef __cplusplus
 }

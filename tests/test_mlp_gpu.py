@@ -1,0 +1,99 @@
+"""Whole-network autograd functions (gsvc_amd/mlp.py: every MLP of reference scene/gaussian_model.py:150-232 as one
+chain of GEMM launches with the activations on the epilogue) against a plain PyTorch fp32 statement of the same networks:
+outputs and the gradient of every parameter and input.  fp32 products and sums on both sides; summation order and the
+GEMM-side erf differ -> 2e-5 of the tensor's scale forward, 1e-3 of the gradient's scale backward (sums over ~6000 rows).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol):
+    scale = max(1e-6, b.abs().max().item())
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, (err, scale)
+
+
+def _torch_generator(net, feat, cond):
+    h = F.linear(F.gelu(F.linear(feat, net.linear1.weight, net.linear1.bias)), net.linear2.weight, net.linear2.bias)
+    f = net.film
+    gamma = F.linear(torch.relu(F.linear(cond, f.fc_gamma0.weight, f.fc_gamma0.bias)), f.fc_gamma1.weight, f.fc_gamma1.bias)
+    beta = F.linear(torch.relu(F.linear(cond, f.fc_beta0.weight, f.fc_beta0.bias)), f.fc_beta1.weight, f.fc_beta1.bias)
+    return net.out_act(F.linear(gamma * h + beta, net.out_linear.weight, net.out_linear.bias))
+
+
+@pytest.mark.parametrize("out_dim,act", [(10, "tanh"), (70, None), (30, "sigmoid")])
+@pytest.mark.parametrize("M", [6001, 4096])
+def test_generator_chain_matches_torch(out_dim, act, M):
+    """GeneratorNet at the production sizes (feature 50 -> 100 -> 100, condition 66 -> 66 -> 100, out 10 / 70 / 30)."""
+    from gsvc_amd.model import GeneratorNet
+    torch.manual_seed(out_dim + M)
+    out_act = {"tanh": torch.nn.Tanh(), "sigmoid": torch.nn.Sigmoid(), None: None}[act]
+    net = GeneratorNet(50, out_dim, 100, 66, out_act=out_act).cuda()
+    feat = (torch.randn(M, 50, device="cuda") * 2).requires_grad_(True)
+    cond = torch.randn(M, 66, device="cuda").requires_grad_(True)
+    g = torch.randn(M, out_dim, device="cuda")
+    with torch.no_grad():
+        # a ReLU pre-activation within rounding of 0 may land on either side of the kink in the two summation orders (its
+        # derivative jumps): rows that have one take no part in the gradient comparison
+        f = net.film
+        pre = torch.cat([F.linear(cond, f.fc_gamma0.weight, f.fc_gamma0.bias), F.linear(cond, f.fc_beta0.weight, f.fc_beta0.bias)], 1)
+        g[(pre.abs() < 1e-4).any(dim=1)] = 0
+    y = net(feat, cond)
+    assert y.grad_fn is not None and "Generator" in type(y.grad_fn).__name__      # the fused function ran
+    (y * g).sum().backward()
+    got = [feat.grad.clone(), cond.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+    feat.grad = cond.grad = None
+    net.zero_grad()
+    ref = _torch_generator(net, feat, cond)
+    _close(y.detach(), ref.detach(), 2e-5)
+    (ref * g).sum().backward()
+    want = [feat.grad, cond.grad] + [p.grad for p in net.parameters()]
+    for a, b in zip(got, want):
+        _close(a, b, 1e-3)
+
+
+@pytest.mark.parametrize("dims", [(116, 100, 100, 100, 100, 30), (192, 150, 100), (192, 50, 1), (192, 100, 100, 12), (66, 7)])
+def test_gelu_sequential_chain_matches_torch(dims):
+    """mlp_deform and the sub-networks of the EntropyParamsNets (Linear -> GELU -> ... -> Linear)."""
+    from gsvc_amd.model import GeluSequential, Linear
+    torch.manual_seed(sum(dims))
+    mods = []
+    for i in range(len(dims) - 1):
+        mods.append(Linear(dims[i], dims[i + 1]))
+        if i + 2 < len(dims):
+            mods.append(torch.nn.GELU())
+    net = GeluSequential(*mods).cuda()
+    M = 5003
+    x = torch.randn(M, dims[0], device="cuda").requires_grad_(True)
+    g = torch.randn(M, dims[-1], device="cuda")
+    y = net(x)
+    assert "SeqGelu" in type(y.grad_fn).__name__
+    (y * g).sum().backward()
+    got = [x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+    x.grad = None
+    net.zero_grad()
+    h = x
+    for m in net:
+        h = F.linear(h, m.weight, m.bias) if isinstance(m, torch.nn.Linear) else F.gelu(h)
+    _close(y.detach(), h.detach(), 2e-5)
+    (h * g).sum().backward()
+    for a, b in zip(got, [x.grad] + [p.grad for p in net.parameters()]):
+        _close(a, b, 1e-3)
+    # no gradient wanted for the input: the first layer's dX product is skipped
+    net.zero_grad()
+    y2 = net(x.detach())
+    (y2 * g).sum().backward()
+    _close(net[0].weight.grad, got[1], 1e-6)
+
+
+def test_chain_falls_back_for_small_batches_and_cpu():
+    from gsvc_amd.model import GeneratorNet
+    net = GeneratorNet(50, 10, 100, 66, out_act=torch.nn.Tanh())
+    y = net(torch.randn(8, 50), torch.randn(8, 66))
+    assert "Generator" not in type(y.grad_fn).__name__
+    net = net.cuda()
+    y = net(torch.randn(8, 50, device="cuda"), torch.randn(8, 66, device="cuda"))
+    assert "Generator" not in type(y.grad_fn).__name__
