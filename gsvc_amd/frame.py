@@ -5,7 +5,7 @@ Same quantities as reference frame_cube/frame.py: ``make_view_matrix`` (:18-43, 
 ``scale = max(H, W, T)/2``, ``x_min = -W/2/scale``, ``y_min = -H/2/scale``, ``z = (id - T/2)/scale``.
 pyglm is not needed: lookAt is written out.  As in the reference the stored ``view_matrix`` is the TRANSPOSE of
 the math matrix (np.array(glm.mat4) is column-major), and the renderer passes ``view_matrix.permute(1, 0)``.
-File loading (PNG / optical-flow pickles) is out of scope; ``SyntheticFrameCube`` provides frames instead.
+Frames from files: ``gsvc_amd.io.FrameCubeDataset``; ``SyntheticFrameCube`` provides procedural frames of the same shape.
 """
 from __future__ import annotations
 

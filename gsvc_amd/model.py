@@ -9,8 +9,8 @@ What is here (reference line ranges in brackets):
   * training_setup / update_learning_rate: 15 Adam groups, eps 1e-15, exponential LR [833-1058, 1148-1154]
   * training_statis [1281-1314], calc_entropy_context [1569-1597], get_encoding_params [506-518]
 Parameter / sub-module names equal the reference's, so a reference ``state_dict`` loads unchanged.
-Densification (adjust_anchor), bit accounting, the codec and ply/checkpoint IO are out of scope
-(SURVEY.md section 2 #7, section 8f).
+Densification lives in densify.py, the stream codec in stream_codec.py / mlp_codec.py, ply / checkpoint IO in io.py
+(SURVEY.md section 8f); the methods here delegate.
 
 Differences in mechanism, not in values: the device is a constructor argument instead of a hard-coded
 "cuda"; ``get_anchor`` etc. stay properties but the renderer caches them per render instead of recomputing
@@ -512,6 +512,44 @@ class GaussianModel(nn.Module):
         log = (f"Estimated sizes in MB: anchor {mb(bit_anchor)}, feat {mb(bit_feat)}, scaling {mb(bit_scaling)}, "
                f"offsets {mb(bit_offsets)}, hash {mb(bit_hash)}, masks {mb(bit_masks)}, MLPs {mb(bit_mlp)}, Total {mb(total)}")
         return log, info
+
+    # ------------------------------------------------------------------ MLP weight coding (reference :1727-1835, gsvc_amd/mlp_codec.py)
+    def quantize_model(self, replace=True):
+        from . import mlp_codec
+        return mlp_codec.quantize_model(self, replace)
+
+    def encode_mlp(self, file_path):
+        from . import mlp_codec
+        return mlp_codec.encode_mlp(self, file_path)
+
+    # ------------------------------------------------------------------ files (reference :556-639, 1156-1240, 1505-1540; gsvc_amd/io.py)
+    def capture(self):
+        from . import io
+        return io.capture(self)
+
+    def restore(self, model_args, training_args):
+        from . import io
+        return io.restore(self, model_args, training_args)
+
+    def init_anchor_params(self, anchor_num):
+        from . import io
+        return io.init_anchor_params(self, anchor_num)
+
+    def save_ply(self, path):
+        from . import io
+        return io.save_ply(self, path)
+
+    def load_ply_sparse_gaussian(self, path):
+        from . import io
+        return io.load_ply_sparse_gaussian(self, path)
+
+    def save_mlp_checkpoints(self, path):
+        from . import io
+        return io.save_mlp_checkpoints(self, path)
+
+    def load_mlp_checkpoints(self, path):
+        from . import io
+        return io.load_mlp_checkpoints(self, path)
 
     # ------------------------------------------------------------------ initialisation (reference :748-800)
     def voxelize_sample(self, data, voxel_size=0.01):

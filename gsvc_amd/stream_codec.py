@@ -12,7 +12,8 @@ utils/encodings.py:827-862 (``reorder_and_split``) in what is coded, in which or
   Gaussian placed so that P(0) = 1 - p;
 * anchor geometry: the reference hands the 16-bit anchor grid to MPEG G-PCC (``tmc3``, an external executable); here the
   quantised anchors are stored raw (3 x uint16 per anchor, in the (x, y, z)-sorted order G-PCC would return);
-* MLP weights are carried as they are (the reference's 8-bit weight quantisation + Huffman stage is not built).
+* MLP weights: 8-bit quantisation + Huffman code as the reference (gsvc_amd/mlp_codec.py; ``mlp_file=`` below) — the
+  quantised networks are the ones that drive the context model of the attribute streams, on both sides.
 
 Everything runs on the device except the byte containers.
 """
@@ -100,10 +101,11 @@ class StreamPack:
     offsets: list = field(default_factory=list)
     masks: bytes = b""
     hash: bytes = b""
+    bit_mlp_encoded: int = None              # size of the MLP file written beside the streams (not part of meta.json)
 
     def bits(self):
         """Coded size per stream in bits (same keys as BitInfo where they exist)."""
-        return {"bit_anchor": self.anchors_q.size * ANCHOR_ROUND_DIGITS, "bit_feat": 8 * sum(map(len, self.feat)),
+        return {**({"bit_mlp_encoded": self.bit_mlp_encoded} if self.bit_mlp_encoded is not None else {}), "bit_anchor": self.anchors_q.size * ANCHOR_ROUND_DIGITS, "bit_feat": 8 * sum(map(len, self.feat)),
                 "bit_scaling": 8 * sum(map(len, self.scaling)), "bit_offsets": 8 * sum(map(len, self.offsets)),
                 "bit_masks": 8 * len(self.masks), "bit_hash": 8 * len(self.hash)}
 
@@ -153,8 +155,15 @@ def _slab_model(pc, anchor):
 
 
 @torch.no_grad()
-def conduct_stream_encoding(pc) -> StreamPack:
+def conduct_stream_encoding(pc, mlp_file=None) -> StreamPack:
+    """``mlp_file``: quantise the MLPs to 8 bits IN PLACE and write them there first (reference :2313-2317: the attribute
+    streams are then coded under the quantised entropy networks, which is what the decoder will hold)."""
     K = pc.n_offsets
+    bit_mlp_encoded = None
+    if mlp_file is not None:
+        from . import mlp_codec
+        mlp_codec.quantize_model(pc, replace=True)
+        bit_mlp_encoded = mlp_codec.encode_mlp(pc, mlp_file)
     keep = pc.get_mask_anchor
     q_anchor, interval, a_min = pc.quantized_anchor
     q_anchor = q_anchor[keep]
@@ -187,14 +196,20 @@ def conduct_stream_encoding(pc) -> StreamPack:
         pack.offsets.append(encoder_gaussian(x[m3], mo[m3], so[m3], qo[m3], *ranges[2])[3] if bool(m3.any()) else b"")
     pack.masks = encode_binary(mask, prob_masks)
     pack.hash = encode_binary((tables + 1) / 2, prob_hash)
+    pack.bit_mlp_encoded = bit_mlp_encoded
     return pack
 
 
 @torch.no_grad()
-def conduct_stream_decoding(pc, pack: StreamPack):
+def conduct_stream_decoding(pc, pack: StreamPack, mlp_file=None):
     """Replace the model's anchors, attributes, masks and hash tables by the decoded ones (``decoded_version`` = True);
-    the MLP weights of ``pc`` must be the encoder's."""
+    the MLP weights of ``pc`` must be the encoder's — given ``mlp_file`` they are read from it first."""
     dev, K = pc._anchor.device, pc.n_offsets
+    if mlp_file is not None:
+        from . import mlp_codec
+        sd = pc.state_dict()
+        for k, v in mlp_codec.decode_mlp(mlp_file).items():
+            sd[k].copy_(v.to(sd[k].device))
     q = torch.from_numpy(pack.anchors_q.astype(np.float32)).to(dev)
     anchor = Quantize_anchor.dequantized(q, torch.from_numpy(pack.anchor_interval).to(dev), torch.from_numpy(pack.anchor_min).to(dev))
     z_order, slabs = reorder_and_split(anchor)

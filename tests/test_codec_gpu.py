@@ -3,6 +3,8 @@ model's own entropy, edge cases of the symbol range and of the model."""
 import math
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -213,3 +215,41 @@ def test_stream_encode_decode_round_trip(tmp_path):
     frames = [cube.get_dummy_frame(i) for i in (30, 31)]
     imgs = list(render_frames(frames, dec, pipe, torch.zeros(3)))
     assert len(imgs) == 2 and all(torch.isfinite(i).all() for i in imgs)
+
+
+def test_stream_round_trip_with_coded_mlps(tmp_path):
+    """The whole model through its files, MLPs included (8-bit + Huffman, reference scene/gaussian_model.py:1727-1835,
+    2313-2317): a decoder that starts from differently initialised networks ends with the encoder's quantised weights and,
+    under them, with exactly the attributes the encoder coded."""
+    from gsvc_amd.stream_codec import StreamPack, conduct_stream_decoding, conduct_stream_encoding
+    dev = torch.device("cuda")
+    pc, cube, pipe = _fitted_like_model(dev, anchors=6000)
+    mlp_file = str(tmp_path / "mlp.b")
+    pack = conduct_stream_encoding(pc, mlp_file=mlp_file)
+    assert pack.bits()["bit_mlp_encoded"] == os.path.getsize(mlp_file) * 8
+    n_w = sum(v.numel() for k, v in pc.state_dict().items() if k.startswith("mlp"))
+    assert pack.bit_mlp_encoded < 0.3 * 32 * n_w          # the reference budgets 30 % of the raw fp32 size (gaussian_model.py:1716)
+    pack.save(str(tmp_path))
+    torch.manual_seed(99)
+    dec, _, _ = _fitted_like_model(dev, anchors=6000)
+    with torch.no_grad():
+        for n, p in dec.named_parameters():
+            if n.startswith("mlp"):
+                p.add_(torch.randn_like(p) * 0.05)         # not the encoder's networks
+    conduct_stream_decoding(dec, StreamPack.load(str(tmp_path)), mlp_file=mlp_file)
+    enc_sd, dec_sd = pc.state_dict(), dec.state_dict()
+    for k in enc_sd:
+        if k.startswith("mlp"):
+            assert torch.equal(enc_sd[k], dec_sd[k]), k
+    ref = copy_of_decoded(pc, pack)
+    N = pack.n
+    for name in ("_anchor", "_anchor_feat", "_scaling", "_offset", "_mask"):
+        assert torch.equal(getattr(dec, name)[:N], getattr(ref, name)[:N]), name
+
+
+def copy_of_decoded(pc, pack):
+    import copy
+    from gsvc_amd.stream_codec import conduct_stream_decoding
+    ref = copy.deepcopy(pc)
+    conduct_stream_decoding(ref, pack)
+    return ref
