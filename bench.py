@@ -10,6 +10,10 @@ Workloads (a "step" is one pass of the hot path over synthetic UVG-shaped 1080p 
                  TRAINING_ENTROPY mode), L1 / SSIM / optical-flow losses, Adam; 200 untimed fitting steps first
   raster_fwd     BASELINE.json configs[1]: 1080p single frame, 200k Gaussians, forward raster only (render fps)
   raster_fwdbwd  same scene, forward + backward of the rasterizer alone
+  stream_decode  BASELINE.json configs[4] shape on one GPU: 4K frames, anchors such that ~2 M Gaussians are generated per frame
+                 (16-frame slab of a 300-frame cube), attributes drawn from the model's own entropy context; the whole model is
+                 entropy-coded, decoded (masks, hash tables, three attribute streams per z-slab) and 24 two-view frames are
+                 rendered from the decoded model: stream_decode fps = frames / (decode + render)
   headline       (default) train_step as the top-level value / ms_per_step / roofline / cpu_baseline, plus a short
                  raster_fwd run reported under the side key "raster_fwd" (render fps, single and two-view)
 
@@ -49,7 +53,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="headline", choices=["headline", "raster_fwd", "raster_fwdbwd", "train_step"])
+    ap.add_argument("--workload", default="headline",
+                    choices=["headline", "raster_fwd", "raster_fwdbwd", "train_step", "stream_decode"])
     ap.add_argument("--gaussians", type=int, default=200_000, help="raster workloads: Gaussians in the slab")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
@@ -112,7 +117,8 @@ def pmc_traffic(workload, kernel):
     try:
         data = json.load(open(path))
         val = data.get(workload, {}).get(kernel)
-        src = {"measured_live": False, "file": "profiles/pmc_latest.json",
+        valu = data.get("valu", {}).get(workload, {}).get(kernel)
+        src = {"measured_live": False, "file": "profiles/pmc_latest.json", "valu": valu,
                "binary": data.get("_binary", {}).get(workload, "unknown"),
                "passes": data.get("_source", {}).get(workload, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")}
         return val, src
@@ -144,6 +150,83 @@ def reduce_sum_max(torch, dist, world, dev, total, elapsed):
         dist.all_reduce(b, op=dist.ReduceOp.MAX)
         return float(a.item()), float(b.item())
     return float(t[0].item()), float(t[1].item())
+
+
+# ------------------------------------------------------------------------------------------------ stream_decode (cfg-5 shape)
+def run_stream_decode(args, dev, height=2160, width=3840, frames=300, gaussians_per_frame=2_000_000, n_render=24):
+    """Entropy decode of a whole coded model + decoder render loop at the BASELINE.json configs[4] shape (reference
+    pipeline/stream_decode.py: conduct_stream_decoding, then render_frames)."""
+    import copy
+    import numpy as np
+    import torch
+    from gsvc_amd.arguments import cfg_20240919
+    from gsvc_amd.frame import SyntheticFrameCube
+    from gsvc_amd.model import GaussianModel
+    from gsvc_amd.ortho_gaussian_renderer import render_frames
+    from gsvc_amd.stream_codec import conduct_stream_decoding, conduct_stream_encoding
+    mp_, opt, pipe = cfg_20240919()
+    cube = SyntheticFrameCube(height, width, frames, seed=1234, device=dev)
+    mp_.threshold = 8.0 / cube.scale
+    K = mp_.n_offsets
+    anchors = int(gaussians_per_frame / K * frames * 1.1 / 16)        # V = anchors * 16 / (frames * 1.1 bleed)
+    torch.manual_seed(0)
+    pc = GaussianModel(mp_, mp_.anchor_feature_dim, K, mp_.voxel_size, mp_.update_depth, mp_.update_init_factor,
+                       mp_.update_hierarchy_factor, mp_.use_feat_bank, n_features_per_level=mp_.grid_feature_dim,
+                       log2_hashmap_size=mp_.log2, log2_hashmap_size_2D=mp_.log2_2D, device=dev)
+    rng = np.random.default_rng(0)
+    lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
+    pc.create_from_points(rng.uniform(lim, -lim, (anchors, 3)), 1.0)
+    pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+    g = torch.Generator(device=dev).manual_seed(17)
+    with torch.no_grad():
+        # a calibrated model without fitting it: entropy nets away from their initial values, attributes drawn from the
+        # context model itself, 1 in 11 anchors without a live offset, ~15 % of the offsets masked
+        for net in (pc.mlp_feature_enet, pc.mlp_scaling_enet, pc.mlp_offset_enet):
+            for prm in net.parameters():
+                prm.add_(torch.randn(prm.shape, device=dev, generator=g) * 0.02)
+        pc._mask.copy_(torch.randn(pc._mask.shape, device=dev, generator=g) * 4.0 + 4.0)
+        pc._mask[::11] = -9.0
+        for lo in range(0, anchors, 1 << 19):
+            sl = slice(lo, lo + (1 << 19))
+            ec = pc.calc_entropy_context(pc.get_anchor[sl])
+            pc._anchor_feat[sl] = ec.mean_feat + ec.scale_feat * torch.randn(ec.mean_feat.shape, device=dev, generator=g)
+            off = ec.mean_offsets + ec.scale_offsets * torch.randn(ec.mean_offsets.shape, device=dev, generator=g)
+            pc._offset[sl] = off.view(-1, K, 3)
+            del ec, off      # (the scalings stay at their 3-NN initial values: footprints of a few pixels)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pack = conduct_stream_encoding(pc)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    target = copy.deepcopy(pc)
+    bg = torch.zeros(3)
+    mid = frames // 3      # away from z = 0: the decoded model pads its tensors to the encoder's anchor count with rows at the origin
+    fr = [cube.get_dummy_frame(i) for i in range(mid - n_render // 2, mid + n_render // 2)]
+    warm = conduct_stream_decoding(copy.deepcopy(pc), pack)              # allocator + kernel warm-up, as a player that loops
+    for _ in render_frames(fr[:4], warm, pipe, bg):
+        pass
+    del warm
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    dec = conduct_stream_decoding(target, pack)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    n = 0
+    act = 0
+    for img in render_frames(fr, dec, pipe, bg):
+        n += 1
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    from gsvc_amd.ortho_gaussian_renderer import prefilter_voxel
+    vis = int(prefilter_voxel(fr[len(fr) // 2], dec, pipe, bg).sum().item())
+    bits = pack.bits()
+    return {"workload": f"stream_decode (BASELINE.json configs[4] shape): {height}x{width}, {frames}-frame cube, {anchors} anchors x K={K}, "
+                        f"16-frame slab, {n} two-view frames rendered from the decoded model",
+            "anchors_coded": pack.n, "gaussians_generated_per_frame": vis * K, "slabs": len(pack.slabs),
+            "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t3 - t2) * 1e3, "render_ms_per_frame": (t4 - t3) * 1e3 / max(n, 1),
+            "stream_decode_fps": n / (t4 - t2), "render_fps_after_decode": n / (t4 - t3),
+            "megabytes": {k[4:]: round(v / 8 / 2 ** 20, 3) for k, v in bits.items()},
+            "render_fps_note": PAIR_NOTE}
 
 
 # ------------------------------------------------------------------------------------------------ train_step
@@ -286,6 +369,8 @@ def run_train_step(args, rank, world, dev):
         "dist_backend": (dist.get_backend() if world > 1 else None),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "note": "this kernel's binding unit is the vector ALU, not HBM: traffic_source.valu holds the SQ counters of the "
+                             "same command (share of the kernel's cycles its SIMDs spent executing vector instructions)",
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": kern[dom]["avg_us"]},
         "gsvc_kernel_us_per_step": kernel_us,
         "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] / args.steps} for k, v in kern.items()},
@@ -490,6 +575,8 @@ def run_raster(args, rank, world, dev, workload, cpu_baseline):
         "render_fps_note": PAIR_NOTE,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "note": "this kernel's binding unit is the vector ALU, not HBM: traffic_source.valu holds the SQ counters of the "
+                             "same command (share of the kernel's cycles its SIMDs spent executing vector instructions)",
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": kern[dom]["avg_us"]},
         "roofline_pipeline": {"algorithmic_bytes_per_step": pipe_bytes, "kernel_us_per_step": kernel_us,
                               "achieved": pipe_bytes / (kernel_us * 1e-6) / 1e9, "unit": "GB/s",
@@ -547,6 +634,19 @@ def main():
                 if "render_fps" in side:
                     res["render_fps"] = side["render_fps"]
                     res["render_fps_two_view"] = side["render_fps_two_view"]
+            # stream_decode fps at the BASELINE.json configs[4] shape (4K, ~2 M Gaussians per frame); same rule for failures
+            if rank == 0 and not os.environ.get("GSVC_BENCH_NO_4K"):
+                try:
+                    del side
+                    torch.cuda.empty_cache()
+                    res["stream_decode_4k"] = run_stream_decode(args, dev)
+                except Exception as e:  # noqa: BLE001
+                    res["stream_decode_4k"] = {"error": f"{type(e).__name__}: {e}"}
+    elif args.workload == "stream_decode":
+        sd = run_stream_decode(args, dev)
+        res = {"metric": "stream_decode fps (entropy decode of the whole model + two-view frames)", "value": sd["stream_decode_fps"],
+               "unit": "frames/s", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": sd["decode_ms"], "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": sd["workload"]}, **sd}
     else:
         res = run_raster(args, rank, world, dev, args.workload, cpu_baseline=cpu)
     if rank == 0:
