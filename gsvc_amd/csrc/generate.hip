@@ -116,6 +116,35 @@ __global__ void __launch_bounds__(256) k_gen_tail_bwd(const float *__restrict__ 
     }
 }
 
+// Conditioning of the generator / deformation networks for the rows of R renders (reference guassian.py:225-230 +
+// utils/time_util.py:7-55): pe[row] = [embed(cam_z of the row's render) | embed(anchor_z - cam_z)], embed(x) = [x, sin(2^0 x),
+// cos(2^0 x), ..., sin(2^(F-1) x), cos(2^(F-1) x)].  One lane per output element (coalesced store); was a dozen launches.
+struct EmbedSegs {
+    long long bound[17];      // row offsets of the renders, bound[R] = rows
+    float cam_z[16];
+};
+
+__global__ void __launch_bounds__(256) k_embed_pe(const float *__restrict__ anchor, EmbedSegs sg, int R, int F, int64_t rows,
+                                                  float *__restrict__ pe)
+{
+    const int W = 2 * F + 1;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * 2 * W) return;
+    const int64_t row = i / (2 * W);
+    const int c = (int)(i - row * 2 * W);
+    int r = 0;
+    while (r + 1 < R && row >= sg.bound[r + 1]) r++;
+    const float cz = sg.cam_z[r];
+    const float x = c < W ? cz : anchor[3 * row + 2] - cz;
+    const int cc = c < W ? c : c - W;
+    float v = x;
+    if (cc > 0) {
+        const float xf = x * (float)(1u << ((cc - 1) >> 1));
+        v = ((cc - 1) & 1) ? cosf(xf) : sinf(xf);
+    }
+    pe[i] = v;
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -161,4 +190,21 @@ extern "C" int gsvc_gen_tail_backward(const float *op_raw, const float *offset_m
                        neural_offset, scale_rot, grid_scaling, world, bd, rows, K, rpb, g_neural_opacity, g_scaling, g_rot, g_world,
                        g_xyz, d_op_raw, d_offset_mask, d_offsets, d_scale_rot, d_grid_scaling, d_anchor);
     return check_launch("gen_tail_backward");
+}
+
+extern "C" int gsvc_embed_pe(const float *anchor, const int64_t *row_bounds, const float *cam_z, int32_t renders, int32_t freqs,
+                             float *pe, void *stream)
+{
+    GSVC_REQUIRE(renders >= 1 && renders <= 16 && freqs >= 1 && freqs <= 24 && row_bounds && cam_z, "embed_pe: bad arguments");
+    gsvc::EmbedSegs sg;
+    for (int r = 0; r <= renders; r++) sg.bound[r] = row_bounds[r];
+    for (int r = 0; r < renders; r++) sg.cam_z[r] = cam_z[r];
+    const int64_t rows = row_bounds[renders];
+    if (rows == 0) return GSVC_OK;
+    GSVC_REQUIRE(anchor && pe, "embed_pe: NULL pointer");
+    const int64_t n = rows * 2 * (2 * freqs + 1);
+    gsvc::ProfScope _prof("k_embed_pe", (hipStream_t)stream);
+    hipLaunchKernelGGL(gsvc::k_embed_pe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, anchor, sg, renders,
+                       freqs, rows, pe);
+    return gsvc::check_launch("embed_pe");
 }

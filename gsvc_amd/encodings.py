@@ -36,12 +36,12 @@ class STE_binary(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         ctx.save_for_backward(x)
-        return torch.where(x >= 0, torch.ones_like(x), -torch.ones_like(x))
+        return torch.where(x >= 0, 1.0, -1.0).to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        return g * ((x >= -1) & (x <= 1)).to(g.dtype)
+        return g * (x.abs() <= 1)
 
 
 def _symbol_bounds(mean, Q):
@@ -187,6 +187,13 @@ class GridEncoder(nn.Module):
     def embeddings(self, test_phase=False, outspace_params=None):
         p = nn.Parameter(outspace_params) if outspace_params is not None else self.params
         if self.ste_binary:
+            # a fitting step reads the binarised table twice (the lookup and the hash-bit term of the loss): inside a step
+            # scope (Trainer sets ``step_cache``) the second reader gets the first one's tensor and autograd node
+            cache = getattr(self, "step_cache", None)
+            if cache is not None and outspace_params is None:
+                if "emb" not in cache:
+                    cache["emb"] = STE_binary.apply(p)
+                return cache["emb"]
             return STE_binary.apply(p)
         if self.add_noise and not test_phase:
             return p + (torch.rand_like(p) - 0.5) * (1 / self.Q)

@@ -125,33 +125,35 @@ class StepPlan:
     def __init__(self, frames, pc, visible_masks, geometry, sample: bool):
         dev = visible_masks[0].device
         A = visible_masks[0].shape[0]
-        self.frames, self.visible_masks, self.geometry, self.R = frames, visible_masks, geometry, len(visible_masks)
+        R = len(visible_masks)
+        self.frames, self.visible_masks, self.geometry, self.R = frames, visible_masks, geometry, R
         self.key = (A, id(pc._anchor), pc._anchor._version, pc._scaling._version, pc._mask._version)
-        self._idx = [torch.nonzero_static(m, size=A).squeeze(1) for m in visible_masks]
-        counts = [m.sum() for m in visible_masks]
-        present = visible_masks[0]
-        for m in visible_masks[1:]:
-            present = present | m
+        # the R views side by side: ONE scan gives every view's ranks and count, ONE compaction of the flattened [R, A] mask
+        # every view's index list (view r's list is the segment behind the r earlier views' counts, minus r * A)
+        M = torch.stack(visible_masks)                                   # [R, A] bool
+        rank = torch.cumsum(M, dim=1)                                    # inclusive: rank - 1 = position among the view's anchors
+        cnt_t = rank[:, -1]
+        starts = torch.cumsum(cnt_t, dim=0) - cnt_t
+        self._flat = torch.nonzero_static(M.view(-1), size=R * A).squeeze(1)
+        present = M.any(dim=0)
+        pos_incl = torch.cumsum(present, dim=0)
         self._distinct = torch.nonzero_static(present, size=A).squeeze(1)
-        self.pos = torch.cumsum(present, dim=0) - 1                      # anchor -> row of the distinct list
-        counts.append(present.sum())
-        self._sel = None
+        self.pos = pos_incl - 1                                          # anchor -> row of the distinct list
+        counts = [cnt_t, pos_incl[-1:]]
+        self._sel_flat = None
         if sample:
             # the rate sample in anchor space: a row is (render r, visible anchor a); its position in the concatenated rows is
             # (visible anchors of the renders before r) + (rank of a among render r's visible anchors)
             with torch.no_grad():
                 live = pc.get_mask.reshape(A, -1).sum(dim=1) > 0          # mask_anchor for every anchor
-            cnt_t = torch.stack(counts[:self.R])
-            starts = torch.cumsum(cnt_t, dim=0) - cnt_t
-            self._sel = []
-            for r, m in enumerate(visible_masks):
-                chosen = m & live & (torch.rand(A, device=dev) <= SAMPLE_RATE)
-                rank = torch.cumsum(m, dim=0) - 1
-                anchors_r = torch.nonzero_static(chosen, size=A).squeeze(1)
-                self._sel.append(starts[r] + rank.index_select(0, anchors_r.clamp_min(0)))
-                counts.append(chosen.sum())
-        self._host = torch.empty(len(counts), dtype=torch.int64, pin_memory=True)
-        self._host.copy_(torch.stack(counts), non_blocking=True)
+            chosen = M & live.unsqueeze(0) & (torch.rand(R, A, device=dev) <= SAMPLE_RATE)
+            row_of = (rank - 1 + starts.unsqueeze(1)).view(-1)            # [R * A]: row of (r, a) when a is visible in r
+            pick = torch.nonzero_static(chosen.view(-1), size=R * A).squeeze(1)       # in (r, a) order = row order
+            self._sel_flat = row_of.index_select(0, pick.clamp_min(0))
+            counts.append(chosen.sum().reshape(1))
+        self._A = A
+        self._host = torch.empty(R + 1 + (1 if sample else 0), dtype=torch.int64, pin_memory=True)
+        self._host.copy_(torch.cat(counts), non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
         self.vis_list = self.distinct = self.sel = None
@@ -165,10 +167,14 @@ class StepPlan:
         if self.vis_list is None:
             self._event.synchronize()
             n = self._host.tolist()
-            self.vis_list = [ix[:c] for ix, c in zip(self._idx, n[:self.R])]
-            self.distinct = self._distinct[:n[self.R]]
-            if self._sel is not None:
-                self.sel = torch.cat([s[:c] for s, c in zip(self._sel, n[self.R + 1:])])
+            R, A = self.R, self._A
+            self.vis_list, at = [], 0
+            for r in range(R):
+                self.vis_list.append(self._flat[at:at + n[r]] - r * A)
+                at += n[r]
+            self.distinct = self._distinct[:n[R]]
+            if self._sel_flat is not None:
+                self.sel = self._sel_flat[:n[R + 1]]
         return self
 
 
@@ -478,6 +484,30 @@ def _entropy_context_distinct(pc, anchor_all, vis, plan=None):
     return pc.calc_entropy_context(anchor_all.index_select(0, distinct)), pos.index_select(0, vis)
 
 
+def _embed_rows(pc, frames, anchor, seg):
+    """pe = [embed_time(cam z of the row's render) | embed(anchor z - cam z)] for the concatenated rows (reference
+    guassian.py:225-230).  Detached CUDA anchors with the standard embedders: one kernel (csrc/generate.hip)."""
+    et, ez = getattr(pc.embed_time_fn, "__self__", None), getattr(pc.embed_fn, "__self__", None)
+    cams = [float(f.cam_pos[-1]) for f in frames]
+    if (anchor.is_cuda and not anchor.requires_grad and seg.R <= 16 and et is not None and ez is not None
+            and all(getattr(e, "include_input", False) and getattr(e, "input_dims", 0) == 1 for e in (et, ez))
+            and et.freq_bands.numel() == ez.freq_bands.numel() <= 24
+            and all(torch.equal(e.freq_bands, 2.0 ** torch.arange(e.freq_bands.numel(), dtype=e.freq_bands.dtype)) for e in (et, ez))):
+        import ctypes as C
+        from . import _lib
+        F = int(ez.freq_bands.numel())
+        pe = torch.empty(seg.rows, 2 * (2 * F + 1), device=anchor.device, dtype=torch.float32)
+        bounds = (C.c_int64 * (seg.R + 1))(*seg.bounds)
+        cz = (C.c_float * seg.R)(*cams)
+        _lib.check(_lib.lib().gsvc_embed_pe(_lib.ptr(anchor.contiguous()), bounds, cz, seg.R, F, _lib.ptr(pe),
+                                            _lib.current_stream(anchor.device)), "gsvc_embed_pe")
+        return pe
+    cam_z = torch.tensor(cams, device=anchor.device, dtype=anchor.dtype)
+    cam_z_row = cam_z.index_select(0, seg.seg_id).unsqueeze(1)
+    ob_view = anchor[:, 2:] - cam_z_row
+    return torch.cat([pc.embed_time_fn(cam_z_row), pc.embed_fn(ob_view)], dim=1)
+
+
 def generator_trunks(pc):
     """Frame-independent half of the three generator MLPs for ALL anchors: ``linear2(GELU(linear1(anchor_feat)))``
     (reference scene/gaussian_model.py:168-196 evaluates it per render).  Valid while the parameters do not change and
@@ -546,10 +576,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         raise ValueError(f"Unknown mode {mode}")
 
     with region('gen.embed'):
-        cam_z = torch.tensor([float(f.cam_pos[-1]) for f in frames], device=dev, dtype=anchor.dtype)
-        cam_z_row = cam_z.index_select(0, seg.seg_id).unsqueeze(1)
-        ob_view = anchor[:, 2:] - cam_z_row
-        pe = torch.cat([pc.embed_time_fn(cam_z_row), pc.embed_fn(ob_view)], dim=1)
+        pe = _embed_rows(pc, frames, anchor, seg)
 
     rows = seg.rows
     with region('gen.mlps'):

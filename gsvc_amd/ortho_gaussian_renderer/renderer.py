@@ -70,7 +70,8 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
                                               anchors=None if anchor_grad else geometry[0], plan=plan)
     results = []
     for frame, visible_mask, gss in zip(frames, visible, gss_list):
-        screenspace_points = torch.zeros_like(gss.xyz, dtype=pc.get_anchor.dtype, requires_grad=True) + 0
+        # (pc._anchor.dtype: the get_anchor property re-quantises all anchors on every access)
+        screenspace_points = torch.zeros_like(gss.xyz, dtype=pc._anchor.dtype, requires_grad=True) + 0
         if retain_grad:
             try:
                 screenspace_points.retain_grad()

@@ -33,8 +33,21 @@ class StepOutput:
 
 
 def hash_grid_bits(pc):
-    """Bernoulli code length of the binarised hash tables (reference pipeline/train.py:456)."""
-    return get_binary_vxl_size_device((pc.get_encoding_params() + 1) / 2)
+    """Bernoulli code length of the binarised hash tables (reference pipeline/train.py:456:
+    ``get_binary_vxl_size((get_encoding_params() + 1) / 2)``).  The count of ones is taken table by table from the binarised
+    tables the grid lookups already made ({-1, +1}: ones = (sum + n) / 2) instead of from a 14 MB concatenation of them."""
+    tables = grid_tables(pc)
+    if not (pc.ste_binary and all(hasattr(g, "embeddings") for g in tables)):
+        return get_binary_vxl_size_device((pc.get_encoding_params() + 1) / 2)
+    total = sum(g.params.numel() for g in tables)
+    ones = (torch.stack([g.embeddings().sum() for g in tables]).sum() + total) / 2
+    p = torch.clamp(ones / total, min=1e-6, max=1 - 1e-6)
+    return ones * (-torch.log2(p)) + (total - ones) * (-torch.log2(1 - p)) + 32
+
+
+def grid_tables(pc):
+    enc = pc.encoding_xyz
+    return [enc.encoding_xyz, enc.encoding_xy, enc.encoding_xz, enc.encoding_yz] if pc.use_2D else [enc]
 
 
 def get_binary_vxl_size_device(binary_vxl):
@@ -129,6 +142,15 @@ class Trainer:
                              grad_threshold=opt.densify_grad_threshold, min_opacity=opt.min_opacity)
 
     def _step(self, iteration: int, frame_idx: int | None = None):
+        for g in grid_tables(self.pc):
+            g.step_cache = {}           # one binarisation of each hash table per step (gsvc_amd.encodings.GridEncoder.embeddings)
+        try:
+            return self._step_body(iteration, frame_idx)
+        finally:
+            for g in grid_tables(self.pc):
+                g.step_cache = None
+
+    def _step_body(self, iteration: int, frame_idx: int | None = None):
         opt, pc = self.opt, self.pc
         dev = pc.device
         pc.update_learning_rate(iteration)

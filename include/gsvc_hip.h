@@ -323,6 +323,13 @@ int gsvc_ans_decode(const uint8_t *bytes, const uint64_t *seg_offsets, const flo
                     int32_t min_symbol, int32_t max_symbol, int32_t seg_len, int32_t *symbols, int32_t *error_flag, void *scratch,
                     void *stream);
 
+/* Conditioning input of the generator / deformation MLPs for the concatenated rows of `renders` (<= 16) views (reference
+ * ortho_gaussian_renderer/guassian.py:225-230, utils/time_util.py:7-55): pe[row] = [embed(cam_z[r]) | embed(anchor[row].z -
+ * cam_z[r])] for the rows row_bounds[r] <= row < row_bounds[r + 1]; embed(x) = [x, sin(2^k x), cos(2^k x)]_{k < freqs}.
+ * anchor: [rows, 3]; pe: [rows, 2 * (2 * freqs + 1)].  row_bounds / cam_z are host arrays. */
+int gsvc_embed_pe(const float *anchor, const int64_t *row_bounds, const float *cam_z, int32_t renders, int32_t freqs, float *pe,
+                  void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Linear layers of the generator / deformation / entropy-parameter MLPs (reference scene/gaussian_model.py:
  * 150-232: every nn.Linear applied to the [anchors, features] matrix)

@@ -97,3 +97,29 @@ def test_chain_falls_back_for_small_batches_and_cpu():
     net = net.cuda()
     y = net(torch.randn(8, 50, device="cuda"), torch.randn(8, 66, device="cuda"))
     assert "Generator" not in type(y.grad_fn).__name__
+
+
+def test_fused_positional_embedding_matches_the_embedders():
+    """csrc/generate.hip k_embed_pe against the module-level expression (reference guassian.py:225-230 + utils/time_util.py)."""
+    from types import SimpleNamespace
+    from gsvc_amd.generate import _Segments, _embed_rows
+    from gsvc_amd.time_util import get_embedder
+    dev = torch.device("cuda")
+    et, _ = get_embedder(16, 1)
+    ez, _ = get_embedder(16, 1)
+    pc = SimpleNamespace(embed_time_fn=et, embed_fn=ez)
+    counts = [5000, 0, 4097, 3]
+    seg = _Segments(counts, dev)
+    torch.manual_seed(1)
+    anchor = (torch.rand(sum(counts), 3, device=dev) - 0.5) * 0.4
+    cams = [-0.031, 0.0, 0.0125, 0.2]
+    frames = [SimpleNamespace(cam_pos=torch.tensor([0.0, 0.0, c])) for c in cams]
+    got = _embed_rows(pc, frames, anchor, seg)
+    cam_row = torch.tensor(cams, device=dev).index_select(0, seg.seg_id).unsqueeze(1)
+    want = torch.cat([et(cam_row), ez(anchor[:, 2:] - cam_row)], dim=1)
+    assert got.shape == want.shape == (sum(counts), 66)
+    # same float32 arguments into sin / cos on both sides
+    assert (got - want).abs().max().item() <= 1e-6
+    # anchors that carry a gradient keep the differentiable path
+    a2 = anchor.clone().requires_grad_(True)
+    assert _embed_rows(pc, frames, a2, seg).requires_grad

@@ -1,0 +1,52 @@
+"""Diagnostic: device time of the PyTorch (non-gsvc) operators of one fitting step, grouped by the gsvc_amd source line that
+dispatched them (forward) or by autograd node (backward)."""
+import os, sys
+from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from torch.profiler import profile, ProfilerActivity
+from gsvc_amd.arguments import cfg_20240919
+from gsvc_amd.frame import SyntheticFrameCube
+from gsvc_amd.model import GaussianModel
+from gsvc_amd.train import Trainer
+dev = torch.device("cuda")
+mp_, opt, pipe = cfg_20240919()
+cube = SyntheticFrameCube(1080, 1920, 64, device=dev).materialize()
+mp_.threshold = 8.0 / cube.scale
+opt.full_precision_training_total = opt.quantized_training_total = 0
+opt.entropy_constrained_train_total = 10 ** 9
+opt.start_stat, opt.update_until, opt.pause_densification = 0, 10 ** 9, 0
+pc = GaussianModel(mp_, 50, 10, 0.001, 3, 16, 4, False, n_features_per_level=8, log2_hashmap_size=13, log2_hashmap_size_2D=15, device=dev)
+rng = np.random.default_rng(0)
+lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
+pc.create_from_points(rng.uniform(lim, -lim, (245000, 3)), 1.0)
+pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+pc.training_setup(opt)
+tr = Trainer(pc, cube, opt, pipe, mp_)
+for i in range(30):
+    tr.step(i + 1)
+torch.cuda.synchronize()
+N = 3
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
+    for i in range(N):
+        tr.step(40 + i)
+    torch.cuda.synchronize()
+by = defaultdict(lambda: [0.0, 0])
+tot = 0.0
+for ev in prof.events():
+    if not ev.name.startswith("aten::") or ev.self_device_time_total <= 0:
+        continue
+    fr = [f for f in ev.stack if "gsvc_amd" in f and "torch/" not in f]
+    where = fr[0].split("gsvc_amd/")[-1].split(":")[0].strip() if fr else "(autograd engine)"
+    k = (where, ev.name)
+    by[k][0] += ev.self_device_time_total
+    by[k][1] += 1
+    tot += ev.self_device_time_total
+print(f"aten device time per step: {tot / N / 1e3:.2f} ms")
+line = defaultdict(float)
+for (w, n), (t, c) in by.items():
+    line[w] += t
+for w, t in sorted(line.items(), key=lambda kv: -kv[1])[:45]:
+    ops = sorted(((n, tt, c) for (ww, n), (tt, c) in by.items() if ww == w), key=lambda x: -x[1])[:5]
+    print(f"{t / N:8.1f} us  {w:34s} " + ", ".join(f"{n[6:]} {tt / N:.0f}us x{c // N}" for n, tt, c in ops))
