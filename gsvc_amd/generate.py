@@ -131,9 +131,11 @@ class StepPlan:
         # the R views side by side: ONE scan gives every view's ranks and count, ONE compaction of the flattened [R, A] mask
         # every view's index list (view r's list is the segment behind the r earlier views' counts, minus r * A)
         M = torch.stack(visible_masks)                                   # [R, A] bool
-        rank = torch.cumsum(M, dim=1)                                    # inclusive: rank - 1 = position among the view's anchors
-        cnt_t = rank[:, -1]
-        starts = torch.cumsum(cnt_t, dim=0) - cnt_t
+        # scan of the FLATTENED mask (a 1-D scan is one fast pass; a [R, A] scan along dim 1 runs row by row): c - 1 is the
+        # row of (r, a) in the concatenated rows, the view boundaries give the counts
+        c = torch.cumsum(M.view(-1), dim=0)
+        ends = c[A - 1::A]
+        cnt_t = torch.diff(ends, prepend=ends.new_zeros(1))
         self._flat = torch.nonzero_static(M.view(-1), size=R * A).squeeze(1)
         present = M.any(dim=0)
         pos_incl = torch.cumsum(present, dim=0)
@@ -147,9 +149,8 @@ class StepPlan:
             with torch.no_grad():
                 live = pc.get_mask.reshape(A, -1).sum(dim=1) > 0          # mask_anchor for every anchor
             chosen = M & live.unsqueeze(0) & (torch.rand(R, A, device=dev) <= SAMPLE_RATE)
-            row_of = (rank - 1 + starts.unsqueeze(1)).view(-1)            # [R * A]: row of (r, a) when a is visible in r
             pick = torch.nonzero_static(chosen.view(-1), size=R * A).squeeze(1)       # in (r, a) order = row order
-            self._sel_flat = row_of.index_select(0, pick.clamp_min(0))
+            self._sel_flat = c.index_select(0, pick.clamp_min(0)) - 1
             counts.append(chosen.sum().reshape(1))
         self._A = A
         self._host = torch.empty(R + 1 + (1 if sample else 0), dtype=torch.int64, pin_memory=True)
