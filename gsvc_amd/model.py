@@ -651,6 +651,29 @@ class GaussianModel(nn.Module):
 
     # ------------------------------------------------------------------ densification statistics (:1281-1314)
     @torch.no_grad()
+    def training_statis_many(self, renders):
+        """``training_statis`` of the un-compacted renders of one step in one pass: the accumulators are sums over renders,
+        so the rows of all renders are concatenated and scattered with ONE index_add per accumulator (instead of four)."""
+        if not renders or not all(r.dense for r in renders):
+            for r in renders:
+                self.training_statis(r)
+            return
+        K, A = self.n_offsets, self.opacity_accum.shape[0]
+        batch = getattr(renders[0].generated_gaussians, "batch", None)
+        if batch is not None and len(renders) > 1 and getattr(batch, "vis", None) is not None:
+            vi, op_all = batch.vis, batch.neural_opacity
+        else:
+            vi, op_all = torch.cat([r.visible_index for r in renders]), torch.cat([r.neural_opacity for r in renders])
+        op = op_all.detach().view(-1).clamp_min(0).view(-1, K)
+        self.opacity_accum.index_add_(0, vi, op.sum(dim=1, keepdim=True))
+        self.anchor_demon.index_add_(0, vi, torch.ones(vi.shape[0], 1, device=vi.device, dtype=self.anchor_demon.dtype))
+        w = torch.cat([r.visibility_filter for r in renders]).to(self.offset_denom.dtype).view(-1, K)
+        g2 = torch.cat([r.viewspace_points.grad[:, :2] for r in renders])
+        gn = torch.norm(g2, dim=-1).view(-1, K) * w
+        self.offset_gradient_accum.view(A, K).index_add_(0, vi, gn.to(self.offset_gradient_accum.dtype))
+        self.offset_denom.view(A, K).index_add_(0, vi, w)
+
+    @torch.no_grad()
     def training_statis(self, render_results):
         """Accumulate, through the nested masks visible anchor -> opacity>0 -> radius>0: per-anchor positive
         opacity sums and visit counts, per-offset screen-gradient norms and counts."""

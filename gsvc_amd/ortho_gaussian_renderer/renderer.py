@@ -70,21 +70,19 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
                                               anchors=None if anchor_grad else geometry[0], plan=plan)
     results = []
     for frame, visible_mask, gss in zip(frames, visible, gss_list):
-        # (pc._anchor.dtype: the get_anchor property re-quantises all anchors on every access)
-        screenspace_points = torch.zeros_like(gss.xyz, dtype=pc._anchor.dtype, requires_grad=True) + 0
-        if retain_grad:
-            try:
-                screenspace_points.retain_grad()
-            except Exception:
-                pass
+        # the tensor whose .grad receives the screen-space gradient: a leaf (the reference's ``zeros_like(...) + 0`` with
+        # retain_grad() holds the same numbers through two more kernels); pc._anchor.dtype, not pc.get_anchor.dtype — the
+        # property re-quantises all anchors on every access
+        screenspace_points = torch.zeros(gss.xyz.shape, dtype=pc._anchor.dtype, device=gss.xyz.device, requires_grad=True)
         rasterizer = GaussianRasterizer(raster_settings=raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier))
         rasterizer.deferred = dense
         rendered_image, radii, num_rendered = rasterizer(
             means3D=gss.xyz, means2D=screenspace_points, shs=None, colors_precomp=gss.color, opacities=gss.opacity,
             scales=gss.scaling, rotations=gss.rot, cov3D_precomp=None)
+        seen = radii > 0
         results.append(RenderResults(
-            rendered_image=rendered_image, viewspace_points=screenspace_points, visibility_filter=radii > 0,
-            visible_mask=visible_mask, radii=radii, active_gaussains=(radii > 0).sum(),
+            rendered_image=rendered_image, viewspace_points=screenspace_points, visibility_filter=seen,
+            visible_mask=visible_mask, radii=radii, active_gaussains=seen.sum(),
             num_rendered=None if dense else num_rendered,
             selection_mask=gss.mask, neural_opacity=gss.neural_opacity, scaling=gss.scaling,
             bit_per_param=gss.bit_per_param, bit_per_feat_param=gss.bit_per_feat_param,

@@ -222,8 +222,11 @@ class Trainer:
                 r.num_rendered = r.raster_state.counters()[0]
         with torch.no_grad():
             if self.controller.gaussian_statis:
-                for r in renders:
-                    pc.training_statis(r)
+                if self.batched:
+                    pc.training_statis_many(renders)
+                else:
+                    for r in renders:
+                        pc.training_statis(r)
             if self.controller.gaussian_adjust_anchor:
                 self._adjust_anchor(iteration)
             if self.controller.clean_denorm:
