@@ -48,6 +48,12 @@ class WgradReduceJobC(C.Structure):
                 ("K", C.c_int32)]
 
 
+class RateSampleC(C.Structure):
+    _fields_ = [("x", C.c_void_p * 3), ("mean", C.c_void_p * 3), ("scale", C.c_void_p * 3), ("Q", C.c_void_p * 3),
+                ("mask", C.c_void_p), ("sel", C.c_void_p), ("sel_ctx", C.c_void_p), ("row_bounds", C.POINTER(C.c_int64)),
+                ("x_mean", C.c_void_p), ("C", C.c_int32 * 3), ("K", C.c_int32), ("renders", C.c_int32), ("n_sel", C.c_int64)]
+
+
 class RasterSizesC(C.Structure):
     _fields_ = [("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)]
 
@@ -102,6 +108,10 @@ _SIGNATURES = {
     "gsvc_linear_wgrad_partial": (C.c_int, [_vp, _vp, C.c_int32, _i64, C.c_int32, C.c_int32, _vp, _i64, C.POINTER(C.c_int32), _vp]),
     "gsvc_linear_wgrad_reduce_many": (C.c_int, [C.POINTER(WgradReduceJobC), C.c_int32, _vp]),
     "gsvc_linear_wgrad_workspace": (_i64, [C.c_int32, C.c_int32]),
+    "gsvc_rate_sample_scratch_floats": (_i64, [_i64]),
+    "gsvc_rate_sample_forward": (C.c_int, [C.POINTER(RateSampleC), _vp, _vp, _vp]),
+    "gsvc_rate_sample_backward": (C.c_int, [C.POINTER(RateSampleC), _vp, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, _vp]),
     "gsvc_rate_backward": (C.c_int, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_int32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -112,6 +112,150 @@ __global__ void __launch_bounds__(256) k_rate_bwd(const float *__restrict__ x, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Sampled rate of the R renders of a fitting step (reference ortho_gaussian_renderer/guassian.py:73-132, per render): the 5 %
+// sample's rows are gathered, priced and summed per render and attribute group in one launch; the backward scatters straight
+// into the dense gradients of the gathered-from tensors.  Was ~45 PyTorch launches each way around three k_rate launches.
+//   group g in {feature, scaling, offsets}: x_g [rows, C_g], step Q_g [rows], model mean_g / scale_g [ctx rows, C_g];
+//   selected row i: s = sel[i] (row of x / Q / mask), e = sel_ctx[i] (row of mean / scale), render r = segment of s;
+//   clamp: x_mean_g -+ 15000 * (mean of Q_g over the selected rows of render r); offsets weighted by mask[s, col / 3].
+constexpr int RS_MAX_R = 16;
+
+struct RateSampleArgs {
+    const float *x[3], *mean[3], *scale[3], *Q[3];
+    const float *mask;              // [rows, K] (offset masks), weight of group 2
+    const long long *sel, *sel_ctx;
+    const float *x_mean;            // device, 3 floats: mean of the whole parameter tensor behind each group
+    int C[3];
+    long long bound[RS_MAX_R + 1];  // row offsets of the renders
+    long long n_sel;
+    int R;
+};
+
+__device__ __forceinline__ int rs_render_of(const RateSampleArgs &a, long long row)
+{
+    int r = 0;
+    while (r + 1 < a.R && row >= a.bound[r + 1]) r++;
+    return r;
+}
+
+// stats[r][0..2] = sum of Q_g over the selected rows of render r, stats[r][3] = their count (one workgroup, fixed order)
+__global__ void __launch_bounds__(256) k_rate_sample_stats(RateSampleArgs a, float *__restrict__ stats)
+{
+    __shared__ float sm[4][RS_MAX_R][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[RS_MAX_R][4];
+#pragma unroll
+    for (int r = 0; r < RS_MAX_R; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[r][j] = 0.f;
+    for (long long i = threadIdx.x; i < a.n_sel; i += 256) {
+        const long long srow = a.sel[i];
+        const int r = rs_render_of(a, srow);
+        const float q0 = a.Q[0][srow], q1 = a.Q[1][srow], q2 = a.Q[2][srow];
+#pragma unroll
+        for (int rr = 0; rr < RS_MAX_R; rr++)
+            if (rr == r) { acc[rr][0] += q0; acc[rr][1] += q1; acc[rr][2] += q2; acc[rr][3] += 1.f; }
+    }
+    for (int r = 0; r < a.R; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v = acc[r][j];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) sm[wave][r][j] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < a.R * 4) {
+        const int r = threadIdx.x >> 2, j = threadIdx.x & 3;
+        stats[r * 4 + j] = (sm[0][r][j] + sm[1][r][j]) + (sm[2][r][j] + sm[3][r][j]);
+    }
+}
+
+// MODE 0: forward — per-block partial sums of weight * bits per (group, render) -> part[block][3][R]
+// MODE 1: backward — gS[r][g] = dL/d(sum of render r, group g); dx / dQ rows stored (selected rows are distinct), dmean /
+//         dscale / dmask added atomically (several selected rows may share a context row) into zero-filled dense tensors
+template <int MODE>
+__global__ void __launch_bounds__(256) k_rate_sample(RateSampleArgs a, const float *__restrict__ stats, float *__restrict__ part,
+                                                     const float *__restrict__ gS, float *const dx0, float *const dx1, float *const dx2,
+                                                     float *const dm0, float *const dm1, float *const dm2, float *const ds0,
+                                                     float *const ds1, float *const ds2, float *const dq0, float *const dq1,
+                                                     float *const dq2, float *__restrict__ dmask, int K)
+{
+    __shared__ float sacc[3][RS_MAX_R];
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.y;
+    if (MODE == 0) {
+        if (threadIdx.x < 3 * RS_MAX_R) (&sacc[0][0])[threadIdx.x] = 0.f;
+        __syncthreads();
+    }
+    const int C = a.C[g];
+    const float *__restrict__ X = a.x[g], *__restrict__ MU = a.mean[g], *__restrict__ SG = a.scale[g], *__restrict__ QQ = a.Q[g];
+    float *const DX = g == 0 ? dx0 : (g == 1 ? dx1 : dx2), *const DM = g == 0 ? dm0 : (g == 1 ? dm1 : dm2);
+    float *const DS = g == 0 ? ds0 : (g == 1 ? ds1 : ds2), *const DQ = g == 0 ? dq0 : (g == 1 ? dq1 : dq2);
+    const long long wave_global = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * 256) >> 6;
+    for (long long i = wave_global; i < a.n_sel; i += n_waves) {
+        const long long srow = a.sel[i], erow = a.sel_ctx ? a.sel_ctx[i] : srow;
+        const int r = rs_render_of(a, srow);
+        const float q = QQ[srow];
+        const float qm = stats[r * 4 + g] / fmaxf(stats[r * 4 + 3], 1.f);
+        const float xm = a.x_mean[g];
+        const float lo = xm - 15000.f * qm, hi = xm + 15000.f * qm;
+        const float gs = MODE == 1 ? gS[r * 3 + g] : 0.f;
+        float row_acc = 0.f, dq_acc = 0.f;
+        for (int col = lane; col < C; col += 64) {
+            const float xr = X[srow * C + col];
+            const float xv = fminf(fmaxf(xr, lo), hi);
+            const float mu = MU[erow * C + col], sigma = SG[erow * C + col], inv_sigma = 1.0f / sigma;
+            const float zl = (xv - 0.5f * q - mu) * inv_sigma, zu = (xv + 0.5f * q - mu) * inv_sigma;
+            const float lower = 0.5f * (1.0f + erff(zl * INV_SQRT2));
+            const float upper = 0.5f * (1.0f + erff(zu * INV_SQRT2));
+            const float lik_raw = upper - lower;
+            const float lik = fmaxf(lik_raw, LOW_BOUND);
+            const float w = (g == 2 && a.mask) ? a.mask[srow * K + col / 3] : 1.0f;
+            const float b = -log2f(lik);
+            if (MODE == 0) {
+                row_acc += b * w;
+            } else {
+                const float dl = (lik_raw >= LOW_BOUND) ? (-INV_LN2 / lik) * w * gs : 0.0f;
+                const float pl = __expf(-0.5f * zl * zl) * INV_SQRT_2PI * inv_sigma;
+                const float pu = __expf(-0.5f * zu * zu) * INV_SQRT_2PI * inv_sigma;
+                const float dlik_dx = pu - pl;
+                if (DX) DX[srow * C + col] = (xr >= lo && xr <= hi) ? dl * dlik_dx : 0.0f;
+                if (DM) atomicAdd(DM + erow * C + col, -dl * dlik_dx);
+                if (DS) atomicAdd(DS + erow * C + col, -dl * (zu * pu - zl * pl));
+                if (g == 2 && dmask && a.mask) atomicAdd(dmask + srow * K + col / 3, b * gs);
+                dq_acc += dl * 0.5f * (pu + pl);
+            }
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) row_acc += __shfl_xor(row_acc, m, 64);
+            if (lane == 0) atomicAdd(&sacc[g][r], row_acc);
+        } else if (DQ) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) dq_acc += __shfl_xor(dq_acc, m, 64);
+            if (lane == 0) DQ[srow] = dq_acc;
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        if (threadIdx.x < a.R) part[((size_t)blockIdx.x * 3 + g) * RS_MAX_R + threadIdx.x] = sacc[g][threadIdx.x];
+    }
+}
+
+// S[r][g] = sum over the blocks' partial sums, in block order
+__global__ void __launch_bounds__(64) k_rate_sample_finalize(const float *__restrict__ part, int blocks, int R, float *__restrict__ S)
+{
+    const int t = threadIdx.x;
+    if (t >= 3 * R) return;
+    const int g = t / R, r = t - g * R;
+    float acc = 0.f;
+    for (int b = 0; b < blocks; b++) acc += part[((size_t)b * 3 + g) * RS_MAX_R + r];
+    S[r * 3 + g] = acc;
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -144,4 +288,62 @@ extern "C" int gsvc_rate_backward(const float *x, const float *mean, const float
     { ProfScope _prof("k_rate_bwd", (hipStream_t)stream); hipLaunchKernelGGL(k_rate_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, scale, Q, Q_scalar,
                        weight, x_lo, x_hi, (int)bounds_per_row, (long long)n, (int)c, gscale_dev, dx, dmean, dscale, dQ, dweight); }
     return check_launch("rate_backward");
+}
+
+static int rate_sample_args(gsvc::RateSampleArgs &a, const gsvc_rate_sample *d, const char *what)
+{
+    GSVC_REQUIRE(d && d->renders >= 1 && d->renders <= gsvc::RS_MAX_R && d->n_sel >= 0 && d->row_bounds, "%s: bad arguments", what);
+    for (int g = 0; g < 3; g++) {
+        GSVC_REQUIRE(d->x[g] && d->mean[g] && d->scale[g] && d->Q[g] && d->C[g] > 0, "%s: NULL input (group %d)", what, g);
+        a.x[g] = d->x[g]; a.mean[g] = d->mean[g]; a.scale[g] = d->scale[g]; a.Q[g] = d->Q[g];
+        a.C[g] = d->C[g];
+    }
+    GSVC_REQUIRE(!d->mask || (d->K > 0 && d->C[2] == 3 * d->K), "%s: the offsets group must have 3 * K columns", what);
+    GSVC_REQUIRE(d->x_mean, "%s: x_mean is NULL", what);
+    a.x_mean = d->x_mean;
+    a.mask = d->mask; a.sel = (const long long *)d->sel; a.sel_ctx = (const long long *)d->sel_ctx;
+    for (int r = 0; r <= d->renders; r++) a.bound[r] = d->row_bounds[r];
+    a.n_sel = d->n_sel; a.R = d->renders;
+    return GSVC_OK;
+}
+
+extern "C" int64_t gsvc_rate_sample_scratch_floats(int64_t n_sel)
+{
+    long long blocks = (n_sel + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return 64 + blocks * 3 * gsvc::RS_MAX_R;
+}
+
+extern "C" int gsvc_rate_sample_forward(const gsvc_rate_sample *d, float *scratch, float *S, void *stream)
+{
+    gsvc::RateSampleArgs a;
+    if (int rc = rate_sample_args(a, d, "rate_sample_forward")) return rc;
+    GSVC_REQUIRE(scratch && S && (d->n_sel == 0 || d->sel), "rate_sample_forward: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    long long blocks = (d->n_sel + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    gsvc::ProfScope _prof("k_rate_sample", s);
+    hipLaunchKernelGGL(gsvc::k_rate_sample_stats, dim3(1), dim3(256), 0, s, a, scratch);
+    hipLaunchKernelGGL(gsvc::k_rate_sample<0>, dim3((unsigned)blocks, 3), dim3(256), 0, s, a, scratch, scratch + 64, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d->K);
+    hipLaunchKernelGGL(gsvc::k_rate_sample_finalize, dim3(1), dim3(64), 0, s, scratch + 64, (int)blocks, d->renders, S);
+    return gsvc::check_launch("rate_sample_forward");
+}
+
+extern "C" int gsvc_rate_sample_backward(const gsvc_rate_sample *d, const float *scratch, const float *gS, float *const *dx,
+                                         float *const *dmean, float *const *dscale, float *const *dQ, float *dmask, void *stream)
+{
+    gsvc::RateSampleArgs a;
+    if (int rc = rate_sample_args(a, d, "rate_sample_backward")) return rc;
+    GSVC_REQUIRE(scratch && gS && dx && dmean && dscale && dQ, "rate_sample_backward: NULL pointer");
+    if (d->n_sel == 0) return GSVC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    long long blocks = (d->n_sel + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    gsvc::ProfScope _prof("k_rate_sample_bwd", s);
+    hipLaunchKernelGGL(gsvc::k_rate_sample<1>, dim3((unsigned)blocks, 3), dim3(256), 0, s, a, scratch, nullptr, gS, dx[0], dx[1], dx[2],
+                       dmean[0], dmean[1], dmean[2], dscale[0], dscale[1], dscale[2], dQ[0], dQ[1], dQ[2], dmask, d->K);
+    return gsvc::check_launch("rate_sample_backward");
 }

@@ -12,6 +12,7 @@ re-evaluates over all anchors several times per call are evaluated once.
 """
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import dataclass
 from enum import Enum
@@ -416,6 +417,69 @@ def _seg_ste(x, Q, seg, x_mean):
     return (x + (torch.round(x / Q) * Q - x).detach()).detach()
 
 
+class _SampledRate(torch.autograd.Function):
+    """S[R, 3]: bits of the sampled rows' features / scalings / offsets summed per render (csrc/rate.hip k_rate_sample): gathers
+    by row index, per-render clamp bounds, the offset mask and the per-render sums in one launch; the backward writes straight
+    into dense gradients of the tensors the rows were gathered from."""
+
+    @staticmethod
+    def forward(ctx, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, mean_f, scale_f, mean_s, scale_s,
+                mean_o, scale_o, sel, sel_ctx, x_mean, bounds, K):
+        import ctypes as C
+        from . import _lib
+        dev = feat.device
+        xs = [feat.contiguous(), grid_scaling.contiguous(), grid_offsets.contiguous().view(grid_offsets.shape[0], -1)]
+        means = [mean_f.contiguous(), mean_s.contiguous(), mean_o.contiguous()]
+        scales = [scale_f.contiguous(), scale_s.contiguous(), scale_o.contiguous()]
+        Qs = [Q_feat.contiguous().view(-1), Q_scaling.contiguous().view(-1), Q_offsets.contiguous().view(-1)]
+        mask = offset_masks.contiguous().view(offset_masks.shape[0], -1)
+        sel = sel.contiguous()
+        sel_ctx = sel_ctx.contiguous() if sel_ctx is not None else None
+        R = len(bounds) - 1
+        d = _lib.RateSampleC()
+        for g in range(3):
+            d.x[g], d.mean[g], d.scale[g], d.Q[g] = xs[g].data_ptr(), means[g].data_ptr(), scales[g].data_ptr(), Qs[g].data_ptr()
+            d.C[g] = int(xs[g].shape[1])
+        x_mean = x_mean.contiguous()
+        d.x_mean = x_mean.data_ptr()
+        d.mask, d.sel = mask.data_ptr(), sel.data_ptr() if sel.numel() else None
+        d.sel_ctx = sel_ctx.data_ptr() if (sel_ctx is not None and sel_ctx.numel()) else None
+        rb = (C.c_int64 * (R + 1))(*[int(b) for b in bounds])
+        d.row_bounds, d.K, d.renders, d.n_sel = rb, int(K), R, int(sel.shape[0])
+        L = _lib.lib()
+        scratch = torch.empty(int(L.gsvc_rate_sample_scratch_floats(d.n_sel)), device=dev, dtype=torch.float32)
+        S = torch.empty(R, 3, device=dev, dtype=torch.float32)
+        _lib.check(L.gsvc_rate_sample_forward(C.byref(d), _lib.ptr(scratch), _lib.ptr(S), _lib.current_stream(dev)),
+                   "gsvc_rate_sample_forward")
+        ctx.save_for_backward(*xs, *means, *scales, *Qs, mask, sel, sel_ctx if sel_ctx is not None else sel, scratch, x_mean)
+        ctx.desc, ctx.rb, ctx.has_ctx = d, rb, sel_ctx is not None
+        ctx.shapes = (grid_offsets.shape, offset_masks.shape, Q_feat.shape, Q_scaling.shape, Q_offsets.shape)
+        return S
+
+    @staticmethod
+    def backward(ctx, gS):
+        import ctypes as C
+        from . import _lib
+        t = ctx.saved_tensors
+        xs, means, scales, Qs, mask, scratch = t[0:3], t[3:6], t[6:9], t[9:12], t[12], t[15]
+        dev = mask.device
+        need = ctx.needs_input_grad
+        z = torch.zeros_like
+        dx = [z(xs[g]) if need[g] else None for g in range(3)]
+        dmask = z(mask) if need[3] else None
+        dQ = [z(Qs[g]) if need[4 + g] else None for g in range(3)]
+        dmean = [z(means[g]) if need[7 + 2 * g] else None for g in range(3)]
+        dscale = [z(scales[g]) if need[8 + 2 * g] else None for g in range(3)]
+        arr = lambda ts: (C.c_void_p * 3)(*[x.data_ptr() if x is not None else None for x in ts])  # noqa: E731
+        _lib.check(_lib.lib().gsvc_rate_sample_backward(C.byref(ctx.desc), _lib.ptr(scratch), _lib.ptr(gS.contiguous()), arr(dx),
+                                                        arr(dmean), arr(dscale), arr(dQ), _lib.ptr(dmask),
+                                                        _lib.current_stream(dev)), "gsvc_rate_sample_backward")
+        go_shape, m_shape, qf, qs, qo = ctx.shapes
+        v = lambda x, sh: x.view(sh) if x is not None else None  # noqa: E731
+        return (dx[0], dx[1], v(dx[2], go_shape), v(dmask, m_shape), v(dQ[0], qf), v(dQ[1], qs), v(dQ[2], qo),
+                dmean[0], dscale[0], dmean[1], dscale[1], dmean[2], dscale[2], None, None, None, None, None)
+
+
 def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row=None, sel=None):
     """Sampled rate of the R renders of a batch (reference guassian.py:73-132 per render): 5 % of the visible anchors that have
     a live offset, bits of their features / scalings / offsets under the entropy context, four normalised means per render.
@@ -436,6 +500,20 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
         sel_seg = seg.seg_id.index_select(0, sel)
         n_sel = torch.zeros(R, device=dev).index_add_(0, sel_seg, torch.ones_like(sel_seg, dtype=torch.float32))
     sel_ec = sel if ec_row is None else ec_row.index_select(0, sel)
+    if (feat.is_cuda and R <= 16 and all(isinstance(q, torch.Tensor) and q.numel() == feat.shape[0] for q in (Q_feat, Q_scaling, Q_offsets))
+            and not os.environ.get("GSVC_NO_FUSED_RATE")):
+        # fused path (csrc/rate.hip k_rate_sample): gathers, per-render clamp bounds, offset mask and per-render sums in one launch
+        with torch.no_grad():
+            xm = torch.stack([pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()]).float()
+        S = _SampledRate.apply(feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec.mean_feat, ec.scale_feat,
+                               ec.mean_scaling, ec.scale_scaling, ec.mean_offsets, ec.scale_offsets, sel,
+                               None if ec_row is None else sel_ec, xm, seg.bounds, K)
+        dims = torch.tensor([float(feat.shape[1]), float(grid_scaling.shape[1]), float(3 * K)], device=dev)
+        N = n_sel.unsqueeze(1) * dims
+        per = S / N * kr.unsqueeze(1)
+        tot = S.sum(dim=1) / N.sum(dim=1) * kr
+        return [RatePack(bit_per_param=tot[r], bit_per_feat_param=per[r, 0], bit_per_scaling_param=per[r, 1],
+                         bit_per_offsets_param=per[r, 2]) for r in range(R)]
     # steps of the chosen rows, the three groups side by side; clamp bounds = x_mean -+ 15000 * (mean step of the row's render)
     Q3 = torch.cat([Q_feat.reshape(-1, 1), Q_scaling.reshape(-1, 1), Q_offsets.reshape(-1, 1)], dim=1).index_select(0, sel)
     Q3T = Q3.t().contiguous()                                                     # [3, n_sel]: one contiguous row per group

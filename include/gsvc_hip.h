@@ -187,6 +187,28 @@ int gsvc_rate_backward(const float *x, const float *mean, const float *scale, co
                        int64_t c, const float *gscale_dev, float *dx, float *dmean, float *dscale, float *dQ, float *dweight,
                        void *stream);
 
+/* Sampled rate of the R (<= 16) renders of a fitting step in one pass (reference ortho_gaussian_renderer/guassian.py:73-132,
+ * evaluated per render there): the n_sel selected rows (sel: row of x / Q / mask; sel_ctx: row of mean / scale, NULL = sel)
+ * are gathered, clamped to x_mean[g] (a device array) -+ 15000 * (mean of Q[g] over the selected rows of the row's render), priced as in
+ * gsvc_rate_forward and summed per render and group: S[r][g], g = 0 feature, 1 scaling, 2 offsets (weighted by
+ * mask[row][col / 3] when mask != NULL).  row_bounds[renders + 1] (host): row offsets of the renders.
+ * scratch: gsvc_rate_sample_scratch_floats(n_sel) floats; the forward leaves the per-render step statistics there and the
+ * backward reads them.  Backward: gS[r][g] = dL/dS; dx[g] / dQ[g] rows are STORED (selected rows are distinct), dmean[g] /
+ * dscale[g] / dmask are ADDED (rows of the context may repeat): all of them dense, zero-filled by the caller. */
+typedef struct gsvc_rate_sample {
+    const float *x[3], *mean[3], *scale[3], *Q[3];
+    const float *mask;
+    const int64_t *sel, *sel_ctx, *row_bounds;
+    const float *x_mean;            /* device, 3 floats */
+    int32_t C[3];
+    int32_t K, renders;
+    int64_t n_sel;
+} gsvc_rate_sample;
+int64_t gsvc_rate_sample_scratch_floats(int64_t n_sel);
+int gsvc_rate_sample_forward(const gsvc_rate_sample *desc, float *scratch, float *S, void *stream);
+int gsvc_rate_sample_backward(const gsvc_rate_sample *desc, const float *scratch, const float *gS, float *const *dx,
+                              float *const *dmean, float *const *dscale, float *const *dQ, float *dmask, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Image distortion of the fitting step (replaces utils/loss_utils.py l1_loss_func + ssim_func and their autograd)
  * ---------------------------------------------------------------------------------------------------- */

@@ -400,3 +400,65 @@ def test_knn3_mean_dist2_matches_brute_force(n, shape):
         k = min(3, n - 1)
         ref[s:s + 2048] = np.sort(d, 1)[:, :k].mean(1) if k > 0 else 0.0
     assert np.allclose(got, ref, rtol=2e-5, atol=1e-12), np.abs(got - ref).max()
+
+
+@pytest.mark.gpu
+def test_fused_sampled_rate_matches_the_tensor_path(monkeypatch):
+    """k_rate_sample (gathers + per-render clamp bounds + offset mask + per-render sums in one launch, dense-gradient scatter in
+    backward) against the same quantities computed with index_select / _GaussianBits / index_add: the four rates of every render
+    and the gradient of every input."""
+    from gsvc_amd.generate import _Segments, _rate_many
+    from gsvc_amd.model import EntropyContext
+    dev = torch.device("cuda")
+    torch.manual_seed(7)
+    K, F = 10, 50
+    counts = [3000, 2500, 0, 3100]
+    M, D = sum(counts), 4000
+    seg = _Segments(counts, dev)
+    pc = SimpleNamespace(n_offsets=K, _anchor_feat=torch.randn(9000, F, device=dev), get_scaling=torch.rand(9000, 6, device=dev) * 0.01,
+                         _offset=torch.randn(9000, K, 3, device=dev) * 0.1)
+
+    def leaf(*shape, scale=1.0, shift=0.0):
+        return (torch.randn(*shape, device=dev) * scale + shift).requires_grad_(True)
+
+    def make():
+        torch.manual_seed(11)
+        t = dict(feat=leaf(M, F, scale=2.0), gs=leaf(M, 6, scale=0.004, shift=0.01), go=leaf(M, K, 3, scale=0.3),
+                 om=(torch.rand(M, K, 1, device=dev) > 0.3).float().requires_grad_(True),
+                 qf=(torch.rand(M, 1, device=dev) * 0.5 + 0.75).requires_grad_(True),
+                 qs=(torch.rand(M, 1, device=dev) * 0.001 + 0.0005).requires_grad_(True),
+                 qo=(torch.rand(M, 1, device=dev) * 0.1 + 0.15).requires_grad_(True),
+                 mf=leaf(D, F), sf=(torch.rand(D, F, device=dev) + 0.5).requires_grad_(True), ms=leaf(D, 6, scale=0.004, shift=0.01),
+                 ss=(torch.rand(D, 6, device=dev) * 0.004 + 0.001).requires_grad_(True), mo=leaf(D, 3 * K, scale=0.3),
+                 so=(torch.rand(D, 3 * K, device=dev) * 0.3 + 0.05).requires_grad_(True))
+        return t
+
+    ec_row = torch.randint(0, D, (M,), device=dev)
+    live = torch.ones(M, dtype=torch.bool, device=dev)
+    sel = ((torch.rand(M, device=dev) < 0.08) & live).nonzero().squeeze(1)
+    w = torch.randn(len(counts), 4, device=dev)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("GSVC_NO_FUSED_RATE", raising=False)
+        else:
+            monkeypatch.setenv("GSVC_NO_FUSED_RATE", "1")
+        t = make()
+        ec = EntropyContext(t["mf"], t["sf"], t["ms"], t["ss"], t["mo"], t["so"], None, None, None)
+        packs = _rate_many(pc, seg, t["feat"], t["gs"], t["go"], t["om"], t["qf"], t["qs"], t["qo"], ec, ec_row=ec_row, sel=sel)
+        vals = torch.stack([torch.stack([p.bit_per_param, p.bit_per_feat_param, p.bit_per_scaling_param, p.bit_per_offsets_param])
+                            for p in packs])
+        live_r = torch.tensor([c > 0 for c in counts], device=dev)
+        (vals[live_r] * w[live_r]).sum().backward()
+        return vals.detach(), {k: v.grad for k, v in t.items()}
+
+    v0, g0 = run(False)
+    v1, g1 = run(True)
+    ok = torch.isfinite(v0)
+    assert torch.equal(ok, torch.isfinite(v1))
+    assert torch.allclose(v1[ok], v0[ok], rtol=2e-5, atol=1e-6)
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None), k
+        if g0[k] is not None:
+            scale = g0[k].abs().max().item()
+            assert (g1[k] - g0[k]).abs().max().item() <= 2e-4 * scale + 1e-12, (k, scale)
