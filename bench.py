@@ -404,7 +404,7 @@ def run_train_step(args, rank, world, dev):
                                "anchors_coded": pack.n, "megabytes": {k[4:]: round(v / 8 / 2 ** 20, 4) for k, v in bits.items()},
                                "ans_decode_kernel": {"launches": kprof.get("k_ans_decode", (0, 0.0))[0],
                                                      "sum_ms": kprof.get("k_ans_decode", (0, 0.0))[1],
-                                                     "note": "sum of the launches' own durations; they run side by side on 8 streams"},
+                                                     "note": "two launches: masks + hash tables, then every attribute stream of every slab (gsvc_ans_decode_many)"},
                                "stream_decode_fps": n_dec / (tc3 - tc1),
                                "note": f"entropy decode of the whole model + {n_dec} two-view frames rendered from it"}
         del dec, pack

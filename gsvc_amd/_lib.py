@@ -54,6 +54,12 @@ class RateSampleC(C.Structure):
                 ("x_mean", C.c_void_p), ("C", C.c_int32 * 3), ("K", C.c_int32), ("renders", C.c_int32), ("n_sel", C.c_int64)]
 
 
+class AnsDecodeJobC(C.Structure):
+    _fields_ = [("bytes", C.c_void_p), ("seg_offsets", C.c_void_p), ("mu", C.c_void_p), ("sigma", C.c_void_p), ("n", C.c_int64),
+                ("min_symbol", C.c_int32), ("max_symbol", C.c_int32), ("seg_len", C.c_int32), ("symbols", C.c_void_p),
+                ("error_flag", C.c_void_p), ("scratch", C.c_void_p)]
+
+
 class RasterSizesC(C.Structure):
     _fields_ = [("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)]
 
@@ -102,6 +108,7 @@ _SIGNATURES = {
     "gsvc_ans_encode": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_ans_decode_scratch_bytes": (_i64, [_i64, C.c_int32]),
     "gsvc_ans_decode": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
+    "gsvc_ans_decode_many": (C.c_int, [C.POINTER(AnsDecodeJobC), C.c_int32, _vp]),
     "gsvc_linear_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "gsvc_linear_forward_ex": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_linear_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, _vp, _i64, _vp]),

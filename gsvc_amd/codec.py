@@ -176,6 +176,65 @@ def ans_decode(stream, mu: torch.Tensor, sigma: torch.Tensor, defer: "DeferredCh
     return sym[:n]
 
 
+def ans_decode_many(jobs, defer: "DeferredChecks | None" = None):
+    """``ans_decode`` of several streams in ONE launch: jobs = [(stream or PreparedStream or None, mu, sigma), ...] -> list of int32
+    symbol tensors (an empty stream gives an empty tensor).  A decode launch lasts as long as one lane's serial segment
+    whatever the number of streams it carries, and separate launches of a few waves each do not overlap reliably."""
+    import ctypes as C
+    if not jobs:
+        return []
+    dev = jobs[0][1].device
+    raw = [j[0] for j in jobs]
+    need = [i for i, st in enumerate(raw) if st is not None and not isinstance(st, PreparedStream)]
+    if need:
+        prep = prepare_streams([raw[i] for i in need], dev)
+        for i, ps in zip(need, prep):
+            raw[i] = ps
+    errs = torch.zeros(len(jobs), dtype=torch.int32, device=dev)
+    arr = (_lib.AnsDecodeJobC * len(jobs))()
+    out, keep = [], []
+    L = _lib.lib()
+    for k, (ps, (_, mu, sigma)) in enumerate(zip(raw, jobs)):
+        n = ps.n if ps is not None else 0
+        if mu.numel() != n or sigma.numel() != n:
+            raise _lib.GsvcError(f"ans_decode: stream holds {n} symbols, the model {mu.numel()}")
+        sym = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        out.append(sym[:n])
+        d = arr[k]
+        d.n = n
+        d.min_symbol, d.max_symbol, d.seg_len = (ps.smin, ps.smax, ps.seg_len) if ps is not None else (0, 1, 1)
+        if n == 0:
+            continue
+        mu, sigma = mu.contiguous(), sigma.contiguous()
+        scratch = torch.empty(int(L.gsvc_ans_decode_scratch_bytes(n, ps.seg_len)), dtype=torch.uint8, device=dev)
+        keep += [mu, sigma, scratch, sym]
+        d.bytes, d.seg_offsets, d.mu, d.sigma = ps.bytes_d.data_ptr(), ps.offs_d.data_ptr(), mu.data_ptr(), sigma.data_ptr()
+        d.symbols, d.error_flag, d.scratch = sym.data_ptr(), errs[k:].data_ptr(), scratch.data_ptr()
+    _lib.check(L.gsvc_ans_decode_many(arr, len(jobs), _lib.current_stream(dev)), "gsvc_ans_decode_many")
+    for t in keep:
+        t.record_stream(torch.cuda.current_stream(dev))
+    if defer is not None:
+        defer.add(errs.max(), "ans_decode")
+    else:
+        code = int(errs.max().item())
+        if code != 0:
+            raise _lib.GsvcError(f"ans_decode: corrupt stream or a model that differs from the encoder's (code {code})")
+    return out
+
+
+def decoder_gaussian_many(jobs, defer=None):
+    """``decoder_gaussian`` of several streams in one launch: jobs = [(mean, scale, Q, stream), ...] -> de-quantised tensors."""
+    models = []
+    for mean, scale, Q, stream in jobs:
+        if not isinstance(Q, torch.Tensor):
+            Q = torch.full_like(mean, float(Q))
+        mu, sigma = _model(mean, scale, Q)
+        models.append((stream, mu, sigma))
+    syms = ans_decode_many(models, defer=defer)
+    return [sym.to(mean.dtype).view(mean.shape) * (Q if isinstance(Q, torch.Tensor) else float(Q))
+            for sym, (mean, scale, Q, _) in zip(syms, jobs)]
+
+
 def encoder_gaussian(x, mean, scale, Q, min_value, max_value, file_name=None):
     """reference utils/encodings.py:102-222.  ``x``: quantised symbols (integers stored as float), same shape as ``mean`` /
     ``scale``; ``Q`` a number or a tensor of that shape.  Returns (bit_len, local_min, local_max, stream)."""

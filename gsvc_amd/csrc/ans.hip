@@ -247,14 +247,12 @@ constexpr int ANS_AHEAD = 16;     // records a decode lane keeps in flight (the 
 // One lane decodes one segment.  Everything a lane reads from memory is fetched ahead of its use: the byte stream through a
 // 16-byte register buffer (a renormalisation byte used to be a dependent global load of ~1 us each with the few waves a
 // decode launch has), the model records ANS_AHEAD symbols ahead (each record register is reloaded as soon as it is consumed).
-__global__ void __launch_bounds__(64) k_ans_decode(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ seg_offsets,
-                                                   int64_t n, int smin, int smax, int seg_len, int64_t n_seg,
-                                                   int32_t *__restrict__ sym, int32_t *__restrict__ error_flag,
-                                                   const uint4 *__restrict__ records)
+__device__ __forceinline__ void ans_decode_body(const uint32_t *__restrict__ phi, const uint8_t *__restrict__ bytes,
+                                                const uint64_t *__restrict__ seg_offsets, int64_t n, int smin, int smax, int seg_len,
+                                                int64_t n_seg, int32_t *__restrict__ sym, int32_t *__restrict__ error_flag,
+                                                const uint4 *__restrict__ records, int64_t block)
 {
-    __shared__ uint32_t phi[PHI_STEPS + 1];
-    load_phi_table(phi, threadIdx.x, 64);
-    const int64_t seg = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t seg = block * 64 + threadIdx.x;
     if (seg >= n_seg) return;
     const int64_t i0 = seg * seg_len;
     const int len = (int)((i0 + seg_len < n ? i0 + seg_len : n) - i0);
@@ -267,7 +265,7 @@ __global__ void __launch_bounds__(64) k_ans_decode(const uint8_t *__restrict__ b
     x |= rd.next() << 16;
     x |= rd.next() << 8;
     x |= rd.next();
-    const uint4 *rec = records + ((int64_t)blockIdx.x * seg_len * 64 + threadIdx.x) * 2;      // + 128 per symbol
+    const uint4 *rec = records + (block * seg_len * 64 + threadIdx.x) * 2;      // + 128 per symbol
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
     uint4 ra[ANS_AHEAD], rb[ANS_AHEAD];
 #pragma unroll
@@ -312,6 +310,64 @@ __global__ void __launch_bounds__(64) k_ans_decode(const uint8_t *__restrict__ b
         }
         if (!ok) return;
     }
+}
+
+__global__ void __launch_bounds__(64) k_ans_decode(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ seg_offsets,
+                                                   int64_t n, int smin, int smax, int seg_len, int64_t n_seg,
+                                                   int32_t *__restrict__ sym, int32_t *__restrict__ error_flag,
+                                                   const uint4 *__restrict__ records)
+{
+    __shared__ uint32_t phi[PHI_STEPS + 1];
+    load_phi_table(phi, threadIdx.x, 64);
+    ans_decode_body(phi, bytes, seg_offsets, n, smin, smax, seg_len, n_seg, sym, error_flag, records, blockIdx.x);
+}
+
+// Several streams in ONE launch (a coded model is dozens of streams, each a handful of waves: launched one by one they run
+// one after another — streams of different HIP queues share hardware queues with whatever else the caller has queued — and
+// every launch lasts as long as its slowest lane's 4 096 serial symbols, ~1.8 ms; together they fill the chip for that long once).
+constexpr int ANS_MAX_JOBS = 16;
+struct AnsJob {
+    const uint8_t *bytes;
+    const uint64_t *seg_offsets;
+    const float *mu, *sigma;
+    int32_t *sym, *err;
+    uint4 *records;
+    long long n, n_seg;
+    int smin, smax, seg_len, first_block, first_model_block, pad;
+};
+struct AnsJobs {
+    AnsJob j[ANS_MAX_JOBS];
+    int n;
+};
+
+__global__ void __launch_bounds__(64) k_ans_decode_many(AnsJobs t)
+{
+    __shared__ uint32_t phi[PHI_STEPS + 1];
+    load_phi_table(phi, threadIdx.x, 64);
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.j[k + 1].first_block) k++;
+    const AnsJob &q = t.j[k];
+    ans_decode_body(phi, q.bytes, q.seg_offsets, q.n, q.smin, q.smax, q.seg_len, q.n_seg, q.sym, q.err, q.records,
+                    (int64_t)blockIdx.x - q.first_block);
+}
+
+__global__ void __launch_bounds__(256) k_ans_model_many(AnsJobs t)
+{
+    __shared__ uint32_t phi[PHI_STEPS + 1];
+    load_phi_table(phi, threadIdx.x, 256);
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.j[k + 1].first_model_block) k++;
+    const AnsJob &q = t.j[k];
+    const int64_t i = ((int64_t)blockIdx.x - q.first_model_block) * 256 + threadIdx.x;
+    if (i >= q.n) return;
+    const float m = q.mu[i], sg = q.sigma[i];
+    const double inv = 1.0 / (double)sg, md = (double)m;
+    const int s0 = ans_mode(m, q.smin, q.smax);
+    const int64_t g = i / q.seg_len, tt = i - g * q.seg_len;
+    uint4 *dst = q.records + (((g >> 6) * q.seg_len + tt) * 64 + (g & 63)) * 2;
+    dst[0] = make_uint4(ans_cdf(phi, s0 - 1, md, inv, q.smin, q.smax), ans_cdf(phi, s0, md, inv, q.smin, q.smax),
+                        ans_cdf(phi, s0 + 1, md, inv, q.smin, q.smax), ans_cdf(phi, s0 + 2, md, inv, q.smin, q.smax));
+    dst[1] = make_uint4(__float_as_uint(m), __float_as_uint(sg), 0u, 0u);
 }
 
 }  // namespace gsvc
@@ -414,4 +470,42 @@ extern "C" int gsvc_ans_decode(const uint8_t *bytes, const uint64_t *seg_offsets
     hipLaunchKernelGGL(k_ans_decode, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, s, bytes, seg_offsets, n, min_symbol, max_symbol,
                        seg_len, n_seg, symbols, error_flag, (const uint4 *)scratch);
     return check_launch("ans_decode");
+}
+
+extern "C" int gsvc_ans_decode_many(const gsvc_ans_decode_job *jobs, int32_t n_jobs, void *stream)
+{
+    GSVC_REQUIRE(jobs && n_jobs >= 0, "ans_decode_many: bad arguments");
+    if (int rc = ensure_phi_table()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    for (int j0 = 0; j0 < n_jobs; j0 += ANS_MAX_JOBS) {
+        AnsJobs t;
+        t.n = 0;
+        long long blocks = 0, mblocks = 0;
+        for (int j = j0; j < n_jobs && t.n < ANS_MAX_JOBS; j++) {
+            const gsvc_ans_decode_job &d = jobs[j];
+            GSVC_REQUIRE(d.n >= 0 && d.seg_len > 0 && d.seg_len <= (1 << 20), "ans_decode_many: bad sizes (job %d)", j);
+            GSVC_REQUIRE(d.max_symbol >= d.min_symbol && (int64_t)d.max_symbol - d.min_symbol + 1 < (int64_t)(ANS_M / 2),
+                         "ans_decode_many: symbol range [%d, %d] does not fit 20-bit frequencies", d.min_symbol, d.max_symbol);
+            if (d.n == 0) continue;
+            GSVC_REQUIRE(d.bytes && d.seg_offsets && d.mu && d.sigma && d.symbols && d.error_flag && d.scratch,
+                         "ans_decode_many: NULL pointer (job %d)", j);
+            GSVC_REQUIRE((reinterpret_cast<uintptr_t>(d.scratch) & 15) == 0, "ans_decode_many: scratch must be 16-byte aligned");
+            AnsJob &q = t.j[t.n++];
+            q.bytes = d.bytes; q.seg_offsets = d.seg_offsets; q.mu = d.mu; q.sigma = d.sigma; q.sym = d.symbols; q.err = d.error_flag;
+            q.records = (uint4 *)d.scratch; q.n = d.n; q.n_seg = gsvc_ans_segments(d.n, d.seg_len);
+            q.smin = d.min_symbol; q.smax = d.max_symbol; q.seg_len = d.seg_len; q.pad = 0;
+            q.first_block = (int)blocks; q.first_model_block = (int)mblocks;
+            blocks += (q.n_seg + 63) / 64;
+            mblocks += (q.n + 255) / 256;
+            GSVC_REQUIRE(blocks < (1ll << 31) && mblocks < (1ll << 31), "ans_decode_many: too many symbols for one launch");
+        }
+        if (t.n == 0) continue;
+        {
+            ProfScope _p("k_ans_model", s);
+            hipLaunchKernelGGL(k_ans_model_many, dim3((unsigned)mblocks), dim3(256), 0, s, t);
+        }
+        ProfScope _p("k_ans_decode", s);
+        hipLaunchKernelGGL(k_ans_decode_many, dim3((unsigned)blocks), dim3(64), 0, s, t);
+    }
+    return check_launch("ans_decode_many");
 }

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .codec import DeferredChecks, ans_decode, ans_encode, decoder_gaussian, encoder_gaussian, prepare_streams
+from .codec import DeferredChecks, ans_decode, ans_decode_many, ans_encode, decoder_gaussian_many, encoder_gaussian, prepare_streams
 from .encodings import ANCHOR_ROUND_DIGITS, Quantize_anchor, STE_multistep
 from .model import calc_symbol_min_max
 
@@ -142,16 +142,26 @@ class StreamPack:
         return pack
 
 
-DECODE_STREAMS = 8
+CONTEXT_CHUNK = 1 << 20     # anchors per evaluation of the context model (bounds its transient memory)
 
 
-def _slab_model(pc, anchor):
-    """Context of one slab: per-element mean / scale / step of the three attribute groups."""
-    ec = pc.calc_entropy_context(anchor)
-    Q = [BASE_Q[0] * ec.Q_feat_adj, BASE_Q[1] * ec.Q_scaling_adj, BASE_Q[2] * ec.Q_offsets_adj]
-    means = [ec.mean_feat, ec.mean_scaling, ec.mean_offsets]
-    scales = [ec.scale_feat, ec.scale_scaling, ec.scale_offsets]
-    return [(m.contiguous(), s.contiguous(), q.repeat(1, m.shape[-1])) for m, s, q in zip(means, scales, Q)]
+def _context_all(pc, anchor):
+    """Context of every kept anchor (z order): per-element mean / scale / step of the three attribute groups, evaluated in
+    fixed chunks.  Encoder and decoder call THIS (same chunks, hence the same kernels on the same rows: the model must agree
+    bit for bit); a slab's model is a row slice.  (The reference evaluates the context slab by slab, scene/gaussian_model.py:
+    2380-2450; per row it is the same function of the anchor.)"""
+    parts = [[] for _ in range(9)]
+    for lo in range(0, anchor.shape[0], CONTEXT_CHUNK):
+        ec = pc.calc_entropy_context(anchor[lo:lo + CONTEXT_CHUNK])
+        Q = [BASE_Q[0] * ec.Q_feat_adj, BASE_Q[1] * ec.Q_scaling_adj, BASE_Q[2] * ec.Q_offsets_adj]
+        means = [ec.mean_feat, ec.mean_scaling, ec.mean_offsets]
+        scales = [ec.scale_feat, ec.scale_scaling, ec.scale_offsets]
+        for g in range(3):
+            parts[3 * g].append(means[g].contiguous())
+            parts[3 * g + 1].append(scales[g].contiguous())
+            parts[3 * g + 2].append(Q[g].repeat(1, means[g].shape[-1]))
+    cat = [torch.cat(p) if len(p) != 1 else p[0] for p in parts]
+    return [(cat[0], cat[1], cat[2]), (cat[3], cat[4], cat[5]), (cat[6], cat[7], cat[8])]
 
 
 @torch.no_grad()
@@ -185,8 +195,9 @@ def conduct_stream_encoding(pc, mlp_file=None) -> StreamPack:
     prob_masks = float((mask.sum() / mask.numel()).item())
     pack = StreamPack(n_full=int(pc._anchor.shape[0]), n=N, anchor_interval=interval.cpu().numpy(), anchor_min=a_min.cpu().numpy(),
                       anchors_q=anchors_q, prob_masks=prob_masks, prob_hash=prob_hash, slabs=list(slabs))
+    model = _context_all(pc, anchor)
     for a, b in slabs:
-        (mf, sf, qf), (ms, ss, qs), (mo, so, qo) = _slab_model(pc, anchor[a:b])
+        (mf, sf, qf), (ms, ss, qs), (mo, so, qo) = [tuple(t[a:b] for t in grp) for grp in model]
         x = STE_multistep.quantize(feat[a:b], qf, *ranges[0])
         pack.feat.append(encoder_gaussian(x, mf, sf, qf, *ranges[0])[3])
         x = STE_multistep.quantize(scaling[a:b], qs, *ranges[1])
@@ -217,47 +228,45 @@ def conduct_stream_decoding(pc, pack: StreamPack, mlp_file=None):
         raise RuntimeError("stream decoding: the slab split of the decoded anchors differs from the encoder's")
     anchor = anchor[z_order]
     N = pack.n
-    mask = decode_binary(pack.masks, N * K, pack.prob_masks, dev).to(torch.float32).view(N, K, 1)
+    # launch 1: the offset masks and the binarised hash tables (two streams, one launch)
     tables = pc.get_encoding_params()
-    hash01 = decode_binary(pack.hash, tables.numel(), pack.prob_hash, dev).to(torch.float32)
-    hash_pm = (hash01 * 2 - 1).view(-1, tables.shape[1])
+    checks = DeferredChecks()
+    mu_m, sg_m = _bernoulli_model(N * K, pack.prob_masks, dev)
+    mu_h, sg_h = _bernoulli_model(tables.numel(), pack.prob_hash, dev)
+    mask_sym, hash_sym = ans_decode_many([(pack.masks, mu_m, sg_m), (pack.hash, mu_h, sg_h)], defer=checks)
+    mask = mask_sym.to(torch.float32).view(N, K, 1)
+    hash_pm = (hash_sym.to(torch.float32) * 2 - 1).view(-1, tables.shape[1])
     _install_tables(pc, hash_pm)                                  # the context model reads the decoded tables
-    feats, scalings, offsets = [], [], []
-    # The slabs' streams are independent and one decode launch is a few waves (one lane per 4 096-symbol segment), so the
-    # launches are spread over a few HIP streams and run side by side.  Nothing inside the loop may synchronise (the host
-    # would wait for one slab's kernels before it can queue the next): every payload is uploaded before the loop with one
-    # copy, the masked offsets are addressed through index lists computed up front (boolean-mask indexing reads a count back),
-    # and the decode kernels' error words are read once at the end.
+    # the coded offsets are the masked ones: index lists per slab, one read-back
     n_slab = len(slabs)
     prepared = prepare_streams(list(pack.feat) + list(pack.scaling) + list(pack.offsets), dev)
     m3_all = mask.repeat(1, 1, 3).view(N, 3 * K) > 0
     nz = m3_all.view(-1).nonzero(as_tuple=False).squeeze(1)                      # flat positions of the coded offsets
     edges = torch.tensor([a * 3 * K for a, _ in slabs] + [N * 3 * K], device=dev)
-    cuts = torch.searchsorted(nz, edges).tolist()                                # the one read-back before the loop
-    checks = DeferredChecks()
-    main = torch.cuda.current_stream(dev)
-    pool = [torch.cuda.Stream(device=dev) for _ in range(min(DECODE_STREAMS, max(n_slab, 1)))]
-    for s, (a, b) in enumerate(slabs):
-        (mf, sf, qf), (ms, ss, qs), (mo, so, qo) = _slab_model(pc, anchor[a:b])
-        sel = nz[cuts[s]:cuts[s + 1]] - a * 3 * K                                # positions inside this slab's [rows, 3K] block
-        side = pool[s % len(pool)]
-        side.wait_stream(main)                                    # the context (means, scales, steps) is computed on `main`
-        with torch.cuda.stream(side):
-            feats.append(decoder_gaussian(mf, sf, qf, stream=prepared[s], defer=checks))
-            scalings.append(decoder_gaussian(ms, ss, qs, stream=prepared[n_slab + s], defer=checks))
-            off = torch.zeros_like(mo)
-            if prepared[2 * n_slab + s] is not None:
-                vals = decoder_gaussian(mo.view(-1)[sel], so.view(-1)[sel], qo.view(-1)[sel], stream=prepared[2 * n_slab + s],
-                                        defer=checks)
-                off.view(-1)[sel] = vals
-            elif cuts[s + 1] != cuts[s]:
-                raise RuntimeError("stream decoding: a slab has coded offsets but an empty offsets stream")
-            offsets.append(off.view(-1, K, 3))
-        for t in (mf, sf, qf, ms, ss, qs, mo, so, qo, sel, feats[-1], scalings[-1], offsets[-1]):
-            t.record_stream(side)
-            t.record_stream(main)
-    for side in pool:
-        main.wait_stream(side)
+    cuts = torch.searchsorted(nz, edges).tolist()
+    # launch 2: every attribute stream of every slab.  The context of all anchors is evaluated first (one pass, the encoder's
+    # chunks); a decode launch lasts as long as one lane's serial segment however many streams it carries, while one launch per
+    # stream ran them one after another (24 x 1.8 ms: HIP streams share hardware queues with the context kernels in between).
+    model = _context_all(pc, anchor)
+    jobs, off_sel = [], []
+    for s_i, (a, b) in enumerate(slabs):
+        (mf, sf, qf), (ms, ss, qs), (mo, so, qo) = [tuple(t[a:b] for t in grp) for grp in model]
+        sel = nz[cuts[s_i]:cuts[s_i + 1]] - a * 3 * K                              # positions inside this slab's [rows, 3K] block
+        jobs.append((mf, sf, qf, prepared[s_i]))
+        jobs.append((ms, ss, qs, prepared[n_slab + s_i]))
+        if prepared[2 * n_slab + s_i] is None and cuts[s_i + 1] != cuts[s_i]:
+            raise RuntimeError("stream decoding: a slab has coded offsets but an empty offsets stream")
+        jobs.append((mo.reshape(-1)[sel], so.reshape(-1)[sel], qo.reshape(-1)[sel], prepared[2 * n_slab + s_i]))
+        off_sel.append((sel, mo.shape))
+    vals = decoder_gaussian_many(jobs, defer=checks)
+    feats, scalings, offsets = [], [], []
+    for s_i in range(n_slab):
+        feats.append(vals[3 * s_i])
+        scalings.append(vals[3 * s_i + 1])
+        sel, shape = off_sel[s_i]
+        off = torch.zeros(shape, device=dev)
+        off.view(-1)[sel] = vals[3 * s_i + 2]
+        offsets.append(off.view(-1, K, 3))
     checks.check()
     Nf = pack.n_full
 

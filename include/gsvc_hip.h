@@ -352,6 +352,19 @@ int gsvc_ans_decode(const uint8_t *bytes, const uint64_t *seg_offsets, const flo
 int gsvc_embed_pe(const float *anchor, const int64_t *row_bounds, const float *cam_z, int32_t renders, int32_t freqs, float *pe,
                   void *stream);
 
+/* Several streams in one launch (each job as gsvc_ans_decode): a coded model is dozens of streams of a few waves each; one
+ * launch lasts as long as a lane's seg_len serial symbols whatever the number of streams it carries. */
+typedef struct gsvc_ans_decode_job {
+    const uint8_t *bytes;
+    const uint64_t *seg_offsets;
+    const float *mu, *sigma;
+    int64_t n;
+    int32_t min_symbol, max_symbol, seg_len;
+    int32_t *symbols, *error_flag;
+    void *scratch;
+} gsvc_ans_decode_job;
+int gsvc_ans_decode_many(const gsvc_ans_decode_job *jobs, int32_t n_jobs, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Linear layers of the generator / deformation / entropy-parameter MLPs (reference scene/gaussian_model.py:
  * 150-232: every nn.Linear applied to the [anchors, features] matrix)

@@ -194,9 +194,10 @@ def test_stream_encode_decode_round_trip(tmp_path):
         rs = calc_symbol_min_max(ec.mean_scaling, BASE_Q[1] * ec.Q_scaling_adj)
         ro = calc_symbol_min_max(ec.mean_offsets, BASE_Q[2] * ec.Q_offsets_adj)
         exp_feat, exp_scaling, exp_off = [], [], []
-        for a, b in slabs:
-            e = pc.calc_entropy_context(anchor[a:b])
-            qf, qs, qo = BASE_Q[0] * e.Q_feat_adj, BASE_Q[1] * e.Q_scaling_adj, BASE_Q[2] * e.Q_offsets_adj
+        from gsvc_amd.stream_codec import _context_all
+        model = _context_all(pc, anchor)      # the codec's own evaluation of the context (all anchors, fixed chunks): the steps
+        for a, b in slabs:                    # must be the floats the encoder quantised with
+            qf, qs, qo = model[0][2][a:b, :1], model[1][2][a:b, :1], model[2][2][a:b, :1]
             exp_feat.append(STE_multistep.quantize(feat[a:b], qf, *rf) * qf)
             exp_scaling.append(STE_multistep.quantize(scaling[a:b], qs, *rs) * qs)
             exp_off.append(STE_multistep.quantize(offsets[a:b], qo.unsqueeze(1), *ro) * qo.unsqueeze(1) * mask[a:b])
