@@ -145,6 +145,114 @@ __global__ void __launch_bounds__(256) k_embed_pe(const float *__restrict__ anch
     pe[i] = v;
 }
 
+// Per-anchor parameters of the batch's rows in one pass each way (reference guassian.py:160-176 gathers them by boolean mask and
+// re-applies the getters' activations per render): feat = _anchor_feat[v], offsets = _offset[v], scaling = exp(_scaling[v]),
+// mask = straight-through threshold of sigmoid(_mask[v]) (forward value ((s > 0.01) - s) + s, gradient of s), v = vis[row].
+// Backward: the rows of one anchor (it is visible in up to R renders) meet in float atomics on the zero-filled dense gradients.
+struct GatherDims {
+    int F, K3, S, K;       // columns of feat, offsets (3 K), scaling, mask
+};
+
+__global__ void __launch_bounds__(256) k_gather_rows_fwd(const float *__restrict__ pf, const float *__restrict__ po,
+                                                         const float *__restrict__ ps, const float *__restrict__ pm,
+                                                         const long long *__restrict__ vis, long long rows, GatherDims d, int decoded,
+                                                         float *__restrict__ feat, float *__restrict__ off, float *__restrict__ scal,
+                                                         float *__restrict__ mask)
+{
+#pragma clang fp contract(off)
+    const int CT = d.F + d.K3 + d.S + d.K;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * CT) return;
+    const long long row = i / CT;
+    int c = (int)(i - row * CT);
+    const long long v = vis[row];
+    if (c < d.F) { feat[row * d.F + c] = pf[v * d.F + c]; return; }
+    c -= d.F;
+    if (c < d.K3) { off[row * d.K3 + c] = po[v * d.K3 + c]; return; }
+    c -= d.K3;
+    if (c < d.S) {
+        const float r = ps[v * d.S + c];
+        scal[row * d.S + c] = decoded ? r : 1.0f * expf(r);
+        return;
+    }
+    c -= d.S;
+    const float r = pm[v * d.K + c];
+    if (decoded) { mask[row * d.K + c] = r; return; }
+    const float sg = 1.0f / (1.0f + expf(-r));
+    const float h = sg > 0.01f ? 1.0f : 0.0f;
+    const float diff = h - sg;
+    mask[row * d.K + c] = diff + sg;
+}
+
+__global__ void __launch_bounds__(256) k_gather_rows_bwd(const float *__restrict__ ps, const float *__restrict__ pm,
+                                                         const long long *__restrict__ vis, long long rows, GatherDims d, int decoded,
+                                                         const float *__restrict__ gf, const float *__restrict__ go,
+                                                         const float *__restrict__ gs, const float *__restrict__ gm,
+                                                         float *__restrict__ df, float *__restrict__ dof, float *__restrict__ ds,
+                                                         float *__restrict__ dm)
+{
+    const int CT = d.F + d.K3 + d.S + d.K;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * CT) return;
+    const long long row = i / CT;
+    int c = (int)(i - row * CT);
+    const long long v = vis[row];
+    if (c < d.F) { if (gf && df) atomicAdd(df + v * d.F + c, gf[row * d.F + c]); return; }
+    c -= d.F;
+    if (c < d.K3) { if (go && dof) atomicAdd(dof + v * d.K3 + c, go[row * d.K3 + c]); return; }
+    c -= d.K3;
+    if (c < d.S) {
+        if (gs && ds) {
+            const float g = gs[row * d.S + c];
+            atomicAdd(ds + v * d.S + c, decoded ? g : g * expf(ps[v * d.S + c]));
+        }
+        return;
+    }
+    c -= d.S;
+    if (gm && dm) {
+        const float g = gm[row * d.K + c];
+        float w = 1.0f;
+        if (!decoded) {
+            const float sg = 1.0f / (1.0f + expf(-pm[v * d.K + c]));
+            w = sg * (1.0f - sg);
+        }
+        atomicAdd(dm + v * d.K + c, g * w);
+    }
+}
+
+// Tail of an EntropyParamsNet (reference scene/gaussian_model.py:1586-1596): params [n, 2 C] = [mean | scale], q [n] ->
+// scale_c = max(scale, 1e-9), adj = exp(clamp(q, -10, 10)); backward assembles d params = [g_mean | g_scale * (scale >= 1e-9)]
+// and d q = g_adj * adj * (|q| <= 10) — was 9 launches forward and ~30 backward for the three networks.
+__global__ void __launch_bounds__(256) k_ctx_post_fwd(const float *__restrict__ params, const float *__restrict__ q, long long n, int C,
+                                                      float *__restrict__ mean, float *__restrict__ scale, float *__restrict__ adj)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * (C + 1)) return;
+    const long long row = i / (C + 1);
+    const int c = (int)(i - row * (C + 1));
+    if (c == C) { adj[row] = expf(fminf(fmaxf(q[row], -10.0f), 10.0f)); return; }
+    mean[row * C + c] = params[row * 2 * C + c];
+    scale[row * C + c] = fmaxf(params[row * 2 * C + C + c], 1e-9f);
+}
+
+__global__ void __launch_bounds__(256) k_ctx_post_bwd(const float *__restrict__ params, const float *__restrict__ q,
+                                                      const float *__restrict__ adj, long long n, int C, const float *__restrict__ g_mean,
+                                                      const float *__restrict__ g_scale, const float *__restrict__ g_adj,
+                                                      float *__restrict__ dparams, float *__restrict__ dq)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * (C + 1)) return;
+    const long long row = i / (C + 1);
+    const int c = (int)(i - row * (C + 1));
+    if (c == C) {
+        const float qv = q[row];
+        dq[row] = (g_adj && qv >= -10.0f && qv <= 10.0f) ? g_adj[row] * adj[row] : 0.0f;
+        return;
+    }
+    dparams[row * 2 * C + c] = g_mean ? g_mean[row * C + c] : 0.0f;
+    dparams[row * 2 * C + C + c] = (g_scale && params[row * 2 * C + C + c] >= 1e-9f) ? g_scale[row * C + c] : 0.0f;
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -207,4 +315,62 @@ extern "C" int gsvc_embed_pe(const float *anchor, const int64_t *row_bounds, con
     hipLaunchKernelGGL(gsvc::k_embed_pe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, anchor, sg, renders,
                        freqs, rows, pe);
     return gsvc::check_launch("embed_pe");
+}
+
+extern "C" int gsvc_gather_rows_forward(const float *feat_p, const float *offset_p, const float *scaling_p, const float *mask_p,
+                                        const int64_t *vis, int64_t rows, int32_t F, int32_t K, int32_t S, int32_t decoded, float *feat,
+                                        float *offsets, float *scaling, float *mask, void *stream)
+{
+    GSVC_REQUIRE(rows >= 0 && F > 0 && K > 0 && S > 0, "gather_rows_forward: bad shape");
+    if (rows == 0) return GSVC_OK;
+    GSVC_REQUIRE(feat_p && offset_p && scaling_p && mask_p && vis && feat && offsets && scaling && mask, "gather_rows_forward: NULL pointer");
+    const gsvc::GatherDims d{F, 3 * K, S, K};
+    const int64_t n = rows * (F + 3 * K + S + K);
+    gsvc::ProfScope _prof("k_gather_rows", (hipStream_t)stream);
+    hipLaunchKernelGGL(gsvc::k_gather_rows_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat_p, offset_p,
+                       scaling_p, mask_p, (const long long *)vis, (long long)rows, d, decoded, feat, offsets, scaling, mask);
+    return gsvc::check_launch("gather_rows_forward");
+}
+
+extern "C" int gsvc_gather_rows_backward(const float *scaling_p, const float *mask_p, const int64_t *vis, int64_t rows, int32_t F,
+                                         int32_t K, int32_t S, int32_t decoded, const float *g_feat, const float *g_offsets,
+                                         const float *g_scaling, const float *g_mask, float *d_feat, float *d_offset, float *d_scaling,
+                                         float *d_mask, void *stream)
+{
+    GSVC_REQUIRE(rows >= 0 && F > 0 && K > 0 && S > 0, "gather_rows_backward: bad shape");
+    if (rows == 0) return GSVC_OK;
+    GSVC_REQUIRE(scaling_p && mask_p && vis, "gather_rows_backward: NULL pointer");
+    const gsvc::GatherDims d{F, 3 * K, S, K};
+    const int64_t n = rows * (F + 3 * K + S + K);
+    gsvc::ProfScope _prof("k_gather_rows_bwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(gsvc::k_gather_rows_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scaling_p, mask_p,
+                       (const long long *)vis, (long long)rows, d, decoded, g_feat, g_offsets, g_scaling, g_mask, d_feat, d_offset,
+                       d_scaling, d_mask);
+    return gsvc::check_launch("gather_rows_backward");
+}
+
+extern "C" int gsvc_ctx_post_forward(const float *params, const float *q, int64_t n, int32_t C, float *mean, float *scale, float *adj,
+                                     void *stream)
+{
+    GSVC_REQUIRE(n >= 0 && C > 0, "ctx_post_forward: bad shape");
+    if (n == 0) return GSVC_OK;
+    GSVC_REQUIRE(params && q && mean && scale && adj, "ctx_post_forward: NULL pointer");
+    const int64_t t = n * (C + 1);
+    gsvc::ProfScope _prof("k_ctx_post", (hipStream_t)stream);
+    hipLaunchKernelGGL(gsvc::k_ctx_post_fwd, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, q,
+                       (long long)n, C, mean, scale, adj);
+    return gsvc::check_launch("ctx_post_forward");
+}
+
+extern "C" int gsvc_ctx_post_backward(const float *params, const float *q, const float *adj, int64_t n, int32_t C, const float *g_mean,
+                                      const float *g_scale, const float *g_adj, float *dparams, float *dq, void *stream)
+{
+    GSVC_REQUIRE(n >= 0 && C > 0, "ctx_post_backward: bad shape");
+    if (n == 0) return GSVC_OK;
+    GSVC_REQUIRE(params && q && adj && dparams && dq, "ctx_post_backward: NULL pointer");
+    const int64_t t = n * (C + 1);
+    gsvc::ProfScope _prof("k_ctx_post_bwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(gsvc::k_ctx_post_bwd, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, q, adj,
+                       (long long)n, C, g_mean, g_scale, g_adj, dparams, dq);
+    return gsvc::check_launch("ctx_post_backward");
 }

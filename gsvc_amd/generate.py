@@ -106,6 +106,56 @@ def _visible_scaling(pc, vis):
     return raw if pc.decoded_version else 1.0 * pc.scaling_activation(raw)
 
 
+class _GatherRows(torch.autograd.Function):
+    """(feat, offsets, scaling, mask) of the rows ``vis`` from the four per-anchor parameter tensors with the getters' activations
+    applied (csrc/generate.hip k_gather_rows): one launch each way instead of four gathers + activations and four scatter-adds."""
+
+    @staticmethod
+    def forward(ctx, feat_p, offset_p, scaling_p, mask_p, vis, decoded):
+        from . import _lib
+        dev = feat_p.device
+        feat_p, offset_p, scaling_p, mask_p, vis = (t.contiguous() for t in (feat_p, offset_p, scaling_p, mask_p, vis))
+        rows, F, K, S = vis.shape[0], feat_p.shape[1], offset_p.shape[1], scaling_p.shape[1]
+        f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
+        feat, off, scal, mask = f(rows, F), f(rows, K, 3), f(rows, S), f(rows, K, 1)
+        _lib.check(_lib.lib().gsvc_gather_rows_forward(_lib.ptr(feat_p), _lib.ptr(offset_p), _lib.ptr(scaling_p), _lib.ptr(mask_p),
+                                                       _lib.ptr(vis), rows, F, K, S, int(decoded), _lib.ptr(feat), _lib.ptr(off),
+                                                       _lib.ptr(scal), _lib.ptr(mask), _lib.current_stream(dev)),
+                   "gsvc_gather_rows_forward")
+        ctx.save_for_backward(scaling_p, mask_p, vis)
+        ctx.dims = (feat_p.shape, offset_p.shape, F, K, S, bool(decoded))
+        ctx.set_materialize_grads(False)      # an output nothing differentiates (detached STE modes) gives no gradient, not zeros
+        return feat, off, scal, mask
+
+    @staticmethod
+    def backward(ctx, g_feat, g_off, g_scal, g_mask):
+        from . import _lib
+        scaling_p, mask_p, vis = ctx.saved_tensors
+        fshape, oshape, F, K, S, decoded = ctx.dims
+        dev = vis.device
+        need = ctx.needs_input_grad
+        z = lambda sh: torch.zeros(sh, device=dev, dtype=torch.float32)  # noqa: E731
+        c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
+        d_feat = z(fshape) if need[0] and g_feat is not None else None
+        d_off = z(oshape) if need[1] and g_off is not None else None
+        d_scal = z(scaling_p.shape) if need[2] and g_scal is not None else None
+        d_mask = z(mask_p.shape) if need[3] and g_mask is not None else None
+        g_feat, g_off, g_scal, g_mask = c(g_feat), c(g_off), c(g_scal), c(g_mask)
+        _lib.check(_lib.lib().gsvc_gather_rows_backward(_lib.ptr(scaling_p), _lib.ptr(mask_p), _lib.ptr(vis), vis.shape[0], F, K, S,
+                                                        int(decoded), _lib.ptr(g_feat), _lib.ptr(g_off), _lib.ptr(g_scal),
+                                                        _lib.ptr(g_mask), _lib.ptr(d_feat), _lib.ptr(d_off), _lib.ptr(d_scal),
+                                                        _lib.ptr(d_mask), _lib.current_stream(dev)), "gsvc_gather_rows_backward")
+        return d_feat, d_off, d_scal, d_mask, None, None
+
+
+def _gather_rows(pc, vis):
+    """(feat, grid_offsets, grid_scaling, offset_masks) of the visible rows."""
+    if (pc._anchor_feat.is_cuda and vis.dtype == torch.int64 and pc._mask.dim() == 3 and pc._mask.shape[2] == 1
+            and pc._offset.dim() == 3 and pc._offset.shape[2] == 3 and not os.environ.get("GSVC_NO_FUSED_GATHER")):
+        return _GatherRows.apply(pc._anchor_feat, pc._offset, pc._scaling, pc._mask, vis, bool(pc.decoded_version))
+    return (pc._anchor_feat.index_select(0, vis), pc._offset.index_select(0, vis), _visible_scaling(pc, vis), _visible_mask(pc, vis))
+
+
 def _as_index(mask_or_index):
     """Boolean mask -> int64 index list (one nonzero); index tensors pass through.  Gathers by index have a
     scatter-add backward (atomics) instead of the sort-based index_put a boolean mask triggers."""
@@ -615,10 +665,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         vis = torch.cat(vis_list)
         anchor_all = pc.get_anchor if anchors is None else anchors
         anchor = anchor_all.index_select(0, vis)
-        feat = pc._anchor_feat.index_select(0, vis)
-        grid_offsets = pc._offset.index_select(0, vis)
-        grid_scaling = _visible_scaling(pc, vis)
-        offset_masks = _visible_mask(pc, vis)
+        feat, grid_offsets, grid_scaling, offset_masks = _gather_rows(pc, vis)
     rates = [RatePack() for _ in range(R)]
     Q_feat, Q_scaling, Q_offsets = BASE_Q_FEAT, BASE_Q_SCALING, BASE_Q_OFFSETS
     time_sub = 0

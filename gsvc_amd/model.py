@@ -253,6 +253,39 @@ class EntropyParamsNet(nn.Module):
         return mean, scale, self.quant_step_net(x)
 
 
+class _CtxPost(torch.autograd.Function):
+    """(mean, max(scale, 1e-9), exp(clamp(q, -10, 10))) from an EntropyParamsNet's raw outputs params = [mean | scale] and q
+    (reference scene/gaussian_model.py:1586-1596)."""
+
+    @staticmethod
+    def forward(ctx, params, q):
+        from . import _lib
+        params, q = params.contiguous(), q.contiguous()
+        n, C = params.shape[0], params.shape[1] // 2
+        f = lambda *sh: torch.empty(*sh, device=params.device, dtype=torch.float32)  # noqa: E731
+        mean, scale, adj = f(n, C), f(n, C), f(n, 1)
+        _lib.check(_lib.lib().gsvc_ctx_post_forward(_lib.ptr(params), _lib.ptr(q), n, C, _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(adj),
+                                                    _lib.current_stream(params.device)), "gsvc_ctx_post_forward")
+        ctx.save_for_backward(params, q, adj)
+        ctx.set_materialize_grads(False)
+        return mean, scale, adj
+
+    @staticmethod
+    def backward(ctx, g_mean, g_scale, g_adj):
+        from . import _lib
+        params, q, adj = ctx.saved_tensors
+        n, C = params.shape[0], params.shape[1] // 2
+        c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
+        g_mean, g_scale, g_adj = c(g_mean), c(g_scale), c(g_adj)
+        if g_mean is None and g_scale is None and g_adj is None:
+            return None, None
+        dparams, dq = torch.empty_like(params), torch.empty_like(q)
+        _lib.check(_lib.lib().gsvc_ctx_post_backward(_lib.ptr(params), _lib.ptr(q), _lib.ptr(adj), n, C, _lib.ptr(g_mean),
+                                                     _lib.ptr(g_scale), _lib.ptr(g_adj), _lib.ptr(dparams), _lib.ptr(dq),
+                                                     _lib.current_stream(params.device)), "gsvc_ctx_post_backward")
+        return dparams, dq
+
+
 def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000, step_sub=0):
     """Log-linear interpolation lr_init -> lr_final over max_steps (reference utils/general_utils.py:49-82)."""
 
@@ -464,6 +497,13 @@ class GaussianModel(nn.Module):
 
     def calc_entropy_context(self, anchor) -> EntropyContext:
         ctx = self.calc_interp_feat(anchor)
+        if ctx.is_cuda and not os.environ.get("GSVC_NO_FUSED_CTX"):
+            # split, scale clamp and step activation of each network's raw outputs as one launch each way (csrc/generate.hip)
+            out = []
+            for net in (self.mlp_feature_enet, self.mlp_scaling_enet, self.mlp_offset_enet):
+                out += list(_CtxPost.apply(net.dist_net(ctx), net.quant_step_net(ctx)))
+            mf, sf, qf, ms, ss, qs, mo, so, qo = out
+            return EntropyContext(mf, sf, ms, ss, mo, so, qf, qs, qo)
         mean_f, scale_f, q_f = self.mlp_feature_enet(ctx)
         mean_s, scale_s, q_s = self.mlp_scaling_enet(ctx)
         mean_o, scale_o, q_o = self.mlp_offset_enet(ctx)

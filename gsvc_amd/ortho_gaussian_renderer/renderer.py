@@ -80,9 +80,11 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
             means3D=gss.xyz, means2D=screenspace_points, shs=None, colors_precomp=gss.color, opacities=gss.opacity,
             scales=gss.scaling, rotations=gss.rot, cov3D_precomp=None)
         seen = radii > 0
+        # un-compacted renders: the rasterizer already counted the Gaussians with radius > 0 (gsvc_raster_counters.num_visible)
+        active = num_rendered.binning[8:12].view(torch.int32)[0] if dense else seen.sum()
         results.append(RenderResults(
             rendered_image=rendered_image, viewspace_points=screenspace_points, visibility_filter=seen,
-            visible_mask=visible_mask, radii=radii, active_gaussains=seen.sum(),
+            visible_mask=visible_mask, radii=radii, active_gaussains=active,
             num_rendered=None if dense else num_rendered,
             selection_mask=gss.mask, neural_opacity=gss.neural_opacity, scaling=gss.scaling,
             bit_per_param=gss.bit_per_param, bit_per_feat_param=gss.bit_per_feat_param,

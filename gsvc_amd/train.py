@@ -39,10 +39,29 @@ def hash_grid_bits(pc):
     tables = grid_tables(pc)
     if not (pc.ste_binary and all(hasattr(g, "embeddings") for g in tables)):
         return get_binary_vxl_size_device((pc.get_encoding_params() + 1) / 2)
-    total = sum(g.params.numel() for g in tables)
-    ones = (torch.stack([g.embeddings().sum() for g in tables]).sum() + total) / 2
-    p = torch.clamp(ones / total, min=1e-6, max=1 - 1e-6)
-    return ones * (-torch.log2(p)) + (total - ones) * (-torch.log2(1 - p)) + 32
+    return _TableBits.apply(*[g.embeddings() for g in tables])
+
+
+class _TableBits(torch.autograd.Function):
+    """bits = n1 (-log2 p) + n0 (-log2 (1 - p)) + 32 over the {-1, +1} tables, p = n1 / n clamped to [1e-6, 1 - 1e-6]
+    (reference utils/encodings.py:34-51).  d bits / d n1 = log2((1 - p) / p) — the terms through p cancel exactly where p is not
+    clamped and vanish where it is — and n1 = (sum of the entries + n) / 2, so every table entry receives the same number:
+    the backward is one scalar expression and an expand instead of a dozen one-element kernels each way."""
+
+    @staticmethod
+    def forward(ctx, *tables):
+        total = sum(t.numel() for t in tables)
+        ones = (torch.stack([t.sum() for t in tables]).sum() + total) / 2
+        p = torch.clamp(ones / total, min=1e-6, max=1 - 1e-6)
+        ctx.save_for_backward(p)
+        ctx.shapes = [t.shape for t in tables]
+        return ones * (-torch.log2(p)) + (total - ones) * (-torch.log2(1 - p)) + 32
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        coef = g * 0.5 * torch.log2((1 - p) / p)
+        return tuple(coef.expand(sh) for sh in ctx.shapes)
 
 
 def grid_tables(pc):

@@ -345,6 +345,24 @@ int gsvc_ans_decode(const uint8_t *bytes, const uint64_t *seg_offsets, const flo
                     int32_t min_symbol, int32_t max_symbol, int32_t seg_len, int32_t *symbols, int32_t *error_flag, void *scratch,
                     void *stream);
 
+/* Per-anchor parameters of the batch's rows (reference ortho_gaussian_renderer/guassian.py:160-176 + the getters of
+ * scene/gaussian_model.py:641-700), v = vis[row]: feat = anchor_feat[v] [rows,F], offsets = offset[v] [rows,3K], scaling =
+ * exp(scaling_p[v]) [rows,S], mask = straight-through (sigmoid(mask_p[v]) > 0.01) [rows,K]; decoded != 0: the stored values as
+ * they are.  Backward ADDS into the dense, caller-zeroed d_* (an anchor is visible in several renders); g_* may be NULL. */
+int gsvc_gather_rows_forward(const float *feat_p, const float *offset_p, const float *scaling_p, const float *mask_p,
+                             const int64_t *vis, int64_t rows, int32_t F, int32_t K, int32_t S, int32_t decoded, float *feat,
+                             float *offsets, float *scaling, float *mask, void *stream);
+int gsvc_gather_rows_backward(const float *scaling_p, const float *mask_p, const int64_t *vis, int64_t rows, int32_t F, int32_t K,
+                              int32_t S, int32_t decoded, const float *g_feat, const float *g_offsets, const float *g_scaling,
+                              const float *g_mask, float *d_feat, float *d_offset, float *d_scaling, float *d_mask, void *stream);
+
+/* Tail of an EntropyParamsNet (reference scene/gaussian_model.py:1586-1596): params [n,2C] = [mean | scale], q [n] ->
+ * mean [n,C], scale = max(scale, 1e-9) [n,C], adj = exp(clamp(q, -10, 10)) [n]; backward -> dparams [n,2C], dq [n]. */
+int gsvc_ctx_post_forward(const float *params, const float *q, int64_t n, int32_t C, float *mean, float *scale, float *adj,
+                          void *stream);
+int gsvc_ctx_post_backward(const float *params, const float *q, const float *adj, int64_t n, int32_t C, const float *g_mean,
+                           const float *g_scale, const float *g_adj, float *dparams, float *dq, void *stream);
+
 /* Conditioning input of the generator / deformation MLPs for the concatenated rows of `renders` (<= 16) views (reference
  * ortho_gaussian_renderer/guassian.py:225-230, utils/time_util.py:7-55): pe[row] = [embed(cam_z[r]) | embed(anchor[row].z -
  * cam_z[r])] for the rows row_bounds[r] <= row < row_bounds[r + 1]; embed(x) = [x, sin(2^k x), cos(2^k x)]_{k < freqs}.

@@ -123,3 +123,54 @@ def test_fused_positional_embedding_matches_the_embedders():
     # anchors that carry a gradient keep the differentiable path
     a2 = anchor.clone().requires_grad_(True)
     assert _embed_rows(pc, frames, a2, seg).requires_grad
+
+
+def test_fused_row_gather_and_context_tail_match_the_tensor_paths(monkeypatch):
+    """k_gather_rows (per-anchor parameters of the visible rows + getter activations, scatter-add backward) and k_ctx_post
+    (split / clamp / exp tail of the entropy networks) against the index_select / clamp / exp expressions they replace."""
+    from types import SimpleNamespace
+    from gsvc_amd.generate import _gather_rows
+    from gsvc_amd.model import _CtxPost
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    A, K, F = 5000, 10, 50
+    vis = torch.cat([torch.randperm(A, device=dev)[:3000], torch.randperm(A, device=dev)[:2500]])      # anchors repeat across renders
+
+    def model(decoded):
+        torch.manual_seed(5)
+        P = lambda *s, sc=1.0: torch.nn.Parameter(torch.randn(*s, device=dev) * sc)  # noqa: E731
+        return SimpleNamespace(_anchor_feat=P(A, F), _offset=P(A, K, 3), _scaling=P(A, 6, sc=0.5), _mask=P(A, K, 1, sc=4.0),
+                               decoded_version=decoded, scaling_activation=torch.exp)
+
+    w = [torch.randn(vis.shape[0], *s, device=dev) for s in ((F,), (K, 3), (6,), (K, 1))]
+    for decoded in (False, True):
+        res = []
+        for fused in (True, False):
+            if fused:
+                monkeypatch.delenv("GSVC_NO_FUSED_GATHER", raising=False)
+            else:
+                monkeypatch.setenv("GSVC_NO_FUSED_GATHER", "1")
+            pc = model(decoded)
+            outs = _gather_rows(pc, vis)
+            sum((o * ww).sum() for o, ww in zip(outs, w)).backward()
+            res.append(([o.detach() for o in outs], [pc._anchor_feat.grad, pc._offset.grad, pc._scaling.grad, pc._mask.grad]))
+        for a, b in zip(res[0][0], res[1][0]):
+            assert torch.equal(a, b)                       # same float operations in the same order
+        for a, b in zip(res[0][1], res[1][1]):
+            assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())     # atomics reorder sums of <= 2 terms
+    # context tail
+    n, C = 4097, 30
+    params = torch.randn(n, 2 * C, device=dev, requires_grad=True)
+    q = (torch.randn(n, 1, device=dev) * 8).requires_grad_(True)          # some |q| > 10: the clamp is active
+    with torch.no_grad():
+        params[::7, C:] = -0.5                                            # scales below the 1e-9 floor
+    gm, gs, ga = torch.randn(n, C, device=dev), torch.randn(n, C, device=dev), torch.randn(n, 1, device=dev)
+    mean, scale, adj = _CtxPost.apply(params, q)
+    ((mean * gm).sum() + (scale * gs).sum() + (adj * ga).sum()).backward()
+    got = (mean.detach(), scale.detach(), adj.detach(), params.grad.clone(), q.grad.clone())
+    params.grad = q.grad = None
+    m2, s2 = params.split([C, C], dim=1)
+    s2c, a2 = torch.clamp(s2, 1e-9), torch.exp(torch.clamp(q, min=-10, max=10))
+    ((m2 * gm).sum() + (s2c * gs).sum() + (a2 * ga).sum()).backward()
+    for a, b in zip(got, (m2.detach(), s2c.detach(), a2.detach(), params.grad, q.grad)):
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
