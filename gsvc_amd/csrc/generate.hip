@@ -321,9 +321,10 @@ extern "C" int gsvc_gather_rows_forward(const float *feat_p, const float *offset
                                         const int64_t *vis, int64_t rows, int32_t F, int32_t K, int32_t S, int32_t decoded, float *feat,
                                         float *offsets, float *scaling, float *mask, void *stream)
 {
-    GSVC_REQUIRE(rows >= 0 && F > 0 && K > 0 && S > 0, "gather_rows_forward: bad shape");
+    GSVC_REQUIRE(rows >= 0 && F >= 0 && K >= 0 && S >= 0 && F + K + S > 0, "gather_rows_forward: bad shape");
     if (rows == 0) return GSVC_OK;
-    GSVC_REQUIRE(feat_p && offset_p && scaling_p && mask_p && vis && feat && offsets && scaling && mask, "gather_rows_forward: NULL pointer");
+    GSVC_REQUIRE(vis && (F == 0 || (feat_p && feat)) && (K == 0 || (offset_p && mask_p && offsets && mask)) && (S == 0 || (scaling_p && scaling)),
+                 "gather_rows_forward: NULL pointer");
     const gsvc::GatherDims d{F, 3 * K, S, K};
     const int64_t n = rows * (F + 3 * K + S + K);
     gsvc::ProfScope _prof("k_gather_rows", (hipStream_t)stream);
@@ -337,9 +338,9 @@ extern "C" int gsvc_gather_rows_backward(const float *scaling_p, const float *ma
                                          const float *g_scaling, const float *g_mask, float *d_feat, float *d_offset, float *d_scaling,
                                          float *d_mask, void *stream)
 {
-    GSVC_REQUIRE(rows >= 0 && F > 0 && K > 0 && S > 0, "gather_rows_backward: bad shape");
+    GSVC_REQUIRE(rows >= 0 && F >= 0 && K >= 0 && S >= 0 && F + K + S > 0, "gather_rows_backward: bad shape");
     if (rows == 0) return GSVC_OK;
-    GSVC_REQUIRE(scaling_p && mask_p && vis, "gather_rows_backward: NULL pointer");
+    GSVC_REQUIRE(vis && (S == 0 || scaling_p) && (K == 0 || mask_p), "gather_rows_backward: NULL pointer");
     const gsvc::GatherDims d{F, 3 * K, S, K};
     const int64_t n = rows * (F + 3 * K + S + K);
     gsvc::ProfScope _prof("k_gather_rows_bwd", (hipStream_t)stream);

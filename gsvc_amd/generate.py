@@ -106,53 +106,81 @@ def _visible_scaling(pc, vis):
     return raw if pc.decoded_version else 1.0 * pc.scaling_activation(raw)
 
 
-class _GatherRows(torch.autograd.Function):
-    """(feat, offsets, scaling, mask) of the rows ``vis`` from the four per-anchor parameter tensors with the getters' activations
-    applied (csrc/generate.hip k_gather_rows): one launch each way instead of four gathers + activations and four scatter-adds."""
+class _GatherFeat(torch.autograd.Function):
+    """feat = _anchor_feat[vis] (csrc/generate.hip k_gather_rows with the feature group only; the scatter-add is its backward)."""
 
     @staticmethod
-    def forward(ctx, feat_p, offset_p, scaling_p, mask_p, vis, decoded):
+    def forward(ctx, feat_p, vis):
         from . import _lib
-        dev = feat_p.device
-        feat_p, offset_p, scaling_p, mask_p, vis = (t.contiguous() for t in (feat_p, offset_p, scaling_p, mask_p, vis))
-        rows, F, K, S = vis.shape[0], feat_p.shape[1], offset_p.shape[1], scaling_p.shape[1]
+        feat_p, vis = feat_p.contiguous(), vis.contiguous()
+        rows, F = vis.shape[0], feat_p.shape[1]
+        feat = torch.empty(rows, F, device=feat_p.device, dtype=torch.float32)
+        _lib.check(_lib.lib().gsvc_gather_rows_forward(_lib.ptr(feat_p), None, None, None, _lib.ptr(vis), rows, F, 0, 0, 0, _lib.ptr(feat),
+                                                       None, None, None, _lib.current_stream(feat_p.device)), "gsvc_gather_rows_forward")
+        ctx.save_for_backward(vis)
+        ctx.shape = feat_p.shape
+        return feat
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        (vis,) = ctx.saved_tensors
+        d = torch.zeros(ctx.shape, device=vis.device, dtype=torch.float32)
+        _lib.check(_lib.lib().gsvc_gather_rows_backward(None, None, _lib.ptr(vis), vis.shape[0], ctx.shape[1], 0, 0, 0,
+                                                        _lib.ptr(g.contiguous()), None, None, None, _lib.ptr(d), None, None, None,
+                                                        _lib.current_stream(vis.device)), "gsvc_gather_rows_backward")
+        return d, None
+
+
+class _GatherRows(torch.autograd.Function):
+    """(offsets, scaling, mask) of the rows ``vis`` from the per-anchor parameter tensors with the getters' activations applied
+    (csrc/generate.hip k_gather_rows): one launch each way instead of three gathers + activations and three scatter-adds.  The
+    features are gathered apart (_GatherFeat): their gradient is complete only after the MLPs' backward, these three right
+    behind the rasterizer's — a data-parallel step starts their all-reduce that much earlier (gsvc_amd.dist.GradReducer)."""
+
+    @staticmethod
+    def forward(ctx, offset_p, scaling_p, mask_p, vis, decoded):
+        from . import _lib
+        dev = offset_p.device
+        offset_p, scaling_p, mask_p, vis = (t.contiguous() for t in (offset_p, scaling_p, mask_p, vis))
+        rows, K, S = vis.shape[0], offset_p.shape[1], scaling_p.shape[1]
         f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
-        feat, off, scal, mask = f(rows, F), f(rows, K, 3), f(rows, S), f(rows, K, 1)
-        _lib.check(_lib.lib().gsvc_gather_rows_forward(_lib.ptr(feat_p), _lib.ptr(offset_p), _lib.ptr(scaling_p), _lib.ptr(mask_p),
-                                                       _lib.ptr(vis), rows, F, K, S, int(decoded), _lib.ptr(feat), _lib.ptr(off),
+        off, scal, mask = f(rows, K, 3), f(rows, S), f(rows, K, 1)
+        _lib.check(_lib.lib().gsvc_gather_rows_forward(None, _lib.ptr(offset_p), _lib.ptr(scaling_p), _lib.ptr(mask_p),
+                                                       _lib.ptr(vis), rows, 0, K, S, int(decoded), None, _lib.ptr(off),
                                                        _lib.ptr(scal), _lib.ptr(mask), _lib.current_stream(dev)),
                    "gsvc_gather_rows_forward")
         ctx.save_for_backward(scaling_p, mask_p, vis)
-        ctx.dims = (feat_p.shape, offset_p.shape, F, K, S, bool(decoded))
+        ctx.dims = (offset_p.shape, K, S, bool(decoded))
         ctx.set_materialize_grads(False)      # an output nothing differentiates (detached STE modes) gives no gradient, not zeros
-        return feat, off, scal, mask
+        return off, scal, mask
 
     @staticmethod
-    def backward(ctx, g_feat, g_off, g_scal, g_mask):
+    def backward(ctx, g_off, g_scal, g_mask):
         from . import _lib
         scaling_p, mask_p, vis = ctx.saved_tensors
-        fshape, oshape, F, K, S, decoded = ctx.dims
+        oshape, K, S, decoded = ctx.dims
         dev = vis.device
         need = ctx.needs_input_grad
         z = lambda sh: torch.zeros(sh, device=dev, dtype=torch.float32)  # noqa: E731
         c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
-        d_feat = z(fshape) if need[0] and g_feat is not None else None
-        d_off = z(oshape) if need[1] and g_off is not None else None
-        d_scal = z(scaling_p.shape) if need[2] and g_scal is not None else None
-        d_mask = z(mask_p.shape) if need[3] and g_mask is not None else None
-        g_feat, g_off, g_scal, g_mask = c(g_feat), c(g_off), c(g_scal), c(g_mask)
-        _lib.check(_lib.lib().gsvc_gather_rows_backward(_lib.ptr(scaling_p), _lib.ptr(mask_p), _lib.ptr(vis), vis.shape[0], F, K, S,
-                                                        int(decoded), _lib.ptr(g_feat), _lib.ptr(g_off), _lib.ptr(g_scal),
-                                                        _lib.ptr(g_mask), _lib.ptr(d_feat), _lib.ptr(d_off), _lib.ptr(d_scal),
+        d_off = z(oshape) if need[0] and g_off is not None else None
+        d_scal = z(scaling_p.shape) if need[1] and g_scal is not None else None
+        d_mask = z(mask_p.shape) if need[2] and g_mask is not None else None
+        g_off, g_scal, g_mask = c(g_off), c(g_scal), c(g_mask)
+        _lib.check(_lib.lib().gsvc_gather_rows_backward(_lib.ptr(scaling_p), _lib.ptr(mask_p), _lib.ptr(vis), vis.shape[0], 0, K, S,
+                                                        int(decoded), None, _lib.ptr(g_off), _lib.ptr(g_scal),
+                                                        _lib.ptr(g_mask), None, _lib.ptr(d_off), _lib.ptr(d_scal),
                                                         _lib.ptr(d_mask), _lib.current_stream(dev)), "gsvc_gather_rows_backward")
-        return d_feat, d_off, d_scal, d_mask, None, None
+        return d_off, d_scal, d_mask, None, None
 
 
 def _gather_rows(pc, vis):
     """(feat, grid_offsets, grid_scaling, offset_masks) of the visible rows."""
     if (pc._anchor_feat.is_cuda and vis.dtype == torch.int64 and pc._mask.dim() == 3 and pc._mask.shape[2] == 1
             and pc._offset.dim() == 3 and pc._offset.shape[2] == 3 and not os.environ.get("GSVC_NO_FUSED_GATHER")):
-        return _GatherRows.apply(pc._anchor_feat, pc._offset, pc._scaling, pc._mask, vis, bool(pc.decoded_version))
+        feat = _GatherFeat.apply(pc._anchor_feat, vis)
+        return (feat,) + tuple(_GatherRows.apply(pc._offset, pc._scaling, pc._mask, vis, bool(pc.decoded_version)))
     return (pc._anchor_feat.index_select(0, vis), pc._offset.index_select(0, vis), _visible_scaling(pc, vis), _visible_mask(pc, vis))
 
 

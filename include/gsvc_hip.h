@@ -348,7 +348,8 @@ int gsvc_ans_decode(const uint8_t *bytes, const uint64_t *seg_offsets, const flo
 /* Per-anchor parameters of the batch's rows (reference ortho_gaussian_renderer/guassian.py:160-176 + the getters of
  * scene/gaussian_model.py:641-700), v = vis[row]: feat = anchor_feat[v] [rows,F], offsets = offset[v] [rows,3K], scaling =
  * exp(scaling_p[v]) [rows,S], mask = straight-through (sigmoid(mask_p[v]) > 0.01) [rows,K]; decoded != 0: the stored values as
- * they are.  Backward ADDS into the dense, caller-zeroed d_* (an anchor is visible in several renders); g_* may be NULL. */
+ * they are.  F, K or S may be 0 (that group is left out: its pointers are not read).  Backward ADDS into the dense, caller-zeroed
+ * d_* (an anchor is visible in several renders); g_* may be NULL. */
 int gsvc_gather_rows_forward(const float *feat_p, const float *offset_p, const float *scaling_p, const float *mask_p,
                              const int64_t *vis, int64_t rows, int32_t F, int32_t K, int32_t S, int32_t decoded, float *feat,
                              float *offsets, float *scaling, float *mask, void *stream);
