@@ -283,7 +283,15 @@ def run_train_step(args, rank, world, dev):
         nonlocal active
         active += step().active_gaussians
 
+    mem0 = torch.cuda.memory_stats(dev)
+    rep0 = getattr(trainer, "repeated_steps", 0)
     elapsed = timed(torch, dist, world, counted, args.steps)
+    mem1 = torch.cuda.memory_stats(dev)
+    timed_region = {"device_mallocs": int(mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0)),
+                    "device_frees": int(mem1.get("num_device_free", 0) - mem0.get("num_device_free", 0)),
+                    "alloc_retries": int(mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0)),
+                    "repeated_steps": int(getattr(trainer, "repeated_steps", 0) - rep0),
+                    "reserved_GiB": round(mem1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2)}
     total_units, elapsed = reduce_sum_max(torch, dist, world, dev, active.item(), elapsed)
 
     # exposed communication: the same K steps with the gradient exchange switched off (replicas diverge: last thing
@@ -373,6 +381,7 @@ def run_train_step(args, rank, world, dev):
                              "same command (share of the kernel's cycles its SIMDs spent executing vector instructions)",
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": kern[dom]["avg_us"]},
         "gsvc_kernel_us_per_step": kernel_us,
+        "timed_region": timed_region,
         "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] / args.steps} for k, v in kern.items()},
         "render_pair_fps_end_to_end": pair_fps,
         "render_frames_fps_end_to_end": frames_fps,

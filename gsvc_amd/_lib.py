@@ -98,6 +98,8 @@ _SIGNATURES = {
     "gsvc_gather_rows_backward": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [_vp] * 9),
     "gsvc_ctx_post_forward": (C.c_int, [_vp, _vp, _i64, C.c_int32, _vp, _vp, _vp, _vp]),
     "gsvc_ctx_post_backward": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_film_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "gsvc_film_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gsvc_embed_pe": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_int32, C.c_int32, _vp, _vp]),
     "gsvc_optical_forward": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, C.c_int32, _i64, _vp, C.c_int32, C.c_int32,
                                        C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),

@@ -169,7 +169,14 @@ class _Generator(torch.autograd.Function):
         beta = linear_ex(cb, Wb1, bb1)
         cg = linear_ex(condition, Wg0, bg0, EPI_RELU)
         x3 = f(Wg1.shape[0])
-        gamma = linear_ex(cg, Wg1, bg1, EPI_FILM, aux1=h, aux2=beta, y2=x3)            # gamma and x3 = gamma * h + beta
+        if (M * Wg1.shape[0]) % 4 == 0:
+            # the FiLM combine as a streaming kernel: whole-line accesses; as the gamma GEMM's epilogue (EPI_FILM) the same
+            # traffic costs ~25 us more per call (64-byte pieces of 400-byte rows)
+            gamma = linear_ex(cg, Wg1, bg1)
+            _lib.check(_lib.lib().gsvc_film_forward(_lib.ptr(gamma), _lib.ptr(h), _lib.ptr(beta), _lib.ptr(x3), gamma.numel(),
+                                                    _lib.current_stream(dev)), "gsvc_film_forward")
+        else:
+            gamma = linear_ex(cg, Wg1, bg1, EPI_FILM, aux1=h, aux2=beta, y2=x3)        # gamma and x3 = gamma * h + beta
         y = linear_ex(x3, W3, b3, (EPI_NONE, EPI_TANH, EPI_SIGMOID)[act])
         ctx.act = act
         ctx.save_for_backward(feature, condition, z1, a1, h, cb, cg, gamma, x3, y, W1, W2, Wg0, Wg1, Wb0, Wb1, W3)
@@ -193,7 +200,12 @@ class _Generator(torch.autograd.Function):
         M, dev = feature.shape[0], feature.device
         gg = torch.empty(M, h.shape[1], device=dev, dtype=torch.float32)
         gh = torch.empty_like(gg)
-        gbeta = linear_ex(go, W3, None, EPI_FILM_GRAD, aux1=h, aux2=gamma, y2=gg, y3=gh, w_in_out=True)
+        if gg.numel() % 4 == 0:
+            gbeta = linear_ex(go, W3, None, w_in_out=True)
+            _lib.check(_lib.lib().gsvc_film_backward(_lib.ptr(gbeta), _lib.ptr(h), _lib.ptr(gamma), _lib.ptr(gg), _lib.ptr(gh),
+                                                     gg.numel(), _lib.current_stream(dev)), "gsvc_film_backward")
+        else:
+            gbeta = linear_ex(go, W3, None, EPI_FILM_GRAD, aux1=h, aux2=gamma, y2=gg, y3=gh, w_in_out=True)
         P[10], P[11] = wg.add(gbeta, cb)
         gcb = linear_ex(gbeta, Wb1, None, EPI_MUL_RELU_MASK, aux1=cb, w_in_out=True)
         P[8], P[9] = wg.add(gcb, condition)

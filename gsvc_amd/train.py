@@ -118,6 +118,7 @@ class Trainer:
             frame_idx = self._plan_idx              # drawn (from the same generator, in the same order) at the end of the last step
         out = self._step(iteration, frame_idx)
         if out is None:      # a rasterizer instance buffer overflowed (capacity now raised): repeat the step
+            self.repeated_steps = getattr(self, "repeated_steps", 0) + 1
             self.pc.optimizer.zero_grad(set_to_none=True)
             out = self._step(iteration, frame_idx if frame_idx is not None else self._last_idx)     # the same frame pair again
             if out is None:

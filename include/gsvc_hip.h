@@ -364,6 +364,11 @@ int gsvc_ctx_post_forward(const float *params, const float *q, int64_t n, int32_
 int gsvc_ctx_post_backward(const float *params, const float *q, const float *adj, int64_t n, int32_t C, const float *g_mean,
                            const float *g_scale, const float *g_adj, float *dparams, float *dq, void *stream);
 
+/* FiLM of the generator networks (reference scene/gaussian_model.py:150-166) over n = rows * features elements (a multiple
+ * of 4, 16-byte aligned tensors): y = gamma * h + beta; backward of the product: dgamma = g * h, dh = g * gamma. */
+int gsvc_film_forward(const float *gamma, const float *h, const float *beta, float *y, int64_t n, void *stream);
+int gsvc_film_backward(const float *g, const float *h, const float *gamma, float *dgamma, float *dh, int64_t n, void *stream);
+
 /* Conditioning input of the generator / deformation MLPs for the concatenated rows of `renders` (<= 16) views (reference
  * ortho_gaussian_renderer/guassian.py:225-230, utils/time_util.py:7-55): pe[row] = [embed(cam_z[r]) | embed(anchor[row].z -
  * cam_z[r])] for the rows row_bounds[r] <= row < row_bounds[r + 1]; embed(x) = [x, sin(2^k x), cos(2^k x)]_{k < freqs}.
