@@ -162,11 +162,10 @@ class _GatherRows(torch.autograd.Function):
         oshape, K, S, decoded = ctx.dims
         dev = vis.device
         need = ctx.needs_input_grad
-        z = lambda sh: torch.zeros(sh, device=dev, dtype=torch.float32)  # noqa: E731
         c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
-        d_off = z(oshape) if need[0] and g_off is not None else None
-        d_scal = z(scaling_p.shape) if need[1] and g_scal is not None else None
-        d_mask = z(mask_p.shape) if need[2] and g_mask is not None else None
+        d_off, d_scal, d_mask = _zeros_many([oshape if need[0] and g_off is not None else None,
+                                             scaling_p.shape if need[1] and g_scal is not None else None,
+                                             mask_p.shape if need[2] and g_mask is not None else None], dev)
         g_off, g_scal, g_mask = c(g_off), c(g_scal), c(g_mask)
         _lib.check(_lib.lib().gsvc_gather_rows_backward(_lib.ptr(scaling_p), _lib.ptr(mask_p), _lib.ptr(vis), vis.shape[0], 0, K, S,
                                                         int(decoded), None, _lib.ptr(g_off), _lib.ptr(g_scal),
@@ -215,27 +214,31 @@ class StepPlan:
         c = torch.cumsum(M.view(-1), dim=0)
         ends = c[A - 1::A]
         cnt_t = torch.diff(ends, prepend=ends.new_zeros(1))
-        self._flat = torch.nonzero_static(M.view(-1), size=R * A).squeeze(1)
         present = M.any(dim=0)
         pos_incl = torch.cumsum(present, dim=0)
-        self._distinct = torch.nonzero_static(present, size=A).squeeze(1)
         self.pos = pos_incl - 1                                          # anchor -> row of the distinct list
         counts = [cnt_t, pos_incl[-1:]]
-        self._sel_flat = None
+        chosen = None
         if sample:
             # the rate sample in anchor space: a row is (render r, visible anchor a); its position in the concatenated rows is
-            # (visible anchors of the renders before r) + (rank of a among render r's visible anchors)
+            # (visible anchors of the renders before r) + (rank of a among render r's visible anchors) = c - 1
             with torch.no_grad():
                 live = pc.get_mask.reshape(A, -1).sum(dim=1) > 0          # mask_anchor for every anchor
             chosen = M & live.unsqueeze(0) & (torch.rand(R, A, device=dev) <= SAMPLE_RATE)
-            pick = torch.nonzero_static(chosen.view(-1), size=R * A).squeeze(1)       # in (r, a) order = row order
-            self._sel_flat = c.index_select(0, pick.clamp_min(0)) - 1
             counts.append(chosen.sum().reshape(1))
+        # the counts leave for the host FIRST: the next step waits for them only, and the compactions below (the bulk of the
+        # plan's GPU time) run while the host is already launching that step
         self._A = A
         self._host = torch.empty(R + 1 + (1 if sample else 0), dtype=torch.int64, pin_memory=True)
         self._host.copy_(torch.cat(counts), non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
+        self._flat = torch.nonzero_static(M.view(-1), size=R * A).squeeze(1)
+        self._distinct = torch.nonzero_static(present, size=A).squeeze(1)
+        self._sel_flat = None
+        if sample:
+            pick = torch.nonzero_static(chosen.view(-1), size=R * A).squeeze(1)       # in (r, a) order = row order
+            self._sel_flat = c.index_select(0, pick.clamp_min(0)) - 1
         self.vis_list = self.distinct = self.sel = None
 
     def matches(self, pc) -> bool:
@@ -495,6 +498,19 @@ def _seg_ste(x, Q, seg, x_mean):
     return (x + (torch.round(x / Q) * Q - x).detach()).detach()
 
 
+def _zeros_many(shapes, device):
+    """Zero tensors of the given shapes (None -> None) carved from ONE zero-filled buffer: one fill launch instead of one per tensor
+    (a backward that scatters into a dozen dense gradients otherwise starts with a dozen memsets)."""
+    sizes = [0 if sh is None else int(torch.Size(sh).numel()) for sh in shapes]
+    padded = [(n + 3) // 4 * 4 for n in sizes]           # keep every tensor 16-byte aligned
+    flat = torch.zeros(max(sum(padded), 1), device=device, dtype=torch.float32)
+    out, at = [], 0
+    for sh, n, p in zip(shapes, sizes, padded):
+        out.append(None if sh is None else flat[at:at + n].view(sh))
+        at += p
+    return out
+
+
 class _SampledRate(torch.autograd.Function):
     """S[R, 3]: bits of the sampled rows' features / scalings / offsets summed per render (csrc/rate.hip k_rate_sample): gathers
     by row index, per-render clamp bounds, the offset mask and the per-render sums in one launch; the backward writes straight
@@ -542,12 +558,10 @@ class _SampledRate(torch.autograd.Function):
         xs, means, scales, Qs, mask, scratch = t[0:3], t[3:6], t[6:9], t[9:12], t[12], t[15]
         dev = mask.device
         need = ctx.needs_input_grad
-        z = torch.zeros_like
-        dx = [z(xs[g]) if need[g] else None for g in range(3)]
-        dmask = z(mask) if need[3] else None
-        dQ = [z(Qs[g]) if need[4 + g] else None for g in range(3)]
-        dmean = [z(means[g]) if need[7 + 2 * g] else None for g in range(3)]
-        dscale = [z(scales[g]) if need[8 + 2 * g] else None for g in range(3)]
+        sh = lambda t, ok: t.shape if ok else None  # noqa: E731
+        zs = _zeros_many([sh(xs[g], need[g]) for g in range(3)] + [sh(mask, need[3])] + [sh(Qs[g], need[4 + g]) for g in range(3)] +
+                         [sh(means[g], need[7 + 2 * g]) for g in range(3)] + [sh(scales[g], need[8 + 2 * g]) for g in range(3)], dev)
+        dx, dmask, dQ, dmean, dscale = zs[0:3], zs[3], zs[4:7], zs[7:10], zs[10:13]
         arr = lambda ts: (C.c_void_p * 3)(*[x.data_ptr() if x is not None else None for x in ts])  # noqa: E731
         _lib.check(_lib.lib().gsvc_rate_sample_backward(C.byref(ctx.desc), _lib.ptr(scratch), _lib.ptr(gS.contiguous()), arr(dx),
                                                         arr(dmean), arr(dscale), arr(dQ), _lib.ptr(dmask),
