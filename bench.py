@@ -373,6 +373,8 @@ def run_train_step(args, rank, world, dev):
                    "gaussians_per_render": P, "active_per_render": n_vis, "instances_per_render": n_inst,
                    "visible_anchors_per_render": P / pc.n_offsets,
                    "parallelism": f"frame-shard x{world} + gradient all-reduce" if world > 1 else "single GPU"},
+        "dp_anchor_optimizer": ("reduce-scatter + sharded Adam + all-gather" if trainer.sharded is not None else
+                                ("all-reduce + replicated Adam" if world > 1 else None)),
         "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
         "dist_backend": (dist.get_backend() if world > 1 else None),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

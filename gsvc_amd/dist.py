@@ -1,5 +1,6 @@
 """Multi-GPU data parallelism for the fitting loop: frames of one video shard across the GPUs of a node,
-parameters are replicated, gradients are summed with one RCCL all-reduce per step over xGMI.
+parameters are replicated, gradients are summed with one RCCL all-reduce per step over xGMI — or, for the per-anchor tensors,
+reduce-scattered over anchor ranges with the Adam update sharded and the updated ranges all-gathered (ShardedAnchorAdam).
 
 The reference is single-GPU (no torch.distributed / NCCL anywhere); this layer is new.
 One process per GPU (torchrun / torch.distributed.run), backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" in
@@ -85,8 +86,9 @@ class GradReducer:
 
     SMALL = 1 << 18     # elements; below this a tensor joins the flat bucket
 
-    def __init__(self, average: bool = True):
+    def __init__(self, average: bool = True, sharded: "ShardedAnchorAdam | None" = None):
         self.average = average
+        self.sharded = sharded      # per-anchor tensors: reduce-scatter + sharded Adam + all-gather instead of all-reduce
         self.enabled = True         # False: no exchange at all (bench.py measures the step without it; replicas diverge)
         self._hooked = {}           # id(param) -> (param, handle of the hook)
         self._pending = []          # (work, grad) of the collectives in flight
@@ -104,13 +106,16 @@ class GradReducer:
         for k in [k for k in self._hooked if k not in live]:
             self._hooked.pop(k)[1].remove()
         for p in self._params:
-            if id(p) not in self._hooked and p.numel() >= self.SMALL:
+            if id(p) not in self._hooked and (p.numel() >= self.SMALL or (self.sharded is not None and self.sharded.owns(p))):
                 self._hooked[id(p)] = (p, p.register_post_accumulate_grad_hook(self._on_grad))
         self._pending = []
         self._armed = True
 
     def _on_grad(self, p):
         if self._armed and p.grad is not None:
+            if self.sharded is not None and self.sharded.owns(p):
+                self.sharded.start(p)          # reduce-scatter of this gradient; its Adam step + all-gather follow in step()
+                return
             self._pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p.grad))
 
     def finish(self):
@@ -121,6 +126,11 @@ class GradReducer:
             return 0
         self._armed = False
         done = {id(g) for _, g in self._pending}
+        if self.sharded is not None:
+            for p in self._params:             # (a sharded parameter whose hook did not fire, e.g. hooks armed late: start it now)
+                if p.grad is not None and self.sharded.owns(p):
+                    self.sharded.start(p)
+                    done.add(id(p.grad))
         small = [p.grad for p in self._params if p.grad is not None and id(p.grad) not in done]
         n = sum(g.numel() for _, g in self._pending)
         if small:
@@ -137,6 +147,160 @@ class GradReducer:
             torch._foreach_div_([g for _, g in self._pending] + small, float(w))
         self._pending = []
         return n
+
+
+class ShardedAnchorAdam:
+    """the per-anchor tensors (``_offset``, ``_mask``, ``_anchor_feat``, ``_scaling``: 96 floats per anchor, ~95 % of
+    the gradient bytes) are exchanged by REDUCE-SCATTER over anchor ranges, each rank runs Adam on its own range only (it holds
+    the Adam moments of that range only) and the updated ranges are ALL-GATHERED — instead of an all-reduce followed by W
+    identical Adam updates of everything.  Same bytes on the links (a ring all-reduce is a reduce-scatter + an all-gather), 1/W of
+    the optimizer work and of its state per rank, same numbers as the replicated update (tests/test_dist_cpu.py).
+
+    Range r of a tensor with A rows = rows [r S, min(A, (r + 1) S)), S = ceil(A / W).  The moments live here, not in the wrapped
+    optimizer (whose step skips these parameters: their .grad is cleared); ``gather_state`` puts full-size moments into
+    ``optimizer.state`` for code that edits them (anchor growing / pruning, checkpoints), ``adopt_state`` takes them back."""
+
+    NAMES = ("offset", "mask", "anchor_feat", "scaling")
+
+    def __init__(self, optimizer, names=NAMES):
+        self.optimizer, self.names = optimizer, tuple(names)
+        self._state = {}        # id(param) -> dict(step, m, v, S)
+        self._work = {}         # id(param) -> (param, work handle, padded gradient buffer, reduced shard)
+        self.adopt_state()
+
+    # ---- which parameters
+    def _groups(self):
+        return [g for g in self.optimizer.param_groups if g.get("name") in self.names]
+
+    def params(self):
+        return [p for g in self._groups() for p in g["params"]]
+
+    def owns(self, p) -> bool:
+        return any(p is q for q in self.params())
+
+    @staticmethod
+    def _geometry(p):
+        A = p.shape[0]
+        w = p.numel() // max(A, 1)
+        W, r = world_size(), rank()
+        S = (A + W - 1) // W
+        lo = min(A, r * S)
+        hi = min(A, lo + S)
+        return A, w, S, lo, hi
+
+    # ---- per step
+    def start(self, p):
+        """Queue the reduce-scatter of p.grad (from the gradient hook: overlaps the rest of the backward)."""
+        if id(p) in self._work:
+            return
+        A, w, S, lo, hi = self._geometry(p)
+        W = world_size()
+        buf = torch.zeros(S * W, w, device=p.device, dtype=p.dtype)
+        buf[:A].copy_(p.grad.reshape(A, w))
+        out = torch.empty(S, w, device=p.device, dtype=p.dtype)
+        work = dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, async_op=True)
+        self._work[id(p)] = (p, work, buf, out)
+
+    def step(self, average: bool = True, skip_update: bool = False):
+        """Adam on this rank's range of every started tensor, then all-gather of the updated ranges; clears the .grad of the
+        sharded parameters (the wrapped optimizer must not step them).  ``skip_update``: only complete the collectives (the
+        parameters were replaced by anchor growing / pruning after the backward: as in the reference, that iteration's
+        gradient is dropped)."""
+        W = world_size()
+        lr_of = {id(p): float(g["lr"]) for g in self._groups() for p in g["params"]}
+        hp = {id(p): (g["betas"], float(g["eps"])) for g in self._groups() for p in g["params"]}
+        jobs = []
+        for key, (p, work, buf, out) in list(self._work.items()):
+            work.wait()
+            if skip_update or key not in lr_of:
+                continue
+            A, w, S, lo, hi = self._geometry(p)
+            st = self._state.get(key)
+            if st is None or st["S"] != S or st["m"].shape[1] != w:
+                st = self._state[key] = {"step": 0, "S": S, "m": torch.zeros(S, w, device=p.device, dtype=p.dtype),
+                                         "v": torch.zeros(S, w, device=p.device, dtype=p.dtype)}
+            st["step"] += 1
+            g = out.div_(W) if average else out
+            jobs.append((p, g, st, lr_of[key], hp[key], (A, w, S, lo, hi)))
+        self._work.clear()
+        if jobs:
+            self._adam(jobs)
+            for p, g, st, lr, _, (A, w, S, lo, hi) in jobs:
+                shard = torch.zeros(S, w, device=p.device, dtype=p.dtype)
+                shard[:hi - lo].copy_(p.data.reshape(A, w)[lo:hi])
+                full = torch.empty(S * W, w, device=p.device, dtype=p.dtype)
+                dist.all_gather_into_tensor(full, shard)
+                p.data.reshape(A, w).copy_(full[:A])
+        for p in self.params():
+            p.grad = None
+
+    def _adam(self, jobs):
+        """torch.optim.Adam's update (no weight decay / amsgrad) on each job's row range; one multi-tensor launch on the GPU."""
+        p0 = jobs[0][0]
+        if p0.is_cuda:
+            from . import _lib
+            jobs = [j for j in jobs if j[5][4] > j[5][3]]            # (a rank whose range is empty has nothing to update)
+            if not jobs:
+                return
+            arr = (_lib.AdamTensorC * len(jobs))()
+            keep = []
+            b1 = b2 = eps = None
+            for e, (p, g, st, lr, ((bb1, bb2), ee), (A, w, S, lo, hi)) in zip(arr, jobs):
+                if b1 is None:
+                    b1, b2, eps = float(bb1), float(bb2), ee
+                elif (float(bb1), float(bb2), ee) != (b1, b2, eps):
+                    raise NotImplementedError("ShardedAnchorAdam: one (betas, eps) for all groups")
+                rows = p.data.reshape(A, w)[lo:hi]
+                n = (hi - lo) * w
+                gg, m, v = g[:hi - lo].contiguous(), st["m"], st["v"]
+                keep.append(gg)
+                e.param, e.grad, e.exp_avg, e.exp_avg_sq = rows.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr()
+                e.n, e.lr = n, lr
+                e.bias_correction1, e.bias_correction2 = 1.0 - b1 ** st["step"], 1.0 - b2 ** st["step"]
+            _lib.check(_lib.lib().gsvc_adam_step(len(jobs), arr, b1, b2, eps, _lib.current_stream(p0.device)), "gsvc_adam_step")
+            return
+        for p, g, st, lr, ((b1, b2), eps), (A, w, S, lo, hi) in jobs:
+            n = hi - lo
+            if n <= 0:
+                continue
+            rows, gg, m, v = p.data.reshape(A, w)[lo:hi], g[:n], st["m"][:n], st["v"][:n]
+            m.lerp_(gg, 1 - b1)
+            v.mul_(b2).addcmul_(gg, gg, value=1 - b2)
+            bc1, bc2 = 1 - b1 ** st["step"], 1 - b2 ** st["step"]
+            denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+            rows.addcdiv_(m, denom, value=-lr / bc1)
+
+    # ---- full-size state for code that edits it
+    def gather_state(self):
+        """Full-size ``exp_avg`` / ``exp_avg_sq`` / ``step`` of the sharded parameters into ``optimizer.state`` (all ranks)."""
+        W = world_size()
+        for p in self.params():
+            st = self._state.get(id(p))
+            A, w, S, lo, hi = self._geometry(p)
+            full = {}
+            for k in ("m", "v"):
+                shard = st[k] if st is not None else torch.zeros(S, w, device=p.device, dtype=p.dtype)
+                buf = torch.empty(S * W, w, device=p.device, dtype=p.dtype)
+                dist.all_gather_into_tensor(buf, shard.contiguous())
+                full[k] = buf[:A].reshape(p.shape).clone()
+            self.optimizer.state[p] = {"step": torch.tensor(float(st["step"] if st is not None else 0)),
+                                       "exp_avg": full["m"], "exp_avg_sq": full["v"]}
+
+    def adopt_state(self):
+        """Take this rank's range of whatever full-size moments ``optimizer.state`` holds for the sharded parameters (after
+        anchor growing / pruning, a checkpoint load, or at start) and drop the full-size copies."""
+        self._state = {}
+        for p in self.params():
+            full = self.optimizer.state.get(p)
+            if not full or "exp_avg" not in full:
+                continue
+            A, w, S, lo, hi = self._geometry(p)
+            st = {"step": int(float(full["step"])), "S": S, "m": torch.zeros(S, w, device=p.device, dtype=p.dtype),
+                  "v": torch.zeros(S, w, device=p.device, dtype=p.dtype)}
+            st["m"][:hi - lo].copy_(full["exp_avg"].reshape(A, w)[lo:hi])
+            st["v"][:hi - lo].copy_(full["exp_avg_sq"].reshape(A, w)[lo:hi])
+            self._state[id(p)] = st
+            del self.optimizer.state[p]
 
 
 def allreduce_statistics(pc):

@@ -9,6 +9,7 @@ collective (gsvc_amd/dist.py).  Anchor growing/pruning runs at the reference's c
 """
 from __future__ import annotations
 
+import os
 import random
 from dataclasses import dataclass
 
@@ -86,12 +87,12 @@ def _mean_over_selected(values, r):
 
 
 class Trainer:
-    def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0, batched: bool = True, prefetch: bool = True):
+    def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0, batched: bool = True, prefetch: bool = True,
+                 shard_optimizer: bool = False):
         self.batched = batched
         # prefetch: the next step's frame pair is drawn, its visibility test run and every data-dependent index list of its
         # generation pass queued at the END of a step (gsvc_amd.generate.StepPlan): the next step then starts with one wait
         # for nine counts instead of six device round trips with an idle GPU
-        import os
         self.prefetch = prefetch and batched and not os.environ.get("GSVC_NO_PREFETCH")      # env: A/B timing only
         self._plan = self._plan_idx = self._plan_mode = None
         self.pc, self.dataset, self.opt, self.pipe, self.mp = gaussians, dataset, opt, pipe, model_params
@@ -104,7 +105,29 @@ class Trainer:
         # anchors are trained with learning rate 0 in GSVC (position_lr_init = position_lr_final = 0): their gradient
         # changes nothing, so the batched step does not compute it unless a non-zero rate is configured
         self.anchor_grad = bool(getattr(opt, "position_lr_init", 0.0) or getattr(opt, "position_lr_final", 0.0))
-        self.reducer = gdist.GradReducer()
+        # GSVC_DP_SHARD=1 (or shard_optimizer=True): reduce-scatter + sharded Adam + all-gather for the per-anchor tensors
+        #  instead of all-reduce + replicated Adam; same parameters after the step (tests/test_dist_cpu.py)
+        self.sharded = None
+        if (shard_optimizer or os.environ.get("GSVC_DP_SHARD")) and gdist.world_size() > 1 and gaussians.optimizer is not None:
+            self.sharded = gdist.ShardedAnchorAdam(gaussians.optimizer)
+        self.reducer = gdist.GradReducer(sharded=self.sharded)
+
+    def full_optimizer_state(self):
+        """Context manager around code that reads or edits ``pc.optimizer.state`` of the per-anchor tensors (checkpoints,
+        ``capture()``): under GSVC_DP_SHARD the Adam moments live range by range on the ranks; inside the block every rank
+        holds them full size (collective: all ranks must enter)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            if self.sharded is not None:
+                self.sharded.gather_state()
+            try:
+                yield self.pc.optimizer
+            finally:
+                if self.sharded is not None:
+                    self.sharded.adopt_state()
+        return scope()
 
     def _two_views(self, frame, mode, retain_grad):
         f = render(frame, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode)
@@ -247,10 +270,20 @@ class Trainer:
                 else:
                     for r in renders:
                         pc.training_statis(r)
+            adjusted = False
             if self.controller.gaussian_adjust_anchor:
+                if self.sharded is not None:
+                    self.sharded.gather_state()           # anchor growing / pruning edits full-size Adam moments
                 self._adjust_anchor(iteration)
+                adjusted = True
             if self.controller.clean_denorm:
                 pc.opacity_accum = pc.offset_gradient_accum = pc.offset_denom = None
+            if self.sharded is not None:
+                # the reduce-scatters started in the backward complete here; after an adjust_anchor the parameters are new
+                # tensors without a gradient (the reference drops that iteration's update for them as well)
+                self.sharded.step(skip_update=adjusted or not iteration < opt.iterations)
+                if adjusted:
+                    self.sharded.adopt_state()
             if iteration < opt.iterations:
                 pc.optimizer.step()
                 pc.optimizer.zero_grad(set_to_none=True)

@@ -109,6 +109,81 @@ def test_two_rank_gloo():
     assert w0 == w1                                   # broadcast made the replicas identical
 
 
+def _sharded_worker(rank, world, port, q):
+    """ShardedAnchorAdam (reduce-scatter over anchor ranges + sharded Adam + all-gather) against a single-process torch Adam
+    on the rank-averaged gradients: same parameters on every rank after every step, same moments when gathered."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from gsvc_amd import dist as gd
+    gd.init_from_env("gloo")
+    A = 7                                             # not a multiple of the world size: the last range is short
+    shapes = {"offset": (A, 2, 3), "mask": (A, 2, 1), "anchor_feat": (A, 5), "scaling": (A, 6), "mlp": (4, 3)}
+    lrs = {"offset": 0.01, "mask": 0.02, "anchor_feat": 0.0075, "scaling": 0.007, "mlp": 0.005}
+
+    def build():
+        torch.manual_seed(1)
+        ps = {k: torch.nn.Parameter(torch.randn(*sh)) for k, sh in shapes.items()}
+        opt = torch.optim.Adam([{"params": [ps[k]], "lr": lrs[k], "name": k} for k in shapes], lr=0.0, eps=1e-15)
+        return ps, opt
+
+    def coeff(k, r, step):                            # d loss / d p on rank r at `step`
+        g = torch.Generator().manual_seed(100 * step + 10 * r + len(k))
+        return torch.randn(*shapes[k], generator=g)
+
+    ps, opt = build()
+    ref_ps, ref_opt = build()
+    sh = gd.ShardedAnchorAdam(opt)
+    red = gd.GradReducer(sharded=sh)
+    assert sorted(n for n in shapes if sh.owns(ps[n])) == ["anchor_feat", "mask", "offset", "scaling"]
+    for step in range(1, 5):
+        red.arm(list(ps.values()))
+        sum((ps[k] * coeff(k, rank, step)).sum() for k in shapes).backward()
+        red.finish()
+        assert torch.allclose(ps["mlp"].grad, sum(coeff("mlp", r, step) for r in range(world)) / world, atol=1e-6)
+        if step == 3:                                 # state round trip through the wrapped optimizer (what anchor growing edits)
+            sh.gather_state()
+            for k in ("offset", "scaling"):
+                assert torch.allclose(opt.state[ps[k]]["exp_avg"], ref_opt.state[ref_ps[k]]["exp_avg"], atol=1e-7)
+                assert torch.allclose(opt.state[ps[k]]["exp_avg_sq"], ref_opt.state[ref_ps[k]]["exp_avg_sq"], atol=1e-9)
+            sh.adopt_state()
+            assert ps["offset"] not in opt.state
+        sh.step()
+        assert all(ps[k].grad is None for k in ("offset", "mask", "anchor_feat", "scaling"))
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        for k in shapes:
+            ref_ps[k].grad = sum(coeff(k, r, step) for r in range(world)) / world
+        ref_opt.step()
+        for k in shapes:
+            assert torch.allclose(ps[k], ref_ps[k], atol=2e-7), (step, k, (ps[k] - ref_ps[k]).abs().max().item())
+            other = [torch.zeros_like(ps[k]) for _ in range(world)]
+            dist.all_gather(other, ps[k].data)
+            assert torch.equal(other[0], other[1]), (step, k)       # replicas stay identical
+    # a step whose parameters were replaced after the backward completes its collectives and updates nothing
+    before = {k: ps[k].detach().clone() for k in shapes}
+    red.arm(list(ps.values()))
+    sum((ps[k] * coeff(k, rank, 9)).sum() for k in shapes).backward()
+    red.finish()
+    sh.step(skip_update=True)
+    assert all(torch.equal(ps[k], before[k]) for k in ("offset", "mask", "anchor_feat", "scaling"))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_sharded_anchor_adam_two_rank_gloo():
+    world, port = 2, 29500 + (os.getpid() + 7) % 400
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(world)) == [0, 1]
+
+
 def test_frame_shard_partitions():
     from gsvc_amd.dist import frame_shard
     with pytest.raises(ValueError, match="adjacent-frame pairs"):
