@@ -711,6 +711,16 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     rates = [RatePack() for _ in range(R)]
     Q_feat, Q_scaling, Q_offsets = BASE_Q_FEAT, BASE_Q_SCALING, BASE_Q_OFFSETS
     time_sub = 0
+    # the conditioning input and the generators' FiLM networks depend on the anchors' z only: issued FIRST, their twelve large
+    # GEMMs keep the GPU busy while the host queues the entropy context's many small launches (a step starts host-bound)
+    with region('gen.embed'):
+        pe = _embed_rows(pc, frames, anchor, seg)
+    films = {}
+    if trunks is None:
+        with region('gen.film'):
+            for name in ("get_opacity_mlp", "get_color_mlp", "get_cov_mlp"):
+                net = getattr(pc, name)
+                films[name] = net.film_nets(pe) if hasattr(net, "film_nets") else None
 
     if mode in (GenerateMode.TRAINING_FULL_PRECISION, GenerateMode.DECODING_AS_IS):
         pass
@@ -743,9 +753,6 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     else:
         raise ValueError(f"Unknown mode {mode}")
 
-    with region('gen.embed'):
-        pe = _embed_rows(pc, frames, anchor, seg)
-
     rows = seg.rows
     with region('gen.mlps'):
         if trunks is not None:      # decoding: the feature-only half of the generators was evaluated once for all anchors
@@ -755,9 +762,11 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
             color = pc.get_color_mlp.head(trunks["get_color_mlp"].index_select(0, vis), pe).reshape(rows * K, 3)
             scale_rot = pc.get_cov_mlp.head(trunks["get_cov_mlp"].index_select(0, vis), pe).reshape(rows * K, 7)
         else:
-            op_raw = pc.get_opacity_mlp(feat, pe)
-            color = pc.get_color_mlp(feat, pe).reshape(rows * K, 3)
-            scale_rot = pc.get_cov_mlp(feat, pe).reshape(rows * K, 7)
+            gen = lambda name: (getattr(pc, name)(feat, pe, film=films[name]) if films.get(name) is not None  # noqa: E731
+                                else getattr(pc, name)(feat, pe))
+            op_raw = gen("get_opacity_mlp")
+            color = gen("get_color_mlp").reshape(rows * K, 3)
+            scale_rot = gen("get_cov_mlp").reshape(rows * K, 7)
         neural_offset = pc.get_deform_mlp(torch.cat([feat, pe], dim=1)).reshape(rows * K, 3)
     if dense:
         # opacity mask, sigmoid scaling, normalised rotation, world position, bound clamp: one kernel (csrc/generate.hip)

@@ -10,11 +10,13 @@ outputs and every gradient), without the graph bookkeeping in between.
 
 Activations ride on the GEMM kernels' epilogue (gsvc_linear_forward_ex):
   forward   ReLU in place; GELU stores the pre-activation and the activated value side by side (the backward needs the
-            former, the next layer and its weight gradient the latter); tanh / sigmoid at the output; FiLM's
-            ``gamma * h + beta`` in the epilogue of the GEMM that produces gamma
+            former, the next layer and its weight gradient the latter); tanh / sigmoid at the output
   backward  dX = (G W) * f'(saved) — the derivative of the PREVIOUS layer's activation is applied where dX is produced
-            (GELU' from the saved pre-activation, ReLU' from the saved output), and the FiLM product rule
-            (d gamma = g * h, d h = g * gamma) is the epilogue of the GEMM that produces g.
+            (GELU' from the saved pre-activation, ReLU' from the saved output).
+FiLM's ``gamma * h + beta`` and its product rule run as streaming kernels (gsvc_film_forward / _backward): the epilogue forms
+(GSVC_LIN_FILM / _FILM_GRAD, kept in the library) move the same bytes in 64-byte pieces of 400-byte rows, 25-35 us slower per call.
+A GeneratorNet is two functions: the FiLM conditioning networks (they read the condition only and can be issued ahead of
+everything that depends on the anchor features) and the trunk.
 """
 from __future__ import annotations
 
@@ -152,39 +154,71 @@ class _SeqGelu(torch.autograd.Function):
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 
 
-class _Generator(torch.autograd.Function):
-    """GeneratorNet: out_act(out_linear(FiLM(linear2(GELU(linear1(feature))), condition))) (reference
-    scene/gaussian_model.py:150-196).  params = linear1 (W, b), linear2, fc_gamma0, fc_gamma1, fc_beta0, fc_beta1, out_linear."""
+class _FilmNets(torch.autograd.Function):
+    """The two conditioning networks of a GeneratorNet's FiLM: gamma = fc_gamma1(relu(fc_gamma0(c))), beta likewise (reference
+    scene/gaussian_model.py:150-166).  They read the condition only (frame time and z embedding), not the anchor features, so a
+    fitting step can issue them before anything that waits for the entropy context — four large GEMMs that keep the GPU busy
+    while the host queues the context's many small launches.  params = fc_gamma0 (W, b), fc_gamma1, fc_beta0, fc_beta1."""
 
     @staticmethod
-    def forward(ctx, feature, condition, act, *params):
-        feature, condition = feature.contiguous(), condition.contiguous()
-        W1, b1, W2, b2, Wg0, bg0, Wg1, bg1, Wb0, bb0, Wb1, bb1, W3, b3 = [p.contiguous() for p in params]
-        M, dev = feature.shape[0], feature.device
-        f = lambda n: torch.empty(M, n, device=dev, dtype=torch.float32)  # noqa: E731
-        a1 = f(W1.shape[0])
-        z1 = linear_ex(feature, W1, b1, EPI_GELU_DUAL, y2=a1)
-        h = linear_ex(a1, W2, b2)
+    def forward(ctx, condition, *params):
+        condition = condition.contiguous()
+        Wg0, bg0, Wg1, bg1, Wb0, bb0, Wb1, bb1 = [p.contiguous() for p in params]
         cb = linear_ex(condition, Wb0, bb0, EPI_RELU)
         beta = linear_ex(cb, Wb1, bb1)
         cg = linear_ex(condition, Wg0, bg0, EPI_RELU)
-        x3 = f(Wg1.shape[0])
-        if (M * Wg1.shape[0]) % 4 == 0:
-            # the FiLM combine as a streaming kernel: whole-line accesses; as the gamma GEMM's epilogue (EPI_FILM) the same
-            # traffic costs ~25 us more per call (64-byte pieces of 400-byte rows)
-            gamma = linear_ex(cg, Wg1, bg1)
-            _lib.check(_lib.lib().gsvc_film_forward(_lib.ptr(gamma), _lib.ptr(h), _lib.ptr(beta), _lib.ptr(x3), gamma.numel(),
+        gamma = linear_ex(cg, Wg1, bg1)
+        ctx.save_for_backward(condition, cb, cg, Wg0, Wg1, Wb0, Wb1)
+        return gamma, beta
+
+    @staticmethod
+    def backward(ctx, gg, gbeta):
+        condition, cb, cg, Wg0, Wg1, Wb0, Wb1 = ctx.saved_tensors
+        gg, gbeta = gg.contiguous(), gbeta.contiguous()
+        P = [None] * 8
+        wg = WgradBatch(gg.device)
+        P[6], P[7] = wg.add(gbeta, cb)
+        gcb = linear_ex(gbeta, Wb1, None, EPI_MUL_RELU_MASK, aux1=cb, w_in_out=True)
+        P[4], P[5] = wg.add(gcb, condition)
+        P[2], P[3] = wg.add(gg, cg)
+        gcg = linear_ex(gg, Wg1, None, EPI_MUL_RELU_MASK, aux1=cg, w_in_out=True)
+        P[0], P[1] = wg.add(gcg, condition)
+        gcond = None
+        if ctx.needs_input_grad[0]:
+            gcond = linear_ex(gcb, Wb0, None, w_in_out=True)
+            gcond += linear_ex(gcg, Wg0, None, w_in_out=True)
+        wg.flush()
+        return (gcond, *P)
+
+
+class _GeneratorTrunk(torch.autograd.Function):
+    """out_act(out_linear(gamma * linear2(GELU(linear1(feature))) + beta)) given the FiLM pair (reference
+    scene/gaussian_model.py:168-196).  params = linear1 (W, b), linear2, out_linear."""
+
+    @staticmethod
+    def forward(ctx, feature, gamma, beta, act, *params):
+        feature, gamma, beta = feature.contiguous(), gamma.contiguous(), beta.contiguous()
+        W1, b1, W2, b2, W3, b3 = [p.contiguous() for p in params]
+        M, dev = feature.shape[0], feature.device
+        a1 = torch.empty(M, W1.shape[0], device=dev, dtype=torch.float32)
+        z1 = linear_ex(feature, W1, b1, EPI_GELU_DUAL, y2=a1)
+        h = linear_ex(a1, W2, b2)
+        if h.numel() % 4 == 0:
+            # the FiLM combine as a streaming kernel (whole-line accesses; as a GEMM epilogue, EPI_FILM, the same traffic moves
+            # in 64-byte pieces of 400-byte rows and costs ~25 us more per call)
+            x3 = torch.empty_like(h)
+            _lib.check(_lib.lib().gsvc_film_forward(_lib.ptr(gamma), _lib.ptr(h), _lib.ptr(beta), _lib.ptr(x3), h.numel(),
                                                     _lib.current_stream(dev)), "gsvc_film_forward")
         else:
-            gamma = linear_ex(cg, Wg1, bg1, EPI_FILM, aux1=h, aux2=beta, y2=x3)        # gamma and x3 = gamma * h + beta
+            x3 = torch.addcmul(beta, gamma, h)
         y = linear_ex(x3, W3, b3, (EPI_NONE, EPI_TANH, EPI_SIGMOID)[act])
         ctx.act = act
-        ctx.save_for_backward(feature, condition, z1, a1, h, cb, cg, gamma, x3, y, W1, W2, Wg0, Wg1, Wb0, Wb1, W3)
+        ctx.save_for_backward(feature, z1, a1, h, gamma, x3, y, W1, W2, W3)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        feature, condition, z1, a1, h, cb, cg, gamma, x3, y, W1, W2, Wg0, Wg1, Wb0, Wb1, W3 = ctx.saved_tensors
+        feature, z1, a1, h, gamma, x3, y, W1, W2, W3 = ctx.saved_tensors
         need = ctx.needs_input_grad
         gy = gy.contiguous()
         if ctx.act == ACT_TANH:
@@ -193,35 +227,41 @@ class _Generator(torch.autograd.Function):
             go = torch.ops.aten.sigmoid_backward(gy, y)
         else:
             go = gy
-        P = [None] * 14
+        P = [None] * 6
         wg = WgradBatch(gy.device)
-        P[12], P[13] = wg.add(go, x3)
-        # g x3 = go W3 is d beta; the same GEMM's epilogue leaves d gamma = g x3 * h and d h = g x3 * gamma
-        M, dev = feature.shape[0], feature.device
-        gg = torch.empty(M, h.shape[1], device=dev, dtype=torch.float32)
-        gh = torch.empty_like(gg)
-        if gg.numel() % 4 == 0:
-            gbeta = linear_ex(go, W3, None, w_in_out=True)
+        P[4], P[5] = wg.add(go, x3)
+        dev = feature.device
+        gbeta = linear_ex(go, W3, None, w_in_out=True)          # d x3 = d beta
+        if h.numel() % 4 == 0:
+            gg, gh = torch.empty_like(h), torch.empty_like(h)
             _lib.check(_lib.lib().gsvc_film_backward(_lib.ptr(gbeta), _lib.ptr(h), _lib.ptr(gamma), _lib.ptr(gg), _lib.ptr(gh),
                                                      gg.numel(), _lib.current_stream(dev)), "gsvc_film_backward")
         else:
-            gbeta = linear_ex(go, W3, None, EPI_FILM_GRAD, aux1=h, aux2=gamma, y2=gg, y3=gh, w_in_out=True)
-        P[10], P[11] = wg.add(gbeta, cb)
-        gcb = linear_ex(gbeta, Wb1, None, EPI_MUL_RELU_MASK, aux1=cb, w_in_out=True)
-        P[8], P[9] = wg.add(gcb, condition)
-        P[6], P[7] = wg.add(gg, cg)
-        gcg = linear_ex(gg, Wg1, None, EPI_MUL_RELU_MASK, aux1=cg, w_in_out=True)
-        P[4], P[5] = wg.add(gcg, condition)
-        gcond = None
-        if need[1]:
-            gcond = linear_ex(gcb, Wb0, None, w_in_out=True)
-            gcond += linear_ex(gcg, Wg0, None, w_in_out=True)
+            gg, gh = gbeta * h, gbeta * gamma
         P[2], P[3] = wg.add(gh, a1)
         gz1 = linear_ex(gh, W2, None, EPI_MUL_GELU_GRAD, aux1=z1, w_in_out=True)
         P[0], P[1] = wg.add(gz1, feature)
         gfeat = linear_ex(gz1, W1, None, w_in_out=True) if need[0] else None
         wg.flush()
-        return (gfeat, gcond, None, *P)
+        return (gfeat, gg if need[1] else None, gbeta if need[2] else None, None, *P)
+
+
+def film_nets(film, condition):
+    """(gamma, beta) of a FiLM module for a tall CUDA condition matrix (one autograd function)."""
+    params = []
+    for l in (film.fc_gamma0, film.fc_gamma1, film.fc_beta0, film.fc_beta1):
+        params += [l.weight, l.bias]
+    return _FilmNets.apply(condition, *params)
+
+
+def generator(net, feature, condition=None, film=None):
+    """GeneratorNet forward as two autograd functions; ``film``: a (gamma, beta) pair computed ahead with ``film_nets``."""
+    act = {"Tanh": ACT_TANH, "Sigmoid": ACT_SIGMOID, "Identity": ACT_NONE}[type(net.out_act).__name__]
+    gamma, beta = film if film is not None else film_nets(net.film, condition)
+    params = []
+    for l in (net.linear1, net.linear2, net.out_linear):
+        params += [l.weight, l.bias]
+    return _GeneratorTrunk.apply(feature, gamma, beta, act, *params)
 
 
 def seq_gelu(x, linears):
@@ -229,13 +269,3 @@ def seq_gelu(x, linears):
     for l in linears:
         params += [l.weight, l.bias]
     return _SeqGelu.apply(x, *params)
-
-
-def generator(net, feature, condition):
-    act = {"Tanh": ACT_TANH, "Sigmoid": ACT_SIGMOID, "Identity": ACT_NONE}[type(net.out_act).__name__]
-    film = net.film
-    ls = (net.linear1, net.linear2, film.fc_gamma0, film.fc_gamma1, film.fc_beta0, film.fc_beta1, net.out_linear)
-    params = []
-    for l in ls:
-        params += [l.weight, l.bias]
-    return _Generator.apply(feature, condition, act, *params)

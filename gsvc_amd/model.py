@@ -225,13 +225,30 @@ class GeneratorNet(nn.Module):
     def head(self, h, condition):
         return self.out_act(self.out_linear(self.film(h, condition)))
 
-    def forward(self, feature, condition):
+    def _fusable(self, feature):
+        from . import mlp
+        return (type(self.out_act).__name__ in ("Tanh", "Sigmoid", "Identity") and not os.environ.get("GSVC_NO_MLP_CHAIN")
+                and mlp.usable(feature, self.linear1, self.linear2, self.out_linear))
+
+    def film_nets(self, condition):
+        """(gamma, beta) of this network's FiLM for ``condition`` as one autograd function, or None when the fused path does
+        not apply.  They depend on the condition only: a caller may evaluate them ahead and pass ``film=`` to forward."""
         from . import mlp
         f = self.film
-        if (type(self.out_act).__name__ in ("Tanh", "Sigmoid", "Identity") and not os.environ.get("GSVC_NO_MLP_CHAIN")
-                and mlp.usable(feature, self.linear1, self.linear2, self.out_linear)
+        if (not os.environ.get("GSVC_NO_MLP_CHAIN")
                 and mlp.usable(condition, f.fc_gamma0, f.fc_gamma1, f.fc_beta0, f.fc_beta1)):
-            return mlp.generator(self, feature, condition)      # the whole network as one autograd function
+            return mlp.film_nets(f, condition)
+        return None
+
+    def forward(self, feature, condition, film=None):
+        from . import mlp
+        if self._fusable(feature):
+            if film is None:
+                film = self.film_nets(condition)
+            if film is not None:
+                return mlp.generator(self, feature, film=film)      # FiLM nets + trunk: two autograd functions
+        if film is not None:
+            return self.out_act(self.out_linear(film[0] * self.trunk(feature) + film[1]))
         return self.head(self.trunk(feature), condition)
 
 
