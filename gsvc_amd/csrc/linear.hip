@@ -8,9 +8,11 @@
 #include "linear_ws.h"
 
 namespace gsvc {
-// the EPI instantiations live in their own translation units (linear_epi_lo.hip: N <= 96, linear_epi_hi.hip: N > 96)
-void launch_ws_epi_lo(const float *X, const float *W, const float *b, float *Y, long long M, int K, int N, int w_in_out, hipStream_t s, const LinEpi &ep);
-void launch_ws_epi_hi(const float *X, const float *W, const float *b, float *Y, long long M, int K, int N, int w_in_out, hipStream_t s, const LinEpi &ep);
+// the EPI instantiations live in their own translation units (linear_epi_{a,b,c,d}.hip: 1-4, 5-7, 8-10, 11-12 column tiles)
+void launch_ws_epi_a(const float *X, const float *W, const float *b, float *Y, long long M, int K, int N, int w_in_out, hipStream_t s, const LinEpi &ep);
+void launch_ws_epi_b(const float *X, const float *W, const float *b, float *Y, long long M, int K, int N, int w_in_out, hipStream_t s, const LinEpi &ep);
+void launch_ws_epi_c(const float *X, const float *W, const float *b, float *Y, long long M, int K, int N, int w_in_out, hipStream_t s, const LinEpi &ep);
+void launch_ws_epi_d(const float *X, const float *W, const float *b, float *Y, long long M, int K, int N, int w_in_out, hipStream_t s, const LinEpi &ep);
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -49,8 +51,11 @@ extern "C" int gsvc_linear_forward_ex(const float *X, const float *W, const floa
     hipStream_t s = (hipStream_t)stream;
     if (epilogue == GSVC_LIN_NONE || epilogue == GSVC_LIN_RELU)
         launch_ws_n<false>(X, W, bias, Y, M, K, N, w_in_out, epilogue == GSVC_LIN_RELU, s, LinEpi{0, nullptr, nullptr, nullptr, nullptr});
-    else
-        ((N + 15) / 16 <= 6 ? launch_ws_epi_lo : launch_ws_epi_hi)(X, W, bias, Y, M, K, N, w_in_out, s, LinEpi{epilogue, aux1, aux2, Y2, Y3});
+    else {
+        const int nt = (N + 15) / 16;
+        (nt <= 4 ? launch_ws_epi_a : (nt <= 7 ? launch_ws_epi_b : (nt <= 10 ? launch_ws_epi_c : launch_ws_epi_d)))(
+            X, W, bias, Y, M, K, N, w_in_out, s, LinEpi{epilogue, aux1, aux2, Y2, Y3});
+    }
     return check_launch("linear_forward_ex");
 }
 

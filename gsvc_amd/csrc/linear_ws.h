@@ -1,5 +1,5 @@
 // gsvc_amd/csrc/linear_ws.h — the weight-stationary MFMA linear kernel (template) shared by the translation units that
-// instantiate it: linear.hip (plain epilogue), linear_epi_lo.hip / linear_epi_hi.hip (epilogue programs, N <= 96 / N > 96),
+// instantiate it: linear.hip (plain epilogue), linear_epi_{a,b,c,d}.hip (epilogue programs, by column-tile count),
 // linear_wgrad.hip (uses the fragment-load helpers).  Split so that the ~650 kernel instantiations compile in parallel.
 #pragma once
 #include "common.h"
