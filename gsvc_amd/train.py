@@ -108,7 +108,8 @@ class Trainer:
         # GSVC_DP_SHARD=1 (or shard_optimizer=True): reduce-scatter + sharded Adam + all-gather for the per-anchor tensors
         #  instead of all-reduce + replicated Adam; same parameters after the step (tests/test_dist_cpu.py)
         self.sharded = None
-        if (shard_optimizer or os.environ.get("GSVC_DP_SHARD")) and gdist.world_size() > 1 and gaussians.optimizer is not None:
+        if ((shard_optimizer or os.environ.get("GSVC_DP_SHARD", "0") not in ("", "0")) and gdist.world_size() > 1
+                and gaussians.optimizer is not None):
             self.sharded = gdist.ShardedAnchorAdam(gaussians.optimizer)
         self.reducer = gdist.GradReducer(sharded=self.sharded)
 
