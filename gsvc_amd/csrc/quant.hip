@@ -149,6 +149,25 @@ static int q_nbx(const QSeg &seg)
     return (int)((longest + 63) / 64);
 }
 
+// STE_binary forward of a hash table (reference utils/encodings.py:375-392: sign with 0 -> +1) together with the count of its
+// +1 entries, which the hash-bit term of the loss needs (pipeline/train.py:456): one pass instead of compare / where / sum.
+__global__ void __launch_bounds__(256) k_ste_binary_count(const float *__restrict__ x, long long n, float *__restrict__ y,
+                                                          float *__restrict__ count)
+{
+    __shared__ float red[4];
+    float c = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const bool pos = x[i] >= 0.f;
+        y[i] = pos ? 1.0f : -1.0f;
+        c += pos ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(count, (red[0] + red[1]) + (red[2] + red[3]));      // integer-valued sums below 2^24: exact
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -199,4 +218,22 @@ extern "C" int gsvc_noise_quant_backward(const float *grad_y, const float *x, co
     hipLaunchKernelGGL(k_quant_bwd, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, grad_y, x, q_rows, q_scalar, noise, centre,
                        seg, C, rpb, grad_x, grad_q_rows);
     return check_launch("noise_quant_backward");
+}
+
+extern "C" int gsvc_ste_binary_count(const float *x, int64_t n, float *y, float *count, void *stream)
+{
+    GSVC_REQUIRE(n >= 0 && n < (1ll << 24), "ste_binary_count: the count must stay exact in float32 (n < 2^24)");
+    GSVC_REQUIRE(count, "ste_binary_count: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(count, 0, sizeof(float), s) != hipSuccess) {
+        gsvc::set_error("ste_binary_count: hipMemsetAsync failed");
+        return GSVC_E_LAUNCH;
+    }
+    if (n == 0) return GSVC_OK;
+    GSVC_REQUIRE(x && y, "ste_binary_count: NULL pointer");
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    gsvc::ProfScope _prof("k_ste_binary", s);
+    hipLaunchKernelGGL(gsvc::k_ste_binary_count, dim3((unsigned)blocks), dim3(256), 0, s, x, (long long)n, y, count);
+    return gsvc::check_launch("ste_binary_count");
 }

@@ -37,7 +37,10 @@ __device__ __forceinline__ float block_sum_256(float v, float *smem)
     return smem[0] + smem[1] + smem[2] + smem[3];
 }
 
-__global__ void __launch_bounds__(256) k_ssim_fwd(SsimWindow win, const float *__restrict__ img1,
+// img1b != NULL: the first image is the two-view frame 0.5 * (img1 + flip_W(img1b)) (reference pipeline/train.py:368-375), formed
+// on load (and stored to avg_out where the caller wants it) instead of by three elementwise launches each way.
+__global__ void __launch_bounds__(256) k_ssim_fwd(SsimWindow win, const float *__restrict__ img1, const float *__restrict__ img1b,
+                                                  float *__restrict__ avg_out,
                                                   const float *__restrict__ img2, int H, int W,
                                                   float *__restrict__ partials /* [SS_SLOTS][2]: ssim, l1 */,
                                                   float *__restrict__ dm_dmu1, float *__restrict__ dm_de11,
@@ -54,10 +57,16 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(SsimWindow win, const float *_
         const int r = i / SS_HALO, c = i - r * SS_HALO;
         const int gy = y0 + r - SS_R, gx = x0 + c - SS_R;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        sx[r][c] = in ? img1[plane + (size_t)gy * W + gx] : 0.f;
+        float xv = in ? img1[plane + (size_t)gy * W + gx] : 0.f;
+        if (img1b && in) xv = (xv + img1b[plane + (size_t)gy * W + (W - 1 - gx)]) / 2.0f;
+        sx[r][c] = xv;
         sy[r][c] = in ? img2[plane + (size_t)gy * W + gx] : 0.f;
     }
     __syncthreads();
+    if (avg_out) {
+        const int gxo = x0 + lx, gyo = y0 + ly;
+        if (gxo < W && gyo < H) avg_out[plane + (size_t)gyo * W + gxo] = sx[ly + SS_R][lx + SS_R];
+    }
     for (int i = tid; i < SS_HALO * SS_TILE; i += 256) {
         const int r = i / SS_TILE, c = i - r * SS_TILE;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
@@ -117,7 +126,8 @@ __global__ void __launch_bounds__(256) k_ssim_finalize(const float *__restrict__
 
 // dL/dimg1 = conv(g*dm_dmu1) + 2 x conv(g*dm_de11) + y conv(g*dm_de12) + g_l1 * sign(x - y),
 // g = grads[0] / (C*H*W) (mean of the map), g_l1 = grads[1] / (C*H*W)
-__global__ void __launch_bounds__(256) k_ssim_bwd(SsimWindow win, const float *__restrict__ img1,
+__global__ void __launch_bounds__(256) k_ssim_bwd(SsimWindow win, const float *__restrict__ img1, const float *__restrict__ img1b,
+                                                  float *__restrict__ dL_dimg1b,
                                                   const float *__restrict__ img2, int H, int W, float inv_count,
                                                   const float *__restrict__ grads, const float *__restrict__ dm_dmu1,
                                                   const float *__restrict__ dm_de11, const float *__restrict__ dm_de12,
@@ -158,11 +168,20 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(SsimWindow win, const float *_
     const int gx = x0 + lx, gy = y0 + ly;
     if (gx < W && gy < H) {
         const size_t o = plane + (size_t)gy * W + gx;
-        const float x = img1[o], y = img2[o];
+        const size_t ob = plane + (size_t)gy * W + (W - 1 - gx);
+        float x = img1[o];
+        if (img1b) x = (x + img1b[ob]) / 2.0f;
+        const float y = img2[o];
         const float g = grads[0] * inv_count, gl = grads[1] * inv_count;
         const float d = x - y;
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        dL_dimg1[o] = g * (b0 + 2.f * x * b1 + y * b2) + gl * sgn;
+        const float v = g * (b0 + 2.f * x * b1 + y * b2) + gl * sgn;
+        if (img1b) {
+            dL_dimg1[o] = 0.5f * v;
+            dL_dimg1b[ob] = 0.5f * v;
+        } else {
+            dL_dimg1[o] = v;
+        }
     }
 }
 
@@ -188,8 +207,25 @@ static SsimWindow make_window()
 
 using namespace gsvc;
 
+static int ssim_forward_impl(const float *img1, const float *img1b, float *avg_out, const float *img2, int32_t C, int32_t H, int32_t W,
+                             float *sums, float *workspace, float *dm_dmu1, float *dm_de11, float *dm_de12, void *stream);
+
 extern "C" int gsvc_ssim_l1_forward(const float *img1, const float *img2, int32_t C, int32_t H, int32_t W, float *sums,
                                     float *workspace, float *dm_dmu1, float *dm_de11, float *dm_de12, void *stream)
+{
+    return ssim_forward_impl(img1, nullptr, nullptr, img2, C, H, W, sums, workspace, dm_dmu1, dm_de11, dm_de12, stream);
+}
+
+extern "C" int gsvc_ssim_l1_pair_forward(const float *img_f, const float *img_b, const float *img2, int32_t C, int32_t H, int32_t W,
+                                         float *sums, float *workspace, float *dm_dmu1, float *dm_de11, float *dm_de12,
+                                         float *avg_out, void *stream)
+{
+    GSVC_REQUIRE(img_b, "ssim_l1_pair_forward: NULL pointer");
+    return ssim_forward_impl(img_f, img_b, avg_out, img2, C, H, W, sums, workspace, dm_dmu1, dm_de11, dm_de12, stream);
+}
+
+static int ssim_forward_impl(const float *img1, const float *img1b, float *avg_out, const float *img2, int32_t C, int32_t H, int32_t W,
+                             float *sums, float *workspace, float *dm_dmu1, float *dm_de11, float *dm_de12, void *stream)
 {
     GSVC_REQUIRE(img1 && img2 && sums && workspace, "ssim_l1_forward: NULL pointer");
     GSVC_REQUIRE(C > 0 && H > 0 && W > 0, "ssim_l1_forward: bad shape");
@@ -204,7 +240,7 @@ extern "C" int gsvc_ssim_l1_forward(const float *img1, const float *img2, int32_
     {
         ProfScope _prof("k_ssim_fwd", s);
         hipLaunchKernelGGL(k_ssim_fwd, dim3((W + SS_TILE - 1) / SS_TILE, (H + SS_TILE - 1) / SS_TILE, C), dim3(256), 0, s,
-                           win, img1, img2, H, W, workspace, dm_dmu1, dm_de11, dm_de12);
+                           win, img1, img1b, avg_out, img2, H, W, workspace, dm_dmu1, dm_de11, dm_de12);
     }
     {
         ProfScope _prof("k_ssim_finalize", s);
@@ -213,9 +249,28 @@ extern "C" int gsvc_ssim_l1_forward(const float *img1, const float *img2, int32_
     return check_launch("ssim_l1_forward");
 }
 
+static int ssim_backward_impl(const float *img1, const float *img1b, float *dL_dimg1b, const float *img2, int32_t C, int32_t H, int32_t W,
+                              const float *grads, const float *dm_dmu1, const float *dm_de11, const float *dm_de12, float *dL_dimg1,
+                              void *stream);
+
 extern "C" int gsvc_ssim_l1_backward(const float *img1, const float *img2, int32_t C, int32_t H, int32_t W,
                                      const float *grads, const float *dm_dmu1, const float *dm_de11,
                                      const float *dm_de12, float *dL_dimg1, void *stream)
+{
+    return ssim_backward_impl(img1, nullptr, nullptr, img2, C, H, W, grads, dm_dmu1, dm_de11, dm_de12, dL_dimg1, stream);
+}
+
+extern "C" int gsvc_ssim_l1_pair_backward(const float *img_f, const float *img_b, const float *img2, int32_t C, int32_t H, int32_t W,
+                                          const float *grads, const float *dm_dmu1, const float *dm_de11, const float *dm_de12,
+                                          float *dL_dimg_f, float *dL_dimg_b, void *stream)
+{
+    GSVC_REQUIRE(img_b && dL_dimg_b, "ssim_l1_pair_backward: NULL pointer");
+    return ssim_backward_impl(img_f, img_b, dL_dimg_b, img2, C, H, W, grads, dm_dmu1, dm_de11, dm_de12, dL_dimg_f, stream);
+}
+
+static int ssim_backward_impl(const float *img1, const float *img1b, float *dL_dimg1b, const float *img2, int32_t C, int32_t H, int32_t W,
+                              const float *grads, const float *dm_dmu1, const float *dm_de11, const float *dm_de12, float *dL_dimg1,
+                              void *stream)
 {
     GSVC_REQUIRE(img1 && img2 && grads && dm_dmu1 && dm_de11 && dm_de12 && dL_dimg1, "ssim_l1_backward: NULL pointer");
     GSVC_REQUIRE(C > 0 && H > 0 && W > 0, "ssim_l1_backward: bad shape");
@@ -224,8 +279,8 @@ extern "C" int gsvc_ssim_l1_backward(const float *img1, const float *img2, int32
     {
         ProfScope _prof("k_ssim_bwd", s);
         hipLaunchKernelGGL(k_ssim_bwd, dim3((W + SS_TILE - 1) / SS_TILE, (H + SS_TILE - 1) / SS_TILE, C), dim3(256), 0, s,
-                           win, img1, img2, H, W, 1.0f / ((float)C * (float)H * (float)W), grads, dm_dmu1, dm_de11, dm_de12,
-                           dL_dimg1);
+                           win, img1, img1b, dL_dimg1b, img2, H, W, 1.0f / ((float)C * (float)H * (float)W), grads, dm_dmu1, dm_de11,
+                           dm_de12, dL_dimg1);
     }
     return check_launch("ssim_l1_backward");
 }

@@ -44,6 +44,28 @@ class STE_binary(torch.autograd.Function):
         return g * (x.abs() <= 1)
 
 
+class STE_binary_counted(torch.autograd.Function):
+    """STE_binary whose forward also returns the number of +1 entries (csrc/quant.hip k_ste_binary_count): the hash-bit term of
+    the fitting loss needs that count of every table it binarises."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import _lib
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        count = torch.empty(1, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().gsvc_ste_binary_count(_lib.ptr(xc), xc.numel(), _lib.ptr(y), _lib.ptr(count),
+                                                    _lib.current_stream(x.device)), "gsvc_ste_binary_count")
+        ctx.save_for_backward(x)
+        ctx.mark_non_differentiable(count)
+        return y, count
+
+    @staticmethod
+    def backward(ctx, g, _g_count):
+        (x,) = ctx.saved_tensors
+        return g * (x.abs() <= 1)
+
+
 def _symbol_bounds(mean, Q):
     centre = mean / Q.mean().detach()
     return centre - CLAMP_STEPS, centre + CLAMP_STEPS
@@ -192,7 +214,10 @@ class GridEncoder(nn.Module):
             cache = getattr(self, "step_cache", None)
             if cache is not None and outspace_params is None:
                 if "emb" not in cache:
-                    cache["emb"] = STE_binary.apply(p)
+                    if p.is_cuda and p.dtype == torch.float32 and p.numel() < (1 << 24):
+                        cache["emb"], cache["ones"] = STE_binary_counted.apply(p)      # + the count the hash-bit term reads
+                    else:
+                        cache["emb"] = STE_binary.apply(p)
                 return cache["emb"]
             return STE_binary.apply(p)
         if self.add_noise and not test_phase:

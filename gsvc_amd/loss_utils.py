@@ -47,6 +47,47 @@ class _SsimL1(torch.autograd.Function):
         return d, None
 
 
+class _SsimL1Pair(torch.autograd.Function):
+    """(mean SSIM, mean |a-b|, a) with a = (img_f + flip_W(img_b)) / 2 formed inside the kernels (the two-view frame of
+    reference pipeline/train.py:368-375): no flip / add / div launches forward, no div / flip backward."""
+
+    @staticmethod
+    def forward(ctx, img_f, img_b, img2):
+        from . import _lib
+        f, b, g = img_f.contiguous().float(), img_b.contiguous().float(), img2.contiguous().float()
+        C_, H, W = f.shape
+        need = img_f.requires_grad or img_b.requires_grad
+        sums = torch.empty(2, device=f.device, dtype=torch.float32)
+        work = torch.empty(2048, device=f.device, dtype=torch.float32)
+        avg = torch.empty_like(f)
+        maps = [torch.empty_like(f) for _ in range(3)] if need else [None, None, None]
+        _lib.check(_lib.lib().gsvc_ssim_l1_pair_forward(_lib.ptr(f), _lib.ptr(b), _lib.ptr(g), C_, H, W, _lib.ptr(sums), _lib.ptr(work),
+                                                        _lib.ptr(maps[0]), _lib.ptr(maps[1]), _lib.ptr(maps[2]), _lib.ptr(avg),
+                                                        _lib.current_stream(f.device)), "gsvc_ssim_l1_pair_forward")
+        if need:
+            ctx.save_for_backward(f, b, g, *maps)
+        ctx.mark_non_differentiable(avg)
+        out = sums / float(C_ * H * W)
+        return out[0], out[1], avg
+
+    @staticmethod
+    def backward(ctx, g_ssim, g_l1, _g_avg):
+        from . import _lib
+        f, b, g, m0, m1, m2 = ctx.saved_tensors
+        C_, H, W = f.shape
+        grads = torch.stack([g_ssim, g_l1]).float().contiguous()
+        df, db = torch.empty_like(f), torch.empty_like(b)
+        _lib.check(_lib.lib().gsvc_ssim_l1_pair_backward(_lib.ptr(f), _lib.ptr(b), _lib.ptr(g), C_, H, W, _lib.ptr(grads), _lib.ptr(m0),
+                                                         _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(df), _lib.ptr(db),
+                                                         _lib.current_stream(f.device)), "gsvc_ssim_l1_pair_backward")
+        return df, db, None
+
+
+def ssim_l1_pair(img_f, img_b, img2):
+    """(ssim_func(a, img2), l1_loss_func(a, img2), a.detach()) for a = (img_f + flip(img_b, W)) / 2, [3,H,W] CUDA images."""
+    return _SsimL1Pair.apply(img_f, img_b, img2)
+
+
 def ssim_l1(img1, img2):
     """Fused (ssim_func(img1, img2), l1_loss_func(img1, img2)) for [3,H,W] CUDA images (one kernel each way)."""
     return _SsimL1.apply(img1, img2)

@@ -17,7 +17,7 @@ import torch
 
 from . import dist as gdist
 from .generate import region
-from .loss_utils import calc_optical_loss, render_regs, ssim_l1
+from .loss_utils import calc_optical_loss, render_regs, ssim_l1, ssim_l1_pair
 from .ortho_gaussian_renderer import plan_views, render, render_many
 from .rasterizer import resolve_deferred
 from .train_util import TrainingController
@@ -40,7 +40,9 @@ def hash_grid_bits(pc):
     tables = grid_tables(pc)
     if not (pc.ste_binary and all(hasattr(g, "embeddings") for g in tables)):
         return get_binary_vxl_size_device((pc.get_encoding_params() + 1) / 2)
-    return _TableBits.apply(*[g.embeddings() for g in tables])
+    embs = [g.embeddings() for g in tables]
+    counts = [(getattr(g, "step_cache", None) or {}).get("ones") for g in tables]
+    return _TableBits.apply(torch.cat(counts) if all(c is not None for c in counts) else None, *embs)
 
 
 class _TableBits(torch.autograd.Function):
@@ -50,9 +52,10 @@ class _TableBits(torch.autograd.Function):
     the backward is one scalar expression and an expand instead of a dozen one-element kernels each way."""
 
     @staticmethod
-    def forward(ctx, *tables):
+    def forward(ctx, counts, *tables):
         total = sum(t.numel() for t in tables)
-        ones = (torch.stack([t.sum() for t in tables]).sum() + total) / 2
+        # counts: the +1 entries of every table, counted by the kernel that binarised it (else: from the tables' sums)
+        ones = counts.sum() if counts is not None else (torch.stack([t.sum() for t in tables]).sum() + total) / 2
         p = torch.clamp(ones / total, min=1e-6, max=1 - 1e-6)
         ctx.save_for_backward(p)
         ctx.shapes = [t.shape for t in tables]
@@ -62,7 +65,7 @@ class _TableBits(torch.autograd.Function):
     def backward(ctx, g):
         (p,) = ctx.saved_tensors
         coef = g * 0.5 * torch.log2((1 - p) / p)
-        return tuple(coef.expand(sh) for sh in ctx.shapes)
+        return (None,) + tuple(coef.expand(sh) for sh in ctx.shapes)
 
 
 def grid_tables(pc):
@@ -213,8 +216,7 @@ class Trainer:
             frame1, frame2 = views[0], views[2]
             r1f, r1b, r2f, r2b = render_many(views, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode,
                                              dense=True, anchor_grad=self.anchor_grad, plan=plan)
-            image1 = (r1f.rendered_image + torch.flip(r1b.rendered_image, dims=(-1,))) / 2
-            image2 = (r2f.rendered_image + torch.flip(r2b.rendered_image, dims=(-1,))) / 2
+            image1 = image2 = None         # the two-view frames are formed inside the SSIM kernels below (ssim_l1_pair)
             # replicas: "did any rank's instance buffer overflow" is reduced right behind the forward kernels, so that
             # the end-of-step check does not have to wait for the backward (overflow word = second int32 of a binning blob)
             ovf_handle = gdist.any_rank_start([r.raster_state.binning[4:8].view(torch.int32) for r in (r1f, r1b, r2f, r2b)])
@@ -224,8 +226,12 @@ class Trainer:
         renders = (r1f, r1b, r2f, r2b)
         gt1 = frame1.image.to(dev).permute(0, 2, 1)
         gt2 = frame2.image.to(dev).permute(0, 2, 1)
-        ssim1, l1_1 = ssim_l1(image1, gt1.contiguous())
-        ssim2, l1_2 = ssim_l1(image2, gt2.contiguous())
+        if image1 is None:
+            ssim1, l1_1, image1 = ssim_l1_pair(r1f.rendered_image, r1b.rendered_image, gt1.contiguous())
+            ssim2, l1_2, image2 = ssim_l1_pair(r2f.rendered_image, r2b.rendered_image, gt2.contiguous())
+        else:
+            ssim1, l1_1 = ssim_l1(image1, gt1.contiguous())
+            ssim2, l1_2 = ssim_l1(image2, gt2.contiguous())
         # the loss is a weighted sum of scalar terms: they are collected and combined with one stack + dot (instead of
         # one tiny kernel per +, *, and their backward nodes)
         terms, weights, const = [l1_1, l1_2, ssim1, ssim2], [1.0 - opt.lambda_dssim] * 2 + [-opt.lambda_dssim] * 2, 2.0 * opt.lambda_dssim

@@ -225,6 +225,19 @@ int gsvc_ssim_l1_backward(const float *img1, const float *img2, int32_t C, int32
                           const float *dm_dmu1, const float *dm_de11, const float *dm_de12, float *dL_dimg1,
                           void *stream);
 
+/* The same with the first image formed on load as the two-view frame 0.5 * (img_f + flip_W(img_b)) (reference
+ * pipeline/train.py:368-375); avg_out (may be NULL) receives that frame; the backward writes both views' gradients. */
+int gsvc_ssim_l1_pair_forward(const float *img_f, const float *img_b, const float *img2, int32_t C, int32_t H, int32_t W,
+                              float *sums, float *workspace, float *dm_dmu1, float *dm_de11, float *dm_de12, float *avg_out,
+                              void *stream);
+int gsvc_ssim_l1_pair_backward(const float *img_f, const float *img_b, const float *img2, int32_t C, int32_t H, int32_t W,
+                               const float *grads, const float *dm_dmu1, const float *dm_de11, const float *dm_de12,
+                               float *dL_dimg_f, float *dL_dimg_b, void *stream);
+
+/* STE_binary forward (reference utils/encodings.py:375-392: y = x >= 0 ? +1 : -1) and count[0] = number of +1 entries
+ * (the hash-bit term of the loss, pipeline/train.py:456, needs it); n < 2^24. */
+int gsvc_ste_binary_count(const float *x, int64_t n, float *y, float *count, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Per-Gaussian loss terms of the fitting step over UN-COMPACTED renders (every visible anchor contributes its K
  * Gaussians; mask[i] = opacity_i > 0)

@@ -331,6 +331,54 @@ def test_fused_ssim_l1_matches_torch_and_reference(H, W):
         assert np.abs(per.cpu().numpy() - g["ssim_per"]).max() < 2e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(48, 64), (70, 100)])
+def test_ssim_l1_pair_equals_the_averaged_frame(H, W):
+    """ssim_l1_pair forms the two-view frame (f + flip_W(b)) / 2 inside the kernels: same losses, same frame and the same gradients
+    for both views as averaging first and calling ssim_l1."""
+    from gsvc_amd import loss_utils as LU
+    gen = torch.Generator().manual_seed(H + W)
+    f = torch.rand(3, H, W, generator=gen).cuda().requires_grad_(True)
+    b = torch.rand(3, H, W, generator=gen).cuda().requires_grad_(True)
+    gt = torch.rand(3, H, W, generator=gen).cuda()
+    s, l, avg = LU.ssim_l1_pair(f, b, gt)
+    (0.2 * (1 - s) + 0.8 * l).backward()
+    got = (f.grad.clone(), b.grad.clone())
+    f.grad = b.grad = None
+    img = (f + torch.flip(b, dims=(-1,))) / 2
+    s2, l2 = LU.ssim_l1(img, gt)
+    (0.2 * (1 - s2) + 0.8 * l2).backward()
+    assert torch.equal(avg, img.detach()) and not avg.requires_grad
+    assert float(s) == float(s2) and float(l) == float(l2)
+    assert torch.allclose(got[0], f.grad, rtol=1e-6, atol=1e-12) and torch.allclose(got[1], b.grad, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_counted_ste_binary_and_table_bits():
+    """STE_binary_counted = STE_binary + the number of +1 entries; the hash-bit term computed from those counts equals the
+    reference-style expression on the concatenated tables (value and gradient)."""
+    from gsvc_amd.encodings import STE_binary, STE_binary_counted
+    from gsvc_amd.train import _TableBits, get_binary_vxl_size_device
+    torch.manual_seed(2)
+    ps = [(torch.randn(n, 8, device="cuda") * 0.7).requires_grad_(True) for n in (1000, 777, 3001)]
+    with torch.no_grad():
+        ps[0][:5] = 0.0                      # zeros binarise to +1
+    outs = [STE_binary_counted.apply(p) for p in ps]
+    for p, (y, c) in zip(ps, outs):
+        assert torch.equal(y, STE_binary.apply(p.detach())) and float(c) == float((p.detach() >= 0).sum())
+    bits = _TableBits.apply(torch.cat([c for _, c in outs]), *[y for y, _ in outs])
+    bits.backward()
+    got = [p.grad.clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    ref = get_binary_vxl_size_device((torch.cat([STE_binary.apply(p) for p in ps], 0) + 1) / 2)
+    ref.backward()
+    assert abs(float(bits) - float(ref)) <= 1e-6 * float(ref)
+    for a, p in zip(got, ps):
+        # (autograd differentiates through p = n1 / n as well: terms that cancel analytically leave ~1e-6 of float32 noise)
+        assert (a - p.grad).abs().max().item() <= 1e-5 * p.grad.abs().max().item() + 1e-12
+
+
 @pytest.mark.parametrize("M,K,N", [(5000, 50, 100), (4097, 116, 100), (8192, 192, 150), (4096, 100, 10), (6000, 66, 66),
                                     (4500, 50, 1), (4096, 8, 16), (70000, 100, 70), (4103, 51, 37), (9001, 192, 192),
                                     (5000, 3, 100), (4099, 150, 192), (4111, 177, 33), (300000, 100, 100)])
