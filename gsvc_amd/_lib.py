@@ -60,6 +60,10 @@ class AnsDecodeJobC(C.Structure):
                 ("error_flag", C.c_void_p), ("scratch", C.c_void_p)]
 
 
+class GridIOC(C.Structure):
+    _fields_ = [("feat_level_stride", C.c_int64), ("feat_point_stride", C.c_int64), ("in_stride", C.c_int32), ("in_col", C.c_int32 * 3)]
+
+
 class RasterSizesC(C.Structure):
     _fields_ = [("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)]
 
@@ -84,6 +88,8 @@ _SIGNATURES = {
     "gsvc_raster_image_layout": (C.c_int, [C.POINTER(RasterSettingsC), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gsvc_grid_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "gsvc_grid_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "gsvc_grid_forward_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, C.POINTER(GridIOC), _vp]),
+    "gsvc_grid_backward_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, C.POINTER(GridIOC), _vp]),
     "gsvc_rate_forward": (C.c_int, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_int32, _i64, _i64, _vp, _vp, _vp]),
     "gsvc_ssim_l1_forward": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_ssim_l1_backward": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),

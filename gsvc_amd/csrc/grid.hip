@@ -15,6 +15,16 @@
 
 namespace gsvc {
 
+// Where a launch reads its points and writes / reads the per-level features.  Default (the reference's layout,
+// gridencoder.cu): inputs [N, D] dense, features [L, N, C].  A caller that wants the concatenated [N, sum of L C] matrix of
+// several grids (Mix3d2dEncoding: scene/gaussian_model.py:81-147) points every grid at its column block of that matrix and at
+// its columns of the shared [N, 3] positions — no input slices, no permute / cat copies on either pass.
+struct GridIO {
+    long long feat_level_stride, feat_point_stride;     // floats: feature (level l, point b, channel c) at l * ls + b * ps + c
+    int in_stride, in_col[3];                           // x[d] of point b at inputs[b * in_stride + in_col[d]]
+};
+
+
 template <uint32_t D>
 __device__ __forceinline__ uint32_t fast_hash(const uint32_t (&p)[D])
 {
@@ -127,7 +137,7 @@ template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inputs, const float *__restrict__ grid,
                                                   const int32_t *__restrict__ offsets,
                                                   const int32_t *__restrict__ resolutions, float *__restrict__ outputs,
-                                                  uint32_t N, uint32_t L, float *__restrict__ dy_dx)
+                                                  uint32_t N, uint32_t L, float *__restrict__ dy_dx, GridIO io)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= N) return;
@@ -139,10 +149,10 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inpu
     bool oob = false;
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
-        x[d] = inputs[(size_t)b * D + d];
+        x[d] = inputs[(size_t)b * io.in_stride + io.in_col[d]];
         oob |= (x[d] < 0.f) | (x[d] > 1.f);
     }
-    float *out = outputs + ((size_t)level * N + b) * C;
+    float *out = outputs + (size_t)level * io.feat_level_stride + (size_t)b * io.feat_point_stride;
     float *dd = dy_dx ? dy_dx + (size_t)b * D * L * C + (size_t)level * D * C : nullptr;
     float res[C];
 #pragma unroll
@@ -220,7 +230,7 @@ template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__restrict__ grad, const float *__restrict__ inputs,
                                                               const int32_t *__restrict__ offsets,
                                                               const int32_t *__restrict__ resolutions,
-                                                              float *__restrict__ grad_grid, uint32_t N, uint32_t chunk)
+                                                              float *__restrict__ grad_grid, uint32_t N, uint32_t chunk, GridIO io)
 {
     extern __shared__ float acc[];
     constexpr uint32_t SLICE_ROWS = BWD_SLICE_FLOATS / C;
@@ -240,11 +250,11 @@ __global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__res
             bool oob = false;
 #pragma unroll
             for (uint32_t d = 0; d < D; d++) {
-                x[d] = inputs[(size_t)b * D + d];
+                x[d] = inputs[(size_t)b * io.in_stride + io.in_col[d]];
                 oob |= (x[d] < 0.f) | (x[d] > 1.f);
             }
             if (oob) continue;
-            const float g = grad[((size_t)level * N + b) * C + ch];
+            const float g = grad[(size_t)level * io.feat_level_stride + (size_t)b * io.feat_point_stride + ch];
             Cell<D> c;
             locate<D>(x, resolution, hashmap_size, c);
 #pragma unroll
@@ -261,7 +271,7 @@ __global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__res
         bool oob = false;
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) {
-            x[d] = inputs[(size_t)b * D + d];
+            x[d] = inputs[(size_t)b * io.in_stride + io.in_col[d]];
             oob |= (x[d] < 0.f) | (x[d] > 1.f);
         }
         if (oob) continue;
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__res
             if ((c.valid & (1u << idx)) && c.row[idx] - row_lo < rows) mine |= 1u << idx;
         if (!mine) continue;
         float g[C];
-        load_row<C>(grad + ((size_t)level * N + b) * C, g);
+        load_row<C>(grad + (size_t)level * io.feat_level_stride + (size_t)b * io.feat_point_stride, g);
 #pragma unroll
         for (uint32_t idx = 0; idx < (1u << D); idx++) {
             if (mine & (1u << idx)) {
@@ -295,7 +305,7 @@ __global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__res
 // grad_inputs[b,d] = sum_l sum_c grad[l,b,c] * dy_dx[b,l,d,c]
 template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(256) k_grid_input_bwd(const float *__restrict__ grad, const float *__restrict__ dy_dx,
-                                                        float *__restrict__ grad_inputs, uint32_t N, uint32_t L)
+                                                        float *__restrict__ grad_inputs, uint32_t N, uint32_t L, GridIO io)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= N * D) return;
@@ -304,7 +314,7 @@ __global__ void __launch_bounds__(256) k_grid_input_bwd(const float *__restrict_
     float r = 0.f;
     for (uint32_t l = 0; l < L; l++) {
         float g[C], y[C];
-        load_row<C>(grad + ((size_t)l * N + b) * C, g);
+        load_row<C>(grad + (size_t)l * io.feat_level_stride + (size_t)b * io.feat_point_stride, g);
         load_row<C>(dd + (size_t)l * D * C + d * C, y);
 #pragma unroll
         for (uint32_t ch = 0; ch < C; ch++) r += g[ch] * y[ch];
@@ -314,15 +324,15 @@ __global__ void __launch_bounds__(256) k_grid_input_bwd(const float *__restrict_
 
 template <uint32_t D, uint32_t C>
 static void launch_fwd(const float *inputs, const float *emb, const int32_t *off, const int32_t *res, float *out,
-                       uint32_t N, uint32_t L, float *dy_dx, hipStream_t s)
+                       uint32_t N, uint32_t L, float *dy_dx, hipStream_t s, const GridIO &io)
 {
     { ProfScope _prof("k_grid_fwd", s); hipLaunchKernelGGL((k_grid_fwd<D, C>), dim3((N + 255) / 256, L), dim3(256), 0, s, inputs, emb, off, res, out, N, L,
-                       dy_dx); }
+                       dy_dx, io); }
 }
 
 template <uint32_t D, uint32_t C>
 static void launch_bwd(const float *grad, const float *inputs, const int32_t *off, const int32_t *res, float *gemb,
-                       uint32_t N, uint32_t L, const float *dy_dx, float *ginp, hipStream_t s)
+                       uint32_t N, uint32_t L, const float *dy_dx, float *ginp, hipStream_t s, const GridIO &io)
 {
     {
         // ~512 resident workgroups: chunk the points so that (chunks x L x typical slices) fills the chip
@@ -338,10 +348,10 @@ static void launch_bwd(const float *grad, const float *inputs, const int32_t *of
         const uint32_t chunk = (N + chunks - 1) / chunks;
         ProfScope _prof("k_grid_bwd", s);
         hipLaunchKernelGGL((k_grid_bwd_lds<D, C>), dim3(chunks, L, BWD_MAX_SLICES), dim3(BWD_THREADS),
-                           BWD_SLICE_FLOATS * sizeof(float), s, grad, inputs, off, res, gemb, N, chunk);
+                           BWD_SLICE_FLOATS * sizeof(float), s, grad, inputs, off, res, gemb, N, chunk, io);
     }
     if (dy_dx && ginp)
-        { ProfScope _prof("k_grid_input_bwd", s); hipLaunchKernelGGL((k_grid_input_bwd<D, C>), dim3((N * D + 255) / 256), dim3(256), 0, s, grad, dy_dx, ginp, N, L); }
+        { ProfScope _prof("k_grid_input_bwd", s); hipLaunchKernelGGL((k_grid_input_bwd<D, C>), dim3((N * D + 255) / 256), dim3(256), 0, s, grad, dy_dx, ginp, N, L, io); }
 }
 
 #define GSVC_DISPATCH_C(D_, CALL)                                                        \
@@ -371,9 +381,31 @@ static void launch_bwd(const float *grad, const float *inputs, const int32_t *of
 
 using namespace gsvc;
 
-extern "C" int gsvc_grid_forward(const float *inputs, const float *embeddings, const int32_t *offsets,
-                                 const int32_t *resolutions, float *outputs, uint32_t N, uint32_t D, uint32_t C,
-                                 uint32_t L, float *dy_dx, void *stream)
+static GridIO grid_io_default(uint32_t N, uint32_t D, uint32_t C)
+{
+    GridIO io;
+    io.feat_level_stride = (long long)N * C; io.feat_point_stride = C;
+    io.in_stride = (int)D; io.in_col[0] = 0; io.in_col[1] = 1; io.in_col[2] = 2;
+    return io;
+}
+
+static int grid_io_from(const gsvc_grid_io *d, uint32_t D, uint32_t C, GridIO &io, const char *what)
+{
+    GSVC_REQUIRE(d && d->feat_level_stride >= 0 && d->feat_point_stride >= (int64_t)C && d->in_stride >= 1, "%s: bad layout", what);
+    // vector row accesses: a point's C features must start on a 4 * min(C, 4)-byte boundary
+    const int64_t al = C >= 4 ? 4 : (int64_t)C;
+    GSVC_REQUIRE(d->feat_level_stride % al == 0 && d->feat_point_stride % al == 0, "%s: feature strides must be multiples of %d floats",
+                 what, (int)al);
+    io.feat_level_stride = d->feat_level_stride; io.feat_point_stride = d->feat_point_stride; io.in_stride = d->in_stride;
+    for (uint32_t k = 0; k < 3; k++) {
+        io.in_col[k] = k < D ? d->in_col[k] : 0;
+        GSVC_REQUIRE(io.in_col[k] >= 0 && io.in_col[k] < d->in_stride, "%s: input column outside the row", what);
+    }
+    return GSVC_OK;
+}
+
+static int grid_forward_impl(const float *inputs, const float *embeddings, const int32_t *offsets, const int32_t *resolutions,
+                             float *outputs, uint32_t N, uint32_t D, uint32_t C, uint32_t L, float *dy_dx, void *stream, const GridIO &io)
 {
     hipStream_t s = (hipStream_t)stream;
     if (N == 0 || L == 0) {
@@ -381,10 +413,30 @@ extern "C" int gsvc_grid_forward(const float *inputs, const float *embeddings, c
         return GSVC_OK;
     }
     GSVC_REQUIRE(inputs && embeddings && offsets && resolutions && outputs, "grid_forward: NULL pointer");
-#define FWD_CALL(D_, C_) launch_fwd<D_, C_>(inputs, embeddings, offsets, resolutions, outputs, N, L, dy_dx, s)
+#define FWD_CALL(D_, C_) launch_fwd<D_, C_>(inputs, embeddings, offsets, resolutions, outputs, N, L, dy_dx, s, io)
     GSVC_DISPATCH_DC(FWD_CALL)
 #undef FWD_CALL
     return check_launch("grid_forward");
+}
+
+static int grid_backward_impl(const float *grad, const float *inputs, const int32_t *offsets, const int32_t *resolutions,
+                              float *grad_embeddings, uint32_t N, uint32_t D, uint32_t C, uint32_t L, const float *dy_dx,
+                              float *grad_inputs, void *stream, const GridIO &io)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0 || L == 0) return GSVC_OK;
+    GSVC_REQUIRE(grad && inputs && offsets && resolutions && grad_embeddings, "grid_backward: NULL pointer");
+#define BWD_CALL(D_, C_) launch_bwd<D_, C_>(grad, inputs, offsets, resolutions, grad_embeddings, N, L, dy_dx, grad_inputs, s, io)
+    GSVC_DISPATCH_DC(BWD_CALL)
+#undef BWD_CALL
+    return check_launch("grid_backward");
+}
+
+extern "C" int gsvc_grid_forward(const float *inputs, const float *embeddings, const int32_t *offsets,
+                                 const int32_t *resolutions, float *outputs, uint32_t N, uint32_t D, uint32_t C,
+                                 uint32_t L, float *dy_dx, void *stream)
+{
+    return grid_forward_impl(inputs, embeddings, offsets, resolutions, outputs, N, D, C, L, dy_dx, stream, grid_io_default(N, D, C));
 }
 
 extern "C" int gsvc_grid_backward(const float *grad, const float *inputs, const float *embeddings,
@@ -393,11 +445,24 @@ extern "C" int gsvc_grid_backward(const float *grad, const float *inputs, const 
                                   void *stream)
 {
     (void)embeddings;
-    hipStream_t s = (hipStream_t)stream;
-    if (N == 0 || L == 0) return GSVC_OK;
-    GSVC_REQUIRE(grad && inputs && offsets && resolutions && grad_embeddings, "grid_backward: NULL pointer");
-#define BWD_CALL(D_, C_) launch_bwd<D_, C_>(grad, inputs, offsets, resolutions, grad_embeddings, N, L, dy_dx, grad_inputs, s)
-    GSVC_DISPATCH_DC(BWD_CALL)
-#undef BWD_CALL
-    return check_launch("grid_backward");
+    return grid_backward_impl(grad, inputs, offsets, resolutions, grad_embeddings, N, D, C, L, dy_dx, grad_inputs, stream,
+                              grid_io_default(N, D, C));
+}
+
+extern "C" int gsvc_grid_forward_ex(const float *inputs, const float *embeddings, const int32_t *offsets, const int32_t *resolutions,
+                                    float *outputs, uint32_t N, uint32_t D, uint32_t C, uint32_t L, const gsvc_grid_io *layout,
+                                    void *stream)
+{
+    GridIO io;
+    if (int rc = grid_io_from(layout, D, C, io, "grid_forward_ex")) return rc;
+    return grid_forward_impl(inputs, embeddings, offsets, resolutions, outputs, N, D, C, L, nullptr, stream, io);
+}
+
+extern "C" int gsvc_grid_backward_ex(const float *grad, const float *inputs, const int32_t *offsets, const int32_t *resolutions,
+                                     float *grad_embeddings, uint32_t N, uint32_t D, uint32_t C, uint32_t L, const gsvc_grid_io *layout,
+                                     void *stream)
+{
+    GridIO io;
+    if (int rc = grid_io_from(layout, D, C, io, "grid_backward_ex")) return rc;
+    return grid_backward_impl(grad, inputs, offsets, resolutions, grad_embeddings, N, D, C, L, nullptr, nullptr, stream, io);
 }

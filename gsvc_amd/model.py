@@ -82,8 +82,76 @@ class Mix3d2dEncoding(nn.Module):
         self.output_dim = sum(e.output_dim for e in (self.encoding_xyz, self.encoding_xy, self.encoding_xz, self.encoding_yz))
 
     def forward(self, x):
+        if (x.is_cuda and x.dim() == 2 and x.shape[1] == 3 and x.dtype == torch.float32 and not x.requires_grad
+                and not os.environ.get("GSVC_NO_FUSED_GRID")
+                and all(g.ste_binary for g in (self.encoding_xyz, self.encoding_xy, self.encoding_xz, self.encoding_yz))):
+            # the four grids write their column blocks of the [N, 192] matrix and read the gradient from them (gsvc_grid_*_ex):
+            # no coordinate slices, no [L, N, C] -> [N, L C] permutes, no cat — on either pass
+            grids = (self.encoding_xyz, self.encoding_xy, self.encoding_xz, self.encoding_yz)
+            return _MixGridEncode.apply(x, grids, *[g.embeddings() for g in grids])
         xy, xz, yz = x[..., 0:2], x[..., 0::2], x[..., 1:3]     # slices, not list indices: their backward is a strided add, not a sort-based index_put
         return torch.cat([self.encoding_xyz(x), self.encoding_xy(xy), self.encoding_xz(xz), self.encoding_yz(yz)], dim=-1)
+
+
+class _MixGridEncode(torch.autograd.Function):
+    """Mix3d2dEncoding for positions that carry no gradient: grid k reads columns ``COLS[k]`` of x [N, 3] and owns columns
+    [c0_k, c0_k + L_k C) of the output [N, sum L C] (level-major inside its block, as the concatenation of the per-grid
+    [N, L C] outputs is)."""
+
+    COLS = ((0, 1, 2), (0, 1), (0, 2), (1, 2))
+
+    @staticmethod
+    def _layout(grids, x, total):
+        import ctypes as C
+        from . import _lib
+        out, c0 = [], 0
+        for g, cols in zip(grids, _MixGridEncode.COLS):
+            io = _lib.GridIOC()
+            io.feat_level_stride, io.feat_point_stride, io.in_stride = g.n_features, total, x.shape[1]
+            for k, c in enumerate(cols):
+                io.in_col[k] = c
+            out.append((io, c0))
+            c0 += g.n_levels * g.n_features
+        return out
+
+    @staticmethod
+    def forward(ctx, x, grids, *embs):
+        import ctypes as C
+        from . import _lib
+        x = x.contiguous()
+        N = x.shape[0]
+        total = sum(g.n_levels * g.n_features for g in grids)
+        out = torch.empty(N, total, device=x.device, dtype=torch.float32)
+        embs = [e.contiguous() for e in embs]
+        st = _lib.current_stream(x.device)
+        for g, e, (io, c0) in zip(grids, embs, _MixGridEncode._layout(grids, x, total)):
+            _lib.check(_lib.lib().gsvc_grid_forward_ex(_lib.ptr(x), _lib.ptr(e), _lib.ptr(g.offsets_list), _lib.ptr(g.resolutions_list),
+                                                       C.c_void_p(out.data_ptr() + 4 * c0), N, g.num_dim, g.n_features, g.n_levels,
+                                                       C.byref(io), st), "gsvc_grid_forward_ex")
+        ctx.save_for_backward(x, *embs)
+        ctx.grids, ctx.total = grids, total
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        import ctypes as C
+        from . import _lib
+        x, *embs = ctx.saved_tensors
+        grids, total = ctx.grids, ctx.total
+        grad = grad.contiguous()
+        N = x.shape[0]
+        st = _lib.current_stream(x.device)
+        outs = []
+        for k, (g, e, (io, c0)) in enumerate(zip(grids, embs, _MixGridEncode._layout(grids, x, total))):
+            if not ctx.needs_input_grad[2 + k]:
+                outs.append(None)
+                continue
+            ge = torch.zeros_like(e)
+            _lib.check(_lib.lib().gsvc_grid_backward_ex(C.c_void_p(grad.data_ptr() + 4 * c0), _lib.ptr(x), _lib.ptr(g.offsets_list),
+                                                        _lib.ptr(g.resolutions_list), _lib.ptr(ge), N, g.num_dim, g.n_features,
+                                                        g.n_levels, C.byref(io), st), "gsvc_grid_backward_ex")
+            outs.append(ge)
+        return (None, None, *outs)
 
 
 MFMA_MAX_DIM = 192      # csrc/linear.hip keeps the whole weight matrix in LDS: in/out features <= 192

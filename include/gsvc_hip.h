@@ -165,6 +165,21 @@ int gsvc_grid_backward(const float *grad, const float *inputs, const float *embe
                        const int32_t *resolutions, float *grad_embeddings, uint32_t N, uint32_t D, uint32_t C,
                        uint32_t L, const float *dy_dx, float *grad_inputs, void *stream);
 
+/* The same kernels with the caller's layout (no input-gradient path): the points' coordinates are columns in_col[0..D) of a
+ * row-major [N, in_stride] matrix, the features of (level l, point b) are the C floats at l * feat_level_stride +
+ * b * feat_point_stride of `outputs` / `grad` (strides in floats, multiples of min(C, 4)).  Several grids over the same
+ * positions — Mix3d2dEncoding, reference scene/gaussian_model.py:81-147 — write their column blocks of ONE [N, sum L C] matrix
+ * (feat_level_stride = C, feat_point_stride = its row length) and read the gradient the same way: no slices, permutes or cat. */
+typedef struct gsvc_grid_io {
+    int64_t feat_level_stride, feat_point_stride;
+    int32_t in_stride, in_col[3];
+} gsvc_grid_io;
+int gsvc_grid_forward_ex(const float *inputs, const float *embeddings, const int32_t *offsets, const int32_t *resolutions,
+                         float *outputs, uint32_t N, uint32_t D, uint32_t C, uint32_t L, const gsvc_grid_io *layout, void *stream);
+int gsvc_grid_backward_ex(const float *grad, const float *inputs, const int32_t *offsets, const int32_t *resolutions,
+                          float *grad_embeddings, uint32_t N, uint32_t D, uint32_t C, uint32_t L, const gsvc_grid_io *layout,
+                          void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Entropy-rate estimator (replaces utils/entropy_models.py EntropyGaussian.forward + Low_bound backward)
  * ---------------------------------------------------------------------------------------------------- */

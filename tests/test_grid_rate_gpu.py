@@ -510,3 +510,37 @@ def test_fused_sampled_rate_matches_the_tensor_path(monkeypatch):
         if g0[k] is not None:
             scale = g0[k].abs().max().item()
             assert (g1[k] - g0[k]).abs().max().item() <= 2e-4 * scale + 1e-12, (k, scale)
+
+
+@pytest.mark.gpu
+def test_mix_encoding_strided_layout_equals_the_module_path(monkeypatch):
+    """Mix3d2dEncoding through gsvc_grid_*_ex (every grid reads its columns of x and writes / reads its column block of the
+    [N, 192] matrix) against the per-grid modules + slices + permutes + cat: same features, same table gradients."""
+    from gsvc_amd.model import Mix3d2dEncoding
+    torch.manual_seed(4)
+    enc = Mix3d2dEncoding(n_features=8, resolutions_list=(18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514), log2_hashmap_size=13,
+                          resolutions_list_2D=(130, 258, 514, 1026), log2_hashmap_size_2D=15, ste_binary=True, ste_multistep=False,
+                          add_noise=False, Q=1).cuda()
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.copy_(torch.randn_like(p))
+    N = 20011
+    x = torch.rand(N, 3, device="cuda")
+    x[0] = 0.0
+    x[1] = 1.0
+    x[2, 1] = -0.2                                   # outside the cube: zero features, no gradient
+    w = torch.randn(N, enc.output_dim, device="cuda")
+    res = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("GSVC_NO_FUSED_GRID", raising=False)
+        else:
+            monkeypatch.setenv("GSVC_NO_FUSED_GRID", "1")
+        enc.zero_grad()
+        y = enc(x)
+        assert ("MixGridEncode" in type(y.grad_fn).__name__) == fused
+        (y * w).sum().backward()
+        res.append((y.detach().clone(), [p.grad.clone() for p in enc.parameters()]))
+    assert res[0][0].shape == (N, 192) and torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-9        # float atomics reorder the sums
