@@ -231,8 +231,8 @@ extern "C" int gsvc_ste_binary_count(const float *x, int64_t n, float *y, float 
     }
     if (n == 0) return GSVC_OK;
     GSVC_REQUIRE(x && y, "ste_binary_count: NULL pointer");
-    long long blocks = (n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    long long blocks = (n + 1023) / 1024;
+    if (blocks > 256) blocks = 256;          // one atomic per block on the same word: keep them few
     gsvc::ProfScope _prof("k_ste_binary", s);
     hipLaunchKernelGGL(gsvc::k_ste_binary_count, dim3((unsigned)blocks), dim3(256), 0, s, x, (long long)n, y, count);
     return gsvc::check_launch("ste_binary_count");

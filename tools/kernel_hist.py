@@ -17,5 +17,5 @@ cnt, tim = Counter(), Counter()
 for s, e, n in seg:
     k = short(n); cnt[k] += 1; tim[k] += e - s
 print("kernels", len(seg), "busy ms", sum(tim.values()) / 1e6)
-for k, c in cnt.most_common(45):
+for k, c in cnt.most_common(90):
     print(f"{c:5d} {tim[k] / 1e3:9.1f} us  {k}")
