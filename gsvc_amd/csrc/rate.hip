@@ -139,8 +139,12 @@ __device__ __forceinline__ int rs_render_of(const RateSampleArgs &a, long long r
     return r;
 }
 
-// stats[r][0..2] = sum of Q_g over the selected rows of render r, stats[r][3] = their count (one workgroup, fixed order)
-__global__ void __launch_bounds__(256) k_rate_sample_stats(RateSampleArgs a, float *__restrict__ stats)
+// stats[r][0..2] = sum of Q_g over the selected rows of render r, stats[r][3] = their count.  Two stages in a fixed order
+// (the same bits every run): RS_STAT_BLOCKS workgroups each leave the sums of a strided share of the rows, one workgroup
+// adds those.  (One workgroup over all rows took 50-64 us: ~100 dependent gather round trips.)
+constexpr int RS_STAT_BLOCKS = 64;
+
+__global__ void __launch_bounds__(256) k_rate_sample_stats(RateSampleArgs a, float *__restrict__ spart)
 {
     __shared__ float sm[4][RS_MAX_R][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(256) k_rate_sample_stats(RateSampleArgs a, flo
     for (int r = 0; r < RS_MAX_R; r++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[r][j] = 0.f;
-    for (long long i = threadIdx.x; i < a.n_sel; i += 256) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n_sel; i += 256LL * RS_STAT_BLOCKS) {
         const long long srow = a.sel[i];
         const int r = rs_render_of(a, srow);
         const float q0 = a.Q[0][srow], q1 = a.Q[1][srow], q2 = a.Q[2][srow];
@@ -168,8 +172,20 @@ __global__ void __launch_bounds__(256) k_rate_sample_stats(RateSampleArgs a, flo
     __syncthreads();
     if (threadIdx.x < a.R * 4) {
         const int r = threadIdx.x >> 2, j = threadIdx.x & 3;
-        stats[r * 4 + j] = (sm[0][r][j] + sm[1][r][j]) + (sm[2][r][j] + sm[3][r][j]);
+        spart[blockIdx.x * 64 + r * 4 + j] = (sm[0][r][j] + sm[1][r][j]) + (sm[2][r][j] + sm[3][r][j]);
     }
+}
+
+__global__ void __launch_bounds__(64) k_rate_sample_stats_sum(const float *__restrict__ spart, int R, float *__restrict__ stats)
+{
+    if ((int)threadIdx.x >= R * 4) return;
+    float v[RS_STAT_BLOCKS];
+#pragma unroll
+    for (int b = 0; b < RS_STAT_BLOCKS; b++) v[b] = spart[b * 64 + threadIdx.x];      // all in flight together
+    float acc = 0.f;
+#pragma unroll
+    for (int b = 0; b < RS_STAT_BLOCKS; b++) acc += v[b];
+    stats[threadIdx.x] = acc;
 }
 
 // MODE 0: forward — per-block partial sums of weight * bits per (group, render) -> part[block][3][R]
@@ -245,15 +261,22 @@ __global__ void __launch_bounds__(256) k_rate_sample(RateSampleArgs a, const flo
     }
 }
 
-// S[r][g] = sum over the blocks' partial sums, in block order
-__global__ void __launch_bounds__(64) k_rate_sample_finalize(const float *__restrict__ part, int blocks, int R, float *__restrict__ S)
+// S[r][g] = sum over the blocks' partial sums: one workgroup per (g, r), each thread a strided share of the blocks, then a
+// fixed tree -> the same bits every run (the serial loop this replaces took 236 us for 1024 blocks: 1024 dependent loads)
+__global__ void __launch_bounds__(256) k_rate_sample_finalize(const float *__restrict__ part, int blocks, int R, float *__restrict__ S)
 {
-    const int t = threadIdx.x;
-    if (t >= 3 * R) return;
-    const int g = t / R, r = t - g * R;
+    __shared__ float sm[256];
+    const int g = blockIdx.x / R, r = blockIdx.x - g * R;
     float acc = 0.f;
-    for (int b = 0; b < blocks; b++) acc += part[((size_t)b * 3 + g) * RS_MAX_R + r];
-    S[r * 3 + g] = acc;
+    for (int b = threadIdx.x; b < blocks; b += 256) acc += part[((size_t)b * 3 + g) * RS_MAX_R + r];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) S[r * 3 + g] = sm[0];
 }
 
 }  // namespace gsvc
@@ -312,7 +335,7 @@ extern "C" int64_t gsvc_rate_sample_scratch_floats(int64_t n_sel)
     long long blocks = (n_sel + 3) / 4;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    return 64 + blocks * 3 * gsvc::RS_MAX_R;
+    return 64 + blocks * 3 * gsvc::RS_MAX_R + 64 * gsvc::RS_STAT_BLOCKS;
 }
 
 extern "C" int gsvc_rate_sample_forward(const gsvc_rate_sample *d, float *scratch, float *S, void *stream)
@@ -325,10 +348,12 @@ extern "C" int gsvc_rate_sample_forward(const gsvc_rate_sample *d, float *scratc
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     gsvc::ProfScope _prof("k_rate_sample", s);
-    hipLaunchKernelGGL(gsvc::k_rate_sample_stats, dim3(1), dim3(256), 0, s, a, scratch);
+    float *spart = scratch + 64 + blocks * 3 * gsvc::RS_MAX_R;
+    hipLaunchKernelGGL(gsvc::k_rate_sample_stats, dim3(gsvc::RS_STAT_BLOCKS), dim3(256), 0, s, a, spart);
+    hipLaunchKernelGGL(gsvc::k_rate_sample_stats_sum, dim3(1), dim3(64), 0, s, spart, d->renders, scratch);
     hipLaunchKernelGGL(gsvc::k_rate_sample<0>, dim3((unsigned)blocks, 3), dim3(256), 0, s, a, scratch, scratch + 64, nullptr, nullptr,
                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d->K);
-    hipLaunchKernelGGL(gsvc::k_rate_sample_finalize, dim3(1), dim3(64), 0, s, scratch + 64, (int)blocks, d->renders, S);
+    hipLaunchKernelGGL(gsvc::k_rate_sample_finalize, dim3(3 * d->renders), dim3(256), 0, s, scratch + 64, (int)blocks, d->renders, S);
     return gsvc::check_launch("rate_sample_forward");
 }
 

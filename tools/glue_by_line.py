@@ -27,7 +27,7 @@ for i in range(30):
     tr.step(i + 1)
 torch.cuda.synchronize()
 N = 3
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True,
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     for i in range(N):
         tr.step(40 + i)
@@ -50,3 +50,18 @@ for (w, n), (t, c) in by.items():
 for w, t in sorted(line.items(), key=lambda kv: -kv[1])[:45]:
     ops = sorted(((n, tt, c) for (ww, n), (tt, c) in by.items() if ww == w), key=lambda x: -x[1])[:5]
     print(f"{t / N:8.1f} us  {w:34s} " + ", ".join(f"{n[6:]} {tt / N:.0f}us x{c // N}" for n, tt, c in ops))
+# the backward's own launches (gradient accumulation at fan-outs, reductions inside autograd nodes): by operator and shape
+bw = defaultdict(lambda: [0.0, 0])
+for ev in prof.events():
+    if not ev.name.startswith("aten::") or ev.self_device_time_total <= 0:
+        continue
+    fr = [f for f in ev.stack if "gsvc_amd" in f and "torch/" not in f]
+    if fr and "train.py(200)" not in fr[0] and "backward" not in fr[0]:
+        continue
+    shp = str([list(x) for x in (ev.input_shapes or []) if x])[:70]
+    k = (ev.name, shp, (fr[0].split("gsvc_amd/")[-1].split(":")[0].strip() if fr else ""))
+    bw[k][0] += ev.self_device_time_total
+    bw[k][1] += 1
+print("backward-side aten launches by shape:")
+for (n, shp, w), (t, c) in sorted(bw.items(), key=lambda kv: -kv[1][0])[:40]:
+    print(f"{t / N:8.1f} us x{c / N:4.1f}  {n[6:]:18s} {shp:72s} {w}")
