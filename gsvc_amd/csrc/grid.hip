@@ -12,6 +12,8 @@
 // with 16-byte loads; the [L,N,C] output row of a lane is contiguous so a wave writes 64*4*C contiguous
 // bytes.  The table backward accumulates table slices in LDS (k_grid_bwd_lds below).
 #include "common.h"
+#include <algorithm>
+#include <atomic>
 
 namespace gsvc {
 
@@ -47,7 +49,10 @@ __device__ __forceinline__ uint32_t grid_row(const uint32_t (&p)[D], uint32_t ha
         }
     }
     if (stride > hashmap_size) index = fast_hash<D>(p);
-    return index % hashmap_size;
+    // index % hashmap_size without the ~30-instruction division where it is not needed: a dense index is already below the
+    // table size, a hashed level's table has 2^log2_hashmap_size rows
+    if (index >= hashmap_size) index = (hashmap_size & (hashmap_size - 1)) == 0 ? index & (hashmap_size - 1) : index % hashmap_size;
+    return index;
 }
 
 template <uint32_t D>
@@ -218,32 +223,174 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inpu
 // per 2-D level in cfg_20240919) and every visible anchor adds into 2^D rows of every level: with global atomics
 // that is N*L*2^D scattered memory-side requests (~17 G requests/s on MI355X: 1.0 ms for 181k points x 12 levels;
 // measured with C consecutive lanes per point so that a corner is one 4*C-byte request).
-// Here a workgroup owns (level, table slice of BWD_SLICE_FLOATS/C rows, chunk of points): it accumulates the chunk's
-// contributions to its slice with LDS atomics and then adds the slice to the gradient table with contiguous
-// atomics (zeros skipped).  A level that needs more than gridDim.z slices falls back to global atomics in its
-// z == 0 workgroups, so one launch covers every table size without the host knowing the (device-resident) offsets.
-constexpr uint32_t BWD_SLICE_FLOATS = 32768;       // 128 KiB of LDS
+// Here a workgroup owns (level, table slice, chunk of points): it accumulates the chunk's contributions to its slice
+// with LDS atomics and then adds the slice to the gradient table with contiguous atomics (zeros skipped).  A level
+// that needs more than gridDim.z slices falls back to global atomics in its z == 0 workgroups, so one launch covers
+// every table size without the host knowing the (device-resident) offsets.
+//
+// The LDS accumulators are 64-bit FIXED-POINT integers, not floats.  Measured on gfx950 (tools/micro/lds_atomics.hip, random
+// rows, 1024-thread workgroups): ds_add_f32 retires 0.33 lanes per cycle and CU, ds_add_u64 5.9, ds_add_u32 10.9 (rows
+// C + 1 words apart; with a stride of C = 8 words a wave instruction falls on 8 banks and the integer forms drop to ~3).
+// With float accumulators the atomics were the kernel's time (115 k points: 3-D 12 levels 515 us, 2-D 4 levels 125 us; now
+// 128 / 79).  Scale: per LEVEL, a power of two 2^e with (largest |grad| of the level) x (most contributions a word can
+// receive: chunk points x 2^D corners) x 2^e <= 2^62, so a word cannot overflow; a contribution is rounded to 2^-47 of the
+// level's largest gradient or better (chunk <= 32 k points), i.e. entries down to 2^-23 of that maximum keep float accuracy
+// and smaller ones lose it gradually (a float sum rounds to 2^-24 of its running value), and the sum of a slice no longer
+// depends on the order of the adds.  The maxima come from k_grid_absmax (block maxima into a slot of a module-level ring; +inf
+// stands for "not finite": that level takes the float path so that NaN / inf propagate as they did).
+constexpr uint32_t BWD_SLICE_BYTES = 147456;       // 144 KiB of LDS: 2048 rows of 8 + 1 eight-byte words
 constexpr uint32_t BWD_THREADS = 1024;
 constexpr uint32_t BWD_MAX_SLICES = 16;
+constexpr uint32_t ABSMAX_BLOCKS = 1024, ABSMAX_RING = 32;     // up to ABSMAX_BLOCKS / L (<= 64) blocks per level
+__device__ float g_grid_absmax[ABSMAX_RING][ABSMAX_BLOCKS];
 
+// largest |grad| of each level: gridDim = (blocks per level, L), block maxima to g_grid_absmax[slot][level * bpl + block]
+template <uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_absmax(const float *__restrict__ grad, uint32_t N, GridIO io, uint32_t slot)
+{
+    __shared__ float red[4];
+    float m = 0.f;
+    bool bad = false;
+    const float *gl = grad + (size_t)blockIdx.y * io.feat_level_stride;
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < N; b += gridDim.x * 256) {
+        float g[C];
+        load_row<C>(gl + (size_t)b * io.feat_point_stride, g);
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) {
+            const float a = fabsf(g[ch]);
+            bad |= !(a <= 3.402823466e38f);
+            m = fmaxf(m, a);
+        }
+    }
+    if (bad) m = __builtin_inff();
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) g_grid_absmax[slot][blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// x = value * 2^e, |x| < 2^51 -> nearest 64-bit integer: adding 1.5 * 2^52 in double leaves the integer in the low mantissa
+// bits (two's complement), so the difference of the bit patterns is the result — 4 instructions (a float-only split into
+// two 31-bit halves took 13, and with 2^D * C values per point the conversion was the loop's largest cost)
+__device__ __forceinline__ long long fx_from_float(float x)
+{
+    const double magic = 6755399441055744.0;
+    return __double_as_longlong((double)x + magic) - __double_as_longlong(magic);
+}
+
+// A located point in the form the table backward keeps in registers: the fractional position and renormalisation (the
+// corner weights are re-multiplied from them, in locate()'s order), the 2^D row indices (16 bits each) and the valid mask.
+template <uint32_t D>
+struct BwdPoint {
+    float frac[D], wn_re;
+    unsigned long long rlo, rhi;       // 16-bit row indices of corners 0-3 / 4-7 (scalars: an array here ends up in scratch)
+    uint32_t valid;                    // bit per corner; 0 for a point outside [0, 1]^D or past the end
+};
+
+// locate() for the table backward: the same float operations in the same order, results straight into the packed form
+template <uint32_t D>
+__device__ __forceinline__ void locate_packed(const float (&x)[D], uint32_t resolution, uint32_t hashmap_size, BwdPoint<D> &o)
+{
+#pragma clang fp contract(off)
+    uint32_t cell[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        oob |= (x[d] < 0.f) | (x[d] > 1.f);
+        const float pos = x[d] * (float)(resolution - 2) + 0.5f;
+        cell[d] = (uint32_t)floorf(pos);
+        o.frac[d] = pos - (float)cell[d];
+    }
+    float wn = 0.f;
+    uint32_t valid = 0;
+    o.rlo = o.rhi = 0;
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1.f;
+        uint32_t pl[D];
+        bool border = false;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) {
+                w *= 1.f - o.frac[d];
+                pl[d] = cell[d];
+            } else {
+                w *= o.frac[d];
+                pl[d] = min(cell[d] + 1, resolution - 1);
+            }
+            border |= (pl[d] == 0) | (pl[d] == resolution - 1);
+        }
+        if (!border) {
+            const unsigned long long rw = (unsigned long long)grid_row<D>(pl, hashmap_size, resolution) << (16 * (idx & 3));
+            if (idx < 4) o.rlo |= rw; else o.rhi |= rw;
+            valid |= 1u << idx;
+            wn += w;
+        }
+    }
+    if (wn == 0.f) wn = 1e-9f;
+    o.wn_re = 1.0f / wn;
+    o.valid = oob ? 0u : valid;
+}
+
+// corners of one located point that fall into the slice [row_lo, row_lo + rows): scaled gradient row -> fixed point -> LDS.
+// A loop over the SET bits of `mine`: a wave runs as many rounds as its busiest lane has corners in the slice (a level
+// of 4 slices: ~5 of 8), and an LDS atomic costs the same ~11 cycles whether 4 or 64 of its lanes are active.
+template <uint32_t D, uint32_t C, uint32_t CP>
+__device__ __forceinline__ void bwd_accumulate(const BwdPoint<D> &pt, uint32_t mine, const float (&g)[C], unsigned long long *acc,
+                                               uint32_t row_lo)
+{
+    while (mine) {
+        const uint32_t idx = (uint32_t)__ffs((int)mine) - 1u;
+        mine &= mine - 1u;
+        const unsigned long long word = (D == 3 && idx >= 4) ? pt.rhi : pt.rlo;
+        const uint32_t r = ((uint32_t)(word >> (16 * (idx & 3))) & 0xffffu) - row_lo;
+        float w = 1.f;               // the corner's weight, multiplied in the order locate() uses
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) w *= (idx & (1u << d)) ? pt.frac[d] : 1.f - pt.frac[d];
+        w *= pt.wn_re;
+        unsigned long long *dst = acc + r * CP;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) atomicAdd(dst + ch, (unsigned long long)fx_from_float(w * g[ch]));
+    }
+}
+
+// A workgroup owns (chunk of points, level, table slice).  The chunks are LARGE (~N * L * slices / 256 points: one round of
+// workgroups on the chip): every workgroup ends by adding its slice to the gradient table with float atomics, and the chip
+// retires only ~0.13 T of those per second however contiguous they are (measured: 23 M in 170 us) — with 2.7 k-point chunks
+// that flush, not the accumulation, was the kernel's time.  A workgroup walks its chunk 1024 points at a time; the loop is
+// software-pipelined over two points per thread (A / B): the positions of the next point and the gradient row of the
+// current one are in flight while the previous point's corners are added.
 template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__restrict__ grad, const float *__restrict__ inputs,
                                                               const int32_t *__restrict__ offsets,
                                                               const int32_t *__restrict__ resolutions,
-                                                              float *__restrict__ grad_grid, uint32_t N, uint32_t chunk, GridIO io)
+                                                              float *__restrict__ grad_grid, uint32_t N, uint32_t chunk, GridIO io,
+                                                              uint32_t slot, uint32_t absmax_bpl)
 {
-    extern __shared__ float acc[];
-    constexpr uint32_t SLICE_ROWS = BWD_SLICE_FLOATS / C;
+    extern __shared__ long long acc[];
+    __shared__ float s_max[BWD_THREADS / 64];
+    constexpr uint32_t CP = C > 1 ? C + 1 : 1;
+    constexpr uint32_t SLICE_ROWS = BWD_SLICE_BYTES / (8 * CP);
     const uint32_t level = blockIdx.y, slice = blockIdx.z, tid = threadIdx.x;
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
     const uint32_t resolution = (uint32_t)resolutions[level];
     const uint32_t slices = (hashmap_size + SLICE_ROWS - 1) / SLICE_ROWS;
-    const bool fallback = slices > gridDim.z;
+    const uint32_t p0 = blockIdx.x * chunk, p1 = min(N, p0 + chunk);
+    // largest |grad| of this level (block maxima of k_grid_absmax)
+    float gmax = tid < absmax_bpl ? g_grid_absmax[slot][level * absmax_bpl + tid] : 0.f;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, k, 64));
+    if ((tid & 63) == 0) s_max[tid >> 6] = gmax;
+    __syncthreads();
+    gmax = 0.f;
+#pragma unroll
+    for (uint32_t w = 0; w < BWD_THREADS / 64; w++) gmax = fmaxf(gmax, s_max[w]);
+    const bool fallback = absmax_bpl == 0 || slices > gridDim.z || hashmap_size > 65536u || !(gmax <= 3.402823466e38f);
     if (fallback ? slice != 0 : slice >= slices) return;         // block-uniform
     grad_grid += (size_t)(uint32_t)offsets[level] * C;
-    const uint32_t p0 = blockIdx.x * chunk, p1 = min(N, p0 + chunk);
     if (fallback) {
-        // C consecutive lanes per point: one contiguous 4*C-byte atomic segment per corner
+        // float atomics straight into the table; C consecutive lanes per point: one contiguous 4*C-byte segment per corner
         for (uint32_t t = p0 * C + tid; t < p1 * C; t += BWD_THREADS) {
             const uint32_t b = t / C, ch = t - b * C;
             float x[D];
@@ -263,42 +410,59 @@ __global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__res
         }
         return;
     }
+    if (gmax == 0.f || p0 >= p1) return;                          // every contribution of the launch is zero / empty chunk
+    // 2^e: gmax < 2^eg, contributions per word <= chunk * 2^D <= 2^ec (and one contribution below 2^51: fx_from_float)
+    const int eg = ilogbf(gmax) + 1, ec = max(32 - __clz((int)max(chunk, 2u) - 1) + (int)D, 11);
+    const int e = min(62 - eg - ec, 120);
+    const float scale = ldexpf(1.f, e), inv_scale = ldexpf(1.f, -e);
     const uint32_t row_lo = slice * SLICE_ROWS, rows = min(SLICE_ROWS, hashmap_size - row_lo);
-    for (uint32_t i = tid; i < rows * C; i += BWD_THREADS) acc[i] = 0.f;
+    for (uint32_t i = tid; i < rows * CP; i += BWD_THREADS) acc[i] = 0;
     __syncthreads();
-    for (uint32_t b = p0 + tid; b < p1; b += BWD_THREADS) {
-        float x[D];
-        bool oob = false;
+    unsigned long long *uacc = reinterpret_cast<unsigned long long *>(acc);
+    const float *glev = grad + (size_t)level * io.feat_level_stride;
+
+    auto load_x = [&](uint32_t b, float (&x)[D]) {
 #pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            x[d] = inputs[(size_t)b * io.in_stride + io.in_col[d]];
-            oob |= (x[d] < 0.f) | (x[d] > 1.f);
-        }
-        if (oob) continue;
-        Cell<D> c;
-        locate<D>(x, resolution, hashmap_size, c);
-        uint32_t mine = 0;
-#pragma unroll
-        for (uint32_t idx = 0; idx < (1u << D); idx++)
-            if ((c.valid & (1u << idx)) && c.row[idx] - row_lo < rows) mine |= 1u << idx;
-        if (!mine) continue;
-        float g[C];
-        load_row<C>(grad + (size_t)level * io.feat_level_stride + (size_t)b * io.feat_point_stride, g);
+        for (uint32_t d = 0; d < D; d++) x[d] = b < p1 ? inputs[(size_t)b * io.in_stride + io.in_col[d]] : -1.f;
+    };
+    // locate point b; which of its corners are this slice's; request its gradient row if any is
+    auto stage1 = [&](uint32_t b, const float (&x)[D], BwdPoint<D> &pt, uint32_t &mine, float (&g)[C]) {
+        locate_packed<D>(x, resolution, hashmap_size, pt);
+        mine = 0;
 #pragma unroll
         for (uint32_t idx = 0; idx < (1u << D); idx++) {
-            if (mine & (1u << idx)) {
-                const float w = c.w[idx] * c.wn_re;
-                float *dst = acc + (c.row[idx] - row_lo) * C;
-#pragma unroll
-                for (uint32_t ch = 0; ch < C; ch++) atomicAdd(dst + ch, w * g[ch]);
-            }
+            const uint32_t r = ((uint32_t)((idx < 4 ? pt.rlo : pt.rhi) >> (16 * (idx & 3))) & 0xffffu) - row_lo;
+            if ((pt.valid & (1u << idx)) && r < rows) mine |= 1u << idx;
         }
+        if (mine) load_row<C>(glev + (size_t)b * io.feat_point_stride, g);
+    };
+    auto stage2 = [&](const BwdPoint<D> &pt, uint32_t mine, float (&g)[C]) {
+        if (!mine) return;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) g[ch] *= scale;      // a power of two: exact
+        bwd_accumulate<D, C, CP>(pt, mine, g, uacc, row_lo);
+    };
+    BwdPoint<D> ptA, ptB;
+    float gA[C], gB[C], xA[D], xB[D];
+    uint32_t mineA = 0, mineB = 0;
+    uint32_t b = p0 + tid;
+    load_x(b, xA);
+    load_x(b + BWD_THREADS, xB);
+    stage1(b, xA, ptA, mineA, gA);
+    // invariant at the top: A = point b (located, row requested), xB = positions of point b + 1024 (requested)
+    for (; b < p1; b += 2 * BWD_THREADS) {
+        load_x(b + 2 * BWD_THREADS, xA);
+        stage1(b + BWD_THREADS, xB, ptB, mineB, gB);
+        stage2(ptA, mineA, gA);
+        load_x(b + 3 * BWD_THREADS, xB);
+        stage1(b + 2 * BWD_THREADS, xA, ptA, mineA, gA);
+        stage2(ptB, mineB, gB);
     }
     __syncthreads();
     float *out = grad_grid + (size_t)row_lo * C;
     for (uint32_t i = tid; i < rows * C; i += BWD_THREADS) {
-        const float v = acc[i];
-        if (v != 0.f) atomicAdd(out + i, v);
+        const long long v = acc[(i / C) * CP + i % C];
+        if (v != 0) atomicAdd(out + i, (float)v * inv_scale);
     }
 }
 
@@ -335,20 +499,29 @@ static void launch_bwd(const float *grad, const float *inputs, const int32_t *of
                        uint32_t N, uint32_t L, const float *dy_dx, float *ginp, hipStream_t s, const GridIO &io)
 {
     {
-        // ~512 resident workgroups: chunk the points so that (chunks x L x typical slices) fills the chip
+        // one round of workgroups on the chip.  The table sizes are device-resident: the slice count per level is taken as
+        // what cfg_20240919's tables need (2^13 rows per 3-D level, 2^15 per 2-D level, 8 features); smaller tables leave
+        // workgroups that return at once
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_bwd_lds<D, C>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BWD_SLICE_FLOATS * sizeof(float)));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_SLICE_BYTES);
             attr_set = true;
         }
-        uint32_t chunks = (512 + L - 1) / L;
-        if (chunks > (N + 2047) / 2048) chunks = (N + 2047) / 2048;      // at least 2048 points per workgroup
+        static const uint32_t want_wgs = getenv("GSVC_GRID_BWD_WGS") ? (uint32_t)atoi(getenv("GSVC_GRID_BWD_WGS")) : 256;
+        const uint32_t slices_guess = D == 3 ? 4 : (D == 2 ? 16 : 1);
+        uint32_t chunks = std::max(1u, want_wgs / (L * slices_guess));      // rounded down: a second round of workgroups doubles the time
+        chunks = std::min(chunks, (N + 2047) / 2048);              // at least 2048 points per workgroup
         if (chunks == 0) chunks = 1;
         const uint32_t chunk = (N + chunks - 1) / chunks;
+        static std::atomic<uint32_t> ring{0};
+        const uint32_t slot = ring.fetch_add(1) % ABSMAX_RING;
+        const uint32_t bpl = std::max(1u, std::min(std::min(ABSMAX_BLOCKS / L, 64u), (N + 1023) / 1024));
         ProfScope _prof("k_grid_bwd", s);
-        hipLaunchKernelGGL((k_grid_bwd_lds<D, C>), dim3(chunks, L, BWD_MAX_SLICES), dim3(BWD_THREADS),
-                           BWD_SLICE_FLOATS * sizeof(float), s, grad, inputs, off, res, gemb, N, chunk, io);
+        if (L <= ABSMAX_BLOCKS)
+            hipLaunchKernelGGL((k_grid_absmax<C>), dim3(bpl, L), dim3(256), 0, s, grad, N, io, slot);
+        hipLaunchKernelGGL((k_grid_bwd_lds<D, C>), dim3(chunks, L, BWD_MAX_SLICES), dim3(BWD_THREADS), BWD_SLICE_BYTES, s, grad,
+                           inputs, off, res, gemb, N, chunk, io, slot, L <= ABSMAX_BLOCKS ? bpl : 0u);
     }
     if (dy_dx && ginp)
         { ProfScope _prof("k_grid_input_bwd", s); hipLaunchKernelGGL((k_grid_input_bwd<D, C>), dim3((N * D + 255) / 256), dim3(256), 0, s, grad, dy_dx, ginp, N, L, io); }

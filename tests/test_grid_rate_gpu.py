@@ -75,6 +75,52 @@ def test_grid_kernels_match_oracle(oracle_lib, D, Cf, res, log2, N):
     assert np.abs(ge.cpu().numpy() - 2 * ref_ge).max() < 2e-5 * max(1.0, np.abs(ref_ge).max())
 
 
+def test_grid_table_backward_fixed_point_range_determinism_and_nonfinite(oracle_lib):
+    """k_grid_bwd_lds sums a table slice in 64-bit fixed point scaled by the level's largest |grad| (csrc/grid.hip): a
+    contribution is resolved to 2^-47 of that or better, so entries six orders of magnitude below the level's largest
+    gradient still carry float accuracy; levels are scaled apart; two launches give the same bits (one chunk of points: the
+    slice sums do not depend on the order of the adds); a non-finite gradient propagates the way the float path did."""
+    from gsvc_amd import gridencoder_backend as be
+    D, Cf, res, log2, N = 3, 8, (18, 24, 33, 44), 13, 2000
+    rng = np.random.default_rng(11)
+    off, rs = _levels(D, res, log2)
+    L = len(res)
+    emb = np.ones((off[-1], Cf), dtype=np.float32)
+    x = rng.uniform(0.05, 0.95, (N, D)).astype(np.float32)
+    g = rng.standard_normal((L, N, Cf)).astype(np.float32)
+    g[..., 0] *= 1e3                 # channel 0 carries each level's largest gradients
+    g[..., 1] *= 1e-3                # channel 1 is six orders of magnitude below them
+    g[..., 2] = 0.0
+    g[3] *= 1e-12                    # a level whose gradients are all tiny keeps its own scale
+    ref_ge, _ = oracle_lib.grid_backward(g, x, emb, off, rs, None)
+    outs = []
+    for _ in range(2):
+        ge = torch.zeros(off[-1], Cf, device="cuda")
+        be.grid_encode_backward(C(g), C(x), C(emb), C(off), C(rs), ge, N, D, Cf, L, 0, 128, None, None, None, None)
+        outs.append(ge)
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].cpu().numpy()
+    for lvl in range(L):
+        for ch in range(Cf):         # per level and channel, relative to that block's own scale
+            a, b = got[off[lvl]:off[lvl + 1], ch], ref_ge[off[lvl]:off[lvl + 1], ch]
+            assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max() + 0.0, (lvl, ch)
+    assert np.all(got[:, 2] == 0)
+    # every gradient zero: nothing is added
+    ge = torch.zeros(off[-1], Cf, device="cuda")
+    be.grid_encode_backward(torch.zeros(L, N, Cf, device="cuda"), C(x), C(emb), C(off), C(rs), ge, N, D, Cf, L, 0, 128, None, None, None, None)
+    assert not ge.any()
+    # one NaN / inf in the incoming gradient reaches the rows that point touches (its level takes the float path)
+    for bad in (np.nan, np.inf):
+        g2 = g.copy()
+        g2[1, 7, 3] = bad
+        ge = torch.zeros(off[-1], Cf, device="cuda")
+        be.grid_encode_backward(C(g2), C(x), C(emb), C(off), C(rs), ge, N, D, Cf, L, 0, 128, None, None, None, None)
+        got = ge.cpu().numpy()
+        assert (~np.isfinite(got[off[1]:off[2], 3])).sum() >= 1 and np.isfinite(np.delete(got, 3, axis=1)).all()
+        fin = np.isfinite(got[:, 3])
+        assert np.abs(got[fin, 3] - ref_ge[fin, 3]).max() <= 1e-5 * np.abs(ref_ge[:, 3]).max()
+
+
 def test_grid_backend_error_behaviour():
     from gsvc_amd import _lib
     from gsvc_amd import gridencoder_backend as be
