@@ -105,6 +105,7 @@ _SIGNATURES = {
     "gsvc_gen_tail_backward": (C.c_int, [_vp] * 7 + [C.POINTER(C.c_float), C.POINTER(C.c_float), _i64, C.c_int32] + [_vp] * 12),
     "gsvc_gather_rows_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_gather_rows_backward": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [_vp] * 9),
+    "gsvc_gather_rows_backward_ranked": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [_vp] * 9),
     "gsvc_ctx_post_forward": (C.c_int, [_vp, _vp, _i64, C.c_int32, _vp, _vp, _vp, _vp]),
     "gsvc_ctx_post_backward": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_film_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),

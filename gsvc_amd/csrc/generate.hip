@@ -220,6 +220,65 @@ __global__ void __launch_bounds__(256) k_gather_rows_bwd(const float *__restrict
     }
 }
 
+// The same backward WITHOUT atomics, for rows that are the concatenation of R ascending index lists (the R views of a
+// fitting step): seen[r * A + a] says whether view r holds anchor a, rank[r * A + a] (inclusive scan of seen) - 1 is its row.
+// One thread per (anchor, channel) adds the <= R rows in view order — the same bits every run, no zero fill before it, and
+// not bound by the ~0.13 T float atomics per second the chip retires (19 M of them per step).
+constexpr int RANKED_ANCHORS = 64, RANKED_VIEWS = 8;      // anchors per workgroup; views held in LDS (R <= 8)
+__global__ void __launch_bounds__(256) k_gather_rows_bwd_ranked(const float *__restrict__ ps, const float *__restrict__ pm,
+                                                                const unsigned char *__restrict__ seen,
+                                                                const long long *__restrict__ rank, int R, long long A, GatherDims d,
+                                                                int decoded, const float *__restrict__ gf, const float *__restrict__ go,
+                                                                const float *__restrict__ gs, const float *__restrict__ gm,
+                                                                float *__restrict__ df, float *__restrict__ dof, float *__restrict__ ds,
+                                                                float *__restrict__ dm)
+{
+    // the row of every (anchor, view) pair of the workgroup's 64 anchors is looked up ONCE (one coalesced load per thread) and
+    // shared through LDS; every (anchor, channel) then adds its <= R rows.  (With each (anchor, channel) thread reading the
+    // mask / rank words itself the kernel was bound by those ~50-fold redundant load instructions: 80-110 us.)
+    __shared__ long long s_row[RANKED_VIEWS][RANKED_ANCHORS];
+    const long long a0 = (long long)blockIdx.x * RANKED_ANCHORS;
+    for (int t = threadIdx.x; t < RANKED_VIEWS * RANKED_ANCHORS; t += 256) {
+        const int v = t / RANKED_ANCHORS, u = t - v * RANKED_ANCHORS;
+        const long long a = a0 + u, j = (long long)v * A + a;
+        const bool in = v < R && a < A;
+        const unsigned char sn = in ? seen[j] : (unsigned char)0;
+        const long long rk = in ? rank[j] : 0;
+        s_row[v][u] = sn ? rk - 1 : -1;
+    }
+    __syncthreads();
+    const int CT = d.F + d.K3 + d.S + d.K;
+    const int n_anchor = (int)min((long long)RANKED_ANCHORS, A - a0);
+    for (int item = threadIdx.x; item < n_anchor * CT; item += 256) {
+        const int u = item / CT;
+        int c = item - u * CT;
+        const float *g;
+        float *out;
+        int W, kind;
+        if (c < d.F) { g = gf; out = df; W = d.F; kind = 0; }
+        else if ((c -= d.F) < d.K3) { g = go; out = dof; W = d.K3; kind = 0; }
+        else if ((c -= d.K3) < d.S) { g = gs; out = ds; W = d.S; kind = 1; }
+        else { c -= d.S; g = gm; out = dm; W = d.K; kind = 2; }
+        if (!g || !out) continue;
+        float val[RANKED_VIEWS];
+#pragma unroll
+        for (int v = 0; v < RANKED_VIEWS; v++) {
+            const long long row = s_row[v][u];
+            val[v] = row >= 0 ? g[row * W + c] : 0.f;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int v = 0; v < RANKED_VIEWS; v++) acc += val[v];
+        const long long a = a0 + u;
+        if (!decoded && kind == 1) acc *= expf(ps[a * W + c]);
+        if (!decoded && kind == 2) {
+            const float sg = 1.0f / (1.0f + expf(-pm[a * W + c]));
+            acc *= sg * (1.0f - sg);
+        }
+        out[a * W + c] = acc;
+    }
+}
+
 // Tail of an EntropyParamsNet (reference scene/gaussian_model.py:1586-1596): params [n, 2 C] = [mean | scale], q [n] ->
 // scale_c = max(scale, 1e-9), adj = exp(clamp(q, -10, 10)); backward assembles d params = [g_mean | g_scale * (scale >= 1e-9)]
 // and d q = g_adj * adj * (|q| <= 10) — was 9 launches forward and ~30 backward for the three networks.
@@ -371,6 +430,24 @@ extern "C" int gsvc_gather_rows_backward(const float *scaling_p, const float *ma
                        (const long long *)vis, (long long)rows, d, decoded, g_feat, g_offsets, g_scaling, g_mask, d_feat, d_offset,
                        d_scaling, d_mask);
     return gsvc::check_launch("gather_rows_backward");
+}
+
+extern "C" int gsvc_gather_rows_backward_ranked(const float *scaling_p, const float *mask_p, const uint8_t *seen, const int64_t *rank,
+                                                int32_t R, int64_t A, int32_t F, int32_t K, int32_t S, int32_t decoded,
+                                                const float *g_feat, const float *g_offsets, const float *g_scaling, const float *g_mask,
+                                                float *d_feat, float *d_offset, float *d_scaling, float *d_mask, void *stream)
+{
+    GSVC_REQUIRE(R >= 0 && A >= 0 && F >= 0 && K >= 0 && S >= 0 && F + K + S > 0, "gather_rows_backward_ranked: bad shape");
+    if (A == 0) return GSVC_OK;
+    GSVC_REQUIRE(R <= gsvc::RANKED_VIEWS, "gather_rows_backward_ranked: at most 8 views");
+    GSVC_REQUIRE((R == 0 || (seen && rank)) && (S == 0 || scaling_p) && (K == 0 || mask_p), "gather_rows_backward_ranked: NULL pointer");
+    const gsvc::GatherDims d{F, 3 * K, S, K};
+    const int64_t blocks = (A + gsvc::RANKED_ANCHORS - 1) / gsvc::RANKED_ANCHORS;
+    gsvc::ProfScope _prof("k_gather_rows_bwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(gsvc::k_gather_rows_bwd_ranked, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, scaling_p,
+                       mask_p, seen, (const long long *)rank, R, (long long)A, d, decoded, g_feat, g_offsets, g_scaling, g_mask, d_feat,
+                       d_offset, d_scaling, d_mask);
+    return gsvc::check_launch("gather_rows_backward_ranked");
 }
 
 extern "C" int gsvc_ctx_post_forward(const float *params, const float *q, int64_t n, int32_t C, float *mean, float *scale, float *adj,

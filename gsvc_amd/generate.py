@@ -107,29 +107,38 @@ def _visible_scaling(pc, vis):
 
 
 class _GatherFeat(torch.autograd.Function):
-    """feat = _anchor_feat[vis] (csrc/generate.hip k_gather_rows with the feature group only; the scatter-add is its backward)."""
+    """feat = _anchor_feat[vis] (csrc/generate.hip k_gather_rows with the feature group only; the scatter-add is its backward).
+    ``seen`` / ``rank`` (a StepPlan's flattened view masks and their inclusive scan) select the atomic-free backward."""
 
     @staticmethod
-    def forward(ctx, feat_p, vis):
+    def forward(ctx, feat_p, vis, seen=None, rank=None):
         from . import _lib
         feat_p, vis = feat_p.contiguous(), vis.contiguous()
         rows, F = vis.shape[0], feat_p.shape[1]
         feat = torch.empty(rows, F, device=feat_p.device, dtype=torch.float32)
         _lib.check(_lib.lib().gsvc_gather_rows_forward(_lib.ptr(feat_p), None, None, None, _lib.ptr(vis), rows, F, 0, 0, 0, _lib.ptr(feat),
                                                        None, None, None, _lib.current_stream(feat_p.device)), "gsvc_gather_rows_forward")
-        ctx.save_for_backward(vis)
+        ctx.save_for_backward(vis, seen, rank)
         ctx.shape = feat_p.shape
         return feat
 
     @staticmethod
     def backward(ctx, g):
         from . import _lib
-        (vis,) = ctx.saved_tensors
+        vis, seen, rank = ctx.saved_tensors
+        A, F = ctx.shape
+        if seen is not None:
+            d = torch.empty(ctx.shape, device=vis.device, dtype=torch.float32)
+            _lib.check(_lib.lib().gsvc_gather_rows_backward_ranked(None, None, _lib.ptr(seen), _lib.ptr(rank), seen.numel() // A, A, F, 0, 0, 0,
+                                                                   _lib.ptr(g.contiguous()), None, None, None, _lib.ptr(d), None, None,
+                                                                   None, _lib.current_stream(vis.device)),
+                       "gsvc_gather_rows_backward_ranked")
+            return d, None, None, None
         d = torch.zeros(ctx.shape, device=vis.device, dtype=torch.float32)
         _lib.check(_lib.lib().gsvc_gather_rows_backward(None, None, _lib.ptr(vis), vis.shape[0], ctx.shape[1], 0, 0, 0,
                                                         _lib.ptr(g.contiguous()), None, None, None, _lib.ptr(d), None, None, None,
                                                         _lib.current_stream(vis.device)), "gsvc_gather_rows_backward")
-        return d, None
+        return d, None, None, None
 
 
 class _GatherRows(torch.autograd.Function):
@@ -139,7 +148,7 @@ class _GatherRows(torch.autograd.Function):
     behind the rasterizer's — a data-parallel step starts their all-reduce that much earlier (gsvc_amd.dist.GradReducer)."""
 
     @staticmethod
-    def forward(ctx, offset_p, scaling_p, mask_p, vis, decoded):
+    def forward(ctx, offset_p, scaling_p, mask_p, vis, decoded, seen=None, rank=None):
         from . import _lib
         dev = offset_p.device
         offset_p, scaling_p, mask_p, vis = (t.contiguous() for t in (offset_p, scaling_p, mask_p, vis))
@@ -150,7 +159,7 @@ class _GatherRows(torch.autograd.Function):
                                                        _lib.ptr(vis), rows, 0, K, S, int(decoded), None, _lib.ptr(off),
                                                        _lib.ptr(scal), _lib.ptr(mask), _lib.current_stream(dev)),
                    "gsvc_gather_rows_forward")
-        ctx.save_for_backward(scaling_p, mask_p, vis)
+        ctx.save_for_backward(scaling_p, mask_p, vis, seen, rank)
         ctx.dims = (offset_p.shape, K, S, bool(decoded))
         ctx.set_materialize_grads(False)      # an output nothing differentiates (detached STE modes) gives no gradient, not zeros
         return off, scal, mask
@@ -158,28 +167,40 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_off, g_scal, g_mask):
         from . import _lib
-        scaling_p, mask_p, vis = ctx.saved_tensors
+        scaling_p, mask_p, vis, seen, rank = ctx.saved_tensors
         oshape, K, S, decoded = ctx.dims
         dev = vis.device
         need = ctx.needs_input_grad
         c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
-        d_off, d_scal, d_mask = _zeros_many([oshape if need[0] and g_off is not None else None,
-                                             scaling_p.shape if need[1] and g_scal is not None else None,
-                                             mask_p.shape if need[2] and g_mask is not None else None], dev)
+        shapes = [oshape if need[0] and g_off is not None else None, scaling_p.shape if need[1] and g_scal is not None else None,
+                  mask_p.shape if need[2] and g_mask is not None else None]
         g_off, g_scal, g_mask = c(g_off), c(g_scal), c(g_mask)
+        if seen is not None:      # rows = a step plan's R ascending lists: every output element is written once, no atomics
+            A = oshape[0]
+            d_off, d_scal, d_mask = (torch.empty(sh, device=dev, dtype=torch.float32) if sh is not None else None for sh in shapes)
+            _lib.check(_lib.lib().gsvc_gather_rows_backward_ranked(_lib.ptr(scaling_p), _lib.ptr(mask_p), _lib.ptr(seen), _lib.ptr(rank),
+                                                                   seen.numel() // A, A, 0, K, S, int(decoded), None, _lib.ptr(g_off),
+                                                                   _lib.ptr(g_scal), _lib.ptr(g_mask), None, _lib.ptr(d_off),
+                                                                   _lib.ptr(d_scal), _lib.ptr(d_mask), _lib.current_stream(dev)),
+                       "gsvc_gather_rows_backward_ranked")
+            return d_off, d_scal, d_mask, None, None, None, None
+        d_off, d_scal, d_mask = _zeros_many(shapes, dev)
         _lib.check(_lib.lib().gsvc_gather_rows_backward(_lib.ptr(scaling_p), _lib.ptr(mask_p), _lib.ptr(vis), vis.shape[0], 0, K, S,
                                                         int(decoded), None, _lib.ptr(g_off), _lib.ptr(g_scal),
                                                         _lib.ptr(g_mask), None, _lib.ptr(d_off), _lib.ptr(d_scal),
                                                         _lib.ptr(d_mask), _lib.current_stream(dev)), "gsvc_gather_rows_backward")
-        return d_off, d_scal, d_mask, None, None
+        return d_off, d_scal, d_mask, None, None, None, None
 
 
-def _gather_rows(pc, vis):
-    """(feat, grid_offsets, grid_scaling, offset_masks) of the visible rows."""
+def _gather_rows(pc, vis, ranks=None):
+    """(feat, grid_offsets, grid_scaling, offset_masks) of the visible rows.  ``ranks`` = (seen, rank) of a StepPlan whose
+    concatenated lists ``vis`` is: the backward then adds each anchor's rows in view order instead of with atomics."""
     if (pc._anchor_feat.is_cuda and vis.dtype == torch.int64 and pc._mask.dim() == 3 and pc._mask.shape[2] == 1
             and pc._offset.dim() == 3 and pc._offset.shape[2] == 3 and not os.environ.get("GSVC_NO_FUSED_GATHER")):
-        feat = _GatherFeat.apply(pc._anchor_feat, vis)
-        return (feat,) + tuple(_GatherRows.apply(pc._offset, pc._scaling, pc._mask, vis, bool(pc.decoded_version)))
+        use = ranks is not None and ranks[0].numel() <= 8 * pc._anchor_feat.shape[0] and not os.environ.get("GSVC_NO_RANKED_GATHER")
+        seen, rank = ranks if use else (None, None)      # the ranked kernel holds at most 8 views
+        feat = _GatherFeat.apply(pc._anchor_feat, vis, seen, rank)
+        return (feat,) + tuple(_GatherRows.apply(pc._offset, pc._scaling, pc._mask, vis, bool(pc.decoded_version), seen, rank))
     return (pc._anchor_feat.index_select(0, vis), pc._offset.index_select(0, vis), _visible_scaling(pc, vis), _visible_mask(pc, vis))
 
 
@@ -212,6 +233,7 @@ class StepPlan:
         # scan of the FLATTENED mask (a 1-D scan is one fast pass; a [R, A] scan along dim 1 runs row by row): c - 1 is the
         # row of (r, a) in the concatenated rows, the view boundaries give the counts
         c = torch.cumsum(M.view(-1), dim=0)
+        self.ranks = (M.view(-1), c)                                     # for the atomic-free gather backward (_gather_rows)
         ends = c[A - 1::A]
         cnt_t = torch.diff(ends, prepend=ends.new_zeros(1))
         present = M.any(dim=0)
@@ -718,7 +740,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         vis = torch.cat(vis_list)
         anchor_all = pc.get_anchor if anchors is None else anchors
         anchor = anchor_all.index_select(0, vis)
-        feat, grid_offsets, grid_scaling, offset_masks = _gather_rows(pc, vis)
+        feat, grid_offsets, grid_scaling, offset_masks = _gather_rows(pc, vis, plan.ranks if plan is not None else None)
     rates = [RatePack() for _ in range(R)]
     Q_feat, Q_scaling, Q_offsets = BASE_Q_FEAT, BASE_Q_SCALING, BASE_Q_OFFSETS
     time_sub = 0

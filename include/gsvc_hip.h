@@ -384,6 +384,13 @@ int gsvc_gather_rows_forward(const float *feat_p, const float *offset_p, const f
 int gsvc_gather_rows_backward(const float *scaling_p, const float *mask_p, const int64_t *vis, int64_t rows, int32_t F, int32_t K,
                               int32_t S, int32_t decoded, const float *g_feat, const float *g_offsets, const float *g_scaling,
                               const float *g_mask, float *d_feat, float *d_offset, float *d_scaling, float *d_mask, void *stream);
+/* The same gradients without atomics (and without a zero fill: every element of the d_* tensors is written), for rows that
+ * are the concatenation of R ascending index lists over A anchors: seen [R*A] (1 = view r holds anchor a), rank [R*A] =
+ * inclusive scan of seen (rank - 1 = the row), R <= 8.  Sums in view order: deterministic. */
+int gsvc_gather_rows_backward_ranked(const float *scaling_p, const float *mask_p, const uint8_t *seen, const int64_t *rank, int32_t R,
+                                     int64_t A, int32_t F, int32_t K, int32_t S, int32_t decoded, const float *g_feat,
+                                     const float *g_offsets, const float *g_scaling, const float *g_mask, float *d_feat,
+                                     float *d_offset, float *d_scaling, float *d_mask, void *stream);
 
 /* Tail of an EntropyParamsNet (reference scene/gaussian_model.py:1586-1596): params [n,2C] = [mean | scale], q [n] ->
  * mean [n,C], scale = max(scale, 1e-9) [n,C], adj = exp(clamp(q, -10, 10)) [n]; backward -> dparams [n,2C], dq [n]. */

@@ -158,6 +158,24 @@ def test_fused_row_gather_and_context_tail_match_the_tensor_paths(monkeypatch):
             assert torch.equal(a, b)                       # same float operations in the same order
         for a, b in zip(res[0][1], res[1][1]):
             assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())     # atomics reorder sums of <= 2 terms
+    # rows that are a step plan's R ascending lists: the ranked backward (no atomics, every element written, view order)
+    monkeypatch.delenv("GSVC_NO_FUSED_GATHER", raising=False)
+    M = torch.rand(3, A, device=dev) < 0.4
+    M[:, 17] = False                                              # an anchor no view holds gets exact zeros
+    vis3 = torch.cat([m.nonzero().squeeze(1) for m in M])
+    ranks = (M.view(-1), torch.cumsum(M.view(-1), dim=0))
+    w3 = [torch.randn(vis3.shape[0], *s, device=dev) for s in ((F,), (K, 3), (6,), (K, 1))]
+    for decoded in (False, True):
+        res = []
+        for rk in (ranks, ranks, None):
+            pc = model(decoded)
+            outs = _gather_rows(pc, vis3, rk)
+            sum((o * ww).sum() for o, ww in zip(outs, w3)).backward()
+            res.append([pc._anchor_feat.grad, pc._offset.grad, pc._scaling.grad, pc._mask.grad])
+        for a, b, c in zip(*res):
+            assert torch.equal(a, b)                               # deterministic
+            assert (a - c).abs().max().item() <= 1e-5 * max(1.0, c.abs().max().item())
+            assert not a[17].any()
     # context tail
     n, C = 4097, 30
     params = torch.randn(n, 2 * C, device=dev, requires_grad=True)
