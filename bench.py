@@ -609,6 +609,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GSVC_HANG_DUMP"):        # diagnostics: every thread's stack to stderr after that many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["GSVC_HANG_DUMP"]), exit=True)
     if world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus}\n")
         sys.exit(2)

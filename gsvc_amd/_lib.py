@@ -97,6 +97,8 @@ _SIGNATURES = {
     "gsvc_ssim_l1_pair_backward": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_ste_binary_count": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "gsvc_adam_step": (C.c_int, [C.c_int32, C.POINTER(AdamTensorC), C.c_double, C.c_double, C.c_double, _vp]),
+    "gsvc_adam_step_guarded": (C.c_int, [C.c_int32, C.POINTER(AdamTensorC), C.c_double, C.c_double, C.c_double, C.POINTER(C.c_void_p),
+                                         C.c_int32, _vp]),
     "gsvc_noise_quant_scratch_floats": (_i64, [C.POINTER(C.c_int64), C.c_int32]),
     "gsvc_noise_quant_forward": (C.c_int, [_vp, _vp, C.c_float, _vp, C.POINTER(C.c_int64), C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "gsvc_noise_quant_backward": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, _vp, C.POINTER(C.c_int64), C.c_int32, C.c_int32, _vp, _vp,

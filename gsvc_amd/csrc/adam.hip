@@ -22,6 +22,8 @@ struct AdamBatch {
     float inv_sqrt_bc2[ADAM_MAX_TENSORS];   // 1 / sqrt(1 - b2^t)
     int first_block[ADAM_MAX_TENSORS + 1];
     int count;
+    const int32_t *guard[4];                // device words; a non-zero one turns the launch into a no-op (gsvc_adam_step_guarded)
+    int n_guards;
 };
 
 // omb1 / omb2 = 1 - beta rounded from double (as torch does), not 1.0f - beta: that differs by 5e-5 relative for beta2 = 0.999
@@ -35,6 +37,8 @@ __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, flo
 
 __global__ void __launch_bounds__(256) k_adam(AdamBatch b, float b1, float b2, float omb1, float omb2, float eps)
 {
+    for (int k = 0; k < b.n_guards; k++)
+        if (*b.guard[k] != 0) return;       // uniform over the grid
     int t = 0;
     {   // which tensor does this block belong to (first_block is ascending): binary search over <= 64 entries
         int lo = 0, hi = b.count;
@@ -79,16 +83,20 @@ __global__ void __launch_bounds__(256) k_adam(AdamBatch b, float b1, float b2, f
 
 using namespace gsvc;
 
-extern "C" int gsvc_adam_step(int32_t n_tensors, const gsvc_adam_tensor *tensors_host, double beta1_d, double beta2_d, double eps_d,
-                              void *stream)
+static int adam_step_impl(int32_t n_tensors, const gsvc_adam_tensor *tensors_host, double beta1_d, double beta2_d, double eps_d,
+                          const int32_t *const *guards, int32_t n_guards, void *stream)
 {
     const float beta1 = (float)beta1_d, beta2 = (float)beta2_d, eps = (float)eps_d;
     GSVC_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || tensors_host), "adam_step: bad arguments");
+    GSVC_REQUIRE(n_guards >= 0 && n_guards <= 4 && (n_guards == 0 || guards), "adam_step: at most 4 guard words");
     hipStream_t s = (hipStream_t)stream;
     int done = 0;
     while (done < n_tensors) {
         AdamBatch b;
         b.count = 0;
+        b.n_guards = n_guards;
+        for (int k = 0; k < 4; k++) b.guard[k] = k < n_guards ? guards[k] : nullptr;
+        for (int k = 0; k < n_guards; k++) GSVC_REQUIRE(guards[k], "adam_step: NULL guard word");
         int blocks = 0;
         while (done < n_tensors && b.count < ADAM_MAX_TENSORS) {
             const gsvc_adam_tensor &t = tensors_host[done++];
@@ -108,4 +116,16 @@ extern "C" int gsvc_adam_step(int32_t n_tensors, const gsvc_adam_tensor *tensors
         hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, b, beta1, beta2, (float)(1.0 - (double)beta1_d), (float)(1.0 - (double)beta2_d), eps);
     }
     return check_launch("adam_step");
+}
+
+extern "C" int gsvc_adam_step(int32_t n_tensors, const gsvc_adam_tensor *tensors_host, double beta1_d, double beta2_d, double eps_d,
+                              void *stream)
+{
+    return adam_step_impl(n_tensors, tensors_host, beta1_d, beta2_d, eps_d, nullptr, 0, stream);
+}
+
+extern "C" int gsvc_adam_step_guarded(int32_t n_tensors, const gsvc_adam_tensor *tensors_host, double beta1_d, double beta2_d,
+                                      double eps_d, const int32_t *const *guards_host, int32_t n_guards, void *stream)
+{
+    return adam_step_impl(n_tensors, tensors_host, beta1_d, beta2_d, eps_d, guards_host, n_guards, stream);
 }

@@ -192,16 +192,40 @@ class _GatherRows(torch.autograd.Function):
         return d_off, d_scal, d_mask, None, None, None, None
 
 
-def _gather_rows(pc, vis, ranks=None):
+def _gather_rows(pc, vis, ranks=None, parts="all"):
     """(feat, grid_offsets, grid_scaling, offset_masks) of the visible rows.  ``ranks`` = (seen, rank) of a StepPlan whose
-    concatenated lists ``vis`` is: the backward then adds each anchor's rows in view order instead of with atomics."""
-    if (pc._anchor_feat.is_cuda and vis.dtype == torch.int64 and pc._mask.dim() == 3 and pc._mask.shape[2] == 1
-            and pc._offset.dim() == 3 and pc._offset.shape[2] == 3 and not os.environ.get("GSVC_NO_FUSED_GATHER")):
+    concatenated lists ``vis`` is: the backward then adds each anchor's rows in view order instead of with atomics.
+    ``parts``: "all", "feat" (the features only) or "rows" (offsets, scaling, masks only) — a fitting step gathers the latter
+    three late in its forward, so that their backward — the last contribution to the gradients of _offset / _scaling / _mask —
+    runs early (autograd runs later-created nodes first)."""
+    fused = (pc._anchor_feat.is_cuda and vis.dtype == torch.int64 and pc._mask.dim() == 3 and pc._mask.shape[2] == 1
+             and pc._offset.dim() == 3 and pc._offset.shape[2] == 3 and not os.environ.get("GSVC_NO_FUSED_GATHER"))
+    out = ()
+    if fused:
         use = ranks is not None and ranks[0].numel() <= 8 * pc._anchor_feat.shape[0] and not os.environ.get("GSVC_NO_RANKED_GATHER")
         seen, rank = ranks if use else (None, None)      # the ranked kernel holds at most 8 views
-        feat = _GatherFeat.apply(pc._anchor_feat, vis, seen, rank)
-        return (feat,) + tuple(_GatherRows.apply(pc._offset, pc._scaling, pc._mask, vis, bool(pc.decoded_version), seen, rank))
-    return (pc._anchor_feat.index_select(0, vis), pc._offset.index_select(0, vis), _visible_scaling(pc, vis), _visible_mask(pc, vis))
+        if parts != "rows":
+            out += (_GatherFeat.apply(pc._anchor_feat, vis, seen, rank),)
+        if parts != "feat":
+            out += tuple(_GatherRows.apply(pc._offset, pc._scaling, pc._mask, vis, bool(pc.decoded_version), seen, rank))
+        return out
+    if parts != "rows":
+        out += (pc._anchor_feat.index_select(0, vis),)
+    if parts != "feat":
+        out += (pc._offset.index_select(0, vis), _visible_scaling(pc, vis), _visible_mask(pc, vis))
+    return out
+
+
+def host_values(values, device, dtype=None):
+    """A small tensor of host numbers on ``device`` WITHOUT blocking the host: ``torch.tensor(values, device=cuda)`` copies from
+    pageable memory, i.e. the call returns only when the copy has run — behind everything already queued on the stream.  With
+    the queue kept full across step boundaries (Trainer._early_tail) each such call stalled the host for the ~2 ms of queued
+    work.  Pinned staging + an asynchronous copy returns at once (the pinned block is recycled by the caching host allocator
+    once the copy has run)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return torch.tensor(values, dtype=dtype, device=device)
+    return torch.tensor(values, dtype=dtype, pin_memory=True).to(device, non_blocking=True)
 
 
 def _as_index(mask_or_index):
@@ -440,9 +464,10 @@ class _Segments:
         for c in self.counts:
             self.bounds.append(self.bounds[-1] + c)
         self.rows = self.bounds[-1]
-        self.counts_t = torch.tensor(self.counts, device=device)
-        self.bounds_t = torch.tensor(self.bounds, device=device)
-        self.seg_id = torch.repeat_interleave(torch.arange(self.R, device=device), self.counts_t)
+        both = host_values(list(self.counts) + list(self.bounds), device)      # one staged copy for both
+        self.counts_t, self.bounds_t = both[:len(self.counts)], both[len(self.counts):]
+        # output_size: without it repeat_interleave reads the total back from the device (a host synchronisation)
+        self.seg_id = torch.repeat_interleave(torch.arange(self.R, device=device), self.counts_t, output_size=self.rows)
 
     def sums(self, x):
         """Per-segment sums of a [rows] tensor as float32 through one scan (an index_add_ onto R addresses serialises on
@@ -633,7 +658,7 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
         S = _SampledRate.apply(feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec.mean_feat, ec.scale_feat,
                                ec.mean_scaling, ec.scale_scaling, ec.mean_offsets, ec.scale_offsets, sel,
                                None if ec_row is None else sel_ec, xm, seg.bounds, K)
-        dims = torch.tensor([float(feat.shape[1]), float(grid_scaling.shape[1]), float(3 * K)], device=dev)
+        dims = host_values([float(feat.shape[1]), float(grid_scaling.shape[1]), float(3 * K)], dev)
         N = n_sel.unsqueeze(1) * dims
         per = S / N * kr.unsqueeze(1)
         tot = S.sum(dim=1) / N.sum(dim=1) * kr
@@ -654,7 +679,7 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
                                 Q3T[g], 0.0, lo[g], hi[g], True) for g in range(3)]
     bits[2] = bits[2] * offset_masks.index_select(0, sel).repeat(1, 1, 3).view(-1, 3 * K)
     S = torch.zeros(R, 3, device=dev).index_add_(0, sel_seg, torch.stack([b.sum(dim=1) for b in bits], dim=1))   # [R, 3] bit sums
-    dims = torch.tensor([float(bits[0].shape[1]), float(bits[1].shape[1]), float(bits[2].shape[1])], device=dev)
+    dims = host_values([float(bits[0].shape[1]), float(bits[1].shape[1]), float(bits[2].shape[1])], dev)
     N = n_sel.unsqueeze(1) * dims                                                 # coded elements per render and group
     per = S / N * kr.unsqueeze(1)
     tot = S.sum(dim=1) / N.sum(dim=1) * kr
@@ -706,7 +731,7 @@ def _embed_rows(pc, frames, anchor, seg):
         _lib.check(_lib.lib().gsvc_embed_pe(_lib.ptr(anchor.contiguous()), bounds, cz, seg.R, F, _lib.ptr(pe),
                                             _lib.current_stream(anchor.device)), "gsvc_embed_pe")
         return pe
-    cam_z = torch.tensor(cams, device=anchor.device, dtype=anchor.dtype)
+    cam_z = host_values(cams, anchor.device, anchor.dtype)
     cam_z_row = cam_z.index_select(0, seg.seg_id).unsqueeze(1)
     ob_view = anchor[:, 2:] - cam_z_row
     return torch.cat([pc.embed_time_fn(cam_z_row), pc.embed_fn(ob_view)], dim=1)
@@ -740,7 +765,14 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         vis = torch.cat(vis_list)
         anchor_all = pc.get_anchor if anchors is None else anchors
         anchor = anchor_all.index_select(0, vis)
-        feat, grid_offsets, grid_scaling, offset_masks = _gather_rows(pc, vis, plan.ranks if plan is not None else None)
+        ranks = plan.ranks if plan is not None else None
+        # TRAINING_ENTROPY gathers (offsets, scaling, masks) behind the generators' forward: see _gather_rows
+        late_rows = mode == GenerateMode.TRAINING_ENTROPY and trunks is None and not os.environ.get("GSVC_NO_LATE_ROWS")
+        if late_rows:
+            (feat,) = _gather_rows(pc, vis, ranks, parts="feat")
+            grid_offsets = grid_scaling = offset_masks = None
+        else:
+            feat, grid_offsets, grid_scaling, offset_masks = _gather_rows(pc, vis, ranks)
     rates = [RatePack() for _ in range(R)]
     Q_feat, Q_scaling, Q_offsets = BASE_Q_FEAT, BASE_Q_SCALING, BASE_Q_OFFSETS
     time_sub = 0
@@ -769,11 +801,21 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
             Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj), Q_scaling * rows_of(ec.Q_scaling_adj),
                                             Q_offsets * rows_of(ec.Q_offsets_adj))
             feat = _seg_noise_quant(feat, Q_feat, seg)
-            grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
-            grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets.unsqueeze(1), seg)
-        with region('gen.rate'):
-            rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row,
-                               sel=plan.sel if plan is not None else None)
+
+        def rows_quant_and_rate():
+            # the same noise draws in the same order (features, scalings, offsets) wherever this runs: nothing between the
+            # features' quantisation and this draws from the generator
+            nonlocal grid_offsets, grid_scaling, offset_masks, rates
+            if late_rows:
+                grid_offsets, grid_scaling, offset_masks = _gather_rows(pc, vis, ranks, parts="rows")
+            with region('gen.noise_quant'):
+                grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
+                grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets.unsqueeze(1), seg)
+            with region('gen.rate'):
+                rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row,
+                                   sel=plan.sel if plan is not None else None)
+        if not late_rows:
+            rows_quant_and_rate()
     elif mode == GenerateMode.TRAININ_STE_ENTROPY:
         ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan)
         rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
@@ -801,6 +843,8 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
             color = gen("get_color_mlp").reshape(rows * K, 3)
             scale_rot = gen("get_cov_mlp").reshape(rows * K, 7)
         neural_offset = pc.get_deform_mlp(torch.cat([feat, pe], dim=1)).reshape(rows * K, 3)
+    if late_rows:
+        rows_quant_and_rate()
     if dense:
         # opacity mask, sigmoid scaling, normalised rotation, world position, bound clamp: one kernel (csrc/generate.hip)
         neural_opacity, mask, scaling, rot, world, xyz = _GenTail.apply(
@@ -834,7 +878,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     xyz = torch.clamp(anchor_rep + offsets_a * scaling_rep[:, :3], pc.x_bound_min, pc.x_bound_max)
     opacity = neural_opacity.index_select(0, alive_idx)
     # split the compacted Gaussians back into the R renders (one host read of R+1 offsets)
-    edges = torch.tensor([b * K for b in seg.bounds], device=dev)
+    edges = host_values([b * K for b in seg.bounds], dev)
     cut = torch.searchsorted(alive_idx, edges).tolist()
     out = []
     for r, (rs, gs) in enumerate(zip(seg.slices(), seg.slices(K))):

@@ -168,7 +168,8 @@ def calc_optical_loss_one_frame(render_results1, render_results2, optical_flow, 
     keep2 = common[render_results2.visible_mask].reshape(-1) & render_results2.generated_gaussians.mask
     xy1 = _world_xy(render_results1, keep1)
     xy2 = _world_xy(render_results2, keep2)
-    pix = ((xy1 - torch.tensor([[x_min, y_min]], dtype=xy1.dtype, device=dev)) * scale).round().long()
+    from .generate import host_values
+    pix = ((xy1 - host_values([[x_min, y_min]], dev, xy1.dtype)) * scale).round().long()
     ok = (pix[:, 0] >= 0) & (pix[:, 1] >= 0) & (pix[:, 0] < x_pix_max) & (pix[:, 1] < y_pix_max)
     oki = ok.nonzero(as_tuple=False).squeeze(1)
     pix = pix.index_select(0, oki)

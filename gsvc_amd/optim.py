@@ -13,7 +13,11 @@ from . import _lib
 
 class FusedAdam(torch.optim.Adam):
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, only=None, guards=None):
+        """``only``: update just these parameters (a set of tensors) and drop their gradients, so that the step's later full
+        ``step()`` passes over them; ``guards``: int32 device tensors (one element each) — if any is non-zero when the kernel
+        runs, nothing is written (gsvc_adam_step_guarded).  The step counters of the ``only`` tensors advance either way; a
+        caller that sees a guard set afterwards takes that back with ``rewind(only)``."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -39,7 +43,7 @@ class FusedAdam(torch.optim.Adam):
             lr = float(group["lr"])
             for p in group["params"]:
                 g = p.grad
-                if g is None:
+                if g is None or (only is not None and not any(p is q for q in only)):
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or g.is_sparse:
                     raise _lib.GsvcError("FusedAdam updates dense float32 CUDA parameters (csrc/adam.hip)")
@@ -68,8 +72,24 @@ class FusedAdam(torch.optim.Adam):
         b1, b2, eps = beta_key
         for i, t in enumerate(torch.stack(steps).tolist()):     # host tensors: no device synchronisation
             arr[i].bias_correction1, arr[i].bias_correction2 = 1.0 - b1 ** t, 1.0 - b2 ** t
-        _lib.check(_lib.lib().gsvc_adam_step(n, arr, b1, b2, eps, _lib.current_stream(dev)), "gsvc_adam_step")
+        if guards:
+            import ctypes
+            gp = (ctypes.c_void_p * len(guards))(*[g.data_ptr() for g in guards])
+            _lib.check(_lib.lib().gsvc_adam_step_guarded(n, arr, b1, b2, eps, gp, len(guards), _lib.current_stream(dev)),
+                       "gsvc_adam_step_guarded")
+        else:
+            _lib.check(_lib.lib().gsvc_adam_step(n, arr, b1, b2, eps, _lib.current_stream(dev)), "gsvc_adam_step")
+        if only is not None:
+            for p in only:
+                p.grad = None
         return loss
+
+    def rewind(self, params):
+        """Take back the step count of parameters whose guarded update did not happen."""
+        for p in params:
+            st = self.state.get(p)
+            if st and "step" in st:
+                st["step"] -= 1
 
     @staticmethod
     def _grow(arr):

@@ -16,8 +16,9 @@ from dataclasses import dataclass
 import torch
 
 from . import dist as gdist
-from .generate import region
+from .generate import GenerateMode, region
 from .loss_utils import calc_optical_loss, render_regs, ssim_l1, ssim_l1_pair
+from .optim import FusedAdam
 from .ortho_gaussian_renderer import plan_views, render, render_many
 from .rasterizer import resolve_deferred
 from .train_util import TrainingController
@@ -143,14 +144,25 @@ class Trainer:
     def step(self, iteration: int, frame_idx: int | None = None) -> StepOutput:
         if frame_idx is None and self._plan_idx is not None:
             frame_idx = self._plan_idx              # drawn (from the same generator, in the same order) at the end of the last step
+        self._early = None
         out = self._step(iteration, frame_idx)
         if out is None:      # a rasterizer instance buffer overflowed (capacity now raised): repeat the step
             self.repeated_steps = getattr(self, "repeated_steps", 0) + 1
+            if self._early is not None:
+                # the guarded early update saw the overflow word and wrote nothing: only its step counts moved.  The plan it
+                # queued is for the NEXT frame pair; the repeat draws its own lists.
+                self.pc.optimizer.rewind(self._early[0])
+                self._early = None
+                self._plan = None
             self.pc.optimizer.zero_grad(set_to_none=True)
-            out = self._step(iteration, frame_idx if frame_idx is not None else self._last_idx)     # the same frame pair again
+            out = self._step(iteration, frame_idx if frame_idx is not None else self._last_idx, early=False)     # the same frame pair again
             if out is None:
                 raise RuntimeError("rasterizer instance buffer overflowed twice in a row")
         self.controller.step()
+        if self._early is not None:          # the next step's plan was queued from inside the backward (_early_tail)
+            _, self._plan_idx, self._plan_mode, self._plan = self._early
+            self._early = None
+            return out
         self._plan = self._plan_idx = None
         if self.prefetch and self.pc._anchor.is_cuda:
             with torch.no_grad():
@@ -158,6 +170,25 @@ class Trainer:
                 self._plan_mode = self.controller.render_mode
                 self._plan = plan_views(self._views(self._plan_idx), self.pc, self.pipe, self.background, self._plan_mode)
         return out
+
+    def _early_tail(self, renders):
+        """Called from inside the backward, the moment the gradients of ``_scaling`` and ``_mask`` are complete (the last
+        contribution is the late row gather's backward: gsvc_amd.generate._gather_rows): these two tensors are all the next
+        step's visibility test and rate sample read that this step changes, so they are updated NOW and the next step's plan
+        is queued behind them — its counts reach the host ~2 ms before the GPU finishes this step, and the host, which runs
+        ahead of the GPU, never has to let the queue drain at a step boundary.  (With the plan queued behind the optimizer the
+        host waited ~1.4 ms per step for it and the GPU then idled until the next step's first kernels arrived.)
+        The update is guarded by the rasterizer's overflow words: a step that must be repeated changes nothing."""
+        from .train_util import render_mode_at
+        pc = self.pc
+        with torch.no_grad():
+            params = [pc._scaling, pc._mask]
+            guards = [r.raster_state.binning[4:8].view(torch.int32) for r in renders]
+            pc.optimizer.step(only=params, guards=guards)
+            idx = self.rng.randint(self.lo, max(self.lo, self.hi - 1))
+            mode = render_mode_at(self.controller.current_iteration + 1, self.opt)
+            plan = plan_views(self._views(idx), pc, self.pipe, self.background, mode) if mode is not None else None
+            self._early = (params, idx, mode, plan)
 
     def _views(self, frame_idx):
         """The step's four views: (frame, frame seen from the opposite side) of the two adjacent frames."""
@@ -188,16 +219,16 @@ class Trainer:
             pc.adjust_anchor(check_interval=opt.update_interval, success_threshold=opt.success_threshold,
                              grad_threshold=opt.densify_grad_threshold, min_opacity=opt.min_opacity)
 
-    def _step(self, iteration: int, frame_idx: int | None = None):
+    def _step(self, iteration: int, frame_idx: int | None = None, early: bool = True):
         for g in grid_tables(self.pc):
             g.step_cache = {}           # one binarisation of each hash table per step (gsvc_amd.encodings.GridEncoder.embeddings)
         try:
-            return self._step_body(iteration, frame_idx)
+            return self._step_body(iteration, frame_idx, early)
         finally:
             for g in grid_tables(self.pc):
                 g.step_cache = None
 
-    def _step_body(self, iteration: int, frame_idx: int | None = None):
+    def _step_body(self, iteration: int, frame_idx: int | None = None, early: bool = True):
         opt, pc = self.opt, self.pc
         dev = pc.device
         pc.update_learning_rate(iteration)
@@ -255,12 +286,29 @@ class Trainer:
             weights += [opt.lmbda] * 4 + [opt.lmbda / denom, 5e-4]
         key = tuple(weights)
         if getattr(self, "_w_key", None) != key:      # the weights change only with the training phase
-            self._w_key, self._w = key, torch.tensor(weights, dtype=torch.float32, device=dev)
+            from .generate import host_values
+            self._w_key, self._w = key, host_values(weights, dev, torch.float32)
         w = self._w
         loss = torch.dot(torch.stack([t.reshape(()) for t in terms]), w) + const
         self.reducer.arm([p for g in pc.optimizer.param_groups for p in g["params"]])
-        with region('step.backward'):
-            loss.backward()
+        handles = []
+        if (early and self.batched and self.prefetch and pc._anchor.is_cuda and gdist.world_size() == 1 and self.sharded is None
+                and mode == GenerateMode.TRAINING_ENTROPY and iteration < opt.iterations and not self.controller.gaussian_adjust_anchor
+                and isinstance(pc.optimizer, FusedAdam) and not os.environ.get("GSVC_NO_EARLY_PLAN")
+                and pc._scaling.requires_grad and pc._mask.requires_grad):
+            pending = [2]
+
+            def arrived(_p):
+                pending[0] -= 1
+                if pending[0] == 0:
+                    self._early_tail(renders)
+            handles = [pc._scaling.register_post_accumulate_grad_hook(arrived), pc._mask.register_post_accumulate_grad_hook(arrived)]
+        try:
+            with region('step.backward'):
+                loss.backward()
+        finally:
+            for h in handles:
+                h.remove()
         self.reducer.finish()
 
         if self.batched:

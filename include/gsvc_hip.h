@@ -331,6 +331,11 @@ typedef struct gsvc_adam_tensor {
 
 /* One Adam update (no weight decay, no amsgrad) of every tensor in the host array, in one launch per 64 tensors. */
 int gsvc_adam_step(int32_t n_tensors, const gsvc_adam_tensor *tensors_host, double beta1, double beta2, double eps, void *stream);
+/* The same update unless one of the (<= 4) device words guards_host[k] points to is non-zero when the launch runs: then nothing is
+ * written.  A fitting step that updates some tensors before it has read the rasterizer's overflow words back (so that the next
+ * step's visibility test can be queued early) passes those words: a step that has to be repeated leaves its parameters alone. */
+int gsvc_adam_step_guarded(int32_t n_tensors, const gsvc_adam_tensor *tensors_host, double beta1, double beta2, double eps,
+                           const int32_t *const *guards_host, int32_t n_guards, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Model creation: mean squared distance to the 3 nearest neighbours (replaces

@@ -1,6 +1,9 @@
 """Worker of tests/test_train_gpu.py::test_two_ranks_keep_identical_anchors_through_densification (run under
 torch.distributed.run, 2 ranks on device 0, gloo): fitting steps across several adjust_anchor calls; every rank must end
 with the same anchors, features and Adam moments although each one steps on its own frames."""
+import faulthandler
+import os as _os
+faulthandler.dump_traceback_later(int(_os.environ.get("GSVC_HANG_DUMP", "300")), exit=True)      # a deadlocked rank prints its stacks and exits
 import os
 import sys
 

@@ -2,6 +2,9 @@
 one data-parallel fitting step — each rank on a frame pair of its own shard, gradients exchanged by the overlapped
 reducer (gsvc_amd/dist.py) — must leave on every rank the MEAN of the two single-process gradients of those two pairs.
 Backend from GSVC_DIST_BACKEND: "nccl" (= RCCL, one GPU per rank) or "gloo" with GSVC_SHARE_GPU=1 (both ranks on device 0)."""
+import faulthandler
+import os as _os
+faulthandler.dump_traceback_later(int(_os.environ.get("GSVC_HANG_DUMP", "300")), exit=True)      # a deadlocked rank prints its stacks and exits
 import os
 import sys
 

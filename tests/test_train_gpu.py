@@ -174,6 +174,47 @@ def test_dense_step_equals_per_render_step(entropy):
         assert (ga[n] - gb[n]).abs().max().item() <= 2e-3 * scale + 1e-12, n
 
 
+def test_early_plan_steps_equal_plain_steps(monkeypatch):
+    """TRAINING_ENTROPY steps with the next step's plan queued from inside the backward (late row gather, early guarded Adam of
+    _scaling / _mask: Trainer._early_tail) against the same steps with everything at the end of the step: the same frames, the
+    same random draws, the same parameters after four steps (sums of <= 3 gradient terms may be taken in another order)."""
+    import gsvc_amd.train as T
+    res = []
+    for early in (True, False):
+        if early:
+            monkeypatch.delenv("GSVC_NO_EARLY_PLAN", raising=False)
+            monkeypatch.delenv("GSVC_NO_LATE_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("GSVC_NO_EARLY_PLAN", "1")
+            monkeypatch.setenv("GSVC_NO_LATE_ROWS", "1")
+        pc, cube, opt, pipe, mp, Trainer = _setup(anchors=6000, seed=4)
+        opt.full_precision_training_total = opt.quantized_training_total = 0
+        opt.entropy_constrained_train_total = 1000
+        opt.start_stat, opt.update_until, opt.pause_densification = 0, 10 ** 9, 0
+        opt.update_from = 10 ** 9                       # no densification in these steps
+        pc.training_setup(opt)
+        torch.manual_seed(7)
+        tr = Trainer(pc, cube, opt, pipe, mp)
+        calls = []
+        orig = tr._early_tail
+        tr._early_tail = lambda renders: (calls.append(1), orig(renders))[1]
+        losses = [float(tr.step(i + 1).loss) for i in range(4)]
+        assert len(calls) == (4 if early else 0)
+        assert tr._plan is not None
+        res.append((losses, {n: p.detach().clone() for n, p in pc.named_parameters()},
+                    {n: int(pc.optimizer.state[p]["step"]) for n, p in pc.named_parameters() if p in pc.optimizer.state}))
+    (la, pa, sa), (lb, pb, sb) = res
+    assert sa == sb and set(sa.values()) == {4}
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 1e-5 * max(1.0, abs(y)), (la, lb)
+    # Adam divides by the gradient's own magnitude: an element whose gradient is rounding noise may move by a whole learning
+    # rate either way, so single elements are not compared — almost all of them must agree closely
+    for n in pa:
+        scale = max(1e-6, pb[n].abs().max().item())
+        off = ((pa[n] - pb[n]).abs() > 1e-4 * scale).float().mean().item()
+        assert off < 5e-3, (n, off)
+
+
 def test_dense_step_equals_per_render_step_at_cfg3_size():
     """The same comparison at BASELINE.json configs[2] size with the production model: 1080p, 245 000 anchors x K = 10 in a
     64-frame cube (about 48 000 visible anchors / 480 000 Gaussians per render in the 16-frame slab), the 12 + 3 x 4-level
@@ -441,12 +482,14 @@ def test_estimate_final_bits_matches_reference():
     assert log == str(b["log_info"])
 
 
-def _run_bench(extra_env, *args, timeout=900):
+def _run_bench(extra_env, *args, timeout=420):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **extra_env)
+    # a rank that is still running after 300 s prints every thread's stack and exits: a deadlock fails the test with the
+    # stacks in its message instead of hanging the suite
+    env = dict(os.environ, GSVC_HANG_DUMP="300", **extra_env)
     env.pop("WORLD_SIZE", None)
     return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], cwd=root, env=env, capture_output=True,
                           text=True, timeout=timeout)
@@ -484,7 +527,7 @@ def _run_dp_grad_worker(env_extra):
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "_dp_grad_worker.py")]
-    out = subprocess.run(cmd, cwd=root, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+    out = subprocess.run(cmd, cwd=root, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=420)
     assert out.returncode == 0 and "DP_GRAD_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
     return out.stdout
 
@@ -523,7 +566,7 @@ def test_two_ranks_keep_identical_anchors_through_densification(sharded):
     env.pop("GSVC_DP_SHARD", None)
     if sharded:
         env["GSVC_DP_SHARD"] = "1"
-    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
     assert out.returncode == 0 and "DP_DENSIFY_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
     assert ("sharded" if sharded else "replicated") in out.stdout
 

@@ -19,3 +19,19 @@ for s, e, n in seg:
 print("kernels", len(seg), "busy ms", sum(tim.values()) / 1e6)
 for k, c in cnt.most_common(90):
     print(f"{c:5d} {tim[k] / 1e3:9.1f} us  {k}")
+# where the GPU waits for the host: idle time between consecutive kernels of that step, largest gaps first
+gaps = []
+for (s0, e0, n0), (s1, e1, n1) in zip(seg[:-1], seg[1:]):
+    if s1 > e0:
+        gaps.append((s1 - e0, short(n0), short(n1), (e0 - seg[0][0]) / 1e6))
+tot = sum(g[0] for g in gaps)
+print(f"step span {(seg[-1][1] - seg[0][0]) / 1e6:.2f} ms, idle between kernels {tot / 1e6:.2f} ms in {len(gaps)} gaps; gaps > 5 us: "
+      f"{sum(g[0] for g in gaps if g[0] > 5000) / 1e6:.2f} ms")
+for g in sorted(gaps, reverse=True)[:25]:
+    print(f"  {g[0] / 1e3:7.1f} us at +{g[3]:6.2f} ms  after {g[1][:40]:40s} before {g[2][:40]}")
+# idle per millisecond of the step
+import collections
+per = collections.Counter()
+for g in gaps:
+    per[int(g[3])] += g[0]
+print("idle us per ms of the step:", " ".join(f"{int(per[k] / 1e3)}" for k in range(int((seg[-1][1] - seg[0][0]) / 1e6) + 1)))
