@@ -279,6 +279,40 @@ __global__ void __launch_bounds__(256) k_gather_rows_bwd_ranked(const float *__r
     }
 }
 
+// Masks of a step plan in one pass over the anchors (gsvc_amd.generate.StepPlan): the R views' visibility masks side by side,
+// "some view sees the anchor", and the rate sample = visible & live (an offset of the anchor is kept: sigmoid(mask) > 0.01,
+// reference scene/gaussian_model.py get_mask_anchor) & (u <= rate) with u drawn by the caller.  Was ~15 PyTorch launches.
+struct PlanViews {
+    const unsigned char *vis[16];
+};
+
+__global__ void __launch_bounds__(256) k_plan_masks(PlanViews pv, int R, long long A, const float *__restrict__ mask_raw, int K,
+                                                    int decoded, const float *__restrict__ u, float rate,
+                                                    unsigned char *__restrict__ M, unsigned char *__restrict__ present,
+                                                    unsigned char *__restrict__ chosen)
+{
+    const long long a = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (a >= A) return;
+    bool live = false;
+    if (chosen) {
+        float sum = 0.f;
+        for (int k = 0; k < K; k++) {
+            const float m = mask_raw[a * K + k];
+            if (decoded) sum += m;
+            else live |= 1.0f / (1.0f + expf(-m)) > 0.01f;
+        }
+        if (decoded) live = sum > 0.f;
+    }
+    bool any = false;
+    for (int r = 0; r < R; r++) {
+        const bool v = pv.vis[r][a] != 0;
+        any |= v;
+        M[(long long)r * A + a] = v;
+        if (chosen) chosen[(long long)r * A + a] = v && live && u[(long long)r * A + a] <= rate;
+    }
+    present[a] = any;
+}
+
 // Tail of an EntropyParamsNet (reference scene/gaussian_model.py:1586-1596): params [n, 2 C] = [mean | scale], q [n] ->
 // scale_c = max(scale, 1e-9), adj = exp(clamp(q, -10, 10)); backward assembles d params = [g_mean | g_scale * (scale >= 1e-9)]
 // and d q = g_adj * adj * (|q| <= 10) — was 9 launches forward and ~30 backward for the three networks.
@@ -448,6 +482,21 @@ extern "C" int gsvc_gather_rows_backward_ranked(const float *scaling_p, const fl
                        mask_p, seen, (const long long *)rank, R, (long long)A, d, decoded, g_feat, g_offsets, g_scaling, g_mask, d_feat,
                        d_offset, d_scaling, d_mask);
     return gsvc::check_launch("gather_rows_backward_ranked");
+}
+
+extern "C" int gsvc_plan_masks(const uint8_t *const *visible_host, int32_t R, int64_t A, const float *mask_raw, int32_t K, int32_t decoded,
+                               const float *u, float rate, uint8_t *M, uint8_t *present, uint8_t *chosen, void *stream)
+{
+    GSVC_REQUIRE(R >= 1 && R <= 16 && A >= 0 && K >= 0, "plan_masks: bad shape (at most 16 views)");
+    if (A == 0) return GSVC_OK;
+    GSVC_REQUIRE(visible_host && M && present && (!chosen || (mask_raw && u)), "plan_masks: NULL pointer");
+    gsvc::PlanViews pv;
+    for (int r = 0; r < 16; r++) pv.vis[r] = r < R ? visible_host[r] : nullptr;
+    for (int r = 0; r < R; r++) GSVC_REQUIRE(pv.vis[r], "plan_masks: NULL view mask");
+    gsvc::ProfScope _prof("k_plan_masks", (hipStream_t)stream);
+    hipLaunchKernelGGL(gsvc::k_plan_masks, dim3((unsigned)((A + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pv, R, (long long)A,
+                       mask_raw, K, decoded, u, rate, M, present, chosen);
+    return gsvc::check_launch("plan_masks");
 }
 
 extern "C" int gsvc_ctx_post_forward(const float *params, const float *q, int64_t n, int32_t C, float *mean, float *scale, float *adj,

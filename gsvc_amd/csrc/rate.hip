@@ -279,6 +279,54 @@ __global__ void __launch_bounds__(256) k_rate_sample_finalize(const float *__res
     if (threadIdx.x == 0) S[r * 3 + g] = sm[0];
 }
 
+// Means of the three whole parameter tensors behind the rate's clamp bounds (reference utils/entropy_models.py: x_mean =
+// pc._anchor_feat.mean() etc., taken over ALL anchors each time the rate is evaluated): one pass over the 86 floats per anchor
+// instead of three reductions, an exp pass and their temporaries (0.18 ms of PyTorch launches per step).  Fixed order:
+// PM_BLOCKS block sums per tensor, then one workgroup adds them.
+constexpr int PM_BLOCKS = 256;
+
+__global__ void __launch_bounds__(256) k_param_means_part(const float *__restrict__ a, long long na, const float *__restrict__ b,
+                                                          long long nb, int b_exp, const float *__restrict__ c, long long nc,
+                                                          float *__restrict__ part)
+{
+    __shared__ float red[3][4];
+    float s[3] = {0.f, 0.f, 0.f};
+    const long long stride = (long long)gridDim.x * 256, first = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (long long i = first; i < na; i += stride) s[0] += a[i];
+    for (long long i = first; i < nb; i += stride) s[1] += b_exp ? expf(b[i]) : b[i];
+    for (long long i = first; i < nc; i += stride) s[2] += c[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float v = s[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) part[blockIdx.x * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ void __launch_bounds__(256) k_param_means_sum(const float *__restrict__ part, int blocks, long long na, long long nb,
+                                                         long long nc, float *__restrict__ out)
+{
+    __shared__ float sm[3][256];
+#pragma unroll
+    for (int k = 0; k < 3; k++) sm[k][threadIdx.x] = (int)threadIdx.x < blocks ? part[threadIdx.x * 3 + k] : 0.f;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) sm[k][threadIdx.x] += sm[k][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = sm[0][0] / (float)max(na, 1LL);
+        out[1] = sm[1][0] / (float)max(nb, 1LL);
+        out[2] = sm[2][0] / (float)max(nc, 1LL);
+    }
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -371,4 +419,21 @@ extern "C" int gsvc_rate_sample_backward(const gsvc_rate_sample *d, const float 
     hipLaunchKernelGGL(gsvc::k_rate_sample<1>, dim3((unsigned)blocks, 3), dim3(256), 0, s, a, scratch, nullptr, gS, dx[0], dx[1], dx[2],
                        dmean[0], dmean[1], dmean[2], dscale[0], dscale[1], dscale[2], dQ[0], dQ[1], dQ[2], dmask, d->K);
     return gsvc::check_launch("rate_sample_backward");
+}
+
+extern "C" int64_t gsvc_param_means_scratch_floats(void) { return 3 * gsvc::PM_BLOCKS; }
+
+extern "C" int gsvc_param_means(const float *feat, int64_t n_feat, const float *scaling, int64_t n_scaling, int32_t scaling_exp,
+                                const float *offset, int64_t n_offset, float *scratch, float *out3, void *stream)
+{
+    GSVC_REQUIRE(n_feat >= 0 && n_scaling >= 0 && n_offset >= 0, "param_means: bad sizes");
+    GSVC_REQUIRE(scratch && out3 && (n_feat == 0 || feat) && (n_scaling == 0 || scaling) && (n_offset == 0 || offset),
+                 "param_means: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    gsvc::ProfScope _prof("k_param_means", s);
+    hipLaunchKernelGGL(gsvc::k_param_means_part, dim3(gsvc::PM_BLOCKS), dim3(256), 0, s, feat, (long long)n_feat, scaling,
+                       (long long)n_scaling, (int)scaling_exp, offset, (long long)n_offset, scratch);
+    hipLaunchKernelGGL(gsvc::k_param_means_sum, dim3(1), dim3(256), 0, s, scratch, gsvc::PM_BLOCKS, (long long)n_feat,
+                       (long long)n_scaling, (long long)n_offset, out3);
+    return gsvc::check_launch("param_means");
 }

@@ -253,24 +253,40 @@ class StepPlan:
         self.key = (A, id(pc._anchor), pc._anchor._version, pc._scaling._version, pc._mask._version)
         # the R views side by side: ONE scan gives every view's ranks and count, ONE compaction of the flattened [R, A] mask
         # every view's index list (view r's list is the segment behind the r earlier views' counts, minus r * A)
-        M = torch.stack(visible_masks)                                   # [R, A] bool
+        fused = (dev.type == "cuda" and R <= 16 and all(m.dtype == torch.bool and m.is_contiguous() for m in visible_masks)
+                 and pc._mask.is_contiguous() and pc._mask.dtype == torch.float32 and not os.environ.get("GSVC_NO_FUSED_PLAN"))
+        chosen = None
+        if fused:
+            # the masks of the plan in one launch (csrc/generate.hip k_plan_masks): views side by side, their union, the rate sample
+            import ctypes
+            from . import _lib
+            M = torch.empty(R, A, dtype=torch.bool, device=dev)
+            present = torch.empty(A, dtype=torch.bool, device=dev)
+            u = torch.rand(R, A, device=dev) if sample else None
+            chosen = torch.empty(R, A, dtype=torch.bool, device=dev) if sample else None
+            vp = (ctypes.c_void_p * R)(*[m.data_ptr() for m in visible_masks])
+            _lib.check(_lib.lib().gsvc_plan_masks(vp, R, A, _lib.ptr(pc._mask), pc._mask.numel() // max(A, 1), int(bool(pc.decoded_version)),
+                                                  _lib.ptr(u), float(SAMPLE_RATE), _lib.ptr(M), _lib.ptr(present), _lib.ptr(chosen),
+                                                  _lib.current_stream(dev)), "gsvc_plan_masks")
+        else:
+            M = torch.stack(visible_masks)                               # [R, A] bool
+            present = M.any(dim=0)
         # scan of the FLATTENED mask (a 1-D scan is one fast pass; a [R, A] scan along dim 1 runs row by row): c - 1 is the
         # row of (r, a) in the concatenated rows, the view boundaries give the counts
         c = torch.cumsum(M.view(-1), dim=0)
         self.ranks = (M.view(-1), c)                                     # for the atomic-free gather backward (_gather_rows)
         ends = c[A - 1::A]
         cnt_t = torch.diff(ends, prepend=ends.new_zeros(1))
-        present = M.any(dim=0)
         pos_incl = torch.cumsum(present, dim=0)
         self.pos = pos_incl - 1                                          # anchor -> row of the distinct list
         counts = [cnt_t, pos_incl[-1:]]
-        chosen = None
         if sample:
             # the rate sample in anchor space: a row is (render r, visible anchor a); its position in the concatenated rows is
             # (visible anchors of the renders before r) + (rank of a among render r's visible anchors) = c - 1
-            with torch.no_grad():
-                live = pc.get_mask.reshape(A, -1).sum(dim=1) > 0          # mask_anchor for every anchor
-            chosen = M & live.unsqueeze(0) & (torch.rand(R, A, device=dev) <= SAMPLE_RATE)
+            if chosen is None:
+                with torch.no_grad():
+                    live = pc.get_mask.reshape(A, -1).sum(dim=1) > 0      # mask_anchor for every anchor
+                chosen = M & live.unsqueeze(0) & (torch.rand(R, A, device=dev) <= SAMPLE_RATE)
             counts.append(chosen.sum().reshape(1))
         # the counts leave for the host FIRST: the next step waits for them only, and the compactions below (the bulk of the
         # plan's GPU time) run while the host is already launching that step
@@ -628,6 +644,22 @@ class _SampledRate(torch.autograd.Function):
                 dmean[0], dscale[0], dmean[1], dscale[1], dmean[2], dscale[2], None, None, None, None, None)
 
 
+def _param_means(pc):
+    """(mean(_anchor_feat), mean(get_scaling), mean(_offset)) over ALL anchors as one float32 [3] tensor (csrc/rate.hip
+    k_param_means: one pass; the torch expression is three reductions + an exp pass)."""
+    from . import _lib
+    f, sc, o = pc._anchor_feat, getattr(pc, "_scaling", None), pc._offset
+    if sc is None or not (f.is_cuda and f.dtype == sc.dtype == o.dtype == torch.float32 and f.is_contiguous() and sc.is_contiguous() and o.is_contiguous()):
+        with torch.no_grad():
+            return torch.stack([f.mean(), pc.get_scaling.mean(), o.mean()]).float()
+    L = _lib.lib()
+    scratch = torch.empty(int(L.gsvc_param_means_scratch_floats()), device=f.device, dtype=torch.float32)
+    out = torch.empty(3, device=f.device, dtype=torch.float32)
+    _lib.check(L.gsvc_param_means(_lib.ptr(f), f.numel(), _lib.ptr(sc), sc.numel(), 0 if pc.decoded_version else 1, _lib.ptr(o), o.numel(),
+                                  _lib.ptr(scratch), _lib.ptr(out), _lib.current_stream(f.device)), "gsvc_param_means")
+    return out
+
+
 def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row=None, sel=None):
     """Sampled rate of the R renders of a batch (reference guassian.py:73-132 per render): 5 % of the visible anchors that have
     a live offset, bits of their features / scalings / offsets under the entropy context, four normalised means per render.
@@ -653,8 +685,7 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
     if (feat.is_cuda and R <= 16 and all(isinstance(q, torch.Tensor) and q.numel() == feat.shape[0] for q in (Q_feat, Q_scaling, Q_offsets))
             and not os.environ.get("GSVC_NO_FUSED_RATE")):
         # fused path (csrc/rate.hip k_rate_sample): gathers, per-render clamp bounds, offset mask and per-render sums in one launch
-        with torch.no_grad():
-            xm = torch.stack([pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()]).float()
+        xm = _param_means(pc)
         S = _SampledRate.apply(feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec.mean_feat, ec.scale_feat,
                                ec.mean_scaling, ec.scale_scaling, ec.mean_offsets, ec.scale_offsets, sel,
                                None if ec_row is None else sel_ec, xm, seg.bounds, K)

@@ -397,6 +397,20 @@ int gsvc_gather_rows_backward_ranked(const float *scaling_p, const float *mask_p
                                      const float *g_offsets, const float *g_scaling, const float *g_mask, float *d_feat,
                                      float *d_offset, float *d_scaling, float *d_mask, void *stream);
 
+/* Masks of a fitting step's plan in one pass over the A anchors: visible_host[r] = view r's visibility mask (bytes, 0 / 1),
+ * M [R*A] = the masks side by side, present [A] = some view holds the anchor, chosen [R*A] (may be NULL: then mask_raw / u are
+ * not read) = visible & live & (u <= rate), live = an offset mask of the anchor is on (mask_raw [A,K]: sigmoid(.) > 0.01, or the
+ * stored 0 / 1 values when decoded; reference scene/gaussian_model.py get_mask_anchor), u [R*A] uniform draws of the caller. */
+int gsvc_plan_masks(const uint8_t *const *visible_host, int32_t R, int64_t A, const float *mask_raw, int32_t K, int32_t decoded,
+                    const float *u, float rate, uint8_t *M, uint8_t *present, uint8_t *chosen, void *stream);
+
+/* Means of three whole parameter tensors in one pass (the x_mean terms of the rate's clamp bounds: reference
+ * utils/entropy_models.py EntropyGaussian.forward, x_mean = mean of the full attribute tensor): out3 = (mean(feat),
+ * mean(scaling_exp ? exp(scaling) : scaling), mean(offset)).  scratch: gsvc_param_means_scratch_floats() floats.  Fixed order. */
+int64_t gsvc_param_means_scratch_floats(void);
+int gsvc_param_means(const float *feat, int64_t n_feat, const float *scaling, int64_t n_scaling, int32_t scaling_exp,
+                     const float *offset, int64_t n_offset, float *scratch, float *out3, void *stream);
+
 /* Tail of an EntropyParamsNet (reference scene/gaussian_model.py:1586-1596): params [n,2C] = [mean | scale], q [n] ->
  * mean [n,C], scale = max(scale, 1e-9) [n,C], adj = exp(clamp(q, -10, 10)) [n]; backward -> dparams [n,2C], dq [n]. */
 int gsvc_ctx_post_forward(const float *params, const float *q, int64_t n, int32_t C, float *mean, float *scale, float *adj,

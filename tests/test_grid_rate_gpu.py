@@ -121,6 +121,23 @@ def test_grid_table_backward_fixed_point_range_determinism_and_nonfinite(oracle_
         assert np.abs(got[fin, 3] - ref_ge[fin, 3]).max() <= 1e-5 * np.abs(ref_ge[:, 3]).max()
 
 
+def test_param_means_match_torch():
+    """csrc/rate.hip k_param_means against the three torch reductions it replaces (x_mean of the rate's clamp bounds)."""
+    from types import SimpleNamespace
+    from gsvc_amd.generate import _param_means
+    torch.manual_seed(2)
+    A = 100_003
+    pc = SimpleNamespace(_anchor_feat=torch.randn(A, 50, device="cuda") + 0.3, _scaling=torch.randn(A, 6, device="cuda") * 0.5 - 3.0,
+                         _offset=torch.randn(A, 10, 3, device="cuda") * 0.1, decoded_version=False)
+    pc.get_scaling = torch.exp(pc._scaling)
+    got = _param_means(pc).double().cpu()
+    want = torch.stack([pc._anchor_feat.double().mean(), pc.get_scaling.double().mean(), pc._offset.double().mean()]).cpu()
+    assert ((got - want).abs() <= 2e-6 * want.abs() + 1e-7).all(), (got, want)
+    assert torch.equal(_param_means(pc), _param_means(pc))            # fixed order
+    pc.decoded_version = True
+    assert abs(float(_param_means(pc)[1]) - float(pc._scaling.double().mean())) <= 2e-6 * abs(float(pc._scaling.double().mean()))
+
+
 def test_grid_backend_error_behaviour():
     from gsvc_amd import _lib
     from gsvc_amd import gridencoder_backend as be

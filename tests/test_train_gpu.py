@@ -174,6 +174,37 @@ def test_dense_step_equals_per_render_step(entropy):
         assert (ga[n] - gb[n]).abs().max().item() <= 2e-3 * scale + 1e-12, n
 
 
+def test_step_plan_matches_the_per_view_index_lists(monkeypatch):
+    """A StepPlan (visible anchors of the four views, their union, the 5 % rate sample: gsvc_amd.generate.StepPlan, masks from
+    csrc/generate.hip k_plan_masks) against the expressions it replaces, and against its own unfused form with the same draws."""
+    import gsvc_amd.generate as G
+    from gsvc_amd.ortho_gaussian_renderer import plan_views
+    pc, cube, opt, pipe, mp, Trainer = _setup(anchors=7000, seed=5)
+    pc.training_setup(opt)
+    with torch.no_grad():
+        pc._mask[::3] = -9.0                          # anchors without a live offset never enter the sample
+    tr = Trainer(pc, cube, opt, pipe, mp)
+    views = tr._views(4)
+    plans = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("GSVC_NO_FUSED_PLAN", raising=False)
+        else:
+            monkeypatch.setenv("GSVC_NO_FUSED_PLAN", "1")
+        torch.manual_seed(11)
+        plans.append(plan_views(views, pc, pipe, tr.background, G.GenerateMode.TRAINING_ENTROPY).resolve())
+    a, b = plans
+    assert len(a.vis_list) == 4 and sum(v.numel() for v in a.vis_list) > 1000
+    for va, vb, m in zip(a.vis_list, b.vis_list, a.visible_masks):
+        assert torch.equal(va, vb) and torch.equal(va, m.nonzero().squeeze(1))
+    union = torch.stack(a.visible_masks).any(dim=0)
+    assert torch.equal(a.distinct, b.distinct) and torch.equal(a.distinct, union.nonzero().squeeze(1))
+    assert torch.equal(a.sel, b.sel) and torch.equal(a.pos, b.pos) and torch.equal(a.ranks[0], b.ranks[0]) and torch.equal(a.ranks[1], b.ranks[1])
+    vis = torch.cat(a.vis_list)
+    live = pc.get_mask_anchor
+    assert 0 < a.sel.numel() < 0.1 * vis.numel() and bool(live[vis[a.sel]].all()) and bool((a.sel[1:] > a.sel[:-1]).all())
+
+
 def test_early_plan_steps_equal_plain_steps(monkeypatch):
     """TRAINING_ENTROPY steps with the next step's plan queued from inside the backward (late row gather, early guarded Adam of
     _scaling / _mask: Trainer._early_tail) against the same steps with everything at the end of the step: the same frames, the

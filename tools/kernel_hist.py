@@ -3,9 +3,16 @@ import csv, re, sys
 from collections import Counter
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
-adam = [i for i, e in enumerate(ev) if 'k_adam' in e[2]]
-ends = [i for j, i in enumerate(adam) if j + 1 == len(adam) or ev[adam[j + 1]][0] - ev[i][1] > 5_000_000]
-a, b = ends[-3], ends[-2]
+# one step = from one positional-embedding launch (one per step, near its start) to the next
+marks = [i for i, e in enumerate(ev) if 'k_embed_pe' in e[2]]
+# fitting steps only (the bench renders frames afterwards): intervals that contain a weight-gradient launch
+steps = [(m0, m1) for m0, m1 in zip(marks[:-1], marks[1:]) if any('k_linear_wgrad' in e[2] for e in ev[m0:m1])]
+if len(steps) >= 2:
+    a, b = steps[-2][0] - 1, steps[-2][1] - 1
+else:
+    adam = [i for i, e in enumerate(ev) if 'k_adam' in e[2]]
+    ends = [i for j, i in enumerate(adam) if j + 1 == len(adam) or ev[adam[j + 1]][0] - ev[i][1] > 5_000_000]
+    a, b = ends[-3], ends[-2]
 seg = ev[a + 1:b + 1]
 def short(n):
     m = re.search(r'(gsvc::k_\w+)', n)
