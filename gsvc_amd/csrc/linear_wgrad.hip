@@ -143,6 +143,166 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad(const float 
         for (int n = tid; n < N; n += blockDim.x) out[(size_t)N * K + n] = sdb[n];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same product with 16-COLUMN granularity (round 2).  k_linear_wgrad above gives every wave a 64 x 64 output block, so
+// N = K = 66 is computed as 128 x 128 (27 % useful MFMA work), 100 x 100 as 128 x 128 (61 %).  Here the ceil(N / 16) column
+// tiles of G are dealt to ceil(tiles / 4) blocks as evenly as possible (5 tiles -> 3 + 2, 7 -> 4 + 3), same for X: a wave
+// owns a (16 TN) x (16 TK) block with TN, TK in 1..4 and runs the loop instantiated for exactly that pair — chosen by ONE
+// wave-uniform switch outside the loop (the attempt with per-tile branches around loads and MFMAs inside the loop lost
+// the compiler's exact vmcnt accounting and was slower than the padding it saved).  A lane loads TN (TK) consecutive columns
+// of its row with one 4 / 8 / 12 / 16-byte buffer load; component i is the operand of strided tile i (columns
+// {TN j + i}).  Columns past N inside a row's last vector are the next row's values (past the block: zeros, the range check
+// is per dword): they only reach output rows / columns >= N / K, which are never stored.
+template <int T>
+__device__ __forceinline__ void wg_load_t(__amdgpu_buffer_rsrc_t rs, int off, float (&dst)[4])
+{
+    if (T == 4) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        dst[0] = __uint_as_float(t.x); dst[1] = __uint_as_float(t.y); dst[2] = __uint_as_float(t.z); dst[3] = __uint_as_float(t.w);
+    } else if (T == 3) {
+        typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0);
+        dst[0] = __uint_as_float(t.x); dst[1] = __uint_as_float(t.y); dst[2] = __uint_as_float(t.z);
+    } else if (T == 2) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+        dst[0] = __uint_as_float(t.x); dst[1] = __uint_as_float(t.y);
+    } else {
+        dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+    }
+}
+
+template <int TN, int TK>
+__device__ __forceinline__ void wg_main_t(const float *__restrict__ G, const float *__restrict__ X, long long M, int N, int K, int n0,
+                                          int k0, long long rb, long long workers, int j, int mq, v4f (&acc)[4][4], float (&gsum)[4])
+{
+    const long long RB = (M + 15) >> 4;
+    const int ca = n0 + TN * j, cb = k0 + TK * j;          // this lane's first column of G / X
+    const bool va = ca < N, vb = cb < K;
+    float fa[4][4], fb[4][4];          // [step][tile]
+    {
+        const __amdgpu_buffer_rsrc_t rg = ws_block_rsrc(G, rb, RB, M, N), rx = ws_block_rsrc(X, rb, RB, M, K);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            wg_load_t<TN>(rg, va ? ((4 * s + mq) * N + ca) * 4 : BUF_OOB, fa[s]);
+            wg_load_t<TK>(rx, vb ? ((4 * s + mq) * K + cb) * 4 : BUF_OOB, fb[s]);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+#pragma unroll
+        for (int t = 0; t < TN; t++) asm volatile("" : "+v"(fa[s][t]));
+#pragma unroll
+        for (int t = 0; t < TK; t++) asm volatile("" : "+v"(fb[s][t]));
+    }
+    for (; rb < RB; rb += workers) {
+        const __amdgpu_buffer_rsrc_t rg = ws_block_rsrc(G, rb + workers, RB, M, N);      // empty past the end
+        const __amdgpu_buffer_rsrc_t rx = ws_block_rsrc(X, rb + workers, RB, M, K);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) {
+                gsum[tn] += fa[s][tn];
+#pragma unroll
+                for (int tk = 0; tk < TK; tk++)
+                    acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][tn], fb[s][tk], acc[tn][tk], 0, 0, 0);
+            }
+            wg_load_t<TN>(rg, va ? ((4 * s + mq) * N + ca) * 4 : BUF_OOB, fa[s]);
+            wg_load_t<TK>(rx, vb ? ((4 * s + mq) * K + cb) * 4 : BUF_OOB, fb[s]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// tiles [first, first + count) of block b when `tiles` tiles are dealt to `blocks` blocks as evenly as possible
+__device__ __forceinline__ void wg_block_tiles(int tiles, int blocks, int b, int &first, int &count)
+{
+    const int base = tiles / blocks, rem = tiles - base * blocks;
+    first = b * base + min(b, rem);
+    count = base + (b < rem ? 1 : 0);
+}
+
+__global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const float *__restrict__ G, const float *__restrict__ X,
+                                                                     float *__restrict__ part, int want_db, long long M, int N, int K,
+                                                                     int BN, int BK, int RS)
+{
+    extern __shared__ float sm[];      // [BN*BK][64][64]
+    __shared__ float sdb[LIN_NT_MAX * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pairs = BN * BK;
+    // row split rs handles the pairs rotated by rs: the blocks differ in size (4 x 4 .. 1 x 1 tiles), and with pair = wave %
+    // pairs every wave of one SIMD (wave % 4) would own the same block
+    const int rs = wave / pairs, pair = (wave + rs) % pairs;
+    const int bn = pair / BK, bk = pair - bn * BK;
+    const int j = lane & 15, mq = lane >> 4;
+    int tn0, TN, tk0, TK;
+    wg_block_tiles((N + 15) >> 4, BN, bn, tn0, TN);
+    wg_block_tiles((K + 15) >> 4, BK, bk, tk0, TK);
+    const int n0 = 16 * tn0, k0 = 16 * tk0;
+    const long long workers = (long long)gridDim.x * RS;
+    const long long rb = (long long)blockIdx.x * RS + rs;
+    if (tid < LIN_NT_MAX * 16) sdb[tid] = 0.f;
+    __syncthreads();
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+#define WG_BODY(a, b) case (a) * 4 + (b): wg_main_t<a, b>(G, X, M, N, K, n0, k0, rb, workers, j, mq, acc, gsum); break
+    switch (TN * 4 + TK) {
+        WG_BODY(1, 1); WG_BODY(1, 2); WG_BODY(1, 3); WG_BODY(1, 4);
+        WG_BODY(2, 1); WG_BODY(2, 2); WG_BODY(2, 3); WG_BODY(2, 4);
+        WG_BODY(3, 1); WG_BODY(3, 2); WG_BODY(3, 3); WG_BODY(3, 4);
+        WG_BODY(4, 1); WG_BODY(4, 2); WG_BODY(4, 3); WG_BODY(4, 4);
+        default: break;
+    }
+#undef WG_BODY
+    // bias gradient: column sums of G (waves of the first k-block; the row splits meet in LDS)
+    if (want_db && bk == 0) {
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++) {
+            float v = gsum[tn];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int n = n0 + TN * j + tn;
+            if (tn < TN && mq == 0 && n < N) atomicAdd(sdb + n, v);
+        }
+    }
+    // sum the row splits of each block in LDS (one wave per block and round), then this workgroup's partial dW (and db) goes
+    // to its slot of `part`
+    float *blk = sm + pair * 4096;
+    for (int round = 0; round < RS; round++) {
+        if (rs == round) {
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++)
+#pragma unroll
+                for (int tk = 0; tk < 4; tk++)
+                    if (tn < TN && tk < TK) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int nl = TN * (4 * mq + r) + tn, kl = TK * j + tk;
+                            float *d = blk + nl * 64 + kl;
+                            *d = (round == 0) ? acc[tn][tk][r] : *d + acc[tn][tk][r];
+                        }
+                    }
+        }
+        __syncthreads();
+    }
+    float *out = part + (size_t)blockIdx.x * ((size_t)N * K + (want_db ? N : 0));
+    for (int i = tid; i < pairs * 4096; i += blockDim.x) {
+        const int pr = i >> 12, nl = (i >> 6) & 63, kl = i & 63;
+        int f, c, g, e;
+        wg_block_tiles((N + 15) >> 4, BN, pr / BK, f, c);
+        wg_block_tiles((K + 15) >> 4, BK, pr % BK, g, e);
+        const int n = 16 * f + nl, k = 16 * g + kl;
+        if (nl < 16 * c && kl < 16 * e && n < N && k < K) out[(size_t)n * K + k] = sm[i];
+    }
+    if (want_db)
+        for (int n = tid; n < N; n += blockDim.x) out[(size_t)N * K + n] = sdb[n];
+}
+
 // dst[i] = sum over the workgroup slots of part[slot][i]: 64 outputs per workgroup, the slots dealt to its 4 waves
 __global__ void __launch_bounds__(256) k_linear_wgrad_reduce(const float *__restrict__ part, int slots, int n, float *__restrict__ dW,
                                                             int nk, float *__restrict__ db)
@@ -234,6 +394,36 @@ static int launch_wgrad2(const float *G, const float *X, float *dW, float *db, b
     return grid;
 }
 
+static int launch_wgrad_t(const float *G, const float *X, float *dW, float *db, bool want_db, float *part, int slots, long long M,
+                          int N, int K, int max_tn, int max_tk, hipStream_t s)
+{
+    // at most max_tn / max_tk tiles per block: a lane's vector load is as wide as its rows' alignment allows (a 16-byte load
+    // of rows that are only 8-byte aligned is split by the memory pipeline: K = 50 ran 20 % slower than with two 8-byte loads)
+    const int BN = ((N + 15) / 16 + max_tn - 1) / max_tn, BK = ((K + 15) / 16 + max_tk - 1) / max_tk, pairs = BN * BK;
+    const int RS = pairs >= WG_MAX_WAVES ? 1 : WG_MAX_WAVES / pairs;
+    const size_t lds = (size_t)pairs * 4096 * sizeof(float);
+    if (lds > 150 * 1024) {      // never dispatch a workgroup the CU cannot hold (the caller checks; this is the last line)
+        set_error("linear_wgrad: %d output blocks do not fit one workgroup's LDS", pairs);
+        return -1;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_wgrad_t), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    const long long RB = (M + 15) / 16, want = (RB + RS - 1) / RS;
+    const int grid = (int)(want < slots ? want : slots);
+    {
+        ProfScope _prof("k_linear_wgrad", s);
+        hipLaunchKernelGGL(k_linear_wgrad_t, dim3(grid), dim3(64 * pairs * RS), lds, s, G, X, part, want_db ? 1 : 0, M, N, K, BN, BK, RS);
+    }
+    if (!dW) return grid;      // partial sums only: the caller adds the slots later (gsvc_linear_wgrad_reduce_many)
+    const int n = N * K + (want_db ? N : 0);
+    ProfScope _prof("k_linear_wgrad_reduce", s);
+    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3((n + 63) / 64), dim3(256), 0, s, part, grid, n, dW, N * K, db);
+    return grid;
+}
+
 static int vec_of(const float *p, int ld)
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
@@ -266,6 +456,17 @@ static int wgrad_launch(const float *G, const float *X, float *dW, float *db, bo
     if (slots > 256) slots = 256;
     const int vg = vec_of(G, N), vx = vec_of(X, K);
     int used = 0;
+    static const bool old_kernel = getenv("GSVC_WGRAD_BLOCK64") != nullptr;      // A/B: the 64 x 64-block kernel
+    // tiles per block: 4 (16-byte loads) only for 16-byte aligned rows — a 16-byte load of rows aligned to 8 is split by the
+    // memory pipeline (K = 50 ran 20 % slower than with two 8-byte loads); 12- and 8-byte loads are fine at 4-byte alignment
+    const int mt_g = vg == 4 ? 4 : 3, mt_x = vx == 4 ? 4 : 3;
+    const int bn_t = ((N + 15) / 16 + mt_g - 1) / mt_g, bk_t = ((K + 15) / 16 + mt_x - 1) / mt_x;
+    if (!old_kernel && bn_t * bk_t <= 9) {        // 9 blocks x 16 KiB of LDS: the limit of one workgroup (as in the 64 x 64 kernel)
+        used = launch_wgrad_t(G, X, dW, db, want_db, workspace, (int)slots, M, N, K, mt_g, mt_x, s);
+        if (used < 0) return GSVC_E_UNSUPPORTED;
+        if (slots_used) *slots_used = used;
+        return check_launch(what);
+    }
 #define WG_CASE(a, b) if (vg == a && vx == b) used = launch_wgrad2<a, b>(G, X, dW, db, want_db, workspace, (int)slots, M, N, K, s)
     WG_CASE(4, 4); WG_CASE(4, 2); WG_CASE(4, 1); WG_CASE(2, 4); WG_CASE(2, 2); WG_CASE(2, 1); WG_CASE(1, 4); WG_CASE(1, 2); WG_CASE(1, 1);
 #undef WG_CASE
