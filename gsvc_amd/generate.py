@@ -798,7 +798,10 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         anchor = anchor_all.index_select(0, vis)
         ranks = plan.ranks if plan is not None else None
         # TRAINING_ENTROPY gathers (offsets, scaling, masks) behind the generators' forward: see _gather_rows
-        late_rows = mode == GenerateMode.TRAINING_ENTROPY and trunks is None and not os.environ.get("GSVC_NO_LATE_ROWS")
+        # (single process only: the gradient hooks of a data-parallel step keep the order they were tested with)
+        late_rows = (mode == GenerateMode.TRAINING_ENTROPY and trunks is None and not os.environ.get("GSVC_NO_LATE_ROWS")
+                     and not (torch.distributed.is_available() and torch.distributed.is_initialized()
+                              and torch.distributed.get_world_size() > 1))
         if late_rows:
             (feat,) = _gather_rows(pc, vis, ranks, parts="feat")
             grid_offsets = grid_scaling = offset_masks = None

@@ -65,3 +65,16 @@ for ev in prof.events():
 print("backward-side aten launches by shape:")
 for (n, shp, w), (t, c) in sorted(bw.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"{t / N:8.1f} us x{c / N:4.1f}  {n[6:]:18s} {shp:72s} {w}")
+# zero fills / copies by shape and source line
+fl = defaultdict(lambda: [0.0, 0])
+for ev in prof.events():
+    if ev.name not in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::cat") or ev.self_device_time_total <= 0:
+        continue
+    fr = [f for f in ev.stack if "gsvc_amd" in f and "torch/" not in f]
+    w = fr[0].split("gsvc_amd/")[-1].split(":")[0].strip() if fr else "(autograd engine)"
+    shp = str([list(x) for x in (ev.input_shapes or []) if x])[:60]
+    fl[(ev.name, shp, w)][0] += ev.self_device_time_total
+    fl[(ev.name, shp, w)][1] += 1
+print("fills / copies / cats by shape:")
+for (n, shp, w), (t, c) in sorted(fl.items(), key=lambda kv: -kv[1][0])[:40]:
+    print(f"{t / N:8.1f} us x{c / N:4.1f}  {n[6:]:8s} {shp:62s} {w}")
