@@ -24,6 +24,9 @@ from .rasterizer import resolve_deferred
 from .train_util import TrainingController
 
 
+EARLY_PLAN_MIN_ROWS = 150_000      # visible anchor rows of a step's views from which Trainer._early_tail is used
+
+
 @dataclass
 class StepOutput:
     loss: torch.Tensor
@@ -295,7 +298,11 @@ class Trainer:
         if (early and self.batched and self.prefetch and pc._anchor.is_cuda and gdist.world_size() == 1 and self.sharded is None
                 and mode == GenerateMode.TRAINING_ENTROPY and iteration < opt.iterations and not self.controller.gaussian_adjust_anchor
                 and isinstance(pc.optimizer, FusedAdam) and not os.environ.get("GSVC_NO_EARLY_PLAN")
-                and pc._scaling.requires_grad and pc._mask.requires_grad):
+                and pc._scaling.requires_grad and pc._mask.requires_grad
+                # it pays when the GPU, not the host, bounds the step (the hook's work costs ~1 ms of host time more on the
+                # autograd thread than at the end of the step: a 6 k-row step went 8.3 -> 9.7 ms, the 200 k-row step 11.95 -> 11.3)
+                and (os.environ.get("GSVC_EARLY_PLAN") or sum(int(r.visible_index.shape[0]) for r in
+                                                               (x.generated_gaussians for x in renders)) >= EARLY_PLAN_MIN_ROWS)):
             pending = [2]
 
             def arrived(_p):

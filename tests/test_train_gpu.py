@@ -215,7 +215,9 @@ def test_early_plan_steps_equal_plain_steps(monkeypatch):
         if early:
             monkeypatch.delenv("GSVC_NO_EARLY_PLAN", raising=False)
             monkeypatch.delenv("GSVC_NO_LATE_ROWS", raising=False)
+            monkeypatch.setenv("GSVC_EARLY_PLAN", "1")              # a step this small does not take the early path by itself
         else:
+            monkeypatch.delenv("GSVC_EARLY_PLAN", raising=False)
             monkeypatch.setenv("GSVC_NO_EARLY_PLAN", "1")
             monkeypatch.setenv("GSVC_NO_LATE_ROWS", "1")
         pc, cube, opt, pipe, mp, Trainer = _setup(anchors=6000, seed=4)
