@@ -444,7 +444,9 @@ def test_counted_ste_binary_and_table_bits():
 
 @pytest.mark.parametrize("M,K,N", [(5000, 50, 100), (4097, 116, 100), (8192, 192, 150), (4096, 100, 10), (6000, 66, 66),
                                     (4500, 50, 1), (4096, 8, 16), (70000, 100, 70), (4103, 51, 37), (9001, 192, 192),
-                                    (5000, 3, 100), (4099, 150, 192), (4111, 177, 33), (300000, 100, 100)])
+                                    (5000, 3, 100), (4099, 150, 192), (4111, 177, 33), (300000, 100, 100),
+                                    # weight-gradient blocks of 1, 2 and 3 column tiles, rows aligned to 4 bytes only
+                                    (4100, 17, 23), (4101, 81, 49), (4097, 33, 129), (4098, 130, 82)])
 def test_mfma_linear_matches_torch(M, K, N):
     """csrc/linear.hip (fp32 MFMA, tall-skinny) vs torch.nn.functional.linear in fp32 on the same GPU: fp32
     products and accumulation on both sides, only the summation order differs -> 1e-5 relative to the row scale."""
