@@ -386,7 +386,9 @@ __global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__res
     gmax = 0.f;
 #pragma unroll
     for (uint32_t w = 0; w < BWD_THREADS / 64; w++) gmax = fmaxf(gmax, s_max[w]);
-    const bool fallback = absmax_bpl == 0 || slices > gridDim.z || hashmap_size > 65536u || !(gmax <= 3.402823466e38f);
+    // (a level whose largest |grad| is below 2^-60 keeps the float path: its scale would leave float's exponent range)
+    const bool fallback = absmax_bpl == 0 || slices > gridDim.z || hashmap_size > 65536u || !(gmax <= 3.402823466e38f) ||
+                          (gmax != 0.f && gmax < 8.673617379884035e-19f);
     if (fallback ? slice != 0 : slice >= slices) return;         // block-uniform
     grad_grid += (size_t)(uint32_t)offsets[level] * C;
     if (fallback) {
@@ -413,7 +415,7 @@ __global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__res
     if (gmax == 0.f || p0 >= p1) return;                          // every contribution of the launch is zero / empty chunk
     // 2^e: gmax < 2^eg, contributions per word <= chunk * 2^D <= 2^ec (and one contribution below 2^51: fx_from_float)
     const int eg = ilogbf(gmax) + 1, ec = max(32 - __clz((int)max(chunk, 2u) - 1) + (int)D, 11);
-    const int e = min(62 - eg - ec, 120);
+    const int e = 62 - eg - ec;                                   // -93 .. 111
     const float scale = ldexpf(1.f, e), inv_scale = ldexpf(1.f, -e);
     const uint32_t row_lo = slice * SLICE_ROWS, rows = min(SLICE_ROWS, hashmap_size - row_lo);
     for (uint32_t i = tid; i < rows * CP; i += BWD_THREADS) acc[i] = 0;
