@@ -248,6 +248,53 @@ def test_early_plan_steps_equal_plain_steps(monkeypatch):
         assert off < 5e-3, (n, off)
 
 
+def test_overflowing_step_with_early_plan_changes_nothing_before_its_repeat(monkeypatch):
+    """A step whose rasterizer instance buffers overflow is repeated (gsvc_amd/train.py step()).  With the early plan its
+    guarded Adam launch of _scaling / _mask has already been queued when the overflow is read back: the kernel sees the
+    overflow words and writes nothing, the step counts it advanced are rewound, and the repeat updates every tensor once."""
+    import gsvc_amd.rasterizer as RZ
+    monkeypatch.setenv("GSVC_EARLY_PLAN", "1")
+    monkeypatch.delenv("GSVC_NO_EARLY_PLAN", raising=False)
+    pc, cube, opt, pipe, mp, Trainer = _setup(anchors=6000, seed=6)
+    opt.full_precision_training_total = opt.quantized_training_total = 0
+    opt.entropy_constrained_train_total = 1000
+    opt.start_stat, opt.update_until, opt.pause_densification, opt.update_from = 0, 10 ** 9, 0, 10 ** 9
+    pc.training_setup(opt)
+    torch.manual_seed(3)
+    tr = Trainer(pc, cube, opt, pipe, mp)
+    tr.step(1)
+    before = {n: p.detach().clone() for n, p in pc.named_parameters()}
+    small = [4]                                     # the next four forwards (one step's renders) get a 200-instance buffer
+    real = RZ.raster_forward
+
+    def tiny(cs, *a, **k):
+        if small[0] > 0 and k.get("max_instances") is None:
+            small[0] -= 1
+            k["max_instances"] = 200
+        return real(cs, *a, **k)
+    monkeypatch.setattr(RZ, "raster_forward", tiny)
+    seen, early = [], []
+    inner, tail = tr._step, tr._early_tail
+
+    def spy(*a, **k):
+        out = inner(*a, **k)
+        if out is None:
+            torch.cuda.synchronize()
+            seen.append({n: p.detach().clone() for n, p in pc.named_parameters()})
+        return out
+    tr._step = spy
+    tr._early_tail = lambda renders: (early.append(1), tail(renders))[1]
+    out = tr.step(2)
+    assert getattr(tr, "repeated_steps", 0) == 1 and len(seen) == 1 and len(early) == 1 and small[0] == 0
+    for n, p in seen[0].items():
+        assert torch.equal(p, before[n]), n          # the overflowed attempt left every parameter alone
+    steps = {n: int(pc.optimizer.state[p]["step"]) for n, p in pc.named_parameters() if p in pc.optimizer.state}
+    assert set(steps.values()) == {2}, steps
+    assert not torch.equal(pc._scaling.detach(), before["_scaling"]) and not torch.equal(pc._mask.detach(), before["_mask"])
+    assert torch.isfinite(out.loss)
+    tr.step(3)                                       # and training goes on (the repeat drew its own plan)
+
+
 def test_dense_step_equals_per_render_step_at_cfg3_size():
     """The same comparison at BASELINE.json configs[2] size with the production model: 1080p, 245 000 anchors x K = 10 in a
     64-frame cube (about 48 000 visible anchors / 480 000 Gaussians per render in the 16-frame slab), the 12 + 3 x 4-level
