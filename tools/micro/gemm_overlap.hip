@@ -1,0 +1,158 @@
+// Microbenchmark: do the fp32 MFMA stream and the HBM stream of a weight-stationary row-block GEMM overlap on gfx950?
+// Per 16-row block a wave loads 7 x 16-byte fragments per lane (K = 100 padded to 112), issues 196 MFMAs (7 column tiles x 28
+// k-steps) and stores 7 x 16 bytes; the next block's fragments are requested behind each k-group's MFMAs (as k_linear_ws
+// does).  Modes: loads + stores only, MFMAs only, both.
+//   hipcc -O3 --offload-arch=gfx950 tools/micro/gemm_overlap.hip -o tools/micro/gemm_overlap
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <bool MEM, bool MATH, int THREADS>
+__global__ void __launch_bounds__(THREADS) k(const float4 *__restrict__ X, float4 *__restrict__ Y, long long M, float wv)
+{
+    constexpr int KG = 7, NT = 7, K4 = 25, N4 = 25;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long RB = M / 16, stride = (long long)gridDim.x * (THREADS / 64);
+    const int fr = lane & 15, kq = lane >> 4;
+    long long rb = (long long)blockIdx.x * (THREADS / 64) + wave;
+    float4 a[KG];
+    float bw[NT];      // one weight value per column tile (distinct, or the compiler merges the tiles)
+#pragma unroll
+    for (int t = 0; t < NT; t++) bw[t] = wv + 0.25f * t + 1e-3f * lane;
+#pragma unroll
+    for (int t = 0; t < NT; t++) asm volatile("" : "+v"(bw[t]));
+#pragma unroll
+    for (int g = 0; g < KG; g++) a[g] = make_float4(1.f, 2.f, 3.f, 4.f);
+    if (MEM && rb < RB) {
+#pragma unroll
+        for (int g = 0; g < KG; g++) a[g] = (4 * g + kq < K4) ? X[(rb * 16 + fr) * K4 + 4 * g + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (; rb < RB; rb += stride) {
+        v4f acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        const long long nb = rb + stride;
+#pragma unroll
+        for (int g = 0; g < KG; g++) {
+            const float4 ag = a[g];
+            if (MATH) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[t], ag.x, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[t], ag.y, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[t], ag.z, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[t], ag.w, acc[t], 0, 0, 0);
+            } else {
+                acc[g][0] += ag.x + ag.y + ag.z + ag.w;
+            }
+            if (MEM) a[g] = (nb < RB && 4 * g + kq < K4) ? X[(nb * 16 + fr) * K4 + 4 * g + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MEM) {
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                if (4 * t + kq < N4) Y[(rb * 16 + fr) * N4 + 4 * t + kq] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        } else if (acc[0][0] == 123.456f) {
+            Y[0] = make_float4(acc[1][0], acc[2][0], acc[3][0], acc[4][0]);
+        }
+    }
+}
+
+// variant: TWO fragment sets; all 7 loads of the next block are requested at the START of a block
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k2(const float4 *__restrict__ X, float4 *__restrict__ Y, long long M, float wv)
+{
+    constexpr int KG = 7, NT = 7, K4 = 25, N4 = 25;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long RB = M / 16, stride = (long long)gridDim.x * (THREADS / 64);
+    const int fr = lane & 15, kq = lane >> 4;
+    long long rb = (long long)blockIdx.x * (THREADS / 64) + wave;
+    float bw[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) bw[t] = wv + 0.25f * t + 1e-3f * lane;
+#pragma unroll
+    for (int t = 0; t < NT; t++) asm volatile("" : "+v"(bw[t]));
+    float4 a[2][KG];
+    auto load = [&](long long b, float4 (&dst)[KG]) {
+#pragma unroll
+        for (int g = 0; g < KG; g++) dst[g] = (b < RB && 4 * g + kq < K4) ? X[(b * 16 + fr) * K4 + 4 * g + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto block = [&](long long b, const float4 (&src)[KG]) {
+        v4f acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < KG; g++) {
+            const float4 ag = src[g];
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[t], ag.x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[t], ag.y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[t], ag.z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[t], ag.w, acc[t], 0, 0, 0);
+        }
+        if (b < RB) {
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                if (4 * t + kq < N4) Y[(b * 16 + fr) * N4 + 4 * t + kq] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        }
+    };
+    load(rb, a[0]);
+    for (; rb < RB; rb += 2 * stride) {
+        load(rb + stride, a[1]);
+        block(rb, a[0]);
+        load(rb + 2 * stride, a[0]);
+        block(rb + stride, a[1]);
+    }
+}
+
+template <bool MEM, bool MATH, int THREADS>
+static void run(const char *name, const float4 *X, float4 *Y, long long M)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k<MEM, MATH, THREADS><<<256, THREADS>>>(X, Y, M, 0.5f);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < 10; r++) k<MEM, MATH, THREADS><<<256, THREADS>>>(X, Y, M, 0.5f);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+    printf("%-44s %7.1f us\n", name, ms * 1e3);
+}
+
+int main()
+{
+    const long long M = 200000;
+    float4 *X, *Y;
+    (void)hipMalloc(&X, M * 100 * 4); (void)hipMalloc(&Y, M * 100 * 4);
+    (void)hipMemset(X, 0, M * 100 * 4);
+    run<true, false, 1024>("loads + stores, 1024 threads", X, Y, M);
+    run<false, true, 1024>("MFMAs only, 1024 threads", X, Y, M);
+    run<true, true, 1024>("both, 1024 threads", X, Y, M);
+    {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        k2<1024><<<256, 1024>>>(X, Y, M, 0.5f);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        for (int r = 0; r < 10; r++) k2<1024><<<256, 1024>>>(X, Y, M, 0.5f);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("%-44s %7.1f us\n", "both, next block's loads at block start", ms * 100);
+        k2<512><<<256, 512>>>(X, Y, M, 0.5f);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        for (int r = 0; r < 10; r++) k2<512><<<256, 512>>>(X, Y, M, 0.5f);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("%-44s %7.1f us\n", "the same, 512 threads", ms * 100);
+    }
+    run<true, false, 512>("loads + stores, 512 threads", X, Y, M);
+    run<false, true, 512>("MFMAs only, 512 threads", X, Y, M);
+    run<true, true, 512>("both, 512 threads", X, Y, M);
+    return 0;
+}
