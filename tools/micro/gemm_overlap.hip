@@ -8,8 +8,9 @@
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <bool MEM, bool MATH, int THREADS>
-__global__ void __launch_bounds__(THREADS) k(const float4 *__restrict__ X, float4 *__restrict__ Y, long long M, float wv)
+__global__ void __launch_bounds__(THREADS) k(const float4 *__restrict__ X, float4 *__restrict__ Y, long long M, float wv, long long wrap)
 {
+    auto at = [&](long long b) { return wrap > 0 ? b % wrap : b; };      // wrap > 0: the same few blocks again and again (L2-resident)
     constexpr int KG = 7, NT = 7, K4 = 25, N4 = 25;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long RB = M / 16, stride = (long long)gridDim.x * (THREADS / 64);
@@ -25,7 +26,7 @@ __global__ void __launch_bounds__(THREADS) k(const float4 *__restrict__ X, float
     for (int g = 0; g < KG; g++) a[g] = make_float4(1.f, 2.f, 3.f, 4.f);
     if (MEM && rb < RB) {
 #pragma unroll
-        for (int g = 0; g < KG; g++) a[g] = (4 * g + kq < K4) ? X[(rb * 16 + fr) * K4 + 4 * g + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < KG; g++) a[g] = (4 * g + kq < K4) ? X[(at(rb) * 16 + fr) * K4 + 4 * g + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (; rb < RB; rb += stride) {
         v4f acc[NT];
@@ -47,13 +48,13 @@ __global__ void __launch_bounds__(THREADS) k(const float4 *__restrict__ X, float
             } else {
                 acc[g][0] += ag.x + ag.y + ag.z + ag.w;
             }
-            if (MEM) a[g] = (nb < RB && 4 * g + kq < K4) ? X[(nb * 16 + fr) * K4 + 4 * g + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MEM) a[g] = (nb < RB && 4 * g + kq < K4) ? X[(at(nb) * 16 + fr) * K4 + 4 * g + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (MEM) {
 #pragma unroll
             for (int t = 0; t < NT; t++)
-                if (4 * t + kq < N4) Y[(rb * 16 + fr) * N4 + 4 * t + kq] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+                if (4 * t + kq < N4) Y[(at(rb) * 16 + fr) * N4 + 4 * t + kq] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
         } else if (acc[0][0] == 123.456f) {
             Y[0] = make_float4(acc[1][0], acc[2][0], acc[3][0], acc[4][0]);
         }
@@ -111,14 +112,14 @@ __global__ void __launch_bounds__(THREADS) k2(const float4 *__restrict__ X, floa
 }
 
 template <bool MEM, bool MATH, int THREADS>
-static void run(const char *name, const float4 *X, float4 *Y, long long M)
+static void run(const char *name, const float4 *X, float4 *Y, long long M, long long wrap = 0)
 {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    k<MEM, MATH, THREADS><<<256, THREADS>>>(X, Y, M, 0.5f);
+    k<MEM, MATH, THREADS><<<256, THREADS>>>(X, Y, M, 0.5f, wrap);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    for (int r = 0; r < 10; r++) k<MEM, MATH, THREADS><<<256, THREADS>>>(X, Y, M, 0.5f);
+    for (int r = 0; r < 10; r++) k<MEM, MATH, THREADS><<<256, THREADS>>>(X, Y, M, 0.5f, wrap);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
     printf("%-44s %7.1f us\n", name, ms * 1e3);
@@ -151,6 +152,8 @@ int main()
         (void)hipEventElapsedTime(&ms, e0, e1);
         printf("%-44s %7.1f us\n", "the same, 512 threads", ms * 100);
     }
+    run<true, false, 1024>("loads + stores from / to L2 (2048 rows)", X, Y, M, 128);
+    run<true, true, 1024>("both, from / to L2 (2048 rows)", X, Y, M, 128);
     run<true, false, 512>("loads + stores, 512 threads", X, Y, M);
     run<false, true, 512>("MFMAs only, 512 threads", X, Y, M);
     run<true, true, 512>("both, 512 threads", X, Y, M);
