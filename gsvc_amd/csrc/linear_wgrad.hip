@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad(const float 
     const int j = lane & 15, mq = lane >> 4;
     const long long RB = (M + 15) >> 4;
     const long long workers = (long long)gridDim.x * RS;
-    long long rb = (long long)blockIdx.x * RS + rs;
+    long long rb = (long long)rs * gridDim.x + blockIdx.x;          // chunks dealt row-split-major (see k_linear_ws)
     if (tid < LIN_NT_MAX * 16) sdb[tid] = 0.f;
     __syncthreads();
 
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const floa
     wg_block_tiles((K + 15) >> 4, BK, bk, tk0, TK);
     const int n0 = 16 * tn0, k0 = 16 * tk0;
     const long long workers = (long long)gridDim.x * RS;
-    const long long rb = (long long)blockIdx.x * RS + rs;
+    const long long rb = (long long)rs * gridDim.x + blockIdx.x;    // chunks dealt row-split-major (see k_linear_ws)
     if (tid < LIN_NT_MAX * 16) sdb[tid] = 0.f;
     __syncthreads();
 

@@ -194,7 +194,11 @@ __global__ void __launch_bounds__(THREADS) k_linear_ws(const float *__restrict__
     const int fr = lane & 15, kq = lane >> 4;
     const int ld = ws_ld(K), KG = (K + 15) >> 4, k16 = KG * 16;
     const long long RB = (M + 15) >> 4, stride = (long long)gridDim.x * WAVES;
-    long long rb = (long long)blockIdx.x * WAVES + wave;
+    // 16-row blocks are dealt wave-major: block rb goes to wave rb / gridDim of workgroup rb % gridDim.  M = 200 k rows are 3.05
+    // blocks per wave with 4096 waves: dealt workgroup-major the 212 blocks of the fourth round all landed on the first 13
+    // workgroups, whose SIMDs then had 16 blocks against 12 everywhere else — the kernel lasted a third longer than its average
+    // CU needed (tools/micro/gemm_overlap.hip: 53 -> 43 us for the 100 x 100 layer's loop)
+    long long rb = (long long)wave * gridDim.x + blockIdx.x;
 
     // first row block's fragments fly while the weights are staged
     float4 a[KGM];
