@@ -303,28 +303,41 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const floa
         for (int n = tid; n < N; n += blockDim.x) out[(size_t)N * K + n] = sdb[n];
 }
 
-// dst[i] = sum over the workgroup slots of part[slot][i]: 64 outputs per workgroup, the slots dealt to its 4 waves
-__global__ void __launch_bounds__(256) k_linear_wgrad_reduce(const float *__restrict__ part, int slots, int n, float *__restrict__ dW,
-                                                            int nk, float *__restrict__ db)
+// dst[i] = sum over the workgroup slots of part[slot][i]: 64 outputs per workgroup, the slots dealt to its 16 waves (256 slots:
+// four rounds of four independent loads per thread — with 4 waves it was sixteen rounds, ~10 us of load latency per launch)
+constexpr int WGR_WAVES = 16;
+
+__device__ __forceinline__ float wg_reduce_slots(const float *__restrict__ part, int slots, int n, int i, int li, int sg, float (*red)[64])
 {
-    __shared__ float red[4][64];
-    const int li = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + li;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (i < n) {
         int s = sg;
-        for (; s + 12 < slots; s += 16) {
+        for (; s + 3 * WGR_WAVES < slots; s += 4 * WGR_WAVES) {
             a0 += part[(size_t)s * n + i];
-            a1 += part[(size_t)(s + 4) * n + i];
-            a2 += part[(size_t)(s + 8) * n + i];
-            a3 += part[(size_t)(s + 12) * n + i];
+            a1 += part[(size_t)(s + WGR_WAVES) * n + i];
+            a2 += part[(size_t)(s + 2 * WGR_WAVES) * n + i];
+            a3 += part[(size_t)(s + 3 * WGR_WAVES) * n + i];
         }
-        for (; s < slots; s += 4) a0 += part[(size_t)s * n + i];
+        for (; s < slots; s += WGR_WAVES) a0 += part[(size_t)s * n + i];
     }
     red[sg][li] = (a0 + a1) + (a2 + a3);
     __syncthreads();
+    float v = 0.f;
+    if (sg == 0) {
+#pragma unroll
+        for (int w = 0; w < WGR_WAVES; w++) v += red[w][li];      // fixed order
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(64 * WGR_WAVES) k_linear_wgrad_reduce(const float *__restrict__ part, int slots, int n, float *__restrict__ dW,
+                                                                       int nk, float *__restrict__ db)
+{
+    __shared__ float red[WGR_WAVES][64];
+    const int li = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + li;
+    const float v = wg_reduce_slots(part, slots, n, i, li, sg, red);
     if (sg == 0 && i < n) {
-        const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
         if (i < nk) dW[i] = v;
         else db[i - nk] = v;
     }
@@ -338,30 +351,15 @@ struct WgReduceJobs {
     int slots[8], n[8], nk[8], first_block[9];
 };
 
-__global__ void __launch_bounds__(256) k_linear_wgrad_reduce_many(WgReduceJobs t, int jobs)
+__global__ void __launch_bounds__(64 * WGR_WAVES) k_linear_wgrad_reduce_many(WgReduceJobs t, int jobs)
 {
-    __shared__ float red[4][64];
+    __shared__ float red[WGR_WAVES][64];
     int job = 0;
     while (job + 1 < jobs && (int)blockIdx.x >= t.first_block[job + 1]) job++;
-    const float *__restrict__ part = t.part[job];
-    const int slots = t.slots[job], n = t.n[job];
     const int li = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int i = ((int)blockIdx.x - t.first_block[job]) * 64 + li;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (i < n) {
-        int s = sg;
-        for (; s + 12 < slots; s += 16) {
-            a0 += part[(size_t)s * n + i];
-            a1 += part[(size_t)(s + 4) * n + i];
-            a2 += part[(size_t)(s + 8) * n + i];
-            a3 += part[(size_t)(s + 12) * n + i];
-        }
-        for (; s < slots; s += 4) a0 += part[(size_t)s * n + i];
-    }
-    red[sg][li] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (sg == 0 && i < n) {
-        const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
+    const float v = wg_reduce_slots(t.part[job], t.slots[job], t.n[job], i, li, sg, red);
+    if (sg == 0 && i < t.n[job]) {
         if (i < t.nk[job]) t.dW[job][i] = v;
         else t.db[job][i - t.nk[job]] = v;
     }
@@ -390,7 +388,7 @@ static int launch_wgrad2(const float *G, const float *X, float *dW, float *db, b
     if (!dW) return grid;      // partial sums only: the caller adds the slots later (gsvc_linear_wgrad_reduce_many)
     const int n = N * K + (want_db ? N : 0);
     ProfScope _prof("k_linear_wgrad_reduce", s);
-    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3((n + 63) / 64), dim3(256), 0, s, part, grid, n, dW, N * K, db);
+    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3((n + 63) / 64), dim3(64 * WGR_WAVES), 0, s, part, grid, n, dW, N * K, db);
     return grid;
 }
 
@@ -420,7 +418,7 @@ static int launch_wgrad_t(const float *G, const float *X, float *dW, float *db, 
     if (!dW) return grid;      // partial sums only: the caller adds the slots later (gsvc_linear_wgrad_reduce_many)
     const int n = N * K + (want_db ? N : 0);
     ProfScope _prof("k_linear_wgrad_reduce", s);
-    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3((n + 63) / 64), dim3(256), 0, s, part, grid, n, dW, N * K, db);
+    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3((n + 63) / 64), dim3(64 * WGR_WAVES), 0, s, part, grid, n, dW, N * K, db);
     return grid;
 }
 
@@ -514,7 +512,7 @@ extern "C" int gsvc_linear_wgrad_reduce_many(const gsvc_wgrad_reduce_job *jobs, 
         }
         t.first_block[nj] = blocks;
         ProfScope _prof("k_linear_wgrad_reduce", s);
-        hipLaunchKernelGGL(k_linear_wgrad_reduce_many, dim3(blocks), dim3(256), 0, s, t, nj);
+        hipLaunchKernelGGL(k_linear_wgrad_reduce_many, dim3(blocks), dim3(64 * WGR_WAVES), 0, s, t, nj);
     }
     return check_launch("linear_wgrad_reduce_many");
 }
