@@ -232,7 +232,14 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const floa
     const int pairs = BN * BK;
     // row split rs handles the pairs rotated by rs: the blocks differ in size (4 x 4 .. 1 x 1 tiles), and with pair = wave %
     // pairs every wave of one SIMD (wave % 4) would own the same block
-    const int rs = wave / pairs, pair = (wave + rs) % pairs;
+    int rs = wave / pairs, pair = (wave + rs) % pairs;
+    if (pairs == 4 && RS == 3) {
+        // the common case (2 x 2 blocks, e.g. 4 x 4 / 4 x 3 / 3 x 4 / 3 x 3 tiles = 16 / 12 / 12 / 9 MFMAs per step): the twelve
+        // (block, row split) pairs are dealt so that the three waves of every SIMD carry 37 / 37 / 37 / 36 of them (the rotation
+        // above gives 40 / 33 / 37 / 37 and the kernel lasts as long as its busiest SIMD)
+        pair = (int)((0xBF9940u >> (2 * wave)) & 3u);      // waves 0..11 -> 0 0 0 1  1 2 1 2  3 3 3 2
+        rs = (int)((0xA450A4u >> (2 * wave)) & 3u);         // waves 0..11 -> 0 1 2 2  0 0 1 1  0 1 2 2
+    }
     const int bn = pair / BK, bk = pair - bn * BK;
     const int j = lane & 15, mq = lane >> 4;
     int tn0, TN, tk0, TK;
