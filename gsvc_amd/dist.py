@@ -79,10 +79,13 @@ def allreduce_gradients(params, average: bool = True):
 
 class GradReducer:
     """Gradient all-reduce that overlaps the backward pass: every large parameter's collective is launched from a
-    post-accumulate-grad hook the moment its gradient is final (the per-anchor offsets / scalings / masks finish early in the
-    backward, right behind the rasterizer), small parameters (the MLP weights) are reduced in one flat bucket at the end.
-    All ranks run the same backward graph, so the hooks fire — and the collectives are issued — in the same order everywhere.
-    On one rank it does nothing."""
+    post-accumulate-grad hook once its gradient is final, small parameters (the MLP weights) are reduced in one flat bucket at
+    the end.  Collectives must be issued in the same order on every rank.  The hooks fire in the order the ranks' backward
+    graphs produce the gradients — the same graph everywhere in a given mode, but the fused / layer-by-layer MLP paths are chosen
+    by the number of visible rows, which differs from rank to rank — so the launch order is FIXED instead: the first step
+    launches nothing from its hooks (everything goes out in ``finish``, in parameter-list order) and adopts rank 0's observed
+    order of completion; afterwards a parameter's collective goes out when it AND every parameter before it in that order
+    are ready (what DistributedDataParallel does with its buckets).  On one rank it does nothing."""
 
     SMALL = 1 << 18     # elements; below this a tensor joins the flat bucket
 
@@ -94,6 +97,12 @@ class GradReducer:
         self._pending = []          # (work, grad) of the collectives in flight
         self._params = []
         self._armed = False
+        self._order = None          # agreed launch order: indices into the list of hooked parameters (in parameter-list order)
+        self._order_key = None      # (number, sizes) of the hooked parameters the order was agreed for
+        self._hook_list = []        # this step's hooked parameters in parameter-list order
+        self._ready = {}            # index in _hook_list -> parameter whose gradient is final
+        self._seen = []             # indices in the order their hooks fired (this step)
+        self._next = 0
 
     def arm(self, params):
         """Call before backward with the step's parameters (new Parameter objects, e.g. after densification, get hooks;
@@ -108,29 +117,51 @@ class GradReducer:
         for p in self._params:
             if id(p) not in self._hooked and (p.numel() >= self.SMALL or (self.sharded is not None and self.sharded.owns(p))):
                 self._hooked[id(p)] = (p, p.register_post_accumulate_grad_hook(self._on_grad))
-        self._pending = []
+        self._hook_list = [p for p in self._params if id(p) in self._hooked]
+        key = tuple(p.numel() for p in self._hook_list)
+        if key != self._order_key:          # another set of large parameters (densification changes their sizes): agree again
+            self._order, self._order_key = None, key
+        self._index = {id(p): i for i, p in enumerate(self._hook_list)}
+        self._pending, self._ready, self._seen, self._next = [], {}, [], 0
         self._armed = True
 
-    def _on_grad(self, p):
-        if self._armed and p.grad is not None:
-            if self.sharded is not None and self.sharded.owns(p):
-                self.sharded.start(p)          # reduce-scatter of this gradient; its Adam step + all-gather follow in step()
-                return
+    def _launch(self, p):
+        if self.sharded is not None and self.sharded.owns(p):
+            self.sharded.start(p)          # reduce-scatter of this gradient; its Adam step + all-gather follow in step()
+        else:
             self._pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p.grad))
 
+    def _launch_ready(self):
+        while self._order is not None and self._next < len(self._order) and self._order[self._next] in self._ready:
+            self._launch(self._ready[self._order[self._next]])
+            self._next += 1
+
+    def _on_grad(self, p):
+        if self._armed and p.grad is not None and id(p) in self._index:
+            i = self._index[id(p)]
+            self._ready[i] = p
+            self._seen.append(i)
+            self._launch_ready()
+
     def finish(self):
-        """Call after backward: reduces the small parameters, waits for everything, averages.  Returns the number of
-        gradient elements reduced."""
+        """Call after backward: launches what the hooks could not (first step: everything), reduces the small parameters, waits for
+        everything, averages.  Returns the number of gradient elements reduced."""
         w = world_size()
         if w == 1 or not self.enabled:
             return 0
         self._armed = False
+        # large parameters not launched from their hooks, in the agreed order (or parameter-list order while there is none);
+        # one whose hook did not fire (hooks armed late) still takes part if it has a gradient
+        for i, p in enumerate(self._hook_list):
+            if i not in self._ready and p.grad is not None:
+                self._ready[i] = p
+        rest = self._order[self._next:] if self._order is not None else range(len(self._hook_list))
+        for i in rest:
+            if i in self._ready:
+                self._launch(self._ready[i])
         done = {id(g) for _, g in self._pending}
         if self.sharded is not None:
-            for p in self._params:             # (a sharded parameter whose hook did not fire, e.g. hooks armed late: start it now)
-                if p.grad is not None and self.sharded.owns(p):
-                    self.sharded.start(p)
-                    done.add(id(p.grad))
+            done |= {id(p.grad) for p in self._hook_list if p.grad is not None and self.sharded.owns(p)}
         small = [p.grad for p in self._params if p.grad is not None and id(p.grad) not in done]
         n = sum(g.numel() for _, g in self._pending)
         if small:
@@ -141,6 +172,12 @@ class GradReducer:
                 g.copy_(flat[off:off + g.numel()].view_as(g))
                 off += g.numel()
             n += off
+        if self._order is None and self._hook_list:
+            # agree on rank 0's order of completion (parameters whose hook did not fire go last, in list order)
+            mine = self._seen + [i for i in range(len(self._hook_list)) if i not in self._seen]
+            t = torch.tensor(mine, dtype=torch.int64, device=small[0].device if small else self._hook_list[0].device)
+            dist.broadcast(t, src=0)
+            self._order = [int(v) for v in t.tolist()]
         for work, _ in self._pending:
             work.wait()
         if self.average:

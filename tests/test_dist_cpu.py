@@ -82,6 +82,29 @@ def _worker(rank, world, port, q):
     ((big2 * float(rank + 1)).sum() + tiny.sum()).backward()
     red.finish()
     assert torch.allclose(big2.grad, torch.full_like(big2, 1.5)) and len(red._hooked) == 1
+    # the ranks' backward graphs may finish the large gradients in DIFFERENT orders (the fused / layer-by-layer MLP paths are
+    # chosen by the number of visible rows): the collectives still go out in one agreed order (rank 0's of the first step)
+    red2 = gd.GradReducer()
+    red2.SMALL = 16
+    pa, pb, pc3 = (torch.nn.Parameter(torch.ones(8, 4) * k) for k in (1.0, 2.0, 3.0))
+    for it in range(3):
+        for p in (pa, pb, pc3):
+            p.grad = None
+        red2.arm([pa, pb, pc3])
+        x = torch.ones(1, requires_grad=True)
+        # rank 0's graph completes pa, pb, pc3 in that order, rank 1's in the opposite order (later-created nodes run first)
+        chain = (pc3, pb, pa) if rank == 0 else (pa, pb, pc3)
+        loss = x.sum() * 0
+        for k, p in enumerate(chain):
+            loss = loss + (p * float(rank + 1 + k)).sum() * (x * 0 + 1).sum()
+        loss.backward()
+        red2.finish()
+        fired = [("a", "b", "c")[i] for i in red2._seen]
+        assert fired == (["a", "b", "c"] if rank == 0 else ["c", "b", "a"]), fired
+        assert red2._order == [0, 1, 2]                    # rank 0's order, on both ranks
+        want = {id(pa): 0.5 * ((1 + 2) + (2 + 0)), id(pb): 0.5 * ((1 + 1) + (2 + 1)), id(pc3): 0.5 * ((1 + 0) + (2 + 2))}
+        for p in (pa, pb, pc3):
+            assert torch.allclose(p.grad, torch.full_like(p, want[id(p)])), (rank, it)
     # collective yes/no decisions: blocking form and the early (start / finish) form
     assert gd.any_rank(rank == 1, torch.device("cpu")) is True and gd.any_rank(False, torch.device("cpu")) is False
     h = gd.any_rank_start([torch.tensor([0, 0]), torch.tensor([1 if rank == 0 else 0, 7])])
