@@ -43,9 +43,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = "train-step Gaussians/sec + render fps @1080p"
-PAIR_NOTE = ("two-view frames come from the fused gsvc_raster_forward_pair pass: the back-to-front composite of the opposite "
-             "view has no T<1e-4 early exit, so pixels agree with two separate renders to 2.5e-3, not to the 1e-4 of "
-             "the single-view path (inference only; training always uses the single-view kernels)")
+PAIR_NOTE = ("two-view frames (reference utils/report_utils.py:297-319: view + opposite view + flip + average) come from "
+             "gsvc_raster_forward_pair: one binning, the opposite view composited by a second pass over the same sorted list from "
+             "its end at that view's own fp32 coordinates with its own alpha / T decisions — within 1e-4 of two separate renders "
+             "on every pixel without a borderline decision (tests/test_raster_gpu.py::test_two_view_pair_kernel_matches_two_renders)")
 
 
 def parse(argv=None):
@@ -67,6 +68,10 @@ def parse(argv=None):
     ap.add_argument("--anchors", type=int, default=245_000,
                     help="train_step: anchors in the cube (245k in 64 frames x 1.1 bleed -> ~50k in a 16-frame slab)")
     ap.add_argument("--train-frames", type=int, default=64, help="train_step: frames of the synthetic video")
+    ap.add_argument("--cfg3", action="store_true",
+                    help="train_step: BASELINE.json configs[3]'s per-GPU workload, reference cfgs/cfg_20240919.yaml AS IS: 100 000 "
+                         "anchors (init_anchor_num), a 600-frame 1080p video, threshold = .05 (a +-48-frame z-slab, reference "
+                         "arguments/__init__.py:54), lambda = .004; overrides --anchors / --train-frames")
     ap.add_argument("--pretrain", type=int, default=200,
                     help="train_step: untimed fitting steps before the warmup (BASELINE.md section 2: 200, so that opacities "
                          "and scales are no longer at their initial values; they also let the caching allocator see every "
@@ -242,11 +247,15 @@ def run_train_step(args, rank, world, dev):
     from gsvc_amd.model import GaussianModel
     from gsvc_amd.train import Trainer
 
+    if args.cfg3:
+        args.anchors, args.train_frames = 100_000, 600
     H, W, T = args.height, args.width, args.train_frames
     mp_, opt, pipe = cfg_20240919()
     # the whole synthetic video resident on the device before the timed region (as the reference holds its video in memory)
     cube = SyntheticFrameCube(H, W, T, seed=1234, device=dev).materialize()
-    mp_.threshold = 8.0 / cube.scale                      # 16-frame sliding window
+    if not args.cfg3:
+        mp_.threshold = 8.0 / cube.scale                  # 16-frame sliding window (configs[2]); --cfg3 keeps the yaml's .05
+    slab_frames = 2.0 * mp_.threshold * cube.scale
     # jump straight to the entropy-constrained phase (lambda = 0.004, noise quantisation + sampled rate)
     opt.full_precision_training_total, opt.quantized_training_total = 0, 0
     opt.entropy_constrained_train_total = 10 ** 9
@@ -278,10 +287,13 @@ def run_train_step(args, rank, world, dev):
     for _ in range(args.pretrain + args.warmup):
         step()
     active = torch.zeros((), device=dev, dtype=torch.float64)
+    submitted = [0]
 
     def counted():
         nonlocal active
-        active += step().active_gaussians
+        o = step()
+        active += o.active_gaussians
+        submitted[0] += sum(int(r.radii.numel()) for r in o.renders)      # shapes: host metadata, no device read
 
     mem0 = torch.cuda.memory_stats(dev)
     rep0 = getattr(trainer, "repeated_steps", 0)
@@ -350,7 +362,7 @@ def run_train_step(args, rank, world, dev):
 
     HW = H * W
     n_inst = inst / (4 * args.steps)                      # instances per render
-    P = float(sum(r.radii.numel() for r in out.renders)) / 4
+    P = submitted[0] / (4.0 * args.steps)                 # Gaussians submitted per render, mean over the timed steps
     n_vis = total_units / (4 * args.steps * world)
     kern = {k: {"launches": n, "avg_us": 1e3 * ms / max(n, 1)} for k, (n, ms) in prof.items()}
     alg = {"k_blend": 40 * n_inst + 20 * HW, "k_blend_bwd": 40 * n_inst + 20 * HW, "k_preprocess": 60 * P + 44 * n_vis,
@@ -366,13 +378,17 @@ def run_train_step(args, rank, world, dev):
         "metric": METRIC, "value": total_units / elapsed, "unit": "Gaussians/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"train_step (BASELINE.json configs[2]): {H}x{W}, {T}-frame synthetic video, {pc._anchor.shape[0]} "
-                               f"anchors x K=10, 16-frame z-slab; 4 renders/step fwd+bwd + hash grid + entropy loss "
+        "config": {"workload": f"train_step ({'BASELINE.json configs[3] per-GPU workload, cfg_20240919.yaml as is' if args.cfg3 else 'BASELINE.json configs[2]'}): "
+                               f"{H}x{W}, {T}-frame synthetic video, {pc._anchor.shape[0]} "
+                               f"anchors x K=10, {slab_frames:.0f}-frame z-slab (threshold {mp_.threshold:.5f}); 4 renders/step fwd+bwd + hash grid + entropy loss "
                                f"(lambda={opt.lmbda}, TRAINING_ENTROPY) + L1/SSIM/optical + Adam; one frame pair per rank; "
                                f"{args.pretrain} untimed fitting steps before the warmup",
                    "gaussians_per_render": P, "active_per_render": n_vis, "instances_per_render": n_inst,
                    "visible_anchors_per_render": P / pc.n_offsets,
+                   "value_counts": "Gaussians with radius > 0 (active_per_render x 4 renders x steps / s); gaussians_per_render are "
+                                   "submitted un-compacted (K per visible anchor), both means over the timed steps",
                    "parallelism": f"frame-shard x{world} + gradient all-reduce" if world > 1 else "single GPU"},
+        "effective_batch": world,      # frame pairs per optimizer step: loss = mean over ranks (the reference steps on one pair)
         "dp_anchor_optimizer": ("reduce-scatter + sharded Adam + all-gather" if trainer.sharded is not None else
                                 ("all-reduce + replicated Adam" if world > 1 else None)),
         "rccl_ranks": (dist.get_world_size() if world > 1 else 1),

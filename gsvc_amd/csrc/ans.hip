@@ -477,11 +477,14 @@ extern "C" int gsvc_ans_decode_many(const gsvc_ans_decode_job *jobs, int32_t n_j
     GSVC_REQUIRE(jobs && n_jobs >= 0, "ans_decode_many: bad arguments");
     if (int rc = ensure_phi_table()) return rc;
     hipStream_t s = (hipStream_t)stream;
-    for (int j0 = 0; j0 < n_jobs; j0 += ANS_MAX_JOBS) {
+    for (int j0 = 0; j0 < n_jobs;) {
         AnsJobs t;
         t.n = 0;
         long long blocks = 0, mblocks = 0;
-        for (int j = j0; j < n_jobs && t.n < ANS_MAX_JOBS; j++) {
+        int j = j0;
+        // a batch is the next ANS_MAX_JOBS NON-EMPTY jobs: the next batch starts behind the last index this one consumed
+        // (empty jobs are skipped without taking a slot; advancing by ANS_MAX_JOBS decoded the surplus jobs a second time)
+        for (; j < n_jobs && t.n < ANS_MAX_JOBS; j++) {
             const gsvc_ans_decode_job &d = jobs[j];
             GSVC_REQUIRE(d.n >= 0 && d.seg_len > 0 && d.seg_len <= (1 << 20), "ans_decode_many: bad sizes (job %d)", j);
             GSVC_REQUIRE(d.max_symbol >= d.min_symbol && (int64_t)d.max_symbol - d.min_symbol + 1 < (int64_t)(ANS_M / 2),
@@ -499,6 +502,7 @@ extern "C" int gsvc_ans_decode_many(const gsvc_ans_decode_job *jobs, int32_t n_j
             mblocks += (q.n + 255) / 256;
             GSVC_REQUIRE(blocks < (1ll << 31) && mblocks < (1ll << 31), "ans_decode_many: too many symbols for one launch");
         }
+        j0 = j;
         if (t.n == 0) continue;
         {
             ProfScope _p("k_ans_model", s);

@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
     int my_tiles = 0;       // instances of this Gaussian = rows it owns in the backward's partial-sum buffer
     float rec2_b = 0.f;
     uint32_t rec2_bx = 0u, rec2_by = 0u;
+    uint32_t ub_bits = 0u;     // pair mode: the opposite view's pixel x of this Gaussian (float bits), kept in GeomRec::pad
     if (i < P) {
         // a Gaussian with opacity <= 0 can never reach alpha >= 1/255: culled here (radius 0), which lets callers
         // pass un-compacted Gaussian sets (GSVC's "opacity > 0" selection) without a host-side compaction
@@ -253,8 +254,16 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         if (!PAIR) {
             bx0 = o.x0; bx1 = o.x1;
         } else if (o.radius_raw > 0) {
-            // opposite view: x_view' = -x_view, same y, same radius; rectangle by the same formula, then mirrored
-            const float ub = (-o.xv - st.x_min) * st.scale - st.pix_off, rf = (float)o.radius_raw;
+            // opposite view: x_view' = -x_view, same y, same radius; rectangle by the same formula, then mirrored.  ub is
+            // what preprocess_gaussian() computes for u under view_matrix_s (same operations, no FMA contraction): k_blend<PAIR>
+            // composites the opposite view at it
+            float ub;
+            {
+#pragma clang fp contract(off)
+                ub = (-o.xv - st.x_min) * st.scale - st.pix_off;
+            }
+            ub_bits = __float_as_uint(ub);
+            const float rf = (float)o.radius_raw;
             const int xb0 = tile_clamp((ub - rf) / (float)TILE, st.gx), xb1 = tile_clamp((ub + rf + (float)(TILE - 1)) / (float)TILE, st.gx);
             const bool vis_b = (xb1 - xb0) * (o.y1 - o.y0) > 0;
             const int mx0 = st.gx - xb1, mx1 = st.gx - xb0;
@@ -295,7 +304,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
             rec.rect_x = rec.rect_y = 0u;
             br.depth = 0.f; br.rect_x = br.rect_y = 0u;
         }
-        rec.goff = 0; rec.pad = 0u;
+        rec.goff = 0; rec.pad = PAIR ? ub_bits : 0u;
         float4 *dst = reinterpret_cast<float4 *>(geom + i);
         const float4 *src = reinterpret_cast<const float4 *>(&rec);
         dst[0] = src[0]; dst[1] = src[1]; dst[3] = src[3];
@@ -789,11 +798,154 @@ constexpr float LOG2E = 1.44269504088896340736f;
 // per-pixel work is p = A' dx^2 + C' dy^2 + B' dx dy, G = exp2(-p): 6 mul/fma + one v_exp_f32.  The inner loop
 // is branch-free: selects on SGPR masks instead of EXEC-mask branches.
 //
-// PAIR = true additionally composites the SAME list back to front ("over" recurrence Cb = c a + (1-a) Cb): that is
-// what the opposite view (view_matrix_s) renders at the mirrored pixel, so image = (front + flip(back)) / 2 — the
-// frame GSVC's evaluation and decoder actually output (reference utils/report_utils.py:297-319, pipeline/train.py:
-// 368-375) — comes out of ONE binning + ONE pass instead of two renders, a flip and an average.  The back composite
-// has no early exit (the opposite view's own T < 1e-4 cut changes a pixel by < 1e-4).
+// PAIR = true renders the two-view frame GSVC's evaluation and decoder actually output (reference utils/report_utils.py:
+// 297-319, pipeline/train.py:368-375): image = (render(view) + flip_W(render(opposite view))) / 2 from ONE binning.  The
+// opposite view (view_matrix_s) sees the same Gaussians mirrored in x in the reverse depth order, so its composite is a second
+// pass over the SAME sorted list, walked from its end, with the opposite view's own numbers: its fp32 pixel coordinate
+// u_b = (-x_view - x_min) scale - 1/2 (what preprocess_gaussian() computes under view_matrix_s, kept in GeomRec::pad by
+// k_preprocess<PAIR>), its conic (A, -B, C) — bit-identical: the mirror only flips signs —, its quadrant (the mirrored one,
+// lanes mirrored) and its own front-to-back recurrence with the alpha >= 1/255 and T < 1e-4 decisions.  Every pixel therefore
+// carries what two separate launches give, decision for decision (round 2 composited the opposite view back to front at this
+// view's coordinates without the T stop: 2.5e-3 on isolated pixels).
+template <bool PAIR, bool BACK>
+__device__ __forceinline__ void blend_pass(const RasterParams &st, int beg, int end, const int32_t *__restrict__ point_list,
+                                           const uint2 *__restrict__ inst_bbox, const GeomRec *__restrict__ geom,
+                                           float4 *w_f0, float4 *w_f1, float2 *w_f2, int lane, int qx0, int qy0, bool inside,
+                                           float &T, float &C0, float &C1, float &C2, int &last)
+{
+    // the quadrant and the lane's pixel in THIS pass's view (BACK: mirrored; the image width is a multiple of the tile size)
+    const int vqx0 = BACK ? st.W - 8 - qx0 : qx0;
+    const int lx = BACK ? 7 - (lane & 7) : (lane & 7);
+    const float fx = (float)(vqx0 + lx), fy = (float)(qy0 + (lane >> 3));
+    // pixel position relative to the quadrant centre, and its products: the lane's side of the polynomial form
+    const float xl = (float)lx - 3.5f, yl = (float)(lane >> 3) - 3.5f;
+    const float xl2 = xl * xl, yl2 = yl * yl, xyl = xl * yl;
+    const float qcx = (float)vqx0 + 3.5f, qcy = (float)qy0 + 3.5f;
+    const int view_bit = BACK ? 2 : 1;
+    unsigned long long done_m = __ballot(!inside);    // lanes that take no further entries (uniform mask, in SGPRs)
+    for (int c0 = BACK ? beg + ((end - beg - 1) & ~63) : beg; BACK ? c0 >= beg : c0 < end; c0 += BACK ? -64 : 64) {
+        // phase 1: 64 list entries per wave-instruction against this wave's quadrant
+        const int k = c0 + lane;
+        bool hit = false;
+        int id = 0;
+        if (k < end) {
+            hit = bbox_hits(inst_bbox[k], qx0, qy0);      // the alpha box is this view's; mirrored it is the opposite view's
+            id = point_list[k];
+            if (PAIR) hit = hit && (id & view_bit);
+        }
+        if (__ballot(hit) == 0ull) continue;
+        // second, exact test on the bbox survivors: does the alpha >= 1/255 ellipse reach this quadrant at all?
+        float4 r0, r1;
+        const float4 *rec = reinterpret_cast<const float4 *>(geom + (PAIR ? (id >> 2) : id));
+        bool safe = true;
+        if (hit) {
+            r0 = rec[0];
+            r1 = rec[1];
+            if (BACK) { r0.x = rec[3].w; r0.w = -r0.w; }
+            hit = ellipse_hits_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)vqx0, (float)qy0);
+            // conic positive definite with a margin and opacity > 0: "power > 0" (spec step 6) cannot happen for this
+            // entry, in exact or in rounded arithmetic, so the composite loop need not test for it
+            safe = r0.z > 0.f && r1.x > 0.f && r0.z * r1.x >= 1.002f * (r0.w * r0.w) && r1.y > 0.f;
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;
+        const bool generic = __ballot(hit && !safe) != 0ull;    // NaN / indefinite conics: the literal loop
+        if (hit) {
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            const float Ap = (0.5f * LOG2E) * r0.z, Bp = LOG2E * r0.w, Cp = (0.5f * LOG2E) * r1.x;
+            const float tagf = __int_as_float(PAIR ? 1 : (k - beg + 1));      // 1-based list position (single view: kept for the backward)
+            if (generic) {
+                w_f0[pos] = make_float4(r0.x, r0.y, Ap, Bp);
+                w_f1[pos] = make_float4(Cp, r1.y, r1.z, r1.w);
+            } else {
+                // -log2(alpha) of pixel (qcx + x, qcy + y) as a polynomial in the lane's (x, y), |x|, |y| <= 3.5:
+                //   A'(U-x)^2 + C'(V-y)^2 + B'(U-x)(V-y) - log2(o),  U = u - qcx, V = v - qcy;  stored negated
+                const float U = r0.x - qcx, V = r0.y - qcy;
+                const float n0 = __builtin_amdgcn_logf(r1.y) - (Ap * U * U + Cp * V * V + Bp * U * V);
+                w_f0[pos] = make_float4(n0, 2.0f * Ap * U + Bp * V, 2.0f * Cp * V + Bp * U, -Ap);
+                w_f1[pos] = make_float4(-Cp, -Bp, r1.z, r1.w);
+            }
+            w_f2[pos] = make_float2(rec[2].x, tagf);
+        }
+        const int cnt = __popcll(mask);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // phase 2: composite the survivors front to back (BACK: from the chunk's last survivor to its first).  Lane predicates
+        // live as uniform 64-bit masks (v_cmp results in SGPRs, combined by scalar instructions); 17 vector instructions per entry.
+        if (!generic) {
+            // alpha of entry j at this lane's pixel (independent of the pixel state: four of them are evaluated
+            // together so that their dependent FMA -> exp chains interleave)
+            auto alpha_of = [&](int j) -> float {
+                const float4 a = w_f0[j];
+                const float2 b = *reinterpret_cast<const float2 *>(&w_f1[j]);
+                float t = fmaf(b.y, xyl, a.x);
+                t = fmaf(a.y, xl, t);
+                t = fmaf(a.z, yl, t);
+                t = fmaf(a.w, xl2, t);
+                t = fmaf(b.x, yl2, t);
+                return fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(t));
+            };
+            auto apply = [&](int j, float alpha) {
+                const float2 rg = *(reinterpret_cast<const float2 *>(&w_f1[j]) + 1);
+                const float2 c = w_f2[j];
+                const float test_T = T - alpha * T;
+                const unsigned long long small_m = __ballot(alpha < ALPHA_MIN), lt_m = __ballot(test_T < T_MIN);
+                const int tagv = __float_as_int(c.y);
+                const unsigned long long keep_m = ~done_m & ~small_m;
+                const unsigned long long acc_m = keep_m & ~lt_m;
+                done_m |= keep_m & lt_m;
+                const bool acc = __builtin_amdgcn_inverse_ballot_w64(acc_m);
+                const float w = acc ? alpha * T : 0.0f;
+                C0 += rg.x * w; C1 += rg.y * w; C2 += c.x * w;
+                T = acc ? test_T : T;
+                last = acc ? tagv : last;
+            };
+            // unrolled by hand: the mask intrinsics are convergent, which rules out "#pragma unroll 4"
+            if (!BACK) {
+                int j = 0;
+                for (; j + 4 <= cnt; j += 4) {
+                    const float a0 = alpha_of(j), a1 = alpha_of(j + 1), a2 = alpha_of(j + 2), a3 = alpha_of(j + 3);
+                    apply(j, a0); apply(j + 1, a1); apply(j + 2, a2); apply(j + 3, a3);
+                }
+                for (; j < cnt; j++) apply(j, alpha_of(j));
+            } else {
+                int j = cnt - 1;
+                for (; j >= 3; j -= 4) {
+                    const float a0 = alpha_of(j), a1 = alpha_of(j - 1), a2 = alpha_of(j - 2), a3 = alpha_of(j - 3);
+                    apply(j, a0); apply(j - 1, a1); apply(j - 2, a2); apply(j - 3, a3);
+                }
+                for (; j >= 0; j--) apply(j, alpha_of(j));
+            }
+        } else {
+            bool done = __builtin_amdgcn_inverse_ballot_w64(done_m);
+            for (int jj = 0; jj < cnt; jj++) {
+                const int j = BACK ? cnt - 1 - jj : jj;
+                const float4 a = w_f0[j];
+                const float4 b = w_f1[j];
+                const float2 c = w_f2[j];
+                const float dx = a.x - fx, dy = a.y - fy;
+                const float p = a.z * dx * dx + b.x * dy * dy + a.w * dx * dy;   // = -power * log2(e)
+                const float alpha = fminf(ALPHA_MAX, b.y * __builtin_amdgcn_exp2f(-p));
+                const float test_T = T - alpha * T;
+                const int tagv = __float_as_int(c.y);
+                const bool contrib = !(p < 0.0f) && !(alpha < ALPHA_MIN);
+                const bool keep = !done && contrib;
+                const bool stop = keep && (test_T < T_MIN);
+                const bool acc = keep && !stop;
+                done |= stop;
+                const float w = acc ? alpha * T : 0.0f;
+                C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
+                T = acc ? test_T : T;
+                last = acc ? tagv : last;
+            }
+            done_m = __ballot(done);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (done_m == ~0ull) break;
+    }
+}
+
 template <bool PAIR>
 __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *__restrict__ tile_offsets,
                                                const int32_t *__restrict__ point_list,
@@ -814,150 +966,23 @@ __global__ void __launch_bounds__(256) k_blend(RasterParams st, const int32_t *_
     const bool inside = px < st.W && py < st.H;
     const int tile = blockIdx.y * st.gx + blockIdx.x;
     const int beg = tile_offsets[tile], end = tile_offsets[tile + 1];
-    const float fx = (float)px, fy = (float)py;
-    float4 *w_f0 = s_f0[wave];
-    float4 *w_f1 = s_f1[wave];
-    float2 *w_f2 = s_f2[wave];
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    float Tb = 1.0f, B0 = 0.f, B1 = 0.f, B2 = 0.f;   // PAIR: back-to-front composite of the same list
     int last = 0;
-    // pixel position relative to the quadrant centre, and its products: the lane's side of the polynomial form
-    const float xl = (float)(lane & 7) - 3.5f, yl = (float)(lane >> 3) - 3.5f;
-    const float xl2 = xl * xl, yl2 = yl * yl, xyl = xl * yl;
-    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;
-    unsigned long long done_m = __ballot(!inside);    // lanes that take no further entries (uniform mask, in SGPRs)
-    for (int c0 = beg; c0 < end; c0 += 64) {
-        // phase 1: 64 list entries per wave-instruction against this wave's quadrant
-        const int k = c0 + lane;
-        bool hit = false;
-        int id = 0;
-        if (k < end) {
-            hit = bbox_hits(inst_bbox[k], qx0, qy0);
-            id = point_list[k];
-        }
-        if (__ballot(hit) == 0ull) continue;
-        // second, exact test on the bbox survivors: does the alpha >= 1/255 ellipse reach this quadrant at all?
-        float4 r0, r1;
-        const float4 *rec = reinterpret_cast<const float4 *>(geom + (PAIR ? (id >> 2) : id));
-        bool safe = true;
-        if (hit) {
-            r0 = rec[0];
-            r1 = rec[1];
-            hit = ellipse_hits_quad(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)qx0, (float)qy0);
-            // conic positive definite with a margin and opacity > 0: "power > 0" (spec step 6) cannot happen for this
-            // entry, in exact or in rounded arithmetic, so the composite loop need not test for it
-            safe = r0.z > 0.f && r1.x > 0.f && r0.z * r1.x >= 1.002f * (r0.w * r0.w) && r1.y > 0.f;
-        }
-        const unsigned long long mask = __ballot(hit);
-        if (mask == 0ull) continue;
-        const bool generic = __ballot(hit && !safe) != 0ull;    // NaN / indefinite conics: the literal loop
-        if (hit) {
-            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-            const float Ap = (0.5f * LOG2E) * r0.z, Bp = LOG2E * r0.w, Cp = (0.5f * LOG2E) * r1.x;
-            // PAIR: the slot's tag carries the two view-membership flags instead of the list position
-            const float tagf = __int_as_float(PAIR ? (id & 3) : (k - beg + 1));
-            if (generic) {
-                w_f0[pos] = make_float4(r0.x, r0.y, Ap, Bp);
-                w_f1[pos] = make_float4(Cp, r1.y, r1.z, r1.w);
-            } else {
-                // -log2(alpha) of pixel (qcx + x, qcy + y) as a polynomial in the lane's (x, y), |x|, |y| <= 3.5:
-                //   A'(U-x)^2 + C'(V-y)^2 + B'(U-x)(V-y) - log2(o),  U = u - qcx, V = v - qcy;  stored negated
-                const float U = r0.x - qcx, V = r0.y - qcy;
-                const float n0 = __builtin_amdgcn_logf(r1.y) - (Ap * U * U + Cp * V * V + Bp * U * V);
-                w_f0[pos] = make_float4(n0, 2.0f * Ap * U + Bp * V, 2.0f * Cp * V + Bp * U, -Ap);
-                w_f1[pos] = make_float4(-Cp, -Bp, r1.z, r1.w);
-            }
-            w_f2[pos] = make_float2(rec[2].x, tagf);
-        }
-        const int cnt = __popcll(mask);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // phase 2: composite the survivors front to back.  Lane predicates live as uniform 64-bit masks (v_cmp
-        // results in SGPRs, combined by scalar instructions); 17 vector instructions per entry.
-        if (!generic) {
-            // alpha of entry j at this lane's pixel (independent of the pixel state: four of them are evaluated
-            // together so that their dependent FMA -> exp chains interleave)
-            auto alpha_of = [&](int j) -> float {
-                const float4 a = w_f0[j];
-                const float2 b = *reinterpret_cast<const float2 *>(&w_f1[j]);
-                float t = fmaf(b.y, xyl, a.x);
-                t = fmaf(a.y, xl, t);
-                t = fmaf(a.z, yl, t);
-                t = fmaf(a.w, xl2, t);
-                t = fmaf(b.x, yl2, t);
-                return fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(t));
-            };
-            auto apply = [&](int j, float alpha) {
-                const float2 rg = *(reinterpret_cast<const float2 *>(&w_f1[j]) + 1);
-                const float2 c = w_f2[j];
-                const float test_T = T - alpha * T;
-                const unsigned long long small_m = __ballot(alpha < ALPHA_MIN), lt_m = __ballot(test_T < T_MIN);
-                const int tagv = __float_as_int(c.y);
-                unsigned long long keep_m = ~done_m & ~small_m;
-                if (PAIR) {
-                    const int fl = __builtin_amdgcn_readfirstlane(tagv);
-                    const bool back = __builtin_amdgcn_inverse_ballot_w64((fl & 2) ? (~small_m & __ballot(inside)) : 0ull);
-                    const float ab = back ? alpha : 0.0f;
-                    const float om = 1.0f - ab;
-                    B0 = rg.x * ab + om * B0; B1 = rg.y * ab + om * B1; B2 = c.x * ab + om * B2;
-                    Tb *= om;
-                    if (!(fl & 1)) keep_m = 0ull;
-                }
-                const unsigned long long acc_m = keep_m & ~lt_m;
-                done_m |= keep_m & lt_m;
-                const bool acc = __builtin_amdgcn_inverse_ballot_w64(acc_m);
-                const float w = acc ? alpha * T : 0.0f;
-                C0 += rg.x * w; C1 += rg.y * w; C2 += c.x * w;
-                T = acc ? test_T : T;
-                last = acc ? tagv : last;
-            };
-            int j = 0;      // unrolled by hand: the mask intrinsics are convergent, which rules out "#pragma unroll 4"
-            for (; j + 4 <= cnt; j += 4) {
-                const float a0 = alpha_of(j), a1 = alpha_of(j + 1), a2 = alpha_of(j + 2), a3 = alpha_of(j + 3);
-                apply(j, a0); apply(j + 1, a1); apply(j + 2, a2); apply(j + 3, a3);
-            }
-            for (; j < cnt; j++) apply(j, alpha_of(j));
-        } else {
-            bool done = __builtin_amdgcn_inverse_ballot_w64(done_m);
-            for (int j = 0; j < cnt; j++) {
-                const float4 a = w_f0[j];
-                const float4 b = w_f1[j];
-                const float2 c = w_f2[j];
-                const float dx = a.x - fx, dy = a.y - fy;
-                const float p = a.z * dx * dx + b.x * dy * dy + a.w * dx * dy;   // = -power * log2(e)
-                const float alpha = fminf(ALPHA_MAX, b.y * __builtin_amdgcn_exp2f(-p));
-                const float test_T = T - alpha * T;
-                const int tagv = __float_as_int(c.y);
-                const bool contrib_any = !(p < 0.0f) && !(alpha < ALPHA_MIN);
-                const bool contrib = PAIR ? (contrib_any && (tagv & 1)) : contrib_any;
-                if (PAIR) {
-                    const float ab = (contrib_any && inside && (tagv & 2)) ? alpha : 0.0f;
-                    const float om = 1.0f - ab;
-                    B0 = b.z * ab + om * B0; B1 = b.w * ab + om * B1; B2 = c.x * ab + om * B2;
-                    Tb *= om;
-                }
-                const bool keep = !done && contrib;
-                const bool stop = keep && (test_T < T_MIN);
-                const bool acc = keep && !stop;
-                done |= stop;
-                const float w = acc ? alpha * T : 0.0f;
-                C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
-                T = acc ? test_T : T;
-                last = acc ? tagv : last;
-            }
-            done_m = __ballot(done);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (!PAIR && done_m == ~0ull) break;
-    }
+    blend_pass<PAIR, false>(st, beg, end, point_list, inst_bbox, geom, s_f0[wave], s_f1[wave], s_f2[wave], lane, qx0, qy0, inside,
+                            T, C0, C1, C2, last);
     if (!PAIR) {
         // per-pixel state for the backward, TILE-MAJOR (tile, quadrant, lane): one coalesced 256-B store per wave here and
         // one coalesced load per quadrant there; pixels outside the image hold T = 1, last = 0 (nothing contributes)
         const int sidx = (tile * 4 + wave) * 64 + lane;
         final_T[sidx] = T;
         n_contrib[sidx] = last;
+    }
+    float Tb = 1.0f, B0 = 0.f, B1 = 0.f, B2 = 0.f;
+    if (PAIR) {
+        int last_b = 0;
+        blend_pass<PAIR, true>(st, beg, end, point_list, inst_bbox, geom, s_f0[wave], s_f1[wave], s_f2[wave], lane, qx0, qy0, inside,
+                               Tb, B0, B1, B2, last_b);
     }
     if (inside) {
         const int HW = st.H * st.W, pix = py * st.W + px;

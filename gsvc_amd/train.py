@@ -296,6 +296,7 @@ class Trainer:
         self.reducer.arm([p for g in pc.optimizer.param_groups for p in g["params"]])
         handles = []
         if (early and self.batched and self.prefetch and pc._anchor.is_cuda and gdist.world_size() == 1 and self.sharded is None
+                and not self.anchor_grad      # a trained anchor tensor moves behind the early plan's visibility test
                 and mode == GenerateMode.TRAINING_ENTROPY and iteration < opt.iterations and not self.controller.gaussian_adjust_anchor
                 and isinstance(pc.optimizer, FusedAdam) and not os.environ.get("GSVC_NO_EARLY_PLAN")
                 and pc._scaling.requires_grad and pc._mask.requires_grad
@@ -322,6 +323,11 @@ class Trainer:
             # the only host synchronisation of the step after the visibility test: the 4 renders' instance counters
             _, overflowed = resolve_deferred([r.raster_state for r in renders])
             if gdist.any_rank_finish(ovf_handle, overflowed):      # replicas repeat the step together (their collectives must pair up)
+                if self.sharded is not None:
+                    # the reduce-scatters this backward started carry gradients the rasterizer declares invalid: wait for
+                    # them and drop them, so that the repeated step's hooks start fresh ones (start() skips a parameter
+                    # that still has one outstanding, and step() would then run Adam on the stale shards)
+                    self.sharded.step(skip_update=True)
                 return None
             for r in renders:
                 r.num_rendered = r.raster_state.counters()[0]

@@ -16,6 +16,26 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def _setup_configs3():
+    import numpy as np
+    from gsvc_amd.arguments import cfg_20240919
+    from gsvc_amd.frame import SyntheticFrameCube
+    from gsvc_amd.model import GaussianModel
+    from gsvc_amd.train import Trainer
+    mp_, opt, pipe = cfg_20240919()
+    assert mp_.threshold == 0.05 and opt.init_anchor_num == 100_000
+    cube = SyntheticFrameCube(1080, 1920, 600, seed=1234, device="cuda")
+    torch.manual_seed(0)
+    pc = GaussianModel(mp_, mp_.anchor_feature_dim, mp_.n_offsets, mp_.voxel_size, mp_.update_depth, mp_.update_init_factor,
+                       mp_.update_hierarchy_factor, mp_.use_feat_bank, n_features_per_level=mp_.grid_feature_dim,
+                       log2_hashmap_size=mp_.log2, log2_hashmap_size_2D=mp_.log2_2D, device="cuda")
+    rng = np.random.default_rng(0)
+    lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
+    pc.create_from_points(rng.uniform(lim, -lim, (opt.init_anchor_num, 3)), spatial_lr_scale=1.0)
+    pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+    return pc, cube, opt, pipe, mp_, Trainer
+
+
 def main():
     backend = os.environ.get("GSVC_DIST_BACKEND", "nccl")
     local = 0 if os.environ.get("GSVC_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
@@ -26,7 +46,11 @@ def main():
         dist.init_process_group(backend)
     from test_train_gpu import _setup
     from gsvc_amd import dist as gd
-    pc, cube, opt, pipe, mp, Trainer = _setup(anchors=3000)
+    if os.environ.get("GSVC_DP_SHAPE") == "configs3":
+        # BASELINE.json configs[3]: reference cfgs/cfg_20240919.yaml as is (100 000 anchors, 600 frames of 1080p, threshold .05)
+        pc, cube, opt, pipe, mp, Trainer = _setup_configs3()
+    else:
+        pc, cube, opt, pipe, mp, Trainer = _setup(anchors=3000)
     opt.full_precision_training_total = 1000          # no quantisation noise: the step is a deterministic function of the frames
     pc.training_setup(opt)
     gd.broadcast_parameters(pc)

@@ -189,6 +189,21 @@ def _sharded_worker(rank, world, port, q):
     red.finish()
     sh.step(skip_update=True)
     assert all(torch.equal(ps[k], before[k]) for k in ("offset", "mask", "anchor_feat", "scaling"))
+    # ... which is also what Trainer does with a step whose rasterizer buffers overflowed (its gradients are invalid) before it
+    # repeats the step: the repeat's hooks must start FRESH reduce-scatters, and its update must come from the repeat's
+    # gradients alone (a collective left in flight made start() skip the parameter and Adam run on the stale shards)
+    opt.zero_grad(set_to_none=True)
+    red.arm(list(ps.values()))
+    sum((ps[k] * coeff(k, rank, 10)).sum() for k in shapes).backward()
+    red.finish()
+    sh.step()
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    for k in shapes:
+        ref_ps[k].grad = sum(coeff(k, r, 10) for r in range(world)) / world
+    ref_opt.step()
+    for k in shapes:
+        assert torch.allclose(ps[k], ref_ps[k], atol=2e-7), ("after the dropped step", k, (ps[k] - ref_ps[k]).abs().max().item())
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))

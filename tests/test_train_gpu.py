@@ -295,11 +295,17 @@ def test_overflowing_step_with_early_plan_changes_nothing_before_its_repeat(monk
     tr.step(3)                                       # and training goes on (the repeat drew its own plan)
 
 
-def test_dense_step_equals_per_render_step_at_cfg3_size():
+@pytest.mark.parametrize("shape", ["configs2", "configs3"])
+def test_dense_step_equals_per_render_step_at_cfg3_size(shape):
     """The same comparison at BASELINE.json configs[2] size with the production model: 1080p, 245 000 anchors x K = 10 in a
     64-frame cube (about 48 000 visible anchors / 480 000 Gaussians per render in the 16-frame slab), the 12 + 3 x 4-level
     hash grids with 8 features (cfg_20240919.yaml), rate term on (deterministic STE mode, rate over every visible
-    anchor): the batched un-compacted step that bench.py times against four reference-style render() calls."""
+    anchor): the batched un-compacted step that bench.py times against four reference-style render() calls.
+    "configs3": BASELINE.json configs[3]'s per-GPU workload, reference cfgs/cfg_20240919.yaml AS IS — 100 000 anchors
+    (init_anchor_num), a 600-frame 1080p video, threshold = .05 (reference arguments/__init__.py:54: a +-48-frame z-slab, i.e.
+    ~14 500 visible anchors / 145 000 Gaussians per render with 6x deeper tile lists per Gaussian footprint than the 16-frame
+    slab), lambda = .004; `bench.py --workload train_step --cfg3` times this shape."""
+    anchors, T, frame_idx, min_p = (245_000, 64, 30, 400_000) if shape == "configs2" else (100_000, 600, 300, 120_000)
     from gsvc_amd.arguments import cfg_20240919
     from gsvc_amd.frame import SyntheticFrameCube
     from gsvc_amd.model import GaussianModel
@@ -308,8 +314,12 @@ def test_dense_step_equals_per_render_step_at_cfg3_size():
     res = []
     for batched in (True, False):
         mp_, opt, pipe = cfg_20240919()
-        cube = SyntheticFrameCube(1080, 1920, 64, seed=1234, device="cuda").materialize()
-        mp_.threshold = 8.0 / cube.scale
+        cube = SyntheticFrameCube(1080, 1920, T, seed=1234, device="cuda")
+        if shape == "configs2":
+            cube.materialize()
+            mp_.threshold = 8.0 / cube.scale
+        else:
+            assert mp_.threshold == 0.05 and opt.lmbda == 0.004 and opt.init_anchor_num == anchors
         opt.full_precision_training_total = opt.quantized_training_total = opt.entropy_constrained_train_total = 0
         opt.ste_entropy_constrained_train_total = 100
         opt.start_stat, opt.pause_densification, opt.iterations = 0, 0, 1
@@ -320,13 +330,13 @@ def test_dense_step_equals_per_render_step_at_cfg3_size():
                            log2_hashmap_size=mp_.log2, log2_hashmap_size_2D=mp_.log2_2D, device="cuda")
         rng = np.random.default_rng(0)
         lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
-        pc.create_from_points(rng.uniform(lim, -lim, (245_000, 3)), spatial_lr_scale=1.0)
+        pc.create_from_points(rng.uniform(lim, -lim, (anchors, 3)), spatial_lr_scale=1.0)
         pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
         pc.training_setup(opt)
         old = G.SAMPLE_RATE
         G.SAMPLE_RATE = 2.0
         try:
-            out = Trainer(pc, cube, opt, pipe, mp_, batched=batched).step(1, frame_idx=30)
+            out = Trainer(pc, cube, opt, pipe, mp_, batched=batched).step(1, frame_idx=frame_idx)
         finally:
             G.SAMPLE_RATE = old
         grads = {n: p.grad.clone() for n, p in pc.named_parameters() if p.grad is not None}
@@ -336,7 +346,7 @@ def test_dense_step_equals_per_render_step_at_cfg3_size():
         del pc, cube, out
         torch.cuda.empty_cache()
     (la, ga, oa, da, ofa, oda, ia, na, pa), (lb, gb, ob, db, ofb, odb, ib, nb, pb) = res
-    assert min(pa) > 400_000, pa                       # un-compacted: K Gaussians per visible anchor
+    assert min(pa) > min_p, pa                         # un-compacted: K Gaussians per visible anchor
     assert na == nb and abs(la - lb) < 1e-5 * max(1.0, abs(lb)), (na, nb, la, lb)
     # 300-entry tile lists: a last-ulp difference in one Gaussian (the two paths run their MLPs over different row counts)
     # moves a pixel by ~1e-5; threshold decisions on the fence (alpha vs 1/255) by up to 1/255 on isolated pixels
@@ -617,6 +627,14 @@ def test_two_rank_step_averages_gradients():
     """One data-parallel step leaves on every rank the mean of the two single-process gradients of the ranks' frame pairs
     (every parameter group; tests/_dp_grad_worker.py).  Both ranks on device 0 through gloo: runs on a 1-GPU box."""
     assert "backend=gloo ranks=2" in _run_dp_grad_worker({"GSVC_DIST_BACKEND": "gloo", "GSVC_SHARE_GPU": "1"})
+
+
+@pytest.mark.gpu
+def test_two_rank_step_averages_gradients_at_configs3_shape():
+    """The same at BASELINE.json configs[3]'s shape — reference cfgs/cfg_20240919.yaml as is: 100 000 anchors, 600 frames of
+    1080p, threshold .05 (a +-48-frame slab) — two frame shards of 300 frames, one pair per rank (gloo, both ranks on device 0)."""
+    assert "backend=gloo ranks=2" in _run_dp_grad_worker({"GSVC_DIST_BACKEND": "gloo", "GSVC_SHARE_GPU": "1",
+                                                          "GSVC_DP_SHAPE": "configs3"})
 
 
 @pytest.mark.gpu
