@@ -347,7 +347,9 @@ def test_dense_step_equals_per_render_step_at_cfg3_size(shape):
         torch.cuda.empty_cache()
     (la, ga, oa, da, ofa, oda, ia, na, pa), (lb, gb, ob, db, ofb, odb, ib, nb, pb) = res
     assert min(pa) > min_p, pa                         # un-compacted: K Gaussians per visible anchor
-    assert na == nb and abs(la - lb) < 1e-5 * max(1.0, abs(lb)), (na, nb, la, lb)
+    # instances per render: the two paths run their MLPs over different row sets (last-ulp differences in a Gaussian's scale), and
+    # a 3-sigma radius on the fence of ceil() moves a tile rectangle: a handful of 1.3 M instances at the +-48-frame slab
+    assert all(abs(a - b) <= 2e-5 * b for a, b in zip(na, nb)) and abs(la - lb) < 1e-5 * max(1.0, abs(lb)), (na, nb, la, lb)
     # 300-entry tile lists: a last-ulp difference in one Gaussian (the two paths run their MLPs over different row counts)
     # moves a pixel by ~1e-5; threshold decisions on the fence (alpha vs 1/255) by up to 1/255 on isolated pixels
     diff = (ia - ib).abs()
