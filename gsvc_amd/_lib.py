@@ -64,6 +64,23 @@ class GridIOC(C.Structure):
     _fields_ = [("feat_level_stride", C.c_int64), ("feat_point_stride", C.c_int64), ("in_stride", C.c_int32), ("in_col", C.c_int32 * 3)]
 
 
+class GeneratorNetC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3", "Wg0", "bg0", "Wg1", "bg1", "Wb0", "bb0", "Wb1", "bb1")] + \
+               [(n, C.c_int32) for n in ("feat_dim", "cond_dim", "hidden_dim", "out_dim", "out_act")]
+
+
+class GeneratorGradsC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3", "Wg0", "bg0", "Wg1", "bg1", "Wb0", "bb0", "Wb1", "bb1")]
+
+
+class DeformNetC(C.Structure):
+    _fields_ = [("W", C.c_void_p * 5), ("b", C.c_void_p * 5)] + [(n, C.c_int32) for n in ("feat_dim", "cond_dim", "hidden_dim", "out_dim")]
+
+
+class DeformGradsC(C.Structure):
+    _fields_ = [("W", C.c_void_p * 5), ("b", C.c_void_p * 5)]
+
+
 class RasterSizesC(C.Structure):
     _fields_ = [("geom_bytes", C.c_uint64), ("binning_bytes", C.c_uint64), ("image_bytes", C.c_uint64)]
 
@@ -136,6 +153,15 @@ _SIGNATURES = {
     "gsvc_linear_wgrad_partial": (C.c_int, [_vp, _vp, C.c_int32, _i64, C.c_int32, C.c_int32, _vp, _i64, C.POINTER(C.c_int32), _vp]),
     "gsvc_linear_wgrad_reduce_many": (C.c_int, [C.POINTER(WgradReduceJobC), C.c_int32, _vp]),
     "gsvc_linear_wgrad_workspace": (_i64, [C.c_int32, C.c_int32]),
+    "gsvc_generator_saved_floats": (_i64, [C.POINTER(GeneratorNetC), _i64]),
+    "gsvc_generator_scratch_floats": (_i64, [C.POINTER(GeneratorNetC), _i64]),
+    "gsvc_generator_forward": (C.c_int, [C.POINTER(GeneratorNetC), _vp, _vp, _i64, _vp, _vp, _vp]),
+    "gsvc_generator_backward": (C.c_int, [C.POINTER(GeneratorNetC), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int32,
+                                          C.POINTER(GeneratorGradsC), _vp]),
+    "gsvc_deform_saved_floats": (_i64, [C.POINTER(DeformNetC), _i64]),
+    "gsvc_deform_scratch_floats": (_i64, [C.POINTER(DeformNetC), _i64]),
+    "gsvc_deform_forward": (C.c_int, [C.POINTER(DeformNetC), _vp, _vp, _i64, _vp, _vp, _vp]),
+    "gsvc_deform_backward": (C.c_int, [C.POINTER(DeformNetC), _vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.POINTER(DeformGradsC), _vp]),
     "gsvc_rate_sample_scratch_floats": (_i64, [_i64]),
     "gsvc_rate_sample_forward": (C.c_int, [C.POINTER(RateSampleC), _vp, _vp, _vp]),
     "gsvc_rate_sample_backward": (C.c_int, [C.POINTER(RateSampleC), _vp, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

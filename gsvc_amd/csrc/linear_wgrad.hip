@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad(const float 
                                                                    long long M, int N, int K, int BN, int BK, int RS)
 {
     extern __shared__ float sm[];      // [BN*BK][64][64]
-    __shared__ float sdb[LIN_NT_MAX * 16];
+    __shared__ float sdb[WG_MAX_WAVES][LIN_NT_MAX * 16];      // per row split: summed in a fixed order below (no float atomics)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pairs = BN * BK;
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad(const float 
     const long long RB = (M + 15) >> 4;
     const long long workers = (long long)gridDim.x * RS;
     long long rb = (long long)rs * gridDim.x + blockIdx.x;          // chunks dealt row-split-major (see k_linear_ws)
-    if (tid < LIN_NT_MAX * 16) sdb[tid] = 0.f;
+    for (int i = tid; i < WG_MAX_WAVES * LIN_NT_MAX * 16; i += blockDim.x) (&sdb[0][0])[i] = 0.f;
     __syncthreads();
 
     v4f acc[4][4];
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad(const float 
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
             const int n = 64 * bn + 16 * VG * (tn / VG) + VG * j + (tn % VG);
-            if (mq == 0 && n < N) atomicAdd(sdb + n, v);
+            if (mq == 0 && n < N) sdb[rs][n] = v;      // one wave per (row split, column)
         }
     }
     // sum the row splits of each 64 x 64 block in LDS (one wave per block and round), then write this workgroup's
@@ -140,7 +140,11 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad(const float 
         if (n < N && k < K) out[(size_t)n * K + k] = sm[i];
     }
     if (want_db)
-        for (int n = tid; n < N; n += blockDim.x) out[(size_t)N * K + n] = sdb[n];
+        for (int n = tid; n < N; n += blockDim.x) {
+            float v = sdb[0][n];
+            for (int r = 1; r < RS; r++) v += sdb[r][n];
+            out[(size_t)N * K + n] = v;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -226,7 +230,7 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const floa
                                                                      int BN, int BK, int RS)
 {
     extern __shared__ float sm[];      // [BN*BK][64][64]
-    __shared__ float sdb[LIN_NT_MAX * 16];
+    __shared__ float sdb[WG_MAX_WAVES][LIN_NT_MAX * 16];      // per row split: summed in a fixed order below (no float atomics)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pairs = BN * BK;
@@ -248,7 +252,7 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const floa
     const int n0 = 16 * tn0, k0 = 16 * tk0;
     const long long workers = (long long)gridDim.x * RS;
     const long long rb = (long long)rs * gridDim.x + blockIdx.x;    // chunks dealt row-split-major (see k_linear_ws)
-    if (tid < LIN_NT_MAX * 16) sdb[tid] = 0.f;
+    for (int i = tid; i < WG_MAX_WAVES * LIN_NT_MAX * 16; i += blockDim.x) (&sdb[0][0])[i] = 0.f;
     __syncthreads();
 
     v4f acc[4][4];
@@ -274,7 +278,7 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const floa
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
             const int n = n0 + TN * j + tn;
-            if (tn < TN && mq == 0 && n < N) atomicAdd(sdb + n, v);
+            if (tn < TN && mq == 0 && n < N) sdb[rs][n] = v;      // one wave per (row split, column)
         }
     }
     // sum the row splits of each block in LDS (one wave per block and round), then this workgroup's partial dW (and db) goes
@@ -307,7 +311,11 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const floa
         if (nl < 16 * c && kl < 16 * e && n < N && k < K) out[(size_t)n * K + k] = sm[i];
     }
     if (want_db)
-        for (int n = tid; n < N; n += blockDim.x) out[(size_t)N * K + n] = sdb[n];
+        for (int n = tid; n < N; n += blockDim.x) {
+            float v = sdb[0][n];
+            for (int r = 1; r < RS; r++) v += sdb[r][n];
+            out[(size_t)N * K + n] = v;
+        }
 }
 
 // dst[i] = sum over the workgroup slots of part[slot][i]: 64 outputs per workgroup, the slots dealt to its 16 waves (256 slots:

@@ -1,0 +1,1075 @@
+// gsvc_amd/csrc/mlp_chain.hip — the generator and deformation MLPs of GSVC as whole-network chain kernels, gfx950.
+//
+// Reference: scene/gaussian_model.py:150-196 (FiLM, GeneratorNet), :468-489 (mlp_deform), evaluated per anchor row at
+// ortho_gaussian_renderer/guassian.py:225-273.  Layer by layer (csrc/linear_ws.h) every activation of these networks crosses
+// HBM three times (forward, dX, dW) in 64-byte pieces and every layer is its own launch.  Here a wave keeps a 16-row block's
+// activations in REGISTERS from the network's input to its output:
+//
+//   * MFMAs (v_mfma_f32_16x16x4_f32, exact fp32) are issued with the WEIGHT fragment as the A operand, so lane (fr, kq) of the
+//     accumulator tile t holds Y[row fr][16 t + 4 kq .. + 3] — which is exactly the B fragment (k-group t) the next layer's
+//     MFMAs want.  Bias, GELU / ReLU / FiLM / tanh / sigmoid and their derivatives are applied to the accumulators in place;
+//     nothing is shuffled between layers.
+//   * the weights of a kernel's layers sit zero-padded in LDS for the life of a persistent workgroup (one per CU), row stride
+//     = 16 ceil(K / 16) + 8 floats (== 8 mod 16: the ds_read_b128 of a B fragment is conflict-free).  A generator's seven
+//     matrices do not fit 160 KiB at once, so it is two kernels each way (FiLM conditioning nets | trunk); mlp_deform likewise
+//     (layers 1-2 | 3-5).  gamma / beta and the deformation's second activation are the only tensors that cross HBM between
+//     kernels — and the backward needs them anyway.
+//   * the forward leaves behind exactly what the backward and the weight gradients read (pre-activations, activations); the
+//     backward chain writes the gradient operand of every layer's dW = G^T X, which the row-split kernels of linear_wgrad.hip
+//     then form (one batched slot reduce per network).
+//   * the last k-group of a layer issues only the MFMA steps that carry a valid k (K = 66, 50: 2 of 4).
+//
+// Instantiated for the production widths (feat 50, condition 66, hidden 100, K = 10 offsets: outputs 10 / 30 / 70 / 30);
+// other widths return GSVC_E_UNSUPPORTED and the caller keeps the layer-by-layer path.
+#include <cstdlib>
+#include <mutex>
+#include <set>
+
+#include "linear_ws.h"
+
+namespace gsvc {
+namespace {
+
+constexpr int cl_kg(int K) { return (K + 15) / 16; }
+constexpr int cl_ld(int K) { return cl_kg(K) * 16 + 8; }
+constexpr int cl_steps(int K) { return K % 16 == 0 ? 4 : (K % 16 >= 4 ? 4 : K % 16); }      // MFMA steps of the last k-group
+constexpr int cl_sv(int N) { return N % 4 == 0 ? 4 : (N % 2 == 0 ? 2 : 1); }
+
+struct Lane {
+    int tid, lane, wave, fr, kq;
+    __device__ Lane()
+    {
+        tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        fr = lane & 15;
+        kq = lane >> 4;
+    }
+};
+
+// ---- LDS images ---------------------------------------------------------------------------------------------------------
+// Copies the [n_cnt][k_cnt] block of a row-major matrix (row stride ldw, first column k_lo) into an image with row stride LD:
+// plain:       img[n][col_off + k]      (forward: contraction over k, output n)
+// transposed:  img[col_off + k][n]      (dX = G W: contraction over n, output k)
+// Loads are 8-byte pieces along W's rows (every width here is even, every base 16-byte aligned), a batch of them in flight
+// per thread before the first LDS write: one memory round trip per batch (an element-by-element loop made ~60 dependent ones:
+// 30 us of prologue per launch).
+template <bool TR>
+__device__ __forceinline__ void stage_block(const float *__restrict__ W, int ldw, int n_cnt, int k_lo, int k_cnt, float *img, int LD,
+                                            int col_off, int tid, int threads)
+{
+    constexpr int BATCH = 8;
+    const int kp = k_cnt >> 1, total = n_cnt * kp;
+    for (int base = tid; base < total; base += threads * BATCH) {
+        float2 v[BATCH];
+        int dst[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            const int i = base + u * threads;
+            dst[u] = -1;
+            if (i < total) {
+                const int n = i / kp, k = 2 * (i - n * kp);
+                v[u] = *reinterpret_cast<const float2 *>(W + (size_t)n * ldw + k_lo + k);
+                dst[u] = TR ? (col_off + k) * LD + n : n * LD + col_off + k;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            if (dst[u] < 0) continue;
+            if (TR) {
+                img[dst[u]] = v[u].x;
+                img[dst[u] + LD] = v[u].y;
+            } else {
+                *reinterpret_cast<float2 *>(img + dst[u]) = v[u];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_bias(const float *__restrict__ b, int n, float *sb, int padded, int tid, int threads)
+{
+    for (int i = tid; i < padded; i += threads) sb[i] = (b && i < n) ? b[i] : 0.f;
+}
+
+__device__ __forceinline__ void zero_lds(float *lds, int floats, int tid, int threads)
+{
+    float4 *p = reinterpret_cast<float4 *>(lds);      // every image size here is a multiple of 4 floats
+    for (int i = tid; i < floats / 4; i += threads) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---- fragments ----------------------------------------------------------------------------------------------------------
+// a[g] of lane (fr, kq) = X[row fr][16 g + 4 kq .. + 3] of the 16-row block rb (zeros past M and past K)
+template <int K>
+__device__ __forceinline__ void load_frags(v4f (&a)[cl_kg(K)], const float *X, long long rb, long long RB, long long M, const Lane &L)
+{
+    constexpr int KG = cl_kg(K), VEC = cl_sv(K);
+    const __amdgpu_buffer_rsrc_t rx = ws_block_rsrc(X, rb, RB, M, K);
+    const int voff = L.fr * K * 4 + 16 * L.kq;
+#pragma unroll
+    for (int g = 0; g < KG; g++) {
+        const float4 v = ws_load_group<VEC, KG>(rx, voff, L.kq, K, g);
+        a[g] = (v4f){v.x, v.y, v.z, v.w};
+    }
+}
+
+// tile-layout access to a row-major [M][N] matrix: lane (fr, kq), tile t <-> row fr, columns 16 t + 4 kq .. + 3
+template <int N>
+struct Tiles {
+    __amdgpu_buffer_rsrc_t r;
+    int yoff, c00;
+    __device__ __forceinline__ Tiles(const float *base, long long rb, long long RB, long long M, const Lane &L)
+    {
+        r = ws_block_rsrc(base, rb, RB, M, N);
+        c00 = 4 * L.kq;
+        yoff = (L.fr * N + c00) * 4;
+    }
+    __device__ __forceinline__ v4f load(int t) const
+    {
+        float v[4];
+        ws_load4(r, yoff + 64 * t, c00 + 16 * t, N, cl_sv(N), v);
+        return (v4f){v[0], v[1], v[2], v[3]};
+    }
+    __device__ __forceinline__ void store(int t, v4f x) const
+    {
+        const float v[4] = {x[0], x[1], x[2], x[3]};
+        ws_store4(r, yoff + 64 * t, c00 + 16 * t, N, cl_sv(N), v);
+    }
+};
+
+// acc[t] += sum_k W_img[16 t + fr'][k] X[row][k]: K = contraction length (a has cl_kg(K) groups), NT output tiles.
+// wimg: image with row stride LD; the lane's view starts at row fr, column 4 kq.
+template <int K, int NT, int LD>
+__device__ __forceinline__ void chain_mm(v4f (&acc)[NT], const v4f (&a)[cl_kg(K)], const float *wimg, const Lane &L)
+{
+    constexpr int KG = cl_kg(K), LAST = cl_steps(K);
+    const float *wb = wimg + L.fr * LD + 4 * L.kq;
+#pragma unroll
+    for (int g = 0; g < KG; g++) {
+        const int steps = g == KG - 1 ? LAST : 4;
+#pragma unroll
+        for (int t0 = 0; t0 < NT; t0 += 4) {
+            v4f b[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++)
+                if (t0 + tt < NT) {
+                    const float4 v = *reinterpret_cast<const float4 *>(wb + (t0 + tt) * 16 * LD + 16 * g);
+                    b[tt] = (v4f){v.x, v.y, v.z, v.w};
+                }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i >= steps) continue;
+#pragma unroll
+                for (int tt = 0; tt < 4; tt++)
+                    if (t0 + tt < NT) acc[t0 + tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[tt][i], a[g][i], acc[t0 + tt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the groups in order: hoisting every B read blows the VGPR budget
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void init_bias(v4f (&acc)[NT], const float *sbias, const Lane &L)
+{
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const float4 v = *reinterpret_cast<const float4 *>(sbias + 16 * t + 4 * L.kq);
+        acc[t] = (v4f){v.x, v.y, v.z, v.w};
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void init_zero(v4f (&acc)[NT])
+{
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+}
+
+// GELU (exact, erf form: torch.nn.GELU()) with the normal cdf from Abramowitz & Stegun 7.1.26 evaluated on the tail side:
+//   Q(|x|) = 1/2 erfc(|x| / sqrt 2) = 1/2 p(t) exp(-x^2 / 2),  t = 1 / (1 + 0.3275911 |x| / sqrt 2),  |error| <= 0.75e-7,
+// cdf(x) = x >= 0 ? 1 - Q : Q (no cancellation in the negative tail).  One v_rcp_f32 + one v_exp_f32 + 8 FMA-class
+// instructions per value, and GELU'(x) = cdf(x) + x pdf(x) reuses the exponential; libm's erff is ~50 instructions, which made
+// the activations of a 16-row block cost as many issue cycles as its MFMAs.
+struct GeluParts {
+    float cdf, e;      // e = exp(-x^2 / 2)
+};
+__device__ __forceinline__ GeluParts gelu_parts(float x)
+{
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-0.5f * 1.44269504088896340736f * ax * ax);
+    const float q = 0.5f * p * e;
+    return GeluParts{x >= 0.f ? 1.0f - q : q, e};
+}
+__device__ __forceinline__ float c_gelu(float x) { return x * gelu_parts(x).cdf; }
+__device__ __forceinline__ float c_gelu_grad(float x)
+{
+    const GeluParts g = gelu_parts(x);
+    return fmaf(x * 0.39894228040143267794f, g.e, g.cdf);
+}
+__device__ __forceinline__ v4f v_gelu(v4f z) { return (v4f){c_gelu(z[0]), c_gelu(z[1]), c_gelu(z[2]), c_gelu(z[3])}; }
+__device__ __forceinline__ v4f v_gelu_grad(v4f z) { return (v4f){c_gelu_grad(z[0]), c_gelu_grad(z[1]), c_gelu_grad(z[2]), c_gelu_grad(z[3])}; }
+__device__ __forceinline__ v4f v_relu(v4f z) { return (v4f){fmaxf(z[0], 0.f), fmaxf(z[1], 0.f), fmaxf(z[2], 0.f), fmaxf(z[3], 0.f)}; }
+
+template <int WAVES>
+__device__ __forceinline__ void row_blocks(long long M, const Lane &L, long long &rb, long long &RB, long long &stride)
+{
+    RB = (M + 15) >> 4;
+    stride = (long long)gridDim.x * WAVES;
+    rb = (long long)L.wave * gridDim.x + blockIdx.x;      // wave-major deal (linear_ws.h: even rounds on every SIMD)
+}
+
+// ======================================================================================================= FiLM nets
+// gamma = Wg1 relu(Wg0 c + bg0) + bg1, beta likewise (reference scene/gaussian_model.py:150-166); cg / cb = the hidden ReLU
+// outputs (the backward's masks and the second layers' dW operands).
+struct FilmW {
+    const float *Wg0, *bg0, *Wg1, *bg1, *Wb0, *bb0, *Wb1, *bb1;
+};
+
+template <int COND, int HID>
+struct FilmFwdLds {
+    static constexpr int LD = cl_ld(COND), NT0 = cl_kg(COND), NT1 = cl_kg(HID);
+    static constexpr int W0 = NT0 * 16 * LD, W1 = NT1 * 16 * LD;
+    static constexpr int o_g0 = 0, o_g1 = W0, o_b0 = W0 + W1, o_b1 = 2 * W0 + W1, o_bias = 2 * W0 + 2 * W1;
+    static constexpr int FLOATS = o_bias + 2 * NT0 * 16 + 2 * NT1 * 16;
+};
+
+template <int COND, int HID, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_film_nets_fwd(const float *__restrict__ cond, FilmW w, float *__restrict__ cg,
+                                                                 float *__restrict__ cb, float *__restrict__ gamma,
+                                                                 float *__restrict__ beta, long long M)
+{
+    extern __shared__ float lds[];
+    using S = FilmFwdLds<COND, HID>;
+    const Lane L;
+    zero_lds(lds, S::FLOATS, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    stage_block<false>(w.Wg0, COND, COND, 0, COND, lds + S::o_g0, S::LD, 0, L.tid, CHAIN_THREADS);
+    stage_block<false>(w.Wg1, COND, HID, 0, COND, lds + S::o_g1, S::LD, 0, L.tid, CHAIN_THREADS);
+    stage_block<false>(w.Wb0, COND, COND, 0, COND, lds + S::o_b0, S::LD, 0, L.tid, CHAIN_THREADS);
+    stage_block<false>(w.Wb1, COND, HID, 0, COND, lds + S::o_b1, S::LD, 0, L.tid, CHAIN_THREADS);
+    float *sb_g0 = lds + S::o_bias, *sb_g1 = sb_g0 + S::NT0 * 16, *sb_b0 = sb_g1 + S::NT1 * 16, *sb_b1 = sb_b0 + S::NT0 * 16;
+    stage_bias(w.bg0, COND, sb_g0, S::NT0 * 16, L.tid, CHAIN_THREADS);
+    stage_bias(w.bg1, HID, sb_g1, S::NT1 * 16, L.tid, CHAIN_THREADS);
+    stage_bias(w.bb0, COND, sb_b0, S::NT0 * 16, L.tid, CHAIN_THREADS);
+    stage_bias(w.bb1, HID, sb_b1, S::NT1 * 16, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    long long rb, RB, stride;
+    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    // memory and MFMA phases of a wave overlap: the next block's condition rows are requested as soon as this block's last use
+    // of them has been issued, and nothing ever waits for a store
+    v4f c[S::NT0];
+    load_frags<COND>(c, cond, rb, RB, M, L);
+    for (; rb < RB; rb += stride) {
+#pragma unroll
+        for (int net = 0; net < 2; net++) {
+            const float *w0 = lds + (net ? S::o_b0 : S::o_g0), *w1 = lds + (net ? S::o_b1 : S::o_g1);
+            v4f hid[S::NT0];
+            init_bias(hid, net ? sb_b0 : sb_g0, L);
+            chain_mm<COND, S::NT0, S::LD>(hid, c, w0, L);
+            if (net == 1) {
+                load_frags<COND>(c, cond, rb + stride, RB, M, L);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const Tiles<COND> th(net ? cb : cg, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NT0; t++) {
+                hid[t] = v_relu(hid[t]);
+                th.store(t, hid[t]);
+            }
+            v4f out[S::NT1];
+            init_bias(out, net ? sb_b1 : sb_g1, L);
+            chain_mm<COND, S::NT1, S::LD>(out, hid, w1, L);
+            const Tiles<HID> to(net ? beta : gamma, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NT1; t++) to.store(t, out[t]);
+        }
+    }
+}
+
+// backward through the second layers and the ReLUs: gcg = (ggamma Wg1) * [cg > 0], gcb likewise (the first layers' dW
+// operands; the condition itself — frame time and z embedding of detached anchors — needs no gradient)
+template <int COND, int HID, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_film_nets_bwd(const float *__restrict__ ggamma, const float *__restrict__ gbeta,
+                                                                 const float *__restrict__ cg, const float *__restrict__ cb,
+                                                                 const float *__restrict__ Wg1, const float *__restrict__ Wb1,
+                                                                 float *__restrict__ gcg, float *__restrict__ gcb, long long M)
+{
+    extern __shared__ float lds[];
+    constexpr int LD = cl_ld(HID), NT = cl_kg(COND), IMG = NT * 16 * LD;
+    const Lane L;
+    zero_lds(lds, 2 * IMG, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    stage_block<true>(Wg1, COND, HID, 0, COND, lds, LD, 0, L.tid, CHAIN_THREADS);
+    stage_block<true>(Wb1, COND, HID, 0, COND, lds + IMG, LD, 0, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    long long rb, RB, stride;
+    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    v4f g[2][cl_kg(HID)];
+    load_frags<HID>(g[0], ggamma, rb, RB, M, L);
+    load_frags<HID>(g[1], gbeta, rb, RB, M, L);
+    for (; rb < RB; rb += stride) {
+        v4f m[2][NT];      // the ReLU outputs (masks) of this block: requested before the products that precede their use
+        {
+            const Tiles<COND> t0(cg, rb, RB, M, L), t1(cb, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < NT; t++) { m[0][t] = t0.load(t); m[1][t] = t1.load(t); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int net = 0; net < 2; net++) {
+            v4f acc[NT];
+            init_zero(acc);
+            chain_mm<HID, NT, LD>(acc, g[net], lds + net * IMG, L);
+            load_frags<HID>(g[net], net ? gbeta : ggamma, rb + stride, RB, M, L);
+            __builtin_amdgcn_sched_barrier(0);
+            const Tiles<COND> to(net ? gcb : gcg, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                v4f o;
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = m[net][t][i] > 0.f ? acc[t][i] : 0.f;
+                to.store(t, o);
+            }
+        }
+    }
+}
+
+// ======================================================================================================= generator trunk
+// y = act(W3 (gamma * (W2 gelu(W1 f + b1) + b2) + beta) + b3)   (reference scene/gaussian_model.py:168-196)
+struct TrunkW {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+};
+
+enum { CH_ACT_NONE = 0, CH_ACT_TANH = 1, CH_ACT_SIGMOID = 2 };
+
+template <int FEAT, int HID, int OUT>
+struct TrunkFwdLds {
+    static constexpr int LD1 = cl_ld(FEAT), LD2 = cl_ld(HID), NTH = cl_kg(HID), NTO = cl_kg(OUT);
+    static constexpr int o_w1 = 0, o_w2 = NTH * 16 * LD1, o_w3 = o_w2 + NTH * 16 * LD2, o_bias = o_w3 + NTO * 16 * LD2;
+    static constexpr int FLOATS = o_bias + 2 * NTH * 16 + NTO * 16;
+};
+
+template <int FEAT, int HID, int OUT, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_fwd(const float *__restrict__ feat, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, TrunkW w, int act,
+                                                             float *__restrict__ z1, float *__restrict__ a1, float *__restrict__ h,
+                                                             float *__restrict__ x3, float *__restrict__ y, long long M)
+{
+    extern __shared__ float lds[];
+    using S = TrunkFwdLds<FEAT, HID, OUT>;
+    const Lane L;
+    zero_lds(lds, S::FLOATS, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    stage_block<false>(w.W1, FEAT, HID, 0, FEAT, lds + S::o_w1, S::LD1, 0, L.tid, CHAIN_THREADS);
+    stage_block<false>(w.W2, HID, HID, 0, HID, lds + S::o_w2, S::LD2, 0, L.tid, CHAIN_THREADS);
+    stage_block<false>(w.W3, HID, OUT, 0, HID, lds + S::o_w3, S::LD2, 0, L.tid, CHAIN_THREADS);
+    float *sb1 = lds + S::o_bias, *sb2 = sb1 + S::NTH * 16, *sb3 = sb2 + S::NTH * 16;
+    stage_bias(w.b1, HID, sb1, S::NTH * 16, L.tid, CHAIN_THREADS);
+    stage_bias(w.b2, HID, sb2, S::NTH * 16, L.tid, CHAIN_THREADS);
+    stage_bias(w.b3, OUT, sb3, S::NTO * 16, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    long long rb, RB, stride;
+    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    v4f f[cl_kg(FEAT)];
+    load_frags<FEAT>(f, feat, rb, RB, M, L);
+    for (; rb < RB; rb += stride) {
+        // this block's gamma / beta travel while its first two products run; the next block's feature rows are requested as
+        // soon as the first product has consumed this block's; no wait ever names a store
+        v4f gam[S::NTH], bet[S::NTH];
+        {
+            const Tiles<HID> tg(gamma, rb, RB, M, L), tb(beta, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) { gam[t] = tg.load(t); bet[t] = tb.load(t); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        v4f u[S::NTH];
+        init_bias(u, sb1, L);
+        chain_mm<FEAT, S::NTH, S::LD1>(u, f, lds + S::o_w1, L);
+        load_frags<FEAT>(f, feat, rb + stride, RB, M, L);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const Tiles<HID> tz(z1, rb, RB, M, L), ta(a1, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) {
+                tz.store(t, u[t]);
+                u[t] = v_gelu(u[t]);
+                ta.store(t, u[t]);
+            }
+        }
+        v4f v[S::NTH];
+        init_bias(v, sb2, L);
+        chain_mm<HID, S::NTH, S::LD2>(v, u, lds + S::o_w2, L);
+        {
+            const Tiles<HID> th(h, rb, RB, M, L), tx(x3, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) {
+                th.store(t, v[t]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[t][i] = fmaf(gam[t][i], v[t][i], bet[t][i]);
+                tx.store(t, v[t]);
+            }
+        }
+        v4f o[S::NTO];
+        init_bias(o, sb3, L);
+        chain_mm<HID, S::NTO, S::LD2>(o, v, lds + S::o_w3, L);
+        const Tiles<OUT> ty(y, rb, RB, M, L);
+#pragma unroll
+        for (int t = 0; t < S::NTO; t++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (act == CH_ACT_TANH) o[t][i] = tanhf(o[t][i]);
+                else if (act == CH_ACT_SIGMOID) o[t][i] = 1.0f / (1.0f + expf(-o[t][i]));
+            }
+            ty.store(t, o[t]);
+        }
+    }
+}
+
+// go = gy * act'(y);  gx3 = go W3 (= d beta);  d gamma = gx3 * h;  gh = gx3 * gamma;  gz1 = (gh W2) * gelu'(z1);
+// gfeat (+)= gz1 W1.  go, gx3, d gamma, gh, gz1 are written out: they are the G operands of the seven weight gradients.
+template <int FEAT, int HID, int OUT>
+struct TrunkBwdLds {
+    static constexpr int LD3 = cl_ld(OUT), LDH = cl_ld(HID), NTH = cl_kg(HID), NTF = cl_kg(FEAT);
+    static constexpr int o_w3 = 0, o_w2 = NTH * 16 * LD3, o_w1 = o_w2 + NTH * 16 * LDH;
+    static constexpr int FLOATS = o_w1 + NTF * 16 * LDH;
+};
+
+template <int FEAT, int HID, int OUT, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_bwd(const float *__restrict__ gy, const float *__restrict__ y, int act,
+                                                             const float *__restrict__ h, const float *__restrict__ gamma,
+                                                             const float *__restrict__ z1, TrunkW w, float *__restrict__ go,
+                                                             float *__restrict__ gbeta, float *__restrict__ ggamma,
+                                                             float *__restrict__ gh, float *__restrict__ gz1,
+                                                             float *__restrict__ gfeat, int accumulate, long long M)
+{
+    extern __shared__ float lds[];
+    using S = TrunkBwdLds<FEAT, HID, OUT>;
+    const Lane L;
+    zero_lds(lds, S::FLOATS, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    stage_block<true>(w.W3, HID, OUT, 0, HID, lds + S::o_w3, S::LD3, 0, L.tid, CHAIN_THREADS);
+    stage_block<true>(w.W2, HID, HID, 0, HID, lds + S::o_w2, S::LDH, 0, L.tid, CHAIN_THREADS);
+    stage_block<true>(w.W1, FEAT, HID, 0, FEAT, lds + S::o_w1, S::LDH, 0, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    long long rb, RB, stride;
+    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    constexpr int NTO = cl_kg(OUT);
+    v4f g0[NTO], yv[NTO];
+    {
+        const Tiles<OUT> tg(gy, rb, RB, M, L), ty(y, rb, RB, M, L);
+#pragma unroll
+        for (int t = 0; t < NTO; t++) { g0[t] = tg.load(t); yv[t] = ty.load(t); }
+    }
+    for (; rb < RB; rb += stride) {
+        // everything this block reads later (h, gamma, z1, the running feature gradient) is requested up front and lands while
+        // the products run; the next block's (gy, y) are requested once this block's have been consumed
+        v4f hh[S::NTH], gg[S::NTH], zz[S::NTH], pf[S::NTF];
+        {
+            const Tiles<HID> th(h, rb, RB, M, L), tg(gamma, rb, RB, M, L), tz(z1, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) { hh[t] = th.load(t); gg[t] = tg.load(t); zz[t] = tz.load(t); }
+            const Tiles<FEAT> tf(gfeat, accumulate ? rb : RB, RB, M, L);      // empty descriptor (zeros) when not accumulating
+#pragma unroll
+            for (int t = 0; t < S::NTF; t++) pf[t] = tf.load(t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        v4f go_[NTO];
+        {
+            const Tiles<OUT> to(go, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < NTO; t++) {
+                go_[t] = g0[t];
+                if (act != CH_ACT_NONE) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        go_[t][i] = act == CH_ACT_TANH ? g0[t][i] * (1.0f - yv[t][i] * yv[t][i]) : g0[t][i] * ((1.0f - yv[t][i]) * yv[t][i]);
+                }
+                to.store(t, go_[t]);
+            }
+            const Tiles<OUT> tg(gy, rb + stride, RB, M, L), ty(y, rb + stride, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < NTO; t++) { g0[t] = tg.load(t); yv[t] = ty.load(t); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        v4f gx[S::NTH];
+        init_zero(gx);
+        chain_mm<OUT, S::NTH, S::LD3>(gx, go_, lds + S::o_w3, L);
+        {
+            const Tiles<HID> ob(gbeta, rb, RB, M, L), og(ggamma, rb, RB, M, L), oh(gh, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) {
+                ob.store(t, gx[t]);
+                v4f dg;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    dg[i] = gx[t][i] * hh[t][i];
+                    gx[t][i] = gx[t][i] * gg[t][i];
+                }
+                og.store(t, dg);
+                oh.store(t, gx[t]);
+            }
+        }
+        v4f ga[S::NTH];
+        init_zero(ga);
+        chain_mm<HID, S::NTH, S::LDH>(ga, gx, lds + S::o_w2, L);
+        {
+            const Tiles<HID> oz(gz1, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) {
+                const v4f d = v_gelu_grad(zz[t]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) ga[t][i] *= d[i];
+                oz.store(t, ga[t]);
+            }
+        }
+        chain_mm<HID, S::NTF, S::LDH>(pf, ga, lds + S::o_w1, L);      // on top of the running sum (or zeros)
+        const Tiles<FEAT> of(gfeat, rb, RB, M, L);
+#pragma unroll
+        for (int t = 0; t < S::NTF; t++) of.store(t, pf[t]);
+    }
+}
+
+// ======================================================================================================= mlp_deform
+// x = [feat | cond] -> L1 GELU -> L2 GELU | -> L3 GELU -> L4 GELU -> L5   (reference scene/gaussian_model.py:468-489).
+// The two inputs stay two matrices: the image of W1 keeps the feature columns in k-groups 0 .. and the condition columns from
+// the next 16-aligned column on (no concatenated [M, 116] copy, no split in the backward).
+struct DeformW {
+    const float *W[5], *b[5];
+};
+
+template <int FEAT, int COND, int HID>
+struct DeformALds {
+    static constexpr int KF = cl_kg(FEAT) * 16, KIN = KF + cl_kg(COND) * 16;      // padded input width of the image
+    static constexpr int LD1 = KIN + 8, LD2 = cl_ld(HID), NTH = cl_kg(HID);
+    static constexpr int o_w1 = 0, o_w2 = NTH * 16 * LD1, o_bias = o_w2 + NTH * 16 * LD2, FLOATS = o_bias + 2 * NTH * 16;
+};
+
+template <int FEAT, int COND, int HID, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_deform_a_fwd(const float *__restrict__ feat, const float *__restrict__ cond, DeformW w,
+                                                                float *__restrict__ z1, float *__restrict__ a1, float *__restrict__ z2,
+                                                                float *__restrict__ a2, long long M)
+{
+    extern __shared__ float lds[];
+    using S = DeformALds<FEAT, COND, HID>;
+    const Lane L;
+    zero_lds(lds, S::FLOATS, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    stage_block<false>(w.W[0], FEAT + COND, HID, 0, FEAT, lds + S::o_w1, S::LD1, 0, L.tid, CHAIN_THREADS);
+    stage_block<false>(w.W[0], FEAT + COND, HID, FEAT, COND, lds + S::o_w1, S::LD1, S::KF, L.tid, CHAIN_THREADS);
+    stage_block<false>(w.W[1], HID, HID, 0, HID, lds + S::o_w2, S::LD2, 0, L.tid, CHAIN_THREADS);
+    float *sb1 = lds + S::o_bias, *sb2 = sb1 + S::NTH * 16;
+    stage_bias(w.b[0], HID, sb1, S::NTH * 16, L.tid, CHAIN_THREADS);
+    stage_bias(w.b[1], HID, sb2, S::NTH * 16, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    long long rb, RB, stride;
+    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    v4f f[cl_kg(FEAT)], c[cl_kg(COND)];
+    load_frags<FEAT>(f, feat, rb, RB, M, L);
+    load_frags<COND>(c, cond, rb, RB, M, L);
+    for (; rb < RB; rb += stride) {
+        v4f u[S::NTH];
+        init_bias(u, sb1, L);
+        chain_mm<FEAT, S::NTH, S::LD1>(u, f, lds + S::o_w1, L);
+        chain_mm<COND, S::NTH, S::LD1>(u, c, lds + S::o_w1 + S::KF, L);
+        load_frags<FEAT>(f, feat, rb + stride, RB, M, L);      // the next block's rows travel during the rest of this one
+        load_frags<COND>(c, cond, rb + stride, RB, M, L);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const Tiles<HID> tz(z1, rb, RB, M, L), ta(a1, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) {
+                tz.store(t, u[t]);
+                u[t] = v_gelu(u[t]);
+                ta.store(t, u[t]);
+            }
+        }
+        v4f v[S::NTH];
+        init_bias(v, sb2, L);
+        chain_mm<HID, S::NTH, S::LD2>(v, u, lds + S::o_w2, L);
+        const Tiles<HID> tz(z2, rb, RB, M, L), ta(a2, rb, RB, M, L);
+#pragma unroll
+        for (int t = 0; t < S::NTH; t++) {
+            tz.store(t, v[t]);
+            ta.store(t, v_gelu(v[t]));
+        }
+    }
+}
+
+template <int HID, int OUT>
+struct DeformBLds {
+    static constexpr int LD = cl_ld(HID), NTH = cl_kg(HID), NTO = cl_kg(OUT);
+    static constexpr int o_w3 = 0, o_w4 = NTH * 16 * LD, o_w5 = 2 * NTH * 16 * LD, o_bias = o_w5 + NTO * 16 * LD;
+    static constexpr int FLOATS = o_bias + 2 * NTH * 16 + NTO * 16;
+};
+
+template <int HID, int OUT, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_deform_b_fwd(const float *__restrict__ a2, DeformW w, float *__restrict__ z3,
+                                                                float *__restrict__ a3, float *__restrict__ z4, float *__restrict__ a4,
+                                                                float *__restrict__ y, long long M)
+{
+    extern __shared__ float lds[];
+    using S = DeformBLds<HID, OUT>;
+    const Lane L;
+    zero_lds(lds, S::FLOATS, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    stage_block<false>(w.W[2], HID, HID, 0, HID, lds + S::o_w3, S::LD, 0, L.tid, CHAIN_THREADS);
+    stage_block<false>(w.W[3], HID, HID, 0, HID, lds + S::o_w4, S::LD, 0, L.tid, CHAIN_THREADS);
+    stage_block<false>(w.W[4], HID, OUT, 0, HID, lds + S::o_w5, S::LD, 0, L.tid, CHAIN_THREADS);
+    float *sb3 = lds + S::o_bias, *sb4 = sb3 + S::NTH * 16, *sb5 = sb4 + S::NTH * 16;
+    stage_bias(w.b[2], HID, sb3, S::NTH * 16, L.tid, CHAIN_THREADS);
+    stage_bias(w.b[3], HID, sb4, S::NTH * 16, L.tid, CHAIN_THREADS);
+    stage_bias(w.b[4], OUT, sb5, S::NTO * 16, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    long long rb, RB, stride;
+    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    v4f x[S::NTH];
+    load_frags<HID>(x, a2, rb, RB, M, L);
+    for (; rb < RB; rb += stride) {
+        v4f u[S::NTH];
+        init_bias(u, sb3, L);
+        chain_mm<HID, S::NTH, S::LD>(u, x, lds + S::o_w3, L);
+        load_frags<HID>(x, a2, rb + stride, RB, M, L);      // the next block's rows travel during the rest of this one
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const Tiles<HID> tz(z3, rb, RB, M, L), ta(a3, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) {
+                tz.store(t, u[t]);
+                u[t] = v_gelu(u[t]);
+                ta.store(t, u[t]);
+            }
+        }
+        v4f v[S::NTH];
+        init_bias(v, sb4, L);
+        chain_mm<HID, S::NTH, S::LD>(v, u, lds + S::o_w4, L);
+        {
+            const Tiles<HID> tz(z4, rb, RB, M, L), ta(a4, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) {
+                tz.store(t, v[t]);
+                v[t] = v_gelu(v[t]);
+                ta.store(t, v[t]);
+            }
+        }
+        v4f o[S::NTO];
+        init_bias(o, sb5, L);
+        chain_mm<HID, S::NTO, S::LD>(o, v, lds + S::o_w5, L);
+        const Tiles<OUT> ty(y, rb, RB, M, L);
+#pragma unroll
+        for (int t = 0; t < S::NTO; t++) ty.store(t, o[t]);
+    }
+}
+
+// g4 = (gy W5) * gelu'(z4);  g3 = (g4 W4) * gelu'(z3);  g2 = (g3 W3) * gelu'(z2)
+template <int HID, int OUT>
+struct DeformBBwdLds {
+    static constexpr int LD5 = cl_ld(OUT), LD = cl_ld(HID), NTH = cl_kg(HID);
+    static constexpr int o_w5 = 0, o_w4 = NTH * 16 * LD5, o_w3 = o_w4 + NTH * 16 * LD, FLOATS = o_w3 + NTH * 16 * LD;
+};
+
+template <int HID, int OUT, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_deform_b_bwd(const float *__restrict__ gy, const float *__restrict__ z4,
+                                                                const float *__restrict__ z3, const float *__restrict__ z2, DeformW w,
+                                                                float *__restrict__ g4, float *__restrict__ g3, float *__restrict__ g2,
+                                                                long long M)
+{
+    extern __shared__ float lds[];
+    using S = DeformBBwdLds<HID, OUT>;
+    const Lane L;
+    zero_lds(lds, S::FLOATS, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    stage_block<true>(w.W[4], HID, OUT, 0, HID, lds + S::o_w5, S::LD5, 0, L.tid, CHAIN_THREADS);
+    stage_block<true>(w.W[3], HID, HID, 0, HID, lds + S::o_w4, S::LD, 0, L.tid, CHAIN_THREADS);
+    stage_block<true>(w.W[2], HID, HID, 0, HID, lds + S::o_w3, S::LD, 0, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    long long rb, RB, stride;
+    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    v4f g[cl_kg(OUT)];
+    load_frags<OUT>(g, gy, rb, RB, M, L);
+    for (; rb < RB; rb += stride) {
+        v4f d4[S::NTH], d3[S::NTH], d2[S::NTH];      // the three pre-activations of this block, requested up front
+        {
+            const Tiles<HID> t4(z4, rb, RB, M, L), t3(z3, rb, RB, M, L), t2(z2, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) { d4[t] = t4.load(t); d3[t] = t3.load(t); d2[t] = t2.load(t); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        v4f p[S::NTH], q[S::NTH];
+        init_zero(p);
+        chain_mm<OUT, S::NTH, S::LD5>(p, g, lds + S::o_w5, L);
+        load_frags<OUT>(g, gy, rb + stride, RB, M, L);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const Tiles<HID> to(g4, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) {
+                const v4f d = v_gelu_grad(d4[t]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) p[t][i] *= d[i];
+                to.store(t, p[t]);
+            }
+        }
+        init_zero(q);
+        chain_mm<HID, S::NTH, S::LD>(q, p, lds + S::o_w4, L);
+        {
+            const Tiles<HID> to(g3, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) {
+                const v4f d = v_gelu_grad(d3[t]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) q[t][i] *= d[i];
+                to.store(t, q[t]);
+            }
+        }
+        init_zero(p);
+        chain_mm<HID, S::NTH, S::LD>(p, q, lds + S::o_w3, L);
+        const Tiles<HID> to(g2, rb, RB, M, L);
+#pragma unroll
+        for (int t = 0; t < S::NTH; t++) {
+            const v4f d = v_gelu_grad(d2[t]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) p[t][i] *= d[i];
+            to.store(t, p[t]);
+        }
+    }
+}
+
+// g1 = (g2 W2) * gelu'(z1);  gfeat (+)= g1 W1[:, :FEAT]   (the condition columns of W1 need no input gradient)
+template <int FEAT, int HID, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_deform_a_bwd(const float *__restrict__ g2, const float *__restrict__ z1, DeformW w,
+                                                                int ldw1, float *__restrict__ g1, float *__restrict__ gfeat,
+                                                                int accumulate, long long M)
+{
+    extern __shared__ float lds[];
+    constexpr int LD = cl_ld(HID), NTH = cl_kg(HID), NTF = cl_kg(FEAT), o_w1 = NTH * 16 * LD, FLOATS = o_w1 + NTF * 16 * LD;
+    const Lane L;
+    zero_lds(lds, FLOATS, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    stage_block<true>(w.W[1], HID, HID, 0, HID, lds, LD, 0, L.tid, CHAIN_THREADS);
+    stage_block<true>(w.W[0], ldw1, HID, 0, FEAT, lds + o_w1, LD, 0, L.tid, CHAIN_THREADS);
+    __syncthreads();
+    long long rb, RB, stride;
+    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    v4f g[NTH];
+    load_frags<HID>(g, g2, rb, RB, M, L);
+    for (; rb < RB; rb += stride) {
+        v4f zz[NTH], pf[NTF];
+        {
+            const Tiles<HID> tz(z1, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < NTH; t++) zz[t] = tz.load(t);
+            const Tiles<FEAT> tf(gfeat, accumulate ? rb : RB, RB, M, L);      // empty descriptor (zeros) when not accumulating
+#pragma unroll
+            for (int t = 0; t < NTF; t++) pf[t] = tf.load(t);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        v4f p[NTH];
+        init_zero(p);
+        chain_mm<HID, NTH, LD>(p, g, lds, L);
+        load_frags<HID>(g, g2, rb + stride, RB, M, L);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const Tiles<HID> to(g1, rb, RB, M, L);
+#pragma unroll
+            for (int t = 0; t < NTH; t++) {
+                const v4f d = v_gelu_grad(zz[t]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) p[t][i] *= d[i];
+                to.store(t, p[t]);
+            }
+        }
+        chain_mm<HID, NTF, LD>(pf, p, lds + o_w1, L);      // on top of the running sum (or zeros)
+        const Tiles<FEAT> of(gfeat, rb, RB, M, L);
+#pragma unroll
+        for (int t = 0; t < NTF; t++) of.store(t, pf[t]);
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+// One launch of a chain kernel: persistent grid (one workgroup per CU), 512 threads = 2 waves per SIMD with up to 256 VGPRs each
+// (the operands a wave keeps in flight across its products need 140-240 of them; 1024-thread builds of the first version,
+// without those prefetches, were no faster: the kernels were serialising memory and MFMA phases, not short of waves).
+constexpr int CHAIN_T = 512;
+
+template <typename... KA, typename... A>
+void chain_launch(const char *name, void (*k)(KA...), size_t lds, long long M, hipStream_t s, A... args)
+{
+    static std::mutex mu;
+    static std::set<const void *> done;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (done.insert(reinterpret_cast<const void *>(k)).second)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    const int waves = CHAIN_T / 64;
+    const long long RB = (M + 15) / 16, want = (RB + waves - 1) / waves;
+    const unsigned grid = (unsigned)(want < 256 ? (want < 1 ? 1 : want) : 256);
+    ProfScope _p(name, s);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(CHAIN_T), lds, s, static_cast<KA>(args)...);
+}
+
+constexpr int FEAT = 50, COND = 66, HID = 100;
+
+bool aligned16(std::initializer_list<const void *> ps)
+{
+    for (const void *p : ps)
+        if (reinterpret_cast<uintptr_t>(p) & 15) return false;
+    return true;
+}
+
+// carve `count` floats (rounded up to a multiple of 4: every matrix starts 16-byte aligned) from a cursor
+inline float *take(float *&cur, long long count)
+{
+    float *p = cur;
+    cur += (count + 3) / 4 * 4;
+    return p;
+}
+
+// per-row floats of the tensors a generator's forward leaves for its backward, in order: cg, cb [COND], gamma [HID],
+// z1, a1, h, x3 [HID]; beta (a forward intermediate) lives behind them
+struct GenSaved {
+    float *cg, *cb, *gamma, *z1, *a1, *h, *x3, *beta;
+    GenSaved(float *base, long long M)
+    {
+        float *cur = base;
+        gamma = take(cur, M * HID); z1 = take(cur, M * HID); a1 = take(cur, M * HID); h = take(cur, M * HID); x3 = take(cur, M * HID);
+        beta = take(cur, M * HID); cg = take(cur, M * COND); cb = take(cur, M * COND);
+    }
+};
+constexpr long long GEN_SAVED_PER_ROW = 2 * COND + 6 * HID;
+
+// backward scratch of a generator: go [OUT], gbeta, ggamma, gh, gz1 [HID], gcg, gcb [COND], then the wgrad partial sums
+struct GenScratch {
+    float *go, *gbeta, *ggamma, *gh, *gz1, *gcg, *gcb, *wg;
+    GenScratch(float *base, long long M, int out)
+    {
+        float *cur = base;
+        go = take(cur, M * out); gbeta = take(cur, M * HID); ggamma = take(cur, M * HID); gh = take(cur, M * HID);
+        gz1 = take(cur, M * HID); gcg = take(cur, M * COND); gcb = take(cur, M * COND); wg = cur;
+    }
+};
+
+long long gen_wgrad_floats(int out)
+{
+    return gsvc_linear_wgrad_workspace(HID, FEAT) + gsvc_linear_wgrad_workspace(HID, HID) + gsvc_linear_wgrad_workspace(out, HID) +
+           2 * gsvc_linear_wgrad_workspace(COND, COND) + 2 * gsvc_linear_wgrad_workspace(HID, COND);
+}
+
+template <int OUT>
+int generator_forward_t(const gsvc_generator_net *n, const float *feat, const float *cond, long long M, float *saved, float *y, hipStream_t s)
+{
+    const GenSaved sv(saved, M);
+    chain_launch("k_film_nets_fwd", &k_film_nets_fwd<COND, HID, CHAIN_T>, FilmFwdLds<COND, HID>::FLOATS * 4, M, s,
+                 cond, FilmW{n->Wg0, n->bg0, n->Wg1, n->bg1, n->Wb0, n->bb0, n->Wb1, n->bb1}, sv.cg, sv.cb, sv.gamma, sv.beta, M);
+    chain_launch("k_trunk_fwd", &k_trunk_fwd<FEAT, HID, OUT, CHAIN_T>, TrunkFwdLds<FEAT, HID, OUT>::FLOATS * 4, M, s,
+                 feat, sv.gamma, sv.beta, TrunkW{n->W1, n->b1, n->W2, n->b2, n->W3, n->b3}, (int)n->out_act, sv.z1, sv.a1, sv.h, sv.x3, y, M);
+    return check_launch("generator_forward");
+}
+
+template <int OUT>
+int generator_backward_t(const gsvc_generator_net *n, const float *feat, const float *cond, long long M, const float *saved,
+                         const float *y, const float *gy, float *scratch, float *gfeat, int accumulate, const gsvc_generator_grads *g,
+                         hipStream_t s)
+{
+    const GenSaved sv(const_cast<float *>(saved), M);
+    const GenScratch sc(scratch, M, OUT);
+    chain_launch("k_trunk_bwd", &k_trunk_bwd<FEAT, HID, OUT, CHAIN_T>, TrunkBwdLds<FEAT, HID, OUT>::FLOATS * 4, M, s,
+                 gy, y, (int)n->out_act, sv.h, sv.gamma, sv.z1, TrunkW{n->W1, n->b1, n->W2, n->b2, n->W3, n->b3}, sc.go, sc.gbeta, sc.ggamma, sc.gh,
+                 sc.gz1, gfeat, accumulate, M);
+    chain_launch("k_film_nets_bwd", &k_film_nets_bwd<COND, HID, CHAIN_T>, (size_t)2 * cl_kg(COND) * 16 * cl_ld(HID) * 4, M, s, sc.ggamma, sc.gbeta, sv.cg, sv.cb, n->Wg1, n->Wb1, sc.gcg, sc.gcb, M);
+    if (int rc = check_launch("generator_backward")) return rc;
+    // the seven weight gradients dW = G^T X (+ db): row-split partial sums, one batched slot reduce
+    struct Job { const float *G, *X; float *dW, *db; int N, K; };
+    const Job jobs[7] = {
+        {sc.gz1, feat, g->W1, g->b1, HID, FEAT},   {sc.gh, sv.a1, g->W2, g->b2, HID, HID},   {sc.go, sv.x3, g->W3, g->b3, OUT, HID},
+        {sc.gcg, cond, g->Wg0, g->bg0, COND, COND}, {sc.ggamma, sv.cg, g->Wg1, g->bg1, HID, COND},
+        {sc.gcb, cond, g->Wb0, g->bb0, COND, COND}, {sc.gbeta, sv.cb, g->Wb1, g->bb1, HID, COND}};
+    gsvc_wgrad_reduce_job red[7];
+    float *ws = sc.wg;
+    int nred = 0;
+    for (const Job &j : jobs) {
+        if (!j.dW) continue;
+        const long long need = gsvc_linear_wgrad_workspace(j.N, j.K);
+        int32_t slots = 0;
+        if (int rc = gsvc_linear_wgrad_partial(j.G, j.X, j.db != nullptr, M, j.N, j.K, ws, need, &slots, s)) return rc;
+        red[nred++] = gsvc_wgrad_reduce_job{ws, j.dW, j.db, slots, j.N, j.K};
+        ws += need;
+    }
+    if (nred) return gsvc_linear_wgrad_reduce_many(red, nred, s);
+    return GSVC_OK;
+}
+
+constexpr int DEF_OUT = 30;
+constexpr long long DEF_SAVED_PER_ROW = 8 * HID;      // z1 a1 z2 a2 z3 a3 z4 a4
+constexpr long long DEF_SCRATCH_PER_ROW = 4 * HID;    // g1 g2 g3 g4
+
+long long deform_wgrad_floats()
+{
+    return gsvc_linear_wgrad_workspace(HID, FEAT) + gsvc_linear_wgrad_workspace(HID, COND) + 3 * gsvc_linear_wgrad_workspace(HID, HID) +
+           gsvc_linear_wgrad_workspace(DEF_OUT, HID);
+}
+
+}  // namespace
+}  // namespace gsvc
+
+using namespace gsvc;
+
+static int gen_supported(const gsvc_generator_net *n, const char *what)
+{
+    GSVC_REQUIRE(n, "%s: NULL network", what);
+    if (n->feat_dim != FEAT || n->cond_dim != COND || n->hidden_dim != HID || (n->out_dim != 10 && n->out_dim != 30 && n->out_dim != 70) ||
+        n->out_act < CH_ACT_NONE || n->out_act > CH_ACT_SIGMOID) {
+        set_error("%s: widths feat %d / cond %d / hidden %d / out %d (act %d) have no chain-kernel instantiation", what, n->feat_dim,
+                  n->cond_dim, n->hidden_dim, n->out_dim, n->out_act);
+        return GSVC_E_UNSUPPORTED;
+    }
+    GSVC_REQUIRE(n->W1 && n->b1 && n->W2 && n->b2 && n->W3 && n->b3 && n->Wg0 && n->bg0 && n->Wg1 && n->bg1 && n->Wb0 && n->bb0 && n->Wb1 &&
+                     n->bb1, "%s: NULL weight pointer", what);
+    return GSVC_OK;
+}
+
+extern "C" int64_t gsvc_generator_saved_floats(const gsvc_generator_net *n, int64_t M)
+{
+    if (!n || M < 0) return -1;
+    return (GEN_SAVED_PER_ROW + HID) * M + 32;
+}
+
+extern "C" int64_t gsvc_generator_scratch_floats(const gsvc_generator_net *n, int64_t M)
+{
+    if (!n || M < 0) return -1;
+    return (int64_t)(n->out_dim + 4 * HID + 2 * COND) * M + gen_wgrad_floats(n->out_dim) + 64;
+}
+
+extern "C" int gsvc_generator_forward(const gsvc_generator_net *n, const float *feat, const float *cond, int64_t M, float *saved, float *y,
+                                      void *stream)
+{
+    if (int rc = gen_supported(n, "generator_forward")) return rc;
+    GSVC_REQUIRE(M >= 0, "generator_forward: bad row count");
+    if (M == 0) return GSVC_OK;
+    GSVC_REQUIRE(feat && cond && saved && y, "generator_forward: NULL pointer");
+    GSVC_REQUIRE(aligned16({feat, cond, saved, y}), "generator_forward: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    switch (n->out_dim) {
+        case 10: return generator_forward_t<10>(n, feat, cond, M, saved, y, s);
+        case 30: return generator_forward_t<30>(n, feat, cond, M, saved, y, s);
+        default: return generator_forward_t<70>(n, feat, cond, M, saved, y, s);
+    }
+}
+
+extern "C" int gsvc_generator_backward(const gsvc_generator_net *n, const float *feat, const float *cond, int64_t M, const float *saved,
+                                       const float *y, const float *gy, float *scratch, float *gfeat, int32_t accumulate_gfeat,
+                                       const gsvc_generator_grads *grads, void *stream)
+{
+    if (int rc = gen_supported(n, "generator_backward")) return rc;
+    GSVC_REQUIRE(M >= 0 && grads, "generator_backward: bad arguments");
+    if (M == 0) return GSVC_OK;
+    GSVC_REQUIRE(feat && cond && saved && y && gy && scratch && gfeat, "generator_backward: NULL pointer");
+    GSVC_REQUIRE(aligned16({feat, cond, saved, y, gy, scratch, gfeat}),
+                 "generator_backward: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    switch (n->out_dim) {
+        case 10: return generator_backward_t<10>(n, feat, cond, M, saved, y, gy, scratch, gfeat, accumulate_gfeat, grads, s);
+        case 30: return generator_backward_t<30>(n, feat, cond, M, saved, y, gy, scratch, gfeat, accumulate_gfeat, grads, s);
+        default: return generator_backward_t<70>(n, feat, cond, M, saved, y, gy, scratch, gfeat, accumulate_gfeat, grads, s);
+    }
+}
+
+static int deform_supported(const gsvc_deform_net *n, const char *what)
+{
+    GSVC_REQUIRE(n, "%s: NULL network", what);
+    if (n->feat_dim != FEAT || n->cond_dim != COND || n->hidden_dim != HID || n->out_dim != DEF_OUT) {
+        set_error("%s: widths feat %d / cond %d / hidden %d / out %d have no chain-kernel instantiation", what, n->feat_dim, n->cond_dim,
+                  n->hidden_dim, n->out_dim);
+        return GSVC_E_UNSUPPORTED;
+    }
+    for (int i = 0; i < 5; i++) GSVC_REQUIRE(n->W[i] && n->b[i], "%s: NULL weight pointer (layer %d)", what, i);
+    return GSVC_OK;
+}
+
+extern "C" int64_t gsvc_deform_saved_floats(const gsvc_deform_net *n, int64_t M)
+{
+    if (!n || M < 0) return -1;
+    return DEF_SAVED_PER_ROW * M;
+}
+
+extern "C" int64_t gsvc_deform_scratch_floats(const gsvc_deform_net *n, int64_t M)
+{
+    if (!n || M < 0) return -1;
+    return DEF_SCRATCH_PER_ROW * M + deform_wgrad_floats() + 2 * (int64_t)HID * (FEAT + COND) + 64;
+}
+
+extern "C" int gsvc_deform_forward(const gsvc_deform_net *n, const float *feat, const float *cond, int64_t M, float *saved, float *y,
+                                   void *stream)
+{
+    if (int rc = deform_supported(n, "deform_forward")) return rc;
+    GSVC_REQUIRE(M >= 0, "deform_forward: bad row count");
+    if (M == 0) return GSVC_OK;
+    GSVC_REQUIRE(feat && cond && saved && y, "deform_forward: NULL pointer");
+    GSVC_REQUIRE(aligned16({feat, cond, saved, y}), "deform_forward: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    DeformW w;
+    for (int i = 0; i < 5; i++) { w.W[i] = n->W[i]; w.b[i] = n->b[i]; }
+    float *z1 = saved, *a1 = z1 + M * HID, *z2 = a1 + M * HID, *a2 = z2 + M * HID, *z3 = a2 + M * HID, *a3 = z3 + M * HID,
+          *z4 = a3 + M * HID, *a4 = z4 + M * HID;
+    chain_launch("k_deform_a_fwd", &k_deform_a_fwd<FEAT, COND, HID, CHAIN_T>, DeformALds<FEAT, COND, HID>::FLOATS * 4, M, s, feat, cond, w, z1, a1, z2, a2, M);
+    chain_launch("k_deform_b_fwd", &k_deform_b_fwd<HID, DEF_OUT, CHAIN_T>, DeformBLds<HID, DEF_OUT>::FLOATS * 4, M, s,
+                 a2, w, z3, a3, z4, a4, y, M);
+    return check_launch("deform_forward");
+}
+
+extern "C" int gsvc_deform_backward(const gsvc_deform_net *n, const float *feat, const float *cond, int64_t M, const float *saved,
+                                    const float *gy, float *scratch, float *gfeat, int32_t accumulate_gfeat, const gsvc_deform_grads *grads,
+                                    void *stream)
+{
+    if (int rc = deform_supported(n, "deform_backward")) return rc;
+    GSVC_REQUIRE(M >= 0 && grads, "deform_backward: bad arguments");
+    if (M == 0) return GSVC_OK;
+    GSVC_REQUIRE(feat && cond && saved && gy && scratch && gfeat, "deform_backward: NULL pointer");
+    GSVC_REQUIRE(aligned16({feat, cond, saved, gy, scratch, gfeat}),
+                 "deform_backward: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    DeformW w;
+    for (int i = 0; i < 5; i++) { w.W[i] = n->W[i]; w.b[i] = n->b[i]; }
+    const float *z1 = saved, *a1 = z1 + M * HID, *z2 = a1 + M * HID, *a2 = z2 + M * HID, *z3 = a2 + M * HID, *a3 = z3 + M * HID,
+                *z4 = a3 + M * HID, *a4 = z4 + M * HID;
+    float *g1 = scratch, *g2 = g1 + M * HID, *g3 = g2 + M * HID, *g4 = g3 + M * HID, *ws = g4 + M * HID;
+    ws = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 15) & ~uintptr_t(15));
+    chain_launch("k_deform_b_bwd", &k_deform_b_bwd<HID, DEF_OUT, CHAIN_T>, DeformBBwdLds<HID, DEF_OUT>::FLOATS * 4,
+                 M, s, gy, z4, z3, z2, w, g4, g3, g2, M);
+    chain_launch("k_deform_a_bwd", &k_deform_a_bwd<FEAT, HID, CHAIN_T>, (size_t)(cl_kg(HID) + cl_kg(FEAT)) * 16 * cl_ld(HID) * 4, M, s, g2, z1, w, FEAT + COND, g1, gfeat, (int)accumulate_gfeat, M);
+    if (int rc = check_launch("deform_backward")) return rc;
+    // weight gradients; layer 1 = [g1^T feat | g1^T cond] formed as two products into a staging area, interleaved by the caller's
+    // layout (grads->W[0] is [HID][FEAT + COND]): the reduce writes contiguous [N][K] blocks, so the two halves go to scratch
+    // and a strided copy puts them side by side
+    struct Job { const float *G, *X; float *dW, *db; int N, K; };
+    float *stage_f = ws, *stage_c = stage_f + (size_t)HID * FEAT;
+    ws = stage_c + (size_t)HID * COND;
+    ws = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 15) & ~uintptr_t(15));
+    const bool want1 = grads->W[0] != nullptr;
+    const Job jobs[6] = {{g1, feat, want1 ? stage_f : nullptr, grads->b[0], HID, FEAT}, {g1, cond, want1 ? stage_c : nullptr, nullptr, HID, COND},
+                         {g2, a1, grads->W[1], grads->b[1], HID, HID},                 {g3, a2, grads->W[2], grads->b[2], HID, HID},
+                         {g4, a3, grads->W[3], grads->b[3], HID, HID},                 {gy, a4, grads->W[4], grads->b[4], DEF_OUT, HID}};
+    gsvc_wgrad_reduce_job red[6];
+    int nred = 0;
+    for (const Job &j : jobs) {
+        if (!j.dW) continue;
+        const long long need = gsvc_linear_wgrad_workspace(j.N, j.K);
+        int32_t slots = 0;
+        if (int rc = gsvc_linear_wgrad_partial(j.G, j.X, j.db != nullptr, M, j.N, j.K, ws, need, &slots, s)) return rc;
+        red[nred++] = gsvc_wgrad_reduce_job{ws, j.dW, j.db, slots, j.N, j.K};
+        ws += need;
+    }
+    if (nred)
+        if (int rc = gsvc_linear_wgrad_reduce_many(red, nred, s)) return rc;
+    if (want1) {
+        (void)hipMemcpy2DAsync(grads->W[0], (size_t)(FEAT + COND) * 4, stage_f, (size_t)FEAT * 4, (size_t)FEAT * 4, HID, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpy2DAsync(grads->W[0] + FEAT, (size_t)(FEAT + COND) * 4, stage_c, (size_t)COND * 4, (size_t)COND * 4, HID,
+                               hipMemcpyDeviceToDevice, s);
+    }
+    return check_launch("deform_backward");
+}

@@ -269,3 +269,158 @@ def seq_gelu(x, linears):
     for l in linears:
         params += [l.weight, l.bias]
     return _SeqGelu.apply(x, *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Whole-network chain kernels (csrc/mlp_chain.hip): the three GeneratorNets and mlp_deform of a generation pass as ONE autograd
+# function.  Forward: 2 launches per network (FiLM nets | trunk, layers 1-2 | 3-5), a 16-row block's activations stay in
+# registers across the layers; backward: 2 chain launches per network + the row-split weight-gradient kernels + one slot reduce,
+# all issued from C.  The anchor features feed all four networks: their gradient is accumulated in place by the kernels
+# (no fan-out additions).  Reference: scene/gaussian_model.py:150-196, 468-489; ortho_gaussian_renderer/guassian.py:251-273.
+GEN_FIELDS = ("W1", "b1", "W2", "b2", "W3", "b3", "Wg0", "bg0", "Wg1", "bg1", "Wb0", "bb0", "Wb1", "bb1")
+
+
+def _generator_params(net):
+    f = net.film
+    out = []
+    for l in (net.linear1, net.linear2, net.out_linear, f.fc_gamma0, f.fc_gamma1, f.fc_beta0, f.fc_beta1):
+        out += [l.weight, l.bias]
+    return out
+
+
+def _act_code(net):
+    return {"Tanh": ACT_TANH, "Sigmoid": ACT_SIGMOID, "Identity": ACT_NONE}.get(type(net.out_act).__name__)
+
+
+def chain_usable(feat, cond, gens, deform_linears):
+    """The chain kernels exist for the production widths only (feature 50, condition 66, hidden 100, outputs 10 / 30 / 70 and
+    30) and need tall contiguous fp32 CUDA matrices; the condition must not require a gradient."""
+    import os
+    if os.environ.get("GSVC_NO_MLP_CHAIN") or os.environ.get("GSVC_NO_MLP_FUSED"):
+        return False
+    if not (feat.is_cuda and cond.is_cuda and feat.dim() == cond.dim() == 2 and feat.dtype == cond.dtype == torch.float32
+            and feat.shape[0] == cond.shape[0] >= MIN_ROWS and not cond.requires_grad):
+        return False
+    if feat.shape[1] != 50 or cond.shape[1] != 66:
+        return False
+    for net in gens:
+        if _act_code(net) is None or net.linear1.out_features != 100 or net.out_linear.out_features not in (10, 30, 70):
+            return False
+        if any(l.bias is None for l in (net.linear1, net.linear2, net.out_linear, net.film.fc_gamma0, net.film.fc_gamma1,
+                                        net.film.fc_beta0, net.film.fc_beta1)):
+            return False
+    if len(deform_linears) != 5 or any(l.bias is None for l in deform_linears):
+        return False
+    dims = [(l.in_features, l.out_features) for l in deform_linears]
+    return dims == [(116, 100), (100, 100), (100, 100), (100, 100), (100, 30)]
+
+
+def _gen_desc(params, act, out_dim):
+    d = _lib.GeneratorNetC()
+    for name, p in zip(GEN_FIELDS, params):
+        setattr(d, name, p.data_ptr())
+    d.feat_dim, d.cond_dim, d.hidden_dim, d.out_dim, d.out_act = 50, 66, 100, out_dim, act
+    return d
+
+
+def _deform_desc(params):
+    d = _lib.DeformNetC()
+    for i in range(5):
+        d.W[i], d.b[i] = params[2 * i].data_ptr(), params[2 * i + 1].data_ptr()
+    d.feat_dim, d.cond_dim, d.hidden_dim, d.out_dim = 50, 66, 100, 30
+    return d
+
+
+class _GenerateAll(torch.autograd.Function):
+    """(opacity, color, cov, deform) outputs of the three GeneratorNets and mlp_deform for the rows (feature, condition).
+    params = 3 x 14 generator tensors (GEN_FIELDS order) + 5 x (W, b) of mlp_deform; acts = the generators' output activations."""
+
+    @staticmethod
+    def forward(ctx, feat, cond, acts, *params):
+        import ctypes as C
+        feat, cond = feat.contiguous(), cond.contiguous()
+        params = [p.contiguous() for p in params]
+        M, dev = feat.shape[0], feat.device
+        L, st = _lib.lib(), _lib.current_stream(dev)
+        outs, saved, descs = [], [], []
+        for g in range(3):
+            pg = params[14 * g:14 * (g + 1)]
+            out_dim = pg[4].shape[0]
+            d = _gen_desc(pg, acts[g], out_dim)
+            sv = torch.empty(int(L.gsvc_generator_saved_floats(C.byref(d), M)), device=dev, dtype=torch.float32)
+            y = torch.empty(M, out_dim, device=dev, dtype=torch.float32)
+            _lib.check(L.gsvc_generator_forward(C.byref(d), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(sv), _lib.ptr(y), st),
+                       "gsvc_generator_forward")
+            outs.append(y)
+            saved.append(sv)
+        pd = params[42:52]
+        dd = _deform_desc(pd)
+        sv = torch.empty(int(L.gsvc_deform_saved_floats(C.byref(dd), M)), device=dev, dtype=torch.float32)
+        y = torch.empty(M, 30, device=dev, dtype=torch.float32)
+        _lib.check(L.gsvc_deform_forward(C.byref(dd), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(sv), _lib.ptr(y), st), "gsvc_deform_forward")
+        outs.append(y)
+        saved.append(sv)
+        ctx.acts = tuple(acts)
+        ctx.save_for_backward(feat, cond, *outs[:3], *saved, *params)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        import ctypes as C
+        t = ctx.saved_tensors
+        feat, cond, ys, saved, params = t[0], t[1], t[2:5], t[5:9], t[9:]
+        M, dev = feat.shape[0], feat.device
+        L, st = _lib.lib(), _lib.current_stream(dev)
+        need = ctx.needs_input_grad
+        gfeat = torch.empty_like(feat)
+        first = True
+        grads = [None] * len(params)
+        scratch = None
+        for g in range(4):
+            if gys[g] is None:
+                continue
+            gy = gys[g].contiguous()
+            pg = params[14 * g:14 * (g + 1)] if g < 3 else params[42:52]
+            flat = torch.empty(sum(p.numel() for p in pg), device=dev, dtype=torch.float32)
+            views, at = [], 0
+            for p in pg:
+                views.append(flat[at:at + p.numel()].view(p.shape))
+                at += p.numel()
+            for i, v in enumerate(views):
+                grads[(14 * g if g < 3 else 42) + i] = v
+            if g < 3:
+                d = _gen_desc(pg, ctx.acts[g], pg[4].shape[0])
+                n = int(L.gsvc_generator_scratch_floats(C.byref(d), M))
+                if scratch is None or scratch.numel() < n:
+                    scratch = torch.empty(n, device=dev, dtype=torch.float32)
+                gd = _lib.GeneratorGradsC()
+                for name, v in zip(GEN_FIELDS, views):
+                    setattr(gd, name, v.data_ptr())
+                _lib.check(L.gsvc_generator_backward(C.byref(d), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(saved[g]), _lib.ptr(ys[g]),
+                                                     _lib.ptr(gy), _lib.ptr(scratch), _lib.ptr(gfeat), 0 if first else 1, C.byref(gd), st),
+                           "gsvc_generator_backward")
+            else:
+                d = _deform_desc(pg)
+                n = int(L.gsvc_deform_scratch_floats(C.byref(d), M))
+                if scratch is None or scratch.numel() < n:
+                    scratch = torch.empty(n, device=dev, dtype=torch.float32)
+                gd = _lib.DeformGradsC()
+                for i in range(5):
+                    gd.W[i], gd.b[i] = views[2 * i].data_ptr(), views[2 * i + 1].data_ptr()
+                _lib.check(L.gsvc_deform_backward(C.byref(d), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(saved[3]), _lib.ptr(gy),
+                                                  _lib.ptr(scratch), _lib.ptr(gfeat), 0 if first else 1, C.byref(gd), st),
+                           "gsvc_deform_backward")
+            first = False
+        if first:
+            gfeat = None
+        return (gfeat if need[0] else None, None, None, *grads)
+
+
+def generate_all(gens, deform_linears, feat, cond):
+    """(opacity_raw, color, scale_rot, neural_offset) = the three generators and mlp_deform on (feat, cond) rows."""
+    params = []
+    for net in gens:
+        params += _generator_params(net)
+    for l in deform_linears:
+        params += [l.weight, l.bias]
+    return _GenerateAll.apply(feat, cond, tuple(_act_code(n) for n in gens), *params)

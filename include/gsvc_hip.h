@@ -494,6 +494,51 @@ int gsvc_linear_wgrad_partial(const float *G, const float *X, int32_t want_db, i
                               float *workspace, int64_t workspace_floats, int32_t *slots_used, void *stream);
 int gsvc_linear_wgrad_reduce_many(const gsvc_wgrad_reduce_job *jobs, int32_t n_jobs, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Whole-network chain kernels of the generator and deformation MLPs (csrc/mlp_chain.hip): a 16-row block's activations stay
+ * in registers from the network's input to its output; weights resident in LDS; fp32 MFMA.
+ * Replaces, per anchor row: GeneratorNet.forward = out_act(out_linear(film(linear2(GELU(linear1(feature))), condition)))
+ * with FiLM = gamma(c) * x + beta(c), gamma / beta = fc_*1(ReLU(fc_*0(c))) (reference scene/gaussian_model.py:150-196, used at
+ * ortho_gaussian_renderer/guassian.py:251-262), and mlp_deform = 5 x Linear with GELU between (scene/gaussian_model.py:468-489,
+ * guassian.py:264-273) on cat([feature, condition]).  All matrices row-major fp32, weights in torch.nn.Linear layout [out, in],
+ * every pointer 16-byte aligned.  Instantiated widths: feature 50, condition 66, hidden 100, outputs 10 / 30 / 70 (generators)
+ * and 30 (deform); anything else returns GSVC_E_UNSUPPORTED (callers keep the gsvc_linear_* layer path).
+ *   _forward : y[M, out]; `saved` (gsvc_*_saved_floats floats, caller-owned) receives what the backward reads.
+ *   _backward: from gy[M, out] forms d feature (gfeat[M, feat]; accumulate_gfeat != 0 adds to what is there — the feature
+ *              matrix feeds four networks), and every weight / bias gradient (dW = G^T X by the row-split kernels of
+ *              gsvc_linear_wgrad_partial + one batched slot reduce: deterministic, no atomics) into the pointers of `grads`
+ *              (a NULL weight pointer skips that layer).  The condition receives no gradient (it is the positional embedding of
+ *              detached anchor positions / the frame time).  `scratch`: gsvc_*_scratch_floats floats.
+ * out_act: 0 identity, 1 tanh, 2 sigmoid. */
+typedef struct gsvc_generator_net {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;                             /* linear1, linear2, out_linear */
+    const float *Wg0, *bg0, *Wg1, *bg1, *Wb0, *bb0, *Wb1, *bb1;           /* film.fc_gamma0/1, film.fc_beta0/1 */
+    int32_t feat_dim, cond_dim, hidden_dim, out_dim, out_act;
+} gsvc_generator_net;
+typedef struct gsvc_generator_grads {
+    float *W1, *b1, *W2, *b2, *W3, *b3, *Wg0, *bg0, *Wg1, *bg1, *Wb0, *bb0, *Wb1, *bb1;
+} gsvc_generator_grads;
+int64_t gsvc_generator_saved_floats(const gsvc_generator_net *net, int64_t M);
+int64_t gsvc_generator_scratch_floats(const gsvc_generator_net *net, int64_t M);
+int gsvc_generator_forward(const gsvc_generator_net *net, const float *feat, const float *cond, int64_t M, float *saved, float *y,
+                           void *stream);
+int gsvc_generator_backward(const gsvc_generator_net *net, const float *feat, const float *cond, int64_t M, const float *saved,
+                            const float *y, const float *gy, float *scratch, float *gfeat, int32_t accumulate_gfeat,
+                            const gsvc_generator_grads *grads, void *stream);
+
+typedef struct gsvc_deform_net {
+    const float *W[5], *b[5];                                             /* mlp_deform's five Linear layers, input = [feat | cond] */
+    int32_t feat_dim, cond_dim, hidden_dim, out_dim;
+} gsvc_deform_net;
+typedef struct gsvc_deform_grads {
+    float *W[5], *b[5];
+} gsvc_deform_grads;
+int64_t gsvc_deform_saved_floats(const gsvc_deform_net *net, int64_t M);
+int64_t gsvc_deform_scratch_floats(const gsvc_deform_net *net, int64_t M);
+int gsvc_deform_forward(const gsvc_deform_net *net, const float *feat, const float *cond, int64_t M, float *saved, float *y, void *stream);
+int gsvc_deform_backward(const gsvc_deform_net *net, const float *feat, const float *cond, int64_t M, const float *saved, const float *gy,
+                         float *scratch, float *gfeat, int32_t accumulate_gfeat, const gsvc_deform_grads *grads, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

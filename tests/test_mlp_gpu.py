@@ -192,3 +192,69 @@ def test_fused_row_gather_and_context_tail_match_the_tensor_paths(monkeypatch):
     ((m2 * gm).sum() + (s2c * gs).sum() + (a2 * ga).sum()).backward()
     for a, b in zip(got, (m2.detach(), s2c.detach(), a2.detach(), params.grad, q.grad)):
         assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("M", [4096, 6001, 20011])
+def test_whole_network_chain_kernels_match_torch(M):
+    """gsvc_generator_* / gsvc_deform_* (csrc/mlp_chain.hip: a 16-row block's activations stay in registers from the network's
+    input to its output) through gsvc_amd.mlp.generate_all — the three GeneratorNets (out 10 tanh / 30 sigmoid / 70) and
+    mlp_deform (116 -> 100 x4 -> 30) on the same (feature, condition) rows — against plain PyTorch fp32: the four outputs, the
+    accumulated feature gradient and every weight / bias gradient (reference scene/gaussian_model.py:150-196, 468-489).
+    M = 4096: whole 16-row blocks; 6001, 20011: ragged last block, odd row counts (8-byte aligned matrix bases)."""
+    from gsvc_amd import mlp
+    from gsvc_amd.model import GeluSequential, GeneratorNet, Linear
+    torch.manual_seed(M)
+    gens = [GeneratorNet(50, 10, 100, 66, out_act=torch.nn.Tanh()).cuda(), GeneratorNet(50, 30, 100, 66, out_act=torch.nn.Sigmoid()).cuda(),
+            GeneratorNet(50, 70, 100, 66).cuda()]
+    deform = GeluSequential(Linear(116, 100), torch.nn.GELU(), Linear(100, 100), torch.nn.GELU(), Linear(100, 100), torch.nn.GELU(),
+                            Linear(100, 100), torch.nn.GELU(), Linear(100, 30)).cuda()
+    lin = list(deform)[0::2]
+    feat = (torch.randn(M, 50, device="cuda") * 2).requires_grad_(True)
+    cond = torch.randn(M, 66, device="cuda")
+    gs = [torch.randn(M, n, device="cuda") for n in (10, 30, 70, 30)]
+    with torch.no_grad():
+        # rows with a FiLM ReLU pre-activation within rounding of its kink take no part in the gradient comparison
+        bad = torch.zeros(M, dtype=torch.bool, device="cuda")
+        for net in gens:
+            f = net.film
+            pre = torch.cat([F.linear(cond, f.fc_gamma0.weight, f.fc_gamma0.bias), F.linear(cond, f.fc_beta0.weight, f.fc_beta0.bias)], 1)
+            bad |= (pre.abs() < 1e-4).any(dim=1)
+        for g in gs:
+            g[bad] = 0
+    assert mlp.chain_usable(feat, cond, gens, lin)
+    outs = mlp.generate_all(gens, lin, feat, cond)
+    assert "GenerateAll" in type(outs[0].grad_fn).__name__
+    sum((o * g).sum() for o, g in zip(outs, gs)).backward()
+    params = [p for net in gens for p in net.parameters()] + list(deform.parameters())
+    got = [feat.grad.clone()] + [p.grad.clone() for p in params]
+    feat.grad = None
+    for p in params:
+        p.grad = None
+    refs = [_torch_generator(net, feat, cond) for net in gens]
+    x = torch.cat([feat, cond], dim=1)
+    for i, l in enumerate(lin):
+        x = F.linear(x, l.weight, l.bias)
+        if i + 1 < len(lin):
+            x = F.gelu(x)
+    refs.append(x)
+    for o, r in zip(outs, refs):
+        _close(o.detach(), r.detach(), 2e-5)
+    sum((r * g).sum() for r, g in zip(refs, gs)).backward()
+    want = [feat.grad] + [p.grad for p in params]
+    for a, b in zip(got, want):
+        _close(a, b, 1e-3)
+    # a second backward through a fresh forward gives bit-identical gradients (no atomics anywhere)
+    feat.grad = None
+    for p in params:
+        p.grad = None
+    outs2 = mlp.generate_all(gens, lin, feat, cond)
+    sum((o * g).sum() for o, g in zip(outs2, gs)).backward()
+    for a, b in zip(got, [feat.grad] + [p.grad for p in params]):
+        assert torch.equal(a, b)
+    # widths without an instantiation are refused by the C-ABI (callers keep the layer path)
+    import ctypes as C
+    from gsvc_amd import _lib
+    d = mlp._gen_desc(mlp._generator_params(gens[0]), 1, 10)
+    d.hidden_dim = 96
+    assert _lib.lib().gsvc_generator_saved_floats(C.byref(d), 16) > 0
+    assert _lib.lib().gsvc_generator_forward(C.byref(d), None, None, 16, None, None, None) == -3
