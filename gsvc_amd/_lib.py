@@ -161,7 +161,11 @@ _SIGNATURES = {
     "gsvc_deform_saved_floats": (_i64, [C.POINTER(DeformNetC), _i64]),
     "gsvc_deform_scratch_floats": (_i64, [C.POINTER(DeformNetC), _i64]),
     "gsvc_deform_forward": (C.c_int, [C.POINTER(DeformNetC), _vp, _vp, _i64, _vp, _vp, _vp]),
-    "gsvc_deform_backward": (C.c_int, [C.POINTER(DeformNetC), _vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.POINTER(DeformGradsC), _vp]),
+    "gsvc_deform_backward": (C.c_int, [C.POINTER(DeformNetC), _vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
+                                       C.POINTER(DeformGradsC), _vp]),
+    "gsvc_generators_forward": (C.c_int, [C.POINTER(GeneratorNetC), C.c_int32, _vp, _vp, _i64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]),
+    "gsvc_generators_backward": (C.c_int, [C.POINTER(GeneratorNetC), C.c_int32, _vp, _vp, _i64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_void_p), _vp, C.POINTER(C.c_void_p), C.POINTER(GeneratorGradsC), _vp]),
     "gsvc_rate_sample_scratch_floats": (_i64, [_i64]),
     "gsvc_rate_sample_forward": (C.c_int, [C.POINTER(RateSampleC), _vp, _vp, _vp]),
     "gsvc_rate_sample_backward": (C.c_int, [C.POINTER(RateSampleC), _vp, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

@@ -215,13 +215,34 @@ __device__ __forceinline__ v4f v_gelu(v4f z) { return (v4f){c_gelu(z[0]), c_gelu
 __device__ __forceinline__ v4f v_gelu_grad(v4f z) { return (v4f){c_gelu_grad(z[0]), c_gelu_grad(z[1]), c_gelu_grad(z[2]), c_gelu_grad(z[3])}; }
 __device__ __forceinline__ v4f v_relu(v4f z) { return (v4f){fmaxf(z[0], 0.f), fmaxf(z[1], 0.f), fmaxf(z[2], 0.f), fmaxf(z[3], 0.f)}; }
 
+// 16-row blocks of one network are dealt wave-major over the nblk workgroups that serve it (linear_ws.h: even rounds on every
+// SIMD); blk = this workgroup's index among them.  A launch may serve several networks at once (MAX_NETS below): workgroup b
+// works for network b % n — one prologue and one partial last round for three networks' rows instead of one each.
+template <int WAVES>
+__device__ __forceinline__ void row_blocks(long long M, const Lane &L, int blk, int nblk, long long &rb, long long &RB, long long &stride)
+{
+    RB = (M + 15) >> 4;
+    stride = (long long)nblk * WAVES;
+    rb = (long long)L.wave * nblk + blk;
+}
 template <int WAVES>
 __device__ __forceinline__ void row_blocks(long long M, const Lane &L, long long &rb, long long &RB, long long &stride)
 {
-    RB = (M + 15) >> 4;
-    stride = (long long)gridDim.x * WAVES;
-    rb = (long long)L.wave * gridDim.x + blockIdx.x;      // wave-major deal (linear_ws.h: even rounds on every SIMD)
+    row_blocks<WAVES>(M, L, (int)blockIdx.x, (int)gridDim.x, rb, RB, stride);
 }
+
+constexpr int MAX_NETS = 3;
+struct NetOfBlock {
+    int net, blk, nblk;
+    __device__ NetOfBlock(int n)
+    {
+        net = (int)blockIdx.x % n;
+        blk = (int)blockIdx.x / n;
+        nblk = ((int)gridDim.x - net + n - 1) / n;
+    }
+};
+template <typename T>
+__device__ __forceinline__ T pick(const T (&a)[MAX_NETS], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
 
 // ======================================================================================================= FiLM nets
 // gamma = Wg1 relu(Wg0 c + bg0) + bg1, beta likewise (reference scene/gaussian_model.py:150-166); cg / cb = the hidden ReLU
@@ -239,7 +260,7 @@ struct FilmFwdLds {
 };
 
 template <int COND, int HID, int CHAIN_THREADS>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_film_nets_fwd(const float *__restrict__ cond, FilmW w, float *__restrict__ cg,
+__device__ __forceinline__ void film_fwd_body(int blk, int nblk, const float *__restrict__ cond, FilmW w, float *__restrict__ cg,
                                                                  float *__restrict__ cb, float *__restrict__ gamma,
                                                                  float *__restrict__ beta, long long M)
 {
@@ -259,7 +280,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_film_nets_fwd(const float *__
     stage_bias(w.bb1, HID, sb_b1, S::NT1 * 16, L.tid, CHAIN_THREADS);
     __syncthreads();
     long long rb, RB, stride;
-    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    row_blocks<CHAIN_THREADS / 64>(M, L, blk, nblk, rb, RB, stride);
     // memory and MFMA phases of a wave overlap: the next block's condition rows are requested as soon as this block's last use
     // of them has been issued, and nothing ever waits for a store
     v4f c[S::NT0];
@@ -294,7 +315,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_film_nets_fwd(const float *__
 // backward through the second layers and the ReLUs: gcg = (ggamma Wg1) * [cg > 0], gcb likewise (the first layers' dW
 // operands; the condition itself — frame time and z embedding of detached anchors — needs no gradient)
 template <int COND, int HID, int CHAIN_THREADS>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_film_nets_bwd(const float *__restrict__ ggamma, const float *__restrict__ gbeta,
+__device__ __forceinline__ void film_bwd_body(int blk, int nblk, const float *__restrict__ ggamma, const float *__restrict__ gbeta,
                                                                  const float *__restrict__ cg, const float *__restrict__ cb,
                                                                  const float *__restrict__ Wg1, const float *__restrict__ Wb1,
                                                                  float *__restrict__ gcg, float *__restrict__ gcb, long long M)
@@ -308,7 +329,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_film_nets_bwd(const float *__
     stage_block<true>(Wb1, COND, HID, 0, COND, lds + IMG, LD, 0, L.tid, CHAIN_THREADS);
     __syncthreads();
     long long rb, RB, stride;
-    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    row_blocks<CHAIN_THREADS / 64>(M, L, blk, nblk, rb, RB, stride);
     v4f g[2][cl_kg(HID)];
     load_frags<HID>(g[0], ggamma, rb, RB, M, L);
     load_frags<HID>(g[1], gbeta, rb, RB, M, L);
@@ -355,7 +376,7 @@ struct TrunkFwdLds {
 };
 
 template <int FEAT, int HID, int OUT, int CHAIN_THREADS>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_fwd(const float *__restrict__ feat, const float *__restrict__ gamma,
+__device__ __forceinline__ void trunk_fwd_body(int blk, int nblk, const float *__restrict__ feat, const float *__restrict__ gamma,
                                                              const float *__restrict__ beta, TrunkW w, int act,
                                                              float *__restrict__ z1, float *__restrict__ a1, float *__restrict__ h,
                                                              float *__restrict__ x3, float *__restrict__ y, long long M)
@@ -374,7 +395,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_fwd(const float *__rest
     stage_bias(w.b3, OUT, sb3, S::NTO * 16, L.tid, CHAIN_THREADS);
     __syncthreads();
     long long rb, RB, stride;
-    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    row_blocks<CHAIN_THREADS / 64>(M, L, blk, nblk, rb, RB, stride);
     v4f f[cl_kg(FEAT)];
     load_frags<FEAT>(f, feat, rb, RB, M, L);
     for (; rb < RB; rb += stride) {
@@ -440,7 +461,7 @@ struct TrunkBwdLds {
 };
 
 template <int FEAT, int HID, int OUT, int CHAIN_THREADS>
-__global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_bwd(const float *__restrict__ gy, const float *__restrict__ y, int act,
+__device__ __forceinline__ void trunk_bwd_body(int blk, int nblk, const float *__restrict__ gy, const float *__restrict__ y, int act,
                                                              const float *__restrict__ h, const float *__restrict__ gamma,
                                                              const float *__restrict__ z1, TrunkW w, float *__restrict__ go,
                                                              float *__restrict__ gbeta, float *__restrict__ ggamma,
@@ -457,7 +478,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_bwd(const float *__rest
     stage_block<true>(w.W1, FEAT, HID, 0, FEAT, lds + S::o_w1, S::LDH, 0, L.tid, CHAIN_THREADS);
     __syncthreads();
     long long rb, RB, stride;
-    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    row_blocks<CHAIN_THREADS / 64>(M, L, blk, nblk, rb, RB, stride);
     constexpr int NTO = cl_kg(OUT);
     v4f g0[NTO], yv[NTO];
     {
@@ -532,6 +553,79 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_bwd(const float *__rest
 #pragma unroll
         for (int t = 0; t < S::NTF; t++) of.store(t, pf[t]);
     }
+}
+
+// ---- one launch for up to MAX_NETS generators (workgroup b serves network b % n) ----------------------------------------------
+struct FilmFwdBatch {
+    int n;
+    FilmW w[MAX_NETS];
+    float *cg[MAX_NETS], *cb[MAX_NETS], *gamma[MAX_NETS], *beta[MAX_NETS];
+};
+template <int COND, int HID, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_film_nets_fwd(const float *__restrict__ cond, FilmFwdBatch b, long long M)
+{
+    const NetOfBlock nb(b.n);
+    film_fwd_body<COND, HID, CHAIN_THREADS>(nb.blk, nb.nblk, cond, pick(b.w, nb.net), pick(b.cg, nb.net), pick(b.cb, nb.net),
+                                            pick(b.gamma, nb.net), pick(b.beta, nb.net), M);
+}
+
+struct FilmBwdBatch {
+    int n;
+    const float *ggamma[MAX_NETS], *gbeta[MAX_NETS], *cg[MAX_NETS], *cb[MAX_NETS], *Wg1[MAX_NETS], *Wb1[MAX_NETS];
+    float *gcg[MAX_NETS], *gcb[MAX_NETS];
+};
+template <int COND, int HID, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_film_nets_bwd(FilmBwdBatch b, long long M)
+{
+    const NetOfBlock nb(b.n);
+    film_bwd_body<COND, HID, CHAIN_THREADS>(nb.blk, nb.nblk, pick(b.ggamma, nb.net), pick(b.gbeta, nb.net), pick(b.cg, nb.net),
+                                            pick(b.cb, nb.net), pick(b.Wg1, nb.net), pick(b.Wb1, nb.net), pick(b.gcg, nb.net),
+                                            pick(b.gcb, nb.net), M);
+}
+
+struct TrunkFwdBatch {
+    int n;
+    int out[MAX_NETS], act[MAX_NETS];
+    TrunkW w[MAX_NETS];
+    const float *gamma[MAX_NETS], *beta[MAX_NETS];
+    float *z1[MAX_NETS], *a1[MAX_NETS], *h[MAX_NETS], *x3[MAX_NETS], *y[MAX_NETS];
+};
+template <int FEAT, int HID, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_fwd(const float *__restrict__ feat, TrunkFwdBatch b, long long M)
+{
+    const NetOfBlock nb(b.n);
+    const int i = nb.net;
+#define GSVC_TRUNK_FWD(OUT) trunk_fwd_body<FEAT, HID, OUT, CHAIN_THREADS>(nb.blk, nb.nblk, feat, pick(b.gamma, i), pick(b.beta, i), pick(b.w, i), \
+        pick(b.act, i), pick(b.z1, i), pick(b.a1, i), pick(b.h, i), pick(b.x3, i), pick(b.y, i), M)
+    switch (pick(b.out, i)) {
+        case 10: GSVC_TRUNK_FWD(10); break;
+        case 30: GSVC_TRUNK_FWD(30); break;
+        default: GSVC_TRUNK_FWD(70); break;
+    }
+#undef GSVC_TRUNK_FWD
+}
+
+struct TrunkBwdBatch {
+    int n;
+    int out[MAX_NETS], act[MAX_NETS], accumulate[MAX_NETS];
+    TrunkW w[MAX_NETS];
+    const float *gy[MAX_NETS], *y[MAX_NETS], *h[MAX_NETS], *gamma[MAX_NETS], *z1[MAX_NETS];
+    float *go[MAX_NETS], *gbeta[MAX_NETS], *ggamma[MAX_NETS], *gh[MAX_NETS], *gz1[MAX_NETS], *gfeat[MAX_NETS];
+};
+template <int FEAT, int HID, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_bwd(TrunkBwdBatch b, long long M)
+{
+    const NetOfBlock nb(b.n);
+    const int i = nb.net;
+#define GSVC_TRUNK_BWD(OUT) trunk_bwd_body<FEAT, HID, OUT, CHAIN_THREADS>(nb.blk, nb.nblk, pick(b.gy, i), pick(b.y, i), pick(b.act, i), pick(b.h, i), \
+        pick(b.gamma, i), pick(b.z1, i), pick(b.w, i), pick(b.go, i), pick(b.gbeta, i), pick(b.ggamma, i), pick(b.gh, i), pick(b.gz1, i), \
+        pick(b.gfeat, i), pick(b.accumulate, i), M)
+    switch (pick(b.out, i)) {
+        case 10: GSVC_TRUNK_BWD(10); break;
+        case 30: GSVC_TRUNK_BWD(30); break;
+        default: GSVC_TRUNK_BWD(70); break;
+    }
+#undef GSVC_TRUNK_BWD
 }
 
 // ======================================================================================================= mlp_deform
@@ -743,7 +837,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_deform_b_bwd(const float *__r
 template <int FEAT, int HID, int CHAIN_THREADS>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_deform_a_bwd(const float *__restrict__ g2, const float *__restrict__ z1, DeformW w,
                                                                 int ldw1, float *__restrict__ g1, float *__restrict__ gfeat,
-                                                                int accumulate, long long M)
+                                                                int accumulate, const float *__restrict__ add0,
+                                                                const float *__restrict__ add1, const float *__restrict__ add2, long long M)
 {
     extern __shared__ float lds[];
     constexpr int LD = cl_ld(HID), NTH = cl_kg(HID), NTF = cl_kg(FEAT), o_w1 = NTH * 16 * LD, FLOATS = o_w1 + NTF * 16 * LD;
@@ -763,9 +858,16 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_deform_a_bwd(const float *__r
             const Tiles<HID> tz(z1, rb, RB, M, L);
 #pragma unroll
             for (int t = 0; t < NTH; t++) zz[t] = tz.load(t);
-            const Tiles<FEAT> tf(gfeat, accumulate ? rb : RB, RB, M, L);      // empty descriptor (zeros) when not accumulating
+            // the feature matrix feeds four networks: the generators' trunk backward leaves one gradient each (add0..2), this
+            // kernel sums them on top of its own product (a NULL addend reads as zeros through an empty descriptor)
+            const Tiles<FEAT> tf(gfeat, accumulate ? rb : RB, RB, M, L), t0(add0, add0 ? rb : RB, RB, M, L), t1(add1, add1 ? rb : RB, RB, M, L),
+                t2(add2, add2 ? rb : RB, RB, M, L);
 #pragma unroll
-            for (int t = 0; t < NTF; t++) pf[t] = tf.load(t);
+            for (int t = 0; t < NTF; t++) {
+                const v4f a = tf.load(t), b = t0.load(t), c = t1.load(t), d = t2.load(t);
+#pragma unroll
+                for (int i = 0; i < 4; i++) pf[t][i] = (a[i] + b[i]) + (c[i] + d[i]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         v4f p[NTH];
@@ -797,7 +899,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_deform_a_bwd(const float *__r
 constexpr int CHAIN_T = 512;
 
 template <typename... KA, typename... A>
-void chain_launch(const char *name, void (*k)(KA...), size_t lds, long long M, hipStream_t s, A... args)
+void chain_launch(const char *name, void (*k)(KA...), size_t lds, long long M, int min_grid, hipStream_t s, A... args)
 {
     static std::mutex mu;
     static std::set<const void *> done;
@@ -808,7 +910,7 @@ void chain_launch(const char *name, void (*k)(KA...), size_t lds, long long M, h
     }
     const int waves = CHAIN_T / 64;
     const long long RB = (M + 15) / 16, want = (RB + waves - 1) / waves;
-    const unsigned grid = (unsigned)(want < 256 ? (want < 1 ? 1 : want) : 256);
+    const unsigned grid = (unsigned)(want < 256 ? (want < min_grid ? min_grid : want) : 256);      // every network of a batch gets a workgroup
     ProfScope _p(name, s);
     hipLaunchKernelGGL(k, dim3(grid), dim3(CHAIN_T), lds, s, static_cast<KA>(args)...);
 }
@@ -860,45 +962,81 @@ long long gen_wgrad_floats(int out)
            2 * gsvc_linear_wgrad_workspace(COND, COND) + 2 * gsvc_linear_wgrad_workspace(HID, COND);
 }
 
-template <int OUT>
-int generator_forward_t(const gsvc_generator_net *n, const float *feat, const float *cond, long long M, float *saved, float *y, hipStream_t s)
+int generators_forward(const gsvc_generator_net *nets, int n, const float *feat, const float *cond, long long M, float *const *saved,
+                       float *const *y, hipStream_t s)
 {
-    const GenSaved sv(saved, M);
-    chain_launch("k_film_nets_fwd", &k_film_nets_fwd<COND, HID, CHAIN_T>, FilmFwdLds<COND, HID>::FLOATS * 4, M, s,
-                 cond, FilmW{n->Wg0, n->bg0, n->Wg1, n->bg1, n->Wb0, n->bb0, n->Wb1, n->bb1}, sv.cg, sv.cb, sv.gamma, sv.beta, M);
-    chain_launch("k_trunk_fwd", &k_trunk_fwd<FEAT, HID, OUT, CHAIN_T>, TrunkFwdLds<FEAT, HID, OUT>::FLOATS * 4, M, s,
-                 feat, sv.gamma, sv.beta, TrunkW{n->W1, n->b1, n->W2, n->b2, n->W3, n->b3}, (int)n->out_act, sv.z1, sv.a1, sv.h, sv.x3, y, M);
-    return check_launch("generator_forward");
+    FilmFwdBatch fb;
+    TrunkFwdBatch tb;
+    fb.n = tb.n = n;
+    for (int i = 0; i < MAX_NETS; i++) {
+        const gsvc_generator_net &g = nets[i < n ? i : 0];
+        const GenSaved sv(saved[i < n ? i : 0], M);
+        fb.w[i] = FilmW{g.Wg0, g.bg0, g.Wg1, g.bg1, g.Wb0, g.bb0, g.Wb1, g.bb1};
+        fb.cg[i] = sv.cg; fb.cb[i] = sv.cb; fb.gamma[i] = sv.gamma; fb.beta[i] = sv.beta;
+        tb.out[i] = g.out_dim; tb.act[i] = g.out_act;
+        tb.w[i] = TrunkW{g.W1, g.b1, g.W2, g.b2, g.W3, g.b3};
+        tb.gamma[i] = sv.gamma; tb.beta[i] = sv.beta; tb.z1[i] = sv.z1; tb.a1[i] = sv.a1; tb.h[i] = sv.h; tb.x3[i] = sv.x3;
+        tb.y[i] = y[i < n ? i : 0];
+    }
+    chain_launch("k_film_nets_fwd", &k_film_nets_fwd<COND, HID, CHAIN_T>, FilmFwdLds<COND, HID>::FLOATS * 4, M * n, n, s, cond, fb, M);
+    chain_launch("k_trunk_fwd", &k_trunk_fwd<FEAT, HID, CHAIN_T>, TrunkFwdLds<FEAT, HID, 70>::FLOATS * 4, M * n, n, s, feat, tb, M);
+    return check_launch("generators_forward");
 }
 
-template <int OUT>
-int generator_backward_t(const gsvc_generator_net *n, const float *feat, const float *cond, long long M, const float *saved,
-                         const float *y, const float *gy, float *scratch, float *gfeat, int accumulate, const gsvc_generator_grads *g,
-                         hipStream_t s)
+int generators_backward(const gsvc_generator_net *nets, int n, const float *feat, const float *cond, long long M, const float *const *saved,
+                        const float *const *y, const float *const *gy, float *scratch, float *const *gfeat, const int *accumulate,
+                        const gsvc_generator_grads *grads, hipStream_t s)
 {
-    const GenSaved sv(const_cast<float *>(saved), M);
-    const GenScratch sc(scratch, M, OUT);
-    chain_launch("k_trunk_bwd", &k_trunk_bwd<FEAT, HID, OUT, CHAIN_T>, TrunkBwdLds<FEAT, HID, OUT>::FLOATS * 4, M, s,
-                 gy, y, (int)n->out_act, sv.h, sv.gamma, sv.z1, TrunkW{n->W1, n->b1, n->W2, n->b2, n->W3, n->b3}, sc.go, sc.gbeta, sc.ggamma, sc.gh,
-                 sc.gz1, gfeat, accumulate, M);
-    chain_launch("k_film_nets_bwd", &k_film_nets_bwd<COND, HID, CHAIN_T>, (size_t)2 * cl_kg(COND) * 16 * cl_ld(HID) * 4, M, s, sc.ggamma, sc.gbeta, sv.cg, sv.cb, n->Wg1, n->Wb1, sc.gcg, sc.gcb, M);
-    if (int rc = check_launch("generator_backward")) return rc;
-    // the seven weight gradients dW = G^T X (+ db): row-split partial sums, one batched slot reduce
+    TrunkBwdBatch tb;
+    FilmBwdBatch fb;
+    tb.n = fb.n = n;
+    long long per_net[MAX_NETS];
+    float *sbase[MAX_NETS];
+    {
+        float *cur = scratch;
+        for (int i = 0; i < n; i++) {
+            per_net[i] = gsvc_generator_scratch_floats(&nets[i], M);
+            sbase[i] = cur;
+            cur += (per_net[i] + 3) / 4 * 4;
+        }
+    }
+    for (int i = 0; i < MAX_NETS; i++) {
+        const int j = i < n ? i : 0;
+        const gsvc_generator_net &g = nets[j];
+        const GenSaved sv(const_cast<float *>(saved[j]), M);
+        const GenScratch sc(sbase[j], M, g.out_dim);
+        tb.out[i] = g.out_dim; tb.act[i] = g.out_act; tb.accumulate[i] = accumulate ? accumulate[j] : 0;
+        tb.w[i] = TrunkW{g.W1, g.b1, g.W2, g.b2, g.W3, g.b3};
+        tb.gy[i] = gy[j]; tb.y[i] = y[j]; tb.h[i] = sv.h; tb.gamma[i] = sv.gamma; tb.z1[i] = sv.z1;
+        tb.go[i] = sc.go; tb.gbeta[i] = sc.gbeta; tb.ggamma[i] = sc.ggamma; tb.gh[i] = sc.gh; tb.gz1[i] = sc.gz1; tb.gfeat[i] = gfeat[j];
+        fb.ggamma[i] = sc.ggamma; fb.gbeta[i] = sc.gbeta; fb.cg[i] = sv.cg; fb.cb[i] = sv.cb; fb.Wg1[i] = g.Wg1; fb.Wb1[i] = g.Wb1;
+        fb.gcg[i] = sc.gcg; fb.gcb[i] = sc.gcb;
+    }
+    chain_launch("k_trunk_bwd", &k_trunk_bwd<FEAT, HID, CHAIN_T>, TrunkBwdLds<FEAT, HID, 70>::FLOATS * 4, M * n, n, s, tb, M);
+    chain_launch("k_film_nets_bwd", &k_film_nets_bwd<COND, HID, CHAIN_T>, (size_t)2 * cl_kg(COND) * 16 * cl_ld(HID) * 4, M * n, n, s, fb, M);
+    if (int rc = check_launch("generators_backward")) return rc;
+    // the seven weight gradients dW = G^T X (+ db) of every network: row-split partial sums, batched slot reduces
     struct Job { const float *G, *X; float *dW, *db; int N, K; };
-    const Job jobs[7] = {
-        {sc.gz1, feat, g->W1, g->b1, HID, FEAT},   {sc.gh, sv.a1, g->W2, g->b2, HID, HID},   {sc.go, sv.x3, g->W3, g->b3, OUT, HID},
-        {sc.gcg, cond, g->Wg0, g->bg0, COND, COND}, {sc.ggamma, sv.cg, g->Wg1, g->bg1, HID, COND},
-        {sc.gcb, cond, g->Wb0, g->bb0, COND, COND}, {sc.gbeta, sv.cb, g->Wb1, g->bb1, HID, COND}};
-    gsvc_wgrad_reduce_job red[7];
-    float *ws = sc.wg;
+    gsvc_wgrad_reduce_job red[7 * MAX_NETS];
     int nred = 0;
-    for (const Job &j : jobs) {
-        if (!j.dW) continue;
-        const long long need = gsvc_linear_wgrad_workspace(j.N, j.K);
-        int32_t slots = 0;
-        if (int rc = gsvc_linear_wgrad_partial(j.G, j.X, j.db != nullptr, M, j.N, j.K, ws, need, &slots, s)) return rc;
-        red[nred++] = gsvc_wgrad_reduce_job{ws, j.dW, j.db, slots, j.N, j.K};
-        ws += need;
+    for (int i = 0; i < n; i++) {
+        const gsvc_generator_net &g = nets[i];
+        const gsvc_generator_grads &gr = grads[i];
+        const GenSaved sv(const_cast<float *>(saved[i]), M);
+        const GenScratch sc(sbase[i], M, g.out_dim);
+        const Job jobs[7] = {
+            {sc.gz1, feat, gr.W1, gr.b1, HID, FEAT},    {sc.gh, sv.a1, gr.W2, gr.b2, HID, HID},    {sc.go, sv.x3, gr.W3, gr.b3, g.out_dim, HID},
+            {sc.gcg, cond, gr.Wg0, gr.bg0, COND, COND}, {sc.ggamma, sv.cg, gr.Wg1, gr.bg1, HID, COND},
+            {sc.gcb, cond, gr.Wb0, gr.bb0, COND, COND}, {sc.gbeta, sv.cb, gr.Wb1, gr.bb1, HID, COND}};
+        float *ws = sc.wg;
+        for (const Job &j : jobs) {
+            if (!j.dW) continue;
+            const long long need = gsvc_linear_wgrad_workspace(j.N, j.K);
+            int32_t slots = 0;
+            if (int rc = gsvc_linear_wgrad_partial(j.G, j.X, j.db != nullptr, M, j.N, j.K, ws, need, &slots, s)) return rc;
+            red[nred++] = gsvc_wgrad_reduce_job{ws, j.dW, j.db, slots, j.N, j.K};
+            ws += need;
+        }
     }
     if (nred) return gsvc_linear_wgrad_reduce_many(red, nred, s);
     return GSVC_OK;
@@ -945,38 +1083,60 @@ extern "C" int64_t gsvc_generator_scratch_floats(const gsvc_generator_net *n, in
     return (int64_t)(n->out_dim + 4 * HID + 2 * COND) * M + gen_wgrad_floats(n->out_dim) + 64;
 }
 
+static int gens_supported(const gsvc_generator_net *nets, int32_t n, const char *what)
+{
+    GSVC_REQUIRE(nets && n >= 1 && n <= MAX_NETS, "%s: 1 .. %d networks per call", what, MAX_NETS);
+    for (int i = 0; i < n; i++)
+        if (int rc = gen_supported(&nets[i], what)) return rc;
+    return GSVC_OK;
+}
+
+extern "C" int gsvc_generators_forward(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
+                                       float *const *saved, float *const *y, void *stream)
+{
+    if (int rc = gens_supported(nets, n_nets, "generators_forward")) return rc;
+    GSVC_REQUIRE(M >= 0, "generators_forward: bad row count");
+    if (M == 0) return GSVC_OK;
+    GSVC_REQUIRE(feat && cond && saved && y && aligned16({feat, cond}), "generators_forward: NULL or unaligned pointer");
+    for (int i = 0; i < n_nets; i++)
+        GSVC_REQUIRE(saved[i] && y[i] && aligned16({saved[i], y[i]}), "generators_forward: NULL or unaligned pointer (network %d)", i);
+    return generators_forward(nets, n_nets, feat, cond, M, saved, y, (hipStream_t)stream);
+}
+
+extern "C" int gsvc_generators_backward(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
+                                        const float *const *saved, const float *const *y, const float *const *gy, float *scratch,
+                                        float *const *gfeat, const gsvc_generator_grads *grads, void *stream)
+{
+    if (int rc = gens_supported(nets, n_nets, "generators_backward")) return rc;
+    GSVC_REQUIRE(M >= 0 && grads, "generators_backward: bad arguments");
+    if (M == 0) return GSVC_OK;
+    GSVC_REQUIRE(feat && cond && saved && y && gy && scratch && gfeat && aligned16({feat, cond, scratch}),
+                 "generators_backward: NULL or unaligned pointer");
+    for (int i = 0; i < n_nets; i++) {
+        GSVC_REQUIRE(saved[i] && y[i] && gy[i] && gfeat[i] && aligned16({saved[i], y[i], gy[i], gfeat[i]}),
+                     "generators_backward: NULL or unaligned pointer (network %d)", i);
+        for (int j = 0; j < i; j++) GSVC_REQUIRE(gfeat[i] != gfeat[j], "generators_backward: the networks' feature gradients must be distinct buffers");
+    }
+    return generators_backward(nets, n_nets, feat, cond, M, saved, y, gy, scratch, gfeat, nullptr, grads, (hipStream_t)stream);
+}
+
 extern "C" int gsvc_generator_forward(const gsvc_generator_net *n, const float *feat, const float *cond, int64_t M, float *saved, float *y,
                                       void *stream)
 {
-    if (int rc = gen_supported(n, "generator_forward")) return rc;
-    GSVC_REQUIRE(M >= 0, "generator_forward: bad row count");
-    if (M == 0) return GSVC_OK;
-    GSVC_REQUIRE(feat && cond && saved && y, "generator_forward: NULL pointer");
-    GSVC_REQUIRE(aligned16({feat, cond, saved, y}), "generator_forward: operands must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    switch (n->out_dim) {
-        case 10: return generator_forward_t<10>(n, feat, cond, M, saved, y, s);
-        case 30: return generator_forward_t<30>(n, feat, cond, M, saved, y, s);
-        default: return generator_forward_t<70>(n, feat, cond, M, saved, y, s);
-    }
+    return gsvc_generators_forward(n, 1, feat, cond, M, &saved, &y, stream);
 }
 
 extern "C" int gsvc_generator_backward(const gsvc_generator_net *n, const float *feat, const float *cond, int64_t M, const float *saved,
                                        const float *y, const float *gy, float *scratch, float *gfeat, int32_t accumulate_gfeat,
                                        const gsvc_generator_grads *grads, void *stream)
 {
-    if (int rc = gen_supported(n, "generator_backward")) return rc;
+    if (int rc = gens_supported(n, 1, "generator_backward")) return rc;
     GSVC_REQUIRE(M >= 0 && grads, "generator_backward: bad arguments");
     if (M == 0) return GSVC_OK;
     GSVC_REQUIRE(feat && cond && saved && y && gy && scratch && gfeat, "generator_backward: NULL pointer");
-    GSVC_REQUIRE(aligned16({feat, cond, saved, y, gy, scratch, gfeat}),
-                 "generator_backward: operands must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    switch (n->out_dim) {
-        case 10: return generator_backward_t<10>(n, feat, cond, M, saved, y, gy, scratch, gfeat, accumulate_gfeat, grads, s);
-        case 30: return generator_backward_t<30>(n, feat, cond, M, saved, y, gy, scratch, gfeat, accumulate_gfeat, grads, s);
-        default: return generator_backward_t<70>(n, feat, cond, M, saved, y, gy, scratch, gfeat, accumulate_gfeat, grads, s);
-    }
+    GSVC_REQUIRE(aligned16({feat, cond, saved, y, gy, scratch, gfeat}), "generator_backward: operands must be 16-byte aligned");
+    const int acc = accumulate_gfeat;
+    return generators_backward(n, 1, feat, cond, M, &saved, &y, &gy, scratch, &gfeat, &acc, grads, (hipStream_t)stream);
 }
 
 static int deform_supported(const gsvc_deform_net *n, const char *what)
@@ -1016,18 +1176,23 @@ extern "C" int gsvc_deform_forward(const gsvc_deform_net *n, const float *feat, 
     for (int i = 0; i < 5; i++) { w.W[i] = n->W[i]; w.b[i] = n->b[i]; }
     float *z1 = saved, *a1 = z1 + M * HID, *z2 = a1 + M * HID, *a2 = z2 + M * HID, *z3 = a2 + M * HID, *a3 = z3 + M * HID,
           *z4 = a3 + M * HID, *a4 = z4 + M * HID;
-    chain_launch("k_deform_a_fwd", &k_deform_a_fwd<FEAT, COND, HID, CHAIN_T>, DeformALds<FEAT, COND, HID>::FLOATS * 4, M, s, feat, cond, w, z1, a1, z2, a2, M);
-    chain_launch("k_deform_b_fwd", &k_deform_b_fwd<HID, DEF_OUT, CHAIN_T>, DeformBLds<HID, DEF_OUT>::FLOATS * 4, M, s,
+    chain_launch("k_deform_a_fwd", &k_deform_a_fwd<FEAT, COND, HID, CHAIN_T>, DeformALds<FEAT, COND, HID>::FLOATS * 4, M, 1, s, feat, cond, w, z1, a1, z2, a2, M);
+    chain_launch("k_deform_b_fwd", &k_deform_b_fwd<HID, DEF_OUT, CHAIN_T>, DeformBLds<HID, DEF_OUT>::FLOATS * 4, M, 1, s,
                  a2, w, z3, a3, z4, a4, y, M);
     return check_launch("deform_forward");
 }
 
 extern "C" int gsvc_deform_backward(const gsvc_deform_net *n, const float *feat, const float *cond, int64_t M, const float *saved,
-                                    const float *gy, float *scratch, float *gfeat, int32_t accumulate_gfeat, const gsvc_deform_grads *grads,
-                                    void *stream)
+                                    const float *gy, float *scratch, float *gfeat, int32_t accumulate_gfeat,
+                                    const float *const *gfeat_addends, int32_t n_addends, const gsvc_deform_grads *grads, void *stream)
 {
     if (int rc = deform_supported(n, "deform_backward")) return rc;
-    GSVC_REQUIRE(M >= 0 && grads, "deform_backward: bad arguments");
+    GSVC_REQUIRE(M >= 0 && grads && n_addends >= 0 && n_addends <= 3 && (n_addends == 0 || gfeat_addends), "deform_backward: bad arguments");
+    const float *add[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < n_addends; i++) {
+        GSVC_REQUIRE(gfeat_addends[i] && aligned16({gfeat_addends[i]}) && gfeat_addends[i] != gfeat, "deform_backward: bad addend %d", i);
+        add[i] = gfeat_addends[i];
+    }
     if (M == 0) return GSVC_OK;
     GSVC_REQUIRE(feat && cond && saved && gy && scratch && gfeat, "deform_backward: NULL pointer");
     GSVC_REQUIRE(aligned16({feat, cond, saved, gy, scratch, gfeat}),
@@ -1040,8 +1205,8 @@ extern "C" int gsvc_deform_backward(const gsvc_deform_net *n, const float *feat,
     float *g1 = scratch, *g2 = g1 + M * HID, *g3 = g2 + M * HID, *g4 = g3 + M * HID, *ws = g4 + M * HID;
     ws = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 15) & ~uintptr_t(15));
     chain_launch("k_deform_b_bwd", &k_deform_b_bwd<HID, DEF_OUT, CHAIN_T>, DeformBBwdLds<HID, DEF_OUT>::FLOATS * 4,
-                 M, s, gy, z4, z3, z2, w, g4, g3, g2, M);
-    chain_launch("k_deform_a_bwd", &k_deform_a_bwd<FEAT, HID, CHAIN_T>, (size_t)(cl_kg(HID) + cl_kg(FEAT)) * 16 * cl_ld(HID) * 4, M, s, g2, z1, w, FEAT + COND, g1, gfeat, (int)accumulate_gfeat, M);
+                 M, 1, s, gy, z4, z3, z2, w, g4, g3, g2, M);
+    chain_launch("k_deform_a_bwd", &k_deform_a_bwd<FEAT, HID, CHAIN_T>, (size_t)(cl_kg(HID) + cl_kg(FEAT)) * 16 * cl_ld(HID) * 4, M, 1, s, g2, z1, w, FEAT + COND, g1, gfeat, (int)accumulate_gfeat, add[0], add[1], add[2], M);
     if (int rc = check_launch("deform_backward")) return rc;
     // weight gradients; layer 1 = [g1^T feat | g1^T cond] formed as two products into a staging area, interleaved by the caller's
     // layout (grads->W[0] is [HID][FEAT + COND]): the reduce writes contiguous [N][K] blocks, so the two halves go to scratch

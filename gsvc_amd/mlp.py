@@ -331,9 +331,15 @@ def _deform_desc(params):
     return d
 
 
+def _ptr_array(tensors):
+    import ctypes as C
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 class _GenerateAll(torch.autograd.Function):
     """(opacity, color, cov, deform) outputs of the three GeneratorNets and mlp_deform for the rows (feature, condition).
-    params = 3 x 14 generator tensors (GEN_FIELDS order) + 5 x (W, b) of mlp_deform; acts = the generators' output activations."""
+    params = 3 x 14 generator tensors (GEN_FIELDS order) + 5 x (W, b) of mlp_deform; acts = the generators' output activations.
+    The three generators run as ONE pair of launches each way (gsvc_generators_*: workgroup b serves network b % 3)."""
 
     @staticmethod
     def forward(ctx, feat, cond, acts, *params):
@@ -342,17 +348,16 @@ class _GenerateAll(torch.autograd.Function):
         params = [p.contiguous() for p in params]
         M, dev = feat.shape[0], feat.device
         L, st = _lib.lib(), _lib.current_stream(dev)
-        outs, saved, descs = [], [], []
+        nets = (_lib.GeneratorNetC * 3)()
+        outs, saved = [], []
         for g in range(3):
             pg = params[14 * g:14 * (g + 1)]
-            out_dim = pg[4].shape[0]
-            d = _gen_desc(pg, acts[g], out_dim)
-            sv = torch.empty(int(L.gsvc_generator_saved_floats(C.byref(d), M)), device=dev, dtype=torch.float32)
-            y = torch.empty(M, out_dim, device=dev, dtype=torch.float32)
-            _lib.check(L.gsvc_generator_forward(C.byref(d), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(sv), _lib.ptr(y), st),
-                       "gsvc_generator_forward")
-            outs.append(y)
-            saved.append(sv)
+            d = _gen_desc(pg, acts[g], pg[4].shape[0])
+            C.memmove(C.byref(nets[g]), C.byref(d), C.sizeof(d))
+            saved.append(torch.empty(int(L.gsvc_generator_saved_floats(C.byref(d), M)), device=dev, dtype=torch.float32))
+            outs.append(torch.empty(M, pg[4].shape[0], device=dev, dtype=torch.float32))
+        _lib.check(L.gsvc_generators_forward(nets, 3, _lib.ptr(feat), _lib.ptr(cond), M, _ptr_array(saved), _ptr_array(outs), st),
+                   "gsvc_generators_forward")
         pd = params[42:52]
         dd = _deform_desc(pd)
         sv = torch.empty(int(L.gsvc_deform_saved_floats(C.byref(dd), M)), device=dev, dtype=torch.float32)
@@ -372,48 +377,43 @@ class _GenerateAll(torch.autograd.Function):
         M, dev = feat.shape[0], feat.device
         L, st = _lib.lib(), _lib.current_stream(dev)
         need = ctx.needs_input_grad
-        gfeat = torch.empty_like(feat)
-        first = True
-        grads = [None] * len(params)
-        scratch = None
-        for g in range(4):
-            if gys[g] is None:
-                continue
-            gy = gys[g].contiguous()
-            pg = params[14 * g:14 * (g + 1)] if g < 3 else params[42:52]
-            flat = torch.empty(sum(p.numel() for p in pg), device=dev, dtype=torch.float32)
-            views, at = [], 0
-            for p in pg:
-                views.append(flat[at:at + p.numel()].view(p.shape))
-                at += p.numel()
-            for i, v in enumerate(views):
-                grads[(14 * g if g < 3 else 42) + i] = v
-            if g < 3:
-                d = _gen_desc(pg, ctx.acts[g], pg[4].shape[0])
-                n = int(L.gsvc_generator_scratch_floats(C.byref(d), M))
-                if scratch is None or scratch.numel() < n:
-                    scratch = torch.empty(n, device=dev, dtype=torch.float32)
-                gd = _lib.GeneratorGradsC()
-                for name, v in zip(GEN_FIELDS, views):
-                    setattr(gd, name, v.data_ptr())
-                _lib.check(L.gsvc_generator_backward(C.byref(d), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(saved[g]), _lib.ptr(ys[g]),
-                                                     _lib.ptr(gy), _lib.ptr(scratch), _lib.ptr(gfeat), 0 if first else 1, C.byref(gd), st),
-                           "gsvc_generator_backward")
-            else:
-                d = _deform_desc(pg)
-                n = int(L.gsvc_deform_scratch_floats(C.byref(d), M))
-                if scratch is None or scratch.numel() < n:
-                    scratch = torch.empty(n, device=dev, dtype=torch.float32)
-                gd = _lib.DeformGradsC()
-                for i in range(5):
-                    gd.W[i], gd.b[i] = views[2 * i].data_ptr(), views[2 * i + 1].data_ptr()
-                _lib.check(L.gsvc_deform_backward(C.byref(d), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(saved[3]), _lib.ptr(gy),
-                                                  _lib.ptr(scratch), _lib.ptr(gfeat), 0 if first else 1, C.byref(gd), st),
-                           "gsvc_deform_backward")
-            first = False
-        if first:
-            gfeat = None
-        return (gfeat if need[0] else None, None, None, *grads)
+        # an output nobody used has no gradient: it contributes zeros (rare: every training mode reads all four)
+        gys = [g.contiguous() if g is not None else torch.zeros(M, n, device=dev, dtype=torch.float32) for g, n in
+               zip(gys, [y.shape[1] for y in ys] + [30])]
+        flat = torch.empty(sum(p.numel() for p in params), device=dev, dtype=torch.float32)      # every weight / bias gradient, back to back
+        grads, at = [], 0
+        for p in params:
+            grads.append(flat[at:at + p.numel()].view(p.shape))
+            at += p.numel()
+        nets = (_lib.GeneratorNetC * 3)()
+        gds = (_lib.GeneratorGradsC * 3)()
+        total = 0
+        for g in range(3):
+            pg = params[14 * g:14 * (g + 1)]
+            d = _gen_desc(pg, ctx.acts[g], pg[4].shape[0])
+            C.memmove(C.byref(nets[g]), C.byref(d), C.sizeof(d))
+            for name, v in zip(GEN_FIELDS, grads[14 * g:14 * (g + 1)]):
+                setattr(gds[g], name, v.data_ptr())
+            total += (int(L.gsvc_generator_scratch_floats(C.byref(d), M)) + 3) // 4 * 4
+        dd = _deform_desc(params[42:52])
+        total = max(total, int(L.gsvc_deform_scratch_floats(C.byref(dd), M)))
+        scratch = torch.empty(total, device=dev, dtype=torch.float32)
+        F_ = feat.shape[1]
+        per = (M * F_ + 3) // 4 * 4                                                      # every buffer starts 16-byte aligned
+        gflat = torch.empty(4 * per, device=dev, dtype=torch.float32)                   # three generators' + the sum
+        gfeats = [gflat[i * per:i * per + M * F_].view(M, F_) for i in range(4)]
+        gen_gf = gfeats[:3]
+        _lib.check(L.gsvc_generators_backward(nets, 3, _lib.ptr(feat), _lib.ptr(cond), M, _ptr_array(saved[:3]), _ptr_array(ys),
+                                              _ptr_array(gys[:3]), _lib.ptr(scratch), _ptr_array(gen_gf), gds, st), "gsvc_generators_backward")
+        gd = _lib.DeformGradsC()
+        for i in range(5):
+            gd.W[i], gd.b[i] = grads[42 + 2 * i].data_ptr(), grads[43 + 2 * i].data_ptr()
+        # the deformation network's backward runs behind the generators' (same stream): it reuses their scratch and adds their
+        # three feature gradients to its own in the pass that writes gfeat
+        _lib.check(L.gsvc_deform_backward(C.byref(dd), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(saved[3]), _lib.ptr(gys[3]),
+                                          _lib.ptr(scratch), _lib.ptr(gfeats[3]), 0, _ptr_array(gen_gf), 3, C.byref(gd), st),
+                   "gsvc_deform_backward")
+        return (gfeats[3] if need[0] else None, None, None, *grads)
 
 
 def generate_all(gens, deform_linears, feat, cond):

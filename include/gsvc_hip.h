@@ -518,10 +518,20 @@ typedef struct gsvc_generator_net {
 typedef struct gsvc_generator_grads {
     float *W1, *b1, *W2, *b2, *W3, *b3, *Wg0, *bg0, *Wg1, *bg1, *Wb0, *bb0, *Wb1, *bb1;
 } gsvc_generator_grads;
+ /* gsvc_generators_*: n_nets (1 .. 3) networks on the same (feat, cond) rows in ONE pair of launches each way (workgroup b serves
+ * network b % n_nets: one prologue and one partial last round for all of them).  saved / y / gy / gfeat are arrays of n_nets
+ * pointers; `scratch` holds the networks' regions back to back (sum of gsvc_generator_scratch_floats, each rounded up to a
+ * multiple of 4 floats); gfeat[i] receives network i's feature gradient (distinct buffers, written, not accumulated: pass them
+ * to gsvc_deform_backward as addends, or add them up). */
 int64_t gsvc_generator_saved_floats(const gsvc_generator_net *net, int64_t M);
 int64_t gsvc_generator_scratch_floats(const gsvc_generator_net *net, int64_t M);
 int gsvc_generator_forward(const gsvc_generator_net *net, const float *feat, const float *cond, int64_t M, float *saved, float *y,
                            void *stream);
+int gsvc_generators_forward(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
+                            float *const *saved, float *const *y, void *stream);
+int gsvc_generators_backward(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
+                             const float *const *saved, const float *const *y, const float *const *gy, float *scratch,
+                             float *const *gfeat, const gsvc_generator_grads *grads, void *stream);
 int gsvc_generator_backward(const gsvc_generator_net *net, const float *feat, const float *cond, int64_t M, const float *saved,
                             const float *y, const float *gy, float *scratch, float *gfeat, int32_t accumulate_gfeat,
                             const gsvc_generator_grads *grads, void *stream);
@@ -536,8 +546,10 @@ typedef struct gsvc_deform_grads {
 int64_t gsvc_deform_saved_floats(const gsvc_deform_net *net, int64_t M);
 int64_t gsvc_deform_scratch_floats(const gsvc_deform_net *net, int64_t M);
 int gsvc_deform_forward(const gsvc_deform_net *net, const float *feat, const float *cond, int64_t M, float *saved, float *y, void *stream);
+/* gfeat_addends: n_addends (0 .. 3) further [M, feat] gradients summed into gfeat in the same pass (the generators' feature gradients) */
 int gsvc_deform_backward(const gsvc_deform_net *net, const float *feat, const float *cond, int64_t M, const float *saved, const float *gy,
-                         float *scratch, float *gfeat, int32_t accumulate_gfeat, const gsvc_deform_grads *grads, void *stream);
+                         float *scratch, float *gfeat, int32_t accumulate_gfeat, const float *const *gfeat_addends, int32_t n_addends,
+                         const gsvc_deform_grads *grads, void *stream);
 
 #ifdef __cplusplus
 }
