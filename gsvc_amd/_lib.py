@@ -48,6 +48,11 @@ class WgradReduceJobC(C.Structure):
                 ("K", C.c_int32)]
 
 
+class WgradPartialJobC(C.Structure):
+    _fields_ = [("G", C.c_void_p), ("X", C.c_void_p), ("workspace", C.c_void_p), ("M", C.c_int64), ("workspace_floats", C.c_int64),
+                ("want_db", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("slots_used", C.c_int32)]
+
+
 class RateSampleC(C.Structure):
     _fields_ = [("x", C.c_void_p * 3), ("mean", C.c_void_p * 3), ("scale", C.c_void_p * 3), ("Q", C.c_void_p * 3),
                 ("mask", C.c_void_p), ("sel", C.c_void_p), ("sel_ctx", C.c_void_p), ("row_bounds", C.POINTER(C.c_int64)),
@@ -152,6 +157,7 @@ _SIGNATURES = {
     "gsvc_linear_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, _vp, _i64, _vp]),
     "gsvc_linear_wgrad_partial": (C.c_int, [_vp, _vp, C.c_int32, _i64, C.c_int32, C.c_int32, _vp, _i64, C.POINTER(C.c_int32), _vp]),
     "gsvc_linear_wgrad_reduce_many": (C.c_int, [C.POINTER(WgradReduceJobC), C.c_int32, _vp]),
+    "gsvc_linear_wgrad_partial_many": (C.c_int, [C.POINTER(WgradPartialJobC), C.c_int32, _vp]),
     "gsvc_linear_wgrad_workspace": (_i64, [C.c_int32, C.c_int32]),
     "gsvc_generator_saved_floats": (_i64, [C.POINTER(GeneratorNetC), _i64]),
     "gsvc_generator_scratch_floats": (_i64, [C.POINTER(GeneratorNetC), _i64]),

@@ -225,9 +225,10 @@ __device__ __forceinline__ void wg_block_tiles(int tiles, int blocks, int b, int
     count = base + (b < rem ? 1 : 0);
 }
 
-__global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const float *__restrict__ G, const float *__restrict__ X,
-                                                                     float *__restrict__ part, int want_db, long long M, int N, int K,
-                                                                     int BN, int BK, int RS)
+// wg of nwg: this workgroup's index among the workgroups that work on this product (a launch may carry several products:
+// k_linear_wgrad_many below)
+__device__ __forceinline__ void wgrad_t_body(const float *__restrict__ G, const float *__restrict__ X, float *__restrict__ part, int want_db,
+                                             long long M, int N, int K, int BN, int BK, int RS, int wg, int nwg)
 {
     extern __shared__ float sm[];      // [BN*BK][64][64]
     __shared__ float sdb[WG_MAX_WAVES][LIN_NT_MAX * 16];      // per row split: summed in a fixed order below (no float atomics)
@@ -250,8 +251,8 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const floa
     wg_block_tiles((N + 15) >> 4, BN, bn, tn0, TN);
     wg_block_tiles((K + 15) >> 4, BK, bk, tk0, TK);
     const int n0 = 16 * tn0, k0 = 16 * tk0;
-    const long long workers = (long long)gridDim.x * RS;
-    const long long rb = (long long)rs * gridDim.x + blockIdx.x;    // chunks dealt row-split-major (see k_linear_ws)
+    const long long workers = (long long)nwg * RS;
+    const long long rb = (long long)rs * nwg + wg;      // chunks dealt row-split-major (see k_linear_ws)
     for (int i = tid; i < WG_MAX_WAVES * LIN_NT_MAX * 16; i += blockDim.x) (&sdb[0][0])[i] = 0.f;
     __syncthreads();
 
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const floa
         }
         __syncthreads();
     }
-    float *out = part + (size_t)blockIdx.x * ((size_t)N * K + (want_db ? N : 0));
+    float *out = part + (size_t)wg * ((size_t)N * K + (want_db ? N : 0));
     for (int i = tid; i < pairs * 4096; i += blockDim.x) {
         const int pr = i >> 12, nl = (i >> 6) & 63, kl = i & 63;
         int f, c, g, e;
@@ -316,6 +317,51 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const floa
             for (int r = 1; r < RS; r++) v += sdb[r][n];
             out[(size_t)N * K + n] = v;
         }
+}
+
+__global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const float *__restrict__ G, const float *__restrict__ X,
+                                                                     float *__restrict__ part, int want_db, long long M, int N, int K,
+                                                                     int BN, int BK, int RS)
+{
+    wgrad_t_body(G, X, part, want_db, M, N, K, BN, BK, RS, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several products in ONE launch (the weight gradients of a whole network: 6-7 layers over the same rows): the workgroups are
+// dealt to the products in proportion to their MFMA work, each product's workgroups fill its own slots.  One prologue, one
+// row-split meeting and one partial last round per network instead of one per layer (a launch of this kernel costs ~10-15 us
+// beyond its MFMAs: at 40 launches per fitting step that was a quarter of the weight-gradient time).  Every product of a batch
+// runs 12 waves (output blocks x row splits = 12).
+constexpr int WG_MANY = 8;
+struct WgManyJobs {
+    int n;
+    const float *G[WG_MANY], *X[WG_MANY];
+    float *part[WG_MANY];
+    long long M[WG_MANY];
+    int want_db[WG_MANY], N[WG_MANY], K[WG_MANY], BN[WG_MANY], BK[WG_MANY], RS[WG_MANY], first[WG_MANY + 1];
+};
+template <typename T>
+__device__ __forceinline__ T wg_pick(const T (&a)[WG_MANY], int i)
+{
+    T v = a[0];
+#pragma unroll
+    for (int q = 1; q < WG_MANY; q++) v = i == q ? a[q] : v;
+    return v;
+}
+
+__global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_many(WgManyJobs t)
+{
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < WG_MANY; q++)
+        if (q < t.n && (int)blockIdx.x >= t.first[q]) j = q;
+    int f0 = t.first[0];
+#pragma unroll
+    for (int q = 1; q < WG_MANY; q++) f0 = j == q ? t.first[q] : f0;
+    int f1 = t.first[WG_MANY];
+#pragma unroll
+    for (int q = WG_MANY - 1; q >= 1; q--) f1 = j == q - 1 ? t.first[q] : f1;
+    wgrad_t_body(wg_pick(t.G, j), wg_pick(t.X, j), wg_pick(t.part, j), wg_pick(t.want_db, j), wg_pick(t.M, j), wg_pick(t.N, j),
+                 wg_pick(t.K, j), wg_pick(t.BN, j), wg_pick(t.BK, j), wg_pick(t.RS, j), (int)blockIdx.x - f0, f1 - f0);
 }
 
 // dst[i] = sum over the workgroup slots of part[slot][i]: 64 outputs per workgroup, the slots dealt to its 16 waves (256 slots:
@@ -507,6 +553,95 @@ extern "C" int gsvc_linear_wgrad_partial(const float *G, const float *X, int32_t
     GSVC_REQUIRE(slots_used, "linear_wgrad_partial: NULL pointer");
     return wgrad_launch(G, X, nullptr, nullptr, want_db != 0, M, N, K, workspace, workspace_floats, (hipStream_t)stream,
                         "linear_wgrad_partial", slots_used);
+}
+
+// Partial sums of several products: those whose blocking gives 12 waves go out together, at most WG_MANY per launch
+// (k_linear_wgrad_many); any other shape takes the single-product path.
+extern "C" int gsvc_linear_wgrad_partial_many(gsvc_wgrad_partial_job *jobs, int32_t n_jobs, void *stream)
+{
+    GSVC_REQUIRE(jobs && n_jobs >= 0, "linear_wgrad_partial_many: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    static const bool single = getenv("GSVC_WGRAD_NO_BATCH") != nullptr;      // A/B timing
+    struct Plan { int job, BN, BK, RS, pairs; double work; };
+    Plan batch[WG_MANY];
+    int nb = 0;
+    auto flush = [&]() -> int {
+        if (nb == 0) return GSVC_OK;
+        WgManyJobs t;
+        t.n = nb;
+        double total = 0;
+        for (int i = 0; i < nb; i++) total += batch[i].work;
+        // workgroups per product in proportion to its MFMA work, at least one, at most its slots / its 16-row chunks
+        int wgs[WG_MANY], sum = 0, max_pairs = 1;
+        for (int i = 0; i < nb; i++) {
+            const gsvc_wgrad_partial_job &q = jobs[batch[i].job];
+            const long long per_slot = (long long)q.N * q.K + (q.want_db ? q.N : 0);
+            long long cap = q.workspace_floats / per_slot;
+            const long long chunks = ((q.M + 15) / 16 + batch[i].RS - 1) / batch[i].RS;
+            if (cap > chunks) cap = chunks;
+            if (cap > 256) cap = 256;
+            int w = (int)(256.0 * batch[i].work / total + 0.5);
+            if (w < 1) w = 1;
+            if (w > cap) w = (int)cap;
+            wgs[i] = w;
+            sum += w;
+            if (batch[i].pairs > max_pairs) max_pairs = batch[i].pairs;
+        }
+        while (sum > 256) {      // rounding: take from the largest
+            int big = 0;
+            for (int i = 1; i < nb; i++)
+                if (wgs[i] > wgs[big]) big = i;
+            wgs[big]--;
+            sum--;
+        }
+        int at = 0;
+        for (int i = 0; i < WG_MANY; i++) {
+            const int k = i < nb ? i : 0;
+            const gsvc_wgrad_partial_job &q = jobs[batch[k].job];
+            t.G[i] = q.G; t.X[i] = q.X; t.part[i] = q.workspace; t.M[i] = q.M; t.want_db[i] = q.want_db ? 1 : 0; t.N[i] = q.N; t.K[i] = q.K;
+            t.BN[i] = batch[k].BN; t.BK[i] = batch[k].BK; t.RS[i] = batch[k].RS;
+            t.first[i] = at;
+            if (i < nb) {
+                jobs[batch[i].job].slots_used = wgs[i];
+                at += wgs[i];
+            }
+        }
+        t.first[WG_MANY] = at;
+        for (int i = nb; i < WG_MANY; i++) t.first[i] = at;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_wgrad_many), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_set = true;
+        }
+        ProfScope _prof("k_linear_wgrad", s);
+        hipLaunchKernelGGL(k_linear_wgrad_many, dim3(at), dim3(64 * WG_MAX_WAVES), (size_t)max_pairs * 4096 * sizeof(float), s, t);
+        nb = 0;
+        return check_launch("linear_wgrad_partial_many");
+    };
+    for (int j = 0; j < n_jobs; j++) {
+        gsvc_wgrad_partial_job &q = jobs[j];
+        GSVC_REQUIRE(q.M > 0 && q.K > 0 && q.N > 0 && q.G && q.X && q.workspace, "linear_wgrad_partial_many: bad job %d", j);
+        q.slots_used = 0;
+        const int vg = vec_of(q.G, q.N), vx = vec_of(q.X, q.K);
+        const int mt_g = vg == 4 ? 4 : 3, mt_x = vx == 4 ? 4 : 3;
+        const int BN = ((q.N + 15) / 16 + mt_g - 1) / mt_g, BK = ((q.K + 15) / 16 + mt_x - 1) / mt_x, pairs = BN * BK;
+        const long long per_slot = (long long)q.N * q.K + (q.want_db ? q.N : 0);
+        const bool fits = q.N <= LIN_NT_MAX * 16 && q.K <= LIN_NT_MAX * 16 && pairs <= 9 && WG_MAX_WAVES % pairs == 0 &&
+                          q.workspace_floats >= per_slot && !getenv("GSVC_WGRAD_BLOCK64");
+        if (single || !fits) {
+            if (int rc = flush()) return rc;
+            int used = 0;
+            if (int rc = wgrad_launch(q.G, q.X, nullptr, nullptr, q.want_db != 0, q.M, q.N, q.K, q.workspace, q.workspace_floats, s,
+                                      "linear_wgrad_partial_many", &used))
+                return rc;
+            q.slots_used = used;
+            continue;
+        }
+        batch[nb++] = Plan{j, BN, BK, WG_MAX_WAVES / pairs, pairs, (double)((q.N + 15) / 16) * ((q.K + 15) / 16) * (double)((q.M + 15) / 16)};
+        if (nb == WG_MANY)
+            if (int rc = flush()) return rc;
+    }
+    return flush();
 }
 
 extern "C" int gsvc_linear_wgrad_reduce_many(const gsvc_wgrad_reduce_job *jobs, int32_t n_jobs, void *stream)

@@ -1017,6 +1017,7 @@ int generators_backward(const gsvc_generator_net *nets, int n, const float *feat
     if (int rc = check_launch("generators_backward")) return rc;
     // the seven weight gradients dW = G^T X (+ db) of every network: row-split partial sums, batched slot reduces
     struct Job { const float *G, *X; float *dW, *db; int N, K; };
+    gsvc_wgrad_partial_job part[7 * MAX_NETS];
     gsvc_wgrad_reduce_job red[7 * MAX_NETS];
     int nred = 0;
     for (int i = 0; i < n; i++) {
@@ -1032,13 +1033,16 @@ int generators_backward(const gsvc_generator_net *nets, int n, const float *feat
         for (const Job &j : jobs) {
             if (!j.dW) continue;
             const long long need = gsvc_linear_wgrad_workspace(j.N, j.K);
-            int32_t slots = 0;
-            if (int rc = gsvc_linear_wgrad_partial(j.G, j.X, j.db != nullptr, M, j.N, j.K, ws, need, &slots, s)) return rc;
-            red[nred++] = gsvc_wgrad_reduce_job{ws, j.dW, j.db, slots, j.N, j.K};
+            part[nred] = gsvc_wgrad_partial_job{j.G, j.X, ws, M, need, j.db != nullptr, j.N, j.K, 0};
+            red[nred++] = gsvc_wgrad_reduce_job{ws, j.dW, j.db, 0, j.N, j.K};
             ws += need;
         }
     }
-    if (nred) return gsvc_linear_wgrad_reduce_many(red, nred, s);
+    if (nred) {
+        if (int rc = gsvc_linear_wgrad_partial_many(part, nred, s)) return rc;
+        for (int i = 0; i < nred; i++) red[i].slots = part[i].slots_used;
+        return gsvc_linear_wgrad_reduce_many(red, nred, s);
+    }
     return GSVC_OK;
 }
 
@@ -1219,18 +1223,21 @@ extern "C" int gsvc_deform_backward(const gsvc_deform_net *n, const float *feat,
     const Job jobs[6] = {{g1, feat, want1 ? stage_f : nullptr, grads->b[0], HID, FEAT}, {g1, cond, want1 ? stage_c : nullptr, nullptr, HID, COND},
                          {g2, a1, grads->W[1], grads->b[1], HID, HID},                 {g3, a2, grads->W[2], grads->b[2], HID, HID},
                          {g4, a3, grads->W[3], grads->b[3], HID, HID},                 {gy, a4, grads->W[4], grads->b[4], DEF_OUT, HID}};
+    gsvc_wgrad_partial_job part[6];
     gsvc_wgrad_reduce_job red[6];
     int nred = 0;
     for (const Job &j : jobs) {
         if (!j.dW) continue;
         const long long need = gsvc_linear_wgrad_workspace(j.N, j.K);
-        int32_t slots = 0;
-        if (int rc = gsvc_linear_wgrad_partial(j.G, j.X, j.db != nullptr, M, j.N, j.K, ws, need, &slots, s)) return rc;
-        red[nred++] = gsvc_wgrad_reduce_job{ws, j.dW, j.db, slots, j.N, j.K};
+        part[nred] = gsvc_wgrad_partial_job{j.G, j.X, ws, M, need, j.db != nullptr, j.N, j.K, 0};
+        red[nred++] = gsvc_wgrad_reduce_job{ws, j.dW, j.db, 0, j.N, j.K};
         ws += need;
     }
-    if (nred)
+    if (nred) {
+        if (int rc = gsvc_linear_wgrad_partial_many(part, nred, s)) return rc;
+        for (int i = 0; i < nred; i++) red[i].slots = part[i].slots_used;
         if (int rc = gsvc_linear_wgrad_reduce_many(red, nred, s)) return rc;
+    }
     if (want1) {
         (void)hipMemcpy2DAsync(grads->W[0], (size_t)(FEAT + COND) * 4, stage_f, (size_t)FEAT * 4, (size_t)FEAT * 4, HID, hipMemcpyDeviceToDevice, s);
         (void)hipMemcpy2DAsync(grads->W[0] + FEAT, (size_t)(FEAT + COND) * 4, stage_c, (size_t)COND * 4, (size_t)COND * 4, HID,

@@ -95,8 +95,8 @@ __global__ void __launch_bounds__(256) k_rate_bwd(const float *__restrict__ x, c
             const float w = weight ? weight[i] : 1.0f;
             // d(-log2 lik)/d lik, zero below the bound (Low_bound net rule)
             const float dl = (lik_raw >= LOW_BOUND) ? (-INV_LN2 / lik) * w * gs : 0.0f;
-            const float pl = __expf(-0.5f * zl * zl) * INV_SQRT_2PI * inv_sigma;
-            const float pu = __expf(-0.5f * zu * zu) * INV_SQRT_2PI * inv_sigma;
+            const float pl = expf(-0.5f * zl * zl) * INV_SQRT_2PI * inv_sigma;
+            const float pu = expf(-0.5f * zu * zu) * INV_SQRT_2PI * inv_sigma;
             const float dlik_dx = pu - pl;
             if (dx) dx[i] = (xr >= lo && xr <= hi) ? dl * dlik_dx : 0.0f;
             if (dmean) dmean[i] = -dl * dlik_dx;
@@ -235,8 +235,8 @@ __global__ void __launch_bounds__(256) k_rate_sample(RateSampleArgs a, const flo
                 row_acc += b * w;
             } else {
                 const float dl = (lik_raw >= LOW_BOUND) ? (-INV_LN2 / lik) * w * gs : 0.0f;
-                const float pl = __expf(-0.5f * zl * zl) * INV_SQRT_2PI * inv_sigma;
-                const float pu = __expf(-0.5f * zu * zu) * INV_SQRT_2PI * inv_sigma;
+                const float pl = expf(-0.5f * zl * zl) * INV_SQRT_2PI * inv_sigma;
+                const float pu = expf(-0.5f * zu * zu) * INV_SQRT_2PI * inv_sigma;
                 const float dlik_dx = pu - pl;
                 if (DX) DX[srow * C + col] = (xr >= lo && xr <= hi) ? dl * dlik_dx : 0.0f;
                 if (DM) atomicAdd(DM + erow * C + col, -dl * dlik_dx);
@@ -283,18 +283,48 @@ __global__ void __launch_bounds__(256) k_rate_sample_finalize(const float *__res
 // pc._anchor_feat.mean() etc., taken over ALL anchors each time the rate is evaluated): one pass over the 86 floats per anchor
 // instead of three reductions, an exp pass and their temporaries (0.18 ms of PyTorch launches per step).  Fixed order:
 // PM_BLOCKS block sums per tensor, then one workgroup adds them.
-constexpr int PM_BLOCKS = 256;
+constexpr int PM_BLOCKS = 2048;      // 8 workgroups per CU: enough 16-byte loads in flight to stream at the HBM rate
+
+// sum of f(x) over a contiguous tensor: 16-byte loads, four independent running sums per lane (one dependent add chain per
+// lane over 4-byte loads from 256 workgroups read 84 MB in 141 us = 0.6 TB/s); the order is fixed by (grid, n) alone
+template <bool EXP>
+__device__ __forceinline__ float pm_stream_sum(const float *__restrict__ x, long long n)
+{
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const long long stride = (long long)gridDim.x * 256, first = (long long)blockIdx.x * 256 + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        const long long n4 = n >> 2;
+        long long i = first;
+        for (; i + stride < n4; i += 2 * stride) {
+            const float4 u = x4[i], v = x4[i + stride];
+            if (EXP) {
+                s0 += expf(u.x) + expf(v.x); s1 += expf(u.y) + expf(v.y); s2 += expf(u.z) + expf(v.z); s3 += expf(u.w) + expf(v.w);
+            } else {
+                s0 += u.x + v.x; s1 += u.y + v.y; s2 += u.z + v.z; s3 += u.w + v.w;
+            }
+        }
+        if (i < n4) {
+            const float4 u = x4[i];
+            if (EXP) { s0 += expf(u.x); s1 += expf(u.y); s2 += expf(u.z); s3 += expf(u.w); }
+            else { s0 += u.x; s1 += u.y; s2 += u.z; s3 += u.w; }
+        }
+        for (long long j = 4 * n4 + first; j < n; j += stride) s0 += EXP ? expf(x[j]) : x[j];
+    } else {
+        for (long long j = first; j < n; j += stride) s0 += EXP ? expf(x[j]) : x[j];
+    }
+    return (s0 + s1) + (s2 + s3);
+}
 
 __global__ void __launch_bounds__(256) k_param_means_part(const float *__restrict__ a, long long na, const float *__restrict__ b,
                                                           long long nb, int b_exp, const float *__restrict__ c, long long nc,
                                                           float *__restrict__ part)
 {
     __shared__ float red[3][4];
-    float s[3] = {0.f, 0.f, 0.f};
-    const long long stride = (long long)gridDim.x * 256, first = (long long)blockIdx.x * 256 + threadIdx.x;
-    for (long long i = first; i < na; i += stride) s[0] += a[i];
-    for (long long i = first; i < nb; i += stride) s[1] += b_exp ? expf(b[i]) : b[i];
-    for (long long i = first; i < nc; i += stride) s[2] += c[i];
+    float s[3];
+    s[0] = pm_stream_sum<false>(a, na);
+    s[1] = b_exp ? pm_stream_sum<true>(b, nb) : pm_stream_sum<false>(b, nb);
+    s[2] = pm_stream_sum<false>(c, nc);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float v = s[k];
@@ -311,7 +341,11 @@ __global__ void __launch_bounds__(256) k_param_means_sum(const float *__restrict
 {
     __shared__ float sm[3][256];
 #pragma unroll
-    for (int k = 0; k < 3; k++) sm[k][threadIdx.x] = (int)threadIdx.x < blocks ? part[threadIdx.x * 3 + k] : 0.f;
+    for (int k = 0; k < 3; k++) {
+        float v = 0.f;
+        for (int bl = threadIdx.x; bl < blocks; bl += 256) v += part[bl * 3 + k];
+        sm[k][threadIdx.x] = v;
+    }
     __syncthreads();
     for (int w = 128; w >= 1; w >>= 1) {
         if ((int)threadIdx.x < w) {

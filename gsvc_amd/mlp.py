@@ -57,8 +57,9 @@ def linear_ex(x, w, b=None, epi=EPI_NONE, aux1=None, aux2=None, y2=None, y3=None
 
 
 class WgradBatch:
-    """Weight gradients of one network's backward pass: every layer's row-split kernel runs at once (its partial sums go to
-    its own region of the workspace), ONE small launch adds up the slots of all layers at the end (``flush``)."""
+    """Weight gradients of one network's backward pass: the layers' row-split products go out together at ``flush`` (one launch
+    for up to eight of them: gsvc_linear_wgrad_partial_many; their partial sums land in their own regions of the workspace),
+    followed by ONE small launch that adds up the slots of all layers."""
 
     ARENA = 1 << 24     # floats
 
@@ -73,8 +74,7 @@ class WgradBatch:
         """dW = G^T X [N, K] and db = column sums of G [N]; the tensors are complete after flush()."""
         M, N = g.shape
         K = x.shape[1]
-        L, C = _lib.lib(), self.C
-        need = int(L.gsvc_linear_wgrad_workspace(N, K))
+        need = int(_lib.lib().gsvc_linear_wgrad_workspace(N, K))
         if self.off + need > self.ws.numel():
             self.flush()
         buf = torch.empty(N * K + N, device=self.dev, dtype=torch.float32)
@@ -84,18 +84,23 @@ class WgradBatch:
             buf.zero_()
             return gw, gb
         region = self.ws[self.off:self.off + need]
-        slots = C.c_int32(0)
-        _lib.check(L.gsvc_linear_wgrad_partial(_lib.ptr(g), _lib.ptr(x), int(want_b), M, N, K, _lib.ptr(region), need,
-                                               C.byref(slots), self.stream), "gsvc_linear_wgrad_partial")
-        self.jobs.append(_lib.WgradReduceJobC(region.data_ptr(), gw.data_ptr(), gb.data_ptr() if want_b else None, slots.value, N, K))
+        self.jobs.append((g, x, region, need, bool(want_b), M, N, K, gw, gb))
         self.keep.append(buf)
         self.off += need
         return gw, gb
 
     def flush(self):
         if self.jobs:
-            arr = (_lib.WgradReduceJobC * len(self.jobs))(*self.jobs)
-            _lib.check(_lib.lib().gsvc_linear_wgrad_reduce_many(arr, len(self.jobs), self.stream), "gsvc_linear_wgrad_reduce_many")
+            L = _lib.lib()
+            n = len(self.jobs)
+            part = (_lib.WgradPartialJobC * n)()
+            for i, (g, x, region, need, want_b, M, N, K, gw, gb) in enumerate(self.jobs):
+                part[i] = _lib.WgradPartialJobC(g.data_ptr(), x.data_ptr(), region.data_ptr(), M, need, int(want_b), N, K, 0)
+            _lib.check(L.gsvc_linear_wgrad_partial_many(part, n, self.stream), "gsvc_linear_wgrad_partial_many")
+            red = (_lib.WgradReduceJobC * n)()
+            for i, (g, x, region, need, want_b, M, N, K, gw, gb) in enumerate(self.jobs):
+                red[i] = _lib.WgradReduceJobC(region.data_ptr(), gw.data_ptr(), gb.data_ptr() if want_b else None, part[i].slots_used, N, K)
+            _lib.check(L.gsvc_linear_wgrad_reduce_many(red, n, self.stream), "gsvc_linear_wgrad_reduce_many")
         self.off, self.jobs, self.keep = 0, [], []
 
 

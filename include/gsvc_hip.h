@@ -493,6 +493,17 @@ typedef struct gsvc_wgrad_reduce_job {
 int gsvc_linear_wgrad_partial(const float *G, const float *X, int32_t want_db, int64_t M, int32_t N, int32_t K,
                               float *workspace, int64_t workspace_floats, int32_t *slots_used, void *stream);
 int gsvc_linear_wgrad_reduce_many(const gsvc_wgrad_reduce_job *jobs, int32_t n_jobs, void *stream);
+/* The partial sums of n_jobs products at once: products of the usual shapes share launches (up to 8 per launch, the workgroups
+ * dealt to them by their MFMA work: the weight gradients of a whole network over the same rows), anything else is launched alone.
+ * Every job names its own workspace region; slots_used is written per job (the `slots` of its reduce job). */
+typedef struct gsvc_wgrad_partial_job {
+    const float *G, *X;
+    float *workspace;
+    int64_t M, workspace_floats;
+    int32_t want_db, N, K;
+    int32_t slots_used;      /* out */
+} gsvc_wgrad_partial_job;
+int gsvc_linear_wgrad_partial_many(gsvc_wgrad_partial_job *jobs, int32_t n_jobs, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Whole-network chain kernels of the generator and deformation MLPs (csrc/mlp_chain.hip): a 16-row block's activations stay
