@@ -310,6 +310,8 @@ def run_train_step(args, rank, world, dev):
     # measured on the model's gradients; parameters are re-broadcast afterwards)
     comm = None
     if world > 1:
+        sent_bytes, sparse_used = trainer.reducer.bytes_sent, trainer.reducer._sparse is not None
+        early_steps = getattr(trainer, "early_steps", 0)
         trainer.reducer.enabled = False
         for _ in range(3):
             step()
@@ -319,7 +321,12 @@ def run_train_step(args, rank, world, dev):
         gdist.broadcast_parameters(pc)
         comm = {"ms_per_step_without_exchange": 1e3 * e2 / args.steps,
                 "exposed_ms_per_step": 1e3 * (elapsed - e2) / args.steps,
-                "gradient_bytes_per_step": 4 * sum(p.numel() for g in pc.optimizer.param_groups for p in g["params"] if p.requires_grad)}
+                # what this rank handed to the collectives in the last exchanged step: per-anchor gradients as rows of its distinct
+                # visible anchors (index + row lists, padded to the largest count over the ranks), hash tables and MLPs dense
+                "gradient_bytes_per_step": int(sent_bytes),
+                "dense_gradient_bytes": 4 * sum(p.numel() for g in pc.optimizer.param_groups for p in g["params"] if p.requires_grad),
+                "per_anchor_exchange": "rows of the distinct visible anchors (all-gather + scatter-add)" if sparse_used else "dense all-reduce",
+                "early_plan_steps": early_steps}
 
     # per-kernel pass: same K steps with HIP events around every launch on the launch stream
     _lib.profile_enable(True)

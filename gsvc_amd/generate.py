@@ -280,6 +280,18 @@ class StepPlan:
         pos_incl = torch.cumsum(present, dim=0)
         self.pos = pos_incl - 1                                          # anchor -> row of the distinct list
         counts = [cnt_t, pos_incl[-1:]]
+        # data parallel: the largest distinct-anchor count over the ranks (the capacity of the sparse gradient exchange:
+        # gsvc_amd.dist.GradReducer.set_sparse) rides along; its collective runs on the plan's own process group
+        self._dp = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        self._gmax = self._gmax_work = None
+        if self._dp:
+            # asynchronous, and waited for only when the next step resolves the plan: a rank that builds its plan from inside the
+            # backward (early tail) must not stop there until a rank that builds it after the backward arrives — that rank's
+            # backward waits for collectives the first one has yet to launch
+            from . import dist as gdist
+            self._gmax = pos_incl[-1:].clone()
+            self._gmax_work = torch.distributed.all_reduce(self._gmax, op=torch.distributed.ReduceOp.MAX, group=gdist.plan_group(),
+                                                           async_op=True)
         if sample:
             # the rate sample in anchor space: a row is (render r, visible anchor a); its position in the concatenated rows is
             # (visible anchors of the renders before r) + (rank of a among render r's visible anchors) = c - 1
@@ -302,6 +314,7 @@ class StepPlan:
             pick = torch.nonzero_static(chosen.view(-1), size=R * A).squeeze(1)       # in (r, a) order = row order
             self._sel_flat = c.index_select(0, pick.clamp_min(0)) - 1
         self.vis_list = self.distinct = self.sel = None
+        self.distinct_cap = None
 
     def matches(self, pc) -> bool:
         return self.key == (self.visible_masks[0].shape[0], id(pc._anchor), pc._anchor._version, pc._scaling._version,
@@ -318,6 +331,9 @@ class StepPlan:
                 self.vis_list.append(self._flat[at:at + n[r]] - r * A)
                 at += n[r]
             self.distinct = self._distinct[:n[R]]
+            if self._gmax_work is not None:
+                self._gmax_work.wait()
+                self.distinct_cap = int(self._gmax.item())      # queued a whole step ago: complete by now
             if self._sel_flat is not None:
                 self.sel = self._sel_flat[:n[R + 1]]
         return self
@@ -798,10 +814,8 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         anchor = anchor_all.index_select(0, vis)
         ranks = plan.ranks if plan is not None else None
         # TRAINING_ENTROPY gathers (offsets, scaling, masks) behind the generators' forward: see _gather_rows
-        # (single process only: the gradient hooks of a data-parallel step keep the order they were tested with)
-        late_rows = (mode == GenerateMode.TRAINING_ENTROPY and trunks is None and not os.environ.get("GSVC_NO_LATE_ROWS")
-                     and not (torch.distributed.is_available() and torch.distributed.is_initialized()
-                              and torch.distributed.get_world_size() > 1))
+        # (data parallel too since round 3: the reducer launches its collectives in an order the ranks agree on)
+        late_rows = mode == GenerateMode.TRAINING_ENTROPY and trunks is None and not os.environ.get("GSVC_NO_LATE_ROWS")
         if late_rows:
             (feat,) = _gather_rows(pc, vis, ranks, parts="feat")
             grid_offsets = grid_scaling = offset_masks = None

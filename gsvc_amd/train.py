@@ -119,6 +119,8 @@ class Trainer:
                 and gaussians.optimizer is not None):
             self.sharded = gdist.ShardedAnchorAdam(gaussians.optimizer)
         self.reducer = gdist.GradReducer(sharded=self.sharded)
+        self._mask_reg_weight = 0.0
+        self._ovf_handle = None
 
     def full_optimizer_state(self):
         """Context manager around code that reads or edits ``pc.optimizer.state`` of the per-anchor tensors (checkpoints,
@@ -174,6 +176,21 @@ class Trainer:
                 self._plan = plan_views(self._views(self._plan_idx), self.pc, self.pipe, self.background, self._plan_mode)
         return out
 
+    def _add_mask_reg(self):
+        """Sparse data-parallel exchange: the mask regulariser 5e-4 * mean(sigmoid(_mask)) touches EVERY row of ``_mask`` with the
+        same number on every rank (the parameters are replicas), so it stays out of the exchanged gradient — its loss term is taken
+        of a detached copy — and its gradient, a closed form, is added on every rank after the exchange."""
+        if self._mask_reg_weight:
+            pc = self.pc
+            with torch.no_grad():
+                sg = torch.sigmoid(pc._mask)
+                reg = sg * (1.0 - sg) * (self._mask_reg_weight / pc._mask.numel())
+                if pc._mask.grad is None:
+                    pc._mask.grad = reg
+                else:
+                    pc._mask.grad.add_(reg)
+            self._mask_reg_weight = 0.0
+
     def _early_tail(self, renders):
         """Called from inside the backward, the moment the gradients of ``_scaling`` and ``_mask`` are complete (the last
         contribution is the late row gather's backward: gsvc_amd.generate._gather_rows): these two tensors are all the next
@@ -187,11 +204,26 @@ class Trainer:
         with torch.no_grad():
             params = [pc._scaling, pc._mask]
             guards = [r.raster_state.binning[4:8].view(torch.int32) for r in renders]
+            if gdist.world_size() > 1:
+                # data parallel: the two gradients are final once their collectives (launched by the reducer's hooks, which run
+                # before this one) have completed; a step in which they have not gone out yet (no agreed order in the very first
+                # one) takes the ordinary end-of-step path.  "Some rank overflowed" guards the update as well.
+                if not self.reducer.complete(params):
+                    return
+                self._add_mask_reg()
+                guards = [self._ovf_handle[2]]        # the MAX over the ranks of the four local words (this rank's included)
             pc.optimizer.step(only=params, guards=guards)
+            self.early_steps = getattr(self, "early_steps", 0) + 1
             idx = self.rng.randint(self.lo, max(self.lo, self.hi - 1))
             mode = render_mode_at(self.controller.current_iteration + 1, self.opt)
             plan = plan_views(self._views(idx), pc, self.pipe, self.background, mode) if mode is not None else None
             self._early = (params, idx, mode, plan)
+
+    def _sparse_dp(self, plan):
+        """Row-sparse gradient exchange of the per-anchor tensors: needs the step plan (the rank's distinct visible anchors and the
+        largest such count over the ranks) and the replicated Adam; GSVC_DP_SPARSE=0 keeps the dense all-reduce."""
+        return (plan is not None and gdist.world_size() > 1 and self.sharded is None and self.reducer.enabled and not self.anchor_grad
+                and getattr(plan, "distinct_cap", None) is not None and os.environ.get("GSVC_DP_SPARSE", "1") != "0")
 
     def _views(self, frame_idx):
         """The step's four views: (frame, frame seen from the opposite side) of the two adjacent frames."""
@@ -254,6 +286,7 @@ class Trainer:
             # replicas: "did any rank's instance buffer overflow" is reduced right behind the forward kernels, so that
             # the end-of-step check does not have to wait for the backward (overflow word = second int32 of a binning blob)
             ovf_handle = gdist.any_rank_start([r.raster_state.binning[4:8].view(torch.int32) for r in (r1f, r1b, r2f, r2b)])
+            self._ovf_handle = ovf_handle
         else:
             r1f, r1b, image1 = self._two_views(frame1, mode, retain_grad)
             r2f, r2b, image2 = self._two_views(frame2, mode, retain_grad)
@@ -285,7 +318,10 @@ class Trainer:
         if self.controller.entropy_constrained:
             assert all(r.entropy_constrained for r in renders)
             denom = pc._anchor.shape[0] * (pc.feat_dim + 6 + 3 * pc.n_offsets)
-            terms += [r.bit_per_param for r in renders] + [hash_grid_bits(pc), torch.mean(torch.sigmoid(pc._mask))]
+            # sparse data-parallel exchange (below): the regulariser's dense gradient is added after the exchange (_add_mask_reg)
+            sparse_dp = self._sparse_dp(plan if self.batched else None)
+            self._mask_reg_weight = 5e-4 if sparse_dp else 0.0
+            terms += [r.bit_per_param for r in renders] + [hash_grid_bits(pc), torch.mean(torch.sigmoid(pc._mask.detach() if sparse_dp else pc._mask))]
             weights += [opt.lmbda] * 4 + [opt.lmbda / denom, 5e-4]
         key = tuple(weights)
         if getattr(self, "_w_key", None) != key:      # the weights change only with the training phase
@@ -294,8 +330,14 @@ class Trainer:
         w = self._w
         loss = torch.dot(torch.stack([t.reshape(()) for t in terms]), w) + const
         self.reducer.arm([p for g in pc.optimizer.param_groups for p in g["params"]])
+        if self.batched and self._sparse_dp(plan):
+            # the per-anchor gradients are non-zero only in the rows of this rank's distinct visible anchors: exchanged as rows
+            self.reducer.set_sparse(plan.distinct, plan.distinct_cap, [pc._offset, pc._mask, pc._anchor_feat, pc._scaling])
+        else:
+            self.reducer.set_sparse(None, 0, [])
         handles = []
-        if (early and self.batched and self.prefetch and pc._anchor.is_cuda and gdist.world_size() == 1 and self.sharded is None
+        if (early and self.batched and self.prefetch and pc._anchor.is_cuda and self.sharded is None
+                and (gdist.world_size() == 1 or (self.reducer.enabled and self.reducer._order is not None))
                 and not self.anchor_grad      # a trained anchor tensor moves behind the early plan's visibility test
                 and mode == GenerateMode.TRAINING_ENTROPY and iteration < opt.iterations and not self.controller.gaussian_adjust_anchor
                 and isinstance(pc.optimizer, FusedAdam) and not os.environ.get("GSVC_NO_EARLY_PLAN")
@@ -318,6 +360,7 @@ class Trainer:
             for h in handles:
                 h.remove()
         self.reducer.finish()
+        self._add_mask_reg()
 
         if self.batched:
             # the only host synchronisation of the step after the visibility test: the 4 renders' instance counters

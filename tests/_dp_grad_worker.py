@@ -52,6 +52,13 @@ def main():
     else:
         pc, cube, opt, pipe, mp, Trainer = _setup(anchors=3000)
     opt.full_precision_training_total = 1000          # no quantisation noise: the step is a deterministic function of the frames
+    if os.environ.get("GSVC_DP_MODE") == "ste":
+        # the entropy-constrained loss (rate over EVERY visible anchor, hash-table bits, the mask regulariser that touches every
+        # row of _mask) in its deterministic form: STE quantisation, no sampling
+        import gsvc_amd.generate as G
+        G.SAMPLE_RATE = 2.0
+        opt.full_precision_training_total = opt.quantized_training_total = opt.entropy_constrained_train_total = 0
+        opt.ste_entropy_constrained_train_total = 1000
     pc.training_setup(opt)
     gd.broadcast_parameters(pc)
     tr = Trainer(pc, cube, opt, pipe, mp, seed=3)
@@ -90,8 +97,36 @@ def main():
         err = float((dp[k] - v).abs().max()) / scale
         worst = max(worst, err)
         assert err < 2e-4, (k, err, scale)
+    # a second data-parallel step, this one on the frame pair the trainer drew itself with the step plan it queued at the end of
+    # the last step: the per-anchor gradients then travel as (row index, row) lists of the rank's distinct visible anchors
+    # (GradReducer.set_sparse) instead of dense all-reduces — same mean of the ranks' gradients
+    tr.reducer.enabled = True
+    planned = tr._plan is not None and tr._plan_idx is not None
+    tr.step(2)
+    dp2 = dict(captured)
+    sparse_used = tr.reducer._sparse is not None
+    mine = torch.tensor([tr._last_idx], device=mine.device)
+    idxs = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(idxs, mine)
+    idxs = [int(t.item()) for t in idxs]
+    tr.reducer.enabled = False
+    ref2 = {}
+    for f in idxs:
+        tr.step(2, frame_idx=f)
+        for k, v in captured.items():
+            ref2[k] = ref2.get(k, 0) + v / len(idxs)
+    worst2 = 0.0
+    for k, v in ref2.items():
+        scale = float(v.abs().max())
+        if scale == 0.0:
+            assert float(dp2[k].abs().max()) == 0.0, k
+            continue
+        err = float((dp2[k] - v).abs().max()) / scale
+        worst2 = max(worst2, err)
+        assert err < 2e-4, ("planned step", k, err, scale)
     if dist.get_rank() == 0:
-        print(f"DP_GRAD_OK backend={dist.get_backend()} ranks={dist.get_world_size()} tensors={len(ref)} worst={worst:.2e}", flush=True)
+        print(f"DP_GRAD_OK backend={dist.get_backend()} ranks={dist.get_world_size()} tensors={len(ref)} worst={worst:.2e} "
+              f"planned={planned} sparse={sparse_used} worst_planned={worst2:.2e} bytes_sent={tr.reducer.bytes_sent}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -628,7 +628,20 @@ def _run_dp_grad_worker(env_extra):
 def test_two_rank_step_averages_gradients():
     """One data-parallel step leaves on every rank the mean of the two single-process gradients of the ranks' frame pairs
     (every parameter group; tests/_dp_grad_worker.py).  Both ranks on device 0 through gloo: runs on a 1-GPU box."""
-    assert "backend=gloo ranks=2" in _run_dp_grad_worker({"GSVC_DIST_BACKEND": "gloo", "GSVC_SHARE_GPU": "1"})
+    out = _run_dp_grad_worker({"GSVC_DIST_BACKEND": "gloo", "GSVC_SHARE_GPU": "1"})
+    assert "backend=gloo ranks=2" in out and "planned=True sparse=True" in out, out
+
+
+@pytest.mark.gpu
+def test_two_rank_entropy_step_with_sparse_row_exchange():
+    """The entropy-constrained step (rate, hash-table bits, the mask regulariser whose gradient touches every row of _mask) under
+    data parallelism, STE form (deterministic): the planned step exchanges the per-anchor gradients as rows of the ranks' distinct
+    visible anchors; the regulariser's dense gradient is added after the exchange (Trainer._add_mask_reg).  Same mean as two
+    single-process steps."""
+    out = _run_dp_grad_worker({"GSVC_DIST_BACKEND": "gloo", "GSVC_SHARE_GPU": "1", "GSVC_DP_MODE": "ste"})
+    assert "planned=True sparse=True" in out, out
+    out = _run_dp_grad_worker({"GSVC_DIST_BACKEND": "gloo", "GSVC_SHARE_GPU": "1", "GSVC_DP_MODE": "ste", "GSVC_DP_SPARSE": "0"})
+    assert "planned=True sparse=False" in out, out
 
 
 @pytest.mark.gpu
