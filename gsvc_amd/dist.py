@@ -293,6 +293,7 @@ class ShardedAnchorAdam:
         self.optimizer, self.names = optimizer, tuple(names)
         self._state = {}        # id(param) -> dict(step, m, v, S)
         self._work = {}         # id(param) -> (param, work handle, padded gradient buffer, reduced shard)
+        optimizer._gsvc_sharded = self      # checkpoint writers find the moments through full_optimizer_state_dict()
         self.adopt_state()
 
     # ---- which parameters
@@ -484,6 +485,20 @@ def any_rank_finish(handle, local_flag: bool) -> bool:
     if ev is not None:
         ev.synchronize()
     return bool(host.item() > 0) or bool(local_flag)
+
+
+def full_optimizer_state_dict(optimizer):
+    """``optimizer.state_dict()`` with the Adam moments of the per-anchor tensors at full size also when a ShardedAnchorAdam holds
+    them range by range (collective in that case: every rank must call it) — what ``capture()`` / ``save_checkpoint`` write.
+    Reading ``optimizer.state_dict()`` directly under GSVC_DP_SHARD would silently drop those moments."""
+    sharded = getattr(optimizer, "_gsvc_sharded", None)
+    if sharded is None or world_size() == 1:
+        return optimizer.state_dict()
+    sharded.gather_state()
+    try:
+        return optimizer.state_dict()
+    finally:
+        sharded.adopt_state()
 
 
 def broadcast_parameters(module, src: int = 0):

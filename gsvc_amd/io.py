@@ -234,6 +234,12 @@ def load_ply_sparse_gaussian(pc, path):
 
 
 # ------------------------------------------------------------------------------------------------ checkpoints
+def _optimizer_state(optimizer):
+    """Optimizer state with the sharded per-anchor moments gathered (gsvc_amd.dist.full_optimizer_state_dict)."""
+    from .dist import full_optimizer_state_dict
+    return full_optimizer_state_dict(optimizer)
+
+
 def _plain(obj):
     """NumPy scalars -> Python numbers (the learning-rate schedule yields ``np.float64``), so that the tuple loads with
     ``torch.load(..., weights_only=True)``."""
@@ -250,7 +256,7 @@ def capture(pc):
     """The reference's checkpoint tuple (:556-584): (state_dict, x_bound_min, x_bound_max, max_radii2D, offset_denom,
     anchor_demon, optimizer state_dict, spatial_lr_scale)."""
     return (pc.state_dict(), pc.x_bound_min, pc.x_bound_max, pc.max_radii2D, pc.offset_denom, pc.anchor_demon,
-            _plain(pc.optimizer.state_dict()), _plain(pc.spatial_lr_scale))
+            _plain(_optimizer_state(pc.optimizer)), _plain(pc.spatial_lr_scale))
 
 
 def init_anchor_params(pc, anchor_num):

@@ -78,11 +78,14 @@ class HuffmanCode:
     """Canonical Huffman code over small non-negative integer symbols.  Only the code lengths define it: symbols are
     ordered by (length, symbol) and numbered consecutively, so ``lengths`` is all a decoder needs."""
 
-    MAX_LEN = 24
+    MAX_LEN = 16      # code lengths are limited (from_data): the decoder's table has 2^L entries
 
     def __init__(self, lengths: dict):
         self.lengths = {int(s): int(l) for s, l in lengths.items()}
-        assert self.lengths and max(self.lengths.values()) <= self.MAX_LEN
+        if not self.lengths or min(self.lengths.values()) < 1 or max(self.lengths.values()) > self.MAX_LEN:
+            raise ValueError(f"HuffmanCode: code lengths must be 1 .. {self.MAX_LEN}")
+        if sum(1 << (self.MAX_LEN - l) for l in self.lengths.values()) > (1 << self.MAX_LEN):
+            raise ValueError("HuffmanCode: the lengths violate Kraft's inequality (not a prefix code)")
         order = sorted(self.lengths, key=lambda s: (self.lengths[s], s))
         self.codes, code, prev = {}, 0, self.lengths[order[0]]
         for s in order:
@@ -105,7 +108,31 @@ class HuffmanCode:
             for s in sa + sb:
                 depth[s] += 1
             heapq.heappush(heap, (wa + wb, min(ta, tb), sa + sb))
-        return cls(depth)
+        return cls(cls._limit_lengths(depth, {int(v): int(c) for v, c in zip(vals, counts)}))
+
+    @classmethod
+    def _limit_lengths(cls, depth: dict, count: dict) -> dict:
+        """Lengths <= MAX_LEN that still satisfy Kraft's inequality.  A very skewed histogram (a few hundred thousand quantised
+        weights over 257 values) can put rare symbols deeper than the limit: those are cut to MAX_LEN and the excess is paid for
+        by lengthening the deepest shorter codes of the rarest symbols by one bit at a time; then codes are shortened again
+        wherever a whole bit is free (most frequent first).  Unlimited codes are returned as they are (optimal)."""
+        L = cls.MAX_LEN
+        if max(depth.values()) <= L:
+            return depth
+        if len(depth) > (1 << L):
+            raise ValueError(f"HuffmanCode: {len(depth)} symbols do not fit codes of at most {L} bits")
+        ln = {s: min(d, L) for s, d in depth.items()}
+        kraft = sum(1 << (L - l) for l in ln.values())          # in units of 2^-L; a prefix code needs <= 2^L
+        full = 1 << L
+        while kraft > full:
+            s = min((x for x in ln if ln[x] < L), key=lambda x: (-ln[x], count[x], x))
+            kraft -= 1 << (L - ln[s] - 1)
+            ln[s] += 1
+        for s in sorted(ln, key=lambda x: (-count[x], x)):
+            while ln[s] > 1 and kraft + (1 << (L - ln[s])) <= full:
+                kraft += 1 << (L - ln[s])
+                ln[s] -= 1
+        return ln
 
     def encode(self, symbols: np.ndarray) -> bytes:
         sym = np.asarray(symbols).reshape(-1).astype(np.int64)
@@ -115,8 +142,10 @@ class HuffmanCode:
         len_of, code_of = np.zeros(top, np.int64), np.zeros(top, np.int64)
         for s, l in self.lengths.items():
             len_of[s], code_of[s] = l, self.codes[s]
-        lens, codes = len_of[sym], code_of[sym]
-        assert lens.min() > 0, "symbol outside the code"
+        lens = len_of[np.clip(sym, 0, top - 1)]
+        codes = code_of[np.clip(sym, 0, top - 1)]
+        if sym.min() < 0 or sym.max() >= top or lens.min() <= 0:
+            raise ValueError("HuffmanCode.encode: symbol outside the code")
         starts = np.cumsum(lens) - lens
         total = int(starts[-1] + lens[-1])
         within = np.arange(total, dtype=np.int64) - np.repeat(starts, lens)

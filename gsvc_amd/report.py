@@ -46,6 +46,12 @@ def evaluate(pc, dataset, pipe, bg_color, frame_ids=None, batch: int = 8) -> dic
             "msssim": sums["msssim"] / n_ms if n_ms else float("nan"), "fps": len(frames) / elapsed if elapsed > 0 else float("inf")}
 
 
+def _optimizer_state(optimizer):
+    """Optimizer state with the sharded per-anchor moments gathered (gsvc_amd.dist.full_optimizer_state_dict)."""
+    from .dist import full_optimizer_state_dict
+    return full_optimizer_state_dict(optimizer)
+
+
 def _plain(obj):
     """NumPy scalars -> Python numbers, recursively (the learning-rate schedule leaves np.float64 in the optimizer's groups;
     a file holding them cannot be read back with ``weights_only=True``)."""
@@ -68,7 +74,7 @@ def save_checkpoint(pc, path, iteration: int = 0):
                 "decoded_version": bool(pc.decoded_version), "voxel_size": float(pc.voxel_size),
                 "spatial_lr_scale": float(pc.spatial_lr_scale), "percent_dense": float(getattr(pc, "percent_dense", 0.0) or 0.0),
                 "bounds": (tuple(float(v) for v in pc.bound_min_host), tuple(float(v) for v in pc.bound_max_host)),
-                "optimizer": _plain(pc.optimizer.state_dict()) if pc.optimizer is not None else None}, path)
+                "optimizer": _plain(_optimizer_state(pc.optimizer)) if pc.optimizer is not None else None}, path)
 
 
 def load_checkpoint(pc, path, training_args=None) -> int:

@@ -113,3 +113,28 @@ def test_corrupt_container_is_rejected(tmp_path):
     bad.write_bytes(blob[:-5])
     with pytest.raises(ValueError):
         mc.decode_mlp(str(bad))
+
+
+def test_huffman_code_lengths_are_limited():
+    """A histogram skewed enough for unlimited Huffman depths beyond the decoder's table (Fibonacci-like counts: depth = number of
+    symbols - 1) still yields a prefix code of at most MAX_LEN bits that round-trips; an unskewed one keeps its optimal lengths."""
+    import numpy as np
+    from gsvc_amd.mlp_codec import HuffmanCode
+    fib = [1, 1]
+    while len(fib) < 30:
+        fib.append(fib[-1] + fib[-2])
+    data = np.concatenate([np.full(c, i, np.int64) for i, c in enumerate(fib)])
+    np.random.default_rng(0).shuffle(data)
+    code = HuffmanCode.from_data(data)
+    assert max(code.lengths.values()) <= HuffmanCode.MAX_LEN == 16
+    assert sum(2.0 ** -l for l in code.lengths.values()) <= 1.0 + 1e-12
+    out = code.decode(code.encode(data), data.size)
+    assert np.array_equal(out, data)
+    # the limit costs little even here (Fibonacci counts are the worst case for depth): within 5 % of the entropy
+    bits = sum(code.lengths[int(s)] for s in data)
+    ent = -sum(c * np.log2(c / data.size) for c in fib)
+    assert bits <= 1.05 * ent + 8
+    with pytest.raises(ValueError):
+        code.encode(np.array([99]))
+    with pytest.raises(ValueError):
+        HuffmanCode({0: 1, 1: 1, 2: 1})
