@@ -78,6 +78,10 @@ class GeneratorGradsC(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3", "Wg0", "bg0", "Wg1", "bg1", "Wb0", "bb0", "Wb1", "bb1")]
 
 
+class FilmRowsC(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("cond", C.c_void_p), ("row_of", C.c_void_p), ("src_a", C.c_void_p), ("src_b", C.c_void_p)]
+
+
 class DeformNetC(C.Structure):
     _fields_ = [("W", C.c_void_p * 5), ("b", C.c_void_p * 5)] + [(n, C.c_int32) for n in ("feat_dim", "cond_dim", "hidden_dim", "out_dim")]
 
@@ -159,8 +163,8 @@ _SIGNATURES = {
     "gsvc_linear_wgrad_reduce_many": (C.c_int, [C.POINTER(WgradReduceJobC), C.c_int32, _vp]),
     "gsvc_linear_wgrad_partial_many": (C.c_int, [C.POINTER(WgradPartialJobC), C.c_int32, _vp]),
     "gsvc_linear_wgrad_workspace": (_i64, [C.c_int32, C.c_int32]),
-    "gsvc_generator_saved_floats": (_i64, [C.POINTER(GeneratorNetC), _i64]),
-    "gsvc_generator_scratch_floats": (_i64, [C.POINTER(GeneratorNetC), _i64]),
+    "gsvc_generator_saved_floats": (_i64, [C.POINTER(GeneratorNetC), _i64, _i64]),
+    "gsvc_generator_scratch_floats": (_i64, [C.POINTER(GeneratorNetC), _i64, _i64]),
     "gsvc_generator_forward": (C.c_int, [C.POINTER(GeneratorNetC), _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsvc_generator_backward": (C.c_int, [C.POINTER(GeneratorNetC), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int32,
                                           C.POINTER(GeneratorGradsC), _vp]),
@@ -169,9 +173,11 @@ _SIGNATURES = {
     "gsvc_deform_forward": (C.c_int, [C.POINTER(DeformNetC), _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsvc_deform_backward": (C.c_int, [C.POINTER(DeformNetC), _vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
                                        C.POINTER(DeformGradsC), _vp]),
-    "gsvc_generators_forward": (C.c_int, [C.POINTER(GeneratorNetC), C.c_int32, _vp, _vp, _i64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]),
-    "gsvc_generators_backward": (C.c_int, [C.POINTER(GeneratorNetC), C.c_int32, _vp, _vp, _i64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                           C.POINTER(C.c_void_p), _vp, C.POINTER(C.c_void_p), C.POINTER(GeneratorGradsC), _vp]),
+    "gsvc_generators_forward": (C.c_int, [C.POINTER(GeneratorNetC), C.c_int32, _vp, _vp, _i64, C.POINTER(FilmRowsC), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), _vp]),
+    "gsvc_generators_backward": (C.c_int, [C.POINTER(GeneratorNetC), C.c_int32, _vp, _vp, _i64, C.POINTER(FilmRowsC), C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp, C.POINTER(C.c_void_p), C.POINTER(GeneratorGradsC),
+                                           _vp]),
     "gsvc_rate_sample_scratch_floats": (_i64, [_i64]),
     "gsvc_rate_sample_forward": (C.c_int, [C.POINTER(RateSampleC), _vp, _vp, _vp]),
     "gsvc_rate_sample_backward": (C.c_int, [C.POINTER(RateSampleC), _vp, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

@@ -637,7 +637,13 @@ extern "C" int gsvc_linear_wgrad_partial_many(gsvc_wgrad_partial_job *jobs, int3
             q.slots_used = used;
             continue;
         }
-        batch[nb++] = Plan{j, BN, BK, WG_MAX_WAVES / pairs, pairs, (double)((q.N + 15) / 16) * ((q.K + 15) / 16) * (double)((q.M + 15) / 16)};
+        // cost of the product on one CU: the larger of its MFMA time (tiles x 4 steps x 32 cycles per 16-row chunk, 4 SIMDs) and its
+        // streaming time (a CU takes in ~10 bytes per cycle: a thin product — 100 x 10 — is bytes, not MFMAs, and dealt by MFMA
+        // work alone it got 8 workgroups for 88 MB and ran 1.5x longer than the whole rest of its batch)
+        const double chunks = (double)((q.M + 15) / 16);
+        const double mfma_cycles = (double)((q.N + 15) / 16) * ((q.K + 15) / 16) * chunks * 4.0 * 32.0 / 4.0;
+        const double byte_cycles = (double)q.M * (q.N + q.K) * 4.0 / 10.0;
+        batch[nb++] = Plan{j, BN, BK, WG_MAX_WAVES / pairs, pairs, mfma_cycles > byte_cycles ? mfma_cycles : byte_cycles};
         if (nb == WG_MANY)
             if (int rc = flush()) return rc;
     }

@@ -136,6 +136,58 @@ struct Tiles {
     }
 };
 
+// Whole-matrix descriptor for accesses by a per-lane row index (rows gathered through a map); the byte offsets are 32-bit:
+// the host refuses matrices of 2 GiB and more.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t whole_rsrc(const float *base, long long rows, int ld)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(base) & 0xffffffffu));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(base) >> 32));
+    const int bytes = __builtin_amdgcn_readfirstlane((int)(base ? rows * ld * 4 : 0));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+
+// Tile-layout LOADS of a row-major [rows][N] matrix where lane (fr, kq) reads row `row` (its own: -1 = none, zeros)
+template <int N>
+struct RowTiles {
+    __amdgpu_buffer_rsrc_t r;
+    int off, c00;
+    bool ok;
+    __device__ __forceinline__ RowTiles(const float *base, long long rows, int row, const Lane &L)
+    {
+        r = whole_rsrc(base, rows, N);
+        c00 = 4 * L.kq;
+        ok = row >= 0;
+        off = (row * N + c00) * 4;
+    }
+    __device__ __forceinline__ v4f load(int t) const
+    {
+        float v[4];
+        ws_load4(r, ok ? off + 64 * t : BUF_OOB, ok ? c00 + 16 * t : N, N, cl_sv(N), v);
+        return (v4f){v[0], v[1], v[2], v[3]};
+    }
+};
+
+// fragments of row `row` (per lane; -1 = zeros) of a row-major [rows][K] matrix
+template <int K>
+__device__ __forceinline__ void load_frags_row(v4f (&a)[cl_kg(K)], const float *X, long long rows, int row, const Lane &L)
+{
+    constexpr int KG = cl_kg(K), VEC = cl_sv(K);
+    const __amdgpu_buffer_rsrc_t rx = whole_rsrc(X, rows, K);
+    const int voff = row >= 0 ? row * K * 4 + 16 * L.kq : 0x7fff0000;      // past any descriptor's range: zeros
+#pragma unroll
+    for (int g = 0; g < KG; g++) {
+        const float4 v = ws_load_group<VEC, KG>(rx, voff, L.kq, K, g);
+        a[g] = (v4f){v.x, v.y, v.z, v.w};
+    }
+}
+
+// the lane's row of a map (int32 per chain row; rows past M read as -1)
+__device__ __forceinline__ int map_row(const int *__restrict__ map, long long rb, long long RB, long long M, const Lane &L)
+{
+    const long long r = rb * 16 + L.fr;
+    return (rb < RB && r < M) ? map[r] : -1;
+}
+
 // acc[t] += sum_k W_img[16 t + fr'][k] X[row][k]: K = contraction length (a has cl_kg(K) groups), NT output tiles.
 // wimg: image with row stride LD; the lane's view starts at row fr, column 4 kq.
 template <int K, int NT, int LD>
@@ -318,7 +370,10 @@ template <int COND, int HID, int CHAIN_THREADS>
 __device__ __forceinline__ void film_bwd_body(int blk, int nblk, const float *__restrict__ ggamma, const float *__restrict__ gbeta,
                                                                  const float *__restrict__ cg, const float *__restrict__ cb,
                                                                  const float *__restrict__ Wg1, const float *__restrict__ Wb1,
-                                                                 float *__restrict__ gcg, float *__restrict__ gcb, long long M)
+                                                                 float *__restrict__ gcg, float *__restrict__ gcb, long long M,
+                                                                 const int *__restrict__ src_a, const int *__restrict__ src_b,
+                                                                 long long src_rows, float *__restrict__ ggamma_sum,
+                                                                 float *__restrict__ gbeta_sum)
 {
     extern __shared__ float lds[];
     constexpr int LD = cl_ld(HID), NT = cl_kg(COND), IMG = NT * 16 * LD;
@@ -330,11 +385,32 @@ __device__ __forceinline__ void film_bwd_body(int blk, int nblk, const float *__
     __syncthreads();
     long long rb, RB, stride;
     row_blocks<CHAIN_THREADS / 64>(M, L, blk, nblk, rb, RB, stride);
-    v4f g[2][cl_kg(HID)];
-    load_frags<HID>(g[0], ggamma, rb, RB, M, L);
-    load_frags<HID>(g[1], gbeta, rb, RB, M, L);
+    // src_a / src_b (shared FiLM rows): this kernel's row q is a (frame, anchor); ggamma / gbeta hold one row per (view, anchor) —
+    // the frame's two opposite views — and the row's gradient is the sum of the two (either may be absent: -1).  The sums are
+    // written out: they are the G operands of the second layers' weight gradients.
+    v4f g[2][cl_kg(HID)], t2[2][cl_kg(HID)];
+    int ra = -1, rb2 = -1, ra_n = -1, rb_n = -1;
+    // the (summed) gradients of a block are requested one block ahead — network by network, as soon as this block's have been
+    // summed into the product's operand —, the map entries two blocks ahead
+    auto fetch = [&](int net, long long b, int a_row, int b_row) {
+        const float *src = net ? gbeta : ggamma;
+        if (src_a) {
+            load_frags_row<HID>(g[net], src, src_rows, a_row, L);
+            load_frags_row<HID>(t2[net], src, src_rows, b_row, L);
+        } else {
+            load_frags<HID>(g[net], src, b, RB, M, L);
+        }
+    };
+    if (src_a) {
+        ra = map_row(src_a, rb, RB, M, L);
+        rb2 = map_row(src_b, rb, RB, M, L);
+        ra_n = map_row(src_a, rb + stride, RB, M, L);
+        rb_n = map_row(src_b, rb + stride, RB, M, L);
+    }
+    fetch(0, rb, ra, rb2);
+    fetch(1, rb, ra, rb2);
     for (; rb < RB; rb += stride) {
-        v4f m[2][NT];      // the ReLU outputs (masks) of this block: requested before the products that precede their use
+        v4f m[2][NT];      // the ReLU outputs (masks) of this block
         {
             const Tiles<COND> t0(cg, rb, RB, M, L), t1(cb, rb, RB, M, L);
 #pragma unroll
@@ -343,11 +419,23 @@ __device__ __forceinline__ void film_bwd_body(int blk, int nblk, const float *__
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int net = 0; net < 2; net++) {
+            v4f cur[cl_kg(HID)];
+#pragma unroll
+            for (int i = 0; i < cl_kg(HID); i++) cur[i] = src_a ? g[net][i] + t2[net][i] : g[net][i];
+            fetch(net, rb + stride, ra_n, rb_n);
+            __builtin_amdgcn_sched_barrier(0);
+            if (src_a) {
+                const Tiles<HID> ts(net ? gbeta_sum : ggamma_sum, rb, RB, M, L);
+#pragma unroll
+                for (int t = 0; t < cl_kg(HID); t++) ts.store(t, cur[t]);
+            }
             v4f acc[NT];
             init_zero(acc);
-            chain_mm<HID, NT, LD>(acc, g[net], lds + net * IMG, L);
-            load_frags<HID>(g[net], net ? gbeta : ggamma, rb + stride, RB, M, L);
-            __builtin_amdgcn_sched_barrier(0);
+            chain_mm<HID, NT, LD>(acc, cur, lds + net * IMG, L);
+            if (net == 1 && src_a) {
+                ra_n = map_row(src_a, rb + 2 * stride, RB, M, L);
+                rb_n = map_row(src_b, rb + 2 * stride, RB, M, L);
+            }
             const Tiles<COND> to(net ? gcb : gcg, rb, RB, M, L);
 #pragma unroll
             for (int t = 0; t < NT; t++) {
@@ -379,7 +467,8 @@ template <int FEAT, int HID, int OUT, int CHAIN_THREADS>
 __device__ __forceinline__ void trunk_fwd_body(int blk, int nblk, const float *__restrict__ feat, const float *__restrict__ gamma,
                                                              const float *__restrict__ beta, TrunkW w, int act,
                                                              float *__restrict__ z1, float *__restrict__ a1, float *__restrict__ h,
-                                                             float *__restrict__ x3, float *__restrict__ y, long long M)
+                                                             float *__restrict__ x3, float *__restrict__ y, long long M,
+                                                             const int *__restrict__ film_row, long long film_rows)
 {
     extern __shared__ float lds[];
     using S = TrunkFwdLds<FEAT, HID, OUT>;
@@ -398,11 +487,20 @@ __device__ __forceinline__ void trunk_fwd_body(int blk, int nblk, const float *_
     row_blocks<CHAIN_THREADS / 64>(M, L, blk, nblk, rb, RB, stride);
     v4f f[cl_kg(FEAT)];
     load_frags<FEAT>(f, feat, rb, RB, M, L);
+    int fr_next = film_row ? map_row(film_row, rb, RB, M, L) : -1;      // the map entry travels one block ahead of its use
     for (; rb < RB; rb += stride) {
         // this block's gamma / beta travel while its first two products run; the next block's feature rows are requested as
         // soon as the first product has consumed this block's; no wait ever names a store
         v4f gam[S::NTH], bet[S::NTH];
-        {
+        if (film_row) {
+            // gamma / beta live once per (frame, anchor): the two opposite views of a frame share the condition (same camera z,
+            // same anchor z), so the FiLM networks ran on those rows only and this row names its (film_row)
+            const int fr_ = fr_next;
+            fr_next = map_row(film_row, rb + stride, RB, M, L);
+            const RowTiles<HID> tg(gamma, film_rows, fr_, L), tb(beta, film_rows, fr_, L);
+#pragma unroll
+            for (int t = 0; t < S::NTH; t++) { gam[t] = tg.load(t); bet[t] = tb.load(t); }
+        } else {
             const Tiles<HID> tg(gamma, rb, RB, M, L), tb(beta, rb, RB, M, L);
 #pragma unroll
             for (int t = 0; t < S::NTH; t++) { gam[t] = tg.load(t); bet[t] = tb.load(t); }
@@ -466,7 +564,8 @@ __device__ __forceinline__ void trunk_bwd_body(int blk, int nblk, const float *_
                                                              const float *__restrict__ z1, TrunkW w, float *__restrict__ go,
                                                              float *__restrict__ gbeta, float *__restrict__ ggamma,
                                                              float *__restrict__ gh, float *__restrict__ gz1,
-                                                             float *__restrict__ gfeat, int accumulate, long long M)
+                                                             float *__restrict__ gfeat, int accumulate, long long M,
+                                                             const int *__restrict__ film_row, long long film_rows)
 {
     extern __shared__ float lds[];
     using S = TrunkBwdLds<FEAT, HID, OUT>;
@@ -486,14 +585,26 @@ __device__ __forceinline__ void trunk_bwd_body(int blk, int nblk, const float *_
 #pragma unroll
         for (int t = 0; t < NTO; t++) { g0[t] = tg.load(t); yv[t] = ty.load(t); }
     }
+    int fr_next = film_row ? map_row(film_row, rb, RB, M, L) : -1;
     for (; rb < RB; rb += stride) {
         // everything this block reads later (h, gamma, z1, the running feature gradient) is requested up front and lands while
         // the products run; the next block's (gy, y) are requested once this block's have been consumed
         v4f hh[S::NTH], gg[S::NTH], zz[S::NTH], pf[S::NTF];
         {
-            const Tiles<HID> th(h, rb, RB, M, L), tg(gamma, rb, RB, M, L), tz(z1, rb, RB, M, L);
+            const Tiles<HID> th(h, rb, RB, M, L), tz(z1, rb, RB, M, L);
 #pragma unroll
-            for (int t = 0; t < S::NTH; t++) { hh[t] = th.load(t); gg[t] = tg.load(t); zz[t] = tz.load(t); }
+            for (int t = 0; t < S::NTH; t++) { hh[t] = th.load(t); zz[t] = tz.load(t); }
+            if (film_row) {
+                const int fr_ = fr_next;
+                fr_next = map_row(film_row, rb + stride, RB, M, L);
+                const RowTiles<HID> tg(gamma, film_rows, fr_, L);
+#pragma unroll
+                for (int t = 0; t < S::NTH; t++) gg[t] = tg.load(t);
+            } else {
+                const Tiles<HID> tg(gamma, rb, RB, M, L);
+#pragma unroll
+                for (int t = 0; t < S::NTH; t++) gg[t] = tg.load(t);
+            }
             const Tiles<FEAT> tf(gfeat, accumulate ? rb : RB, RB, M, L);      // empty descriptor (zeros) when not accumulating
 #pragma unroll
             for (int t = 0; t < S::NTF; t++) pf[t] = tf.load(t);
@@ -573,6 +684,9 @@ struct FilmBwdBatch {
     int n;
     const float *ggamma[MAX_NETS], *gbeta[MAX_NETS], *cg[MAX_NETS], *cb[MAX_NETS], *Wg1[MAX_NETS], *Wb1[MAX_NETS];
     float *gcg[MAX_NETS], *gcb[MAX_NETS];
+    const int *src_a, *src_b;      // shared FiLM rows: the two (view, anchor) rows behind every (frame, anchor) row; NULL = one to one
+    long long src_rows;
+    float *ggamma_sum[MAX_NETS], *gbeta_sum[MAX_NETS];
 };
 template <int COND, int HID, int CHAIN_THREADS>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_film_nets_bwd(FilmBwdBatch b, long long M)
@@ -580,7 +694,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_film_nets_bwd(FilmBwdBatch b,
     const NetOfBlock nb(b.n);
     film_bwd_body<COND, HID, CHAIN_THREADS>(nb.blk, nb.nblk, pick(b.ggamma, nb.net), pick(b.gbeta, nb.net), pick(b.cg, nb.net),
                                             pick(b.cb, nb.net), pick(b.Wg1, nb.net), pick(b.Wb1, nb.net), pick(b.gcg, nb.net),
-                                            pick(b.gcb, nb.net), M);
+                                            pick(b.gcb, nb.net), M, b.src_a, b.src_b, b.src_rows, pick(b.ggamma_sum, nb.net),
+                                            pick(b.gbeta_sum, nb.net));
 }
 
 struct TrunkFwdBatch {
@@ -589,6 +704,8 @@ struct TrunkFwdBatch {
     TrunkW w[MAX_NETS];
     const float *gamma[MAX_NETS], *beta[MAX_NETS];
     float *z1[MAX_NETS], *a1[MAX_NETS], *h[MAX_NETS], *x3[MAX_NETS], *y[MAX_NETS];
+    const int *film_row;           // shared FiLM rows: chain row -> row of gamma / beta; NULL = the same row
+    long long film_rows;
 };
 template <int FEAT, int HID, int CHAIN_THREADS>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_fwd(const float *__restrict__ feat, TrunkFwdBatch b, long long M)
@@ -596,7 +713,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_fwd(const float *__rest
     const NetOfBlock nb(b.n);
     const int i = nb.net;
 #define GSVC_TRUNK_FWD(OUT) trunk_fwd_body<FEAT, HID, OUT, CHAIN_THREADS>(nb.blk, nb.nblk, feat, pick(b.gamma, i), pick(b.beta, i), pick(b.w, i), \
-        pick(b.act, i), pick(b.z1, i), pick(b.a1, i), pick(b.h, i), pick(b.x3, i), pick(b.y, i), M)
+        pick(b.act, i), pick(b.z1, i), pick(b.a1, i), pick(b.h, i), pick(b.x3, i), pick(b.y, i), M, b.film_row, b.film_rows)
     switch (pick(b.out, i)) {
         case 10: GSVC_TRUNK_FWD(10); break;
         case 30: GSVC_TRUNK_FWD(30); break;
@@ -611,6 +728,8 @@ struct TrunkBwdBatch {
     TrunkW w[MAX_NETS];
     const float *gy[MAX_NETS], *y[MAX_NETS], *h[MAX_NETS], *gamma[MAX_NETS], *z1[MAX_NETS];
     float *go[MAX_NETS], *gbeta[MAX_NETS], *ggamma[MAX_NETS], *gh[MAX_NETS], *gz1[MAX_NETS], *gfeat[MAX_NETS];
+    const int *film_row;
+    long long film_rows;
 };
 template <int FEAT, int HID, int CHAIN_THREADS>
 __global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_bwd(TrunkBwdBatch b, long long M)
@@ -619,7 +738,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_bwd(TrunkBwdBatch b, lo
     const int i = nb.net;
 #define GSVC_TRUNK_BWD(OUT) trunk_bwd_body<FEAT, HID, OUT, CHAIN_THREADS>(nb.blk, nb.nblk, pick(b.gy, i), pick(b.y, i), pick(b.act, i), pick(b.h, i), \
         pick(b.gamma, i), pick(b.z1, i), pick(b.w, i), pick(b.go, i), pick(b.gbeta, i), pick(b.ggamma, i), pick(b.gh, i), pick(b.gz1, i), \
-        pick(b.gfeat, i), pick(b.accumulate, i), M)
+        pick(b.gfeat, i), pick(b.accumulate, i), M, b.film_row, b.film_rows)
     switch (pick(b.out, i)) {
         case 10: GSVC_TRUNK_BWD(10); break;
         case 30: GSVC_TRUNK_BWD(30); break;
@@ -936,23 +1055,27 @@ inline float *take(float *&cur, long long count)
 // z1, a1, h, x3 [HID]; beta (a forward intermediate) lives behind them
 struct GenSaved {
     float *cg, *cb, *gamma, *z1, *a1, *h, *x3, *beta;
-    GenSaved(float *base, long long M)
+    GenSaved(float *base, long long M, long long Mf)      // Mf: rows of the FiLM networks (= M unless the views share them)
     {
         float *cur = base;
-        gamma = take(cur, M * HID); z1 = take(cur, M * HID); a1 = take(cur, M * HID); h = take(cur, M * HID); x3 = take(cur, M * HID);
-        beta = take(cur, M * HID); cg = take(cur, M * COND); cb = take(cur, M * COND);
+        gamma = take(cur, Mf * HID); beta = take(cur, Mf * HID); cg = take(cur, Mf * COND); cb = take(cur, Mf * COND);
+        z1 = take(cur, M * HID); a1 = take(cur, M * HID); h = take(cur, M * HID); x3 = take(cur, M * HID);
     }
 };
-constexpr long long GEN_SAVED_PER_ROW = 2 * COND + 6 * HID;
+constexpr long long GEN_SAVED_PER_ROW = 4 * HID, GEN_SAVED_PER_FILM_ROW = 2 * COND + 2 * HID;
 
-// backward scratch of a generator: go [OUT], gbeta, ggamma, gh, gz1 [HID], gcg, gcb [COND], then the wgrad partial sums
+// backward scratch of a generator: go [OUT], gbeta, ggamma, gh, gz1 [HID] per chain row; gcg, gcb [COND] and (shared FiLM rows)
+// the two views' summed gbeta / ggamma [HID] per FiLM row; then the wgrad partial sums
 struct GenScratch {
-    float *go, *gbeta, *ggamma, *gh, *gz1, *gcg, *gcb, *wg;
-    GenScratch(float *base, long long M, int out)
+    float *go, *gbeta, *ggamma, *gh, *gz1, *gcg, *gcb, *gbeta_sum, *ggamma_sum, *wg;
+    GenScratch(float *base, long long M, long long Mf, int out, bool shared)
     {
         float *cur = base;
         go = take(cur, M * out); gbeta = take(cur, M * HID); ggamma = take(cur, M * HID); gh = take(cur, M * HID);
-        gz1 = take(cur, M * HID); gcg = take(cur, M * COND); gcb = take(cur, M * COND); wg = cur;
+        gz1 = take(cur, M * HID); gcg = take(cur, Mf * COND); gcb = take(cur, Mf * COND);
+        gbeta_sum = shared ? take(cur, Mf * HID) : gbeta;
+        ggamma_sum = shared ? take(cur, Mf * HID) : ggamma;
+        wg = cur;
     }
 };
 
@@ -962,15 +1085,34 @@ long long gen_wgrad_floats(int out)
            2 * gsvc_linear_wgrad_workspace(COND, COND) + 2 * gsvc_linear_wgrad_workspace(HID, COND);
 }
 
-int generators_forward(const gsvc_generator_net *nets, int n, const float *feat, const float *cond, long long M, float *const *saved,
-                       float *const *y, hipStream_t s)
+struct FilmRows {      // resolved gsvc_film_rows (rows == M and NULL maps when the views do not share the FiLM rows)
+    long long rows;
+    const float *cond;
+    const int *row_of, *src_a, *src_b;
+    bool shared;
+    FilmRows(const gsvc_film_rows *f, long long M, const float *cond_rows)
+    {
+        shared = f != nullptr && f->rows > 0;
+        rows = shared ? f->rows : M;
+        cond = shared ? f->cond : cond_rows;
+        row_of = shared ? f->row_of : nullptr;
+        src_a = shared ? f->src_a : nullptr;
+        src_b = shared ? f->src_b : nullptr;
+    }
+};
+
+int generators_forward(const gsvc_generator_net *nets, int n, const float *feat, const float *cond, long long M, const gsvc_film_rows *film,
+                       float *const *saved, float *const *y, hipStream_t s)
 {
+    const FilmRows fr(film, M, cond);
     FilmFwdBatch fb;
     TrunkFwdBatch tb;
     fb.n = tb.n = n;
+    tb.film_row = fr.row_of;
+    tb.film_rows = fr.rows;
     for (int i = 0; i < MAX_NETS; i++) {
         const gsvc_generator_net &g = nets[i < n ? i : 0];
-        const GenSaved sv(saved[i < n ? i : 0], M);
+        const GenSaved sv(saved[i < n ? i : 0], M, fr.rows);
         fb.w[i] = FilmW{g.Wg0, g.bg0, g.Wg1, g.bg1, g.Wb0, g.bb0, g.Wb1, g.bb1};
         fb.cg[i] = sv.cg; fb.cb[i] = sv.cb; fb.gamma[i] = sv.gamma; fb.beta[i] = sv.beta;
         tb.out[i] = g.out_dim; tb.act[i] = g.out_act;
@@ -978,62 +1120,67 @@ int generators_forward(const gsvc_generator_net *nets, int n, const float *feat,
         tb.gamma[i] = sv.gamma; tb.beta[i] = sv.beta; tb.z1[i] = sv.z1; tb.a1[i] = sv.a1; tb.h[i] = sv.h; tb.x3[i] = sv.x3;
         tb.y[i] = y[i < n ? i : 0];
     }
-    chain_launch("k_film_nets_fwd", &k_film_nets_fwd<COND, HID, CHAIN_T>, FilmFwdLds<COND, HID>::FLOATS * 4, M * n, n, s, cond, fb, M);
+    chain_launch("k_film_nets_fwd", &k_film_nets_fwd<COND, HID, CHAIN_T>, FilmFwdLds<COND, HID>::FLOATS * 4, fr.rows * n, n, s, fr.cond, fb, fr.rows);
     chain_launch("k_trunk_fwd", &k_trunk_fwd<FEAT, HID, CHAIN_T>, TrunkFwdLds<FEAT, HID, 70>::FLOATS * 4, M * n, n, s, feat, tb, M);
     return check_launch("generators_forward");
 }
 
-int generators_backward(const gsvc_generator_net *nets, int n, const float *feat, const float *cond, long long M, const float *const *saved,
-                        const float *const *y, const float *const *gy, float *scratch, float *const *gfeat, const int *accumulate,
-                        const gsvc_generator_grads *grads, hipStream_t s)
+int generators_backward(const gsvc_generator_net *nets, int n, const float *feat, const float *cond, long long M, const gsvc_film_rows *film,
+                        const float *const *saved, const float *const *y, const float *const *gy, float *scratch, float *const *gfeat,
+                        const int *accumulate, const gsvc_generator_grads *grads, hipStream_t s)
 {
+    const FilmRows fr(film, M, cond);
     TrunkBwdBatch tb;
     FilmBwdBatch fb;
     tb.n = fb.n = n;
-    long long per_net[MAX_NETS];
+    tb.film_row = fr.row_of;
+    tb.film_rows = fr.rows;
+    fb.src_a = fr.src_a; fb.src_b = fr.src_b; fb.src_rows = M;
     float *sbase[MAX_NETS];
     {
         float *cur = scratch;
         for (int i = 0; i < n; i++) {
-            per_net[i] = gsvc_generator_scratch_floats(&nets[i], M);
             sbase[i] = cur;
-            cur += (per_net[i] + 3) / 4 * 4;
+            cur += (gsvc_generator_scratch_floats(&nets[i], M, fr.shared ? fr.rows : 0) + 3) / 4 * 4;
         }
     }
     for (int i = 0; i < MAX_NETS; i++) {
         const int j = i < n ? i : 0;
         const gsvc_generator_net &g = nets[j];
-        const GenSaved sv(const_cast<float *>(saved[j]), M);
-        const GenScratch sc(sbase[j], M, g.out_dim);
+        const GenSaved sv(const_cast<float *>(saved[j]), M, fr.rows);
+        const GenScratch sc(sbase[j], M, fr.rows, g.out_dim, fr.shared);
         tb.out[i] = g.out_dim; tb.act[i] = g.out_act; tb.accumulate[i] = accumulate ? accumulate[j] : 0;
         tb.w[i] = TrunkW{g.W1, g.b1, g.W2, g.b2, g.W3, g.b3};
         tb.gy[i] = gy[j]; tb.y[i] = y[j]; tb.h[i] = sv.h; tb.gamma[i] = sv.gamma; tb.z1[i] = sv.z1;
         tb.go[i] = sc.go; tb.gbeta[i] = sc.gbeta; tb.ggamma[i] = sc.ggamma; tb.gh[i] = sc.gh; tb.gz1[i] = sc.gz1; tb.gfeat[i] = gfeat[j];
         fb.ggamma[i] = sc.ggamma; fb.gbeta[i] = sc.gbeta; fb.cg[i] = sv.cg; fb.cb[i] = sv.cb; fb.Wg1[i] = g.Wg1; fb.Wb1[i] = g.Wb1;
-        fb.gcg[i] = sc.gcg; fb.gcb[i] = sc.gcb;
+        fb.gcg[i] = sc.gcg; fb.gcb[i] = sc.gcb; fb.ggamma_sum[i] = sc.ggamma_sum; fb.gbeta_sum[i] = sc.gbeta_sum;
     }
     chain_launch("k_trunk_bwd", &k_trunk_bwd<FEAT, HID, CHAIN_T>, TrunkBwdLds<FEAT, HID, 70>::FLOATS * 4, M * n, n, s, tb, M);
-    chain_launch("k_film_nets_bwd", &k_film_nets_bwd<COND, HID, CHAIN_T>, (size_t)2 * cl_kg(COND) * 16 * cl_ld(HID) * 4, M * n, n, s, fb, M);
+    chain_launch("k_film_nets_bwd", &k_film_nets_bwd<COND, HID, CHAIN_T>, (size_t)2 * cl_kg(COND) * 16 * cl_ld(HID) * 4, fr.rows * n, n, s, fb,
+                 fr.rows);
     if (int rc = check_launch("generators_backward")) return rc;
-    // the seven weight gradients dW = G^T X (+ db) of every network: row-split partial sums, batched slot reduces
-    struct Job { const float *G, *X; float *dW, *db; int N, K; };
+    // the seven weight gradients dW = G^T X (+ db) of every network: row-split partial sums, batched slot reduces.  The FiLM
+    // networks' four run over the FiLM rows (the summed gradients of the two views when they share them)
+    struct Job { const float *G, *X; float *dW, *db; int N, K; long long rows; };
     gsvc_wgrad_partial_job part[7 * MAX_NETS];
     gsvc_wgrad_reduce_job red[7 * MAX_NETS];
     int nred = 0;
     for (int i = 0; i < n; i++) {
         const gsvc_generator_net &g = nets[i];
         const gsvc_generator_grads &gr = grads[i];
-        const GenSaved sv(const_cast<float *>(saved[i]), M);
-        const GenScratch sc(sbase[i], M, g.out_dim);
+        const GenSaved sv(const_cast<float *>(saved[i]), M, fr.rows);
+        const GenScratch sc(sbase[i], M, fr.rows, g.out_dim, fr.shared);
         const Job jobs[7] = {
-            {sc.gz1, feat, gr.W1, gr.b1, HID, FEAT},    {sc.gh, sv.a1, gr.W2, gr.b2, HID, HID},    {sc.go, sv.x3, gr.W3, gr.b3, g.out_dim, HID},
-            {sc.gcg, cond, gr.Wg0, gr.bg0, COND, COND}, {sc.ggamma, sv.cg, gr.Wg1, gr.bg1, HID, COND},
-            {sc.gcb, cond, gr.Wb0, gr.bb0, COND, COND}, {sc.gbeta, sv.cb, gr.Wb1, gr.bb1, HID, COND}};
+            {sc.gz1, feat, gr.W1, gr.b1, HID, FEAT, M},        {sc.gh, sv.a1, gr.W2, gr.b2, HID, HID, M},
+            {sc.go, sv.x3, gr.W3, gr.b3, g.out_dim, HID, M},   {sc.gcg, fr.cond, gr.Wg0, gr.bg0, COND, COND, fr.rows},
+            {sc.ggamma_sum, sv.cg, gr.Wg1, gr.bg1, HID, COND, fr.rows}, {sc.gcb, fr.cond, gr.Wb0, gr.bb0, COND, COND, fr.rows},
+            {sc.gbeta_sum, sv.cb, gr.Wb1, gr.bb1, HID, COND, fr.rows}};
         float *ws = sc.wg;
         for (const Job &j : jobs) {
             if (!j.dW) continue;
             const long long need = gsvc_linear_wgrad_workspace(j.N, j.K);
-            part[nred] = gsvc_wgrad_partial_job{j.G, j.X, ws, M, need, j.db != nullptr, j.N, j.K, 0};
+            part[nred] = gsvc_wgrad_partial_job{j.G, j.X, ws, j.rows, need, j.db != nullptr, j.N, j.K, 0};
             red[nred++] = gsvc_wgrad_reduce_job{ws, j.dW, j.db, 0, j.N, j.K};
             ws += need;
         }
@@ -1075,16 +1222,17 @@ static int gen_supported(const gsvc_generator_net *n, const char *what)
     return GSVC_OK;
 }
 
-extern "C" int64_t gsvc_generator_saved_floats(const gsvc_generator_net *n, int64_t M)
+extern "C" int64_t gsvc_generator_saved_floats(const gsvc_generator_net *n, int64_t M, int64_t film_rows)
 {
-    if (!n || M < 0) return -1;
-    return (GEN_SAVED_PER_ROW + HID) * M + 32;
+    if (!n || M < 0 || film_rows < 0) return -1;
+    return GEN_SAVED_PER_ROW * M + GEN_SAVED_PER_FILM_ROW * (film_rows > 0 ? film_rows : M) + 64;
 }
 
-extern "C" int64_t gsvc_generator_scratch_floats(const gsvc_generator_net *n, int64_t M)
+extern "C" int64_t gsvc_generator_scratch_floats(const gsvc_generator_net *n, int64_t M, int64_t film_rows)
 {
-    if (!n || M < 0) return -1;
-    return (int64_t)(n->out_dim + 4 * HID + 2 * COND) * M + gen_wgrad_floats(n->out_dim) + 64;
+    if (!n || M < 0 || film_rows < 0) return -1;
+    const int64_t Mf = film_rows > 0 ? film_rows : M;
+    return (int64_t)(n->out_dim + 4 * HID) * M + (int64_t)(2 * COND + (film_rows > 0 ? 2 * HID : 0)) * Mf + gen_wgrad_floats(n->out_dim) + 96;
 }
 
 static int gens_supported(const gsvc_generator_net *nets, int32_t n, const char *what)
@@ -1095,39 +1243,51 @@ static int gens_supported(const gsvc_generator_net *nets, int32_t n, const char 
     return GSVC_OK;
 }
 
+static int film_rows_ok(const gsvc_film_rows *f, int64_t M, const char *what)
+{
+    if (!f || f->rows <= 0) return GSVC_OK;
+    GSVC_REQUIRE(f->cond && f->row_of && f->src_a && f->src_b && aligned16({f->cond}), "%s: shared FiLM rows need cond, row_of, src_a, src_b", what);
+    GSVC_REQUIRE((M > f->rows ? M : f->rows) * (int64_t)HID * 4 < ((int64_t)1 << 31), "%s: %lld rows exceed the 2 GiB reach of the row maps", what,
+                 (long long)(M > f->rows ? M : f->rows));
+    return GSVC_OK;
+}
+
 extern "C" int gsvc_generators_forward(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
-                                       float *const *saved, float *const *y, void *stream)
+                                       const gsvc_film_rows *film, float *const *saved, float *const *y, void *stream)
 {
     if (int rc = gens_supported(nets, n_nets, "generators_forward")) return rc;
     GSVC_REQUIRE(M >= 0, "generators_forward: bad row count");
     if (M == 0) return GSVC_OK;
     GSVC_REQUIRE(feat && cond && saved && y && aligned16({feat, cond}), "generators_forward: NULL or unaligned pointer");
+    if (int rc = film_rows_ok(film, M, "generators_forward")) return rc;
     for (int i = 0; i < n_nets; i++)
         GSVC_REQUIRE(saved[i] && y[i] && aligned16({saved[i], y[i]}), "generators_forward: NULL or unaligned pointer (network %d)", i);
-    return generators_forward(nets, n_nets, feat, cond, M, saved, y, (hipStream_t)stream);
+    return generators_forward(nets, n_nets, feat, cond, M, film, saved, y, (hipStream_t)stream);
 }
 
 extern "C" int gsvc_generators_backward(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
-                                        const float *const *saved, const float *const *y, const float *const *gy, float *scratch,
-                                        float *const *gfeat, const gsvc_generator_grads *grads, void *stream)
+                                        const gsvc_film_rows *film, const float *const *saved, const float *const *y,
+                                        const float *const *gy, float *scratch, float *const *gfeat, const gsvc_generator_grads *grads,
+                                        void *stream)
 {
     if (int rc = gens_supported(nets, n_nets, "generators_backward")) return rc;
     GSVC_REQUIRE(M >= 0 && grads, "generators_backward: bad arguments");
     if (M == 0) return GSVC_OK;
     GSVC_REQUIRE(feat && cond && saved && y && gy && scratch && gfeat && aligned16({feat, cond, scratch}),
                  "generators_backward: NULL or unaligned pointer");
+    if (int rc = film_rows_ok(film, M, "generators_backward")) return rc;
     for (int i = 0; i < n_nets; i++) {
         GSVC_REQUIRE(saved[i] && y[i] && gy[i] && gfeat[i] && aligned16({saved[i], y[i], gy[i], gfeat[i]}),
                      "generators_backward: NULL or unaligned pointer (network %d)", i);
         for (int j = 0; j < i; j++) GSVC_REQUIRE(gfeat[i] != gfeat[j], "generators_backward: the networks' feature gradients must be distinct buffers");
     }
-    return generators_backward(nets, n_nets, feat, cond, M, saved, y, gy, scratch, gfeat, nullptr, grads, (hipStream_t)stream);
+    return generators_backward(nets, n_nets, feat, cond, M, film, saved, y, gy, scratch, gfeat, nullptr, grads, (hipStream_t)stream);
 }
 
 extern "C" int gsvc_generator_forward(const gsvc_generator_net *n, const float *feat, const float *cond, int64_t M, float *saved, float *y,
                                       void *stream)
 {
-    return gsvc_generators_forward(n, 1, feat, cond, M, &saved, &y, stream);
+    return gsvc_generators_forward(n, 1, feat, cond, M, nullptr, &saved, &y, stream);
 }
 
 extern "C" int gsvc_generator_backward(const gsvc_generator_net *n, const float *feat, const float *cond, int64_t M, const float *saved,
@@ -1140,7 +1300,7 @@ extern "C" int gsvc_generator_backward(const gsvc_generator_net *n, const float 
     GSVC_REQUIRE(feat && cond && saved && y && gy && scratch && gfeat, "generator_backward: NULL pointer");
     GSVC_REQUIRE(aligned16({feat, cond, saved, y, gy, scratch, gfeat}), "generator_backward: operands must be 16-byte aligned");
     const int acc = accumulate_gfeat;
-    return generators_backward(n, 1, feat, cond, M, &saved, &y, &gy, scratch, &gfeat, &acc, grads, (hipStream_t)stream);
+    return generators_backward(n, 1, feat, cond, M, nullptr, &saved, &y, &gy, scratch, &gfeat, &acc, grads, (hipStream_t)stream);
 }
 
 static int deform_supported(const gsvc_deform_net *n, const char *what)

@@ -784,6 +784,35 @@ def _embed_rows(pc, frames, anchor, seg):
     return torch.cat([pc.embed_time_fn(cam_z_row), pc.embed_fn(ob_view)], dim=1)
 
 
+def _film_rows(pc, frames, plan, vis, seg, anchor_all):
+    """Rows of the generators' FiLM networks when the step's views come in opposite pairs (frame f seen from both sides: same
+    camera z, so the same condition for the same anchor — reference frame_cube/frame.py:18-43, guassian.py:225-230): one row per
+    (frame, distinct visible anchor) instead of one per (view, anchor).  Returns (cond_film, row_of, src_a, src_b) for
+    gsvc_amd.mlp.generate_all, or None (no plan, an odd number of views, views that are not such pairs, or GSVC_NO_FILM_SHARE)."""
+    R = seg.R
+    if (plan is None or R % 2 != 0 or plan.distinct is None or os.environ.get("GSVC_NO_FILM_SHARE")
+            or any(float(frames[2 * i].cam_pos[-1]) != float(frames[2 * i + 1].cam_pos[-1]) for i in range(R // 2))):
+        return None
+    dev = vis.device
+    D, A = int(plan.distinct.shape[0]), plan._A
+    if D == 0 or seg.rows == 0:
+        return None
+    F = R // 2
+    with torch.no_grad():
+        # FiLM row of chain row (view r, anchor a) = (r // 2) * D + position of a in the distinct list
+        frame_of_row = torch.div(seg.seg_id, 2, rounding_mode="floor")
+        row_of = (plan.pos.index_select(0, vis) + frame_of_row * D).to(torch.int32)
+        # the chain rows behind FiLM row (f, a): the row of a in views 2 f and 2 f + 1 (scan of the flattened view masks - 1), -1 if unseen
+        Mflat, c = plan.ranks
+        base = (torch.arange(R, device=dev, dtype=torch.int64) * A).view(R, 1) + plan.distinct.view(1, D)      # [R, D] flat positions
+        rows = torch.where(Mflat.index_select(0, base.view(-1)), c.index_select(0, base.view(-1)) - 1,
+                           torch.full((), -1, device=dev, dtype=c.dtype)).view(F, 2, D).to(torch.int32)
+        src_a, src_b = rows[:, 0, :].reshape(-1).contiguous(), rows[:, 1, :].reshape(-1).contiguous()
+        seg_f = _Segments([D] * F, dev)
+        cond_film = _embed_rows(pc, [frames[2 * i] for i in range(F)], anchor_all.index_select(0, plan.distinct).repeat(F, 1), seg_f)
+    return cond_film, row_of, src_a, src_b
+
+
 def generator_trunks(pc):
     """Frame-independent half of the three generator MLPs for ALL anchors: ``linear2(GELU(linear1(anchor_feat)))``
     (reference scene/gaussian_model.py:168-196 evaluates it per render).  Valid while the parameters do not change and
@@ -894,7 +923,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
             color = pc.get_color_mlp.head(trunks["get_color_mlp"].index_select(0, vis), pe).reshape(rows * K, 3)
             scale_rot = pc.get_cov_mlp.head(trunks["get_cov_mlp"].index_select(0, vis), pe).reshape(rows * K, 7)
         elif chain:
-            op_raw, color, scale_rot, neural_offset = _mlp.generate_all(gens, deform_linears, feat, pe)
+            op_raw, color, scale_rot, neural_offset = _mlp.generate_all(gens, deform_linears, feat, pe, film=_film_rows(pc, frames, plan, vis, seg, anchor_all))
             color, scale_rot, neural_offset = color.reshape(rows * K, 3), scale_rot.reshape(rows * K, 7), neural_offset.reshape(rows * K, 3)
         else:
             gen = lambda name: (getattr(pc, name)(feat, pe, film=films[name]) if films.get(name) is not None  # noqa: E731

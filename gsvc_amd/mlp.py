@@ -336,6 +336,16 @@ def _deform_desc(params):
     return d
 
 
+def _film_desc(film):
+    """gsvc_film_rows of (cond_film [Mf, 66], row_of [M] int32, src_a [Mf] int32, src_b [Mf] int32), or NULL."""
+    if film is None:
+        return None
+    import ctypes as C
+    cond_f, row_of, src_a, src_b = film
+    d = _lib.FilmRowsC(int(cond_f.shape[0]), cond_f.data_ptr(), row_of.data_ptr(), src_a.data_ptr(), src_b.data_ptr())
+    return C.byref(d)
+
+
 def _ptr_array(tensors):
     import ctypes as C
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
@@ -347,7 +357,7 @@ class _GenerateAll(torch.autograd.Function):
     The three generators run as ONE pair of launches each way (gsvc_generators_*: workgroup b serves network b % 3)."""
 
     @staticmethod
-    def forward(ctx, feat, cond, acts, *params):
+    def forward(ctx, feat, cond, acts, film, *params):
         import ctypes as C
         feat, cond = feat.contiguous(), cond.contiguous()
         params = [p.contiguous() for p in params]
@@ -355,14 +365,15 @@ class _GenerateAll(torch.autograd.Function):
         L, st = _lib.lib(), _lib.current_stream(dev)
         nets = (_lib.GeneratorNetC * 3)()
         outs, saved = [], []
+        Mf = int(film[0].shape[0]) if film is not None else 0
         for g in range(3):
             pg = params[14 * g:14 * (g + 1)]
             d = _gen_desc(pg, acts[g], pg[4].shape[0])
             C.memmove(C.byref(nets[g]), C.byref(d), C.sizeof(d))
-            saved.append(torch.empty(int(L.gsvc_generator_saved_floats(C.byref(d), M)), device=dev, dtype=torch.float32))
+            saved.append(torch.empty(int(L.gsvc_generator_saved_floats(C.byref(d), M, Mf)), device=dev, dtype=torch.float32))
             outs.append(torch.empty(M, pg[4].shape[0], device=dev, dtype=torch.float32))
-        _lib.check(L.gsvc_generators_forward(nets, 3, _lib.ptr(feat), _lib.ptr(cond), M, _ptr_array(saved), _ptr_array(outs), st),
-                   "gsvc_generators_forward")
+        _lib.check(L.gsvc_generators_forward(nets, 3, _lib.ptr(feat), _lib.ptr(cond), M, _film_desc(film), _ptr_array(saved),
+                                             _ptr_array(outs), st), "gsvc_generators_forward")
         pd = params[42:52]
         dd = _deform_desc(pd)
         sv = torch.empty(int(L.gsvc_deform_saved_floats(C.byref(dd), M)), device=dev, dtype=torch.float32)
@@ -371,6 +382,7 @@ class _GenerateAll(torch.autograd.Function):
         outs.append(y)
         saved.append(sv)
         ctx.acts = tuple(acts)
+        ctx.film = film          # index tensors and the FiLM rows' condition: no gradient flows to them
         ctx.save_for_backward(feat, cond, *outs[:3], *saved, *params)
         return tuple(outs)
 
@@ -399,7 +411,7 @@ class _GenerateAll(torch.autograd.Function):
             C.memmove(C.byref(nets[g]), C.byref(d), C.sizeof(d))
             for name, v in zip(GEN_FIELDS, grads[14 * g:14 * (g + 1)]):
                 setattr(gds[g], name, v.data_ptr())
-            total += (int(L.gsvc_generator_scratch_floats(C.byref(d), M)) + 3) // 4 * 4
+            total += (int(L.gsvc_generator_scratch_floats(C.byref(d), M, int(ctx.film[0].shape[0]) if ctx.film is not None else 0)) + 3) // 4 * 4
         dd = _deform_desc(params[42:52])
         total = max(total, int(L.gsvc_deform_scratch_floats(C.byref(dd), M)))
         scratch = torch.empty(total, device=dev, dtype=torch.float32)
@@ -408,8 +420,9 @@ class _GenerateAll(torch.autograd.Function):
         gflat = torch.empty(4 * per, device=dev, dtype=torch.float32)                   # three generators' + the sum
         gfeats = [gflat[i * per:i * per + M * F_].view(M, F_) for i in range(4)]
         gen_gf = gfeats[:3]
-        _lib.check(L.gsvc_generators_backward(nets, 3, _lib.ptr(feat), _lib.ptr(cond), M, _ptr_array(saved[:3]), _ptr_array(ys),
-                                              _ptr_array(gys[:3]), _lib.ptr(scratch), _ptr_array(gen_gf), gds, st), "gsvc_generators_backward")
+        _lib.check(L.gsvc_generators_backward(nets, 3, _lib.ptr(feat), _lib.ptr(cond), M, _film_desc(ctx.film), _ptr_array(saved[:3]),
+                                              _ptr_array(ys), _ptr_array(gys[:3]), _lib.ptr(scratch), _ptr_array(gen_gf), gds, st),
+                   "gsvc_generators_backward")
         gd = _lib.DeformGradsC()
         for i in range(5):
             gd.W[i], gd.b[i] = grads[42 + 2 * i].data_ptr(), grads[43 + 2 * i].data_ptr()
@@ -418,14 +431,19 @@ class _GenerateAll(torch.autograd.Function):
         _lib.check(L.gsvc_deform_backward(C.byref(dd), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(saved[3]), _lib.ptr(gys[3]),
                                           _lib.ptr(scratch), _lib.ptr(gfeats[3]), 0, _ptr_array(gen_gf), 3, C.byref(gd), st),
                    "gsvc_deform_backward")
-        return (gfeats[3] if need[0] else None, None, None, *grads)
+        return (gfeats[3] if need[0] else None, None, None, None, *grads)
 
 
-def generate_all(gens, deform_linears, feat, cond):
-    """(opacity_raw, color, scale_rot, neural_offset) = the three generators and mlp_deform on (feat, cond) rows."""
+def generate_all(gens, deform_linears, feat, cond, film=None):
+    """(opacity_raw, color, scale_rot, neural_offset) = the three generators and mlp_deform on (feat, cond) rows.
+    ``film`` = (cond_film, row_of, src_a, src_b): the generators' FiLM networks run on the rows ``cond_film`` only (one per
+    (frame, anchor): the opposite views of a frame share the condition) — include/gsvc_hip.h gsvc_film_rows."""
     params = []
     for net in gens:
         params += _generator_params(net)
     for l in deform_linears:
         params += [l.weight, l.bias]
-    return _GenerateAll.apply(feat, cond, tuple(_act_code(n) for n in gens), *params)
+    if film is not None:
+        film = tuple(t.contiguous() for t in film)
+        assert film[0].dtype == torch.float32 and all(t.dtype == torch.int32 for t in film[1:])
+    return _GenerateAll.apply(feat, cond, tuple(_act_code(n) for n in gens), film, *params)

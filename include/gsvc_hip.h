@@ -534,15 +534,28 @@ typedef struct gsvc_generator_grads {
  * pointers; `scratch` holds the networks' regions back to back (sum of gsvc_generator_scratch_floats, each rounded up to a
  * multiple of 4 floats); gfeat[i] receives network i's feature gradient (distinct buffers, written, not accumulated: pass them
  * to gsvc_deform_backward as addends, or add them up). */
-int64_t gsvc_generator_saved_floats(const gsvc_generator_net *net, int64_t M);
-int64_t gsvc_generator_scratch_floats(const gsvc_generator_net *net, int64_t M);
+/* Shared FiLM rows.  gamma / beta depend on the condition only, and the two opposite views of a frame (the training step renders
+ * both: reference pipeline/train.py:353-387) have the same condition for the same anchor — same camera z, same anchor z — while
+ * their features differ (independent quantisation noise per render).  With a gsvc_film_rows the FiLM networks (4 of a
+ * generator's 7 layers, forward, backward and weight gradients) run once per (frame, anchor) instead of once per (view, anchor):
+ *   rows      number of FiLM rows;  cond [rows, cond_dim] their condition
+ *   row_of    [M] int32: chain row (view, anchor) -> its FiLM row
+ *   src_a/_b  [rows] int32: the (up to) two chain rows of a FiLM row, -1 = that view does not see the anchor
+ * NULL (or rows = 0): one FiLM row per chain row, conditions = cond.  The sizes below take the FiLM row count (0 = M). */
+typedef struct gsvc_film_rows {
+    int64_t rows;
+    const float *cond;
+    const int32_t *row_of, *src_a, *src_b;
+} gsvc_film_rows;
+int64_t gsvc_generator_saved_floats(const gsvc_generator_net *net, int64_t M, int64_t film_rows);
+int64_t gsvc_generator_scratch_floats(const gsvc_generator_net *net, int64_t M, int64_t film_rows);
 int gsvc_generator_forward(const gsvc_generator_net *net, const float *feat, const float *cond, int64_t M, float *saved, float *y,
                            void *stream);
 int gsvc_generators_forward(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
-                            float *const *saved, float *const *y, void *stream);
+                            const gsvc_film_rows *film, float *const *saved, float *const *y, void *stream);
 int gsvc_generators_backward(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
-                             const float *const *saved, const float *const *y, const float *const *gy, float *scratch,
-                             float *const *gfeat, const gsvc_generator_grads *grads, void *stream);
+                             const gsvc_film_rows *film, const float *const *saved, const float *const *y, const float *const *gy,
+                             float *scratch, float *const *gfeat, const gsvc_generator_grads *grads, void *stream);
 int gsvc_generator_backward(const gsvc_generator_net *net, const float *feat, const float *cond, int64_t M, const float *saved,
                             const float *y, const float *gy, float *scratch, float *gfeat, int32_t accumulate_gfeat,
                             const gsvc_generator_grads *grads, void *stream);

@@ -194,8 +194,8 @@ def test_fused_row_gather_and_context_tail_match_the_tensor_paths(monkeypatch):
         assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
 
 
-@pytest.mark.parametrize("M", [4096, 6001, 20011])
-def test_whole_network_chain_kernels_match_torch(M):
+@pytest.mark.parametrize("M,share", [(4096, False), (6001, False), (20011, False), (6001, True), (20011, True)])
+def test_whole_network_chain_kernels_match_torch(M, share):
     """gsvc_generator_* / gsvc_deform_* (csrc/mlp_chain.hip: a 16-row block's activations stay in registers from the network's
     input to its output) through gsvc_amd.mlp.generate_all — the three GeneratorNets (out 10 tanh / 30 sigmoid / 70) and
     mlp_deform (116 -> 100 x4 -> 30) on the same (feature, condition) rows — against plain PyTorch fp32: the four outputs, the
@@ -211,6 +211,23 @@ def test_whole_network_chain_kernels_match_torch(M):
     lin = list(deform)[0::2]
     feat = (torch.randn(M, 50, device="cuda") * 2).requires_grad_(True)
     cond = torch.randn(M, 66, device="cuda")
+    film = None
+    if share:
+        # shared FiLM rows (gsvc_film_rows): the rows are two "views" of overlapping anchor sets; a FiLM row = one anchor of the
+        # union, its condition shared by the (up to) two chain rows that name it
+        Mf = int(0.6 * M)
+        cond_film = torch.randn(Mf, 66, device="cuda")
+        gen = torch.Generator(device="cuda").manual_seed(M)
+        na = M // 2
+        in_a = torch.randperm(Mf, device="cuda", generator=gen)[:na].sort().values           # view a sees these FiLM rows
+        in_b = torch.randperm(Mf, device="cuda", generator=gen)[:M - na].sort().values       # view b these
+        row_of = torch.cat([in_a, in_b]).to(torch.int32)
+        src_a = torch.full((Mf,), -1, dtype=torch.int32, device="cuda")
+        src_b = torch.full((Mf,), -1, dtype=torch.int32, device="cuda")
+        src_a[in_a] = torch.arange(na, dtype=torch.int32, device="cuda")
+        src_b[in_b] = torch.arange(na, M, dtype=torch.int32, device="cuda")
+        cond = cond_film.index_select(0, row_of.long())
+        film = (cond_film, row_of, src_a, src_b)
     gs = [torch.randn(M, n, device="cuda") for n in (10, 30, 70, 30)]
     with torch.no_grad():
         # rows with a FiLM ReLU pre-activation within rounding of its kink take no part in the gradient comparison
@@ -222,7 +239,7 @@ def test_whole_network_chain_kernels_match_torch(M):
         for g in gs:
             g[bad] = 0
     assert mlp.chain_usable(feat, cond, gens, lin)
-    outs = mlp.generate_all(gens, lin, feat, cond)
+    outs = mlp.generate_all(gens, lin, feat, cond, film=film)
     assert "GenerateAll" in type(outs[0].grad_fn).__name__
     sum((o * g).sum() for o, g in zip(outs, gs)).backward()
     params = [p for net in gens for p in net.parameters()] + list(deform.parameters())
@@ -247,7 +264,7 @@ def test_whole_network_chain_kernels_match_torch(M):
     feat.grad = None
     for p in params:
         p.grad = None
-    outs2 = mlp.generate_all(gens, lin, feat, cond)
+    outs2 = mlp.generate_all(gens, lin, feat, cond, film=film)
     sum((o * g).sum() for o, g in zip(outs2, gs)).backward()
     for a, b in zip(got, [feat.grad] + [p.grad for p in params]):
         assert torch.equal(a, b)
@@ -256,5 +273,5 @@ def test_whole_network_chain_kernels_match_torch(M):
     from gsvc_amd import _lib
     d = mlp._gen_desc(mlp._generator_params(gens[0]), 1, 10)
     d.hidden_dim = 96
-    assert _lib.lib().gsvc_generator_saved_floats(C.byref(d), 16) > 0
+    assert _lib.lib().gsvc_generator_saved_floats(C.byref(d), 16, 0) > 0
     assert _lib.lib().gsvc_generator_forward(C.byref(d), None, None, 16, None, None, None) == -3
