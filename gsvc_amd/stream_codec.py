@@ -10,8 +10,9 @@ utils/encodings.py:827-862 (``reorder_and_split``) in what is coded, in which or
   write the reference's file names: ``feat_{s}.b``, ``scaling_{s}.b``, ``offsets_{s}.b``, ``masks.b``, ``hash.b``);
 * binary symbols (masks, hash tables) go through the same coder as a two-symbol alphabet whose model is a unit-range
   Gaussian placed so that P(0) = 1 - p;
-* anchor geometry: the reference hands the 16-bit anchor grid to MPEG G-PCC (``tmc3``, an external executable); here the
-  quantised anchors are stored raw (3 x uint16 per anchor, in the (x, y, z)-sorted order G-PCC would return);
+* anchor geometry: the reference hands the 16-bit anchor grid to MPEG G-PCC (``tmc3``, an external executable); here an own
+  lossless occupancy-octree coder (gsvc_amd/anchor_codec.py) codes it, and the decoder gets the anchors back in the
+  (x, y, z)-sorted order a geometry codec returns;
 * MLP weights: 8-bit quantisation + Huffman code as the reference (gsvc_amd/mlp_codec.py; ``mlp_file=`` below) — the
   quantised networks are the ones that drive the context model of the attribute streams, on both sides.
 
@@ -28,6 +29,7 @@ import torch
 import torch.nn as nn
 
 from .codec import DeferredChecks, ans_decode, ans_decode_many, ans_encode, decoder_gaussian_many, encoder_gaussian, prepare_streams
+from . import anchor_codec
 from .encodings import ANCHOR_ROUND_DIGITS, Quantize_anchor, STE_multistep
 from .model import calc_symbol_min_max
 
@@ -92,7 +94,7 @@ class StreamPack:
     n: int
     anchor_interval: np.ndarray
     anchor_min: np.ndarray
-    anchors_q: np.ndarray                    # uint16 [n, 3], (x, y, z)-sorted
+    anchors_q: np.ndarray                    # uint16 [n, 3], (x, y, z)-sorted (the decoded form of anchor_stream)
     prob_masks: float
     prob_hash: float
     slabs: list = field(default_factory=list)            # [(start, end)] in z order
@@ -102,10 +104,12 @@ class StreamPack:
     masks: bytes = b""
     hash: bytes = b""
     bit_mlp_encoded: int = None              # size of the MLP file written beside the streams (not part of meta.json)
+    anchor_stream: bytes = b""               # gsvc_amd.anchor_codec: occupancy octree + rANS of the anchor geometry
 
     def bits(self):
         """Coded size per stream in bits (same keys as BitInfo where they exist)."""
-        return {**({"bit_mlp_encoded": self.bit_mlp_encoded} if self.bit_mlp_encoded is not None else {}), "bit_anchor": self.anchors_q.size * ANCHOR_ROUND_DIGITS, "bit_feat": 8 * sum(map(len, self.feat)),
+        return {**({"bit_mlp_encoded": self.bit_mlp_encoded} if self.bit_mlp_encoded is not None else {}), "bit_anchor": 8 * len(self.anchor_stream) if self.anchor_stream else self.anchors_q.size * ANCHOR_ROUND_DIGITS,
+                "bit_feat": 8 * sum(map(len, self.feat)),
                 "bit_scaling": 8 * sum(map(len, self.scaling)), "bit_offsets": 8 * sum(map(len, self.offsets)),
                 "bit_masks": 8 * len(self.masks), "bit_hash": 8 * len(self.hash)}
 
@@ -118,7 +122,8 @@ class StreamPack:
         for name, blob in (("masks.b", self.masks), ("hash.b", self.hash)):
             with open(os.path.join(path, name), "wb") as f:
                 f.write(blob)
-        self.anchors_q.tofile(os.path.join(path, "anchor_q16.bin"))
+        with open(os.path.join(path, "anchor.b"), "wb") as f:      # in place of the reference's anchor_compressed.drc (G-PCC)
+            f.write(self.anchor_stream if self.anchor_stream else anchor_codec.encode_anchors(self.anchors_q))
         meta = {"n_full": self.n_full, "n": self.n, "prob_masks": self.prob_masks, "prob_hash": self.prob_hash,
                 "slabs": [list(s) for s in self.slabs],
                 # float32 values survive the trip through JSON doubles exactly
@@ -134,8 +139,9 @@ class StreamPack:
         meta["anchor_interval"] = np.asarray(meta["anchor_interval"], np.float32)
         meta["anchor_min"] = np.asarray(meta["anchor_min"], np.float32)
         meta["slabs"] = [tuple(s) for s in meta["slabs"]]
-        pack = cls(anchors_q=np.fromfile(os.path.join(path, "anchor_q16.bin"), dtype=np.uint16).reshape(-1, 3), **meta)
         rd = lambda name: open(os.path.join(path, name), "rb").read()  # noqa: E731
+        stream = rd("anchor.b")
+        pack = cls(anchors_q=anchor_codec.decode_anchors(stream), anchor_stream=stream, **meta)
         for s in range(len(pack.slabs)):
             pack.feat.append(rd(f"feat_{s}.b")); pack.scaling.append(rd(f"scaling_{s}.b")); pack.offsets.append(rd(f"offsets_{s}.b"))
         pack.masks, pack.hash = rd("masks.b"), rd("hash.b")
@@ -193,8 +199,14 @@ def conduct_stream_encoding(pc, mlp_file=None) -> StreamPack:
     tables = pc.get_encoding_params()                          # {-1, +1}
     prob_hash = float((((tables + 1) / 2).sum() / tables.numel()).item())
     prob_masks = float((mask.sum() / mask.numel()).item())
+    # anchor geometry: occupancy octree over the voxel lattice the anchors sit on (lattice mode), falling back to the 16-bit grid
+    anchor_stream = anchor_codec.encode_anchors(anchors_q, positions=pc._anchor[keep][sel].detach().cpu().numpy(),
+                                                voxel_size=float(pc.voxel_size), interval=interval.cpu().numpy(), a_min=a_min.cpu().numpy())
+    decoded = anchor_codec.decode_anchors(anchor_stream)
+    if not np.array_equal(decoded, anchors_q):
+        raise RuntimeError("stream encoding: the anchor geometry does not survive its own decoder")
     pack = StreamPack(n_full=int(pc._anchor.shape[0]), n=N, anchor_interval=interval.cpu().numpy(), anchor_min=a_min.cpu().numpy(),
-                      anchors_q=anchors_q, prob_masks=prob_masks, prob_hash=prob_hash, slabs=list(slabs))
+                      anchors_q=anchors_q, prob_masks=prob_masks, prob_hash=prob_hash, slabs=list(slabs), anchor_stream=anchor_stream)
     model = _context_all(pc, anchor)
     for a, b in slabs:
         (mf, sf, qf), (ms, ss, qs), (mo, so, qo) = [tuple(t[a:b] for t in grp) for grp in model]

@@ -177,6 +177,16 @@ def test_stream_encode_decode_round_trip(tmp_path):
     # the scalings of this synthetic model are NOT calibrated: symbols beyond the estimator's 2^-16 floor cost the coder
     # up to 20 bits instead of 16
     assert 0.98 * float(info.bit_scaling) <= bits["bit_scaling"] <= 1.3 * float(info.bit_scaling) + 4096
+    # anchor geometry: the occupancy-octree coder in lattice mode (gsvc_amd/anchor_codec.py; the reference's G-PCC stage) — the
+    # anchors sit on the 0.001 voxel lattice: under 20 bits each where the raw 16-bit grid takes 48 (and estimate_final_bits,
+    # like the reference's estimate, books bit_anchor / 2 for a geometry codec)
+    assert pack.anchor_stream and pack.anchor_stream[5] == 1 and bits["bit_anchor"] == 8 * len(pack.anchor_stream)
+    # 18 k anchors scattered over a 2100 x 2100 x 550 lattice: log2(cells / anchors) + 2.6 = 20 bits each (the 245 k-anchor
+    # bench model: 13); the reference's estimate books 24 for its geometry codec
+    import math
+    cells = 2100.0 * 2100.0 * 550.0
+    assert bits["bit_anchor"] / pack.n < math.log2(cells / pack.n) + 4.0, bits["bit_anchor"] / pack.n
+    assert bits["bit_anchor"] < float(info.bit_anchor_gpcc)
     # expected decoded tensors, from the encoder-side model
     K = pc.n_offsets
     with torch.no_grad():
