@@ -211,6 +211,11 @@ def run_stream_decode(args, dev, height=2160, width=3840, frames=300, gaussians_
     for _ in render_frames(fr[:4], warm, pipe, bg):
         pass
     del warm
+    from gsvc_amd import anchor_codec
+    ta0 = time.perf_counter()
+    geo = anchor_codec.decode_anchors(pack.anchor_stream)        # the anchor geometry (host, NumPy): the reference's tmc3 step
+    anchor_decode_s = time.perf_counter() - ta0
+    assert np.array_equal(geo, pack.anchors_q)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     dec = conduct_stream_decoding(target, pack)
@@ -230,6 +235,11 @@ def run_stream_decode(args, dev, height=2160, width=3840, frames=300, gaussians_
             "anchors_coded": pack.n, "gaussians_generated_per_frame": vis * K, "slabs": len(pack.slabs),
             "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t3 - t2) * 1e3, "render_ms_per_frame": (t4 - t3) * 1e3 / max(n, 1),
             "stream_decode_fps": n / (t4 - t2), "render_fps_after_decode": n / (t4 - t3),
+            "anchor_geometry_decode_ms": anchor_decode_s * 1e3, "anchor_bits_per_anchor": bits["bit_anchor"] / max(pack.n, 1),
+            "stream_decode_fps_incl_anchor_geometry": n / (t4 - t2 + anchor_decode_s),
+            "anchor_geometry_note": "occupancy octree + rANS over the voxel lattice (gsvc_amd/anchor_codec.py, NumPy on the host; the "
+                                    "reference runs the external tmc3 executable here); decode_ms / stream_decode_fps are the attribute, "
+                                    "mask and hash-table streams on the GPU, the _incl_ number adds the geometry decode",
             "megabytes": {k[4:]: round(v / 8 / 2 ** 20, 3) for k, v in bits.items()},
             "render_fps_note": PAIR_NOTE}
 
@@ -434,7 +444,13 @@ def run_train_step(args, rank, world, dev):
         torch.cuda.synchronize()
         tc3 = time.perf_counter()
         bits = pack.bits()
+        from gsvc_amd import anchor_codec
+        ta0 = time.perf_counter()
+        anchor_codec.decode_anchors(pack.anchor_stream)
+        anchor_decode_s = time.perf_counter() - ta0
         res["stream_codec"] = {"encode_ms": (tc1 - tc0) * 1e3, "decode_ms": (tc2 - tc1) * 1e3, "slabs": len(pack.slabs),
+                               "anchor_geometry_decode_ms": anchor_decode_s * 1e3, "anchor_bits_per_anchor": bits["bit_anchor"] / max(pack.n, 1),
+                               "stream_decode_fps_incl_anchor_geometry": n_dec / (tc3 - tc1 + anchor_decode_s),
                                "anchors_coded": pack.n, "megabytes": {k[4:]: round(v / 8 / 2 ** 20, 4) for k, v in bits.items()},
                                "ans_decode_kernel": {"launches": kprof.get("k_ans_decode", (0, 0.0))[0],
                                                      "sum_ms": kprof.get("k_ans_decode", (0, 0.0))[1],

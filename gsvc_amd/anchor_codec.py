@@ -11,7 +11,7 @@ with on this side of the boundary; round trips and sizes are what the tests pin)
   single point costs log2(8) = 3 bits per remaining level under the level's own symbol statistics, i.e. its raw coordinates —
   no special case needed.
 * **entropy stage**: a static model per level (the histogram of that level's masks, 12-bit frequencies) and an interleaved
-  rANS coder (32-bit states, 16-bit renormalisation, one lane per 256 symbols up to 1024 lanes) written as NumPy array operations — a level of a
+  rANS coder (32-bit states, 16-bit renormalisation, one lane per 256 symbols, at most 16 384) written as NumPy array operations — a level of a
   million symbols is a thousand vector steps.  Every operation is integer: the streams are exactly reproducible.
 * **lattice mode**: GSVC's anchors are voxel centres (``voxel_size`` = 0.001: reference scene/gaussian_model.py:748-752 and the
   anchor growing of :1316-1449 place them on multiples of the voxel size), which the 16-bit grid then quantises with a
@@ -34,7 +34,7 @@ MAGIC = b"GSAO1"
 PROB_BITS = 12
 PROB_SCALE = 1 << PROB_BITS
 RANS_L = 1 << 16            # lower bound of the normalised state interval [2^16, 2^32)
-MAX_LANES = 1024
+MAX_LANES = 16384        # one lane per 256 symbols (32 state bits per lane): a level of 4 M symbols is 256 vector steps
 
 
 # ------------------------------------------------------------------------------------------------ interleaved rANS (NumPy)
@@ -153,21 +153,34 @@ def _unpack_level(buf: memoryview, at: int, expect: int):
 
 
 # ------------------------------------------------------------------------------------------------ octree over integer points
+def _spread(v: np.ndarray) -> np.ndarray:
+    """Bits b of a 16-bit value -> bit 3 b (the classic magic-number spread)."""
+    v = v.astype(np.uint64) & np.uint64(0xFFFF)
+    v = (v | (v << np.uint64(32))) & np.uint64(0x001F00000000FFFF)
+    v = (v | (v << np.uint64(16))) & np.uint64(0x001F0000FF0000FF)
+    v = (v | (v << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+    v = (v | (v << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+    v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+    return v
+
+
+def _compact(v: np.ndarray) -> np.ndarray:
+    v = v & np.uint64(0x1249249249249249)
+    v = (v | (v >> np.uint64(2))) & np.uint64(0x10C30C30C30C30C3)
+    v = (v | (v >> np.uint64(4))) & np.uint64(0x100F00F00F00F00F)
+    v = (v | (v >> np.uint64(8))) & np.uint64(0x001F0000FF0000FF)
+    v = (v | (v >> np.uint64(16))) & np.uint64(0x001F00000000FFFF)
+    v = (v | (v >> np.uint64(32))) & np.uint64(0xFFFF)
+    return v
+
+
 def _morton(pts: np.ndarray, bits: int) -> np.ndarray:
-    key = np.zeros(pts.shape[0], dtype=np.uint64)
-    p = pts.astype(np.uint64)
-    for b in range(bits - 1, -1, -1):
-        for d in range(3):
-            key = (key << np.uint64(1)) | ((p[:, d] >> np.uint64(b)) & np.uint64(1))
-    return key
+    """Per level (from the top) the bits (x, y, z): x at position 3 b + 2, y at 3 b + 1, z at 3 b."""
+    return (_spread(pts[:, 0]) << np.uint64(2)) | (_spread(pts[:, 1]) << np.uint64(1)) | _spread(pts[:, 2])
 
 
 def _demorton(key: np.ndarray, bits: int) -> np.ndarray:
-    pts = np.zeros((key.size, 3), dtype=np.int64)
-    for b in range(bits):
-        for d in range(3):
-            pts[:, d] |= ((key >> np.uint64(3 * b + (2 - d))) & np.uint64(1)).astype(np.int64) << b
-    return pts
+    return np.stack([_compact(key >> np.uint64(2)), _compact(key >> np.uint64(1)), _compact(key)], axis=1).astype(np.int64)
 
 
 def _encode_octree(pts: np.ndarray, bits: int) -> bytes:
@@ -187,16 +200,26 @@ def _encode_octree(pts: np.ndarray, bits: int) -> bytes:
 _BIT = np.arange(8, dtype=np.int64)
 
 
+_POP = np.array([bin(i).count("1") for i in range(256)], dtype=np.int64)
+_CHILDREN = np.concatenate([[c for c in range(8) if (i >> c) & 1] for i in range(256)] + [[]]).astype(np.uint64)
+_CHILD_AT = np.concatenate([[0], np.cumsum(_POP)]).astype(np.int64)        # where mask i's children start in _CHILDREN
+
+
 def _decode_octree(buf: memoryview, at: int, n_points: int, bits: int):
     nodes = np.zeros(1, dtype=np.uint64)
     for level in range(bits):
         occ, at = _unpack_level(buf, at, nodes.size)
         if (occ < 1).any() or (occ > 255).any():
             raise ValueError("anchor_codec: corrupt occupancy symbol")
-        mask = ((occ[:, None] >> _BIT[None, :]) & 1).astype(bool)
-        nodes = ((nodes[:, None] << np.uint64(3)) | _BIT.astype(np.uint64)[None, :])[mask]
-        if nodes.size > n_points:
+        cnt = _POP[occ]
+        total = int(cnt.sum())
+        if total > n_points:
             raise ValueError("anchor_codec: corrupt stream (more nodes than points)")
+        # child j of node i: the j-th set bit of its mask (table look-up instead of an [n, 8] expansion)
+        first = np.cumsum(cnt) - cnt
+        within = np.arange(total, dtype=np.int64) - np.repeat(first, cnt)
+        child = _CHILDREN[np.repeat(_CHILD_AT[occ], cnt) + within]
+        nodes = (np.repeat(nodes, cnt) << np.uint64(3)) | child
     if nodes.size != n_points:
         raise ValueError("anchor_codec: corrupt stream (point count)")
     return _demorton(nodes, bits), at
@@ -204,6 +227,14 @@ def _decode_octree(buf: memoryview, at: int, n_points: int, bits: int):
 
 # ------------------------------------------------------------------------------------------------ public
 def _lex(p: np.ndarray) -> np.ndarray:
+    """Rows sorted by (x, y, z); values below 2^20 go through one packed 64-bit key (a plain sort, no argsort + gather)."""
+    if p.shape[0] == 0:
+        return p
+    if p.min() >= 0 and p.max() < (1 << 20):
+        q = p.astype(np.uint64)
+        key = np.sort((q[:, 0] << np.uint64(40)) | (q[:, 1] << np.uint64(20)) | q[:, 2])
+        m = np.uint64((1 << 20) - 1)
+        return np.stack([key >> np.uint64(40), (key >> np.uint64(20)) & m, key & m], axis=1).astype(p.dtype)
     return p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
 
 
@@ -275,17 +306,21 @@ def decode_anchors(data: bytes) -> np.ndarray:
     pts, at = _decode_octree(buf, at, int(n_uniq), int(bits))
     if mode == 0:
         dup = np.frombuffer(extra, dtype="<i8").reshape(-1, 2)
-        rep = np.ones(pts.shape[0], dtype=np.int64)
-        pts = _lex(pts)
-        rep[dup[:, 0]] = dup[:, 1]
-        out = np.repeat(pts, rep, axis=0)
+        out = pts
+        if dup.size:                                           # multiplicities are indexed in np.unique's (lexicographic) order
+            rep = np.ones(pts.shape[0], dtype=np.int64)
+            pts = _lex(pts)
+            rep[dup[:, 0]] = dup[:, 1]
+            out = np.repeat(pts, rep, axis=0)
     else:
         dup = np.frombuffer(extra, dtype="<i8", count=2 * n_dup).reshape(-1, 2)
         exc = np.frombuffer(extra, dtype="<u2", offset=16 * n_dup, count=3 * n_exc).reshape(-1, 3).astype(np.int64)
-        pts = _lex(pts)                                        # np.unique's order at the encoder
-        rep = np.ones(pts.shape[0], dtype=np.int64)
-        rep[dup[:, 0]] = dup[:, 1]
-        idx = np.repeat(pts, rep, axis=0) + np.array([ox, oy, oz], dtype=np.int64)
+        if n_dup:                                              # multiplicities are indexed in np.unique's (lexicographic) order
+            pts = _lex(pts)
+            rep = np.ones(pts.shape[0], dtype=np.int64)
+            rep[dup[:, 0]] = dup[:, 1]
+            pts = np.repeat(pts, rep, axis=0)
+        idx = pts + np.array([ox, oy, oz], dtype=np.int64)
         out = np.concatenate([_grid_of(idx, voxel, np.array([i0, i1, i2], np.float32), np.array([m0, m1, m2], np.float32)), exc])
     if out.shape[0] != n:
         raise ValueError("anchor_codec: corrupt stream (anchor count)")
