@@ -162,7 +162,7 @@ struct Sums9 {
 // leaves T and bd unchanged (rcp(1) = 1, 0 * cd + 1 * bd = bd) and adds zeros.  No EXEC-mask branches: the compiler's
 // branchy form spent a third of its instructions on zero-filling the nine sums on every path.
 template <bool CLAMP_STOP>
-__device__ __forceinline__ void bwd_pixel(PixState &p, float dx, float dy, const float4 &a, const float4 &b, float cb,
+__device__ __forceinline__ bool bwd_pixel(PixState &p, float dx, float dy, const float4 &a, const float4 &b, float cb,
                                           int contributor, Sums9 &s)
 {
     float t1 = a.z * dx;                        // -power*log2(e) = A' dx^2 + C' dy^2 + B' dx dy, conic pre-scaled
@@ -188,6 +188,7 @@ __device__ __forceinline__ void bwd_pixel(PixState &p, float dx, float dy, const
     const float hx = h * dx, hy = h * dy;
     s.h += h; s.x += hx; s.y += hy;
     s.xx = fmaf(hx, dx, s.xx); s.xy = fmaf(hx, dy, s.xy); s.yy = fmaf(hy, dy, s.yy);
+    return valid;
 }
 
 // ONE wave per 16x16 tile; lane l owns pixel l of each of the four 8x8 quadrants and walks the quadrants a Gaussian can
@@ -296,6 +297,7 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
         if (k >= beg) { bb_n = inst_bbox[k]; id_n = point_list[k]; gs_n = gslot[k]; }
     }
     if (dbg & 4) return;                                      // timing experiment only: prologue + zero rows
+    int probe_replays = 0, probe_lanes = 0, probe_entries = 0;
     for (int c1 = beg + tile_last; c1 > beg; c1 -= 64) {
         const int k = c1 - 1 - lane;
         const uint2 bb = bb_n;
@@ -336,6 +338,7 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
             s_f2[pos] = make_float2(r2x, __int_as_float(lane | (qm << 8) | ((k - beg + 1) << 12)));
         }
         const int cnt = (dbg & 8) ? 0 : __popcll(mask);      // timing experiment only: chunk overhead without entries
+        probe_entries += cnt;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -351,8 +354,13 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
             if (dbg & 1) { s.h = dxb; s.x = dyb; return; }     // timing experiment only (GSVC_BWD_DEBUG): no replay
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (quads & (1 << q))
-                    bwd_pixel<CLAMP_STOP>(ps[q], dxb - (float)(8 * (q & 1)), dyb - (float)(8 * (q >> 1)), a, b, c.x, contributor, s);
+                if (quads & (1 << q)) {
+                    const bool v = bwd_pixel<CLAMP_STOP>(ps[q], dxb - (float)(8 * (q & 1)), dyb - (float)(8 * (q >> 1)), a, b, c.x, contributor, s);
+                    if (dbg & 128) {      // lane-efficiency probe (tools/bwd_lane_efficiency.py): replays and the lanes they were for
+                        probe_replays++;
+                        probe_lanes += __popcll(__ballot(v));
+                    }
+                }
         };
         // after a reduction lane 8g holds the total of value g (g < 8) in the first register, lane 63 the total of the ninth
         int j = 0;
@@ -391,6 +399,13 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
             row[3] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if ((dbg & 128) && lane == 0) {
+        // bytes 64 .. 87 of the 256-byte counters block (unused by gsvc_raster_counters): replays, valid lanes, replayed entries
+        unsigned long long *pr = reinterpret_cast<unsigned long long *>(const_cast<gsvc_raster_counters *>(counters)) + 8;
+        atomicAdd(pr + 0, (unsigned long long)probe_replays);
+        atomicAdd(pr + 1, (unsigned long long)probe_lanes);
+        atomicAdd(pr + 2, (unsigned long long)probe_entries);
     }
 }
 

@@ -4,7 +4,9 @@ BASELINE.md section 4: the reference's `generate_neural_gaussians` (anchor -> ne
 through our CPU grid oracle in the `_gridencoder` slot, entropy context, quantisation noise, rate, the generator /
 deformation MLPs) forward + backward, followed by our CPU raster oracle forward + backward on the Gaussians it
 produced, at BASELINE.json configs[0] size (~5k Gaussians) and at a 50k-anchor size.  3 warm-ups + N timed
-iterations, median and min.  Writes profiles/r01/reference_cpu_timing.json.
+iterations, median and min.  Writes profiles/r01/reference_cpu_timing.json; `--round3` times the round-3 shapes instead
+(BASELINE.json configs[2]: 245 k anchors in a 64-frame 1080p cube, 16-frame slab; configs[3]: cfg_20240919.yaml as is, 100 k
+anchors in a 600-frame cube, threshold .05) and writes profiles/r03/reference_cpu_timing.json.
 
 Run: python tests/golden/time_reference_cpu.py
 """
@@ -24,7 +26,7 @@ sys.path.insert(0, ROOT)
 import _ref_import  # noqa: E402
 
 
-def build(ref_mods, anchors, seed):
+def build(ref_mods, anchors, seed, zl=-0.3125):
     A, GM = ref_mods
     mp = A.ModelParams()
     mp.threshold = 0.05
@@ -33,7 +35,7 @@ def build(ref_mods, anchors, seed):
                            update_hierachy_factor=4, use_feat_bank=False, n_features_per_level=2, log2_hashmap_size=13,
                            log2_hashmap_size_2D=15)
     g = torch.Generator().manual_seed(seed + 1)
-    xl, yl, zl = -1.0, -0.5625, -0.3125
+    xl, yl = -1.0, -0.5625
     ref.update_anchor_bound(xl, yl, zl)
     lim = torch.tensor([[-xl, -yl, -zl]])
     import torch.nn as nn
@@ -62,12 +64,17 @@ def main():
                    "what": "reference generate_neural_gaussians (TRAINING_ENTROPY) fwd+bwd on PyTorch-CPU with the CPU grid "
                            "oracle in the _gridencoder slot, then the CPU raster oracle fwd+bwd on its output",
                    "cases": []}
-        for label, anchors, (H, W), iters in (("configs[0]-size: 256x256, ~5k Gaussians", 7000, (256, 256), 10),
-                                              ("50k anchors, 1080p", 50000, (1080, 1920), 3)):
-            ref = build((A, GM), anchors, 7)
+        round3 = "--round3" in sys.argv
+        cases = ((("configs[0]-size: 256x256, ~5k Gaussians", 7000, (256, 256), 10, None, -0.3125),
+                  ("50k anchors, 1080p", 50000, (1080, 1920), 3, None, -0.3125)) if not round3 else
+                 (("configs[2] shape: 1080p, 245k anchors in a 64-frame cube, 16-frame slab", 245000, (1080, 1920), 2, 8.0 / 960.0, -64 / 2 / 960.0),
+                  ("configs[3] shape (cfg_20240919.yaml as is): 1080p, 100k anchors in a 600-frame cube, threshold .05", 100000, (1080, 1920), 2,
+                   0.05, -0.3125)))
+        for label, anchors, (H, W), iters, thr_fixed, zl in cases:
+            ref = build((A, GM), anchors, 7, zl)
             z_cam = 0.0
             frame = SimpleNamespace(cam_pos=torch.tensor([0.0, 0.0, z_cam]))
-            thr = 0.05 if anchors <= 7000 else 8.0 / 960.0 * 4
+            thr = thr_fixed if thr_fixed is not None else (0.05 if anchors <= 7000 else 8.0 / 960.0 * 4)
             visible = (ref.get_anchor[:, 2] - z_cam).abs() < thr
             scale = max(H, W, 64) / 2
             view = np.eye(4, dtype=np.float32)
@@ -95,7 +102,7 @@ def main():
                 "oracle_raster_fwd_bwd_s": {"median": float(np.median(t_ras)), "min": float(np.min(t_ras))},
                 "gaussians_per_s_generate_plus_raster": P / float(np.median(t_gen) + np.median(t_ras))})
             print(json.dumps(results["cases"][-1]))
-    out = os.path.join(ROOT, "profiles", "r01", "reference_cpu_timing.json")
+    out = os.path.join(ROOT, "profiles", "r03" if "--round3" in sys.argv else "r01", "reference_cpu_timing.json")
     json.dump(results, open(out, "w"), indent=1)
     print("wrote", out)
 
