@@ -37,15 +37,16 @@ extern "C" int gsvc_linear_forward_ex(const float *X, const float *W, const floa
                                       float *Y2, float *Y3, void *stream)
 {
     GSVC_REQUIRE(M >= 0 && K > 0 && N > 0, "linear_forward_ex: bad shape");
-    GSVC_REQUIRE(epilogue >= GSVC_LIN_NONE && epilogue <= GSVC_LIN_FILM_GRAD, "linear_forward_ex: unknown epilogue %d", epilogue);
+    GSVC_REQUIRE(epilogue >= GSVC_LIN_NONE && epilogue <= GSVC_LIN_ADD, "linear_forward_ex: unknown epilogue %d", epilogue);
     if (N > LIN_NT_MAX * 16 || K > LIN_NT_MAX * 16) {
         set_error("linear_forward_ex: N=%d / K=%d exceed %d", N, K, LIN_NT_MAX * 16);
         return GSVC_E_UNSUPPORTED;
     }
     if (M == 0) return GSVC_OK;
     GSVC_REQUIRE(X && W && Y, "linear_forward_ex: NULL pointer");
-    const bool need1 = epilogue >= GSVC_LIN_MUL_GELU_GRAD, need2 = epilogue >= GSVC_LIN_FILM;
-    const bool out2 = epilogue == GSVC_LIN_GELU_DUAL || epilogue >= GSVC_LIN_FILM, out3 = epilogue == GSVC_LIN_FILM_GRAD;
+    const bool films = epilogue == GSVC_LIN_FILM || epilogue == GSVC_LIN_FILM_GRAD;
+    const bool need1 = epilogue >= GSVC_LIN_MUL_GELU_GRAD, need2 = films;
+    const bool out2 = epilogue == GSVC_LIN_GELU_DUAL || films, out3 = epilogue == GSVC_LIN_FILM_GRAD;
     GSVC_REQUIRE((!need1 || aux1) && (!need2 || aux2) && (!out2 || Y2) && (!out3 || Y3),
                  "linear_forward_ex: epilogue %d misses an operand", epilogue);
     hipStream_t s = (hipStream_t)stream;

@@ -133,8 +133,9 @@ template <int NT, int MODE>
 __device__ __forceinline__ void ws_epilogue(const v4f (&acc)[NT], const float *sbias, __amdgpu_buffer_rsrc_t ry, int yoff, int c00,
                                             int sv, long long rb, long long RB, long long M, int N, const LinEpi &ep)
 {
-    constexpr bool HAS1 = MODE >= GSVC_LIN_MUL_GELU_GRAD, HAS2 = MODE >= GSVC_LIN_FILM;
-    constexpr bool OUT2 = MODE == GSVC_LIN_GELU_DUAL || MODE >= GSVC_LIN_FILM, OUT3 = MODE == GSVC_LIN_FILM_GRAD;
+    constexpr bool FILMS = MODE == GSVC_LIN_FILM || MODE == GSVC_LIN_FILM_GRAD;
+    constexpr bool HAS1 = MODE >= GSVC_LIN_MUL_GELU_GRAD, HAS2 = FILMS;
+    constexpr bool OUT2 = MODE == GSVC_LIN_GELU_DUAL || FILMS, OUT3 = MODE == GSVC_LIN_FILM_GRAD;
     const __amdgpu_buffer_rsrc_t r1 = ws_block_rsrc(HAS1 ? ep.aux1 : nullptr, HAS1 ? rb : RB, RB, M, N);
     const __amdgpu_buffer_rsrc_t r2 = ws_block_rsrc(HAS2 ? ep.aux2 : nullptr, HAS2 ? rb : RB, RB, M, N);
     const __amdgpu_buffer_rsrc_t q2 = ws_block_rsrc(OUT2 ? ep.y2 : nullptr, OUT2 ? rb : RB, RB, M, N);
@@ -167,6 +168,7 @@ __device__ __forceinline__ void ws_epilogue(const v4f (&acc)[NT], const float *s
                 if (MODE == GSVC_LIN_MUL_RELU_MASK) v[i] = x1[tt][i] > 0.f ? v[i] : 0.f;
                 if (MODE == GSVC_LIN_FILM) v2[i] = fmaf(v[i], x1[tt][i], x2[tt][i]);
                 if (MODE == GSVC_LIN_FILM_GRAD) { v2[i] = v[i] * x1[tt][i]; v3[i] = v[i] * x2[tt][i]; }
+                if (MODE == GSVC_LIN_ADD) v[i] += x1[tt][i];
             }
             ws_store4(ry, yoff + 64 * t, c00 + 16 * t, N, sv, v);
             if (OUT2) ws_store4(q2, yoff + 64 * t, c00 + 16 * t, N, sv, v2);
@@ -338,7 +340,8 @@ __global__ void __launch_bounds__(THREADS) k_linear_ws(const float *__restrict__
                 case GSVC_LIN_MUL_GELU_GRAD: ws_epilogue<NT, GSVC_LIN_MUL_GELU_GRAD>(acc, sbias, ry, yoff, c00, sv, rb, RB, M, N, ep); break;
                 case GSVC_LIN_MUL_RELU_MASK: ws_epilogue<NT, GSVC_LIN_MUL_RELU_MASK>(acc, sbias, ry, yoff, c00, sv, rb, RB, M, N, ep); break;
                 case GSVC_LIN_FILM: ws_epilogue<NT, GSVC_LIN_FILM>(acc, sbias, ry, yoff, c00, sv, rb, RB, M, N, ep); break;
-                default: ws_epilogue<NT, GSVC_LIN_FILM_GRAD>(acc, sbias, ry, yoff, c00, sv, rb, RB, M, N, ep); break;
+                case GSVC_LIN_FILM_GRAD: ws_epilogue<NT, GSVC_LIN_FILM_GRAD>(acc, sbias, ry, yoff, c00, sv, rb, RB, M, N, ep); break;
+                default: ws_epilogue<NT, GSVC_LIN_ADD>(acc, sbias, ry, yoff, c00, sv, rb, RB, M, N, ep); break;
             }
         }
     }

@@ -28,7 +28,7 @@ MFMA_MAX_DIM = 192
 MIN_ROWS = 4096
 
 # epilogue codes of gsvc_linear_forward_ex (include/gsvc_hip.h)
-EPI_NONE, EPI_RELU, EPI_GELU_DUAL, EPI_TANH, EPI_SIGMOID, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK, EPI_FILM, EPI_FILM_GRAD = range(9)
+EPI_NONE, EPI_RELU, EPI_GELU_DUAL, EPI_TANH, EPI_SIGMOID, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK, EPI_FILM, EPI_FILM_GRAD, EPI_ADD = range(10)
 
 _workspaces = {}
 
@@ -154,6 +154,79 @@ class _SeqGelu(torch.autograd.Function):
                 g = None
         wg.flush()
         return (g, *grads)
+
+
+class _SeqGeluMany(torch.autograd.Function):
+    """Several Linear -> GELU -> ... -> Linear networks that read the SAME input matrix — the six sub-networks of the three
+    EntropyParamsNets all read the hash-grid feature of the visible anchors (reference scene/gaussian_model.py:198-232,
+    1569-1597) — as ONE autograd function: the forward runs the chains back to back, the backward walks them in turn with the
+    first layers' input gradients ACCUMULATED in place by the product's epilogue (GSVC_LIN_ADD: autograd summed them with five
+    [rows, 192] additions per step) and every weight gradient of every chain in one batch (two launches + one slot reduce).
+    sizes = layers per chain; params = (W, b) of every layer, chain after chain."""
+
+    @staticmethod
+    def forward(ctx, x, sizes, *params):
+        x = x.contiguous()
+        outs, saved, at = [], [x], 0
+        for n in sizes:
+            h = x
+            for i in range(n):
+                w, b = params[at + 2 * i].contiguous(), params[at + 2 * i + 1].contiguous()
+                if i + 1 < n:
+                    a = torch.empty(h.shape[0], w.shape[0], device=h.device, dtype=torch.float32)
+                    z = linear_ex(h, w, b, EPI_GELU_DUAL, y2=a)
+                    saved += [z, a]
+                    h = a
+                else:
+                    h = linear_ex(h, w, b)
+            outs.append(h)
+            at += 2 * n
+        ctx.sizes = tuple(sizes)
+        ctx.set_materialize_grads(False)          # an unused output arrives as None, not as a matrix of zeros
+        ctx.save_for_backward(*saved, *params)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        sizes = ctx.sizes
+        n_saved = 1 + 2 * sum(n - 1 for n in sizes)
+        t = ctx.saved_tensors
+        saved, params = t[:n_saved], t[n_saved:]
+        x = saved[0]
+        grads = [None] * len(params)
+        wg = WgradBatch(x.device)
+        gx = None
+        at, sv = 0, 1
+        for c, n in enumerate(sizes):
+            g = gs[c]
+            zs = [saved[sv + 2 * i] for i in range(n - 1)]
+            acts = [x] + [saved[sv + 2 * i + 1] for i in range(n - 1)]
+            sv += 2 * (n - 1)
+            if g is not None:
+                g = g.contiguous()
+                for i in range(n - 1, -1, -1):
+                    w = params[at + 2 * i].contiguous()
+                    if ctx.needs_input_grad[2 + at + 2 * i]:
+                        grads[at + 2 * i], grads[at + 2 * i + 1] = wg.add(g, acts[i])
+                    if i > 0:
+                        g = linear_ex(g, w, None, EPI_MUL_GELU_GRAD, aux1=zs[i - 1], w_in_out=True)
+                    elif ctx.needs_input_grad[0]:
+                        if gx is None:
+                            gx = linear_ex(g, w, None, w_in_out=True)
+                        else:
+                            linear_ex(g, w, None, EPI_ADD, aux1=gx, w_in_out=True, out=gx)      # gx += g W, in place
+            at += 2 * n
+        wg.flush()
+        return (gx, None, *grads)
+
+
+def seq_gelu_many(x, chains):
+    """chains: lists of nn.Linear (Linear -> GELU -> ... -> Linear each); returns one output per chain."""
+    params = []
+    for linears in chains:
+        for l in linears:
+            params += [l.weight, l.bias]
+    return _SeqGeluMany.apply(x, tuple(len(c) for c in chains), *params)
 
 
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2

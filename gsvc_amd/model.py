@@ -585,8 +585,18 @@ class GaussianModel(nn.Module):
         if ctx.is_cuda and not os.environ.get("GSVC_NO_FUSED_CTX"):
             # split, scale clamp and step activation of each network's raw outputs as one launch each way (csrc/generate.hip)
             out = []
-            for net in (self.mlp_feature_enet, self.mlp_scaling_enet, self.mlp_offset_enet):
-                out += list(_CtxPost.apply(net.dist_net(ctx), net.quant_step_net(ctx)))
+            nets = (self.mlp_feature_enet, self.mlp_scaling_enet, self.mlp_offset_enet)
+            from . import mlp
+            chains = [list(s)[0::2] for net in nets for s in (net.dist_net, net.quant_step_net)]
+            if (all(isinstance(s, GeluSequential) for net in nets for s in (net.dist_net, net.quant_step_net))
+                    and all(mlp.usable(ctx, *c) for c in chains) and not os.environ.get("GSVC_NO_MLP_CHAIN")):
+                # the six sub-networks read the same feature matrix: one autograd function (gsvc_amd.mlp._SeqGeluMany)
+                raw = mlp.seq_gelu_many(ctx, chains)
+                for i in range(3):
+                    out += list(_CtxPost.apply(raw[2 * i], raw[2 * i + 1]))
+            else:
+                for net in nets:
+                    out += list(_CtxPost.apply(net.dist_net(ctx), net.quant_step_net(ctx)))
             mf, sf, qf, ms, ss, qs, mo, so, qo = out
             return EntropyContext(mf, sf, ms, ss, mo, so, qf, qs, qo)
         mean_f, scale_f, q_f = self.mlp_feature_enet(ctx)

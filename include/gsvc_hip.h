@@ -464,10 +464,12 @@ int gsvc_linear_forward(const float *X, const float *W, const float *bias, float
  *   GSVC_LIN_MUL_GELU_GRAD      Y = v * GELU'(aux1)            (dX of a layer behind a GELU: aux1 = its pre-activation)
  *   GSVC_LIN_MUL_RELU_MASK      Y = aux1 > 0 ? v : 0           (dX of a layer behind a ReLU: aux1 = its output)
  *   GSVC_LIN_FILM               Y = v (gamma), Y2 = v * aux1 + aux2          (FiLM: aux1 = h, aux2 = beta)
- *   GSVC_LIN_FILM_GRAD          Y = v (d beta), Y2 = v * aux1 (d gamma, aux1 = h), Y3 = v * aux2 (d h, aux2 = gamma) */
+ *   GSVC_LIN_FILM_GRAD          Y = v (d beta), Y2 = v * aux1 (d gamma, aux1 = h), Y3 = v * aux2 (d h, aux2 = gamma)
+ *   GSVC_LIN_ADD                Y = v + aux1 (aux1 may be Y itself: the input gradients of several networks that read the same
+ *                               matrix — the six entropy sub-networks all read the hash-grid feature — accumulate in place) */
 enum {
     GSVC_LIN_NONE = 0, GSVC_LIN_RELU = 1, GSVC_LIN_GELU_DUAL = 2, GSVC_LIN_TANH = 3, GSVC_LIN_SIGMOID = 4,
-    GSVC_LIN_MUL_GELU_GRAD = 5, GSVC_LIN_MUL_RELU_MASK = 6, GSVC_LIN_FILM = 7, GSVC_LIN_FILM_GRAD = 8
+    GSVC_LIN_MUL_GELU_GRAD = 5, GSVC_LIN_MUL_RELU_MASK = 6, GSVC_LIN_FILM = 7, GSVC_LIN_FILM_GRAD = 8, GSVC_LIN_ADD = 9
 };
 int gsvc_linear_forward_ex(const float *X, const float *W, const float *bias, float *Y, int64_t M, int32_t K, int32_t N,
                            int32_t w_in_out, int32_t epilogue, const float *aux1, const float *aux2, float *Y2, float *Y3,

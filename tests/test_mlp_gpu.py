@@ -275,3 +275,45 @@ def test_whole_network_chain_kernels_match_torch(M, share):
     d.hidden_dim = 96
     assert _lib.lib().gsvc_generator_saved_floats(C.byref(d), 16, 0) > 0
     assert _lib.lib().gsvc_generator_forward(C.byref(d), None, None, 16, None, None, None) == -3
+
+
+def test_entropy_sub_networks_as_one_function_match_torch():
+    """gsvc_amd.mlp.seq_gelu_many: the six sub-networks of the three EntropyParamsNets (reference scene/gaussian_model.py:198-232)
+    on one [rows, 192] feature matrix — outputs, every weight / bias gradient and the input gradient that the first layers'
+    products accumulate in place (GSVC_LIN_ADD) against plain PyTorch."""
+    from gsvc_amd import mlp
+    from gsvc_amd.model import Linear
+    torch.manual_seed(5)
+    M = 6001
+    dims = [(192, 150, 100), (192, 50, 1), (192, 100, 100, 12), (192, 100, 1), (192, 150, 60), (192, 150, 1)]
+    chains = [[Linear(a, b).cuda() for a, b in zip(d[:-1], d[1:])] for d in dims]
+    x = torch.randn(M, 192, device="cuda").requires_grad_(True)
+    gs = [torch.randn(M, d[-1], device="cuda") for d in dims]
+    outs = mlp.seq_gelu_many(x, chains)
+    assert "SeqGeluMany" in type(outs[0].grad_fn).__name__
+    sum((o * g).sum() for o, g in zip(outs, gs)).backward()
+    params = [p for c in chains for l in c for p in (l.weight, l.bias)]
+    got = [x.grad.clone()] + [p.grad.clone() for p in params]
+    x.grad = None
+    for p in params:
+        p.grad = None
+    refs = []
+    for c in chains:
+        h = x
+        for i, l in enumerate(c):
+            h = F.linear(h, l.weight, l.bias)
+            if i + 1 < len(c):
+                h = F.gelu(h)
+        refs.append(h)
+    for o, r in zip(outs, refs):
+        _close(o.detach(), r.detach(), 2e-5)
+    sum((r * g).sum() for r, g in zip(refs, gs)).backward()
+    for a, b in zip(got, [x.grad] + [p.grad for p in params]):
+        _close(a, b, 1e-3)
+    # an output nobody used contributes nothing (and its chain's weights get no gradient)
+    x.grad = None
+    for p in params:
+        p.grad = None
+    outs = mlp.seq_gelu_many(x, chains)
+    (outs[0] * gs[0]).sum().backward()
+    assert chains[1][0].weight.grad is None and chains[0][0].weight.grad is not None and x.grad is not None

@@ -32,6 +32,8 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     for i in range(N):
         tr.step(40 + i)
     torch.cuda.synchronize()
+_src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gsvc_amd", "train.py")).read().splitlines()
+BACKWARD_LINES = [i + 1 for i, l in enumerate(_src) if "loss.backward()" in l or "return self._step_body(" in l]
 by = defaultdict(lambda: [0.0, 0])
 tot = 0.0
 for ev in prof.events():
@@ -56,12 +58,27 @@ for ev in prof.events():
     if not ev.name.startswith("aten::") or ev.self_device_time_total <= 0:
         continue
     fr = [f for f in ev.stack if "gsvc_amd" in f and "torch/" not in f]
-    if fr and "train.py(200)" not in fr[0] and "backward" not in fr[0]:
+    if fr and not any(f"train.py({ln})" in fr[0] for ln in BACKWARD_LINES) and "backward" not in fr[0]:
         continue
     shp = str([list(x) for x in (ev.input_shapes or []) if x])[:70]
     k = (ev.name, shp, (fr[0].split("gsvc_amd/")[-1].split(":")[0].strip() if fr else ""))
     bw[k][0] += ev.self_device_time_total
     bw[k][1] += 1
+# by shape for the three most expensive source lines
+top = [w for w, _ in sorted(line.items(), key=lambda kv: -kv[1])[:3]]
+ts = defaultdict(lambda: [0.0, 0])
+for ev in prof.events():
+    if not ev.name.startswith("aten::") or ev.self_device_time_total <= 0:
+        continue
+    fr = [f for f in ev.stack if "gsvc_amd" in f and "torch/" not in f]
+    where = fr[0].split("gsvc_amd/")[-1].split(":")[0].strip() if fr else "(autograd engine)"
+    if where in top and where != "(autograd engine)":
+        shp = str([list(x) for x in (ev.input_shapes or []) if x])[:70]
+        ts[(where, ev.name, shp)][0] += ev.self_device_time_total
+        ts[(where, ev.name, shp)][1] += 1
+print("most expensive lines, by operator and shape:")
+for (w, n, shp), (t, c) in sorted(ts.items(), key=lambda kv: -kv[1][0])[:40]:
+    print(f"{t / N:8.1f} us x{c / N:4.1f}  {w:22s} {n[6:]:14s} {shp}")
 print("backward-side aten launches by shape:")
 for (n, shp, w), (t, c) in sorted(bw.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"{t / N:8.1f} us x{c / N:4.1f}  {n[6:]:18s} {shp:72s} {w}")
