@@ -944,7 +944,8 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         sizes = [c * K for c in seg.counts]
         parts = [t.split(sizes, dim=0) for t in (xyz, color, neural_opacity, scaling, rot, world)]
         from types import SimpleNamespace
-        batch = SimpleNamespace(scaling=scaling, neural_opacity=neural_opacity, mask=mask, seg_offsets=[b * K for b in seg.bounds], vis=vis)
+        batch = SimpleNamespace(scaling=scaling, neural_opacity=neural_opacity, mask=mask, seg_offsets=[b * K for b in seg.bounds], vis=vis,
+                                xyz=xyz, color=color, rot=rot)      # the un-split tensors: rasterize_many works on their row ranges
         out = []
         for r, gs in enumerate(seg.slices(K)):
             out.append(GeneratedGaussians(

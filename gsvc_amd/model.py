@@ -802,8 +802,13 @@ class GaussianModel(nn.Module):
         op = op_all.detach().view(-1).clamp_min(0).view(-1, K)
         self.opacity_accum.index_add_(0, vi, op.sum(dim=1, keepdim=True))
         self.anchor_demon.index_add_(0, vi, torch.ones(vi.shape[0], 1, device=vi.device, dtype=self.anchor_demon.dtype))
-        w = torch.cat([r.visibility_filter for r in renders]).to(self.offset_denom.dtype).view(-1, K)
-        g2 = torch.cat([r.viewspace_points.grad[:, :2] for r in renders])
+        if batch is not None and getattr(batch, "viewspace", None) is not None and len(renders) > 1:
+            # rasterize_many: one leaf, one radii tensor for all renders
+            w = batch.seen.to(self.offset_denom.dtype).view(-1, K)
+            g2 = batch.viewspace.grad[:, :2]
+        else:
+            w = torch.cat([r.visibility_filter for r in renders]).to(self.offset_denom.dtype).view(-1, K)
+            g2 = torch.cat([r.viewspace_points.grad[:, :2] for r in renders])
         gn = torch.norm(g2, dim=-1).view(-1, K) * w
         self.offset_gradient_accum.view(A, K).index_add_(0, vi, gn.to(self.offset_gradient_accum.dtype))
         self.offset_denom.view(A, K).index_add_(0, vi, w)

@@ -8,7 +8,7 @@ import torch
 
 from ..common.base import RenderResults
 from ..generate import GenerateMode, generate_neural_gaussians, generate_neural_gaussians_many, generator_trunks
-from ..rasterizer import GaussianRasterizer, raster_forward, settings_to_c
+from ..rasterizer import GaussianRasterizer, raster_forward, rasterize_many, settings_to_c
 from .preprocess import prefilter_geometry, prefilter_voxel, raster_settings_for
 
 
@@ -69,6 +69,28 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
     gss_list = generate_neural_gaussians_many(frames, pc, visible, mode, dense=dense,
                                               anchors=None if anchor_grad else geometry[0], plan=plan)
     results = []
+    batch = getattr(gss_list[0], "batch", None) if (dense and gss_list) else None
+    if batch is not None and getattr(batch, "xyz", None) is not None and len(batch.seg_offsets) == len(frames) + 1:
+        # the R renders are row ranges of one set of tensors: one autograd function rasterizes them all (no split of the inputs,
+        # no concatenation of their gradients, one means2D leaf, one radii tensor)
+        bounds = batch.seg_offsets
+        leaf = torch.empty(bounds[-1], 3, dtype=pc._anchor.dtype, device=batch.xyz.device, requires_grad=True)   # value never read
+        cs_list = [settings_to_c(raster_settings_for(f, pc, pipe, bg_color, scaling_modifier)) for f in frames]
+        images, radii_all, states = rasterize_many(cs_list, bounds, batch.xyz, leaf, batch.color, batch.neural_opacity, batch.scaling,
+                                                   batch.rot)
+        seen_all = radii_all > 0
+        batch.viewspace, batch.seen = leaf, seen_all
+        for r, (frame, visible_mask, gss) in enumerate(zip(frames, visible, gss_list)):
+            a, b = bounds[r], bounds[r + 1]
+            results.append(RenderResults(
+                rendered_image=images[r], viewspace_points=_GradRows(leaf, a, b), visibility_filter=seen_all[a:b],
+                visible_mask=visible_mask, radii=radii_all[a:b], active_gaussains=states[r].binning[8:12].view(torch.int32)[0],
+                num_rendered=None, selection_mask=gss.mask, neural_opacity=gss.neural_opacity, scaling=gss.scaling,
+                bit_per_param=gss.bit_per_param, bit_per_feat_param=gss.bit_per_feat_param,
+                bit_per_scaling_param=gss.bit_per_scaling_param, bit_per_offsets_param=gss.bit_per_offsets_param,
+                entropy_constrained=(gss.bit_per_param is not None), generated_gaussians=gss, time_sub=gss.time_sub,
+                dense=dense, visible_index=gss.visible_index, raster_state=states[r]))
+        return results
     for frame, visible_mask, gss in zip(frames, visible, gss_list):
         # the tensor whose .grad receives the screen-space gradient: a leaf (the reference's ``zeros_like(...) + 0`` with
         # retain_grad() holds the same numbers through two more kernels); pc._anchor.dtype, not pc.get_anchor.dtype — the
@@ -92,6 +114,22 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
             entropy_constrained=(gss.bit_per_param is not None), generated_gaussians=gss, time_sub=gss.time_sub,
             dense=dense, visible_index=gss.visible_index, raster_state=num_rendered if dense else None))
     return results
+
+
+class _GradRows:
+    """``viewspace_points`` of one render of a batched step: its ``.grad`` is the render's rows of the batch leaf's gradient
+    (reference scene/gaussian_model.py:1311 reads ``viewspace_points.grad[:, :2]``)."""
+
+    def __init__(self, leaf, a, b):
+        self.leaf, self.a, self.b = leaf, a, b
+
+    @property
+    def grad(self):
+        return None if self.leaf.grad is None else self.leaf.grad[self.a:self.b]
+
+    @property
+    def shape(self):
+        return torch.Size((self.b - self.a, 3))
 
 
 def render_pair(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, mode=GenerateMode.DECODING_AS_IS):

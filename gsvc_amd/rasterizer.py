@@ -122,7 +122,7 @@ _capacity_hint = {}
 
 
 def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales, rotations, max_instances=None,
-                   sync=True, pair=False, readback=False):
+                   sync=True, pair=False, readback=False, radii_out=None):
     """Launch the forward pipeline.  Returns (image, radii, state).  With ``sync`` the instance counters
     are read back (16 B) and the call is repeated with a larger instance capacity if it overflowed; without
     it the caller must check ``state.counters()[1]`` itself (``readback``: the counters' copy to the host is queued right
@@ -143,7 +143,7 @@ def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales,
         binning = torch.empty(sizes.binning_bytes, dtype=torch.uint8, device=dev)
         image_state = torch.empty(sizes.image_bytes, dtype=torch.uint8, device=dev)
         image = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        radii = radii_out if radii_out is not None else torch.empty(P, dtype=torch.int32, device=dev)
         fn = L.gsvc_raster_forward_pair if pair else L.gsvc_raster_forward
         _lib.check(fn(C.byref(cs), P, max_instances, _lib.ptr(means3D), _lib.ptr(colors),
                                          _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(image),
@@ -225,6 +225,67 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.ptr(st.image_state), _lib.ptr(g), _lib.ptr(d3), _lib.ptr(d2), _lib.ptr(dc), _lib.ptr(do), _lib.ptr(ds),
             _lib.ptr(dq), _lib.ptr(scratch), _lib.current_stream(dev)), "gsvc_raster_backward")
         return d3, d2, dc, do, ds, dq, None, None, None
+
+
+class _RasterizeMany(torch.autograd.Function):
+    """R rasterizations of consecutive row ranges of ONE set of Gaussian tensors (the un-compacted renders of a fitting step are
+    slices of the batch the generation pass produced): the forward launches the R pipelines on the ranges in place, the backward
+    writes every render's gradients straight into its rows of batch-sized tensors.  As R separate autograd functions the batch
+    tensors were split on the way in and their six gradients concatenated on the way back (six cat launches, 84 us per step),
+    with a zero-filled means2D leaf and a radii tensor per render."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, cs_list, bounds, holder):
+        means3D, colors = _as_f32(means3D, "means3D"), _as_f32(colors, "colors_precomp")
+        opacities, scales, rotations = _as_f32(opacities, "opacities"), _as_f32(scales, "scales"), _as_f32(rotations, "rotations")
+        N = int(means3D.shape[0])
+        radii = torch.empty(N, dtype=torch.int32, device=means3D.device)
+        images, states = [], []
+        for r, cs in enumerate(cs_list):
+            a, b = bounds[r], bounds[r + 1]
+            img, _, st = raster_forward(cs, means3D[a:b], colors[a:b], opacities[a:b], scales[a:b], rotations[a:b], sync=False,
+                                        readback=True, radii_out=radii[a:b])
+            images.append(img)
+            states.append(st)
+        ctx.states, ctx.bounds = states, tuple(bounds)
+        ctx.save_for_backward(means3D, colors, opacities, scales, rotations)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
+        holder["states"] = states
+        return (*images, radii)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        means3D, colors, opacities, scales, rotations = ctx.saved_tensors
+        N, dev = means3D.shape[0], means3D.device
+        d3, d2, dc = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
+        do, ds, dq = torch.empty(N, 1, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, 4, device=dev)
+        L, stream = _lib.lib(), _lib.current_stream(dev)
+        for r, st in enumerate(ctx.states):
+            a, b = ctx.bounds[r], ctx.bounds[r + 1]
+            g = grads[r]
+            if g is None:           # a render nothing was computed from: its Gaussians get no gradient
+                for t in (d3, d2, dc, do, ds, dq):
+                    t[a:b].zero_()
+                continue
+            g = _as_f32(g, "grad_image")
+            P = st.P
+            scratch = torch.empty(backward_scratch_floats(P, st.max_instances), device=dev)
+            _lib.check(L.gsvc_raster_backward(
+                C.byref(st.cs), P, st.max_instances, _lib.ptr(means3D[a:b]), _lib.ptr(colors[a:b]), _lib.ptr(opacities[a:b]),
+                _lib.ptr(scales[a:b]), _lib.ptr(rotations[a:b]), _lib.ptr(st.radii), _lib.ptr(st.geom), _lib.ptr(st.binning),
+                _lib.ptr(st.image_state), _lib.ptr(g), _lib.ptr(d3[a:b]), _lib.ptr(d2[a:b]), _lib.ptr(dc[a:b]), _lib.ptr(do[a:b]),
+                _lib.ptr(ds[a:b]), _lib.ptr(dq[a:b]), _lib.ptr(scratch), stream), "gsvc_raster_backward")
+        return d3, d2, dc, do, ds, dq, None, None, None
+
+
+def rasterize_many(cs_list, bounds, means3D, means2D, colors, opacities, scales, rotations):
+    """(images [R], radii [N] int32, states [R]) of R un-synchronised rasterizations over the row ranges ``bounds`` (R + 1
+    offsets) of the given tensors; ``means2D`` is the [N, 3] leaf whose .grad receives the screen-space gradients.  The caller
+    resolves the instance counters with resolve_deferred(states)."""
+    holder = {}
+    out = _RasterizeMany.apply(means3D, means2D, colors, opacities, scales, rotations, list(cs_list), list(bounds), holder)
+    return list(out[:-1]), out[-1], holder["states"]
 
 
 class GaussianRasterizer(nn.Module):
