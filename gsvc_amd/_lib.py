@@ -135,6 +135,7 @@ _SIGNATURES = {
     "gsvc_gather_rows_backward": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [_vp] * 9),
     "gsvc_gather_rows_backward_ranked": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [_vp] * 9),
     "gsvc_plan_masks": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, _i64, _vp, C.c_int32, C.c_int32, _vp, C.c_float, _vp, _vp, _vp, _vp]),
+    "gsvc_compact_by_scan": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "gsvc_param_means_scratch_floats": (C.c_int64, []),
     "gsvc_param_means": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int32, _vp, _i64, _vp, _vp, _vp]),
     "gsvc_ctx_post_forward": (C.c_int, [_vp, _vp, _i64, C.c_int32, _vp, _vp, _vp, _vp]),

@@ -499,6 +499,31 @@ extern "C" int gsvc_plan_masks(const uint8_t *const *visible_host, int32_t R, in
     return gsvc::check_launch("plan_masks");
 }
 
+// Compaction of a mask by its inclusive scan: out[scan[i] - 1] = (value ? value[i] : i) for every set mask[i] — one
+// elementwise pass (torch.nonzero_static re-scans: 38 us for the step plan's 1 M-entry view mask, three of them per step).
+// The tail of `out` (capacity - count entries) is left untouched: callers cut the list to the count they read back.
+namespace gsvc {
+__global__ void __launch_bounds__(256) k_compact_by_scan(const uint8_t *__restrict__ mask, const long long *__restrict__ scan,
+                                                         const long long *__restrict__ value, long long value_bias, long long n,
+                                                         long long *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && mask[i]) out[scan[i] - 1] = value ? value[i] + value_bias : i;
+}
+}  // namespace gsvc
+
+extern "C" int gsvc_compact_by_scan(const uint8_t *mask, const int64_t *scan, const int64_t *value, int64_t value_bias, int64_t n,
+                                    int64_t *out, void *stream)
+{
+    GSVC_REQUIRE(n >= 0, "compact_by_scan: bad size");
+    if (n == 0) return GSVC_OK;
+    GSVC_REQUIRE(mask && scan && out, "compact_by_scan: NULL pointer");
+    gsvc::ProfScope _prof("k_compact_by_scan", (hipStream_t)stream);
+    hipLaunchKernelGGL(gsvc::k_compact_by_scan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask,
+                       (const long long *)scan, (const long long *)value, (long long)value_bias, (long long)n, (long long *)out);
+    return gsvc::check_launch("compact_by_scan");
+}
+
 extern "C" int gsvc_ctx_post_forward(const float *params, const float *q, int64_t n, int32_t C, float *mean, float *scale, float *adj,
                                      void *stream)
 {

@@ -299,7 +299,9 @@ class StepPlan:
                 with torch.no_grad():
                     live = pc.get_mask.reshape(A, -1).sum(dim=1) > 0      # mask_anchor for every anchor
                 chosen = M & live.unsqueeze(0) & (torch.rand(R, A, device=dev) <= SAMPLE_RATE)
-            counts.append(chosen.sum().reshape(1))
+            # the sample's size: last element of the scan its compaction below needs anyway (fused plan), else a sum
+            chosen_scan = torch.cumsum(chosen.view(-1), dim=0) if fused else None
+            counts.append(chosen_scan[-1:] if fused else chosen.sum().reshape(1))
         # the counts leave for the host FIRST: the next step waits for them only, and the compactions below (the bulk of the
         # plan's GPU time) run while the host is already launching that step
         self._A = A
@@ -307,12 +309,26 @@ class StepPlan:
         self._host.copy_(torch.cat(counts), non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
-        self._flat = torch.nonzero_static(M.view(-1), size=R * A).squeeze(1)
-        self._distinct = torch.nonzero_static(present, size=A).squeeze(1)
         self._sel_flat = None
-        if sample:
-            pick = torch.nonzero_static(chosen.view(-1), size=R * A).squeeze(1)       # in (r, a) order = row order
-            self._sel_flat = c.index_select(0, pick.clamp_min(0)) - 1
+        if fused:
+            # index lists by the scans that exist anyway: one elementwise scatter each (gsvc_compact_by_scan)
+            from . import _lib
+            L, st = _lib.lib(), _lib.current_stream(dev)
+            self._flat = torch.empty(R * A, dtype=torch.int64, device=dev)
+            self._distinct = torch.empty(A, dtype=torch.int64, device=dev)
+            _lib.check(L.gsvc_compact_by_scan(_lib.ptr(M), _lib.ptr(c), None, 0, R * A, _lib.ptr(self._flat), st), "gsvc_compact_by_scan")
+            _lib.check(L.gsvc_compact_by_scan(_lib.ptr(present), _lib.ptr(pos_incl), None, 0, A, _lib.ptr(self._distinct), st),
+                       "gsvc_compact_by_scan")
+            if sample:
+                self._sel_flat = torch.empty(R * A, dtype=torch.int64, device=dev)      # row (= scan of the view mask - 1) of every chosen (r, a)
+                _lib.check(L.gsvc_compact_by_scan(_lib.ptr(chosen), _lib.ptr(chosen_scan), _lib.ptr(c), -1, R * A, _lib.ptr(self._sel_flat), st),
+                           "gsvc_compact_by_scan")
+        else:
+            self._flat = torch.nonzero_static(M.view(-1), size=R * A).squeeze(1)
+            self._distinct = torch.nonzero_static(present, size=A).squeeze(1)
+            if sample:
+                pick = torch.nonzero_static(chosen.view(-1), size=R * A).squeeze(1)       # in (r, a) order = row order
+                self._sel_flat = c.index_select(0, pick.clamp_min(0)) - 1
         self.vis_list = self.distinct = self.sel = None
         self.distinct_cap = None
 

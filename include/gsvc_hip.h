@@ -403,6 +403,10 @@ int gsvc_gather_rows_backward_ranked(const float *scaling_p, const float *mask_p
  * stored 0 / 1 values when decoded; reference scene/gaussian_model.py get_mask_anchor), u [R*A] uniform draws of the caller. */
 int gsvc_plan_masks(const uint8_t *const *visible_host, int32_t R, int64_t A, const float *mask_raw, int32_t K, int32_t decoded,
                     const float *u, float rate, uint8_t *M, uint8_t *present, uint8_t *chosen, void *stream);
+/* out[scan[i] - 1] = (value ? value[i] + value_bias : i) for every i with mask[i] != 0, `scan` = inclusive scan of the mask
+ * (int64): the index lists of the step plan in one elementwise pass each; entries of `out` past the count are not written. */
+int gsvc_compact_by_scan(const uint8_t *mask, const int64_t *scan, const int64_t *value, int64_t value_bias, int64_t n, int64_t *out,
+                         void *stream);
 
 /* Means of three whole parameter tensors in one pass (the x_mean terms of the rate's clamp bounds: reference
  * utils/entropy_models.py EntropyGaussian.forward, x_mean = mean of the full attribute tensor): out3 = (mean(feat),
