@@ -181,7 +181,11 @@ __device__ __forceinline__ void wg_main_t(const float *__restrict__ G, const flo
 {
     const long long RB = (M + 15) >> 4;
     const int ca = n0 + TN * j, cb = k0 + TK * j;          // this lane's first column of G / X
+#ifdef GSVC_WG_NO_DUP      // timing experiment: every operand block loaded by ONE wave of the workgroup (results wrong)
+    const bool va = ca < N && k0 == 0, vb = cb < K && n0 == 0;
+#else
     const bool va = ca < N, vb = cb < K;
+#endif
     float fa[4][4], fb[4][4];          // [step][tile]
     {
         const __amdgpu_buffer_rsrc_t rg = ws_block_rsrc(G, rb, RB, M, N), rx = ws_block_rsrc(X, rb, RB, M, K);
@@ -207,11 +211,18 @@ __device__ __forceinline__ void wg_main_t(const float *__restrict__ G, const flo
             for (int tn = 0; tn < TN; tn++) {
                 gsum[tn] += fa[s][tn];
 #pragma unroll
-                for (int tk = 0; tk < TK; tk++)
+                for (int tk = 0; tk < TK; tk++) {
+#ifdef GSVC_WG_NO_MFMA      // timing experiment (tools/scratch): the operand stream alone
+                    acc[tn][tk][0] += fa[s][tn] + fb[s][tk];
+#else
                     acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][tn], fb[s][tk], acc[tn][tk], 0, 0, 0);
+#endif
+                }
             }
+#ifndef GSVC_WG_NO_LOAD     // timing experiment: the MFMAs alone (operands of the first chunk reused)
             wg_load_t<TN>(rg, va ? ((4 * s + mq) * N + ca) * 4 : BUF_OOB, fa[s]);
             wg_load_t<TK>(rx, vb ? ((4 * s + mq) * K + cb) * 4 : BUF_OOB, fb[s]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
