@@ -122,6 +122,14 @@ _SIGNATURES = {
     "gsvc_ssim_l1_pair_forward": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_ssim_l1_pair_backward": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_ste_binary_count": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "gsvc_rate_normalise_scratch_bytes": (_i64, []),
+    "gsvc_rate_normalise_forward": (C.c_int, [_vp, _vp, C.c_int32, _vp, _i64, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_float), _vp, _vp,
+                                              _vp, _vp, _vp]),
+    "gsvc_rate_normalise_backward": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),
+    "gsvc_training_statis": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _i64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_ste_binary_count_many": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, _vp]),
+    "gsvc_ste_binary_backward_many": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, C.c_int32, _vp, _vp]),
+    "gsvc_table_bits": (C.c_int, [_vp, C.c_int32, _i64, _vp, _vp]),
     "gsvc_adam_step": (C.c_int, [C.c_int32, C.POINTER(AdamTensorC), C.c_double, C.c_double, C.c_double, _vp]),
     "gsvc_adam_step_guarded": (C.c_int, [C.c_int32, C.POINTER(AdamTensorC), C.c_double, C.c_double, C.c_double, C.POINTER(C.c_void_p),
                                          C.c_int32, _vp]),

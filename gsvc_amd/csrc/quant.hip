@@ -168,6 +168,90 @@ __global__ void __launch_bounds__(256) k_ste_binary_count(const float *__restric
     if (threadIdx.x == 0) atomicAdd(count, (red[0] + red[1]) + (red[2] + red[3]));      // integer-valued sums below 2^24: exact
 }
 
+// The same for every hash table of the model in ONE launch (four tables per fitting step), the hash-bit term itself, and the
+// straight-through backward with the bit term's gradient folded in — the per-table PyTorch form was ~40 one-table launches a step.
+constexpr int STE_MAX_TABLES = 8;
+constexpr int STE_CHUNK = 4096;          // elements per block
+struct SteTables {
+    const float *x[STE_MAX_TABLES];
+    const float *g[STE_MAX_TABLES];
+    float *y[STE_MAX_TABLES];
+    long long n[STE_MAX_TABLES];
+    int first_block[STE_MAX_TABLES + 1];
+    int tables;
+};
+
+__device__ __forceinline__ int ste_table_of(const SteTables &t, int b)
+{
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < STE_MAX_TABLES; q++)
+        if (q < t.tables && b >= t.first_block[q]) k = q;
+    return k;
+}
+
+__global__ void __launch_bounds__(256) k_ste_binary_count_many(SteTables t, float *__restrict__ counts)
+{
+    __shared__ float red[4];
+    const int k = ste_table_of(t, (int)blockIdx.x);
+    const float *__restrict__ x = t.x[0];
+    float *__restrict__ y = t.y[0];
+    long long n = t.n[0];
+    int fb = t.first_block[0];
+#pragma unroll
+    for (int q = 1; q < STE_MAX_TABLES; q++)
+        if (k == q) { x = t.x[q]; y = t.y[q]; n = t.n[q]; fb = t.first_block[q]; }
+    const long long i0 = (long long)((int)blockIdx.x - fb) * STE_CHUNK;
+    float c = 0.f;
+#pragma unroll 4
+    for (int e = threadIdx.x; e < STE_CHUNK; e += 256) {
+        const long long i = i0 + e;
+        if (i < n) {
+            const bool pos = x[i] >= 0.f;
+            y[i] = pos ? 1.0f : -1.0f;
+            c += pos ? 1.f : 0.f;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(counts + k, (red[0] + red[1]) + (red[2] + red[3]));      // integer-valued sums below 2^24: exact
+}
+
+// out[0] = bits = n1 (-log2 p) + n0 (-log2 (1 - p)) + 32, p = n1 / total clamped to [1e-6, 1 - 1e-6] (reference
+// utils/encodings.py:34-51, float32 as there); out[1] = d bits / d n1 = log2((1 - p) / p) (the terms through p cancel where p
+// is not clamped and vanish where it is)
+__global__ void k_table_bits(const float *__restrict__ counts, int tables, float total, float *__restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float ones = 0.f;
+    for (int k = 0; k < tables; k++) ones += counts[k];
+    const float p = fminf(fmaxf(ones / total, 1e-6f), 1.f - 1e-6f);
+    out[0] = ones * (-log2f(p)) + (total - ones) * (-log2f(1.f - p)) + 32.f;
+    out[1] = log2f((1.f - p) / p);
+}
+
+// grad x = (|x| <= 1) ? grad y + 0.5 * grad count : 0   (count = (sum of y + n) / 2: every entry's share of it is 1/2)
+__global__ void __launch_bounds__(256) k_ste_binary_bwd_many(SteTables t, const float *__restrict__ count_grads, int count_stride)
+{
+    const int k = ste_table_of(t, (int)blockIdx.x);
+    const float *__restrict__ x = t.x[0], *__restrict__ g = t.g[0];
+    float *__restrict__ y = t.y[0];
+    long long n = t.n[0];
+    int fb = t.first_block[0];
+#pragma unroll
+    for (int q = 1; q < STE_MAX_TABLES; q++)
+        if (k == q) { x = t.x[q]; g = t.g[q]; y = t.y[q]; n = t.n[q]; fb = t.first_block[q]; }
+    const float add = count_grads ? 0.5f * count_grads[k * count_stride] : 0.f;
+    const long long i0 = (long long)((int)blockIdx.x - fb) * STE_CHUNK;
+#pragma unroll 4
+    for (int e = threadIdx.x; e < STE_CHUNK; e += 256) {
+        const long long i = i0 + e;
+        if (i < n) y[i] = fabsf(x[i]) <= 1.f ? (g ? g[i] : 0.f) + add : 0.f;
+    }
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -236,4 +320,57 @@ extern "C" int gsvc_ste_binary_count(const float *x, int64_t n, float *y, float 
     gsvc::ProfScope _prof("k_ste_binary", s);
     hipLaunchKernelGGL(gsvc::k_ste_binary_count, dim3((unsigned)blocks), dim3(256), 0, s, x, (long long)n, y, count);
     return gsvc::check_launch("ste_binary_count");
+}
+
+static bool ste_fill(const float *const *x, const float *const *g, float *const *y, const int64_t *n, int32_t tables, SteTables &t, int &blocks)
+{
+    if (!x || !y || !n || tables < 1 || tables > STE_MAX_TABLES) return false;
+    blocks = 0;
+    for (int k = 0; k < STE_MAX_TABLES; k++) {
+        const int q = k < tables ? k : 0;
+        if (n[q] < 0 || n[q] >= (1ll << 24) || (n[q] > 0 && (!x[q] || !y[q]))) return false;
+        t.x[k] = x[q]; t.g[k] = g ? g[q] : nullptr; t.y[k] = y[q]; t.n[k] = n[q];
+        t.first_block[k] = blocks;
+        if (k < tables) blocks += (int)((n[q] + STE_CHUNK - 1) / STE_CHUNK);
+    }
+    t.first_block[STE_MAX_TABLES] = blocks;
+    t.tables = tables;
+    return true;
+}
+
+extern "C" int gsvc_ste_binary_count_many(const float *const *x, float *const *y, const int64_t *n, int32_t tables, float *counts,
+                                          void *stream)
+{
+    SteTables t;
+    int blocks = 0;
+    GSVC_REQUIRE(ste_fill(x, nullptr, y, n, tables, t, blocks) && counts, "ste_binary_count_many: 1..8 tables of fewer than 2^24 entries");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(float) * tables, s) != hipSuccess) {
+        gsvc::set_error("ste_binary_count_many: hipMemsetAsync failed");
+        return GSVC_E_LAUNCH;
+    }
+    if (blocks == 0) return GSVC_OK;
+    gsvc::ProfScope _prof("k_ste_binary", s);
+    hipLaunchKernelGGL(gsvc::k_ste_binary_count_many, dim3((unsigned)blocks), dim3(256), 0, s, t, counts);
+    return gsvc::check_launch("ste_binary_count_many");
+}
+
+extern "C" int gsvc_ste_binary_backward_many(const float *const *x, const float *const *grad_y, const int64_t *n, int32_t tables,
+                                             const float *count_grads, int32_t count_grad_stride, float *const *grad_x, void *stream)
+{
+    SteTables t;
+    int blocks = 0;
+    GSVC_REQUIRE(ste_fill(x, grad_y, grad_x, n, tables, t, blocks), "ste_binary_backward_many: 1..8 tables of fewer than 2^24 entries");
+    if (blocks == 0) return GSVC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    gsvc::ProfScope _prof("k_ste_binary_bwd", s);
+    hipLaunchKernelGGL(gsvc::k_ste_binary_bwd_many, dim3((unsigned)blocks), dim3(256), 0, s, t, count_grads, (int)count_grad_stride);
+    return gsvc::check_launch("ste_binary_backward_many");
+}
+
+extern "C" int gsvc_table_bits(const float *counts, int32_t tables, int64_t total, float *out, void *stream)
+{
+    GSVC_REQUIRE(counts && out && tables >= 1 && total > 0, "table_bits: bad arguments");
+    hipLaunchKernelGGL(gsvc::k_table_bits, dim3(1), dim3(64), 0, (hipStream_t)stream, counts, tables, (float)total, out);
+    return gsvc::check_launch("table_bits");
 }

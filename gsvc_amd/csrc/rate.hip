@@ -361,6 +361,112 @@ __global__ void __launch_bounds__(256) k_param_means_sum(const float *__restrict
     }
 }
 
+// Normalisation of the sampled rate (reference guassian.py:110-132 per render): bits per coded parameter of the three groups
+// and of all of them, scaled by the render's keep rate = its rows with a live offset / its rows.  The PyTorch form was ~20
+// few-element launches forward (mask sums, a searchsorted for the sample sizes, divisions) and as many backward.
+constexpr int RN_BLOCKS = 256;
+struct RateNormBounds { long long b[RS_MAX_R + 1]; };
+
+// part[block][r] = rows of render r in the block's share of the rows whose K offset masks sum to more than zero
+__global__ void __launch_bounds__(256) k_rate_live_part(const float *__restrict__ offset_masks, long long rows, int K, RateNormBounds rb, int R,
+                                                        int *__restrict__ part)
+{
+    __shared__ int cnt[RS_MAX_R];
+    if (threadIdx.x < RS_MAX_R) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const long long per = (rows + gridDim.x - 1) / gridDim.x, r0 = per * blockIdx.x;
+    const long long r1 = r0 + per < rows ? r0 + per : rows;
+    for (long long row = r0 + threadIdx.x; row < r1; row += 256) {
+        float s = 0.f;
+        for (int k = 0; k < K; k++) s += offset_masks[row * K + k];
+        if (s > 0.f) {
+            int r = 0;
+            while (r + 1 < R && row >= rb.b[r + 1]) r++;
+            atomicAdd(&cnt[r], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < RS_MAX_R) part[blockIdx.x * RS_MAX_R + threadIdx.x] = cnt[threadIdx.x];
+}
+
+__device__ __forceinline__ long long rn_lower_bound(const long long *__restrict__ a, long long n, long long v)
+{
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// out[r] = {all, features, scalings, offsets} bits per parameter; coef[r] = d out[r][i] / d (the S it divides); sum = sum_r out[r][0]
+__global__ void __launch_bounds__(64) k_rate_normalise(const float *__restrict__ S, const int *__restrict__ part, int blocks,
+                                                       const long long *__restrict__ sel, long long n_sel, RateNormBounds rb, int R, float d0,
+                                                       float d1, float d2, float *__restrict__ out, float *__restrict__ coef, float *__restrict__ sum)
+{
+    __shared__ float tot[RS_MAX_R];
+    const int r = threadIdx.x;
+    if (r < R) {
+        int live = 0;
+        for (int b = 0; b < blocks; b++) live += part[b * RS_MAX_R + r];
+        const long long rows = rb.b[r + 1] - rb.b[r];
+        const float kr = (float)live / (float)(rows > 1 ? rows : 1);
+        const float ns = (float)(rn_lower_bound(sel, n_sel, rb.b[r + 1]) - rn_lower_bound(sel, n_sel, rb.b[r]));
+        const float N0 = ns * d0, N1 = ns * d1, N2 = ns * d2, NA = (N0 + N1) + N2;
+        const float s0 = S[r * 3], s1 = S[r * 3 + 1], s2 = S[r * 3 + 2];
+        out[r * 4] = ((s0 + s1) + s2) / NA * kr;
+        out[r * 4 + 1] = s0 / N0 * kr;
+        out[r * 4 + 2] = s1 / N1 * kr;
+        out[r * 4 + 3] = s2 / N2 * kr;
+        coef[r * 4] = kr / NA; coef[r * 4 + 1] = kr / N0; coef[r * 4 + 2] = kr / N1; coef[r * 4 + 3] = kr / N2;
+        tot[r] = out[r * 4];
+    }
+    __syncthreads();
+    if (r == 0) {
+        float t = 0.f;
+        for (int q = 0; q < R; q++) t += tot[q];
+        sum[0] = t;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_rate_normalise_bwd(const float *__restrict__ coef, const float *__restrict__ g_out,
+                                                           const float *__restrict__ g_sum, int R, float *__restrict__ gS)
+{
+    const int i = threadIdx.x;
+    if (i >= 3 * R) return;
+    const int r = i / 3, g = i - 3 * r;
+    const float ga = (g_out ? g_out[r * 4] : 0.f) + (g_sum ? g_sum[0] : 0.f);
+    gS[i] = ga * coef[r * 4] + (g_out ? g_out[r * 4 + 1 + g] * coef[r * 4 + 1 + g] : 0.f);
+}
+
+// Densification statistics of the un-compacted renders of a step (reference scene/gaussian_model.py:1281-1314 through the
+// nested masks visible anchor -> opacity > 0 -> radius > 0): per anchor the positive opacities of its K Gaussians and one visit,
+// per (anchor, slot) the screen-space gradient norm and one count where the Gaussian was rasterised.  One launch instead of
+// eleven (clamp, sums, a norm, four index_adds and their temporaries).
+__global__ void __launch_bounds__(256) k_training_statis(const long long *__restrict__ vis, const float *__restrict__ opacity,
+                                                         const uint8_t *__restrict__ seen, const float *__restrict__ grad, int grad_stride,
+                                                         long long rows, int K, float *__restrict__ opacity_accum,
+                                                         float *__restrict__ anchor_denom, float *__restrict__ grad_accum,
+                                                         float *__restrict__ denom)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * K) return;
+    const long long row = i / K;
+    const int k = (int)(i - row * K);
+    const long long a = vis[row];
+    if (seen[i]) {
+        const float gx = grad[i * grad_stride], gy = grad[i * grad_stride + 1];
+        atomicAdd(grad_accum + a * K + k, sqrtf(gx * gx + gy * gy));
+        atomicAdd(denom + a * K + k, 1.f);
+    }
+    if (k == 0) {
+        float s = 0.f;
+        for (int q = 0; q < K; q++) s += fmaxf(opacity[row * K + q], 0.f);
+        atomicAdd(opacity_accum + a, s);
+        atomicAdd(anchor_denom + a, 1.f);
+    }
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -470,4 +576,51 @@ extern "C" int gsvc_param_means(const float *feat, int64_t n_feat, const float *
     hipLaunchKernelGGL(gsvc::k_param_means_sum, dim3(1), dim3(256), 0, s, scratch, gsvc::PM_BLOCKS, (long long)n_feat,
                        (long long)n_scaling, (long long)n_offset, out3);
     return gsvc::check_launch("param_means");
+}
+
+static bool rn_bounds(const int64_t *row_bounds, int32_t R, gsvc::RateNormBounds &rb)
+{
+    if (!row_bounds || R < 1 || R > gsvc::RS_MAX_R) return false;
+    for (int r = 0; r <= gsvc::RS_MAX_R; r++) rb.b[r] = row_bounds[r <= R ? r : R];
+    for (int r = 0; r < R; r++)
+        if (rb.b[r + 1] < rb.b[r]) return false;
+    return true;
+}
+
+extern "C" int64_t gsvc_rate_normalise_scratch_bytes(void) { return (int64_t)gsvc::RN_BLOCKS * gsvc::RS_MAX_R * sizeof(int); }
+
+extern "C" int gsvc_rate_normalise_forward(const float *S, const float *offset_masks, int32_t K, const int64_t *sel, int64_t n_sel,
+                                           const int64_t *row_bounds_host, int32_t R, const float *dims3_host, void *scratch,
+                                           float *out, float *coef, float *sum, void *stream)
+{
+    gsvc::RateNormBounds rb;
+    GSVC_REQUIRE(rn_bounds(row_bounds_host, R, rb) && K > 0 && n_sel >= 0 && dims3_host, "rate_normalise_forward: 1..16 renders, K > 0");
+    GSVC_REQUIRE(S && scratch && out && coef && sum && (n_sel == 0 || sel) && (rb.b[R] == 0 || offset_masks), "rate_normalise_forward: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gsvc::k_rate_live_part, dim3(gsvc::RN_BLOCKS), dim3(256), 0, s, offset_masks, (long long)rb.b[R], (int)K, rb, (int)R,
+                       (int *)scratch);
+    hipLaunchKernelGGL(gsvc::k_rate_normalise, dim3(1), dim3(64), 0, s, S, (const int *)scratch, gsvc::RN_BLOCKS, (const long long *)sel,
+                       (long long)n_sel, rb, (int)R, dims3_host[0], dims3_host[1], dims3_host[2], out, coef, sum);
+    return gsvc::check_launch("rate_normalise_forward");
+}
+
+extern "C" int gsvc_rate_normalise_backward(const float *coef, const float *g_out, const float *g_sum, int32_t R, float *gS, void *stream)
+{
+    GSVC_REQUIRE(coef && gS && R >= 1 && R <= gsvc::RS_MAX_R, "rate_normalise_backward: bad arguments");
+    hipLaunchKernelGGL(gsvc::k_rate_normalise_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, coef, g_out, g_sum, (int)R, gS);
+    return gsvc::check_launch("rate_normalise_backward");
+}
+
+extern "C" int gsvc_training_statis(const int64_t *vis, const float *opacity, const uint8_t *seen, const float *grad, int32_t grad_stride,
+                                    int64_t rows, int32_t K, float *opacity_accum, float *anchor_denom, float *grad_accum, float *denom,
+                                    void *stream)
+{
+    GSVC_REQUIRE(rows >= 0 && K > 0 && grad_stride >= 2, "training_statis: bad shape");
+    if (rows == 0) return GSVC_OK;
+    GSVC_REQUIRE(vis && opacity && seen && grad && opacity_accum && anchor_denom && grad_accum && denom, "training_statis: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    gsvc::ProfScope _prof("k_training_statis", s);
+    hipLaunchKernelGGL(gsvc::k_training_statis, dim3((unsigned)((rows * K + 255) / 256)), dim3(256), 0, s, (const long long *)vis, opacity, seen,
+                       grad, (int)grad_stride, (long long)rows, (int)K, opacity_accum, anchor_denom, grad_accum, denom);
+    return gsvc::check_launch("training_statis");
 }

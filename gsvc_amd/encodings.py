@@ -66,6 +66,83 @@ class STE_binary_counted(torch.autograd.Function):
         return g * (x.abs() <= 1)
 
 
+class STE_binary_tables(torch.autograd.Function):
+    """STE_binary_counted for several tables at once (csrc/quant.hip k_ste_binary_count_many): returns the binarised tables and
+    ``counts`` [T], the +1 entries of each.  ``counts`` is differentiable — a table entry's share of its count is 1/2 — so a
+    loss term written on the counts (the hash-bit term) reaches the tables inside this node's one backward launch."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        import ctypes as C
+        from . import _lib
+        xs = [x.contiguous() for x in xs]
+        T, dev = len(xs), xs[0].device
+        sizes = [x.numel() for x in xs]
+        flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        ys = [v.view(x.shape) for v, x in zip(flat.split(sizes), xs)]
+        counts = torch.empty(T, device=dev, dtype=torch.float32)
+        ptrs = lambda ts: (C.c_void_p * T)(*[t.data_ptr() for t in ts])
+        _lib.check(_lib.lib().gsvc_ste_binary_count_many(ptrs(xs), ptrs(ys), (C.c_int64 * T)(*sizes), T, _lib.ptr(counts),
+                                                         _lib.current_stream(dev)), "gsvc_ste_binary_count_many")
+        ctx.save_for_backward(*xs)
+        ctx.set_materialize_grads(False)
+        return (*ys, counts)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        import ctypes as C
+        from . import _lib
+        xs = ctx.saved_tensors
+        T, dev = len(xs), xs[0].device
+        g_ys = [None if g is None else g.contiguous() for g in gs[:T]]
+        g_counts = gs[T]
+        if g_counts is not None and g_counts.stride(0) not in (0, 1):
+            g_counts = g_counts.contiguous()
+        sizes = [x.numel() for x in xs]
+        flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        outs = [v.view(x.shape) for v, x in zip(flat.split(sizes), xs)]
+        ptrs = lambda ts: (C.c_void_p * T)(*[None if t is None else t.data_ptr() for t in ts])
+        _lib.check(_lib.lib().gsvc_ste_binary_backward_many(ptrs(xs), ptrs(g_ys), (C.c_int64 * T)(*sizes), T, _lib.ptr(g_counts),
+                                                            0 if g_counts is None else g_counts.stride(0), ptrs(outs), _lib.current_stream(dev)), "gsvc_ste_binary_backward_many")
+        return tuple(outs)
+
+
+class CountBits(torch.autograd.Function):
+    """Bernoulli code length of {-1, +1} tables from the counts of their +1 entries: bits = n1 (-log2 p) + n0 (-log2 (1 - p)) + 32,
+    p = n1 / total clamped to [1e-6, 1 - 1e-6] (reference utils/encodings.py:34-51 over the concatenated tables,
+    pipeline/train.py:456).  One launch each way (csrc/quant.hip k_table_bits)."""
+
+    @staticmethod
+    def forward(ctx, counts, total):
+        from . import _lib
+        counts = counts.contiguous()
+        out = torch.empty(2, device=counts.device, dtype=torch.float32)
+        _lib.check(_lib.lib().gsvc_table_bits(_lib.ptr(counts), counts.numel(), int(total), _lib.ptr(out),
+                                              _lib.current_stream(counts.device)), "gsvc_table_bits")
+        ctx.save_for_backward(out)
+        ctx.T = counts.numel()
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return (g * out[1]).expand(ctx.T), None
+
+
+def binarized_tables(grids):
+    """``embeddings()`` of several grids.  Inside a step scope (``step_cache``) the STE-binary tables that have not been
+    binarised yet go through ONE launch (STE_binary_tables); the first grid's cache keeps the whole count vector for the
+    hash-bit term."""
+    caches = [getattr(g, "step_cache", None) for g in grids]
+    if (1 < len(grids) <= 8 and all(c is not None and "emb" not in c for c in caches)
+            and all(g.ste_binary and g.params.is_cuda and g.params.dtype == torch.float32 and g.params.numel() < (1 << 24) for g in grids)):
+        *ys, counts = STE_binary_tables.apply(*[g.params for g in grids])
+        for c, y in zip(caches, ys):
+            c["emb"] = y
+        caches[0]["counts_all"] = (counts, tuple(id(g) for g in grids))
+    return [g.embeddings() for g in grids]
+
+
 def _symbol_bounds(mean, Q):
     centre = mean / Q.mean().detach()
     return centre - CLAMP_STEPS, centre + CLAMP_STEPS

@@ -676,6 +676,45 @@ class _SampledRate(torch.autograd.Function):
                 dmean[0], dscale[0], dmean[1], dscale[1], dmean[2], dscale[2], None, None, None, None, None)
 
 
+class _RateNorm(torch.autograd.Function):
+    """(out [R, 4], sum of out[:, 0]): the per-render bit sums S [R, 3] divided by the coded parameters of each group and of all
+    three, times the render's keep rate (csrc/rate.hip k_rate_normalise; reference guassian.py:110-132)."""
+
+    @staticmethod
+    def forward(ctx, S, offset_masks, sel, bounds, dims, K):
+        import ctypes as C
+        from . import _lib
+        dev = S.device
+        R = len(bounds) - 1
+        S, sel = S.contiguous(), sel.contiguous()
+        om = offset_masks.contiguous()
+        L = _lib.lib()
+        scratch = torch.empty(int(L.gsvc_rate_normalise_scratch_bytes()) // 4, dtype=torch.int32, device=dev)
+        res = torch.empty(8 * R + 1, dtype=torch.float32, device=dev)
+        out, coef, total = res[:4 * R].view(R, 4), res[4 * R:8 * R], res[8 * R:]
+        _lib.check(L.gsvc_rate_normalise_forward(_lib.ptr(S), _lib.ptr(om), int(K), _lib.ptr(sel) if sel.numel() else None, sel.numel(),
+                                                 (C.c_int64 * (R + 1))(*[int(b) for b in bounds]), R, (C.c_float * 3)(*dims),
+                                                 _lib.ptr(scratch), _lib.ptr(out), C.c_void_p(coef.data_ptr()), C.c_void_p(total.data_ptr()),
+                                                 _lib.current_stream(dev)), "gsvc_rate_normalise_forward")
+        ctx.save_for_backward(coef)
+        ctx.R = R
+        ctx.set_materialize_grads(False)
+        return out, total.view(())
+
+    @staticmethod
+    def backward(ctx, g_out, g_sum):
+        from . import _lib
+        (coef,) = ctx.saved_tensors
+        if g_out is None and g_sum is None:
+            return None, None, None, None, None, None
+        gS = torch.empty(ctx.R, 3, dtype=torch.float32, device=coef.device)
+        g_out = None if g_out is None else g_out.contiguous()
+        g_sum = None if g_sum is None else g_sum.contiguous()
+        _lib.check(_lib.lib().gsvc_rate_normalise_backward(_lib.ptr(coef), _lib.ptr(g_out), _lib.ptr(g_sum), ctx.R, _lib.ptr(gS),
+                                                           _lib.current_stream(coef.device)), "gsvc_rate_normalise_backward")
+        return gS, None, None, None, None, None
+
+
 def _param_means(pc):
     """(mean(_anchor_feat), mean(get_scaling), mean(_offset)) over ALL anchors as one float32 [3] tensor (csrc/rate.hip
     k_param_means: one pass; the torch expression is three reductions + an exp pass)."""
@@ -703,6 +742,20 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
     ~120 kernels forward and as many backward to produce sixteen numbers."""
     from .entropy_models import CLAMP_STEPS, _GaussianBits
     K, R, dev = pc.n_offsets, seg.R, feat.device
+    fused = (feat.is_cuda and R <= 16 and all(isinstance(q, torch.Tensor) and q.numel() == feat.shape[0] for q in (Q_feat, Q_scaling, Q_offsets))
+             and not os.environ.get("GSVC_NO_FUSED_RATE"))
+    if fused and sel is not None and offset_masks.dtype == torch.float32:
+        # everything on the device in a dozen launches: the parameter means, the sampled bits summed per render (k_rate_sample),
+        # and their normalisation with the keep rates and sample sizes (k_rate_normalise)
+        sel_ec = sel if ec_row is None else ec_row.index_select(0, sel)
+        S = _SampledRate.apply(feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec.mean_feat, ec.scale_feat,
+                               ec.mean_scaling, ec.scale_scaling, ec.mean_offsets, ec.scale_offsets, sel,
+                               None if ec_row is None else sel_ec, _param_means(pc), seg.bounds, K)
+        out, total = _RateNorm.apply(S, offset_masks, sel, seg.bounds, (float(feat.shape[1]), float(grid_scaling.shape[1]), float(3 * K)), K)
+        packs = [RatePack(bit_per_param=out[r, 0], bit_per_feat_param=out[r, 1], bit_per_scaling_param=out[r, 2],
+                          bit_per_offsets_param=out[r, 3]) for r in range(R)]
+        packs[0].bit_per_param_sum = total        # sum over the renders: the fitting loss takes this one scalar (one backward node)
+        return packs
     with torch.no_grad():
         live = (torch.sum(offset_masks, dim=1)[:, 0] > 0)
         kr = seg.sums(live) / seg.counts_t.clamp_min(1)                  # keep rate per render
@@ -714,8 +767,7 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
         edges = torch.searchsorted(sel, seg.bounds_t)
         n_sel = (edges[1:] - edges[:-1]).to(torch.float32)
     sel_ec = sel if ec_row is None else ec_row.index_select(0, sel)
-    if (feat.is_cuda and R <= 16 and all(isinstance(q, torch.Tensor) and q.numel() == feat.shape[0] for q in (Q_feat, Q_scaling, Q_offsets))
-            and not os.environ.get("GSVC_NO_FUSED_RATE")):
+    if fused:
         # fused path (csrc/rate.hip k_rate_sample): gathers, per-render clamp bounds, offset mask and per-render sums in one launch
         xm = _param_means(pc)
         S = _SampledRate.apply(feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec.mean_feat, ec.scale_feat,
@@ -961,7 +1013,8 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         parts = [t.split(sizes, dim=0) for t in (xyz, color, neural_opacity, scaling, rot, world)]
         from types import SimpleNamespace
         batch = SimpleNamespace(scaling=scaling, neural_opacity=neural_opacity, mask=mask, seg_offsets=[b * K for b in seg.bounds], vis=vis,
-                                xyz=xyz, color=color, rot=rot)      # the un-split tensors: rasterize_many works on their row ranges
+                                xyz=xyz, color=color, rot=rot,      # the un-split tensors: rasterize_many works on their row ranges
+                                bit_per_param_sum=getattr(rates[0], "bit_per_param_sum", None))
         out = []
         for r, gs in enumerate(seg.slices(K)):
             out.append(GeneratedGaussians(

@@ -88,7 +88,8 @@ class Mix3d2dEncoding(nn.Module):
             # the four grids write their column blocks of the [N, 192] matrix and read the gradient from them (gsvc_grid_*_ex):
             # no coordinate slices, no [L, N, C] -> [N, L C] permutes, no cat — on either pass
             grids = (self.encoding_xyz, self.encoding_xy, self.encoding_xz, self.encoding_yz)
-            return _MixGridEncode.apply(x, grids, *[g.embeddings() for g in grids])
+            from .encodings import binarized_tables
+            return _MixGridEncode.apply(x, grids, *binarized_tables(grids))
         xy, xz, yz = x[..., 0:2], x[..., 0::2], x[..., 1:3]     # slices, not list indices: their backward is a strided add, not a sort-based index_put
         return torch.cat([self.encoding_xyz(x), self.encoding_xy(xy), self.encoding_xz(xz), self.encoding_yz(yz)], dim=-1)
 
@@ -142,11 +143,14 @@ class _MixGridEncode(torch.autograd.Function):
         N = x.shape[0]
         st = _lib.current_stream(x.device)
         outs = []
+        # the tables' gradients: slices of one zeroed buffer (one fill, not one per grid)
+        sizes = [e.numel() if ctx.needs_input_grad[2 + k] else 0 for k, e in enumerate(embs)]
+        zeros = torch.zeros(sum(sizes), device=x.device, dtype=torch.float32).split(sizes)
         for k, (g, e, (io, c0)) in enumerate(zip(grids, embs, _MixGridEncode._layout(grids, x, total))):
             if not ctx.needs_input_grad[2 + k]:
                 outs.append(None)
                 continue
-            ge = torch.zeros_like(e)
+            ge = zeros[k].view(e.shape)
             _lib.check(_lib.lib().gsvc_grid_backward_ex(C.c_void_p(grad.data_ptr() + 4 * c0), _lib.ptr(x), _lib.ptr(g.offsets_list),
                                                         _lib.ptr(g.resolutions_list), _lib.ptr(ge), N, g.num_dim, g.n_features,
                                                         g.n_levels, C.byref(io), st), "gsvc_grid_backward_ex")
@@ -799,17 +803,26 @@ class GaussianModel(nn.Module):
             vi, op_all = batch.vis, batch.neural_opacity
         else:
             vi, op_all = torch.cat([r.visible_index for r in renders]), torch.cat([r.neural_opacity for r in renders])
+        if batch is not None and getattr(batch, "viewspace", None) is not None and len(renders) > 1:
+            # rasterize_many: one leaf, one radii tensor for all renders
+            seen, g = batch.seen, batch.viewspace.grad
+        else:
+            seen, g = torch.cat([r.visibility_filter for r in renders]), torch.cat([r.viewspace_points.grad for r in renders])
+        accs = (self.opacity_accum, self.anchor_demon, self.offset_gradient_accum, self.offset_denom)
+        if (vi.is_cuda and seen.dtype == torch.bool and g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1
+                and all(a.dtype == torch.float32 and a.is_contiguous() for a in accs) and not os.environ.get("GSVC_NO_FUSED_STATIS")):
+            # one launch (csrc/rate.hip k_training_statis) for the clamp, the sums, the gradient norms and the four scatters
+            from . import _lib
+            op = op_all.detach().contiguous()
+            _lib.check(_lib.lib().gsvc_training_statis(_lib.ptr(vi.contiguous()), _lib.ptr(op), _lib.ptr(seen.contiguous()), _lib.ptr(g),
+                                                       g.stride(0), vi.shape[0], K, *[_lib.ptr(a) for a in accs],
+                                                       _lib.current_stream(vi.device)), "gsvc_training_statis")
+            return
         op = op_all.detach().view(-1).clamp_min(0).view(-1, K)
         self.opacity_accum.index_add_(0, vi, op.sum(dim=1, keepdim=True))
         self.anchor_demon.index_add_(0, vi, torch.ones(vi.shape[0], 1, device=vi.device, dtype=self.anchor_demon.dtype))
-        if batch is not None and getattr(batch, "viewspace", None) is not None and len(renders) > 1:
-            # rasterize_many: one leaf, one radii tensor for all renders
-            w = batch.seen.to(self.offset_denom.dtype).view(-1, K)
-            g2 = batch.viewspace.grad[:, :2]
-        else:
-            w = torch.cat([r.visibility_filter for r in renders]).to(self.offset_denom.dtype).view(-1, K)
-            g2 = torch.cat([r.viewspace_points.grad[:, :2] for r in renders])
-        gn = torch.norm(g2, dim=-1).view(-1, K) * w
+        w = seen.to(self.offset_denom.dtype).view(-1, K)
+        gn = torch.norm(g[:, :2], dim=-1).view(-1, K) * w
         self.offset_gradient_accum.view(A, K).index_add_(0, vi, gn.to(self.offset_gradient_accum.dtype))
         self.offset_denom.view(A, K).index_add_(0, vi, w)
 

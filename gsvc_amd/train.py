@@ -44,7 +44,13 @@ def hash_grid_bits(pc):
     tables = grid_tables(pc)
     if not (pc.ste_binary and all(hasattr(g, "embeddings") for g in tables)):
         return get_binary_vxl_size_device((pc.get_encoding_params() + 1) / 2)
-    embs = [g.embeddings() for g in tables]
+    from .encodings import CountBits, binarized_tables
+    embs = binarized_tables(tables)
+    cache0 = getattr(tables[0], "step_cache", None) or {}
+    if "counts_all" in cache0 and cache0["counts_all"][1] == tuple(id(g) for g in tables):
+        # every table was binarised by one launch that also counted its +1 entries: the term and its gradient are written
+        # on that count vector (two one-thread launches; the tables receive it inside their straight-through backward)
+        return CountBits.apply(cache0["counts_all"][0], sum(e.numel() for e in embs))
     counts = [(getattr(g, "step_cache", None) or {}).get("ones") for g in tables]
     return _TableBits.apply(torch.cat(counts) if all(c is not None for c in counts) else None, *embs)
 
@@ -321,8 +327,11 @@ class Trainer:
             # sparse data-parallel exchange (below): the regulariser's dense gradient is added after the exchange (_add_mask_reg)
             sparse_dp = self._sparse_dp(plan if self.batched else None)
             self._mask_reg_weight = 5e-4 if sparse_dp else 0.0
-            terms += [r.bit_per_param for r in renders] + [hash_grid_bits(pc), torch.mean(torch.sigmoid(pc._mask.detach() if sparse_dp else pc._mask))]
-            weights += [opt.lmbda] * 4 + [opt.lmbda / denom, 5e-4]
+            rate_sum = getattr(batch, "bit_per_param_sum", None)
+            # the renders' rates enter with one weight: their sum, when the batched generation already formed it, is one term
+            terms += ([rate_sum] if rate_sum is not None else [r.bit_per_param for r in renders]) + \
+                     [hash_grid_bits(pc), torch.mean(torch.sigmoid(pc._mask.detach() if sparse_dp else pc._mask))]
+            weights += [opt.lmbda] * (1 if rate_sum is not None else 4) + [opt.lmbda / denom, 5e-4]
         key = tuple(weights)
         if getattr(self, "_w_key", None) != key:      # the weights change only with the training phase
             from .generate import host_values

@@ -224,6 +224,24 @@ int gsvc_rate_sample_forward(const gsvc_rate_sample *desc, float *scratch, float
 int gsvc_rate_sample_backward(const gsvc_rate_sample *desc, const float *scratch, const float *gS, float *const *dx,
                               float *const *dmean, float *const *dscale, float *const *dQ, float *dmask, void *stream);
 
+/* Normalisation of the sampled rate (reference gaussian_renderer/guassian.py:110-132 per render): out[r] = {all, features,
+ * scalings, offsets} bits per coded parameter = S[r][g] / (n_sel_r dims[g]) x keep rate_r, keep rate = the render's rows whose K
+ * offset masks (offset_masks [rows, K]) sum to more than 0 / its rows; n_sel_r = entries of the sorted row list sel inside
+ * [row_bounds[r], row_bounds[r+1]).  coef [R, 4] (saved for the backward) = d out[r][i] / d S; sum[0] = sum_r out[r][0].
+ * backward: gS [R, 3] from g_out [R, 4] and / or g_sum [1] (either may be NULL). */
+int64_t gsvc_rate_normalise_scratch_bytes(void);
+int gsvc_rate_normalise_forward(const float *S, const float *offset_masks, int32_t K, const int64_t *sel, int64_t n_sel,
+                                const int64_t *row_bounds_host, int32_t R, const float *dims3_host, void *scratch, float *out,
+                                float *coef, float *sum, void *stream);
+int gsvc_rate_normalise_backward(const float *coef, const float *g_out, const float *g_sum, int32_t R, float *gS, void *stream);
+
+/* Densification statistics of un-compacted renders (reference scene/gaussian_model.py:1281-1314 training_statis): row i of
+ * the concatenated renders is anchor vis[i] with K Gaussians; opacity_accum[a] += sum_k max(opacity, 0), anchor_denom[a] += 1,
+ * and where seen[i K + k]: grad_accum[a K + k] += |grad[i K + k][0:2]|, denom[a K + k] += 1 (grad rows grad_stride floats apart). */
+int gsvc_training_statis(const int64_t *vis, const float *opacity, const uint8_t *seen, const float *grad, int32_t grad_stride,
+                         int64_t rows, int32_t K, float *opacity_accum, float *anchor_denom, float *grad_accum, float *denom,
+                         void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Image distortion of the fitting step (replaces utils/loss_utils.py l1_loss_func + ssim_func and their autograd)
  * ---------------------------------------------------------------------------------------------------- */
@@ -252,6 +270,14 @@ int gsvc_ssim_l1_pair_backward(const float *img_f, const float *img_b, const flo
 /* STE_binary forward (reference utils/encodings.py:375-392: y = x >= 0 ? +1 : -1) and count[0] = number of +1 entries
  * (the hash-bit term of the loss, pipeline/train.py:456, needs it); n < 2^24. */
 int gsvc_ste_binary_count(const float *x, int64_t n, float *y, float *count, void *stream);
+/* The same for up to 8 tables in one launch (x[k], y[k]: n[k] floats; counts[k]); its straight-through backward
+ * grad_x[k][i] = |x[k][i]| <= 1 ? grad_y[k][i] + 0.5 count_grads[k count_grad_stride] : 0 (grad_y[k] or count_grads may be NULL = zero: a table
+ * entry's share of its count is 1/2); and the Bernoulli code length of the tables from their counts (reference
+ * utils/encodings.py:34-51 get_binary_vxl_size over all tables, pipeline/train.py:456): out[0] = bits, out[1] = d bits / d count. */
+int gsvc_ste_binary_count_many(const float *const *x, float *const *y, const int64_t *n, int32_t tables, float *counts, void *stream);
+int gsvc_ste_binary_backward_many(const float *const *x, const float *const *grad_y, const int64_t *n, int32_t tables,
+                                  const float *count_grads, int32_t count_grad_stride, float *const *grad_x, void *stream);
+int gsvc_table_bits(const float *counts, int32_t tables, int64_t total, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Per-Gaussian loss terms of the fitting step over UN-COMPACTED renders (every visible anchor contributes its K

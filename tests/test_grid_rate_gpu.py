@@ -444,6 +444,116 @@ def test_counted_ste_binary_and_table_bits():
         assert (a - p.grad).abs().max().item() <= 1e-5 * p.grad.abs().max().item() + 1e-12
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,rows,empty", [(4, 5000, None), (2, 700, None), (4, 900, 2), (1, 300, None)])
+def test_rate_normalise_matches_tensor_expression(R, rows, empty):
+    """k_rate_normalise (keep rates from the offset masks, sample sizes from the sorted row list, per-group and overall bits
+    per parameter, their sum) = the tensor expression of reference guassian.py:110-132 per render, values and gradient; a render
+    without sampled rows gives the same NaN / inf as the expression."""
+    from gsvc_amd.generate import _RateNorm
+    torch.manual_seed(R * 1000 + rows)
+    K, dev = 10, "cuda"
+    cuts = sorted(torch.randint(1, rows, (R - 1,)).tolist())
+    bounds = [0] + cuts + [rows]
+    om = (torch.rand(rows, K, 1, device=dev) < 0.12).float()
+    pick = torch.rand(rows, device=dev) < 0.07
+    if empty is not None:
+        pick[bounds[empty]:bounds[empty + 1]] = False
+    sel = pick.nonzero().squeeze(1)
+    S = (torch.rand(R, 3, device=dev) * 1e4).requires_grad_(True)
+    dims = (50.0, 6.0, 30.0)
+    out, total = _RateNorm.apply(S, om, sel, bounds, dims, K)
+    w = torch.randn(R, 4, device=dev)
+    ok = torch.ones(R, dtype=torch.bool, device=dev)
+    if empty is not None:
+        ok[empty] = False
+    ((out * w)[ok].sum() + (0.0 if empty is not None else 0.5 * total)).backward()
+    got = S.grad.clone()
+    S.grad = None
+    live = om.sum(dim=1)[:, 0] > 0
+    bt = torch.tensor(bounds, device=dev)
+    cnt = (bt[1:] - bt[:-1]).float()
+    kr = torch.stack([live[bounds[r]:bounds[r + 1]].sum() for r in range(R)]).float() / cnt.clamp_min(1)
+    edges = torch.searchsorted(sel, bt)
+    N = (edges[1:] - edges[:-1]).float().unsqueeze(1) * torch.tensor(dims, device=dev)
+    per = S / N * kr.unsqueeze(1)
+    tot = S.sum(dim=1) / N.sum(dim=1) * kr
+    ref = torch.cat([tot.unsqueeze(1), per], dim=1)
+    ((ref * w)[ok].sum() + (0.0 if empty is not None else 0.5 * tot.sum())).backward()
+    assert torch.allclose(out[ok], ref[ok], rtol=1e-6, atol=0)
+    if empty is None:
+        assert abs(float(total) - float(tot.sum())) <= 1e-6 * float(tot.sum())
+    else:
+        assert not torch.isfinite(out[empty]).any() or float(S[empty].abs().sum()) == 0
+    assert torch.allclose(got[ok], S.grad[ok], rtol=1e-5, atol=0)
+
+
+@pytest.mark.gpu
+def test_training_statis_kernel_matches_index_adds():
+    """gsvc_training_statis = clamp + sums + gradient norms + four index_adds (reference scene/gaussian_model.py:1281-1314 through
+    the nested masks), anchors repeated over the rows as the four views of a step repeat them."""
+    import ctypes as C
+    from gsvc_amd import _lib
+    torch.manual_seed(11)
+    A, K, rows, dev = 3000, 10, 7001, "cuda"
+    vis = torch.randint(0, A, (rows,), device=dev)
+    op = torch.randn(rows * K, 1, device=dev)
+    seen = torch.rand(rows * K, device=dev) < 0.4
+    g = torch.randn(rows * K, 3, device=dev)
+    accs = [torch.rand(A, 1, device=dev), torch.full((A, 1), 3.0, device=dev), torch.rand(A * K, 1, device=dev), torch.zeros(A * K, 1, device=dev)]
+    ref = [a.double() for a in accs]
+    o = op.double().view(-1).clamp_min(0).view(-1, K)
+    ref[0].index_add_(0, vis, o.sum(dim=1, keepdim=True))
+    ref[1].index_add_(0, vis, torch.ones(rows, 1, device=dev, dtype=torch.float64))
+    w = seen.double().view(-1, K)
+    ref[2].view(A, K).index_add_(0, vis, torch.norm(g[:, :2].double(), dim=-1).view(-1, K) * w)
+    ref[3].view(A, K).index_add_(0, vis, w)
+    _lib.check(_lib.lib().gsvc_training_statis(_lib.ptr(vis), _lib.ptr(op), _lib.ptr(seen), _lib.ptr(g), 3, rows, K,
+                                               *[_lib.ptr(a) for a in accs], _lib.current_stream(torch.device(dev))), "gsvc_training_statis")
+    for a, r in zip(accs, ref):
+        assert torch.allclose(a.double(), r, rtol=2e-6, atol=1e-6)
+    assert torch.equal(accs[3], ref[3].float()) and torch.equal(accs[1], ref[1].float())      # counts: exact
+
+
+@pytest.mark.gpu
+def test_tables_binarised_in_one_launch_with_count_bits():
+    """STE_binary_tables (all tables in one launch, differentiable counts) + CountBits = the per-table STE_binary and the
+    reference-style bit expression on the concatenated tables; the tables also feed another consumer (as the grid lookups do),
+    one of them none (gradient through its count only), and sizes straddle the 4096-entry blocks."""
+    from gsvc_amd.encodings import STE_binary, STE_binary_tables, CountBits
+    from gsvc_amd.train import get_binary_vxl_size_device
+    torch.manual_seed(5)
+    ps = [(torch.randn(n, 8, device="cuda") * 0.9).requires_grad_(True) for n in (1000, 512, 3001, 1)]
+    with torch.no_grad():
+        ps[1][:3] = 0.0
+    ws = [torch.randn_like(p) for p in ps]
+
+    def loss(embs, bits):
+        return 1e-3 * bits + sum((e * w).sum() for e, w in list(zip(embs, ws))[:3])     # the last table: count only
+
+    *ys, counts = STE_binary_tables.apply(*ps)
+    for p, y, c in zip(ps, ys, counts):
+        assert torch.equal(y, STE_binary.apply(p.detach())) and float(c) == float((p.detach() >= 0).sum())
+    bits = CountBits.apply(counts, sum(p.numel() for p in ps))
+    loss(ys, bits).backward()
+    got = [p.grad.clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    es = [STE_binary.apply(p) for p in ps]
+    ref = get_binary_vxl_size_device((torch.cat(es, 0) + 1) / 2)
+    loss(es, ref).backward()
+    assert abs(float(bits) - float(ref)) <= 1e-6 * float(ref)
+    for a, p in zip(got, ps):
+        assert (a - p.grad).abs().max().item() <= 1e-5 * p.grad.abs().max().item() + 1e-9
+    # no bit term at all: the plain straight-through gradient
+    for p in ps:
+        p.grad = None
+    *ys, _ = STE_binary_tables.apply(*ps)
+    sum((e * w).sum() for e, w in zip(ys, ws)).backward()
+    for p, w in zip(ps, ws):
+        assert torch.equal(p.grad, w * (p.detach().abs() <= 1))
+
+
 @pytest.mark.parametrize("M,K,N", [(5000, 50, 100), (4097, 116, 100), (8192, 192, 150), (4096, 100, 10), (6000, 66, 66),
                                     (4500, 50, 1), (4096, 8, 16), (70000, 100, 70), (4103, 51, 37), (9001, 192, 192),
                                     (5000, 3, 100), (4099, 150, 192), (4111, 177, 33), (300000, 100, 100),
