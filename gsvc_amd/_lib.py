@@ -106,6 +106,7 @@ _SIGNATURES = {
     "gsvc_profile_collect": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int]),
     "gsvc_raster_sizes_query": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64, C.POINTER(RasterSizesC)]),
     "gsvc_raster_visible_filter": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_raster_visible_masks": (C.c_int, [_vp, C.c_int32, _i64, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp]),
     "gsvc_raster_forward": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64] + [_vp] * 11),
     "gsvc_raster_forward_pair": (C.c_int, [C.POINTER(RasterSettingsC), _i64, _i64] + [_vp] * 11),
     "gsvc_raster_backward_scratch_bytes": (_i64, [_i64, _i64]),
@@ -127,6 +128,11 @@ _SIGNATURES = {
                                               _vp, _vp, _vp]),
     "gsvc_rate_normalise_backward": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "gsvc_training_statis": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _i64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_q_rows_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i64, _vp, _vp]),
+    "gsvc_q_rows_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i64, _i64, _vp, _vp]),
+    "gsvc_plan_scans_scratch_bytes": (_i64, [C.c_int32, _i64]),
+    "gsvc_plan_scans": (C.c_int, [_vp, _vp, _vp, C.c_int32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_film_row_maps": (C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_ste_binary_count_many": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, _vp]),
     "gsvc_ste_binary_backward_many": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, C.c_int32, _vp, _vp]),
     "gsvc_table_bits": (C.c_int, [_vp, C.c_int32, _i64, _vp, _vp]),

@@ -369,6 +369,181 @@ __global__ void __launch_bounds__(256) k_film_bwd(const float4 *__restrict__ g, 
     }
 }
 
+// Row maps of the generators' shared FiLM rows (gsvc_amd.generate._film_rows): the R views of a step come in opposite pairs
+// (2 f, 2 f + 1) that share their condition, so the FiLM networks run once per (frame f, distinct visible anchor d).
+//   row_of[i]  = FiLM row of chain row i = (view of i / 2) * D + pos[vis[i]]            (pos: anchor -> index in the distinct list)
+//   src_a/b[f D + d] = chain row of anchor distinct[d] in view 2 f / 2 f + 1 (inclusive scan of the flattened [R, A] view masks
+//                      - 1), -1 where that view does not see it
+struct FilmBounds { long long b[17]; };
+__global__ void __launch_bounds__(256) k_film_rows(const long long *__restrict__ vis, FilmBounds rb, int R, long long rows,
+                                                   const long long *__restrict__ pos, long long D, long long A,
+                                                   const uint8_t *__restrict__ mflat, const long long *__restrict__ scan,
+                                                   const long long *__restrict__ distinct, int *__restrict__ row_of,
+                                                   int *__restrict__ src_a, int *__restrict__ src_b)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) {
+        int r = 0;
+        while (r + 1 < R && i >= rb.b[r + 1]) r++;
+        row_of[i] = (int)(pos[vis[i]] + (long long)(r >> 1) * D);
+    }
+    if (i < (long long)(R >> 1) * D) {
+        const long long f = i / D, d = i - f * D;
+        const long long p0 = 2 * f * A + distinct[d], p1 = p0 + A;
+        src_a[i] = mflat[p0] ? (int)(scan[p0] - 1) : -1;
+        src_b[i] = mflat[p1] ? (int)(scan[p1] - 1) : -1;
+    }
+}
+
+// Per-row quantisation steps of the three attribute groups: Q_g[i] = base_g * adj_g[ctx_row[i]] (reference
+// gaussian_renderer/guassian.py:250-262: Q_feat * Q_feat_adj etc.; the entropy context is evaluated once per DISTINCT anchor, so
+// its step adjustments are gathered by ctx_row).  One launch instead of three gathers and three products; the backward
+// scatter-adds the rows' gradients onto the distinct anchors (one launch instead of three products, three fills, three index_adds).
+__global__ void __launch_bounds__(256) k_q_rows_fwd(const float *__restrict__ a0, const float *__restrict__ a1, const float *__restrict__ a2,
+                                                    const long long *__restrict__ ctx_row, float q0, float q1, float q2, long long rows,
+                                                    float *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    const long long d = ctx_row ? ctx_row[i] : i;
+    out[i] = q0 * a0[d];
+    out[rows + i] = q1 * a1[d];
+    out[2 * rows + i] = q2 * a2[d];
+}
+
+__global__ void __launch_bounds__(256) k_q_rows_bwd(const float *__restrict__ g0, const float *__restrict__ g1, const float *__restrict__ g2,
+                                                    const long long *__restrict__ ctx_row, float q0, float q1, float q2, long long rows,
+                                                    long long D, float *__restrict__ gadj)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    if (ctx_row) {
+        const long long d = ctx_row[i];
+        if (g0) atomicAdd(gadj + d, q0 * g0[i]);
+        if (g1) atomicAdd(gadj + D + d, q1 * g1[i]);
+        if (g2) atomicAdd(gadj + 2 * D + d, q2 * g2[i]);
+    } else {
+        gadj[i] = g0 ? q0 * g0[i] : 0.f;
+        gadj[D + i] = g1 ? q1 * g1[i] : 0.f;
+        gadj[2 * D + i] = g2 ? q2 * g2[i] : 0.f;
+    }
+}
+
+// The scans and compactions of a step plan (gsvc_amd.generate.StepPlan) in three launches: inclusive scan c of the flattened
+// view masks M [R A] with the list of the anchors (position mod A) at its set positions, the rate sample's list (rows c - 1 of the chosen (view, anchor)
+// pairs, chosen a subset of M) and, over the anchors, pos = scan of `present` - 1 with the list of distinct anchors.  The tensor
+// form was three cumsums (each preceded by a bool -> int64 copy), slicing / differences for the counts and three compactions.
+//   phase 1: set bytes per 4096-element chunk;  phase 2: one workgroup scans the chunk counts;  phase 3: chunk-local scans + writes.
+constexpr int PS_CHUNK = 4096;
+
+__device__ __forceinline__ int ps_count16(const uint8_t *__restrict__ m, long long i0, long long n, uint8_t (&v)[16])
+{
+    int c = 0;
+    if (m && i0 + 16 <= n && ((reinterpret_cast<uintptr_t>(m) + i0) & 15) == 0) {
+        const uint4 u = *reinterpret_cast<const uint4 *>(m + i0);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int q = 0; q < 16; q++) { v[q] = (w[q >> 2] >> (8 * (q & 3))) & 0xff ? 1 : 0; c += v[q]; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) { v[q] = (m && i0 + q < n && m[i0 + q]) ? 1 : 0; c += v[q]; }
+    }
+    return c;
+}
+
+// exclusive prefix of `c` over the 256 threads of the workgroup (thread order), total in *total
+__device__ __forceinline__ int ps_block_excl(int c, int *sm, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) sm[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += sm[w];
+    *total = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+    return base + inc - c;
+}
+
+__global__ void __launch_bounds__(256) k_plan_scan_count(const uint8_t *__restrict__ M, const uint8_t *__restrict__ chosen, long long nM,
+                                                         const uint8_t *__restrict__ present, long long A, int nbM, int *__restrict__ counts)
+{
+    __shared__ int sm[4];
+    const int b = blockIdx.x;
+    uint8_t v[16];
+    int total;
+    if (b < nbM) {
+        const long long i0 = (long long)b * PS_CHUNK + 16 * threadIdx.x;
+        ps_block_excl(ps_count16(M, i0, nM, v), sm, &total);
+        if (threadIdx.x == 0) counts[b] = total;
+        ps_block_excl(ps_count16(chosen, i0, nM, v), sm, &total);
+        if (threadIdx.x == 0) counts[nbM + b] = total;
+    } else {
+        const long long i0 = (long long)(b - nbM) * PS_CHUNK + 16 * threadIdx.x;
+        ps_block_excl(ps_count16(present, i0, A, v), sm, &total);
+        if (threadIdx.x == 0) counts[nbM + b] = total;           // = 2 nbM + (b - nbM)
+    }
+}
+
+// offsets[k] = exclusive scan of counts within each of the three arrays; totals[0..2] = their sums (M, chosen, present)
+__global__ void __launch_bounds__(64) k_plan_scan_offsets(const int *__restrict__ counts, int nbM, int nbP, long long *__restrict__ offsets,
+                                                          long long *__restrict__ totals)
+{
+    const int j = threadIdx.x;
+    if (j >= 3) return;
+    const int first = j == 0 ? 0 : (j == 1 ? nbM : 2 * nbM), n = j == 2 ? nbP : nbM;
+    long long run = 0;
+    for (int k = 0; k < n; k++) {
+        offsets[first + k] = run;
+        run += counts[first + k];
+    }
+    totals[j] = run;
+}
+
+__global__ void __launch_bounds__(256) k_plan_scan_write(const uint8_t *__restrict__ M, const uint8_t *__restrict__ chosen, long long nM,
+                                                         const uint8_t *__restrict__ present, long long A, int nbM,
+                                                         const long long *__restrict__ offsets, long long *__restrict__ c,
+                                                         long long *__restrict__ flat, long long *__restrict__ sel_rows,
+                                                         long long *__restrict__ pos, long long *__restrict__ distinct,
+                                                         long long *__restrict__ view_ends)
+{
+    __shared__ int sm[4];
+    const int b = blockIdx.x;
+    uint8_t v[16], w[16];
+    int total;
+    if (b < nbM) {
+        const long long i0 = (long long)b * PS_CHUNK + 16 * threadIdx.x;
+        long long cm = offsets[b] + ps_block_excl(ps_count16(M, i0, nM, v), sm, &total);
+        long long cc = chosen ? offsets[nbM + b] + ps_block_excl(ps_count16(chosen, i0, nM, w), sm, &total) : 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const long long i = i0 + q;
+            if (i >= nM) break;
+            cm += v[q];
+            c[i] = cm;
+            if (v[q]) flat[cm - 1] = i % A;          // the anchor: view r's list is the r-th segment of this one list
+            if (chosen && w[q]) sel_rows[cc++] = cm - 1;
+            if ((i + 1) % A == 0) view_ends[(i + 1) / A - 1] = cm;
+        }
+    } else {
+        const long long i0 = (long long)(b - nbM) * PS_CHUNK + 16 * threadIdx.x;
+        long long cp = offsets[nbM + b] + ps_block_excl(ps_count16(present, i0, A, v), sm, &total);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const long long i = i0 + q;
+            if (i >= A) break;
+            cp += v[q];
+            pos[i] = cp - 1;
+            if (v[q]) distinct[cp - 1] = i;
+        }
+    }
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -576,4 +751,80 @@ extern "C" int gsvc_film_backward(const float *g, const float *h, const float *g
     hipLaunchKernelGGL(gsvc::k_film_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)g, (const float4 *)h,
                        (const float4 *)gamma, (float4 *)dgamma, (float4 *)dh, n4);
     return gsvc::check_launch("film_backward");
+}
+
+extern "C" int gsvc_film_row_maps(const int64_t *vis, const int64_t *row_bounds_host, int32_t R, const int64_t *pos, int64_t D, int64_t A,
+                              const uint8_t *view_masks, const int64_t *scan, const int64_t *distinct, int32_t *row_of, int32_t *src_a,
+                              int32_t *src_b, void *stream)
+{
+    GSVC_REQUIRE(row_bounds_host && R >= 2 && R <= 16 && R % 2 == 0 && D >= 0 && A > 0, "film_rows: an even number of views (2..16)");
+    gsvc::FilmBounds rb;
+    for (int r = 0; r <= 16; r++) rb.b[r] = row_bounds_host[r <= R ? r : R];
+    const long long rows = rb.b[R], n = rows > (R / 2) * D ? rows : (R / 2) * D;
+    GSVC_REQUIRE(rows < ((int64_t)1 << 31) && (R / 2) * D < ((int64_t)1 << 31), "film_rows: row numbers must fit int32");
+    if (n == 0) return GSVC_OK;
+    GSVC_REQUIRE(vis && pos && view_masks && scan && distinct && row_of && src_a && src_b, "film_rows: NULL pointer");
+    hipLaunchKernelGGL(gsvc::k_film_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const long long *)vis, rb,
+                       (int)R, rows, (const long long *)pos, (long long)D, (long long)A, view_masks, (const long long *)scan,
+                       (const long long *)distinct, row_of, src_a, src_b);
+    return gsvc::check_launch("film_rows");
+}
+
+extern "C" int gsvc_q_rows_forward(const float *adj_feat, const float *adj_scaling, const float *adj_offsets, const int64_t *ctx_row,
+                                   float q_feat, float q_scaling, float q_offsets, int64_t rows, float *out3, void *stream)
+{
+    GSVC_REQUIRE(rows >= 0, "q_rows_forward: bad shape");
+    if (rows == 0) return GSVC_OK;
+    GSVC_REQUIRE(adj_feat && adj_scaling && adj_offsets && out3, "q_rows_forward: NULL pointer");
+    hipLaunchKernelGGL(gsvc::k_q_rows_fwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj_feat, adj_scaling,
+                       adj_offsets, (const long long *)ctx_row, q_feat, q_scaling, q_offsets, (long long)rows, out3);
+    return gsvc::check_launch("q_rows_forward");
+}
+
+extern "C" int gsvc_q_rows_backward(const float *g_feat, const float *g_scaling, const float *g_offsets, const int64_t *ctx_row,
+                                    float q_feat, float q_scaling, float q_offsets, int64_t rows, int64_t D, float *grad_adj3, void *stream)
+{
+    GSVC_REQUIRE(rows >= 0 && D >= 0 && (ctx_row || D == rows), "q_rows_backward: bad shape");
+    if (D == 0) return GSVC_OK;
+    GSVC_REQUIRE(grad_adj3, "q_rows_backward: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (ctx_row && hipMemsetAsync(grad_adj3, 0, sizeof(float) * 3 * (size_t)D, s) != hipSuccess) {
+        gsvc::set_error("q_rows_backward: hipMemsetAsync failed");
+        return GSVC_E_LAUNCH;
+    }
+    if (rows == 0) return GSVC_OK;
+    hipLaunchKernelGGL(gsvc::k_q_rows_bwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, g_feat, g_scaling, g_offsets,
+                       (const long long *)ctx_row, q_feat, q_scaling, q_offsets, (long long)rows, (long long)D, grad_adj3);
+    return gsvc::check_launch("q_rows_backward");
+}
+
+extern "C" int64_t gsvc_plan_scans_scratch_bytes(int32_t R, int64_t A)
+{
+    if (R < 1 || A < 1) return -1;
+    const int64_t nbM = (R * A + gsvc::PS_CHUNK - 1) / gsvc::PS_CHUNK, nbP = (A + gsvc::PS_CHUNK - 1) / gsvc::PS_CHUNK;
+    return (2 * nbM + nbP) * (int64_t)(sizeof(int) + sizeof(long long)) + 16;
+}
+
+extern "C" int gsvc_plan_scans(const uint8_t *view_masks, const uint8_t *chosen, const uint8_t *present, int32_t R, int64_t A, void *scratch,
+                               int64_t *scan, int64_t *flat, int64_t *sel_rows, int64_t *pos, int64_t *distinct, int64_t *counts,
+                               void *stream)
+{
+    GSVC_REQUIRE(R >= 1 && A >= 1 && R * A < ((int64_t)1 << 40), "plan_scans: bad shape");
+    GSVC_REQUIRE(view_masks && present && scratch && scan && flat && pos && distinct && counts && (!chosen || sel_rows), "plan_scans: NULL pointer");
+    const long long nM = (long long)R * A;
+    const int nbM = (int)((nM + gsvc::PS_CHUNK - 1) / gsvc::PS_CHUNK), nbP = (int)((A + gsvc::PS_CHUNK - 1) / gsvc::PS_CHUNK);
+    GSVC_REQUIRE(nbM <= 65536, "plan_scans: too many chunks for the one-workgroup offset pass");
+    // scratch: [offsets: (2 nbM + nbP) int64][counts: (2 nbM + nbP) int]
+    long long *offsets = (long long *)scratch;
+    int *bc = (int *)(offsets + 2 * nbM + nbP);
+    hipStream_t s = (hipStream_t)stream;
+    gsvc::ProfScope _prof("k_plan_scans", s);
+    hipLaunchKernelGGL(gsvc::k_plan_scan_count, dim3(nbM + nbP), dim3(256), 0, s, view_masks, chosen, nM, present, (long long)A, nbM, bc);
+    // counts: [0, R) the scan at each view's end, [R] chosen pairs, [R + 1] distinct anchors: the totals (M, chosen, present) land on
+    // counts[R - 1 ..] (the first repeats the last view's end)
+    hipLaunchKernelGGL(gsvc::k_plan_scan_offsets, dim3(1), dim3(64), 0, s, bc, nbM, nbP, offsets, (long long *)counts + R - 1);
+    hipLaunchKernelGGL(gsvc::k_plan_scan_write, dim3(nbM + nbP), dim3(256), 0, s, view_masks, chosen, nM, present, (long long)A, nbM, offsets,
+                       (long long *)scan, (long long *)flat, (long long *)sel_rows, (long long *)pos, (long long *)distinct,
+                       (long long *)counts);
+    return gsvc::check_launch("plan_scans");
 }

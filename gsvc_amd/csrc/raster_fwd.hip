@@ -69,6 +69,36 @@ __global__ void __launch_bounds__(256) k_visible_filter(RasterParams st, int P, 
                                    scales[3 * i + 1], scales[3 * i + 2], q.x, q.y, q.z, q.w, o);
 }
 
+// The visibility test of R views over the same anchors in one launch (a fitting step tests its four views): the anchor is read
+// once, masks[r][i] = radius under view r > 0.  The per-anchor scales / rotations may be given raw — scales as their logarithm
+// (``scale_exp``: scene/gaussian_model.py scaling_activation = exp), rows ``scale_stride`` floats apart (the first three of the
+// six per-anchor scales are the ones tested), rotations un-normalised (``rot_normalise``: rotation_activation = normalize with
+// eps 1e-12) — which folds the activations' elementwise passes into the test.
+constexpr int VIS_MAX_VIEWS = 8;
+struct VisViews { RasterParams p[VIS_MAX_VIEWS]; };
+
+__global__ void __launch_bounds__(256) k_visible_masks(VisViews v, int R, int P, const float *__restrict__ means3D,
+                                                       const float *__restrict__ scales, int scale_stride, int scale_exp,
+                                                       const float *__restrict__ rotations, int rot_normalise, uint8_t *__restrict__ masks)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float4 q = reinterpret_cast<const float4 *>(rotations)[i];
+    if (rot_normalise) {
+        const float n = fmaxf(sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w)), 1e-12f);
+        q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+    }
+    float sx = scales[(size_t)scale_stride * i], sy = scales[(size_t)scale_stride * i + 1], sz = scales[(size_t)scale_stride * i + 2];
+    if (scale_exp) { sx = expf(sx); sy = expf(sy); sz = expf(sz); }
+    const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+#pragma unroll
+    for (int r = 0; r < VIS_MAX_VIEWS; r++)
+        if (r < R) {
+            PreOut o;
+            masks[(size_t)r * P + i] = preprocess_gaussian(v.p[r], x, y, z, sx, sy, sz, q.x, q.y, q.z, q.w, o) > 0 ? 1 : 0;
+        }
+}
+
 // ------------------------------------------------------------------------------------------------- K2
 // tile_offsets = exclusive scan of (tile_count + tile_extra); tile_extra is zeroed (K3's cursor for the
 // instances beyond BIN_SLOTS, which sit behind the tile_count[t] slotted ones).  One workgroup; rounds of 8192
@@ -1060,6 +1090,26 @@ extern "C" int gsvc_raster_visible_filter(const gsvc_raster_settings *settings, 
                            scales, rotations, radii);
     }
     return check_launch("visible_filter");
+}
+
+extern "C" int gsvc_raster_visible_masks(const gsvc_raster_settings *const *settings, int32_t views, int64_t P, const float *means3D,
+                                         const float *scales, int32_t scale_stride, int32_t scale_exp, const float *rotations,
+                                         int32_t rot_normalise, uint8_t *masks, void *stream)
+{
+    GSVC_REQUIRE(settings && views >= 1 && views <= VIS_MAX_VIEWS && scale_stride >= 3, "visible_masks: 1..8 views, scale rows of >= 3 floats");
+    VisViews v;
+    for (int r = 0; r < VIS_MAX_VIEWS; r++) {
+        const gsvc_raster_settings *st = settings[r < views ? r : 0];
+        if (int rc = check_settings(st, P)) return rc;
+        v.p[r] = make_params(*st);
+    }
+    if (P == 0) return GSVC_OK;
+    GSVC_REQUIRE(means3D && scales && rotations && masks, "visible_masks: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope _prof("k_visible_filter", s);
+    hipLaunchKernelGGL(k_visible_masks, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, v, (int)views, (int)P, means3D, scales,
+                       (int)scale_stride, (int)scale_exp, rotations, (int)rot_normalise, masks);
+    return check_launch("visible_masks");
 }
 
 static int raster_forward_impl(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,

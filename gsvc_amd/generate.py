@@ -271,65 +271,70 @@ class StepPlan:
         else:
             M = torch.stack(visible_masks)                               # [R, A] bool
             present = M.any(dim=0)
-        # scan of the FLATTENED mask (a 1-D scan is one fast pass; a [R, A] scan along dim 1 runs row by row): c - 1 is the
-        # row of (r, a) in the concatenated rows, the view boundaries give the counts
-        c = torch.cumsum(M.view(-1), dim=0)
-        self.ranks = (M.view(-1), c)                                     # for the atomic-free gather backward (_gather_rows)
-        ends = c[A - 1::A]
-        cnt_t = torch.diff(ends, prepend=ends.new_zeros(1))
-        pos_incl = torch.cumsum(present, dim=0)
-        self.pos = pos_incl - 1                                          # anchor -> row of the distinct list
-        counts = [cnt_t, pos_incl[-1:]]
-        # data parallel: the largest distinct-anchor count over the ranks (the capacity of the sparse gradient exchange:
-        # gsvc_amd.dist.GradReducer.set_sparse) rides along; its collective runs on the plan's own process group
         self._dp = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         self._gmax = self._gmax_work = None
+        self._A, self._sel_flat, self._ends = A, None, fused
+        if fused:
+            # scans, counts and index lists in three launches (csrc/generate.hip gsvc_plan_scans): c - 1 is the row of (r, a) in the
+            # concatenated rows, view r's index list is the segment of the flat list behind the r earlier views' counts (minus r A),
+            # pos maps an anchor to its row of the distinct list, the sample is listed by row
+            L, st = _lib.lib(), _lib.current_stream(dev)
+            big = torch.empty(3 * R * A + 2 * A + R + 2, dtype=torch.int64, device=dev)
+            c, self._flat, sel_flat = big[:R * A], big[R * A:2 * R * A], big[2 * R * A:3 * R * A]
+            self.pos, self._distinct = big[3 * R * A:3 * R * A + A], big[3 * R * A + A:3 * R * A + 2 * A]
+            counts = big[3 * R * A + 2 * A:]                         # [R view ends | chosen pairs | distinct anchors]
+            scratch = torch.empty(int(L.gsvc_plan_scans_scratch_bytes(R, A)), dtype=torch.uint8, device=dev)
+            _lib.check(L.gsvc_plan_scans(_lib.ptr(M), _lib.ptr(chosen), _lib.ptr(present), R, A, _lib.ptr(scratch), _lib.ptr(c), _lib.ptr(self._flat),
+                                         _lib.ptr(sel_flat) if sample else None, ctypes.c_void_p(self.pos.data_ptr()),
+                                         ctypes.c_void_p(self._distinct.data_ptr()), ctypes.c_void_p(counts.data_ptr()), st), "gsvc_plan_scans")
+            self.ranks = (M.view(-1), c)                                 # for the atomic-free gather backward (_gather_rows)
+            if sample:
+                self._sel_flat = sel_flat
+            n_distinct = counts[R + 1:R + 2]
+        else:
+            # scan of the FLATTENED mask (a 1-D scan is one fast pass; a [R, A] scan along dim 1 runs row by row): c - 1 is the
+            # row of (r, a) in the concatenated rows, the view boundaries give the counts
+            c = torch.cumsum(M.view(-1), dim=0)
+            self.ranks = (M.view(-1), c)
+            ends = c[A - 1::A]
+            pos_incl = torch.cumsum(present, dim=0)
+            self.pos = pos_incl - 1                                      # anchor -> row of the distinct list
+            n_distinct = pos_incl[-1:]
+            parts = [torch.diff(ends, prepend=ends.new_zeros(1))]
+            if sample:
+                # the rate sample in anchor space: a row is (render r, visible anchor a); its position in the concatenated rows is
+                # (visible anchors of the renders before r) + (rank of a among render r's visible anchors) = c - 1
+                with torch.no_grad():
+                    live = pc.get_mask.reshape(A, -1).sum(dim=1) > 0      # mask_anchor for every anchor
+                chosen = M & live.unsqueeze(0) & (torch.rand(R, A, device=dev) <= SAMPLE_RATE)
+                parts.append(chosen.sum().reshape(1))
+            else:
+                parts.append(c.new_zeros(1))
+            parts.append(n_distinct)
+            counts = torch.cat(parts)
+        # data parallel: the largest distinct-anchor count over the ranks (the capacity of the sparse gradient exchange:
+        # gsvc_amd.dist.GradReducer.set_sparse) rides along; its collective runs on the plan's own process group
         if self._dp:
             # asynchronous, and waited for only when the next step resolves the plan: a rank that builds its plan from inside the
             # backward (early tail) must not stop there until a rank that builds it after the backward arrives — that rank's
             # backward waits for collectives the first one has yet to launch
             from . import dist as gdist
-            self._gmax = pos_incl[-1:].clone()
+            self._gmax = n_distinct.clone()
             self._gmax_work = torch.distributed.all_reduce(self._gmax, op=torch.distributed.ReduceOp.MAX, group=gdist.plan_group(),
                                                            async_op=True)
-        if sample:
-            # the rate sample in anchor space: a row is (render r, visible anchor a); its position in the concatenated rows is
-            # (visible anchors of the renders before r) + (rank of a among render r's visible anchors) = c - 1
-            if chosen is None:
-                with torch.no_grad():
-                    live = pc.get_mask.reshape(A, -1).sum(dim=1) > 0      # mask_anchor for every anchor
-                chosen = M & live.unsqueeze(0) & (torch.rand(R, A, device=dev) <= SAMPLE_RATE)
-            # the sample's size: last element of the scan its compaction below needs anyway (fused plan), else a sum
-            chosen_scan = torch.cumsum(chosen.view(-1), dim=0) if fused else None
-            counts.append(chosen_scan[-1:] if fused else chosen.sum().reshape(1))
-        # the counts leave for the host FIRST: the next step waits for them only, and the compactions below (the bulk of the
-        # plan's GPU time) run while the host is already launching that step
-        self._A = A
-        self._host = torch.empty(R + 1 + (1 if sample else 0), dtype=torch.int64, pin_memory=True)
-        self._host.copy_(torch.cat(counts), non_blocking=True)
+        # the counts leave for the host: the next step waits for this copy only
+        self._sample = sample
+        self._host = torch.empty(R + 2, dtype=torch.int64, pin_memory=True)
+        self._host.copy_(counts, non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
-        self._sel_flat = None
-        if fused:
-            # index lists by the scans that exist anyway: one elementwise scatter each (gsvc_compact_by_scan)
-            from . import _lib
-            L, st = _lib.lib(), _lib.current_stream(dev)
-            self._flat = torch.empty(R * A, dtype=torch.int64, device=dev)
-            self._distinct = torch.empty(A, dtype=torch.int64, device=dev)
-            _lib.check(L.gsvc_compact_by_scan(_lib.ptr(M), _lib.ptr(c), None, 0, R * A, _lib.ptr(self._flat), st), "gsvc_compact_by_scan")
-            _lib.check(L.gsvc_compact_by_scan(_lib.ptr(present), _lib.ptr(pos_incl), None, 0, A, _lib.ptr(self._distinct), st),
-                       "gsvc_compact_by_scan")
-            if sample:
-                self._sel_flat = torch.empty(R * A, dtype=torch.int64, device=dev)      # row (= scan of the view mask - 1) of every chosen (r, a)
-                _lib.check(L.gsvc_compact_by_scan(_lib.ptr(chosen), _lib.ptr(chosen_scan), _lib.ptr(c), -1, R * A, _lib.ptr(self._sel_flat), st),
-                           "gsvc_compact_by_scan")
-        else:
+        if not fused:
             self._flat = torch.nonzero_static(M.view(-1), size=R * A).squeeze(1)
             self._distinct = torch.nonzero_static(present, size=A).squeeze(1)
             if sample:
                 pick = torch.nonzero_static(chosen.view(-1), size=R * A).squeeze(1)       # in (r, a) order = row order
                 self._sel_flat = c.index_select(0, pick.clamp_min(0)) - 1
-        self.vis_list = self.distinct = self.sel = None
+        self.vis_list = self.distinct = self.sel = self.vis_all = None
         self.distinct_cap = None
 
     def matches(self, pc) -> bool:
@@ -342,16 +347,20 @@ class StepPlan:
             self._event.synchronize()
             n = self._host.tolist()
             R, A = self.R, self._A
+            if self._ends:                   # the fused scans report the scan at each view's end: counts are the differences
+                n = [n[r] - (n[r - 1] if r else 0) for r in range(R)] + n[R:]
             self.vis_list, at = [], 0
             for r in range(R):
-                self.vis_list.append(self._flat[at:at + n[r]] - r * A)
+                # the fused scans list anchors, torch.nonzero_static positions of the flattened [R, A] mask
+                self.vis_list.append(self._flat[at:at + n[r]] if self._ends else self._flat[at:at + n[r]] - r * A)
                 at += n[r]
-            self.distinct = self._distinct[:n[R]]
+            self.vis_all = self._flat[:at] if self._ends else None      # the views' lists concatenated (they are one list already)
+            self.distinct = self._distinct[:n[R + 1]]
             if self._gmax_work is not None:
                 self._gmax_work.wait()
                 self.distinct_cap = int(self._gmax.item())      # queued a whole step ago: complete by now
             if self._sel_flat is not None:
-                self.sel = self._sel_flat[:n[R + 1]]
+                self.sel = self._sel_flat[:n[R]]
         return self
 
 
@@ -389,6 +398,7 @@ class _GenTail(torch.autograd.Function):
         ctx.save_for_backward(op_raw, offset_mask, grid_offsets, neural_offset, scale_rot, grid_scaling, world)
         ctx.K, ctx.bounds, ctx.anchor_grad = K, (lo, hi), anchor.requires_grad
         ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)      # an output nothing differentiates (world without the optical loss) arrives as None, not zeros
         return no, mask, scaling, rot, world, xyz
 
     @staticmethod
@@ -512,10 +522,30 @@ class _Segments:
         for c in self.counts:
             self.bounds.append(self.bounds[-1] + c)
         self.rows = self.bounds[-1]
-        both = host_values(list(self.counts) + list(self.bounds), device)      # one staged copy for both
-        self.counts_t, self.bounds_t = both[:len(self.counts)], both[len(self.counts):]
-        # output_size: without it repeat_interleave reads the total back from the device (a host synchronisation)
-        self.seg_id = torch.repeat_interleave(torch.arange(self.R, device=device), self.counts_t, output_size=self.rows)
+        self._device = device
+        self._both = self._seg_id = None
+
+    def _tensors(self):
+        if self._both is None:
+            self._both = host_values(list(self.counts) + list(self.bounds), self._device)      # one staged copy for both
+        return self._both
+
+    # device copies of the counts / bounds and the row -> render map: built on first use (the fused paths take the bounds by value
+    # and never ask; eagerly they cost a staged copy, an arange and a repeat_interleave per batch)
+    @property
+    def counts_t(self):
+        return self._tensors()[:len(self.counts)]
+
+    @property
+    def bounds_t(self):
+        return self._tensors()[len(self.counts):]
+
+    @property
+    def seg_id(self):
+        if self._seg_id is None:
+            # output_size: without it repeat_interleave reads the total back from the device (a host synchronisation)
+            self._seg_id = torch.repeat_interleave(torch.arange(self.R, device=self._device), self.counts_t, output_size=self.rows)
+        return self._seg_id
 
     def sums(self, x):
         """Per-segment sums of a [rows] tensor as float32 through one scan (an index_add_ onto R addresses serialises on
@@ -674,6 +704,39 @@ class _SampledRate(torch.autograd.Function):
         v = lambda x, sh: x.view(sh) if x is not None else None  # noqa: E731
         return (dx[0], dx[1], v(dx[2], go_shape), v(dmask, m_shape), v(dQ[0], qf), v(dQ[1], qs), v(dQ[2], qo),
                 dmean[0], dscale[0], dmean[1], dscale[1], dmean[2], dscale[2], None, None, None, None, None)
+
+
+class _QRows(torch.autograd.Function):
+    """(Q_feat, Q_scaling, Q_offsets) per row = base step x the entropy context's adjustment of the row's anchor (csrc/generate.hip
+    k_q_rows_fwd / _bwd), three [rows, 1] tensors carved from one buffer."""
+
+    @staticmethod
+    def forward(ctx, adj_f, adj_s, adj_o, ctx_row, q_f, q_s, q_o):
+        from . import _lib
+        adj = [a.contiguous().view(-1) for a in (adj_f, adj_s, adj_o)]
+        D, dev = adj[0].shape[0], adj[0].device
+        ctx_row = ctx_row.contiguous() if ctx_row is not None else None
+        rows = ctx_row.shape[0] if ctx_row is not None else D
+        out = torch.empty(3, rows, 1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().gsvc_q_rows_forward(_lib.ptr(adj[0]), _lib.ptr(adj[1]), _lib.ptr(adj[2]), _lib.ptr(ctx_row), float(q_f), float(q_s),
+                                                  float(q_o), rows, _lib.ptr(out), _lib.current_stream(dev)), "gsvc_q_rows_forward")
+        ctx.save_for_backward(ctx_row)
+        ctx.q, ctx.rows, ctx.D, ctx.shapes = (float(q_f), float(q_s), float(q_o)), rows, D, (adj_f.shape, adj_s.shape, adj_o.shape)
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_f, g_s, g_o):
+        from . import _lib
+        (ctx_row,) = ctx.saved_tensors
+        gs = [None if g is None else g.contiguous() for g in (g_f, g_s, g_o)]
+        dev = next(g.device for g in gs if g is not None) if any(g is not None for g in gs) else None
+        if dev is None:
+            return (None,) * 7
+        gadj = torch.empty(3, ctx.D, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().gsvc_q_rows_backward(_lib.ptr(gs[0]), _lib.ptr(gs[1]), _lib.ptr(gs[2]), _lib.ptr(ctx_row), *ctx.q, ctx.rows, ctx.D,
+                                                   _lib.ptr(gadj), _lib.current_stream(dev)), "gsvc_q_rows_backward")
+        return gadj[0].view(ctx.shapes[0]), gadj[1].view(ctx.shapes[1]), gadj[2].view(ctx.shapes[2]), None, None, None, None
 
 
 class _RateNorm(torch.autograd.Function):
@@ -867,15 +930,25 @@ def _film_rows(pc, frames, plan, vis, seg, anchor_all):
         return None
     F = R // 2
     with torch.no_grad():
-        # FiLM row of chain row (view r, anchor a) = (r // 2) * D + position of a in the distinct list
-        frame_of_row = torch.div(seg.seg_id, 2, rounding_mode="floor")
-        row_of = (plan.pos.index_select(0, vis) + frame_of_row * D).to(torch.int32)
-        # the chain rows behind FiLM row (f, a): the row of a in views 2 f and 2 f + 1 (scan of the flattened view masks - 1), -1 if unseen
+        # FiLM row of chain row (view r, anchor a) = (r // 2) * D + position of a in the distinct list; the chain rows behind
+        # FiLM row (f, a): the row of a in views 2 f and 2 f + 1 (scan of the flattened view masks - 1), -1 if unseen
         Mflat, c = plan.ranks
-        base = (torch.arange(R, device=dev, dtype=torch.int64) * A).view(R, 1) + plan.distinct.view(1, D)      # [R, D] flat positions
-        rows = torch.where(Mflat.index_select(0, base.view(-1)), c.index_select(0, base.view(-1)) - 1,
-                           torch.full((), -1, device=dev, dtype=c.dtype)).view(F, 2, D).to(torch.int32)
-        src_a, src_b = rows[:, 0, :].reshape(-1).contiguous(), rows[:, 1, :].reshape(-1).contiguous()
+        if vis.is_cuda and R <= 16 and Mflat.dtype == torch.bool and c.dtype == torch.int64 and seg.rows < 2 ** 31 and F * D < 2 ** 31:
+            import ctypes as C
+            from . import _lib
+            maps = torch.empty(seg.rows + 2 * F * D, dtype=torch.int32, device=dev)
+            row_of, src_a, src_b = maps[:seg.rows], maps[seg.rows:seg.rows + F * D], maps[seg.rows + F * D:]
+            _lib.check(_lib.lib().gsvc_film_row_maps(_lib.ptr(vis.contiguous()), (C.c_int64 * (R + 1))(*seg.bounds), R, _lib.ptr(plan.pos.contiguous()),
+                                                 D, A, _lib.ptr(Mflat.contiguous()), _lib.ptr(c.contiguous()), _lib.ptr(plan.distinct.contiguous()),
+                                                 _lib.ptr(row_of), C.c_void_p(src_a.data_ptr()), C.c_void_p(src_b.data_ptr()),
+                                                 _lib.current_stream(dev)), "gsvc_film_row_maps")
+        else:
+            frame_of_row = torch.div(seg.seg_id, 2, rounding_mode="floor")
+            row_of = (plan.pos.index_select(0, vis) + frame_of_row * D).to(torch.int32)
+            base = (torch.arange(R, device=dev, dtype=torch.int64) * A).view(R, 1) + plan.distinct.view(1, D)      # [R, D] flat positions
+            rows = torch.where(Mflat.index_select(0, base.view(-1)), c.index_select(0, base.view(-1)) - 1,
+                               torch.full((), -1, device=dev, dtype=c.dtype)).view(F, 2, D).to(torch.int32)
+            src_a, src_b = rows[:, 0, :].reshape(-1).contiguous(), rows[:, 1, :].reshape(-1).contiguous()
         seg_f = _Segments([D] * F, dev)
         cond_film = _embed_rows(pc, [frames[2 * i] for i in range(F)], anchor_all.index_select(0, plan.distinct).repeat(F, 1), seg_f)
     return cond_film, row_of, src_a, src_b
@@ -906,7 +979,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     dev = vis_list[0].device
     seg = _Segments([v.shape[0] for v in vis_list], dev)
     with region('gen.gather'):
-        vis = torch.cat(vis_list)
+        vis = plan.vis_all if (plan is not None and plan.vis_all is not None) else torch.cat(vis_list)
         anchor_all = pc.get_anchor if anchors is None else anchors
         anchor = anchor_all.index_select(0, vis)
         ranks = plan.ranks if plan is not None else None
@@ -951,9 +1024,13 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         with region('gen.entropy_context'):
             ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan)
         with region('gen.noise_quant'):
-            rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
-            Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj), Q_scaling * rows_of(ec.Q_scaling_adj),
-                                            Q_offsets * rows_of(ec.Q_offsets_adj))
+            if (feat.is_cuda and all(isinstance(q, (int, float)) for q in (Q_feat, Q_scaling, Q_offsets))
+                    and all(a.dtype == torch.float32 and a.numel() == ec.Q_feat_adj.numel() for a in (ec.Q_feat_adj, ec.Q_scaling_adj, ec.Q_offsets_adj))):
+                Q_feat, Q_scaling, Q_offsets = _QRows.apply(ec.Q_feat_adj, ec.Q_scaling_adj, ec.Q_offsets_adj, ec_row, Q_feat, Q_scaling, Q_offsets)
+            else:
+                rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
+                Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj), Q_scaling * rows_of(ec.Q_scaling_adj),
+                                                Q_offsets * rows_of(ec.Q_offsets_adj))
             feat = _seg_noise_quant(feat, Q_feat, seg)
 
         def rows_quant_and_rate():

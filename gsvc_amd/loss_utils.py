@@ -67,6 +67,7 @@ class _SsimL1Pair(torch.autograd.Function):
         if need:
             ctx.save_for_backward(f, b, g, *maps)
         ctx.mark_non_differentiable(avg)
+        ctx.set_materialize_grads(False)      # no zero image for the averaged frame's (absent) gradient
         out = sums / float(C_ * H * W)
         return out[0], out[1], avg
 
@@ -75,7 +76,10 @@ class _SsimL1Pair(torch.autograd.Function):
         from . import _lib
         f, b, g, m0, m1, m2 = ctx.saved_tensors
         C_, H, W = f.shape
-        grads = torch.stack([g_ssim, g_l1]).float().contiguous()
+        zero = None
+        if g_ssim is None or g_l1 is None:
+            zero = torch.zeros((), device=f.device)
+        grads = torch.stack([zero if g_ssim is None else g_ssim, zero if g_l1 is None else g_l1]).float().contiguous()
         df, db = torch.empty_like(f), torch.empty_like(b)
         _lib.check(_lib.lib().gsvc_ssim_l1_pair_backward(_lib.ptr(f), _lib.ptr(b), _lib.ptr(g), C_, H, W, _lib.ptr(grads), _lib.ptr(m0),
                                                          _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(df), _lib.ptr(db),
@@ -247,13 +251,18 @@ class _RenderRegs(torch.autograd.Function):
                                        _lib.ptr(out), _lib.current_stream(dev)), "gsvc_regs_forward")
         ctx.save_for_backward(scaling, m, sums)
         ctx.seg, ctx.R, ctx.op_shape = seg, R, neural_opacity.shape
-        return out
+        ctx.set_materialize_grads(False)
+        return out[0], out[1]      # two scalars (indexing a returned 2-vector costs a zero-fill + copy + add per element in the backward)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g0, g1):
         from . import _lib
         scaling, m, sums = ctx.saved_tensors
         dev = scaling.device
+        if g0 is None and g1 is None:
+            return None, None, None, None
+        zero = torch.zeros((), device=dev) if (g0 is None or g1 is None) else None
+        g = torch.stack([zero if g0 is None else g0, zero if g1 is None else g1])
         gs = torch.empty_like(scaling)
         go = torch.empty(scaling.shape[0], dtype=torch.float32, device=dev)
         _lib.check(_lib.lib().gsvc_regs_backward(_lib.ptr(scaling), _lib.ptr(m), ctx.seg, ctx.R, _lib.ptr(sums),
@@ -263,7 +272,7 @@ class _RenderRegs(torch.autograd.Function):
 
 
 def render_regs(scaling, neural_opacity, mask, seg_offsets):
-    """Returns the 2-vector (scaling regulariser, opacity regulariser) summed over the renders delimited by seg_offsets."""
+    """Returns the pair (scaling regulariser, opacity regulariser) summed over the renders delimited by seg_offsets."""
     return _RenderRegs.apply(scaling, neural_opacity, mask, seg_offsets)
 
 

@@ -9,7 +9,7 @@ import torch
 from ..common.base import RenderResults
 from ..generate import GenerateMode, generate_neural_gaussians, generate_neural_gaussians_many, generator_trunks
 from ..rasterizer import GaussianRasterizer, raster_forward, rasterize_many, settings_to_c
-from .preprocess import prefilter_geometry, prefilter_voxel, raster_settings_for
+from .preprocess import prefilter_geometry, prefilter_voxel, prefilter_voxels_many, raster_settings_for
 
 
 def render(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain_grad=False,
@@ -42,7 +42,7 @@ def plan_views(frames, pc, pipe, bg_color: torch.Tensor, mode=GenerateMode.TRAIN
     fitting step for the next one, it replaces the step's six count read-backs by one wait."""
     from ..generate import StepPlan
     geometry = prefilter_geometry(pc)
-    visible = [prefilter_voxel(f, pc, pipe, bg_color, geometry=geometry) for f in frames]
+    visible = prefilter_voxels_many(frames, pc, pipe, bg_color, geometry=geometry)
     return StepPlan(frames, pc, visible, geometry, sample=(mode == GenerateMode.TRAINING_ENTROPY))
 
 
@@ -65,7 +65,7 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
         geometry, visible = plan.geometry, plan.visible_masks
     else:
         geometry = prefilter_geometry(pc)
-        visible = [prefilter_voxel(f, pc, pipe, bg_color, geometry=geometry) for f in frames]
+        visible = prefilter_voxels_many(frames, pc, pipe, bg_color, geometry=geometry)
     gss_list = generate_neural_gaussians_many(frames, pc, visible, mode, dense=dense,
                                               anchors=None if anchor_grad else geometry[0], plan=plan)
     results = []
@@ -178,7 +178,7 @@ def render_frames(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0
             chunk = frames[i:i + batch]
             while True:
                 geometry = prefilter_geometry(pc)
-                visible = [prefilter_voxel(f, pc, pipe, bg_color, geometry=geometry) for f in chunk]
+                visible = prefilter_voxels_many(chunk, pc, pipe, bg_color, geometry=geometry)
                 gss_list = generate_neural_gaussians_many(chunk, pc, visible, mode, dense=True, anchors=geometry[0],
                                                           trunks=trunks)
                 images, states = [], []

@@ -118,6 +118,7 @@ class Trainer:
         # anchors are trained with learning rate 0 in GSVC (position_lr_init = position_lr_final = 0): their gradient
         # changes nothing, so the batched step does not compute it unless a non-zero rate is configured
         self.anchor_grad = bool(getattr(opt, "position_lr_init", 0.0) or getattr(opt, "position_lr_final", 0.0))
+        gaussians.anchor_static = not self.anchor_grad      # the quantised anchors may be cached between steps (prefilter_geometry)
         # GSVC_DP_SHARD=1 (or shard_optimizer=True): reduce-scatter + sharded Adam + all-gather for the per-anchor tensors
         #  instead of all-reduce + replicated Adam; same parameters after the step (tests/test_dist_cpu.py)
         self.sharded = None

@@ -106,6 +106,13 @@ int gsvc_raster_sizes_query(const gsvc_raster_settings *settings, int64_t P, int
 /* radii[P] (int32): >0 iff the Gaussian's 3-sigma ellipse intersects the z-slab and the screen. */
 int gsvc_raster_visible_filter(const gsvc_raster_settings *settings, int64_t P, const float *means3D,
                                const float *scales, const float *rotations, int32_t *radii, void *stream);
+/* The same test for 1..8 views over the same P Gaussians in one launch: masks[r P + i] = (radius under settings[r] > 0).
+ * scales: rows scale_stride floats apart, the first three read; scale_exp != 0: they are logarithms (reference
+ * scene/gaussian_model.py scaling_activation = exp); rot_normalise != 0: rotations are un-normalised quaternions (rotation_activation
+ * = normalize, eps 1e-12) — the per-anchor activations of reference ortho_gaussian_renderer/preprocess.py:88-104 folded in. */
+int gsvc_raster_visible_masks(const gsvc_raster_settings *const *settings, int32_t views, int64_t P, const float *means3D,
+                              const float *scales, int32_t scale_stride, int32_t scale_exp, const float *rotations,
+                              int32_t rot_normalise, uint8_t *masks, void *stream);
 
 /* Forward: means3D[P,3] colors[P,3] opacities[P] scales[P,3] rotations[P,4]  ->  image[3,H,W], radii[P].
  * State blobs sized by gsvc_raster_sizes_query(settings, P, max_instances).  The counters struct sits at
@@ -429,6 +436,32 @@ int gsvc_gather_rows_backward_ranked(const float *scaling_p, const float *mask_p
  * stored 0 / 1 values when decoded; reference scene/gaussian_model.py get_mask_anchor), u [R*A] uniform draws of the caller. */
 int gsvc_plan_masks(const uint8_t *const *visible_host, int32_t R, int64_t A, const float *mask_raw, int32_t K, int32_t decoded,
                     const float *u, float rate, uint8_t *M, uint8_t *present, uint8_t *chosen, void *stream);
+/* Per-row quantisation steps: out3 [3, rows], out3[g][i] = q_g adj_g[ctx_row ? ctx_row[i] : i] for the features, scalings and
+ * offsets (reference gaussian_renderer/guassian.py:250-262, Q * Q_adj of the entropy context; ctx_row maps a row to its row of a
+ * context evaluated once per distinct anchor).  backward: grad_adj3 [3, D] = scatter-add of q_g g_g[i] (any g_g may be NULL). */
+int gsvc_q_rows_forward(const float *adj_feat, const float *adj_scaling, const float *adj_offsets, const int64_t *ctx_row,
+                        float q_feat, float q_scaling, float q_offsets, int64_t rows, float *out3, void *stream);
+int gsvc_q_rows_backward(const float *g_feat, const float *g_scaling, const float *g_offsets, const int64_t *ctx_row, float q_feat,
+                         float q_scaling, float q_offsets, int64_t rows, int64_t D, float *grad_adj3, void *stream);
+
+/* Scans and compactions of a step plan in three launches.  view_masks [R, A] (bytes, 0 / 1), chosen [R, A] (a subset of
+ * view_masks: the rate sample, or NULL), present [A] (the union of the views).  Outputs: scan [R A] = inclusive scan of the
+ * flattened view masks (row of (view, anchor) in the concatenated rows + 1); flat = the anchors (position mod A) at the set
+ * positions of view_masks in order — the views' visible-anchor lists one after the other (capacity R A); sel_rows = scan - 1 at the chosen positions (capacity R A); pos [A] = inclusive scan of present - 1; distinct =
+ * the set positions of present (capacity A); counts [R + 2]: the scan at each view's end, the chosen pairs, the distinct anchors. */
+int64_t gsvc_plan_scans_scratch_bytes(int32_t R, int64_t A);
+int gsvc_plan_scans(const uint8_t *view_masks, const uint8_t *chosen, const uint8_t *present, int32_t R, int64_t A, void *scratch,
+                    int64_t *scan, int64_t *flat, int64_t *sel_rows, int64_t *pos, int64_t *distinct, int64_t *counts, void *stream);
+
+/* Row maps for FiLM rows shared by the opposite views of a frame (views 2 f and 2 f + 1 of R have the same camera z, hence the
+ * same condition per anchor: reference frame_cube/frame.py:18-43, gaussian_renderer/guassian.py:225-230).  vis [rows]: anchor of
+ * every chain row (views concatenated, row_bounds_host [R + 1]); pos [A]: anchor -> index in the list distinct [D] of the anchors
+ * some view sees; view_masks [R A] / scan [R A]: the flattened view masks and their inclusive scan.  Outputs: row_of [rows] =
+ * (view / 2) D + pos[vis]; src_a / src_b [R / 2, D] = chain row of the anchor in view 2 f / 2 f + 1, or -1. */
+int gsvc_film_row_maps(const int64_t *vis, const int64_t *row_bounds_host, int32_t R, const int64_t *pos, int64_t D, int64_t A,
+                   const uint8_t *view_masks, const int64_t *scan, const int64_t *distinct, int32_t *row_of, int32_t *src_a,
+                   int32_t *src_b, void *stream);
+
 /* out[scan[i] - 1] = (value ? value[i] + value_bias : i) for every i with mask[i] != 0, `scan` = inclusive scan of the mask
  * (int64): the index lists of the step plan in one elementwise pass each; entries of `out` past the count are not written. */
 int gsvc_compact_by_scan(const uint8_t *mask, const int64_t *scan, const int64_t *value, int64_t value_bias, int64_t n, int64_t *out,

@@ -489,6 +489,106 @@ def test_rate_normalise_matches_tensor_expression(R, rows, empty):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R,A", [(4, 5000), (2, 333), (6, 1200)])
+def test_film_row_maps_match_tensor_expression(R, A):
+    """gsvc_film_row_maps = the index arithmetic it replaces (gsvc_amd.generate._film_rows): FiLM row of every chain row and,
+    per (frame, distinct anchor), the chain rows of the two opposite views (-1 where a view does not see the anchor)."""
+    import ctypes as C
+    from gsvc_amd import _lib
+    torch.manual_seed(R * A)
+    dev = "cuda"
+    M = torch.rand(R, A, device=dev) < 0.3
+    M[1] = M[0] ^ (torch.rand(A, device=dev) < 0.05)        # opposite views see almost the same anchors
+    present = M.any(dim=0)
+    distinct = present.nonzero().squeeze(1)
+    D = int(distinct.shape[0])
+    pos = torch.cumsum(present, 0) - 1
+    c = torch.cumsum(M.view(-1), 0)
+    vis_list = [M[r].nonzero().squeeze(1) for r in range(R)]
+    vis = torch.cat(vis_list)
+    bounds = [0]
+    for v in vis_list:
+        bounds.append(bounds[-1] + int(v.shape[0]))
+    rows, F = bounds[-1], R // 2
+    maps = torch.full((rows + 2 * F * D,), -7, dtype=torch.int32, device=dev)
+    row_of, src_a, src_b = maps[:rows], maps[rows:rows + F * D], maps[rows + F * D:]
+    _lib.check(_lib.lib().gsvc_film_row_maps(_lib.ptr(vis), (C.c_int64 * (R + 1))(*bounds), R, _lib.ptr(pos), D, A, _lib.ptr(M), _lib.ptr(c),
+                                             _lib.ptr(distinct), _lib.ptr(row_of), C.c_void_p(src_a.data_ptr()), C.c_void_p(src_b.data_ptr()),
+                                             _lib.current_stream(torch.device(dev))), "gsvc_film_row_maps")
+    seg_id = torch.repeat_interleave(torch.arange(R, device=dev), torch.tensor([b - a for a, b in zip(bounds[:-1], bounds[1:])], device=dev))
+    ref_row = (pos[vis] + (seg_id // 2) * D).int()
+    base = (torch.arange(R, device=dev) * A).view(R, 1) + distinct.view(1, D)
+    ref = torch.where(M.view(-1)[base.view(-1)], c[base.view(-1)] - 1, torch.full((), -1, device=dev, dtype=c.dtype)).view(F, 2, D).int()
+    assert torch.equal(row_of, ref_row)
+    assert torch.equal(src_a.view(F, D), ref[:, 0]) and torch.equal(src_b.view(F, D), ref[:, 1])
+    # every chain row is the source of exactly one FiLM row entry
+    both = torch.cat([src_a, src_b])
+    assert torch.equal(both[both >= 0].sort().values, torch.arange(rows, device=dev, dtype=torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,A,sample", [(4, 50007, True), (1, 4096, True), (3, 4097, False), (5, 13, True), (2, 8192, True), (4, 244860, True)])
+def test_plan_scans_match_cumsum_and_nonzero(R, A, sample):
+    """gsvc_plan_scans (three launches) = cumsum / nonzero of the flattened view masks, of the union mask and of the rate sample:
+    chunk boundaries inside views, views that are not multiples of the 16-byte loads, empty and full masks."""
+    import ctypes as C
+    from gsvc_amd import _lib
+    torch.manual_seed(R * A)
+    dev = "cuda"
+    M = torch.rand(R, A, device=dev) < 0.35
+    if R >= 3:
+        M[1] = False
+        M[2] = True
+    present = M.any(dim=0)
+    chosen = (M & (torch.rand(R, A, device=dev) < 0.2)) if sample else None
+    L = _lib.lib()
+    big = torch.full((3 * R * A + 2 * A + R + 2,), -5, dtype=torch.int64, device=dev)
+    c, flat, sel = big[:R * A], big[R * A:2 * R * A], big[2 * R * A:3 * R * A]
+    pos, distinct, counts = big[3 * R * A:3 * R * A + A], big[3 * R * A + A:3 * R * A + 2 * A], big[3 * R * A + 2 * A:]
+    scratch = torch.empty(int(L.gsvc_plan_scans_scratch_bytes(R, A)), dtype=torch.uint8, device=dev)
+    v = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(L.gsvc_plan_scans(_lib.ptr(M), _lib.ptr(chosen), _lib.ptr(present), R, A, _lib.ptr(scratch), v(c), v(flat), v(sel) if sample else None,
+                                 v(pos), v(distinct), v(counts), _lib.current_stream(torch.device(dev))), "gsvc_plan_scans")
+    ref_c = torch.cumsum(M.view(-1), 0)
+    assert torch.equal(c, ref_c)
+    assert torch.equal(pos, torch.cumsum(present, 0) - 1)
+    n = counts.tolist()
+    ends = ref_c[A - 1::A].tolist()
+    assert n[:R] == ends and n[R] == (int(chosen.sum()) if sample else 0) and n[R + 1] == int(present.sum())
+    nz = M.view(-1).nonzero().squeeze(1)
+    assert torch.equal(flat[:ends[-1]], nz % A)
+    assert torch.equal(distinct[:n[R + 1]], present.nonzero().squeeze(1))
+    if sample:
+        assert torch.equal(sel[:n[R]], ref_c[chosen.view(-1).nonzero().squeeze(1)] - 1)
+
+
+@pytest.mark.gpu
+def test_q_rows_match_gather_and_product():
+    """_QRows = base step x adjustment gathered by context row, for the three groups; gradient = scatter-add onto the distinct rows;
+    without a row map the rows are the context rows."""
+    from gsvc_amd.generate import _QRows
+    torch.manual_seed(3)
+    D, rows, dev = 700, 2500, "cuda"
+    for with_map in (True, False):
+        adj = [(torch.rand(D, 1, device=dev) + 0.5).requires_grad_(True) for _ in range(3)]
+        ctx_row = torch.randint(0, D, (rows,), device=dev) if with_map else None
+        n = rows if with_map else D
+        ws = [torch.randn(n, 1, device=dev) for _ in range(3)]
+        qs = (1, 0.001, 0.2)
+        out = _QRows.apply(*adj, ctx_row, *qs)
+        sum((o * w).sum() for o, w in list(zip(out, ws))[:2]).backward()          # the third output: no gradient
+        got = [a.grad for a in adj]
+        assert got[2] is None or float(got[2].abs().max()) == 0.0
+        ref_adj = [a.detach().clone().requires_grad_(True) for a in adj]
+        ref = [q * (a if ctx_row is None else a.index_select(0, ctx_row)) for q, a in zip(qs, ref_adj)]
+        sum((o * w).sum() for o, w in list(zip(ref, ws))[:2]).backward()
+        for o, r in zip(out, ref):
+            assert o.shape == r.shape and torch.equal(o, r)
+        for g, a in list(zip(got, ref_adj))[:2]:
+            assert torch.allclose(g, a.grad, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
 def test_training_statis_kernel_matches_index_adds():
     """gsvc_training_statis = clamp + sums + gradient norms + four index_adds (reference scene/gaussian_model.py:1281-1314 through
     the nested masks), anchors repeated over the rows as the four views of a step repeat them."""

@@ -58,6 +58,45 @@ def test_step_runs_in_every_phase_and_loss_falls():
     assert pc.optimizer.state[pc.mlp_feature_enet.dist_net[0].weight]["step"] > 0
 
 
+def test_multi_view_visibility_equals_the_per_view_filter():
+    """prefilter_voxels_many (one launch, activations folded in, quantised anchors cached) = rasterizer.visible_filter on the
+    activated tensors, view by view; the cache follows an in-place change of the anchors and a new bound."""
+    from gsvc_amd.ortho_gaussian_renderer.preprocess import RawGeometry, prefilter_geometry, prefilter_voxels_many, raster_settings_for
+    from gsvc_amd.rasterizer import GaussianRasterizer
+    pc, cube, opt, pipe, mp, Trainer = _setup(anchors=5003)
+    pc.training_setup(opt)
+    with torch.no_grad():
+        pc._rotation.copy_(torch.randn_like(pc._rotation))           # un-normalised
+        pc._scaling.add_(torch.randn_like(pc._scaling) * 0.5)
+    bg = torch.zeros(3, device="cuda")
+    frames = [cube[i] for i in (0, 3, 4, 5, 7, 8, 9, 10, 11)]        # nine views: two launches
+
+    def check():
+        geo = prefilter_geometry(pc)
+        assert isinstance(geo, RawGeometry)
+        got = prefilter_voxels_many(frames, pc, pipe, bg, geometry=geo)
+        seen = 0
+        for f, m in zip(frames, got):
+            r = GaussianRasterizer(raster_settings=raster_settings_for(f, pc, pipe, bg))
+            ref = r.visible_filter(means3D=pc.get_anchor.contiguous(), scales=pc.get_scaling[:, :3].contiguous(),
+                                   rotations=pc.get_rotation.contiguous()) > 0
+            assert m.dtype == torch.bool and int((m != ref).sum()) <= 1          # (a radius on the boundary may round differently)
+            seen += int(ref.sum())
+        assert 0 < seen < len(frames) * pc._anchor.shape[0]
+        return geo[0]
+
+    a0 = check()
+    pc.anchor_static = True
+    a1 = check()
+    assert check().data_ptr() == a1.data_ptr() and torch.equal(a0, a1)          # cached
+    with torch.no_grad():
+        pc._anchor.mul_(0.9)
+    a2 = check()
+    assert a2.data_ptr() != a1.data_ptr()
+    pc.update_anchor_bound(cube.x_min * 1.5, cube.y_min * 1.5, cube.z_min * 1.5)
+    assert check().data_ptr() != a2.data_ptr()
+
+
 def test_averaged_image_is_view_symmetric():
     """(image_f + flip(image_b)) / 2 does not depend on which of the two views is called forward."""
     from gsvc_amd.generate import GenerateMode

@@ -95,3 +95,22 @@ for ev in prof.events():
 print("fills / copies / cats by shape:")
 for (n, shp, w), (t, c) in sorted(fl.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"{t / N:8.1f} us x{c / N:4.1f}  {n[6:]:8s} {shp:62s} {w}")
+# backward-side launches by the autograd node that issued them (gradient accumulation at a fan-out shows up under the node
+# whose output is accumulated: "evaluate_function: XBackward" with an aten::add)
+nd = defaultdict(lambda: [0.0, 0])
+for ev in prof.events():
+    if not ev.name.startswith("aten::") or ev.self_device_time_total <= 0:
+        continue
+    p, node = ev.cpu_parent, None
+    while p is not None:
+        if "evaluate_function" in p.name or p.name.endswith("Backward") or "Backward" in p.name:
+            node = p.name
+        p = p.cpu_parent
+    if node is None:
+        continue
+    shp = str([list(x) for x in (ev.input_shapes or []) if x])[:48]
+    nd[(node.replace("autograd::engine::evaluate_function: ", "")[:44], ev.name[6:], shp)][0] += ev.self_device_time_total
+    nd[(node.replace("autograd::engine::evaluate_function: ", "")[:44], ev.name[6:], shp)][1] += 1
+print("backward launches by autograd node:")
+for (node, n, shp), (t, c) in sorted(nd.items(), key=lambda kv: -kv[1][0])[:70]:
+    print(f"{t / N:8.1f} us x{c / N:4.1f}  {node:44s} {n:16s} {shp}")
