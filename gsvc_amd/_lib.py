@@ -159,6 +159,12 @@ _SIGNATURES = {
     "gsvc_embed_pe": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_int32, C.c_int32, _vp, _vp]),
     "gsvc_optical_forward": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, C.c_int32, _i64, _vp, C.c_int32, C.c_int32,
                                        C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_optical_many_partial_floats": (_i64, [C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32]),
+    "gsvc_optical_many_forward": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
+                                            C.c_int32, _i64, _vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,
+                                            _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_optical_many_backward": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
+                                             C.c_int32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_optical_backward": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_regs_partial_floats": (_i64, [C.POINTER(C.c_int64), C.c_int32]),
     "gsvc_regs_forward": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, _vp, _vp, _vp]),

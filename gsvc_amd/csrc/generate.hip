@@ -491,18 +491,26 @@ __global__ void __launch_bounds__(256) k_plan_scan_count(const uint8_t *__restri
 }
 
 // offsets[k] = exclusive scan of counts within each of the three arrays; totals[0..2] = their sums (M, chosen, present)
-__global__ void __launch_bounds__(64) k_plan_scan_offsets(const int *__restrict__ counts, int nbM, int nbP, long long *__restrict__ offsets,
-                                                          long long *__restrict__ totals)
+// wave j scans array j, 64 chunk counts per round (a one-thread loop over ~240 counts took 20 us of dependent loads)
+__global__ void __launch_bounds__(192) k_plan_scan_offsets(const int *__restrict__ counts, int nbM, int nbP, long long *__restrict__ offsets,
+                                                           long long *__restrict__ totals)
 {
-    const int j = threadIdx.x;
-    if (j >= 3) return;
+    const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int first = j == 0 ? 0 : (j == 1 ? nbM : 2 * nbM), n = j == 2 ? nbP : nbM;
     long long run = 0;
-    for (int k = 0; k < n; k++) {
-        offsets[first + k] = run;
-        run += counts[first + k];
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        const long long v = k < n ? counts[first + k] : 0;
+        long long inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (k < n) offsets[first + k] = run + inc - v;
+        run += __shfl(inc, 63, 64);
     }
-    totals[j] = run;
+    if (lane == 0) totals[j] = run;
 }
 
 __global__ void __launch_bounds__(256) k_plan_scan_write(const uint8_t *__restrict__ M, const uint8_t *__restrict__ chosen, long long nM,
@@ -822,7 +830,7 @@ extern "C" int gsvc_plan_scans(const uint8_t *view_masks, const uint8_t *chosen,
     hipLaunchKernelGGL(gsvc::k_plan_scan_count, dim3(nbM + nbP), dim3(256), 0, s, view_masks, chosen, nM, present, (long long)A, nbM, bc);
     // counts: [0, R) the scan at each view's end, [R] chosen pairs, [R + 1] distinct anchors: the totals (M, chosen, present) land on
     // counts[R - 1 ..] (the first repeats the last view's end)
-    hipLaunchKernelGGL(gsvc::k_plan_scan_offsets, dim3(1), dim3(64), 0, s, bc, nbM, nbP, offsets, (long long *)counts + R - 1);
+    hipLaunchKernelGGL(gsvc::k_plan_scan_offsets, dim3(1), dim3(192), 0, s, bc, nbM, nbP, offsets, (long long *)counts + R - 1);
     hipLaunchKernelGGL(gsvc::k_plan_scan_write, dim3(nbM + nbP), dim3(256), 0, s, view_masks, chosen, nM, present, (long long)A, nbM, offsets,
                        (long long *)scan, (long long *)flat, (long long *)sel_rows, (long long *)pos, (long long *)distinct,
                        (long long *)counts);

@@ -133,6 +133,120 @@ __global__ void __launch_bounds__(256) k_optical_bwd(const int32_t *__restrict__
     g2[3 * r + 1] = sy;
 }
 
+// The same loss for several frame pairs whose renders are row ranges of ONE set of tensors (a fitting step: renders f1, b1, f2,
+// b2 concatenated; pairs f1 -> f2 and b1 -> b2) — four launches forward and one backward for all pairs, no per-Gaussian table,
+// no zero-filled gradients, the gradient written straight in the concatenated layout:
+//   k_optical_rows      : table[r][anchor] = row + 1 of the anchor in render r (the pairing is by anchor and offset slot)
+//   k_optical_fwd_many  : grid.y = pair; a source Gaussian looks its partner up through the destination render's table
+//   k_optical_fin_many  : per-pair sums, out[0] = sum_p sums[p][0] / (2 sums[p][1])
+//   k_optical_bwd_many  : every Gaussian of every render writes its own gradient (a destination Gaussian finds the source
+//                         through the source render's table and reads that one's sign code)
+struct OpticalBatch {
+    int64_t goff[MAX_RENDERS + 1];      // Gaussian offsets of the renders
+    int R, P;
+    int src[MAX_RENDERS / 2], dst[MAX_RENDERS / 2];
+    int pair_of[MAX_RENDERS];           // render -> pair (or -1), and whether it is the pair's source
+    int is_src[MAX_RENDERS];
+};
+
+__global__ void __launch_bounds__(256) k_optical_rows(const int64_t *__restrict__ vis, OpticalBatch ob, int K, int64_t A,
+                                                      int32_t *__restrict__ table)
+{
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row * K >= ob.goff[ob.R]) return;
+    int r = 0;
+    while (r + 1 < ob.R && row * K >= ob.goff[r + 1]) r++;
+    table[(int64_t)r * A + vis[row]] = (int32_t)(row - ob.goff[r] / K) + 1;
+}
+
+__global__ void __launch_bounds__(256) k_optical_fwd_many(const float *__restrict__ world, const uint8_t *__restrict__ mask,
+                                                          const int64_t *__restrict__ vis, OpticalBatch ob, int K, int64_t A,
+                                                          const int32_t *__restrict__ table, const float *__restrict__ flow, float x_min,
+                                                          float y_min, float scale, int x_pix_max, int y_pix_max, int flow_h, int flow_w,
+                                                          int32_t *__restrict__ partner, float *__restrict__ part)
+{
+    __shared__ float red[4];
+    const int p = blockIdx.y, rs = ob.src[p], rd = ob.dst[p];
+    const int64_t i = ob.goff[rs] + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = i < ob.goff[rs + 1];
+    float err = 0.f, cnt = 0.f;
+    int32_t code = 0;
+    if (in && mask[i]) {
+        const int64_t row = i / K;
+        const int k = (int)(i - row * K);
+        const int32_t r2 = table[(int64_t)rd * A + vis[row]];
+        const int64_t j = ob.goff[rd] + (int64_t)(r2 - 1) * K + k;
+        if (r2 && mask[j]) {
+            const float x1 = world[3 * i], y1 = world[3 * i + 1];
+            const float fx = rintf((x1 - x_min) * scale), fy = rintf((y1 - y_min) * scale);
+            if (fx >= 0.f && fy >= 0.f && fx < (float)x_pix_max && fy < (float)y_pix_max) {
+                const int px = (int)fx, py = (int)fy;
+                const float u = flow[(size_t)py * flow_w + px] / scale;
+                const float v = flow[(size_t)flow_h * flow_w + (size_t)py * flow_w + px] / scale;
+                const float ex = (world[3 * j] - x1) - u, ey = (world[3 * j + 1] - y1) - v;
+                err = fabsf(ex) + fabsf(ey);
+                cnt = 1.f;
+                const int sx = (ex > 0.f) - (ex < 0.f), sy = (ey > 0.f) - (ey < 0.f);
+                code = 16 | ((sx + 1) << 2) | (sy + 1);
+            }
+        }
+    }
+    if (in) partner[i] = code;
+    err = block_sum256(err, red);
+    cnt = block_sum256(cnt, red);
+    if (threadIdx.x == 0) {
+        float *d = part + 2 * ((size_t)p * gridDim.x + blockIdx.x);
+        d[0] = err;
+        d[1] = cnt;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_optical_fin_many(const float *__restrict__ part, int blocks, int P, float *__restrict__ sums,
+                                                          float *__restrict__ out)
+{
+    __shared__ float red[4];
+    for (int p = 0; p < P; p++) reduce_partials<2>(part + 2 * (size_t)p * blocks, blocks, sums + 2 * p, red);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int p = 0; p < P; p++) a += sums[2 * p] / (2.0f * sums[2 * p + 1]);      // 0 / 0 = nan: the mean over no pairs
+        out[0] = a;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_optical_bwd_many(const int32_t *__restrict__ partner, const int64_t *__restrict__ vis,
+                                                          OpticalBatch ob, int K, int64_t A, const int32_t *__restrict__ table,
+                                                          const float *__restrict__ sums, const float *__restrict__ grad_out,
+                                                          float *__restrict__ g)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ob.goff[ob.R]) return;
+    int r = 0;
+    while (r + 1 < ob.R && i >= ob.goff[r + 1]) r++;
+    float gx = 0.f, gy = 0.f;
+    const int p = ob.pair_of[r];
+    if (p >= 0) {
+        int32_t code = 0;
+        float sign = -1.f;
+        if (ob.is_src[r]) {
+            code = partner[i];
+        } else {
+            const int64_t row = i / K;
+            const int32_t r1 = table[(int64_t)ob.src[p] * A + vis[row]];
+            if (r1) code = partner[ob.goff[ob.src[p]] + (int64_t)(r1 - 1) * K + (i - row * K)];
+            sign = 1.f;
+        }
+        if (code) {
+            const float k = sign * grad_out[0] / (2.0f * sums[2 * p + 1]);
+            gx = (float)(((code >> 2) & 3) - 1) * k;
+            gy = (float)((code & 3) - 1) * k;
+        }
+    }
+    g[3 * i] = gx;
+    g[3 * i + 1] = gy;
+    g[3 * i + 2] = 0.f;
+}
+
 // ------------------------------------------------------------------------------------------------ regularisers
 // part[(r*nbx + bx)*3 + {0,1,2}] = block sums of (m_i prod_c s_ic, m_i, 1 - o_i) over render r's Gaussians
 __global__ void __launch_bounds__(256) k_regs_fwd(const float *__restrict__ scaling, const float *__restrict__ opacity,
@@ -289,4 +403,87 @@ extern "C" int gsvc_regs_backward(const float *scaling, const uint8_t *mask, con
                            grad_opacity);
     }
     return check_launch("regs_backward");
+}
+
+static bool fill_optical(const int64_t *gaussian_offsets_host, int R, const int32_t *pair_src_host, const int32_t *pair_dst_host, int P, int K,
+                         OpticalBatch &ob)
+{
+    if (!gaussian_offsets_host || !pair_src_host || !pair_dst_host || R < 2 || R > MAX_RENDERS || P < 1 || P > MAX_RENDERS / 2 || K < 1)
+        return false;
+    ob.R = R; ob.P = P;
+    for (int r = 0; r <= MAX_RENDERS; r++) ob.goff[r] = gaussian_offsets_host[r <= R ? r : R];
+    for (int r = 0; r < R; r++)
+        if (ob.goff[r + 1] < ob.goff[r] || ob.goff[r] % K) return false;
+    if (ob.goff[R] % K || ob.goff[R] >= ((int64_t)1 << 31)) return false;
+    for (int r = 0; r < MAX_RENDERS; r++) { ob.pair_of[r] = -1; ob.is_src[r] = 0; }
+    for (int p = 0; p < MAX_RENDERS / 2; p++) {
+        const int q = p < P ? p : 0;
+        ob.src[p] = pair_src_host[q]; ob.dst[p] = pair_dst_host[q];
+        if (p >= P) continue;
+        if (ob.src[p] < 0 || ob.src[p] >= R || ob.dst[p] < 0 || ob.dst[p] >= R || ob.src[p] == ob.dst[p]) return false;
+        if (ob.pair_of[ob.src[p]] >= 0 || ob.pair_of[ob.dst[p]] >= 0) return false;      // a render belongs to one pair
+        ob.pair_of[ob.src[p]] = p; ob.is_src[ob.src[p]] = 1;
+        ob.pair_of[ob.dst[p]] = p;
+    }
+    return true;
+}
+
+static int optical_blocks(const OpticalBatch &ob)
+{
+    int64_t longest = 1;
+    for (int p = 0; p < ob.P; p++) {
+        const int64_t n = ob.goff[ob.src[p] + 1] - ob.goff[ob.src[p]];
+        longest = n > longest ? n : longest;
+    }
+    return (int)((longest + 255) / 256);
+}
+
+extern "C" int64_t gsvc_optical_many_partial_floats(const int64_t *gaussian_offsets_host, int32_t R, const int32_t *pair_src_host,
+                                                    const int32_t *pair_dst_host, int32_t P, int32_t K)
+{
+    OpticalBatch ob;
+    if (!fill_optical(gaussian_offsets_host, R, pair_src_host, pair_dst_host, P, K, ob)) return -1;
+    return 2 * (int64_t)P * optical_blocks(ob);
+}
+
+extern "C" int gsvc_optical_many_forward(const float *world, const uint8_t *mask, const int64_t *vis, const int64_t *gaussian_offsets_host,
+                                         int32_t R, const int32_t *pair_src_host, const int32_t *pair_dst_host, int32_t P, int32_t K,
+                                         int64_t anchors, const float *flow, int32_t flow_h, int32_t flow_w, float x_min, float y_min,
+                                         float scale, int32_t x_pix_max, int32_t y_pix_max, int32_t *table, int32_t *partner, float *sums,
+                                         float *partial, float *loss, void *stream)
+{
+    OpticalBatch ob;
+    GSVC_REQUIRE(fill_optical(gaussian_offsets_host, R, pair_src_host, pair_dst_host, P, K, ob) && anchors > 0,
+                 "optical_many_forward: 2..8 renders of whole rows, 1..4 disjoint pairs, fewer than 2^31 Gaussians");
+    GSVC_REQUIRE(x_pix_max <= flow_w && y_pix_max <= flow_h, "optical_many_forward: pixel bounds exceed the flow field");
+    GSVC_REQUIRE(table && partner && sums && partial && loss && flow && (ob.goff[R] == 0 || (world && mask && vis)),
+                 "optical_many_forward: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(table, 0, sizeof(int32_t) * (size_t)R * anchors, s) != hipSuccess) {
+        set_error("optical_many_forward: hipMemsetAsync failed");
+        return GSVC_E_LAUNCH;
+    }
+    const int64_t rows = ob.goff[R] / K;
+    const int blocks = optical_blocks(ob);
+    ProfScope _p("k_optical_fwd", s);
+    if (rows) hipLaunchKernelGGL(k_optical_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, vis, ob, (int)K, anchors, table);
+    hipLaunchKernelGGL(k_optical_fwd_many, dim3(blocks, P), dim3(256), 0, s, world, mask, vis, ob, (int)K, anchors, table, flow, x_min, y_min,
+                       scale, x_pix_max, y_pix_max, flow_h, flow_w, partner, partial);
+    hipLaunchKernelGGL(k_optical_fin_many, dim3(1), dim3(256), 0, s, partial, blocks, (int)P, sums, loss);
+    return check_launch("optical_many_forward");
+}
+
+extern "C" int gsvc_optical_many_backward(const int32_t *partner, const int64_t *vis, const int64_t *gaussian_offsets_host, int32_t R,
+                                          const int32_t *pair_src_host, const int32_t *pair_dst_host, int32_t P, int32_t K, int64_t anchors,
+                                          const int32_t *table, const float *sums, const float *grad_out, float *grad_world, void *stream)
+{
+    OpticalBatch ob;
+    GSVC_REQUIRE(fill_optical(gaussian_offsets_host, R, pair_src_host, pair_dst_host, P, K, ob) && anchors > 0, "optical_many_backward: bad arguments");
+    if (ob.goff[R] == 0) return GSVC_OK;
+    GSVC_REQUIRE(partner && vis && table && sums && grad_out && grad_world, "optical_many_backward: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope _p("k_optical_bwd", s);
+    hipLaunchKernelGGL(k_optical_bwd_many, dim3((unsigned)((ob.goff[R] + 255) / 256)), dim3(256), 0, s, partner, vis, ob, (int)K, anchors, table,
+                       sums, grad_out, grad_world);
+    return check_launch("optical_many_backward");
 }

@@ -400,18 +400,31 @@ __device__ __forceinline__ long long rn_lower_bound(const long long *__restrict_
 }
 
 // out[r] = {all, features, scalings, offsets} bits per parameter; coef[r] = d out[r][i] / d (the S it divides); sum = sum_r out[r][0]
-__global__ void __launch_bounds__(64) k_rate_normalise(const float *__restrict__ S, const int *__restrict__ part, int blocks,
-                                                       const long long *__restrict__ sel, long long n_sel, RateNormBounds rb, int R, float d0,
-                                                       float d1, float d2, float *__restrict__ out, float *__restrict__ coef, float *__restrict__ sum)
+__global__ void __launch_bounds__(256) k_rate_normalise(const float *__restrict__ S, const int *__restrict__ part, int blocks,
+                                                        const long long *__restrict__ sel, long long n_sel, RateNormBounds rb, int R, float d0,
+                                                        float d1, float d2, float *__restrict__ out, float *__restrict__ coef, float *__restrict__ sum)
 {
+    __shared__ int live_s[RS_MAX_R];
+    __shared__ long long edge[RS_MAX_R + 1];
     __shared__ float tot[RS_MAX_R];
-    const int r = threadIdx.x;
+    const int t = threadIdx.x;
+    if (t < RS_MAX_R) live_s[t] = 0;
+    __syncthreads();
+    // the blocks' live-row counts: thread t takes blocks t, t + 256, ... (integer sums: any order)
+    for (int r = 0; r < R; r++) {
+        int v = 0;
+        for (int b = t; b < blocks; b += 256) v += part[b * RS_MAX_R + r];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((t & 63) == 0 && v) atomicAdd(&live_s[r], v);
+    }
+    if (t <= R) edge[t] = rn_lower_bound(sel, n_sel, rb.b[t]);      // the R + 1 searches side by side
+    __syncthreads();
+    const int r = t;
     if (r < R) {
-        int live = 0;
-        for (int b = 0; b < blocks; b++) live += part[b * RS_MAX_R + r];
         const long long rows = rb.b[r + 1] - rb.b[r];
-        const float kr = (float)live / (float)(rows > 1 ? rows : 1);
-        const float ns = (float)(rn_lower_bound(sel, n_sel, rb.b[r + 1]) - rn_lower_bound(sel, n_sel, rb.b[r]));
+        const float kr = (float)live_s[r] / (float)(rows > 1 ? rows : 1);
+        const float ns = (float)(edge[r + 1] - edge[r]);
         const float N0 = ns * d0, N1 = ns * d1, N2 = ns * d2, NA = (N0 + N1) + N2;
         const float s0 = S[r * 3], s1 = S[r * 3 + 1], s2 = S[r * 3 + 2];
         out[r * 4] = ((s0 + s1) + s2) / NA * kr;
@@ -422,10 +435,10 @@ __global__ void __launch_bounds__(64) k_rate_normalise(const float *__restrict__
         tot[r] = out[r * 4];
     }
     __syncthreads();
-    if (r == 0) {
-        float t = 0.f;
-        for (int q = 0; q < R; q++) t += tot[q];
-        sum[0] = t;
+    if (t == 0) {
+        float a = 0.f;
+        for (int q = 0; q < R; q++) a += tot[q];
+        sum[0] = a;
     }
 }
 
@@ -599,7 +612,7 @@ extern "C" int gsvc_rate_normalise_forward(const float *S, const float *offset_m
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gsvc::k_rate_live_part, dim3(gsvc::RN_BLOCKS), dim3(256), 0, s, offset_masks, (long long)rb.b[R], (int)K, rb, (int)R,
                        (int *)scratch);
-    hipLaunchKernelGGL(gsvc::k_rate_normalise, dim3(1), dim3(64), 0, s, S, (const int *)scratch, gsvc::RN_BLOCKS, (const long long *)sel,
+    hipLaunchKernelGGL(gsvc::k_rate_normalise, dim3(1), dim3(256), 0, s, S, (const int *)scratch, gsvc::RN_BLOCKS, (const long long *)sel,
                        (long long)n_sel, rb, (int)R, dims3_host[0], dims3_host[1], dims3_host[2], out, coef, sum);
     return gsvc::check_launch("rate_normalise_forward");
 }

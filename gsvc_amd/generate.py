@@ -1090,7 +1090,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         parts = [t.split(sizes, dim=0) for t in (xyz, color, neural_opacity, scaling, rot, world)]
         from types import SimpleNamespace
         batch = SimpleNamespace(scaling=scaling, neural_opacity=neural_opacity, mask=mask, seg_offsets=[b * K for b in seg.bounds], vis=vis,
-                                xyz=xyz, color=color, rot=rot,      # the un-split tensors: rasterize_many works on their row ranges
+                                xyz=xyz, color=color, rot=rot, world=world,      # the un-split tensors: rasterize_many works on their row ranges
                                 bit_per_param_sum=getattr(rates[0], "bit_per_param_sum", None))
         out = []
         for r, gs in enumerate(seg.slices(K)):

@@ -230,6 +230,45 @@ def _optical_loss_dense(r1, r2, optical_flow, x_min, y_min, scale, x_pix_max: in
                               x_pix_max, y_pix_max)
 
 
+class _OpticalMany(torch.autograd.Function):
+    """calc_optical_loss over renders that are row ranges of one set of tensors (render_many(dense=True)): every pair in four
+    launches forward and one backward, the gradient in the concatenated layout (csrc/losses.hip k_optical_*_many)."""
+
+    @staticmethod
+    def forward(ctx, world, mask, vis, goff, pairs, flow, K, anchors, x_min, y_min, scale, x_pix_max, y_pix_max):
+        import ctypes as C
+        from . import _lib
+        dev = world.device
+        world, vis, flow = world.contiguous(), vis.contiguous(), flow.contiguous()
+        m = mask.contiguous().view(torch.uint8)
+        R, P = len(goff) - 1, len(pairs)
+        off = (C.c_int64 * (R + 1))(*[int(v) for v in goff])
+        src, dst = (C.c_int32 * P)(*[p[0] for p in pairs]), (C.c_int32 * P)(*[p[1] for p in pairs])
+        L = _lib.lib()
+        table = torch.empty(R * anchors, dtype=torch.int32, device=dev)
+        partner = torch.empty(max(int(goff[-1]), 1), dtype=torch.int32, device=dev)
+        res = torch.empty(2 * P + 1 + int(L.gsvc_optical_many_partial_floats(off, R, src, dst, P, K)), dtype=torch.float32, device=dev)
+        sums, loss, partial = res[:2 * P], res[2 * P:2 * P + 1], res[2 * P + 1:]
+        _lib.check(L.gsvc_optical_many_forward(_lib.ptr(world), _lib.ptr(m), _lib.ptr(vis), off, R, src, dst, P, K, anchors, _lib.ptr(flow),
+                                               flow.shape[1], flow.shape[2], float(x_min), float(y_min), float(scale), int(x_pix_max),
+                                               int(y_pix_max), _lib.ptr(table), _lib.ptr(partner), _lib.ptr(sums), C.c_void_p(partial.data_ptr()),
+                                               C.c_void_p(loss.data_ptr()), _lib.current_stream(dev)), "gsvc_optical_many_forward")
+        ctx.save_for_backward(partner, vis, table, sums)
+        ctx.meta = (off, R, src, dst, P, K, anchors, world.shape)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        partner, vis, table, sums = ctx.saved_tensors
+        off, R, src, dst, P, K, anchors, shape = ctx.meta
+        gw = torch.empty(shape, dtype=torch.float32, device=partner.device)
+        _lib.check(_lib.lib().gsvc_optical_many_backward(_lib.ptr(partner), _lib.ptr(vis), off, R, src, dst, P, K, anchors, _lib.ptr(table),
+                                                         _lib.ptr(sums), _lib.ptr(g.contiguous().float()), _lib.ptr(gw),
+                                                         _lib.current_stream(partner.device)), "gsvc_optical_many_backward")
+        return (gw,) + (None,) * 12
+
+
 class _RenderRegs(torch.autograd.Function):
     """(sum_r mean over opacity>0 of prod(scaling), sum_r mean(1 - neural_opacity)) over the concatenated
     un-compacted Gaussians of R renders (csrc/losses.hip)."""
@@ -279,6 +318,14 @@ def render_regs(scaling, neural_opacity, mask, seg_offsets):
 def calc_optical_loss(render_results1_f, render_results1_b, render_results2_f, render_results2_b, optical_flow,
                       x_min, y_min, scale, x_pix_max: int, y_pix_max: int, n_offsets=10):
     if render_results1_f.dense:
+        rs = (render_results1_f, render_results1_b, render_results2_f, render_results2_b)
+        batch = getattr(rs[0].generated_gaussians, "batch", None)
+        if (batch is not None and getattr(batch, "world", None) is not None and batch.world.is_cuda and len(batch.seg_offsets) == 5
+                and all(getattr(r.generated_gaussians, "batch", None) is batch for r in rs)):
+            # the four renders are row ranges of the batch's tensors, in this order: both pairs in one pass
+            return _OpticalMany.apply(batch.world, batch.mask, batch.vis, batch.seg_offsets, ((0, 2), (1, 3)),
+                                      optical_flow.to(batch.world.device), n_offsets, rs[0].visible_mask.shape[0], x_min, y_min, scale,
+                                      x_pix_max, y_pix_max)
         args = (optical_flow, x_min, y_min, scale, x_pix_max, y_pix_max, n_offsets)
         return (_optical_loss_dense(render_results1_f, render_results2_f, *args)
                 + _optical_loss_dense(render_results1_b, render_results2_b, *args))

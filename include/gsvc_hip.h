@@ -306,6 +306,23 @@ int gsvc_optical_forward(const float *world1, const uint8_t *mask1, const int64_
 int gsvc_optical_backward(const int32_t *partner, int64_t n1, int64_t n2, const float *sums, const float *grad_out,
                           float *grad_world1, float *grad_world2, void *stream);
 
+/* The same loss summed over P disjoint pairs of renders that are row ranges of ONE set of tensors (a fitting step's renders
+ * f1, b1, f2, b2 concatenated, pairs f1 -> f2 and b1 -> b2: reference utils/loss_utils.py:138-153 calc_optical_loss).  world [N, 3],
+ * mask [N], vis [N / K] cover all R renders, gaussian_offsets_host [R + 1]; pair p takes its frame-t Gaussians from render
+ * pair_src_host[p] and their partners from pair_dst_host[p].  loss[0] = sum_p sums[2p] / (2 sums[2p + 1]).  Scratch: table
+ * int32 [R, anchors] (anchor -> row + 1, kept for the backward), partner int32 [N], sums float [2 P], partial float
+ * [gsvc_optical_many_partial_floats].  backward: grad_world [N, 3] is written completely (zeros outside the pairs). */
+int64_t gsvc_optical_many_partial_floats(const int64_t *gaussian_offsets_host, int32_t R, const int32_t *pair_src_host,
+                                         const int32_t *pair_dst_host, int32_t P, int32_t K);
+int gsvc_optical_many_forward(const float *world, const uint8_t *mask, const int64_t *vis, const int64_t *gaussian_offsets_host, int32_t R,
+                              const int32_t *pair_src_host, const int32_t *pair_dst_host, int32_t P, int32_t K, int64_t anchors,
+                              const float *flow, int32_t flow_h, int32_t flow_w, float x_min, float y_min, float scale,
+                              int32_t x_pix_max, int32_t y_pix_max, int32_t *table, int32_t *partner, float *sums, float *partial,
+                              float *loss, void *stream);
+int gsvc_optical_many_backward(const int32_t *partner, const int64_t *vis, const int64_t *gaussian_offsets_host, int32_t R,
+                               const int32_t *pair_src_host, const int32_t *pair_dst_host, int32_t P, int32_t K, int64_t anchors,
+                               const int32_t *table, const float *sums, const float *grad_out, float *grad_world, void *stream);
+
 /* Regularisers of the R renders of one step (reference pipeline/train.py:417-424) over their concatenated Gaussians
  * (render r = [seg_offsets[r], seg_offsets[r+1]), host array of R+1 entries, R <= 8):
  *   out[0] = sum_r mean_{i in r, mask_i}(scaling_i0 scaling_i1 scaling_i2),  out[1] = sum_r mean_{i in r}(1 - neural_opacity_i).

@@ -473,6 +473,30 @@ def test_fused_loss_terms_match_torch():
     ref.backward()
     assert torch.allclose(g1, w1.grad, rtol=1e-4, atol=1e-8) and torch.allclose(g2, w2.grad, rtol=1e-4, atol=1e-8)
 
+    # ---- both pairs of a step over the concatenated renders (f1, b1, f2, b2) = the sum of the two per-pair losses
+    rs = [fake_render(s_)[0] for s_ in (21, 22, 23, 24)]
+    rs[1].generated_gaussians.mask[:] = False                 # a render with nothing alive: its pair contributes 0/0
+    for empty_pair in (False, True):
+        worlds = [r.generated_gaussians.world_xyz.detach().clone().requires_grad_(True) for r in rs]
+        goff = [0]
+        for wld in worlds:
+            goff.append(goff[-1] + wld.shape[0])
+        pairs = ((0, 2), (1, 3)) if empty_pair else ((0, 2),)
+        world_all = torch.cat(worlds).detach().requires_grad_(True)
+        many = LU._OpticalMany.apply(world_all, torch.cat([r.generated_gaussians.mask for r in rs]), torch.cat([r.visible_index for r in rs]),
+                                     goff, pairs, flow, K, A, x_min, y_min, scale, W, H)
+        for r, wld in zip(rs, worlds):
+            r.generated_gaussians.world_xyz = wld
+        each = sum(LU._optical_loss_dense(rs[a], rs[b], flow, x_min, y_min, scale, W, H, K) for a, b in pairs)
+        if empty_pair:
+            assert torch.isnan(many) and torch.isnan(each)
+            continue
+        assert float(many) == float(each)
+        many.backward()
+        each.backward()
+        ref_g = torch.cat([wld.grad if wld.grad is not None else torch.zeros_like(wld) for wld in worlds])
+        assert torch.equal(world_all.grad, ref_g) and float(ref_g.abs().sum()) > 0
+
 
 def test_training_crosses_densification_steps():
     """The step keeps running through adjust_anchor (grow + prune every update_interval steps): parameter, statistic
