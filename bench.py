@@ -586,6 +586,29 @@ def run_raster(args, rank, world, dev, workload, cpu_baseline):
         _, tq = reduce_sum_max(torch, dist, world, dev, 0.0, tq)
         pipelined_fps = args.steps * world / tq
 
+    # the same step replayed from a captured HIP graph (every C-ABI call is capturable: no allocation, no synchronisation inside):
+    # what the launch gaps between the pipeline's dependent kernels cost.  Reported beside the eager numbers.
+    graph_ms = None
+    try:
+        side = torch.cuda.Stream(device=dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            step()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                graph_image = step()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            g.replay()
+        tg = timed(torch, dist, world, g.replay, args.steps)
+        _, tg = reduce_sum_max(torch, dist, world, dev, 0.0, tg)
+        graph_ms = 1e3 * tg / args.steps
+        if not torch.equal(graph_image, step()):
+            graph_ms = None          # a replay must give the eager image bit for bit
+        del g, graph_image
+    except Exception as e:          # capture is an extra: never fail the bench line over it
+        print(f"[bench] graph capture skipped: {e}", file=sys.stderr)
+
     _lib.profile_enable(True)
     for _ in range(args.steps):
         step()
@@ -620,6 +643,9 @@ def run_raster(args, rank, world, dev, workload, cpu_baseline):
                    "parallelism": f"frame-shard x{world}"},
         "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
         "render_fps": args.steps * world / elapsed,
+        "graph_replay": (None if graph_ms is None else
+                         {"ms_per_step": graph_ms, "render_fps": 1e3 * world / graph_ms,
+                          "note": "the same step captured once into a HIP graph and replayed (image bit-identical to the eager step)"}),
         "render_fps_two_view": pair_fps,
         "render_fps_two_view_2streams": pipelined_fps,
         "render_fps_note": PAIR_NOTE,

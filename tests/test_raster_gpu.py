@@ -435,3 +435,50 @@ def test_convention_switches_keep_parity(oracle_lib, flags, low_pass):
         with pytest.raises(_lib.GsvcError, match="raster_forward_pair"):
             rasterizer.raster_forward(r._c_settings(), d["means3D"].detach(), d["colors"].detach(),
                                       d["opacities"].detach().view(-1).contiguous(), d["scales"].detach(), d["rotations"].detach(), pair=True)
+
+
+def test_forward_and_backward_replay_from_a_captured_hip_graph():
+    """include/gsvc_hip.h promises calls that allocate nothing and never synchronise, i.e. that can be captured into a hipGraph:
+    the forward pipeline + backward of one frame captured once and replayed give the eager call's image and gradients bit for bit
+    (the backward adds per-tile partial rows in a fixed order: no atomics)."""
+    import ctypes as C
+    from gsvc_amd import _lib, rasterizer
+    sc = synthetic.raster_scene(20000, H=270, W=480, T=64, seed=7, window_frames=16, frame_id=32, sigma_px=(0.5, 4.0))
+    s = sc["settings"]
+    d = _to_dev(sc)
+    d["opacities"] = d["opacities"].view(-1).contiguous()
+    cs = rasterizer.settings_to_c(_rasterizer(s).raster_settings)
+    P = d["means3D"].shape[0]
+    _, _, st0 = rasterizer.raster_forward(cs, d["means3D"], d["colors"], d["opacities"], d["scales"], d["rotations"])
+    cap = int(st0.counters()[0] * 1.1) + 1024
+    dL = torch.randn(3, s["H"], s["W"], device="cuda")
+    L = _lib.lib()
+
+    def step():
+        grads = [torch.empty(P, 3, device="cuda"), torch.empty(P, 3, device="cuda"), torch.empty(P, 3, device="cuda"),
+                 torch.empty(P, device="cuda"), torch.empty(P, 3, device="cuda"), torch.empty(P, 4, device="cuda")]
+        scratch = torch.empty(rasterizer.backward_scratch_floats(P, cap), device="cuda")
+        image, radii, st = rasterizer.raster_forward(cs, d["means3D"], d["colors"], d["opacities"], d["scales"], d["rotations"],
+                                                     max_instances=cap, sync=False)
+        _lib.check(L.gsvc_raster_backward(C.byref(cs), P, cap, _lib.ptr(d["means3D"]), _lib.ptr(d["colors"]), _lib.ptr(d["opacities"]),
+                                          _lib.ptr(d["scales"]), _lib.ptr(d["rotations"]), _lib.ptr(radii), _lib.ptr(st.geom),
+                                          _lib.ptr(st.binning), _lib.ptr(st.image_state), _lib.ptr(dL), *[_lib.ptr(g) for g in grads],
+                                          _lib.ptr(scratch), _lib.current_stream(torch.device("cuda"))), "gsvc_raster_backward")
+        return [image, radii] + grads
+
+    eager = [t.clone() for t in step()]
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        step()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            held = step()
+    torch.cuda.synchronize()
+    for t in held:
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(eager[0].abs().sum()) > 0 and float(eager[2].abs().sum()) > 0
+    for a, b in zip(eager, held):
+        assert torch.equal(a, b)
