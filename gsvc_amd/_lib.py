@@ -115,6 +115,8 @@ _SIGNATURES = {
     "gsvc_raster_image_layout": (C.c_int, [C.POINTER(RasterSettingsC), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gsvc_grid_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "gsvc_grid_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "gsvc_pack_sign_bits": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "gsvc_grid_forward_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, C.POINTER(GridIOC), _vp]),
     "gsvc_grid_forward_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, C.POINTER(GridIOC), _vp]),
     "gsvc_grid_backward_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, C.POINTER(GridIOC), _vp]),
     "gsvc_rate_forward": (C.c_int, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_int32, _i64, _i64, _vp, _vp, _vp]),

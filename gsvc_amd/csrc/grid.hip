@@ -138,7 +138,16 @@ __device__ __forceinline__ void store_row(float *__restrict__ p, const float (&v
     }
 }
 
-template <uint32_t D, uint32_t C>
+// One row of a BIT-PACKED binarised table: byte `row` holds the signs of the row's 8 features (bit f set: +1, clear: -1) — the
+// table as the bitstream carries it (reference utils/encodings.py:375-392 STE_binary over whole tables; 1/32 of the float form)
+__device__ __forceinline__ void load_row_bits(const uint8_t *__restrict__ p, uint32_t row, float (&v)[8])
+{
+    const uint32_t b = p[row];
+#pragma unroll
+    for (uint32_t f = 0; f < 8; f++) v[f] = (b >> f) & 1u ? 1.0f : -1.0f;
+}
+
+template <uint32_t D, uint32_t C, bool PACKED = false>
 __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inputs, const float *__restrict__ grid,
                                                   const int32_t *__restrict__ offsets,
                                                   const int32_t *__restrict__ resolutions, float *__restrict__ outputs,
@@ -147,6 +156,7 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inpu
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= N) return;
     const uint32_t level = blockIdx.y;
+    const uint8_t *bits = reinterpret_cast<const uint8_t *>(grid) + (uint32_t)offsets[level];      // PACKED: one byte per row
     grid += (size_t)(uint32_t)offsets[level] * C;
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
     const uint32_t resolution = (uint32_t)resolutions[level];
@@ -178,7 +188,8 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inpu
 #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
         if (c.valid & (1u << idx)) {
-            load_row<C>(grid + (size_t)c.row[idx] * C, g[idx]);
+            if constexpr (PACKED) load_row_bits(bits, c.row[idx], g[idx]);
+            else load_row<C>(grid + (size_t)c.row[idx] * C, g[idx]);
         } else {
 #pragma unroll
             for (uint32_t ch = 0; ch < C; ch++) g[idx][ch] = 0.f;
@@ -552,6 +563,16 @@ static void launch_bwd(const float *grad, const float *inputs, const int32_t *of
             return GSVC_E_UNSUPPORTED;                                     \
     }
 
+// bits[row] = sign bits of x[row][0..8) (x >= 0 -> 1: the STE_binary rule, 0 -> +1)
+__global__ void __launch_bounds__(256) k_pack_sign_bits(const float *__restrict__ x, long long rows, uint8_t *__restrict__ bits)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float4 a = reinterpret_cast<const float4 *>(x)[2 * r], b = reinterpret_cast<const float4 *>(x)[2 * r + 1];
+    bits[r] = (uint8_t)((a.x >= 0.f) | ((a.y >= 0.f) << 1) | ((a.z >= 0.f) << 2) | ((a.w >= 0.f) << 3) | ((b.x >= 0.f) << 4) |
+                        ((b.y >= 0.f) << 5) | ((b.z >= 0.f) << 6) | ((b.w >= 0.f) << 7));
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -640,4 +661,38 @@ extern "C" int gsvc_grid_backward_ex(const float *grad, const float *inputs, con
     GridIO io;
     if (int rc = grid_io_from(layout, D, C, io, "grid_backward_ex")) return rc;
     return grid_backward_impl(grad, inputs, offsets, resolutions, grad_embeddings, N, D, C, L, nullptr, nullptr, stream, io);
+}
+
+extern "C" int gsvc_pack_sign_bits(const float *x, int64_t rows, uint8_t *bits, void *stream)
+{
+    GSVC_REQUIRE(rows >= 0, "pack_sign_bits: bad size");
+    if (rows == 0) return GSVC_OK;
+    GSVC_REQUIRE(x && bits && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "pack_sign_bits: NULL or unaligned pointer");
+    hipLaunchKernelGGL(k_pack_sign_bits, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, bits);
+    return check_launch("pack_sign_bits");
+}
+
+extern "C" int gsvc_grid_forward_packed(const float *inputs, const uint8_t *table_bits, const int32_t *offsets, const int32_t *resolutions,
+                                        float *outputs, uint32_t N, uint32_t D, uint32_t L, const gsvc_grid_io *layout, void *stream)
+{
+    const uint32_t C = 8;
+    GridIO io = grid_io_default(N, D, C);
+    if (layout)
+        if (int rc = grid_io_from(layout, D, C, io, "grid_forward_packed")) return rc;
+    if (D != 2 && D != 3) {
+        set_error("grid_forward_packed: num_dim must be 2 or 3 (8 features per row)");
+        return GSVC_E_UNSUPPORTED;
+    }
+    if (N == 0 || L == 0) return GSVC_OK;
+    GSVC_REQUIRE(inputs && table_bits && offsets && resolutions && outputs, "grid_forward_packed: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope _prof("k_grid_fwd", s);
+    const float *tb = reinterpret_cast<const float *>(table_bits);
+    if (D == 3)
+        hipLaunchKernelGGL((k_grid_fwd<3, 8, true>), dim3((N + 255) / 256, L), dim3(256), 0, s, inputs, tb, offsets, resolutions, outputs, N, L,
+                           (float *)nullptr, io);
+    else
+        hipLaunchKernelGGL((k_grid_fwd<2, 8, true>), dim3((N + 255) / 256, L), dim3(256), 0, s, inputs, tb, offsets, resolutions, outputs, N, L,
+                           (float *)nullptr, io);
+    return check_launch("grid_forward_packed");
 }

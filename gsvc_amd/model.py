@@ -88,10 +88,35 @@ class Mix3d2dEncoding(nn.Module):
             # the four grids write their column blocks of the [N, 192] matrix and read the gradient from them (gsvc_grid_*_ex):
             # no coordinate slices, no [L, N, C] -> [N, L C] permutes, no cat — on either pass
             grids = (self.encoding_xyz, self.encoding_xy, self.encoding_xz, self.encoding_yz)
+            if (not torch.is_grad_enabled() and all(g.n_features == 8 and g.params.is_contiguous() for g in grids)
+                    and not os.environ.get("GSVC_NO_PACKED_GRID")):
+                # inference (evaluation, the decoder): the tables as the bitstream carries them — one sign bit per entry, one byte
+                # per row of 8 features — packed on the fly (one pass over the float tables) and looked up as bytes
+                return _mix_grid_packed(x, grids)
             from .encodings import binarized_tables
             return _MixGridEncode.apply(x, grids, *binarized_tables(grids))
         xy, xz, yz = x[..., 0:2], x[..., 0::2], x[..., 1:3]     # slices, not list indices: their backward is a strided add, not a sort-based index_put
         return torch.cat([self.encoding_xyz(x), self.encoding_xy(xy), self.encoding_xz(xz), self.encoding_yz(yz)], dim=-1)
+
+
+def _mix_grid_packed(x, grids):
+    """Mix3d2dEncoding without autograd through bit-packed tables (csrc/grid.hip gsvc_pack_sign_bits + gsvc_grid_forward_packed):
+    the same numbers as the lookup in the {-1, +1} float tables, from 1/32 of the table bytes."""
+    import ctypes as C
+    from . import _lib
+    x = x.contiguous()
+    N = x.shape[0]
+    total = sum(g.n_levels * g.n_features for g in grids)
+    out = torch.empty(N, total, device=x.device, dtype=torch.float32)
+    st, L = _lib.current_stream(x.device), _lib.lib()
+    for g, (io, c0) in zip(grids, _MixGridEncode._layout(grids, x, total)):
+        rows = g.params.shape[0]
+        bits = torch.empty(rows, dtype=torch.uint8, device=x.device)
+        _lib.check(L.gsvc_pack_sign_bits(_lib.ptr(g.params.detach()), rows, _lib.ptr(bits), st), "gsvc_pack_sign_bits")
+        _lib.check(L.gsvc_grid_forward_packed(_lib.ptr(x), _lib.ptr(bits), _lib.ptr(g.offsets_list), _lib.ptr(g.resolutions_list),
+                                              C.c_void_p(out.data_ptr() + 4 * c0), N, g.num_dim, g.n_levels, C.byref(io), st),
+                   "gsvc_grid_forward_packed")
+    return out
 
 
 class _MixGridEncode(torch.autograd.Function):

@@ -187,6 +187,14 @@ int gsvc_grid_backward_ex(const float *grad, const float *inputs, const int32_t 
                           float *grad_embeddings, uint32_t N, uint32_t D, uint32_t C, uint32_t L, const gsvc_grid_io *layout,
                           void *stream);
 
+/* Lookup in BIT-PACKED binarised tables (8 features per row: one byte per row, bit f set = +1, clear = -1 — the {-1, +1} tables of
+ * reference utils/encodings.py:375-392 STE_binary as the bitstream carries them: 1/32 of the float tables).  Same interpolation,
+ * same results bit for bit as gsvc_grid_forward_ex on the float tables; layout may be NULL (default layout).  Inference only.
+ * gsvc_pack_sign_bits: bits[row] from a float table x [rows, 8] (x >= 0 -> 1). */
+int gsvc_pack_sign_bits(const float *x, int64_t rows, uint8_t *bits, void *stream);
+int gsvc_grid_forward_packed(const float *inputs, const uint8_t *table_bits, const int32_t *offsets, const int32_t *resolutions,
+                             float *outputs, uint32_t N, uint32_t D, uint32_t L, const gsvc_grid_io *layout, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Entropy-rate estimator (replaces utils/entropy_models.py EntropyGaussian.forward + Low_bound backward)
  * ---------------------------------------------------------------------------------------------------- */

@@ -821,3 +821,34 @@ def test_mix_encoding_strided_layout_equals_the_module_path(monkeypatch):
     assert res[0][0].shape == (N, 192) and torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1], res[1][1]):
         assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-9        # float atomics reorder the sums
+
+
+@pytest.mark.gpu
+def test_bit_packed_tables_give_the_float_tables_lookup(monkeypatch):
+    """Inference through bit-packed tables (one byte per row of 8 features: gsvc_pack_sign_bits + gsvc_grid_forward_packed) is
+    the lookup in the binarised float tables bit for bit: every level of the 3-D and the 2-D grids, points on the cube's faces
+    and outside it, zeros in the tables (binarise to +1)."""
+    from gsvc_amd.model import Mix3d2dEncoding
+    torch.manual_seed(9)
+    enc = Mix3d2dEncoding(n_features=8, resolutions_list=(18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514), log2_hashmap_size=13,
+                          resolutions_list_2D=(130, 258, 514, 1026), log2_hashmap_size_2D=15, ste_binary=True, ste_multistep=False,
+                          add_noise=False, Q=1).cuda()
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.copy_(torch.randn_like(p))
+            p[::7] = 0.0
+    N = 30001
+    x = torch.rand(N, 3, device="cuda")
+    x[0] = 0.0
+    x[1] = 1.0
+    x[2, 2] = 1.3
+    with torch.no_grad():
+        packed = enc(x)
+        monkeypatch.setenv("GSVC_NO_PACKED_GRID", "1")
+        plain = enc(x)
+    assert packed.shape == (N, 192) and torch.equal(packed, plain)
+    # z outside the cube: the 3-D grid (first 96 columns) and the xz / yz grids give zeros, the xy grid does not
+    assert float(packed[2, :96].abs().sum()) == 0.0 and float(packed[2, 96:128].abs().sum()) > 0 and float(packed[2, 128:].abs().sum()) == 0.0
+    monkeypatch.delenv("GSVC_NO_PACKED_GRID")
+    y = enc(x)                                      # with autograd the float tables are used (their gradient is needed)
+    assert "MixGridEncode" in type(y.grad_fn).__name__ and torch.equal(y.detach(), packed)
