@@ -213,6 +213,54 @@ def test_dense_step_equals_per_render_step(entropy):
         assert (ga[n] - gb[n]).abs().max().item() <= 2e-3 * scale + 1e-12, n
 
 
+def test_fitting_at_the_configs0_shape():
+    """BASELINE.json configs[0]: 8 synthetic 256 x 256 frames, 5 k Gaussians (500 anchors x K = 10), lambda = 0 (the full-precision
+    phase: no rate term).  The batched step equals the reference-style per-render step there too (loss, gradients, accumulators),
+    and fitting lowers the loss."""
+    from gsvc_amd.arguments import ModelParams, OptimizationParams, PipelineParams
+    from gsvc_amd.frame import SyntheticFrameCube
+    from gsvc_amd.model import GaussianModel
+    from gsvc_amd.train import Trainer
+
+    def setup():
+        mp = ModelParams()
+        mp.grid_feature_dim = 2
+        opt = OptimizationParams()
+        opt.lmbda = 0.0
+        cube = SyntheticFrameCube(256, 256, 8, device="cuda")
+        mp.threshold = 4.0 / cube.scale                    # the whole 8-frame video inside the slab
+        torch.manual_seed(0)
+        np.random.seed(0)
+        pc = GaussianModel(mp, 16, 10, 0.001, 3, 16, 4, False, n_features_per_level=2, log2_hashmap_size=10, log2_hashmap_size_2D=12,
+                           resolutions_list=(18, 24, 33, 44), resolutions_list_2D=(130, 258), device="cuda")
+        rng = np.random.default_rng(0)
+        lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
+        pc.create_from_points(rng.uniform(lim, -lim, (500, 3)), spatial_lr_scale=1.0)
+        pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+        opt.full_precision_training_total = 10 ** 6
+        opt.start_stat, opt.pause_densification = 0, 0
+        return pc, cube, opt, PipelineParams(), mp
+
+    res = []
+    for batched in (True, False):
+        pc, cube, opt, pipe, mp = setup()
+        opt.iterations = 1                                  # iteration 1 == iterations: no Adam step
+        pc.training_setup(opt)
+        out = Trainer(pc, cube, opt, pipe, mp, batched=batched).step(1, frame_idx=3)
+        res.append((float(out.loss), {n: p.grad.clone() for n, p in pc.named_parameters() if p.grad is not None},
+                    pc.opacity_accum.clone(), pc.offset_denom.clone(), [r.num_rendered for r in out.renders]))
+    (la, ga, oa, da, na), (lb, gb, ob, db, nb) = res
+    assert na == nb and sum(na) > 1000 and abs(la - lb) < 1e-5 * max(1.0, abs(lb))
+    assert torch.allclose(oa, ob, rtol=1e-5, atol=1e-6) and torch.equal(da, db)
+    for n in ga:
+        assert (ga[n] - gb[n]).abs().max().item() <= 2e-3 * gb[n].abs().max().item() + 1e-12, n
+    pc, cube, opt, pipe, mp = setup()
+    pc.training_setup(opt)
+    tr = Trainer(pc, cube, opt, pipe, mp)
+    losses = [float(tr.step(it, frame_idx=it % 7).loss) for it in range(1, 61)]
+    assert np.isfinite(losses).all() and np.mean(losses[-7:]) < 0.85 * np.mean(losses[:7])
+
+
 def test_step_plan_matches_the_per_view_index_lists(monkeypatch):
     """A StepPlan (visible anchors of the four views, their union, the 5 % rate sample: gsvc_amd.generate.StepPlan, masks from
     csrc/generate.hip k_plan_masks) against the expressions it replaces, and against its own unfused form with the same draws."""
