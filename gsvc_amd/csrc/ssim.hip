@@ -3,21 +3,25 @@
 // Replaces the distortion part of the fitting step: reference utils/loss_utils.py:20-72 (l1_loss_func and
 // ssim_func/_ssim: five depthwise 11x11 Gaussian-window conv2d calls with zero padding plus ~15 elementwise
 // kernels per image pair, and their autograd).  One kernel each way:
-//   forward   per 16x16 tile: img1/img2 with a 5-pixel halo staged in LDS, separable 11-tap blur of the five
+//   forward   per 32x32 tile: img1/img2 with a 5-pixel halo staged in LDS, separable 11-tap blur of the five
 //             moments (x, y, x^2, y^2, xy) through LDS, the SSIM map, its sum, |x-y| summed, and the three
 //             per-pixel partials d(map)/d(mu1), d(map)/d(E[x^2]), d(map)/d(E[xy]) for the backward
-//   backward  per 16x16 tile: the three partial maps (times dL/dmap) blurred again (the window is symmetric,
+//   backward  per 32x32 tile: the three partial maps (times dL/dmap) blurred again (the window is symmetric,
 //             so the transposed convolution is the same convolution) and combined with x, y; + the L1 sign
-// HBM-bound: forward reads 2 images, writes 3 maps; backward reads 2 images + 3 maps, writes 1 gradient.
+// Both passes are REGISTER-BLOCKED (round 3): a thread produces 4 adjacent outputs of a row (horizontal pass: 14 + 2 staged
+// values per image through four 16-byte LDS reads) or of a column (vertical pass: 14 LDS reads per moment), so an output
+// costs 7 + 17.5 LDS reads instead of 22 + 55, and the 32x32 tile reads 1.7x its pixels from HBM instead of 2.6x (16x16).
 #include "common.h"
 
 #include <cmath>
 
 namespace gsvc {
 
-constexpr int SS_TILE = 16;
+constexpr int SS_TILE = 32;
 constexpr int SS_R = 5;                     // window radius (11 taps)
-constexpr int SS_HALO = SS_TILE + 2 * SS_R;  // 26
+constexpr int SS_HALO = SS_TILE + 2 * SS_R;  // 42
+constexpr int SS_LD = 44;                   // row stride of the staged images: 16-byte aligned groups of 4 columns
+constexpr int SS_HLD = SS_TILE + 1;         // row stride of the horizontally blurred moments
 constexpr float SS_C1 = 0.01f * 0.01f;
 constexpr float SS_C2 = 0.03f * 0.03f;
 constexpr int SS_SLOTS = 1024;             // rows of the partial-sum workspace
@@ -46,66 +50,113 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(SsimWindow win, const float *_
                                                   float *__restrict__ dm_dmu1, float *__restrict__ dm_de11,
                                                   float *__restrict__ dm_de12)
 {
-    __shared__ float sx[SS_HALO][SS_HALO + 1];
-    __shared__ float sy[SS_HALO][SS_HALO + 1];
-    __shared__ float hb[5][SS_HALO][SS_TILE + 1];  // horizontally blurred moments
+    __shared__ __attribute__((aligned(16))) float sx[SS_HALO][SS_LD];
+    __shared__ __attribute__((aligned(16))) float sy[SS_HALO][SS_LD];
+    __shared__ float hb[5][SS_HALO][SS_HLD];  // horizontally blurred moments
     __shared__ float red[4];
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int tid = threadIdx.x;
     const int x0 = blockIdx.x * SS_TILE, y0 = blockIdx.y * SS_TILE;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int i = tid; i < SS_HALO * SS_HALO; i += 256) {
+    // every load of the tile is issued before the first is waited for (7 per thread and image: with one load per loop
+    // iteration the block spent its time in 7 dependent memory round trips)
+    constexpr int SS_LOADS = (SS_HALO * SS_HALO + 255) / 256;
+    float xa[SS_LOADS], xb[SS_LOADS], ya[SS_LOADS];
+#pragma unroll
+    for (int it = 0; it < SS_LOADS; it++) {
+        const int i = tid + 256 * it;
         const int r = i / SS_HALO, c = i - r * SS_HALO;
         const int gy = y0 + r - SS_R, gx = x0 + c - SS_R;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        float xv = in ? img1[plane + (size_t)gy * W + gx] : 0.f;
-        if (img1b && in) xv = (xv + img1b[plane + (size_t)gy * W + (W - 1 - gx)]) / 2.0f;
-        sx[r][c] = xv;
-        sy[r][c] = in ? img2[plane + (size_t)gy * W + gx] : 0.f;
+        const bool in = i < SS_HALO * SS_HALO && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        xa[it] = in ? img1[plane + (size_t)gy * W + gx] : 0.f;
+        xb[it] = (img1b && in) ? img1b[plane + (size_t)gy * W + (W - 1 - gx)] : 0.f;
+        ya[it] = in ? img2[plane + (size_t)gy * W + gx] : 0.f;
     }
-    __syncthreads();
-    if (avg_out) {
-        const int gxo = x0 + lx, gyo = y0 + ly;
-        if (gxo < W && gyo < H) avg_out[plane + (size_t)gyo * W + gxo] = sx[ly + SS_R][lx + SS_R];
-    }
-    for (int i = tid; i < SS_HALO * SS_TILE; i += 256) {
-        const int r = i / SS_TILE, c = i - r * SS_TILE;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float x = sx[r][c + k], y = sy[r][c + k], w = win.w[k];
-            a0 += w * x; a1 += w * y; a2 += w * x * x; a3 += w * y * y; a4 += w * x * y;
+    for (int it = 0; it < SS_LOADS; it++) {
+        const int i = tid + 256 * it;
+        const int r = i / SS_HALO, c = i - r * SS_HALO;
+        if (i < SS_HALO * SS_HALO) {
+            sx[r][c] = img1b ? (xa[it] + xb[it]) / 2.0f : xa[it];
+            sy[r][c] = ya[it];
         }
-        hb[0][r][c] = a0; hb[1][r][c] = a1; hb[2][r][c] = a2; hb[3][r][c] = a3; hb[4][r][c] = a4;
+    }
+    if (tid < 2 * SS_HALO) {      // the two pad columns the 16-byte reads touch (never used in arithmetic): keep them finite
+        sx[tid >> 1][SS_HALO + (tid & 1)] = 0.f;
+        sy[tid >> 1][SS_HALO + (tid & 1)] = 0.f;
     }
     __syncthreads();
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    // horizontal pass: group g = (row r, columns 4 cg .. 4 cg + 3)
+    for (int g = tid; g < SS_HALO * (SS_TILE / 4); g += 256) {
+        const int r = g >> 3, c0 = 4 * (g & 7);
+        float xv[16], yv[16];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = win.w[k];
-        mu1 += w * hb[0][ly + k][lx]; mu2 += w * hb[1][ly + k][lx]; e11 += w * hb[2][ly + k][lx];
-        e22 += w * hb[3][ly + k][lx]; e12 += w * hb[4][ly + k][lx];
+        for (int q = 0; q < 4; q++) {
+            const float4 a = *reinterpret_cast<const float4 *>(&sx[r][c0 + 4 * q]);
+            const float4 b = *reinterpret_cast<const float4 *>(&sy[r][c0 + 4 * q]);
+            xv[4 * q] = a.x; xv[4 * q + 1] = a.y; xv[4 * q + 2] = a.z; xv[4 * q + 3] = a.w;
+            yv[4 * q] = b.x; yv[4 * q + 1] = b.y; yv[4 * q + 2] = b.z; yv[4 * q + 3] = b.w;
+        }
+        // the products once per staged element (the reference blurs img1 * img1 etc.: products first), 5 FMAs per tap
+        float xx[14], yy[14], xy[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) { xx[k] = xv[k] * xv[k]; yy[k] = yv[k] * yv[k]; xy[k] = xv[k] * yv[k]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const float w = win.w[k];
+                a0 = fmaf(w, xv[j + k], a0); a1 = fmaf(w, yv[j + k], a1); a2 = fmaf(w, xx[j + k], a2);
+                a3 = fmaf(w, yy[j + k], a3); a4 = fmaf(w, xy[j + k], a4);
+            }
+            hb[0][r][c0 + j] = a0; hb[1][r][c0 + j] = a1; hb[2][r][c0 + j] = a2; hb[3][r][c0 + j] = a3; hb[4][r][c0 + j] = a4;
+        }
     }
-    const int gx = x0 + lx, gy = y0 + ly;
-    const bool in = gx < W && gy < H;
-    float ssim = 0.f, l1 = 0.f;
-    if (in) {
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-        const float num1 = 2.f * mu12 + SS_C1, num2 = 2.f * s12 + SS_C2;
-        const float A = mu1_sq + mu2_sq + SS_C1, B = s1 + s2 + SS_C2;
-        const float inv = 1.0f / (A * B);
-        ssim = num1 * num2 * inv;
-        l1 = fabsf(sx[ly + SS_R][lx + SS_R] - sy[ly + SS_R][lx + SS_R]);
-        if (dm_dmu1) {
+    __syncthreads();
+    // vertical pass: thread = (column lx, rows 4 gq .. 4 gq + 3)
+    const int lx = tid & 31, gq = tid >> 5;
+    float mom[5][4];
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+        float v[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) v[k] = hb[m][4 * gq + k][lx];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) a += win.w[k] * v[j + k];
+            mom[m][j] = a;
+        }
+    }
+    const int gx = x0 + lx;
+    float ssim_sum = 0.f, l1_sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int ly = 4 * gq + j, gy = y0 + ly;
+        if (gx < W && gy < H) {
+            const float mu1 = mom[0][j], mu2 = mom[1][j], e11 = mom[2][j], e22 = mom[3][j], e12 = mom[4][j];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+            const float num1 = 2.f * mu12 + SS_C1, num2 = 2.f * s12 + SS_C2;
+            const float A = mu1_sq + mu2_sq + SS_C1, B = s1 + s2 + SS_C2;
+            const float inv = 1.0f / (A * B);
+            const float ssim = num1 * num2 * inv;
+            const float xc = sx[ly + SS_R][lx + SS_R], yc = sy[ly + SS_R][lx + SS_R];
+            ssim_sum += ssim;
+            l1_sum += fabsf(xc - yc);
             const size_t o = plane + (size_t)gy * W + gx;
-            // map as a function of (mu1, E[x^2], E[xy]) with sigma1^2 = E[x^2] - mu1^2, sigma12 = E[xy] - mu1 mu2
-            dm_dmu1[o] = 2.f * mu2 * (num2 - num1) * inv - 2.f * mu1 * ssim * (1.0f / A - 1.0f / B);
-            dm_de11[o] = -ssim / B;
-            dm_de12[o] = 2.f * num1 * inv;
+            if (avg_out) avg_out[o] = xc;
+            if (dm_dmu1) {
+                // map as a function of (mu1, E[x^2], E[xy]) with sigma1^2 = E[x^2] - mu1^2, sigma12 = E[xy] - mu1 mu2
+                dm_dmu1[o] = 2.f * mu2 * (num2 - num1) * inv - 2.f * mu1 * ssim * (1.0f / A - 1.0f / B);
+                dm_de11[o] = -ssim / B;
+                dm_de12[o] = 2.f * num1 * inv;
+            }
         }
     }
-    const float ssum = block_sum_256(ssim, red);
-    const float lsum = block_sum_256(l1, red);
+    const float ssum = block_sum_256(ssim_sum, red);
+    const float lsum = block_sum_256(l1_sum, red);
     if (tid == 0) {
         // spread the per-block sums over SS_SLOTS rows: atomics on one address serialise at the memory side
         const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) % SS_SLOTS;
@@ -133,54 +184,92 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(SsimWindow win, const float *_
                                                   const float *__restrict__ dm_de11, const float *__restrict__ dm_de12,
                                                   float *__restrict__ dL_dimg1)
 {
-    __shared__ float sm[3][SS_HALO][SS_HALO + 1];
-    __shared__ float hb[3][SS_HALO][SS_TILE + 1];
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    __shared__ __attribute__((aligned(16))) float sm[3][SS_HALO][SS_LD];
+    __shared__ float hb[3][SS_HALO][SS_HLD];
+    const int tid = threadIdx.x;
     const int x0 = blockIdx.x * SS_TILE, y0 = blockIdx.y * SS_TILE;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int i = tid; i < SS_HALO * SS_HALO; i += 256) {
+    constexpr int SS_LOADS = (SS_HALO * SS_HALO + 255) / 256;
+    float ma[3][SS_LOADS];
+#pragma unroll
+    for (int it = 0; it < SS_LOADS; it++) {          // all loads first (see k_ssim_fwd)
+        const int i = tid + 256 * it;
         const int r = i / SS_HALO, c = i - r * SS_HALO;
         const int gy = y0 + r - SS_R, gx = x0 + c - SS_R;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool in = i < SS_HALO * SS_HALO && gy >= 0 && gy < H && gx >= 0 && gx < W;
         const size_t o = plane + (size_t)gy * W + gx;
-        sm[0][r][c] = in ? dm_dmu1[o] : 0.f;
-        sm[1][r][c] = in ? dm_de11[o] : 0.f;
-        sm[2][r][c] = in ? dm_de12[o] : 0.f;
+        ma[0][it] = in ? dm_dmu1[o] : 0.f;
+        ma[1][it] = in ? dm_de11[o] : 0.f;
+        ma[2][it] = in ? dm_de12[o] : 0.f;
     }
-    __syncthreads();
-    for (int i = tid; i < SS_HALO * SS_TILE; i += 256) {
-        const int r = i / SS_TILE, c = i - r * SS_TILE;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = win.w[k];
-            a0 += w * sm[0][r][c + k]; a1 += w * sm[1][r][c + k]; a2 += w * sm[2][r][c + k];
+    for (int it = 0; it < SS_LOADS; it++) {
+        const int i = tid + 256 * it;
+        const int r = i / SS_HALO, c = i - r * SS_HALO;
+        if (i < SS_HALO * SS_HALO) {
+            sm[0][r][c] = ma[0][it]; sm[1][r][c] = ma[1][it]; sm[2][r][c] = ma[2][it];
         }
-        hb[0][r][c] = a0; hb[1][r][c] = a1; hb[2][r][c] = a2;
+    }
+    if (tid < 2 * SS_HALO) {
+#pragma unroll
+        for (int m = 0; m < 3; m++) sm[m][tid >> 1][SS_HALO + (tid & 1)] = 0.f;
     }
     __syncthreads();
-    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    for (int g = tid; g < SS_HALO * (SS_TILE / 4); g += 256) {
+        const int r = g >> 3, c0 = 4 * (g & 7);
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = win.w[k];
-        b0 += w * hb[0][ly + k][lx]; b1 += w * hb[1][ly + k][lx]; b2 += w * hb[2][ly + k][lx];
+        for (int m = 0; m < 3; m++) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 a = *reinterpret_cast<const float4 *>(&sm[m][r][c0 + 4 * q]);
+                v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) a += win.w[k] * v[j + k];
+                hb[m][r][c0 + j] = a;
+            }
+        }
     }
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx < W && gy < H) {
-        const size_t o = plane + (size_t)gy * W + gx;
-        const size_t ob = plane + (size_t)gy * W + (W - 1 - gx);
-        float x = img1[o];
-        if (img1b) x = (x + img1b[ob]) / 2.0f;
-        const float y = img2[o];
-        const float g = grads[0] * inv_count, gl = grads[1] * inv_count;
-        const float d = x - y;
-        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        const float v = g * (b0 + 2.f * x * b1 + y * b2) + gl * sgn;
-        if (img1b) {
-            dL_dimg1[o] = 0.5f * v;
-            dL_dimg1b[ob] = 0.5f * v;
-        } else {
-            dL_dimg1[o] = v;
+    __syncthreads();
+    const int lx = tid & 31, gq = tid >> 5;
+    float bl[3][4];
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        float v[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) v[k] = hb[m][4 * gq + k][lx];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) a += win.w[k] * v[j + k];
+            bl[m][j] = a;
+        }
+    }
+    const int gx = x0 + lx;
+    const float g = grads[0] * inv_count, gl = grads[1] * inv_count;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int gy = y0 + 4 * gq + j;
+        if (gx < W && gy < H) {
+            const size_t o = plane + (size_t)gy * W + gx;
+            const size_t ob = plane + (size_t)gy * W + (W - 1 - gx);
+            float x = img1[o];
+            if (img1b) x = (x + img1b[ob]) / 2.0f;
+            const float y = img2[o];
+            const float d = x - y;
+            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            const float v = g * (bl[0][j] + 2.f * x * bl[1][j] + y * bl[2][j]) + gl * sgn;
+            if (img1b) {
+                dL_dimg1[o] = 0.5f * v;
+                dL_dimg1b[ob] = 0.5f * v;
+            } else {
+                dL_dimg1[o] = v;
+            }
         }
     }
 }
