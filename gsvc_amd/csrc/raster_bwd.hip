@@ -435,15 +435,28 @@ __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, co
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
         float a2 = 0.f;
         int jx = 0, tpx = (int)(rx & 0xffff) * TILE, tpy = (int)(ry & 0xffff) * TILE;
-        for (int j = 0; j < n_rows; j++, row += ROW_FLOATS / 4) {
-            const bool hit = bbox_hits_tile(abx, aby, tpx, tpy);     // rows exist only where the box touches the tile (B1)
-            if (++jx == tw) { jx = 0; tpx = (int)(rx & 0xffff) * TILE; tpy += TILE; } else tpx += TILE;
-            if (!hit) continue;
-            const float4 x0 = row[0], x1 = row[1];
-            const float x2 = row[2].x;
-            a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
-            a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
-            a2 += x2;
+        // four rows per round: their loads are issued together, then added in tile order (a load per iteration made the loop one
+        // dependent memory round trip per tile of the rectangle)
+        for (int j = 0; j < n_rows; j += 4, row += 4 * (ROW_FLOATS / 4)) {
+            float4 x0[4], x1[4];
+            float x2[4];
+            bool hit[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                hit[u] = j + u < n_rows && bbox_hits_tile(abx, aby, tpx, tpy);     // rows exist only where the box touches the tile (B1)
+                if (++jx == tw) { jx = 0; tpx = (int)(rx & 0xffff) * TILE; tpy += TILE; } else tpx += TILE;
+                const float4 *r4 = row + u * (ROW_FLOATS / 4);
+                x0[u] = hit[u] ? r4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+                x1[u] = hit[u] ? r4[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                x2[u] = hit[u] ? r4[2].x : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!hit[u]) continue;          // (adding a skipped row's zeros could turn a -0 sum into +0: keep the old sums bit for bit)
+                a0.x += x0[u].x; a0.y += x0[u].y; a0.z += x0[u].z; a0.w += x0[u].w;
+                a1.x += x1[u].x; a1.y += x1[u].y; a1.z += x1[u].z; a1.w += x1[u].w;
+                a2 += x2[u];
+            }
         }
         float du, dv, dA, dB, dC;
         PreOut o;
