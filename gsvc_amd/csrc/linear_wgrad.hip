@@ -314,13 +314,20 @@ __device__ __forceinline__ void wgrad_t_body(const float *__restrict__ G, const 
         __syncthreads();
     }
     float *out = part + (size_t)wg * ((size_t)N * K + (want_db ? N : 0));
+    // the blocks' tile ranges once per workgroup (two integer divisions per ELEMENT of the 64 x 64 blocks were ~1000 instructions
+    // per thread of this epilogue)
+    __shared__ int s_blk[WG_MAX_WAVES][4];      // first output row, rows, first output column, columns of block pr
+    if (tid < pairs) {
+        int f, c, g, e;
+        wg_block_tiles((N + 15) >> 4, BN, tid / BK, f, c);
+        wg_block_tiles((K + 15) >> 4, BK, tid % BK, g, e);
+        s_blk[tid][0] = 16 * f; s_blk[tid][1] = 16 * c; s_blk[tid][2] = 16 * g; s_blk[tid][3] = 16 * e;
+    }
+    __syncthreads();
     for (int i = tid; i < pairs * 4096; i += blockDim.x) {
         const int pr = i >> 12, nl = (i >> 6) & 63, kl = i & 63;
-        int f, c, g, e;
-        wg_block_tiles((N + 15) >> 4, BN, pr / BK, f, c);
-        wg_block_tiles((K + 15) >> 4, BK, pr % BK, g, e);
-        const int n = 16 * f + nl, k = 16 * g + kl;
-        if (nl < 16 * c && kl < 16 * e && n < N && k < K) out[(size_t)n * K + k] = sm[i];
+        const int n = s_blk[pr][0] + nl, k = s_blk[pr][2] + kl;
+        if (nl < s_blk[pr][1] && kl < s_blk[pr][3] && n < N && k < K) out[(size_t)n * K + k] = sm[i];
     }
     if (want_db)
         for (int n = tid; n < N; n += blockDim.x) {
