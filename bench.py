@@ -212,11 +212,16 @@ def run_stream_decode(args, dev, height=2160, width=3840, frames=300, gaussians_
         pass
     del warm
     from gsvc_amd import anchor_codec
-    ta0 = time.perf_counter()
-    geo = anchor_codec.decode_anchors(pack.anchor_stream)        # the anchor geometry (host, NumPy): the reference's tmc3 step
-    anchor_decode_s = time.perf_counter() - ta0
-    assert np.array_equal(geo, pack.anchors_q)
+    anchor_codec.decode_anchors_gpu(pack.anchor_stream, dev)     # warm-up (first-use allocations), as for the streams above
     torch.cuda.synchronize()
+    ta0 = time.perf_counter()
+    geo = anchor_codec.decode_anchors_gpu(pack.anchor_stream, dev)      # the anchor geometry: the reference's tmc3 step
+    torch.cuda.synchronize()
+    anchor_decode_s = time.perf_counter() - ta0
+    assert np.array_equal(geo.cpu().numpy().astype(np.uint16), pack.anchors_q)
+    th0 = time.perf_counter()
+    anchor_codec.decode_anchors(pack.anchor_stream)
+    anchor_host_s = time.perf_counter() - th0
     t2 = time.perf_counter()
     dec = conduct_stream_decoding(target, pack)
     torch.cuda.synchronize()
@@ -235,11 +240,13 @@ def run_stream_decode(args, dev, height=2160, width=3840, frames=300, gaussians_
             "anchors_coded": pack.n, "gaussians_generated_per_frame": vis * K, "slabs": len(pack.slabs),
             "encode_ms": (t1 - t0) * 1e3, "decode_ms": (t3 - t2) * 1e3, "render_ms_per_frame": (t4 - t3) * 1e3 / max(n, 1),
             "stream_decode_fps": n / (t4 - t2), "render_fps_after_decode": n / (t4 - t3),
-            "anchor_geometry_decode_ms": anchor_decode_s * 1e3, "anchor_bits_per_anchor": bits["bit_anchor"] / max(pack.n, 1),
+            "anchor_geometry_decode_ms": anchor_decode_s * 1e3, "anchor_geometry_decode_host_numpy_ms": anchor_host_s * 1e3,
+            "anchor_bits_per_anchor": bits["bit_anchor"] / max(pack.n, 1),
             "stream_decode_fps_incl_anchor_geometry": n / (t4 - t2 + anchor_decode_s),
-            "anchor_geometry_note": "occupancy octree + rANS over the voxel lattice (gsvc_amd/anchor_codec.py, NumPy on the host; the "
-                                    "reference runs the external tmc3 executable here); decode_ms / stream_decode_fps are the attribute, "
-                                    "mask and hash-table streams on the GPU, the _incl_ number adds the geometry decode",
+            "anchor_geometry_note": "occupancy octree + rANS over the voxel lattice (gsvc_amd/anchor_codec.py; the reference runs the "
+                                    "external tmc3 executable here), decoded on the GPU (csrc/anchor.hip: one workgroup per level's "
+                                    "entropy stream, then the expansion level by level); decode_ms / stream_decode_fps are the attribute, "
+                                    "mask and hash-table streams, the _incl_ number adds the geometry decode",
             "megabytes": {k[4:]: round(v / 8 / 2 ** 20, 3) for k, v in bits.items()},
             "render_fps_note": PAIR_NOTE}
 
@@ -445,8 +452,11 @@ def run_train_step(args, rank, world, dev):
         tc3 = time.perf_counter()
         bits = pack.bits()
         from gsvc_amd import anchor_codec
+        anchor_codec.decode_anchors_gpu(pack.anchor_stream, dev)
+        torch.cuda.synchronize()
         ta0 = time.perf_counter()
-        anchor_codec.decode_anchors(pack.anchor_stream)
+        anchor_codec.decode_anchors_gpu(pack.anchor_stream, dev)          # on the GPU (csrc/anchor.hip)
+        torch.cuda.synchronize()
         anchor_decode_s = time.perf_counter() - ta0
         res["stream_codec"] = {"encode_ms": (tc1 - tc0) * 1e3, "decode_ms": (tc2 - tc1) * 1e3, "slabs": len(pack.slabs),
                                "anchor_geometry_decode_ms": anchor_decode_s * 1e3, "anchor_bits_per_anchor": bits["bit_anchor"] / max(pack.n, 1),

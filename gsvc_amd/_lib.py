@@ -48,6 +48,11 @@ class WgradReduceJobC(C.Structure):
                 ("K", C.c_int32)]
 
 
+class AnchorLevelC(C.Structure):
+    _fields_ = [("states", C.c_void_p), ("words", C.c_void_p), ("freq", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64),
+                ("n_words", C.c_int64), ("lanes", C.c_int32)]
+
+
 class WgradPartialJobC(C.Structure):
     _fields_ = [("G", C.c_void_p), ("X", C.c_void_p), ("workspace", C.c_void_p), ("M", C.c_int64), ("workspace_floats", C.c_int64),
                 ("want_db", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("slots_used", C.c_int32)]
@@ -130,6 +135,10 @@ _SIGNATURES = {
                                               _vp, _vp, _vp]),
     "gsvc_rate_normalise_backward": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "gsvc_training_statis": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _i64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_anchor_rans_decode": (C.c_int, [C.POINTER(AnchorLevelC), C.c_int32, _vp, _vp]),
+    "gsvc_octree_popcount": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "gsvc_octree_expand": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "gsvc_morton_decode": (C.c_int, [_vp, _i64, _vp, _vp]),
     "gsvc_q_rows_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i64, _vp, _vp]),
     "gsvc_q_rows_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i64, _i64, _vp, _vp]),
     "gsvc_plan_scans_scratch_bytes": (_i64, [C.c_int32, _i64]),

@@ -325,3 +325,135 @@ def decode_anchors(data: bytes) -> np.ndarray:
     if out.shape[0] != n:
         raise ValueError("anchor_codec: corrupt stream (anchor count)")
     return _lex(out).astype(np.uint16)
+
+
+# ------------------------------------------------------------------------------------------------ decode on the GPU
+def _level_headers(buf: memoryview, at: int, bits: int):
+    """Walks the per-level records without decoding them: [(n, table [n_present, 2], lanes, states view, words view)], end offset."""
+    levels = []
+    for _ in range(bits):
+        n, n_present, lanes, n_words = struct.unpack_from("<IHHI", buf, at)
+        at += 12
+        if lanes < 1 or lanes > MAX_LANES or n_present < 1 or n_present > 256:
+            raise ValueError("anchor_codec: corrupt level header")
+        table = np.frombuffer(buf, dtype="<u2", count=2 * n_present, offset=at).reshape(n_present, 2)
+        at += 4 * n_present
+        states = np.frombuffer(buf, dtype="<u4", count=lanes, offset=at)
+        at += 4 * lanes
+        words = np.frombuffer(buf, dtype="<u2", count=n_words, offset=at)
+        at += 2 * n_words
+        levels.append((int(n), table, int(lanes), states, words))
+    return levels, at
+
+
+def decode_anchors_gpu(data: bytes, device="cuda"):
+    """``decode_anchors`` with the entropy decode and the octree expansion on the GPU (csrc/anchor.hip): returns an int32 CUDA
+    tensor [n, 3] sorted by (x, y, z) — the same values as ``decode_anchors``.  The host only walks the level headers (the
+    symbol counts of all levels are in the stream, so nothing is read back before the end) and stages the streams in one copy."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    buf = memoryview(data)
+    if bytes(buf[:5]) != MAGIC:
+        raise ValueError("anchor_codec: not an anchor stream")
+    mode, n, n_uniq, bits, n_extra = struct.unpack_from("<BQQBI", buf, 5)
+    at = 5 + struct.calcsize("<BQQBI")
+    if mode not in (0, 1) or bits < 1 or bits > 16 or n_uniq > n:
+        raise ValueError("anchor_codec: corrupt header")
+    if mode == 1:
+        n_dup, n_exc, ox, oy, oz, voxel, i0, i1, i2, m0, m1, m2 = struct.unpack_from("<QQ3qd3f3f", buf, at)
+        at += struct.calcsize("<QQ3qd3f3f")
+    extra = zlib.decompress(bytes(buf[at:at + n_extra]))
+    at += n_extra
+    dev = torch.device(device)
+    if n == 0:
+        return torch.zeros(0, 3, dtype=torch.int32, device=dev)
+    levels, _ = _level_headers(buf, at, int(bits))
+    expect = 1
+    for lv in levels:                         # a level has as many symbols as the level above has children: checked on the device
+        if lv[0] < 1 or lv[0] > n_uniq:
+            raise ValueError("anchor_codec: corrupt level header")
+    if levels[0][0] != 1:
+        raise ValueError("anchor_codec: corrupt level header")
+    # one staged blob: per level [freq 256 x u16][states][words], every section 16-byte aligned
+    sections, size = [], 0
+    def put(arr):
+        nonlocal size
+        off = size
+        sections.append((off, arr))
+        size = (off + arr.nbytes + 15) // 16 * 16
+        return off
+    offs = []
+    for n_l, table, lanes, states, words in levels:
+        freq = np.zeros(256, dtype=np.uint16)
+        freq[table[:, 0] & 0xFF] = table[:, 1]
+        if int(freq.astype(np.int64).sum()) != PROB_SCALE:
+            raise ValueError("anchor_codec: corrupt frequency table")
+        offs.append((put(freq), put(np.ascontiguousarray(states)), put(np.ascontiguousarray(words))))
+    blob = np.zeros(max(size, 16), dtype=np.uint8)
+    for off, arr in sections:
+        blob[off:off + arr.nbytes] = arr.view(np.uint8).reshape(-1)
+    st = _lib.current_stream(dev)
+    L = _lib.lib()
+    g = torch.from_numpy(blob).to(dev, non_blocking=False)
+    total_syms = sum(lv[0] for lv in levels)
+    syms = torch.empty(total_syms, dtype=torch.uint8, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    descs = (_lib.AnchorLevelC * len(levels))()
+    sym_at = []
+    pos = 0
+    for d, (n_l, table, lanes, states, words), (o_f, o_s, o_w) in zip(descs, levels, offs):
+        d.freq, d.states, d.words = g.data_ptr() + o_f, g.data_ptr() + o_s, g.data_ptr() + o_w
+        d.out, d.n, d.n_words, d.lanes = syms.data_ptr() + pos, n_l, int(words.size), lanes
+        sym_at.append(pos)
+        pos += n_l
+    _lib.check(L.gsvc_anchor_rans_decode(descs, len(levels), _lib.ptr(err), st), "gsvc_anchor_rans_decode")
+    # expansion, level after level: nodes of level l + 1 = children of level l's nodes
+    nodes = None
+    for li, (n_l, *_rest) in enumerate(levels):
+        occ = syms[sym_at[li]:sym_at[li] + n_l]
+        nxt = levels[li + 1][0] if li + 1 < len(levels) else int(n_uniq)
+        cnt = torch.empty(n_l, dtype=torch.int64, device=dev)
+        _lib.check(L.gsvc_octree_popcount(_lib.ptr(occ), n_l, _lib.ptr(cnt), st), "gsvc_octree_popcount")
+        incl = torch.cumsum(cnt, dim=0)
+        out = torch.full((nxt,), -1, dtype=torch.int64, device=dev)
+        _lib.check(L.gsvc_octree_expand(_lib.ptr(nodes), _lib.ptr(occ), _lib.ptr(incl), n_l, nxt, _lib.ptr(out), _lib.ptr(err), st),
+                   "gsvc_octree_expand")
+        # the children must fill the next level exactly
+        err.bitwise_or_((incl[-1:] != nxt).to(torch.int32) * 16)
+        nodes = out
+    pts = torch.empty(int(n_uniq), 3, dtype=torch.int64, device=dev)
+    _lib.check(L.gsvc_morton_decode(_lib.ptr(nodes), int(n_uniq), _lib.ptr(pts), st), "gsvc_morton_decode")
+    code = int(err.item())                     # the one read-back
+    if code:
+        raise ValueError(f"anchor_codec: corrupt stream (device decode error {code})")
+
+    def lex(p):
+        key = torch.sort((p[:, 0] << 40) | (p[:, 1] << 20) | p[:, 2]).values
+        m = (1 << 20) - 1
+        return torch.stack([key >> 40, (key >> 20) & m, key & m], dim=1)
+
+    def with_multiplicity(p, dup):
+        if dup.size == 0:
+            return p
+        p = lex(p)                             # multiplicities are indexed in np.unique's (lexicographic) order
+        rep = torch.ones(p.shape[0], dtype=torch.int64, device=dev)
+        rep[torch.from_numpy(dup[:, 0].copy()).to(dev)] = torch.from_numpy(dup[:, 1].copy()).to(dev)
+        return torch.repeat_interleave(p, rep, dim=0)
+
+    if mode == 0:
+        dup = np.frombuffer(extra, dtype="<i8").reshape(-1, 2)
+        out = with_multiplicity(pts, dup)
+    else:
+        dup = np.frombuffer(extra, dtype="<i8", count=2 * n_dup).reshape(-1, 2)
+        exc = np.frombuffer(extra, dtype="<u2", offset=16 * n_dup, count=3 * n_exc).reshape(-1, 3).astype(np.int64)
+        idx = with_multiplicity(pts, dup) + torch.tensor([ox, oy, oz], dtype=torch.int64, device=dev)
+        # Quantize_anchor's grid value of the lattice point, in the float32 arithmetic of _grid_of
+        a = (idx.to(torch.float64) * float(voxel)).to(torch.float32)
+        a_min = torch.tensor([m0, m1, m2], dtype=torch.float32, device=dev)
+        interval = torch.tensor([i0, i1, i2], dtype=torch.float32, device=dev)
+        q = torch.floor((a - a_min) / interval).clamp_(0, 65535).to(torch.int64)
+        out = torch.cat([q, torch.from_numpy(exc).to(dev)]) if n_exc else q
+    if out.shape[0] != n:
+        raise ValueError("anchor_codec: corrupt stream (anchor count)")
+    return lex(out).to(torch.int32)

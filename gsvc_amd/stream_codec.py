@@ -141,7 +141,11 @@ class StreamPack:
         meta["slabs"] = [tuple(s) for s in meta["slabs"]]
         rd = lambda name: open(os.path.join(path, name), "rb").read()  # noqa: E731
         stream = rd("anchor.b")
-        pack = cls(anchors_q=anchor_codec.decode_anchors(stream), anchor_stream=stream, **meta)
+        if torch.cuda.is_available():      # entropy decode + octree expansion on the GPU (csrc/anchor.hip)
+            anchors_q = anchor_codec.decode_anchors_gpu(stream).cpu().numpy().astype(np.uint16)
+        else:
+            anchors_q = anchor_codec.decode_anchors(stream)
+        pack = cls(anchors_q=anchors_q, anchor_stream=stream, **meta)
         for s in range(len(pack.slabs)):
             pack.feat.append(rd(f"feat_{s}.b")); pack.scaling.append(rd(f"scaling_{s}.b")); pack.offsets.append(rd(f"offsets_{s}.b"))
         pack.masks, pack.hash = rd("masks.b"), rd("hash.b")

@@ -665,6 +665,29 @@ int gsvc_deform_backward(const gsvc_deform_net *net, const float *feat, const fl
                          float *scratch, float *gfeat, int32_t accumulate_gfeat, const float *const *gfeat_addends, int32_t n_addends,
                          const gsvc_deform_grads *grads, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Anchor geometry decode (the G-PCC tmc3 step of reference utils/encodings.py:780-826 decode_anchor; coder and bitstream are this
+ * library's own: gsvc_amd/anchor_codec.py).  An occupancy octree over the integer anchor lattice, one 8-bit mask per node,
+ * per level a static 12-bit model and an interleaved rANS stream (32-bit states, 16-bit words, symbol i in lane i % lanes).
+ * gsvc_anchor_rans_decode: all levels' symbols in one launch (one workgroup per level); error: OR of 1 bad table, 2 truncated,
+ * 4 the coder did not return to its initial state.  gsvc_octree_popcount / _expand: a level's masks -> the next level's nodes
+ * (Morton keys; counts_inclusive_scan = inclusive scan of the popcounts; error |= 8 on an empty mask or more than `capacity`
+ * children).  gsvc_morton_decode: keys (x at bit 3 b + 2, y at 3 b + 1, z at 3 b) -> xyz [n, 3].
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct gsvc_anchor_level {
+    const uint32_t *states;     /* [lanes] */
+    const uint16_t *words;      /* [n_words] */
+    const uint16_t *freq;       /* [256], sum 4096 */
+    uint8_t *out;               /* [n] decoded masks */
+    int64_t n, n_words;
+    int32_t lanes;
+} gsvc_anchor_level;
+int gsvc_anchor_rans_decode(const gsvc_anchor_level *levels_host, int32_t n_levels, int32_t *error, void *stream);
+int gsvc_octree_popcount(const uint8_t *occ, int64_t n, int64_t *counts, void *stream);
+int gsvc_octree_expand(const int64_t *nodes, const uint8_t *occ, const int64_t *counts_inclusive_scan, int64_t n, int64_t capacity,
+                       int64_t *nodes_out, int32_t *error, void *stream);
+int gsvc_morton_decode(const int64_t *keys, int64_t n, int64_t *xyz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

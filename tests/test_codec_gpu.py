@@ -264,3 +264,53 @@ def copy_of_decoded(pc, pack):
     ref = copy.deepcopy(pc)
     conduct_stream_decoding(ref, pack)
     return ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 2, 777, 50_000, 1_200_000])
+def test_anchor_geometry_decodes_on_the_gpu_grid_mode(n):
+    """decode_anchors_gpu (csrc/anchor.hip: every level's interleaved rANS stream by one workgroup, octree expansion level by level)
+    returns exactly what the host decoder returns: 16-bit grid mode with duplicates, one lane up to the 16 384-lane cap."""
+    from gsvc_amd import anchor_codec as ac
+    rng = np.random.default_rng(n)
+    q = rng.integers(0, 65536, (n, 3)).astype(np.uint16)
+    if n > 10:
+        q[5] = q[3]; q[6] = q[3]; q[-1] = q[0]
+    if n > 100_000:
+        q[:, 2] = rng.integers(30000, 30512, n)                 # a thin slab: many full upper levels
+    data = ac.encode_anchors(q)
+    got = ac.decode_anchors_gpu(data)
+    want = ac.decode_anchors(data)
+    assert got.dtype == torch.int32 and got.is_cuda and got.shape == (n, 3)
+    assert np.array_equal(got.cpu().numpy().astype(np.uint16), want)
+
+
+@pytest.mark.gpu
+def test_anchor_geometry_decodes_on_the_gpu_lattice_mode_and_refuses_corrupt_streams():
+    from gsvc_amd import anchor_codec as ac
+    rng = np.random.default_rng(7)
+    voxel = 0.001
+    lo, hi = np.array([-1.1, -0.62, -0.0367]), np.array([1.1, 0.62, 0.0367])
+    idx = np.unique(np.round(rng.uniform(lo, hi, (300_000, 3)) / voxel), axis=0)
+    idx = np.concatenate([idx, idx[:40]])                       # anchors that share a lattice point
+    pos = (idx * voxel).astype(np.float32)
+    a_min, a_max = pos.min(axis=0), pos.max(axis=0)
+    interval = ((a_max - a_min) / 65536.0 + 1e-6).astype(np.float32)
+    q = np.clip(np.floor((pos - a_min) / interval), 0, 65535).astype(np.uint16)
+    pos[100:150] += np.float32(0.00037)                         # exceptions: not lattice points
+    q[100:150] = np.clip(np.floor((pos[100:150] - a_min) / interval), 0, 65535).astype(np.uint16)
+    data = ac.encode_anchors(q, positions=pos, voxel_size=voxel, interval=interval, a_min=a_min)
+    assert data[5] == 1
+    want = ac.decode_anchors(data)
+    got = ac.decode_anchors_gpu(data)
+    assert np.array_equal(got.cpu().numpy().astype(np.uint16), want)
+    # a flipped bit in the entropy streams either fails a device-side check or changes the points; a cut stream is refused
+    with pytest.raises(ValueError):
+        ac.decode_anchors_gpu(data[:len(data) // 2])
+    bad = bytearray(data)
+    bad[-len(data) // 3] ^= 0x10
+    try:
+        out = ac.decode_anchors_gpu(bytes(bad))
+        assert not np.array_equal(out.cpu().numpy().astype(np.uint16), want)
+    except ValueError:
+        pass
