@@ -219,6 +219,7 @@ def run_stream_decode(args, dev, height=2160, width=3840, frames=300, gaussians_
     torch.cuda.synchronize()
     anchor_decode_s = time.perf_counter() - ta0
     assert np.array_equal(geo.cpu().numpy().astype(np.uint16), pack.anchors_q)
+    pack.anchors_q_dev = geo            # the attribute decode below starts from the decoded geometry where it is: on the device
     th0 = time.perf_counter()
     anchor_codec.decode_anchors(pack.anchor_stream)
     anchor_host_s = time.perf_counter() - th0

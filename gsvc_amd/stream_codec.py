@@ -105,6 +105,7 @@ class StreamPack:
     hash: bytes = b""
     bit_mlp_encoded: int = None              # size of the MLP file written beside the streams (not part of meta.json)
     anchor_stream: bytes = b""               # gsvc_amd.anchor_codec: occupancy octree + rANS of the anchor geometry
+    anchors_q_dev: object = None             # the decoded geometry as a device tensor (decode_anchors_gpu): spares the decoder an upload
 
     def bits(self):
         """Coded size per stream in bits (same keys as BitInfo where they exist)."""
@@ -141,11 +142,13 @@ class StreamPack:
         meta["slabs"] = [tuple(s) for s in meta["slabs"]]
         rd = lambda name: open(os.path.join(path, name), "rb").read()  # noqa: E731
         stream = rd("anchor.b")
+        dev_q = None
         if torch.cuda.is_available():      # entropy decode + octree expansion on the GPU (csrc/anchor.hip)
-            anchors_q = anchor_codec.decode_anchors_gpu(stream).cpu().numpy().astype(np.uint16)
+            dev_q = anchor_codec.decode_anchors_gpu(stream)
+            anchors_q = dev_q.cpu().numpy().astype(np.uint16)
         else:
             anchors_q = anchor_codec.decode_anchors(stream)
-        pack = cls(anchors_q=anchors_q, anchor_stream=stream, **meta)
+        pack = cls(anchors_q=anchors_q, anchor_stream=stream, anchors_q_dev=dev_q, **meta)
         for s in range(len(pack.slabs)):
             pack.feat.append(rd(f"feat_{s}.b")); pack.scaling.append(rd(f"scaling_{s}.b")); pack.offsets.append(rd(f"offsets_{s}.b"))
         pack.masks, pack.hash = rd("masks.b"), rd("hash.b")
@@ -237,7 +240,10 @@ def conduct_stream_decoding(pc, pack: StreamPack, mlp_file=None):
         sd = pc.state_dict()
         for k, v in mlp_codec.decode_mlp(mlp_file).items():
             sd[k].copy_(v.to(sd[k].device))
-    q = torch.from_numpy(pack.anchors_q.astype(np.float32)).to(dev)
+    if pack.anchors_q_dev is not None and pack.anchors_q_dev.device == dev:
+        q = pack.anchors_q_dev.to(torch.float32)
+    else:
+        q = torch.from_numpy(pack.anchors_q.astype(np.float32)).to(dev)
     anchor = Quantize_anchor.dequantized(q, torch.from_numpy(pack.anchor_interval).to(dev), torch.from_numpy(pack.anchor_min).to(dev))
     z_order, slabs = reorder_and_split(anchor)
     if list(slabs) != [tuple(s) for s in pack.slabs]:
