@@ -205,6 +205,10 @@ _SIGNATURES = {
     "gsvc_deform_forward": (C.c_int, [C.POINTER(DeformNetC), _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsvc_deform_backward": (C.c_int, [C.POINTER(DeformNetC), _vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
                                        C.POINTER(DeformGradsC), _vp]),
+    "gsvc_generator_inference_floats": (_i64, [C.POINTER(GeneratorNetC), _i64, _i64]),
+    "gsvc_generators_forward_inference": (C.c_int, [C.POINTER(GeneratorNetC), C.c_int32, _vp, _vp, _i64, C.POINTER(FilmRowsC), C.POINTER(C.c_void_p),
+                                                    C.POINTER(C.c_void_p), _vp]),
+    "gsvc_deform_forward_inference": (C.c_int, [C.POINTER(DeformNetC), _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsvc_generators_forward": (C.c_int, [C.POINTER(GeneratorNetC), C.c_int32, _vp, _vp, _i64, C.POINTER(FilmRowsC), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), _vp]),
     "gsvc_generators_backward": (C.c_int, [C.POINTER(GeneratorNetC), C.c_int32, _vp, _vp, _i64, C.POINTER(FilmRowsC), C.POINTER(C.c_void_p),

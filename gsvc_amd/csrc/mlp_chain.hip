@@ -348,7 +348,7 @@ __device__ __forceinline__ void film_fwd_body(int blk, int nblk, const float *__
                 load_frags<COND>(c, cond, rb + stride, RB, M, L);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const Tiles<COND> th(net ? cb : cg, rb, RB, M, L);
+            const Tiles<COND> th(net ? cb : cg, (net ? cb : cg) ? rb : RB, RB, M, L);      // NULL (inference): an empty descriptor drops the stores
 #pragma unroll
             for (int t = 0; t < S::NT0; t++) {
                 hid[t] = v_relu(hid[t]);
@@ -512,7 +512,7 @@ __device__ __forceinline__ void trunk_fwd_body(int blk, int nblk, const float *_
         load_frags<FEAT>(f, feat, rb + stride, RB, M, L);
         __builtin_amdgcn_sched_barrier(0);
         {
-            const Tiles<HID> tz(z1, rb, RB, M, L), ta(a1, rb, RB, M, L);
+            const Tiles<HID> tz(z1, z1 ? rb : RB, RB, M, L), ta(a1, a1 ? rb : RB, RB, M, L);      // NULL (inference): stores dropped
 #pragma unroll
             for (int t = 0; t < S::NTH; t++) {
                 tz.store(t, u[t]);
@@ -524,7 +524,7 @@ __device__ __forceinline__ void trunk_fwd_body(int blk, int nblk, const float *_
         init_bias(v, sb2, L);
         chain_mm<HID, S::NTH, S::LD2>(v, u, lds + S::o_w2, L);
         {
-            const Tiles<HID> th(h, rb, RB, M, L), tx(x3, rb, RB, M, L);
+            const Tiles<HID> th(h, h ? rb : RB, RB, M, L), tx(x3, x3 ? rb : RB, RB, M, L);
 #pragma unroll
             for (int t = 0; t < S::NTH; t++) {
                 th.store(t, v[t]);
@@ -793,7 +793,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_deform_a_fwd(const float *__r
         load_frags<COND>(c, cond, rb + stride, RB, M, L);
         __builtin_amdgcn_sched_barrier(0);
         {
-            const Tiles<HID> tz(z1, rb, RB, M, L), ta(a1, rb, RB, M, L);
+            const Tiles<HID> tz(z1, z1 ? rb : RB, RB, M, L), ta(a1, a1 ? rb : RB, RB, M, L);      // NULL (inference): stores dropped
 #pragma unroll
             for (int t = 0; t < S::NTH; t++) {
                 tz.store(t, u[t]);
@@ -804,7 +804,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_deform_a_fwd(const float *__r
         v4f v[S::NTH];
         init_bias(v, sb2, L);
         chain_mm<HID, S::NTH, S::LD2>(v, u, lds + S::o_w2, L);
-        const Tiles<HID> tz(z2, rb, RB, M, L), ta(a2, rb, RB, M, L);
+        const Tiles<HID> tz(z2, z2 ? rb : RB, RB, M, L), ta(a2, rb, RB, M, L);
 #pragma unroll
         for (int t = 0; t < S::NTH; t++) {
             tz.store(t, v[t]);
@@ -849,7 +849,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_deform_b_fwd(const float *__r
         load_frags<HID>(x, a2, rb + stride, RB, M, L);      // the next block's rows travel during the rest of this one
         __builtin_amdgcn_sched_barrier(0);
         {
-            const Tiles<HID> tz(z3, rb, RB, M, L), ta(a3, rb, RB, M, L);
+            const Tiles<HID> tz(z3, z3 ? rb : RB, RB, M, L), ta(a3, a3 ? rb : RB, RB, M, L);      // NULL (inference): stores dropped
 #pragma unroll
             for (int t = 0; t < S::NTH; t++) {
                 tz.store(t, u[t]);
@@ -861,7 +861,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_deform_b_fwd(const float *__r
         init_bias(v, sb4, L);
         chain_mm<HID, S::NTH, S::LD>(v, u, lds + S::o_w4, L);
         {
-            const Tiles<HID> tz(z4, rb, RB, M, L), ta(a4, rb, RB, M, L);
+            const Tiles<HID> tz(z4, z4 ? rb : RB, RB, M, L), ta(a4, a4 ? rb : RB, RB, M, L);
 #pragma unroll
             for (int t = 0; t < S::NTH; t++) {
                 tz.store(t, v[t]);
@@ -1055,10 +1055,15 @@ inline float *take(float *&cur, long long count)
 // z1, a1, h, x3 [HID]; beta (a forward intermediate) lives behind them
 struct GenSaved {
     float *cg, *cb, *gamma, *z1, *a1, *h, *x3, *beta;
-    GenSaved(float *base, long long M, long long Mf)      // Mf: rows of the FiLM networks (= M unless the views share them)
+    GenSaved(float *base, long long M, long long Mf, bool inference = false)      // Mf: rows of the FiLM networks (= M unless the views share them)
     {
         float *cur = base;
-        gamma = take(cur, Mf * HID); beta = take(cur, Mf * HID); cg = take(cur, Mf * COND); cb = take(cur, Mf * COND);
+        gamma = take(cur, Mf * HID); beta = take(cur, Mf * HID);
+        if (inference) {       // forward only: gamma / beta travel from the FiLM kernel to the trunk kernel, nothing else is kept
+            cg = cb = z1 = a1 = h = x3 = nullptr;
+            return;
+        }
+        cg = take(cur, Mf * COND); cb = take(cur, Mf * COND);
         z1 = take(cur, M * HID); a1 = take(cur, M * HID); h = take(cur, M * HID); x3 = take(cur, M * HID);
     }
 };
@@ -1102,7 +1107,7 @@ struct FilmRows {      // resolved gsvc_film_rows (rows == M and NULL maps when 
 };
 
 int generators_forward(const gsvc_generator_net *nets, int n, const float *feat, const float *cond, long long M, const gsvc_film_rows *film,
-                       float *const *saved, float *const *y, hipStream_t s)
+                       float *const *saved, float *const *y, hipStream_t s, bool inference = false)
 {
     const FilmRows fr(film, M, cond);
     FilmFwdBatch fb;
@@ -1112,7 +1117,7 @@ int generators_forward(const gsvc_generator_net *nets, int n, const float *feat,
     tb.film_rows = fr.rows;
     for (int i = 0; i < MAX_NETS; i++) {
         const gsvc_generator_net &g = nets[i < n ? i : 0];
-        const GenSaved sv(saved[i < n ? i : 0], M, fr.rows);
+        const GenSaved sv(saved[i < n ? i : 0], M, fr.rows, inference);
         fb.w[i] = FilmW{g.Wg0, g.bg0, g.Wg1, g.bg1, g.Wb0, g.bb0, g.Wb1, g.bb1};
         fb.cg[i] = sv.cg; fb.cb[i] = sv.cb; fb.gamma[i] = sv.gamma; fb.beta[i] = sv.beta;
         tb.out[i] = g.out_dim; tb.act[i] = g.out_act;
@@ -1265,6 +1270,27 @@ extern "C" int gsvc_generators_forward(const gsvc_generator_net *nets, int32_t n
     return generators_forward(nets, n_nets, feat, cond, M, film, saved, y, (hipStream_t)stream);
 }
 
+extern "C" int64_t gsvc_generator_inference_floats(const gsvc_generator_net *n, int64_t M, int64_t film_rows)
+{
+    if (!n || M < 0 || film_rows < 0) return -1;
+    return 2 * (int64_t)HID * (film_rows > 0 ? film_rows : M) + 64;
+}
+
+// forward only: nothing the backward would read is written (the trunk of a generator stores four [M, 100] activations per
+// network for it: 60 % of the forward's traffic)
+extern "C" int gsvc_generators_forward_inference(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
+                                                 const gsvc_film_rows *film, float *const *scratch, float *const *y, void *stream)
+{
+    if (int rc = gens_supported(nets, n_nets, "generators_forward_inference")) return rc;
+    GSVC_REQUIRE(M >= 0, "generators_forward_inference: bad row count");
+    if (M == 0) return GSVC_OK;
+    GSVC_REQUIRE(feat && cond && scratch && y && aligned16({feat, cond}), "generators_forward_inference: NULL or unaligned pointer");
+    if (int rc = film_rows_ok(film, M, "generators_forward_inference")) return rc;
+    for (int i = 0; i < n_nets; i++)
+        GSVC_REQUIRE(scratch[i] && y[i] && aligned16({scratch[i], y[i]}), "generators_forward_inference: NULL or unaligned pointer (network %d)", i);
+    return generators_forward(nets, n_nets, feat, cond, M, film, scratch, y, (hipStream_t)stream, true);
+}
+
 extern "C" int gsvc_generators_backward(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
                                         const gsvc_film_rows *film, const float *const *saved, const float *const *y,
                                         const float *const *gy, float *scratch, float *const *gfeat, const gsvc_generator_grads *grads,
@@ -1344,6 +1370,25 @@ extern "C" int gsvc_deform_forward(const gsvc_deform_net *n, const float *feat, 
     chain_launch("k_deform_b_fwd", &k_deform_b_fwd<HID, DEF_OUT, CHAIN_T>, DeformBLds<HID, DEF_OUT>::FLOATS * 4, M, 1, s,
                  a2, w, z3, a3, z4, a4, y, M);
     return check_launch("deform_forward");
+}
+
+// forward only: scratch = HID * M floats (the activation that travels from the first kernel to the second)
+extern "C" int gsvc_deform_forward_inference(const gsvc_deform_net *n, const float *feat, const float *cond, int64_t M, float *scratch, float *y,
+                                             void *stream)
+{
+    if (int rc = deform_supported(n, "deform_forward_inference")) return rc;
+    GSVC_REQUIRE(M >= 0, "deform_forward_inference: bad row count");
+    if (M == 0) return GSVC_OK;
+    GSVC_REQUIRE(feat && cond && scratch && y && aligned16({feat, cond, scratch, y}), "deform_forward_inference: NULL or unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    DeformW w;
+    for (int i = 0; i < 5; i++) { w.W[i] = n->W[i]; w.b[i] = n->b[i]; }
+    float *none = nullptr;
+    chain_launch("k_deform_a_fwd", &k_deform_a_fwd<FEAT, COND, HID, CHAIN_T>, DeformALds<FEAT, COND, HID>::FLOATS * 4, M, 1, s, feat, cond, w, none, none,
+                 none, scratch, M);
+    chain_launch("k_deform_b_fwd", &k_deform_b_fwd<HID, DEF_OUT, CHAIN_T>, DeformBLds<HID, DEF_OUT>::FLOATS * 4, M, 1, s,
+                 (const float *)scratch, w, none, none, none, none, y, M);
+    return check_launch("deform_forward_inference");
 }
 
 extern "C" int gsvc_deform_backward(const gsvc_deform_net *n, const float *feat, const float *cond, int64_t M, const float *saved,

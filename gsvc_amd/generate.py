@@ -1005,9 +1005,14 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     gens = [getattr(pc, n) for n in ("get_opacity_mlp", "get_color_mlp", "get_cov_mlp")]
     deform_mods = list(pc.get_deform_mlp) if isinstance(pc.get_deform_mlp, torch.nn.Sequential) else []
     deform_linears = deform_mods[0::2]
-    chain = (trunks is None and all(hasattr(g, "film") and hasattr(g, "out_linear") for g in gens)
+    # (decoding hands in the cached feature-only half of the generators: with the production widths the forward-only chain kernels,
+    # which read the features once and keep a row block in registers through all layers, are faster per frame and are preferred)
+    chain = ((trunks is None or (not torch.is_grad_enabled() and not os.environ.get("GSVC_NO_DECODE_CHAIN")))
+             and all(hasattr(g, "film") and hasattr(g, "out_linear") for g in gens)
              and all(isinstance(m, torch.nn.Linear) for m in deform_linears) and all(isinstance(m, torch.nn.GELU) for m in deform_mods[1::2])
              and _mlp.chain_usable(feat, pe, gens, deform_linears))
+    if chain:
+        trunks = None
     if trunks is None and not chain:
         with region('gen.film'):
             for name in ("get_opacity_mlp", "get_color_mlp", "get_cov_mlp"):

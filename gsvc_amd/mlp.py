@@ -519,4 +519,35 @@ def generate_all(gens, deform_linears, feat, cond, film=None):
     if film is not None:
         film = tuple(t.contiguous() for t in film)
         assert film[0].dtype == torch.float32 and all(t.dtype == torch.int32 for t in film[1:])
-    return _GenerateAll.apply(feat, cond, tuple(_act_code(n) for n in gens), film, *params)
+    acts = tuple(_act_code(n) for n in gens)
+    if not torch.is_grad_enabled():
+        return _generate_all_inference(feat, cond, acts, film, params)
+    return _GenerateAll.apply(feat, cond, acts, film, *params)
+
+
+def _generate_all_inference(feat, cond, acts, film, params):
+    """generate_all without autograd (the decoder's render loop, evaluation): the chain kernels leave out every store only a
+    backward would read (gsvc_generators_forward_inference, gsvc_deform_forward_inference)."""
+    import ctypes as C
+    feat, cond = feat.contiguous(), cond.contiguous()
+    params = [p.detach().contiguous() for p in params]
+    M, dev = feat.shape[0], feat.device
+    L, st = _lib.lib(), _lib.current_stream(dev)
+    nets = (_lib.GeneratorNetC * 3)()
+    outs, scratch = [], []
+    Mf = int(film[0].shape[0]) if film is not None else 0
+    for g in range(3):
+        pg = params[14 * g:14 * (g + 1)]
+        d = _gen_desc(pg, acts[g], pg[4].shape[0])
+        C.memmove(C.byref(nets[g]), C.byref(d), C.sizeof(d))
+        scratch.append(torch.empty(int(L.gsvc_generator_inference_floats(C.byref(d), M, Mf)), device=dev, dtype=torch.float32))
+        outs.append(torch.empty(M, pg[4].shape[0], device=dev, dtype=torch.float32))
+    _lib.check(L.gsvc_generators_forward_inference(nets, 3, _lib.ptr(feat), _lib.ptr(cond), M, _film_desc(film), _ptr_array(scratch),
+                                                   _ptr_array(outs), st), "gsvc_generators_forward_inference")
+    dd = _deform_desc(params[42:52])
+    sc = torch.empty(max(M, 1) * 100, device=dev, dtype=torch.float32)
+    y = torch.empty(M, 30, device=dev, dtype=torch.float32)
+    _lib.check(L.gsvc_deform_forward_inference(C.byref(dd), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(sc), _lib.ptr(y), st),
+               "gsvc_deform_forward_inference")
+    outs.append(y)
+    return tuple(outs)

@@ -4,6 +4,8 @@ Same signature and RenderResults fields as reference ortho_gaussian_renderer/ren
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ..common.base import RenderResults

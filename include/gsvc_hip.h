@@ -643,6 +643,11 @@ int gsvc_generator_forward(const gsvc_generator_net *net, const float *feat, con
                            void *stream);
 int gsvc_generators_forward(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
                             const gsvc_film_rows *film, float *const *saved, float *const *y, void *stream);
+/* Forward only (the decoder's render loop, evaluation): the same kernels with every store the backward alone would read left out.
+ * scratch[i]: gsvc_generator_inference_floats(net, M, film_rows) floats (gamma / beta of the FiLM networks); deform: HID M floats. */
+int64_t gsvc_generator_inference_floats(const gsvc_generator_net *net, int64_t M, int64_t film_rows);
+int gsvc_generators_forward_inference(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
+                                      const gsvc_film_rows *film, float *const *scratch, float *const *y, void *stream);
 int gsvc_generators_backward(const gsvc_generator_net *nets, int32_t n_nets, const float *feat, const float *cond, int64_t M,
                              const gsvc_film_rows *film, const float *const *saved, const float *const *y, const float *const *gy,
                              float *scratch, float *const *gfeat, const gsvc_generator_grads *grads, void *stream);
@@ -661,6 +666,8 @@ int64_t gsvc_deform_saved_floats(const gsvc_deform_net *net, int64_t M);
 int64_t gsvc_deform_scratch_floats(const gsvc_deform_net *net, int64_t M);
 int gsvc_deform_forward(const gsvc_deform_net *net, const float *feat, const float *cond, int64_t M, float *saved, float *y, void *stream);
 /* gfeat_addends: n_addends (0 .. 3) further [M, feat] gradients summed into gfeat in the same pass (the generators' feature gradients) */
+int gsvc_deform_forward_inference(const gsvc_deform_net *net, const float *feat, const float *cond, int64_t M, float *scratch, float *y,
+                                  void *stream);
 int gsvc_deform_backward(const gsvc_deform_net *net, const float *feat, const float *cond, int64_t M, const float *saved, const float *gy,
                          float *scratch, float *gfeat, int32_t accumulate_gfeat, const float *const *gfeat_addends, int32_t n_addends,
                          const gsvc_deform_grads *grads, void *stream);

@@ -268,6 +268,11 @@ def test_whole_network_chain_kernels_match_torch(M, share):
     sum((o * g).sum() for o, g in zip(outs2, gs)).backward()
     for a, b in zip(got, [feat.grad] + [p.grad for p in params]):
         assert torch.equal(a, b)
+    # forward only (decoder / evaluation): the same kernels without the stores a backward reads — the same numbers bit for bit
+    with torch.no_grad():
+        outs3 = mlp.generate_all(gens, lin, feat, cond, film=film)
+    for o, r in zip(outs3, outs):
+        assert o.grad_fn is None and torch.equal(o, r.detach())
     # widths without an instantiation are refused by the C-ABI (callers keep the layer path)
     import ctypes as C
     from gsvc_amd import _lib
