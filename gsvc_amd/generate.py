@@ -954,12 +954,26 @@ def _film_rows(pc, frames, plan, vis, seg, anchor_all):
     return cond_film, row_of, src_a, src_b
 
 
+class _LazyTrunks(dict):
+    """``generator_trunks`` evaluated on first access: a decoder loop whose generation takes the whole-network chain kernels
+    never reads them (three GEMM passes over ALL anchors saved per call)."""
+
+    def __init__(self, pc):
+        super().__init__()
+        self._pc = pc
+
+    def __missing__(self, key):
+        with torch.no_grad():
+            for name in ("get_opacity_mlp", "get_color_mlp", "get_cov_mlp"):
+                dict.__setitem__(self, name, getattr(self._pc, name).trunk(self._pc._anchor_feat))
+        return dict.__getitem__(self, key)
+
+
 def generator_trunks(pc):
     """Frame-independent half of the three generator MLPs for ALL anchors: ``linear2(GELU(linear1(anchor_feat)))``
     (reference scene/gaussian_model.py:168-196 evaluates it per render).  Valid while the parameters do not change and
-    the generation mode leaves the features as stored (decoding): the decoder loop computes it once per video."""
-    with torch.no_grad():
-        return {name: getattr(pc, name).trunk(pc._anchor_feat) for name in ("get_opacity_mlp", "get_color_mlp", "get_cov_mlp")}
+    the generation mode leaves the features as stored (decoding): the decoder loop computes it once per video — on first use."""
+    return _LazyTrunks(pc)
 
 
 def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False,
