@@ -725,6 +725,8 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
                                                     const gsvc_raster_counters *__restrict__ counters, int id_shift)
 {
     __shared__ uint64_t s_all[4 * SORT_WAVE_MAX];   // 32 KiB: one 8-KiB strip per wave
+    __shared__ __attribute__((aligned(16))) uint32_t s_dep[4][SORT_RANK_MAX];      // rank sort: the keys' depth words
+    __shared__ uint16_t s_chk[4][SORT_RANK_MAX];                                   // rank sort: who claimed rank r
     const int overflow = counters->overflow;   // loaded together with the segment bounds (one scalar round trip, not two)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -761,16 +763,57 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
                 if (gslot) row[q] = row_of_instance(f2, rec[3], tx, ty);
             }
         }
+        // Rank = number of smaller keys.  First by the DEPTH word alone (32-bit compares, four staged depths per 16-byte LDS read:
+        // a 64-bit compare costs several times a 32-bit one, and its result cannot be consumed by the next instruction); the
+        // ranks are then checked for uniqueness through LDS — equal depths (the only way two entries can share a rank) are rare,
+        // and a tile that has them takes the 64-bit loop, which breaks ties by the Gaussian's index exactly as the key says.
+        uint32_t *sd = s_dep[wave];
+        uint16_t *chk = s_chk[wave];
+        uint32_t d4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            d4[q] = (uint32_t)(k[q] >> 32);
+            sd[lane + 64 * q] = lane + 64 * q < n ? d4[q] : 0xffffffffu;      // padding never counts as smaller
+        }
         sort_sync<true>();
         int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        const int n4 = (n + 3) & ~3;
         if (n <= 64) {
-            for (int j = 0; j < n; j++) r0 += s[j] < k[0];
+            for (int j = 0; j < n4; j += 4) {
+                const uint4 dj = *reinterpret_cast<const uint4 *>(sd + j);
+                r0 += (dj.x < d4[0]) + (dj.y < d4[0]) + (dj.z < d4[0]) + (dj.w < d4[0]);
+            }
         } else if (n <= 128) {
-            for (int j = 0; j < n; j++) { const uint64_t kj = s[j]; r0 += kj < k[0]; r1 += kj < k[1]; }
+            for (int j = 0; j < n4; j += 4) {
+                const uint4 dj = *reinterpret_cast<const uint4 *>(sd + j);
+                r0 += (dj.x < d4[0]) + (dj.y < d4[0]) + (dj.z < d4[0]) + (dj.w < d4[0]);
+                r1 += (dj.x < d4[1]) + (dj.y < d4[1]) + (dj.z < d4[1]) + (dj.w < d4[1]);
+            }
         } else {
-            for (int j = 0; j < n; j++) {
-                const uint64_t kj = s[j];
-                r0 += kj < k[0]; r1 += kj < k[1]; r2 += kj < k[2]; r3 += kj < k[3];
+            for (int j = 0; j < n4; j += 4) {
+                const uint4 dj = *reinterpret_cast<const uint4 *>(sd + j);
+                r0 += (dj.x < d4[0]) + (dj.y < d4[0]) + (dj.z < d4[0]) + (dj.w < d4[0]);
+                r1 += (dj.x < d4[1]) + (dj.y < d4[1]) + (dj.z < d4[1]) + (dj.w < d4[1]);
+                r2 += (dj.x < d4[2]) + (dj.y < d4[2]) + (dj.z < d4[2]) + (dj.w < d4[2]);
+                r3 += (dj.x < d4[3]) + (dj.y < d4[3]) + (dj.z < d4[3]) + (dj.w < d4[3]);
+            }
+        }
+        {
+            const int rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (lane + 64 * q < n) chk[rr[q]] = (uint16_t)(lane + 64 * q);
+            sort_sync<true>();
+            bool clash = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (lane + 64 * q < n) clash |= chk[rr[q]] != (uint16_t)(lane + 64 * q);
+            if (__ballot(clash) != 0ull) {          // equal depths in this tile: the exact 64-bit ranks
+                r0 = r1 = r2 = r3 = 0;
+                for (int j = 0; j < n; j++) {
+                    const uint64_t kj = s[j];
+                    r0 += kj < k[0]; r1 += kj < k[1]; r2 += kj < k[2]; r3 += kj < k[3];
+                }
             }
         }
         const int r[4] = {r0, r1, r2, r3};
