@@ -756,12 +756,14 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
+#ifndef GSVC_SORT_NO_GATHER      // timing experiment (tools/scratch): the sort without the per-instance record gather
             if (lane + 64 * q < n) {
                 const float4 *rec = reinterpret_cast<const float4 *>(geom + ((uint32_t)k[q] >> id_shift));
                 const float4 f2 = rec[2];
                 bb[q] = make_uint2(__float_as_uint(f2.y), __float_as_uint(f2.z));
                 if (gslot) row[q] = row_of_instance(f2, rec[3], tx, ty);
             }
+#endif
         }
         // Rank = number of smaller keys.  First by the DEPTH word alone (32-bit compares, four staged depths per 16-byte LDS read:
         // a 64-bit compare costs several times a 32-bit one, and its result cannot be consumed by the next instruction); the
@@ -816,6 +818,9 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
                 }
             }
         }
+#ifdef GSVC_SORT_NO_RANK         // timing experiment: no ranking (entries stay where they are)
+        r0 = lane; r1 = lane + 64; r2 = lane + 128; r3 = lane + 192;
+#endif
         const int r[4] = {r0, r1, r2, r3};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
