@@ -107,6 +107,11 @@ __global__ void __launch_bounds__(256) k_visible_masks(VisViews v, int R, int P,
 constexpr int SCAN_CHUNK = 8192;
 constexpr int SORT_RANK_MAX = 256;    // entries one wave rank-sorts (4 keys per lane)
 constexpr int SORT_WAVE_MAX = 1024;   // entries one wave sorts in LDS (8 KiB)
+#ifdef GSVC_SORT_NO_BUCKET
+constexpr bool SORT_DEBUG_NO_BUCKET = true;      // timing / A-B experiment: the round-2 paths only
+#else
+constexpr bool SORT_DEBUG_NO_BUCKET = false;
+#endif
 
 // s_v: SCAN_CHUNK ints of LDS; called by all 1024 threads of one workgroup.
 __device__ __forceinline__ void scan_tiles_body(int T, const int32_t *__restrict__ tile_count, int32_t *__restrict__ tile_extra,
@@ -712,6 +717,109 @@ __device__ __forceinline__ void emit_entry(int pos, uint64_t key, const GeomRec 
     if (gslot) gslot[pos] = row_of_instance(f2, reinterpret_cast<const float4 *>(geom + id)[3], tx, ty);
 }
 
+// Bucket sort of one tile's keys by one wave, 64 < n <= 64 KPL (round 3; replaces the LDS bitonic network for 257..1024 entries and
+// the all-pairs ranking above 128): the keys' DEPTH word is mapped monotonically onto 256 buckets between the tile's smallest and
+// largest depth (float scale: conversion, multiplication by a positive constant and truncation are all monotone), a histogram
+// (LDS integer atomics: their order does not matter) and its scan give every bucket a range, the keys' indices are dropped into
+// their bucket in whatever order the atomics hand out, and every key then ranks itself inside its bucket with exact 64-bit
+// compares — so the result is the total order of the keys (depth, then Gaussian index) whatever the placement was.  ~n / 256
+// entries per bucket: O(n) instead of O(n^2) or O(n log^2 n).  Returns false (nothing written) when some bucket holds more than
+// BUCKET_MAX entries (many equal or tightly clustered depths): the caller falls back to the exact networks.
+constexpr int BUCKET_MAX = 48;
+template <int KPL>
+__device__ __forceinline__ bool bucket_rank(const uint64_t *__restrict__ s, int n, int lane, uint32_t *scr /* 2 KiB */, int (&rank)[KPL])
+{
+    // the depth VALUE (the key's high word is order_bits(depth): a monotone but exponent-shaped image of it — bucketed by the bit
+    // pattern, depths on both sides of zero pile up in a few buckets at the two ends)
+    auto depth_of = [](uint64_t key) -> float {
+        const uint32_t u = (uint32_t)(key >> 32);
+        return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+    };
+    float dmin = 3.0e38f, dmax = -3.0e38f;
+#pragma unroll
+    for (int q = 0; q < KPL; q++) {
+        const int i = lane + 64 * q;
+        if (i < n) {
+            const float d = depth_of(s[i]);
+            dmin = fminf(dmin, d); dmax = fmaxf(dmax, d);
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        dmin = fminf(dmin, __shfl_xor(dmin, m, 64));
+        dmax = fmaxf(dmax, __shfl_xor(dmax, m, 64));
+    }
+    const float span = dmax - dmin;
+    const float scale = span > 0.f ? 255.0f / span : 0.f;      // (NaN / inf depths never reach a tile list)
+    uint32_t *cnt = scr;                                        // [256] counts; the same bytes hold the index list afterwards
+    uint16_t *bidx = reinterpret_cast<uint16_t *>(scr);         // [1024] key indices grouped by bucket
+#pragma unroll
+    for (int q = 0; q < 4; q++) cnt[lane + 64 * q] = 0u;
+    sort_sync<true>();
+    uint32_t bs[KPL];          // bucket << 16 | slot inside the bucket
+#pragma unroll
+    for (int q = 0; q < KPL; q++) {
+        const int i = lane + 64 * q;
+        bs[q] = 0;
+        if (i < n) {
+            const uint32_t b = (uint32_t)fminf(255.0f, fmaxf(0.0f, (depth_of(s[i]) - dmin) * scale));      // monotone in the depth
+            bs[q] = (b << 16) | atomicAdd(&cnt[b], 1u);
+        }
+    }
+    sort_sync<true>();
+    // exclusive scan of the 256 counts (lane l: buckets 4 l .. 4 l + 3), largest bucket
+    uint32_t c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) c[q] = cnt[4 * lane + q];
+    uint32_t big = max(max(c[0], c[1]), max(c[2], c[3]));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, m, 64));
+    if (big > (uint32_t)BUCKET_MAX) return false;
+    const uint32_t tot = (c[0] + c[1]) + (c[2] + c[3]);
+    uint32_t inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    // the buckets' (start: 10 bits, count: 6 bits) stay in the registers of the lane that scanned them, two per register;
+    // bucket b's pair is fetched from lane b / 4 (ds_bpermute: no memory)
+    uint32_t run = inc - tot, t16[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { t16[q] = run | (c[q] << 10); run += c[q]; }
+    const uint32_t p01 = t16[0] | (t16[1] << 16), p23 = t16[2] | (t16[3] << 16);
+    auto bucket_of = [&](uint32_t b, int &start, int &count) {
+        const int src = (int)(b >> 2) << 2;                      // byte address of the source lane
+        const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)p01), z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)p23);
+        const uint32_t v = ((b & 2u) ? z : a) >> ((b & 1u) * 16u);
+        start = (int)(v & 0x3ffu);
+        count = (int)((v >> 10) & 0x3fu);
+    };
+    sort_sync<true>();          // every count has been read: the bytes become the index list
+#pragma unroll
+    for (int q = 0; q < KPL; q++) {
+        const int i = lane + 64 * q;
+        int start, count;
+        bucket_of(bs[q] >> 16, start, count);                    // (all lanes take part in the exchange)
+        if (i < n) bidx[start + (int)(bs[q] & 0xffffu)] = (uint16_t)i;
+    }
+    sort_sync<true>();
+#pragma unroll
+    for (int q = 0; q < KPL; q++) {
+        const int i = lane + 64 * q;
+        int start, count;
+        bucket_of(bs[q] >> 16, start, count);
+        rank[q] = 0;
+        if (i < n) {
+            const uint64_t ki = s[i];
+            int r = start;
+            for (int t = 0; t < count; t++) r += s[bidx[start + t]] < ki;
+            rank[q] = r;
+        }
+    }
+    return true;
+}
+
 // One launch sorts every tile: 256-lane workgroups, each wave takes one tile at a time (tile = 4*block + wave):
 //   n <= 256   rank sort: every key is compared with every other from LDS (keys are unique: rank = position);
 //              the bbox gather of the lane's own entries is issued BEFORE the ranking so its latency hides under it
@@ -725,8 +833,9 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
                                                     const gsvc_raster_counters *__restrict__ counters, int id_shift)
 {
     __shared__ uint64_t s_all[4 * SORT_WAVE_MAX];   // 32 KiB: one 8-KiB strip per wave
-    __shared__ __attribute__((aligned(16))) uint32_t s_dep[4][SORT_RANK_MAX];      // rank sort: the keys' depth words
-    __shared__ uint16_t s_chk[4][SORT_RANK_MAX];                                   // rank sort: who claimed rank r
+    // 2 KiB of scratch per wave.  Rank sort: the keys' depth words [256] + who claimed rank r [256 x 16 bit]; bucket sort: the
+    // bucket counts [256], then the key indices grouped by bucket [1024 x 16 bit]
+    __shared__ __attribute__((aligned(16))) uint32_t s_scr[4][512];
     const int overflow = counters->overflow;   // loaded together with the segment bounds (one scalar round trip, not two)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -739,7 +848,30 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
     }
     if (overflow) n = 0;
     const int ty = t / gx, tx = t - ty * gx;
-    if (n > 0 && n <= SORT_RANK_MAX) {
+    bool done = false;
+    if (n > SORT_RANK_MAX && n <= SORT_WAVE_MAX && !(SORT_DEBUG_NO_BUCKET)) {
+        for (int i = lane; i < n; i += 64) s[i] = keys[beg + i];
+        sort_sync<true>();
+        auto emit = [&](int i, int r) { emit_entry(beg + r, s[i], geom, point_list, inst_bbox, gslot, tx, ty, id_shift); };
+        if (n <= 512) {
+            int rk[8];
+            done = bucket_rank<8>(s, n, lane, s_scr[wave], rk);
+            if (done) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) if (lane + 64 * q < n) emit(lane + 64 * q, rk[q]);
+            }
+        } else {
+            int rk[16];
+            done = bucket_rank<16>(s, n, lane, s_scr[wave], rk);
+            if (done) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) if (lane + 64 * q < n) emit(lane + 64 * q, rk[q]);
+            }
+        }
+        sort_sync<true>();
+    }
+    if (done) {
+    } else if (n > 0 && n <= SORT_RANK_MAX) {
         uint64_t k[4];
         uint2 bb[4];
         int32_t row[4];
@@ -769,8 +901,8 @@ __global__ void __launch_bounds__(256) k_sort_tiles(int T, const int32_t *__rest
         // a 64-bit compare costs several times a 32-bit one, and its result cannot be consumed by the next instruction); the
         // ranks are then checked for uniqueness through LDS — equal depths (the only way two entries can share a rank) are rare,
         // and a tile that has them takes the 64-bit loop, which breaks ties by the Gaussian's index exactly as the key says.
-        uint32_t *sd = s_dep[wave];
-        uint16_t *chk = s_chk[wave];
+        uint32_t *sd = s_scr[wave];
+        uint16_t *chk = reinterpret_cast<uint16_t *>(s_scr[wave] + SORT_RANK_MAX);
         uint32_t d4[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
