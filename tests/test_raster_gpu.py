@@ -98,6 +98,26 @@ def test_forward_long_tile_lists(oracle_lib):
         _compare_forward(oracle_lib, sc, max_borderline=2e-2)
 
 
+@pytest.mark.parametrize("P,ties", [(700, "none"), (700, "pairs"), (1100, "runs"), (900, "clustered"), (2200, "none")])
+def test_forward_medium_tile_lists_bucket_sort(oracle_lib, P, ties):
+    """Tile lists of 257..1024 entries take the bucket sort of k_sort_tiles (depth value -> 256 buckets, exact 64-bit ranking inside
+    a bucket): distinct depths, pairs of equal depths (index order decides), runs of 60 equal depths and depths clustered in a
+    sliver of the slab (a bucket overflows: the tile falls back to the bitonic network), depths on both sides of the camera
+    plane.  Lists, radii and pixels against the oracle."""
+    sc = synthetic.raster_scene(P, H=48, W=48, T=64, seed=P, window_frames=8, sigma_px=(0.5, 2.0), opacity=(0.01, 0.05))
+    sc["means3D"][:, :2] *= 0.3                                   # everything on the same few tiles
+    z = sc["means3D"][:, 2]
+    if ties == "pairs":
+        sc["means3D"][P // 2:, 2] = z[:P - P // 2]
+    elif ties == "runs":
+        for a in range(0, P - 60, 180):
+            sc["means3D"][a:a + 60, 2] = z[a]
+    elif ties == "clustered":
+        zc = float(np.median(z))
+        sc["means3D"][: 3 * P // 4, 2] = zc + (z[: 3 * P // 4] - zc) * 1e-4
+    _compare_forward(oracle_lib, sc, max_borderline=2e-2)
+
+
 def test_forward_edge_cases(oracle_lib):
     sc = synthetic.raster_scene(64, H=40, W=56, T=32, seed=3, window_frames=8)
     s = sc["settings"]
