@@ -126,6 +126,7 @@ class Trainer:
                 and gaussians.optimizer is not None):
             self.sharded = gdist.ShardedAnchorAdam(gaussians.optimizer)
         self.reducer = gdist.GradReducer(sharded=self.sharded)
+        gdist.plan_group()      # created HERE, where every rank stands at the same point (creating a group is itself collective)
         self._mask_reg_weight = 0.0
         self._ovf_handle = None
 
