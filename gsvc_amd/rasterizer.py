@@ -18,6 +18,7 @@ colors_precomp / scales+rotations) and raise NotImplementedError here.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import NamedTuple, Optional
 
@@ -122,7 +123,7 @@ _capacity_hint = {}
 
 
 def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales, rotations, max_instances=None,
-                   sync=True, pair=False, readback=False, radii_out=None):
+                   sync=True, pair=False, readback=False, radii_out=None, side_stream=None):
     """Launch the forward pipeline.  Returns (image, radii, state).  With ``sync`` the instance counters
     are read back (16 B) and the call is repeated with a larger instance capacity if it overflowed; without
     it the caller must check ``state.counters()[1]`` itself (``readback``: the counters' copy to the host is queued right
@@ -135,7 +136,9 @@ def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales,
     key = (H, W)
     if max_instances is None:
         max_instances = max(_capacity_hint.get(key, 0), 4 * P, 1 << 16)
-    stream = _lib.current_stream(dev)
+    # side_stream (a torch.cuda.Stream the caller has made wait for the inputs, and waits for afterwards): the kernels go there;
+    # every buffer is still allocated on the CURRENT stream's pool (the caller's join orders any reuse behind the side work)
+    stream = _lib.current_stream(dev) if side_stream is None else C.c_void_p(side_stream.cuda_stream)
     while True:
         sizes = _lib.RasterSizesC()
         _lib.check(L.gsvc_raster_sizes_query(C.byref(cs), P, max_instances, C.byref(sizes)), "gsvc_raster_sizes_query")
@@ -155,9 +158,11 @@ def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales,
             # now, behind the forward only, so that resolve_deferred() later waits for THIS copy and not for
             # everything queued after it (the whole backward of a fitting step)
             state._host = torch.empty(4, dtype=torch.int32, pin_memory=True)
-            state._host.copy_(binning[:16].view(torch.int32), non_blocking=True)
-            state._event = torch.cuda.Event()
-            state._event.record()
+            src = binning[:16].view(torch.int32)
+            with torch.cuda.stream(side_stream) if side_stream is not None else contextlib.nullcontext():
+                state._host.copy_(src, non_blocking=True)
+                state._event = torch.cuda.Event()
+                state._event.record()
         if not sync:
             return image, radii, state
         n, overflow, _, _ = state.counters()
@@ -227,6 +232,22 @@ class _RasterizeGaussians(torch.autograd.Function):
         return d3, d2, dc, do, ds, dq, None, None, None
 
 
+_SIDE = {}
+
+
+def _side_streams(device, renders):
+    """Two side streams per device for the independent renders of a step (GSVC_RASTER_STREAMS=1: everything on the current
+    stream)."""
+    import os
+    n = int(os.environ.get("GSVC_RASTER_STREAMS", "2"))
+    if n <= 1 or renders < 2 or torch.device(device).type != "cuda":
+        return []
+    key = (torch.device(device).index, n)
+    if key not in _SIDE:
+        _SIDE[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _SIDE[key]
+
+
 class _RasterizeMany(torch.autograd.Function):
     """R rasterizations of consecutive row ranges of ONE set of Gaussian tensors (the un-compacted renders of a fitting step are
     slices of the batch the generation pass produced): the forward launches the R pipelines on the ranges in place, the backward
@@ -241,12 +262,20 @@ class _RasterizeMany(torch.autograd.Function):
         N = int(means3D.shape[0])
         radii = torch.empty(N, dtype=torch.int32, device=means3D.device)
         images, states = [], []
+        # the renders are independent pipelines of dependent kernels (bin, scatter, sort, composite): dealt to two side streams,
+        # one render's kernel boundaries and tails are filled by the other's kernels
+        side = _side_streams(means3D.device, len(cs_list))
+        main = torch.cuda.current_stream(means3D.device)
+        for sd in side:
+            sd.wait_stream(main)
         for r, cs in enumerate(cs_list):
             a, b = bounds[r], bounds[r + 1]
             img, _, st = raster_forward(cs, means3D[a:b], colors[a:b], opacities[a:b], scales[a:b], rotations[a:b], sync=False,
-                                        readback=True, radii_out=radii[a:b])
+                                        readback=True, radii_out=radii[a:b], side_stream=side[r % len(side)] if side else None)
             images.append(img)
             states.append(st)
+        for sd in side:
+            main.wait_stream(sd)
         ctx.states, ctx.bounds = states, tuple(bounds)
         ctx.save_for_backward(means3D, colors, opacities, scales, rotations)
         ctx.mark_non_differentiable(radii)
@@ -260,10 +289,16 @@ class _RasterizeMany(torch.autograd.Function):
         N, dev = means3D.shape[0], means3D.device
         d3, d2, dc = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
         do, ds, dq = torch.empty(N, 1, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, 4, device=dev)
-        L, stream = _lib.lib(), _lib.current_stream(dev)
+        L = _lib.lib()
+        side = _side_streams(dev, len(ctx.states))
+        main = torch.cuda.current_stream(dev)
+        for sd in side:
+            sd.wait_stream(main)
+        scratches = []              # alive until the join below
         for r, st in enumerate(ctx.states):
             a, b = ctx.bounds[r], ctx.bounds[r + 1]
             g = grads[r]
+            stream = C.c_void_p(side[r % len(side)].cuda_stream) if side else _lib.current_stream(dev)
             if g is None:           # a render nothing was computed from: its Gaussians get no gradient
                 for t in (d3, d2, dc, do, ds, dq):
                     t[a:b].zero_()
@@ -271,11 +306,15 @@ class _RasterizeMany(torch.autograd.Function):
             g = _as_f32(g, "grad_image")
             P = st.P
             scratch = torch.empty(backward_scratch_floats(P, st.max_instances), device=dev)
+            scratches.append((scratch, g))
             _lib.check(L.gsvc_raster_backward(
                 C.byref(st.cs), P, st.max_instances, _lib.ptr(means3D[a:b]), _lib.ptr(colors[a:b]), _lib.ptr(opacities[a:b]),
                 _lib.ptr(scales[a:b]), _lib.ptr(rotations[a:b]), _lib.ptr(st.radii), _lib.ptr(st.geom), _lib.ptr(st.binning),
                 _lib.ptr(st.image_state), _lib.ptr(g), _lib.ptr(d3[a:b]), _lib.ptr(d2[a:b]), _lib.ptr(dc[a:b]), _lib.ptr(do[a:b]),
                 _lib.ptr(ds[a:b]), _lib.ptr(dq[a:b]), _lib.ptr(scratch), stream), "gsvc_raster_backward")
+        for sd in side:
+            main.wait_stream(sd)
+        del scratches
         return d3, d2, dc, do, ds, dq, None, None, None
 
 
