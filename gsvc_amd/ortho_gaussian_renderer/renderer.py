@@ -184,12 +184,23 @@ def render_frames(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0
                 gss_list = generate_neural_gaussians_many(chunk, pc, visible, mode, dense=True, anchors=geometry[0],
                                                           trunks=trunks)
                 images, states = [], []
-                for f, gss in zip(chunk, gss_list):
+                # the frames of a batch are independent pipelines: dealt to two side streams (rasterizer._side_streams), one frame's
+                # kernel boundaries and tails are filled by the next frame's kernels
+                from ..rasterizer import _side_streams
+                dev = pc._anchor.device
+                side = _side_streams(dev, len(chunk))
+                main = torch.cuda.current_stream(dev) if side else None
+                args = [(gss.xyz.contiguous(), gss.color.contiguous(), gss.opacity.contiguous(), gss.scaling.contiguous(), gss.rot.contiguous())
+                        for gss in gss_list]
+                for sd in side:
+                    sd.wait_stream(main)
+                for k, (f, a) in enumerate(zip(chunk, args)):
                     cs = settings_to_c(raster_settings_for(f, pc, pipe, bg_color, scaling_modifier))
-                    image, _, state = raster_forward(cs, gss.xyz.contiguous(), gss.color.contiguous(), gss.opacity.contiguous(),
-                                                     gss.scaling.contiguous(), gss.rot.contiguous(), pair=True, sync=False)
+                    image, _, state = raster_forward(cs, *a, pair=True, sync=False, side_stream=side[k % len(side)] if side else None)
                     images.append(image)
                     states.append(state)
+                for sd in side:
+                    main.wait_stream(sd)
                 if not resolve_deferred(states)[1]:
                     break              # else: an instance buffer overflowed, the capacity hint is raised: once more
             yield from images
