@@ -200,7 +200,9 @@ __device__ __forceinline__ bool bwd_pixel(PixState &p, float dx, float dy, const
 #ifndef GSVC_BWD_WAVES
 #define GSVC_BWD_WAVES 4
 #endif
-template <bool CLAMP_STOP>
+// DBG: the timing experiments / lane-efficiency probe selected by the run-time word `dbg` (GSVC_BWD_DEBUG); the production
+// instantiation (DBG = false) carries none of their code or registers
+template <bool CLAMP_STOP, bool DBG>
 __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterParams st, const int32_t *__restrict__ tile_offsets,
                                                        const int32_t *__restrict__ point_list,
                                                        const uint2 *__restrict__ inst_bbox,
@@ -209,8 +211,9 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
                                                        const float *__restrict__ final_T,
                                                        const int32_t *__restrict__ n_contrib,
                                                        const float *__restrict__ dL_dimage, float *__restrict__ rows,
-                                                       const gsvc_raster_counters *__restrict__ counters, int dbg)
+                                                       const gsvc_raster_counters *__restrict__ counters, int dbg_word)
 {
+    const int dbg = DBG ? dbg_word : 0;
     __shared__ float4 s_f0[64];     // u v A' B'
     __shared__ float4 s_f1[64];     // C' opacity r g
     __shared__ float2 s_f2[64];     // b, tag = chunk entry | quadrant mask << 8 | list position << 12
@@ -565,12 +568,12 @@ extern "C" int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_
     static const int dbg = getenv("GSVC_BWD_DEBUG") ? atoi(getenv("GSVC_BWD_DEBUG")) : 0;   // kernel-timing experiments
     {
         ProfScope _prof("k_blend_bwd", s);
-        if (p.flags & GSVC_RASTER_CLAMP_STOPS_GRADIENT)
-            hipLaunchKernelGGL(k_blend_bwd_tile<true>, dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, inst_bbox,
-                               gslot, (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters, dbg);
-        else
-            hipLaunchKernelGGL(k_blend_bwd_tile<false>, dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, inst_bbox,
-                               gslot, (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters, dbg);
+#define GSVC_BWD_LAUNCH(CS, DB) hipLaunchKernelGGL((k_blend_bwd_tile<CS, DB>), dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, \
+            inst_bbox, gslot, (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters, dbg)
+        const bool cs = p.flags & GSVC_RASTER_CLAMP_STOPS_GRADIENT;
+        if (dbg) { if (cs) GSVC_BWD_LAUNCH(true, true); else GSVC_BWD_LAUNCH(false, true); }
+        else { if (cs) GSVC_BWD_LAUNCH(true, false); else GSVC_BWD_LAUNCH(false, false); }
+#undef GSVC_BWD_LAUNCH
     }
     {
         ProfScope _prof("k_gaussian_bwd", s);
