@@ -31,7 +31,10 @@ for _ in range(150):
 res = {va: [], vb: []}
 for rep in range(5):
     for v in (va, vb):
-        os.environ[var] = v
+        if v == "unset":
+            os.environ.pop(var, None)
+        else:
+            os.environ[var] = v
         for _ in range(3):
             it += 1; tr.step(it)
         torch.cuda.synchronize(); t0 = time.perf_counter()
