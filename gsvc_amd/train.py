@@ -230,8 +230,14 @@ class Trainer:
     def _sparse_dp(self, plan):
         """Row-sparse gradient exchange of the per-anchor tensors: needs the step plan (the rank's distinct visible anchors and the
         largest such count over the ranks) and the replicated Adam; GSVC_DP_SPARSE=0 keeps the dense all-reduce."""
-        return (plan is not None and gdist.world_size() > 1 and self.sharded is None and self.reducer.enabled and not self.anchor_grad
-                and getattr(plan, "distinct_cap", None) is not None and os.environ.get("GSVC_DP_SPARSE", "1") != "0")
+        if not (plan is not None and gdist.world_size() > 1 and self.sharded is None and self.reducer.enabled and not self.anchor_grad
+                and getattr(plan, "distinct_cap", None) is not None and os.environ.get("GSVC_DP_SPARSE", "1") != "0"):
+            return False
+        # every rank receives the other ranks' row lists (all-gather, padded to the largest): worth it while those rows are fewer
+        # than what a ring all-reduce of the dense tensors moves (2 (W - 1) / W of the anchors) — two ranks always, eight ranks
+        # only when a rank sees less than a quarter of the anchors.  The same decision on every rank (cap is their maximum).
+        W, A = gdist.world_size(), int(self.pc._anchor.shape[0])
+        return os.environ.get("GSVC_DP_SPARSE") == "1" or (W - 1) * plan.distinct_cap < 2 * (W - 1) * A // W
 
     def _views(self, frame_idx):
         """The step's four views: (frame, frame seen from the opposite side) of the two adjacent frames."""
