@@ -631,6 +631,13 @@ extern "C" int gsvc_linear_wgrad_partial_many(gsvc_wgrad_partial_job *jobs, int3
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_wgrad_many), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             attr_set = true;
         }
+        static const bool trace = getenv("GSVC_WGRAD_TRACE") != nullptr;      // one line per launch: the products and their workgroups
+        if (trace) {
+            fprintf(stderr, "wgrad_many:");
+            for (int i = 0; i < nb; i++)
+                fprintf(stderr, " [M=%lld N=%d K=%d wgs=%d]", (long long)t.M[i], t.N[i], t.K[i], wgs[i]);
+            fprintf(stderr, "\n");
+        }
         ProfScope _prof("k_linear_wgrad", s);
         hipLaunchKernelGGL(k_linear_wgrad_many, dim3(at), dim3(64 * WG_MAX_WAVES), (size_t)max_pairs * 4096 * sizeof(float), s, t);
         nb = 0;
