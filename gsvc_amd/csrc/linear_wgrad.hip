@@ -85,7 +85,10 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad(const float 
     for (int s = 0; s < 4; s++)
 #pragma unroll
         for (int t = 0; t < 4; t++) asm volatile("" : "+v"(fa[s][t]), "+v"(fb[s][t]));
-    for (; rb < RB; rb += workers) {
+    // lockstep over the chunks (see wg_main_t): the waves that read the same rows ask for them together
+    const long long n_it = (RB - (long long)blockIdx.x + workers - 1) / workers;
+    for (long long it = 0; it < n_it; it++, rb += workers) {
+        __builtin_amdgcn_s_barrier();
         const __amdgpu_buffer_rsrc_t rg = ws_block_rsrc(G, rb + workers, RB, M, N);      // empty past the end
         const __amdgpu_buffer_rsrc_t rx = ws_block_rsrc(X, rb + workers, RB, M, K);
 #pragma unroll
@@ -177,7 +180,7 @@ __device__ __forceinline__ void wg_load_t(__amdgpu_buffer_rsrc_t rs, int off, fl
 
 template <int TN, int TK>
 __device__ __forceinline__ void wg_main_t(const float *__restrict__ G, const float *__restrict__ X, long long M, int N, int K, int n0,
-                                          int k0, long long rb, long long workers, int j, int mq, v4f (&acc)[4][4], float (&gsum)[4])
+                                          int k0, long long rb, long long workers, int j, int mq, v4f (&acc)[4][4], float (&gsum)[4], long long n_it)
 {
     const long long RB = (M + 15) >> 4;
     const int ca = n0 + TN * j, cb = k0 + TK * j;          // this lane's first column of G / X
@@ -202,7 +205,13 @@ __device__ __forceinline__ void wg_main_t(const float *__restrict__ G, const flo
 #pragma unroll
         for (int t = 0; t < TK; t++) asm volatile("" : "+v"(fb[s][t]));
     }
-    for (; rb < RB; rb += workers) {
+    // The waves of a workgroup walk their chunks in LOCKSTEP (a barrier per 16-row chunk, the same trip count for all: a wave
+    // past its last chunk multiplies the zeros of an empty descriptor).  The four waves of a row split read the same rows — the
+    // same G block by two of them, the same X block by two, and the blocks of a row share cache lines — and left to
+    // themselves they drift apart (16 vs 9 MFMAs per step), so that every line came from L2 two to four times: with the waves
+    // asking together the launch's operand stream went from 2.7 to 3.6 TB/s (k_linear_wgrad_many 161 -> 123 us in the fitting step).
+    for (long long it = 0; it < n_it; it++, rb += workers) {
+        __builtin_amdgcn_s_barrier();
         const __amdgpu_buffer_rsrc_t rg = ws_block_rsrc(G, rb + workers, RB, M, N);      // empty past the end
         const __amdgpu_buffer_rsrc_t rx = ws_block_rsrc(X, rb + workers, RB, M, K);
 #pragma unroll
@@ -273,7 +282,8 @@ __device__ __forceinline__ void wgrad_t_body(const float *__restrict__ G, const 
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
     float gsum[4] = {0.f, 0.f, 0.f, 0.f};
-#define WG_BODY(a, b) case (a) * 4 + (b): wg_main_t<a, b>(G, X, M, N, K, n0, k0, rb, workers, j, mq, acc, gsum); break
+    const long long n_it = (((M + 15) >> 4) - wg + workers - 1) / workers;      // chunks of the workgroup's first row split = trip count of all its waves
+#define WG_BODY(a, b) case (a) * 4 + (b): wg_main_t<a, b>(G, X, M, N, K, n0, k0, rb, workers, j, mq, acc, gsum, n_it); break
     switch (TN * 4 + TK) {
         WG_BODY(1, 1); WG_BODY(1, 2); WG_BODY(1, 3); WG_BODY(1, 4);
         WG_BODY(2, 1); WG_BODY(2, 2); WG_BODY(2, 3); WG_BODY(2, 4);
