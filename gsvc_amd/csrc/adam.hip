@@ -55,6 +55,29 @@ __global__ void __launch_bounds__(256) k_adam(AdamBatch b, float b1, float b2, f
     const float ss = b.step_size[t], ib = b.inv_sqrt_bc2[t];
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                        reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    // a whole chunk inside the tensor and 16-byte aligned (all but a tensor's last workgroup): the four pieces' 16 loads are
+    // issued before the first is used (piece by piece each thread made four dependent memory round trips)
+    if (vec && base + ADAM_CHUNK <= n) {
+        float4 P[4], M[4], V[4], G[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long i = base + (long long)(u * 256 + threadIdx.x) * 4;
+            P[u] = *reinterpret_cast<const float4 *>(p + i); M[u] = *reinterpret_cast<const float4 *>(m + i);
+            V[u] = *reinterpret_cast<const float4 *>(v + i); G[u] = *reinterpret_cast<const float4 *>(g + i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long i = base + (long long)(u * 256 + threadIdx.x) * 4;
+            adam1(P[u].x, G[u].x, M[u].x, V[u].x, b1, b2, omb1, omb2, eps, ss, ib);
+            adam1(P[u].y, G[u].y, M[u].y, V[u].y, b1, b2, omb1, omb2, eps, ss, ib);
+            adam1(P[u].z, G[u].z, M[u].z, V[u].z, b1, b2, omb1, omb2, eps, ss, ib);
+            adam1(P[u].w, G[u].w, M[u].w, V[u].w, b1, b2, omb1, omb2, eps, ss, ib);
+            *reinterpret_cast<float4 *>(p + i) = P[u];
+            *reinterpret_cast<float4 *>(m + i) = M[u];
+            *reinterpret_cast<float4 *>(v + i) = V[u];
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const long long i = base + (long long)(u * 256 + threadIdx.x) * 4;

@@ -61,6 +61,11 @@ __global__ void __launch_bounds__(256) k_gen_tail_bwd(const float *__restrict__ 
                                                       float *__restrict__ d_anchor)
 {
     __shared__ float part[256][9];      // per Gaussian: gw*offset (3), g_scaling*sigmoid (3), gw (3)
+    // the 7- and 3-float records of the block's Gaussians are contiguous in memory: they are collected here and stored as whole
+    // segments (lane-per-component stores at a 28- / 12-byte stride wrote every line 7 / 3 times: 272 MB of write traffic per
+    // launch for 95 MB of output, profiles/r03 PMC)
+    __shared__ float s_dsr[256 * 7];
+    __shared__ float s_dof[256 * 3];
     const int t = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * rpb;
     const int lr = t / K;                                   // row inside the block
@@ -73,13 +78,13 @@ __global__ void __launch_bounds__(256) k_gen_tail_bwd(const float *__restrict__ 
         d_offset_mask[i] = gno * op_raw[i];
         const float *sr = scale_rot + 7 * i;
         const float *gs = grid_scaling + 6 * r;
-        float *dsr = d_scale_rot + 7 * i;
+        float *dsr = s_dsr + 7 * t;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float w = world[3 * i + c];
             float gw = g_world ? g_world[3 * i + c] : 0.f;
             if (g_xyz && w >= bd.lo[c] && w <= bd.hi[c]) gw += g_xyz[3 * i + c];
-            d_offsets[3 * i + c] = gw * gs[c];
+            s_dof[3 * t + c] = gw * gs[c];
             const float sg = 1.0f / (1.0f + expf(-sr[c]));
             const float gsc = g_scaling ? g_scaling[3 * i + c] : 0.f;
             dsr[c] = gsc * gs[3 + c] * sg * (1.0f - sg);
@@ -104,6 +109,13 @@ __global__ void __launch_bounds__(256) k_gen_tail_bwd(const float *__restrict__ 
 #pragma unroll
     for (int c = 0; c < 9; c++) part[t][c] = c9[c];
     __syncthreads();
+    {
+        const int64_t i0 = row0 * K;
+        const int64_t left = rows - row0;
+        const int n_live = (int)(left < rpb ? left : rpb) * K;      // live lanes are 0 .. n_live - 1 (t = lr * K + k)
+        for (int v = t; v < n_live * 7; v += 256) d_scale_rot[7 * i0 + v] = s_dsr[v];
+        for (int v = t; v < n_live * 3; v += 256) d_offsets[3 * i0 + v] = s_dof[v];
+    }
     // lane (row, component): 9 components x rpb rows
     for (int v = t; v < rpb * 9; v += 256) {
         const int rr = v / 9, c = v - rr * 9;
