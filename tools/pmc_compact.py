@@ -5,7 +5,7 @@ from collections import defaultdict
 acc = defaultdict(list)
 with open(sys.argv[1], newline="") as f:
     for row in csv.DictReader(f):
-        m = re.search(r"(gsvc::k_\w+(<[^>(]*>)?)", row["Kernel_Name"])
+        m = re.search(r"(gsvc::(?:\(anonymous namespace\)::)?k_\w+(<[^>(]*>)?)", row["Kernel_Name"])
         if m:
             acc[(m.group(1), row["Counter_Name"])].append(float(row["Counter_Value"]))
 w = csv.writer(sys.stdout)
