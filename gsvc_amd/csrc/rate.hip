@@ -285,65 +285,63 @@ __global__ void __launch_bounds__(256) k_rate_sample_finalize(const float *__res
 // PM_BLOCKS block sums per tensor, then one workgroup adds them.
 constexpr int PM_BLOCKS = 2048;      // 8 workgroups per CU: enough 16-byte loads in flight to stream at the HBM rate
 
-// sum of f(x) over a contiguous tensor: 16-byte loads, four independent running sums per lane (one dependent add chain per
-// lane over 4-byte loads from 256 workgroups read 84 MB in 141 us = 0.6 TB/s); the order is fixed by (grid, n) alone
+// sum of f(x) over a contiguous tensor by the workgroups [0, nblk) it was given: 16-byte loads, FOUR of them in flight per lane,
+// four independent running sums (one dependent add chain per lane over 4-byte loads from 256 workgroups read 84 MB in 141 us =
+// 0.6 TB/s; this form 29 us = 2.9 TB/s, the same as with every workgroup walking the three tensors in turn); the order is fixed
+// by (nblk, n) alone
 template <bool EXP>
-__device__ __forceinline__ float pm_stream_sum(const float *__restrict__ x, long long n)
+__device__ __forceinline__ float pm_stream_sum(const float *__restrict__ x, long long n, int blk, int nblk)
 {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    const long long stride = (long long)gridDim.x * 256, first = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)nblk * 256, first = (long long)blk * 256 + threadIdx.x;
+    auto f = [](float v) { return EXP ? expf(v) : v; };
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
         const long long n4 = n >> 2;
         long long i = first;
-        for (; i + stride < n4; i += 2 * stride) {
-            const float4 u = x4[i], v = x4[i + stride];
-            if (EXP) {
-                s0 += expf(u.x) + expf(v.x); s1 += expf(u.y) + expf(v.y); s2 += expf(u.z) + expf(v.z); s3 += expf(u.w) + expf(v.w);
-            } else {
-                s0 += u.x + v.x; s1 += u.y + v.y; s2 += u.z + v.z; s3 += u.w + v.w;
-            }
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const float4 u = x4[i], v = x4[i + stride], w = x4[i + 2 * stride], z = x4[i + 3 * stride];
+            s0 += (f(u.x) + f(v.x)) + (f(w.x) + f(z.x)); s1 += (f(u.y) + f(v.y)) + (f(w.y) + f(z.y));
+            s2 += (f(u.z) + f(v.z)) + (f(w.z) + f(z.z)); s3 += (f(u.w) + f(v.w)) + (f(w.w) + f(z.w));
         }
-        if (i < n4) {
+        for (; i < n4; i += stride) {
             const float4 u = x4[i];
-            if (EXP) { s0 += expf(u.x); s1 += expf(u.y); s2 += expf(u.z); s3 += expf(u.w); }
-            else { s0 += u.x; s1 += u.y; s2 += u.z; s3 += u.w; }
+            s0 += f(u.x); s1 += f(u.y); s2 += f(u.z); s3 += f(u.w);
         }
-        for (long long j = 4 * n4 + first; j < n; j += stride) s0 += EXP ? expf(x[j]) : x[j];
+        for (long long j = 4 * n4 + first; j < n; j += stride) s0 += f(x[j]);
     } else {
-        for (long long j = first; j < n; j += stride) s0 += EXP ? expf(x[j]) : x[j];
+        for (long long j = first; j < n; j += stride) s0 += f(x[j]);
     }
     return (s0 + s1) + (s2 + s3);
 }
 
+// workgroups [0, fb) sum tensor a, [fb, fc) tensor b, [fc, gridDim) tensor c (dealt by size on the host); part[block] = its sum
 __global__ void __launch_bounds__(256) k_param_means_part(const float *__restrict__ a, long long na, const float *__restrict__ b,
                                                           long long nb, int b_exp, const float *__restrict__ c, long long nc,
-                                                          float *__restrict__ part)
+                                                          int fb, int fc, float *__restrict__ part)
 {
-    __shared__ float red[3][4];
-    float s[3];
-    s[0] = pm_stream_sum<false>(a, na);
-    s[1] = b_exp ? pm_stream_sum<true>(b, nb) : pm_stream_sum<false>(b, nb);
-    s[2] = pm_stream_sum<false>(c, nc);
+    __shared__ float red[4];
+    const int blk = blockIdx.x;
+    float v;
+    if (blk < fb) v = pm_stream_sum<false>(a, na, blk, fb);
+    else if (blk < fc) v = b_exp ? pm_stream_sum<true>(b, nb, blk - fb, fc - fb) : pm_stream_sum<false>(b, nb, blk - fb, fc - fb);
+    else v = pm_stream_sum<false>(c, nc, blk - fc, (int)gridDim.x - fc);
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float v = s[k];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
-    }
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x < 3) part[blockIdx.x * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x == 0) part[blk] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void __launch_bounds__(256) k_param_means_sum(const float *__restrict__ part, int blocks, long long na, long long nb,
-                                                         long long nc, float *__restrict__ out)
+__global__ void __launch_bounds__(256) k_param_means_sum(const float *__restrict__ part, int blocks, int fb, int fc, long long na,
+                                                         long long nb, long long nc, float *__restrict__ out)
 {
     __shared__ float sm[3][256];
+    const int lo[3] = {0, fb, fc}, hi[3] = {fb, fc, blocks};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float v = 0.f;
-        for (int bl = threadIdx.x; bl < blocks; bl += 256) v += part[bl * 3 + k];
+        for (int bl = lo[k] + (int)threadIdx.x; bl < hi[k]; bl += 256) v += part[bl];
         sm[k][threadIdx.x] = v;
     }
     __syncthreads();
@@ -584,9 +582,23 @@ extern "C" int gsvc_param_means(const float *feat, int64_t n_feat, const float *
                  "param_means: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     gsvc::ProfScope _prof("k_param_means", s);
+    // workgroups dealt to the three tensors by size (a tensor with elements gets at least one)
+    const double tot = (double)n_feat + (double)n_scaling + (double)n_offset;
+    int wa = 0, wb = 0, wc = 0;
+    if (tot > 0) {
+        wa = n_feat ? (int)(gsvc::PM_BLOCKS * ((double)n_feat / tot)) : 0;
+        wb = n_scaling ? (int)(gsvc::PM_BLOCKS * ((double)n_scaling / tot)) : 0;
+        if (n_feat && wa < 1) wa = 1;
+        if (n_scaling && wb < 1) wb = 1;
+        wc = gsvc::PM_BLOCKS - wa - wb;
+        if (wc < 0) { wb += wc; wc = 0; }
+        if (n_offset == 0) { wa += wc; wc = 0; if (n_feat == 0) { wb += wa; wa = 0; } }
+        else if (wc < 1) { wc = 1; if (wa > wb) wa--; else wb--; }
+    }
+    const int fb = wa, fc = wa + wb;
     hipLaunchKernelGGL(gsvc::k_param_means_part, dim3(gsvc::PM_BLOCKS), dim3(256), 0, s, feat, (long long)n_feat, scaling,
-                       (long long)n_scaling, (int)scaling_exp, offset, (long long)n_offset, scratch);
-    hipLaunchKernelGGL(gsvc::k_param_means_sum, dim3(1), dim3(256), 0, s, scratch, gsvc::PM_BLOCKS, (long long)n_feat,
+                       (long long)n_scaling, (int)scaling_exp, offset, (long long)n_offset, fb, fc, scratch);
+    hipLaunchKernelGGL(gsvc::k_param_means_sum, dim3(1), dim3(256), 0, s, scratch, gsvc::PM_BLOCKS, fb, fc, (long long)n_feat,
                        (long long)n_scaling, (long long)n_offset, out3);
     return gsvc::check_launch("param_means");
 }
