@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(64 * WG_MAX_WAVES) k_linear_wgrad_t(const floa
 // row-split meeting and one partial last round per network instead of one per layer (a launch of this kernel costs ~10-15 us
 // beyond its MFMAs: at 40 launches per fitting step that was a quarter of the weight-gradient time).  Every product of a batch
 // runs 12 waves (output blocks x row splits = 12).
-constexpr int WG_MANY = 8;
+constexpr int WG_MANY = 12;
 struct WgManyJobs {
     int n;
     const float *G[WG_MANY], *X[WG_MANY];
@@ -434,10 +434,11 @@ __global__ void __launch_bounds__(64 * WGR_WAVES) k_linear_wgrad_reduce(const fl
 
 // The same sum for up to 8 weight gradients in one launch (the layers of one network's backward pass): a block finds its
 // job through the by-value table of first blocks.
+constexpr int WGR_JOBS = 16;
 struct WgReduceJobs {
-    const float *part[8];
-    float *dW[8], *db[8];
-    int slots[8], n[8], nk[8], first_block[9];
+    const float *part[WGR_JOBS];
+    float *dW[WGR_JOBS], *db[WGR_JOBS];
+    int slots[WGR_JOBS], n[WGR_JOBS], nk[WGR_JOBS], first_block[WGR_JOBS + 1];
 };
 
 __global__ void __launch_bounds__(64 * WGR_WAVES) k_linear_wgrad_reduce_many(WgReduceJobs t, int jobs)
@@ -689,9 +690,9 @@ extern "C" int gsvc_linear_wgrad_reduce_many(const gsvc_wgrad_reduce_job *jobs, 
 {
     GSVC_REQUIRE(jobs && n_jobs >= 0, "linear_wgrad_reduce_many: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    for (int j0 = 0; j0 < n_jobs; j0 += 8) {
+    for (int j0 = 0; j0 < n_jobs; j0 += WGR_JOBS) {
         WgReduceJobs t;
-        const int nj = n_jobs - j0 < 8 ? n_jobs - j0 : 8;
+        const int nj = n_jobs - j0 < WGR_JOBS ? n_jobs - j0 : WGR_JOBS;
         int blocks = 0;
         for (int j = 0; j < nj; j++) {
             const gsvc_wgrad_reduce_job &q = jobs[j0 + j];

@@ -58,10 +58,10 @@ def linear_ex(x, w, b=None, epi=EPI_NONE, aux1=None, aux2=None, y2=None, y3=None
 
 class WgradBatch:
     """Weight gradients of one network's backward pass: the layers' row-split products go out together at ``flush`` (one launch
-    for up to eight of them: gsvc_linear_wgrad_partial_many; their partial sums land in their own regions of the workspace),
+    for up to twelve of them: gsvc_linear_wgrad_partial_many; their partial sums land in their own regions of the workspace),
     followed by ONE small launch that adds up the slots of all layers."""
 
-    ARENA = 1 << 24     # floats
+    ARENA = 1 << 26     # floats (a product asks for 256 slots of N K + N; the batch launch uses 256 slots in all)
 
     def __init__(self, dev):
         import ctypes as C
