@@ -136,25 +136,56 @@ struct EmbedSegs {
     float cam_z[16];
 };
 
+// One lane per (row, frequency): sin and cos of an argument come from ONE sincosf, the camera half of a row — the same 2 F + 1
+// numbers for every row of a render — from a table the workgroup fills once, and the rows leave through LDS as whole segments
+// (one lane per output element called sinf / cosf 4 F + 2 times per row, half of them on the render's constant, and stored 4 bytes
+// at a time: 40 us for 198 k rows).  256 / F rows per workgroup.
+constexpr int EMBED_MAX_F = 24, EMBED_OUT_FLOATS = 1536;      // (256 / F) * 2 (2 F + 1) <= 1536 for F >= 1
 __global__ void __launch_bounds__(256) k_embed_pe(const float *__restrict__ anchor, EmbedSegs sg, int R, int F, int64_t rows,
                                                   float *__restrict__ pe)
 {
-    const int W = 2 * F + 1;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * 2 * W) return;
-    const int64_t row = i / (2 * W);
-    const int c = (int)(i - row * 2 * W);
-    int r = 0;
-    while (r + 1 < R && row >= sg.bound[r + 1]) r++;
-    const float cz = sg.cam_z[r];
-    const float x = c < W ? cz : anchor[3 * row + 2] - cz;
-    const int cc = c < W ? c : c - W;
-    float v = x;
-    if (cc > 0) {
-        const float xf = x * (float)(1u << ((cc - 1) >> 1));
-        v = ((cc - 1) & 1) ? cosf(xf) : sinf(xf);
+    __shared__ float s_cam[16][2 * EMBED_MAX_F + 1];
+    __shared__ float s_out[EMBED_OUT_FLOATS];
+    __shared__ long long s_bound[17];      // (a lane-varying index into the by-value struct would go through scratch)
+    const int W = 2 * F + 1, rpb = 256 / F, t = threadIdx.x;
+    if (t < 17) s_bound[t] = sg.bound[t];
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int n_rows = (int)(rows - r0 < rpb ? rows - r0 : rpb);
+    // renders of the workgroup's first and last row
+    int r_lo = 0, r_hi = 0;
+    while (r_lo + 1 < R && r0 >= sg.bound[r_lo + 1]) r_lo++;
+    r_hi = r_lo;
+    while (r_hi + 1 < R && r0 + n_rows - 1 >= sg.bound[r_hi + 1]) r_hi++;
+    for (int e = t; e < (r_hi - r_lo + 1) * (F + 1); e += 256) {
+        const int rr = e / (F + 1), k = e - rr * (F + 1);
+        const float cz = sg.cam_z[r_lo + rr];
+        if (k == F) s_cam[rr][0] = cz;
+        else {
+            float sn, cs;
+            sincosf(cz * (float)(1u << k), &sn, &cs);
+            s_cam[rr][1 + 2 * k] = sn;
+            s_cam[rr][2 + 2 * k] = cs;
+        }
     }
-    pe[i] = v;
+    __syncthreads();
+    const int lr = t / F, k = t - lr * F;
+    if (lr < n_rows) {
+        const int64_t row = r0 + lr;
+        int r = r_lo;
+        while (r < r_hi && row >= s_bound[r + 1]) r++;
+        const float xa = anchor[3 * row + 2] - s_cam[r - r_lo][0];
+        float sn, cs;
+        sincosf(xa * (float)(1u << k), &sn, &cs);
+        float *o = s_out + lr * 2 * W;
+        o[1 + 2 * k] = s_cam[r - r_lo][1 + 2 * k];
+        o[2 + 2 * k] = s_cam[r - r_lo][2 + 2 * k];
+        o[W + 1 + 2 * k] = sn;
+        o[W + 2 + 2 * k] = cs;
+        if (k == 0) { o[0] = s_cam[r - r_lo][0]; o[W] = xa; }
+    }
+    __syncthreads();
+    float *dst = pe + r0 * 2 * W;
+    for (int e = t; e < n_rows * 2 * W; e += 256) dst[e] = s_out[e];
 }
 
 // Per-anchor parameters of the batch's rows in one pass each way (reference guassian.py:160-176 gathers them by boolean mask and
@@ -165,6 +196,8 @@ struct GatherDims {
     int F, K3, S, K;       // columns of feat, offsets (3 K), scaling, mask
 };
 
+// 32 lanes per row (8 rows per workgroup), a lane takes columns l, l + 32, ... of the row's F + 3 K + S + K values: the row index
+// is read once per lane (not once per element behind a 64-bit division), and a lane's loads are independent of each other
 __global__ void __launch_bounds__(256) k_gather_rows_fwd(const float *__restrict__ pf, const float *__restrict__ po,
                                                          const float *__restrict__ ps, const float *__restrict__ pm,
                                                          const long long *__restrict__ vis, long long rows, GatherDims d, int decoded,
@@ -173,27 +206,28 @@ __global__ void __launch_bounds__(256) k_gather_rows_fwd(const float *__restrict
 {
 #pragma clang fp contract(off)
     const int CT = d.F + d.K3 + d.S + d.K;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * CT) return;
-    const long long row = i / CT;
-    int c = (int)(i - row * CT);
+    const long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= rows) return;
     const long long v = vis[row];
-    if (c < d.F) { feat[row * d.F + c] = pf[v * d.F + c]; return; }
-    c -= d.F;
-    if (c < d.K3) { off[row * d.K3 + c] = po[v * d.K3 + c]; return; }
-    c -= d.K3;
-    if (c < d.S) {
-        const float r = ps[v * d.S + c];
-        scal[row * d.S + c] = decoded ? r : 1.0f * expf(r);
-        return;
+    for (int c0 = threadIdx.x & 31; c0 < CT; c0 += 32) {
+        int c = c0;
+        if (c < d.F) { feat[row * d.F + c] = pf[v * d.F + c]; continue; }
+        c -= d.F;
+        if (c < d.K3) { off[row * d.K3 + c] = po[v * d.K3 + c]; continue; }
+        c -= d.K3;
+        if (c < d.S) {
+            const float r = ps[v * d.S + c];
+            scal[row * d.S + c] = decoded ? r : 1.0f * expf(r);
+            continue;
+        }
+        c -= d.S;
+        const float r = pm[v * d.K + c];
+        if (decoded) { mask[row * d.K + c] = r; continue; }
+        const float sg = 1.0f / (1.0f + expf(-r));
+        const float h = sg > 0.01f ? 1.0f : 0.0f;
+        const float diff = h - sg;
+        mask[row * d.K + c] = diff + sg;
     }
-    c -= d.S;
-    const float r = pm[v * d.K + c];
-    if (decoded) { mask[row * d.K + c] = r; return; }
-    const float sg = 1.0f / (1.0f + expf(-r));
-    const float h = sg > 0.01f ? 1.0f : 0.0f;
-    const float diff = h - sg;
-    mask[row * d.K + c] = diff + sg;
 }
 
 __global__ void __launch_bounds__(256) k_gather_rows_bwd(const float *__restrict__ ps, const float *__restrict__ pm,
@@ -621,9 +655,9 @@ extern "C" int gsvc_embed_pe(const float *anchor, const int64_t *row_bounds, con
     const int64_t rows = row_bounds[renders];
     if (rows == 0) return GSVC_OK;
     GSVC_REQUIRE(anchor && pe, "embed_pe: NULL pointer");
-    const int64_t n = rows * 2 * (2 * freqs + 1);
+    const int rpb = 256 / freqs;
     gsvc::ProfScope _prof("k_embed_pe", (hipStream_t)stream);
-    hipLaunchKernelGGL(gsvc::k_embed_pe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, anchor, sg, renders,
+    hipLaunchKernelGGL(gsvc::k_embed_pe, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, anchor, sg, renders,
                        freqs, rows, pe);
     return gsvc::check_launch("embed_pe");
 }
@@ -637,9 +671,8 @@ extern "C" int gsvc_gather_rows_forward(const float *feat_p, const float *offset
     GSVC_REQUIRE(vis && (F == 0 || (feat_p && feat)) && (K == 0 || (offset_p && mask_p && offsets && mask)) && (S == 0 || (scaling_p && scaling)),
                  "gather_rows_forward: NULL pointer");
     const gsvc::GatherDims d{F, 3 * K, S, K};
-    const int64_t n = rows * (F + 3 * K + S + K);
     gsvc::ProfScope _prof("k_gather_rows", (hipStream_t)stream);
-    hipLaunchKernelGGL(gsvc::k_gather_rows_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat_p, offset_p,
+    hipLaunchKernelGGL(gsvc::k_gather_rows_fwd, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, feat_p, offset_p,
                        scaling_p, mask_p, (const long long *)vis, (long long)rows, d, decoded, feat, offsets, scaling, mask);
     return gsvc::check_launch("gather_rows_forward");
 }
