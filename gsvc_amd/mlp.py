@@ -196,6 +196,7 @@ class _SeqGeluMany(torch.autograd.Function):
         grads = [None] * len(params)
         wg = WgradBatch(x.device)
         gx = None
+        first = []          # (g, W) of the chains' first layers: their input gradients meet in gx
         at, sv = 0, 1
         for c, n in enumerate(sizes):
             g = gs[c]
@@ -211,13 +212,37 @@ class _SeqGeluMany(torch.autograd.Function):
                     if i > 0:
                         g = linear_ex(g, w, None, EPI_MUL_GELU_GRAD, aux1=zs[i - 1], w_in_out=True)
                     elif ctx.needs_input_grad[0]:
-                        if gx is None:
-                            gx = linear_ex(g, w, None, w_in_out=True)
-                        else:
-                            linear_ex(g, w, None, EPI_ADD, aux1=gx, w_in_out=True, out=gx)      # gx += g W, in place
+                        first.append((g, w))
             at += 2 * n
+        if first:
+            gx = _sum_of_products(first, x.shape[1])
         wg.flush()
         return (gx, None, *grads)
+
+
+def _sum_of_products(pairs, N):
+    """sum over (g [M, K], W [K, N]) of g W: one launch that keeps the rows' accumulators in registers across the products
+    (gsvc_linear_accumulate_many: at most 8 products, M <= 65536), else product by product with the accumulate epilogue."""
+    import os
+    g0 = pairs[0][0]
+    M = g0.shape[0]
+    if (2 <= len(pairs) <= 8 and 0 < M <= 65536 and N <= MFMA_MAX_DIM and not os.environ.get("GSVC_NO_ACCUM_MANY")
+            and all(g.shape[1] <= MFMA_MAX_DIM and g.shape[1] % 2 == 0 and g.is_contiguous() and w.is_contiguous()
+                    and g.data_ptr() % 8 == 0 for g, w in pairs)):
+        out = torch.empty(M, N, device=g0.device, dtype=torch.float32)
+        jobs = (_lib.AccumJobC * len(pairs))()
+        for i, (g, w) in enumerate(pairs):
+            jobs[i] = _lib.AccumJobC(g.data_ptr(), w.data_ptr(), g.shape[1], 0)
+        _lib.check(_lib.lib().gsvc_linear_accumulate_many(jobs, len(pairs), _lib.ptr(out), M, N, _lib.current_stream(g0.device)),
+                   "gsvc_linear_accumulate_many")
+        return out
+    gx = None
+    for g, w in pairs:
+        if gx is None:
+            gx = linear_ex(g, w, None, w_in_out=True)
+        else:
+            linear_ex(g, w, None, EPI_ADD, aux1=gx, w_in_out=True, out=gx)      # gx += g W, in place
+    return gx
 
 
 def seq_gelu_many(x, chains):

@@ -563,6 +563,19 @@ int gsvc_linear_forward_ex(const float *X, const float *W, const float *bias, fl
                            int32_t w_in_out, int32_t epilogue, const float *aux1, const float *aux2, float *Y2, float *Y3,
                            void *stream);
 
+/* Y[M,N] = sum_p X_p[M,K_p] W_p with W_p given [K_p][N] (input-major: the dX = G W products of a backward pass whose input
+ * gradients meet in one matrix — the six sub-networks of the three EntropyParamsNets all read the hash-grid feature, reference
+ * scene/gaussian_model.py:198-232, 1569-1597) in ONE launch: a wave keeps its rows' accumulators in registers across the
+ * products and stores the sum once.  At most 8 products, N, K_p <= 192, M <= 65536 (GSVC_E_UNSUPPORTED beyond: use
+ * gsvc_linear_forward_ex with GSVC_LIN_ADD product by product). */
+typedef struct {
+    const float *X;      /* [M][K] */
+    const float *W;      /* [K][N] */
+    int32_t K;
+    int32_t pad;
+} gsvc_accum_job;
+int gsvc_linear_accumulate_many(const gsvc_accum_job *jobs, int32_t n_jobs, float *Y, int64_t M, int32_t N, void *stream);
+
 /* dW[N,K] = G[M,N]^T X[M,K] and (db != NULL) db[N] = column sums of G: the weight / bias gradients of the same
  * layers.  Rows are split over the chip instead of the tiny output; every workgroup writes its partial sums to its
  * slot of `workspace` ((N*K + N) floats per slot, gsvc_linear_wgrad_workspace() = 256 slots) and a second small

@@ -3,6 +3,8 @@ chain of GEMM launches with the activations on the epilogue) against a plain PyT
 outputs and the gradient of every parameter and input.  fp32 products and sums on both sides; summation order and the
 GEMM-side erf differ -> 2e-5 of the tensor's scale forward, 1e-3 of the gradient's scale backward (sums over ~6000 rows).
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -322,3 +324,31 @@ def test_entropy_sub_networks_as_one_function_match_torch():
     outs = mlp.seq_gelu_many(x, chains)
     (outs[0] * gs[0]).sum().backward()
     assert chains[1][0].weight.grad is None and chains[0][0].weight.grad is not None and x.grad is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 4097, 52481, 65536])
+def test_sum_of_products_in_one_launch_matches_the_accumulate_epilogue(M):
+    """gsvc_linear_accumulate_many (csrc/linear_accum.hip): Y = sum_p G_p W_p for the six first-layer input gradients of the entropy
+    networks (reference scene/gaussian_model.py:198-232 read by 1569-1597) against float64 and against the product-by-product path."""
+    import torch
+    from gsvc_amd import mlp
+    torch.manual_seed(M)
+    dev = torch.device("cuda")
+    Ks = [150, 50, 100, 50, 150, 50]
+    pairs = [(torch.randn(M, k, device=dev), torch.randn(k, 192, device=dev) * 0.1) for k in Ks]
+    got = mlp._sum_of_products(pairs, 192)
+    ref = sum(g.double() @ w.double() for g, w in pairs)
+    scale = ref.abs().max().item()
+    assert (got.double() - ref).abs().max().item() <= 2e-6 * scale
+    os.environ["GSVC_NO_ACCUM_MANY"] = "1"
+    try:
+        old = mlp._sum_of_products(pairs, 192)
+    finally:
+        del os.environ["GSVC_NO_ACCUM_MANY"]
+    assert (got - old).abs().max().item() <= 2e-6 * scale
+    assert torch.equal(got, mlp._sum_of_products(pairs, 192))         # fixed order
+    # a product the fused kernel does not take (odd K): the fallback answers
+    odd = [(torch.randn(M, 51, device=dev), torch.randn(51, 192, device=dev)), pairs[0]]
+    r2 = mlp._sum_of_products(odd, 192)
+    assert (r2.double() - sum(g.double() @ w.double() for g, w in odd)).abs().max().item() <= 2e-5 * scale * 10
