@@ -62,6 +62,10 @@ class AccumJobC(C.Structure):
     _fields_ = [("X", C.c_void_p), ("W", C.c_void_p), ("K", C.c_int32), ("pad", C.c_int32)]
 
 
+class SharedInputJobC(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("Y", C.c_void_p), ("Y2", C.c_void_p), ("N", C.c_int32), ("pad", C.c_int32)]
+
+
 class RateSampleC(C.Structure):
     _fields_ = [("x", C.c_void_p * 3), ("mean", C.c_void_p * 3), ("scale", C.c_void_p * 3), ("Q", C.c_void_p * 3),
                 ("mask", C.c_void_p), ("sel", C.c_void_p), ("sel_ctx", C.c_void_p), ("row_bounds", C.POINTER(C.c_int64)),
@@ -199,6 +203,7 @@ _SIGNATURES = {
     "gsvc_linear_wgrad_reduce_many": (C.c_int, [C.POINTER(WgradReduceJobC), C.c_int32, _vp]),
     "gsvc_linear_wgrad_partial_many": (C.c_int, [C.POINTER(WgradPartialJobC), C.c_int32, _vp]),
     "gsvc_linear_accumulate_many": (C.c_int, [C.POINTER(AccumJobC), C.c_int32, _vp, _i64, C.c_int32, _vp]),
+    "gsvc_linear_forward_shared_input": (C.c_int, [_vp, _i64, C.c_int32, C.POINTER(SharedInputJobC), C.c_int32, _vp]),
     "gsvc_linear_wgrad_workspace": (_i64, [C.c_int32, C.c_int32]),
     "gsvc_generator_saved_floats": (_i64, [C.POINTER(GeneratorNetC), _i64, _i64]),
     "gsvc_generator_scratch_floats": (_i64, [C.POINTER(GeneratorNetC), _i64, _i64]),

@@ -145,6 +145,130 @@ __global__ void __launch_bounds__(ACC_THREADS) k_linear_accum_many(AccumJobs job
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The forward counterpart: Y_p[M,N_p] = X[M,K] W_p^T + b_p (+ the GELU pair) for several layers that read the SAME input — the six
+// first layers of the entropy networks.  A wave reads the fragments of its (at most two) blocks once and keeps them across
+// the products; the workgroup re-stages the weight image per product.  W_p is [N_p][K] (output-major, as nn.Linear stores it).
+constexpr int SH_MAX_JOBS = 8, SH_NT = 10;      // N_p <= 160: with K = 192 the image is 160 x 200 words = 128 KB
+
+struct SharedInputJobs {
+    int n;
+    const float *W[SH_MAX_JOBS], *bias[SH_MAX_JOBS];
+    float *Y[SH_MAX_JOBS], *Y2[SH_MAX_JOBS];      // Y2 != NULL: Y = pre-activation, Y2 = GELU(Y)
+    int N[SH_MAX_JOBS];
+};
+
+// 32 n-rows of W [N][K] (K % 4 == 0, 16-byte aligned rows) as float4 pieces along k: piece i = row n_lo + i / kp, k = 4 (i % kp)
+constexpr int SH_ROWS = 32, SH_PIECES = SH_ROWS * (ACC_NT * 16 / 4) / ACC_THREADS;      // 3 per thread at K = 192
+__device__ __forceinline__ void sh_stage_load(const float *__restrict__ W, int tid, int n_lo, int N, int K, int kp, float4 (&v)[SH_PIECES])
+{
+#pragma unroll
+    for (int u = 0; u < SH_PIECES; u++) {
+        const int i = tid + u * ACC_THREADS, r = i / kp, k = (i - r * kp) * 4, n = n_lo + r;
+        v[u] = (r < SH_ROWS && n < N && k < K) ? *reinterpret_cast<const float4 *>(W + (size_t)n * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void sh_stage_write(float *__restrict__ lds, int tid, int ld, int n_lo, int kp, const float4 (&v)[SH_PIECES])
+{
+#pragma unroll
+    for (int u = 0; u < SH_PIECES; u++) {
+        const int i = tid + u * ACC_THREADS, r = i / kp, k = (i - r * kp) * 4;
+        if (r < SH_ROWS) *reinterpret_cast<float4 *>(lds + (n_lo + r) * ld + k) = v[u];
+    }
+}
+
+__global__ void __launch_bounds__(ACC_THREADS) k_linear_shared_input(const float *__restrict__ X, SharedInputJobs jobs, long long M, int K,
+                                                                     int img_floats)
+{
+    extern __shared__ float lds[];
+    float *s_bias = lds + img_floats;      // behind the weight image (static LDS would come off the 160 KB the attribute asks for)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, kq = lane >> 4;
+    const long long RB = (M + 15) >> 4, stride = (long long)gridDim.x * (ACC_THREADS / 64);
+    const long long rb0 = (long long)wave * gridDim.x + blockIdx.x, rb1 = rb0 + stride;
+    const int ld = ws_ld(K), KG = (K + 15) >> 4, kp = (KG * 16) >> 2;
+    // the two blocks' fragments: read once, used by every product
+    float4 a[2][ACC_NT];
+    {
+        const __amdgpu_buffer_rsrc_t r0 = ws_block_rsrc(X, rb0, RB, M, K), r1 = ws_block_rsrc(X, rb1, RB, M, K);
+        const int voff = fr * K * 4 + 16 * kq;
+#pragma unroll
+        for (int g = 0; g < ACC_NT; g++) {
+            a[0][g] = ws_load_a<4, true>(r0, voff + 64 * g, 16 * g + 4 * kq, K);
+            a[1][g] = ws_load_a<4, true>(r1, voff + 64 * g, 16 * g + 4 * kq, K);
+        }
+    }
+    const float *wb = lds + fr * ld + 4 * kq;
+    for (int p = 0; p < jobs.n; p++) {
+        const float *W = jobs.W[0], *bias = jobs.bias[0];
+        float *Y = jobs.Y[0], *Y2 = jobs.Y2[0];
+        int N = jobs.N[0];
+#pragma unroll
+        for (int q = 1; q < SH_MAX_JOBS; q++)
+            if (p == q) { W = jobs.W[q]; bias = jobs.bias[q]; Y = jobs.Y[q]; Y2 = jobs.Y2[q]; N = jobs.N[q]; }
+        const int NT = (N + 15) >> 4;
+        __syncthreads();      // every wave is done with the previous product's image and bias
+        {
+            // the image [16 NT][ld] in pieces of 32 n-rows, the next piece's loads in flight while this one is written
+            float4 v0[SH_PIECES], v1[SH_PIECES];
+            sh_stage_load(W, tid, 0, N, K, kp, v0);
+            for (int n_lo = 0; n_lo < NT * 16; n_lo += 2 * SH_ROWS) {
+                if (n_lo + SH_ROWS < NT * 16) sh_stage_load(W, tid, n_lo + SH_ROWS, N, K, kp, v1);
+                sh_stage_write(lds, tid, ld, n_lo, kp, v0);
+                if (n_lo + 2 * SH_ROWS < NT * 16) sh_stage_load(W, tid, n_lo + 2 * SH_ROWS, N, K, kp, v0);
+                if (n_lo + SH_ROWS < NT * 16) sh_stage_write(lds, tid, ld, n_lo + SH_ROWS, kp, v1);
+            }
+            if (tid < SH_NT * 16) s_bias[tid] = (bias && tid < N) ? bias[tid] : 0.f;
+        }
+        __syncthreads();
+        const int sv = (N % 4 == 0 && ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Y2)) & 15) == 0) ? 4
+                       : ((N % 2 == 0 && ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Y2)) & 7) == 0) ? 2 : 1);
+        const int c00 = 4 * kq, yoff = (fr * N + c00) * 4;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            v4f acc[SH_NT];
+#pragma unroll
+            for (int t = 0; t < SH_NT; t++) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < ACC_NT; g++) {
+                if (g < KG) {
+                    const float4 x = a[b][g];
+#pragma unroll
+                    for (int t0 = 0; t0 < SH_NT; t0 += 2) {
+                        if (t0 < NT) {      // tiles in pairs (NT is uniform): N = 50 takes 4 of the 10
+                            const float4 w0 = *reinterpret_cast<const float4 *>(wb + t0 * 16 * ld + 16 * g);
+                            const float4 w1 = *reinterpret_cast<const float4 *>(wb + (t0 + 1) * 16 * ld + 16 * g);
+                            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, x.x, acc[t0], 0, 0, 0);
+                            acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, x.x, acc[t0 + 1], 0, 0, 0);
+                            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, x.y, acc[t0], 0, 0, 0);
+                            acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, x.y, acc[t0 + 1], 0, 0, 0);
+                            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, x.z, acc[t0], 0, 0, 0);
+                            acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, x.z, acc[t0 + 1], 0, 0, 0);
+                            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, x.w, acc[t0], 0, 0, 0);
+                            acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, x.w, acc[t0 + 1], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const long long rb = b ? rb1 : rb0;
+            const __amdgpu_buffer_rsrc_t ry = ws_block_rsrc(Y, rb, RB, M, N), r2 = ws_block_rsrc(Y2, Y2 ? rb : RB, RB, M, N);
+#pragma unroll
+            for (int t = 0; t < SH_NT; t++) {
+                if (t < NT) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(s_bias + c00 + 16 * t);
+                    float v[4] = {acc[t][0] + bv.x, acc[t][1] + bv.y, acc[t][2] + bv.z, acc[t][3] + bv.w};
+                    ws_store4(ry, yoff + 64 * t, c00 + 16 * t, N, sv, v);
+                    float v2[4] = {gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+                    ws_store4(r2, yoff + 64 * t, c00 + 16 * t, N, sv, v2);      // dropped through the empty descriptor when Y2 is NULL
+                }
+            }
+        }
+    }
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
@@ -185,4 +309,44 @@ extern "C" int gsvc_linear_accumulate_many(const gsvc_accum_job *jobs, int32_t n
     ProfScope _prof("k_linear_accum", s);
     hipLaunchKernelGGL(k_linear_accum_many, dim3((unsigned)grid), dim3(ACC_THREADS), lds, s, t, Y, (long long)M, (int)N, sv);
     return check_launch("linear_accumulate_many");
+}
+
+extern "C" int gsvc_linear_forward_shared_input(const float *X, int64_t M, int32_t K, const gsvc_shared_input_job *jobs, int32_t n_jobs,
+                                                void *stream)
+{
+    GSVC_REQUIRE(jobs && n_jobs >= 1 && M >= 0 && K > 0, "linear_forward_shared_input: bad arguments");
+    if (n_jobs > SH_MAX_JOBS || K > LIN_NT_MAX * 16 || (K & 3) || (reinterpret_cast<uintptr_t>(X) & 15) || M > (int64_t)16 * 256 * 16) {
+        set_error("linear_forward_shared_input: at most %d products, K <= %d and a multiple of 4, X 16-byte aligned, M <= 65536", SH_MAX_JOBS,
+                  LIN_NT_MAX * 16);
+        return GSVC_E_UNSUPPORTED;
+    }
+    if (M == 0) return GSVC_OK;
+    GSVC_REQUIRE(X, "linear_forward_shared_input: NULL pointer");
+    SharedInputJobs t;
+    t.n = n_jobs;
+    int nmax = 1;
+    for (int i = 0; i < SH_MAX_JOBS; i++) {
+        const gsvc_shared_input_job &q = jobs[i < n_jobs ? i : 0];
+        GSVC_REQUIRE(q.W && q.Y && q.N > 0, "linear_forward_shared_input: bad job %d", i);
+        if (q.N > SH_NT * 16 || (reinterpret_cast<uintptr_t>(q.W) & 15)) {
+            set_error("linear_forward_shared_input: N=%d: at most %d, W 16-byte aligned", q.N, SH_NT * 16);
+            return GSVC_E_UNSUPPORTED;
+        }
+        t.W[i] = q.W; t.bias[i] = q.bias; t.Y[i] = q.Y; t.Y2[i] = q.Y2; t.N[i] = q.N;
+        if (q.N > nmax) nmax = q.N;
+    }
+    const int img_floats = ((nmax + 31) / 32 * 32) * ws_ld(K);      // whole tile PAIRS (the product loop's unit)
+    const size_t lds = ((size_t)img_floats + SH_NT * 16) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linear_shared_input), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const long long RB = (M + 15) / 16;
+    long long grid = (RB + 7) / 8;
+    if (grid > 256) grid = 256;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope _prof("k_linear_shared_input", s);
+    hipLaunchKernelGGL(k_linear_shared_input, dim3((unsigned)grid), dim3(ACC_THREADS), lds, s, X, t, (long long)M, (int)K, img_floats);
+    return check_launch("linear_forward_shared_input");
 }

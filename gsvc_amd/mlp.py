@@ -167,12 +167,17 @@ class _SeqGeluMany(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, sizes, *params):
         x = x.contiguous()
+        first = _first_layers_shared_input(x, sizes, params)      # [(z, a)] per chain, or None: layer by layer
         outs, saved, at = [], [x], 0
-        for n in sizes:
+        for c, n in enumerate(sizes):
             h = x
             for i in range(n):
                 w, b = params[at + 2 * i].contiguous(), params[at + 2 * i + 1].contiguous()
-                if i + 1 < n:
+                if i == 0 and first is not None:
+                    z, a = first[c]
+                    saved += [z, a]
+                    h = a
+                elif i + 1 < n:
                     a = torch.empty(h.shape[0], w.shape[0], device=h.device, dtype=torch.float32)
                     z = linear_ex(h, w, b, EPI_GELU_DUAL, y2=a)
                     saved += [z, a]
@@ -218,6 +223,34 @@ class _SeqGeluMany(torch.autograd.Function):
             gx = _sum_of_products(first, x.shape[1])
         wg.flush()
         return (gx, None, *grads)
+
+
+def _first_layers_shared_input(x, sizes, params):
+    """The chains' first layers (Linear + GELU, every chain has a second layer) read the same x: one launch that keeps the rows'
+    fragments in registers across the layers (gsvc_linear_forward_shared_input).  Returns [(z, a)] per chain, or None when the
+    shapes are not the kernel's (the caller then runs layer by layer)."""
+    import os
+    M, K = x.shape
+    if (os.environ.get("GSVC_NO_SHARED_INPUT") or not (2 <= len(sizes) <= 8) or any(n < 2 for n in sizes) or not 0 < M <= 65536
+            or K > MFMA_MAX_DIM or K % 4 or x.data_ptr() % 16):
+        return None
+    ws, at = [], 0
+    for n in sizes:
+        w, b = params[at], params[at + 1]
+        if w.shape[0] > 160 or not w.is_contiguous() or w.data_ptr() % 16 or not b.is_contiguous():
+            return None
+        ws.append((w, b))
+        at += 2 * n
+    jobs = (_lib.SharedInputJobC * len(ws))()
+    out = []
+    for i, (w, b) in enumerate(ws):
+        z = torch.empty(M, w.shape[0], device=x.device, dtype=torch.float32)
+        a = torch.empty_like(z)
+        jobs[i] = _lib.SharedInputJobC(w.data_ptr(), b.data_ptr(), z.data_ptr(), a.data_ptr(), w.shape[0], 0)
+        out.append((z, a))
+    _lib.check(_lib.lib().gsvc_linear_forward_shared_input(_lib.ptr(x), M, K, jobs, len(ws), _lib.current_stream(x.device)),
+               "gsvc_linear_forward_shared_input")
+    return out
 
 
 def _sum_of_products(pairs, N):

@@ -576,6 +576,20 @@ typedef struct {
 } gsvc_accum_job;
 int gsvc_linear_accumulate_many(const gsvc_accum_job *jobs, int32_t n_jobs, float *Y, int64_t M, int32_t N, void *stream);
 
+/* The forward counterpart: several layers that read the SAME input, Y_p[M,N_p] = X[M,K] W_p^T + b_p with W_p [N_p][K] as nn.Linear
+ * stores it; Y2_p != NULL: Y_p keeps the pre-activation and Y2_p = GELU(Y_p) (the GSVC_LIN_GELU_DUAL pair).  One launch: a wave
+ * reads its rows' fragments once and keeps them across the products.  At most 8 products, N_p <= 160, K <= 192 and a multiple
+ * of 4, M <= 65536 (GSVC_E_UNSUPPORTED beyond: gsvc_linear_forward_ex layer by layer). */
+typedef struct {
+    const float *W;      /* [N][K] */
+    const float *bias;   /* [N] or NULL */
+    float *Y, *Y2;       /* [M][N]; Y2 may be NULL */
+    int32_t N;
+    int32_t pad;
+} gsvc_shared_input_job;
+int gsvc_linear_forward_shared_input(const float *X, int64_t M, int32_t K, const gsvc_shared_input_job *jobs, int32_t n_jobs,
+                                     void *stream);
+
 /* dW[N,K] = G[M,N]^T X[M,K] and (db != NULL) db[N] = column sums of G: the weight / bias gradients of the same
  * layers.  Rows are split over the chip instead of the tiny output; every workgroup writes its partial sums to its
  * slot of `workspace` ((N*K + N) floats per slot, gsvc_linear_wgrad_workspace() = 256 slots) and a second small

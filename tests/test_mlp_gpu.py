@@ -352,3 +352,49 @@ def test_sum_of_products_in_one_launch_matches_the_accumulate_epilogue(M):
     odd = [(torch.randn(M, 51, device=dev), torch.randn(51, 192, device=dev)), pairs[0]]
     r2 = mlp._sum_of_products(odd, 192)
     assert (r2.double() - sum(g.double() @ w.double() for g, w in odd)).abs().max().item() <= 2e-5 * scale * 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 4097, 52481])
+def test_first_layers_with_a_shared_input_in_one_launch(M):
+    """gsvc_linear_forward_shared_input (csrc/linear_accum.hip) against the layer kernel it replaces for the entropy networks' six
+    first layers (same bits: the same MFMA order per output) and against float64."""
+    from gsvc_amd import mlp
+    torch.manual_seed(M)
+    dev = torch.device("cuda")
+    Ns = [150, 50, 100, 50, 150, 50]
+    x = torch.randn(M, 192, device=dev)
+    params, sizes = [], []
+    for n in Ns:
+        params += [torch.randn(n, 192, device=dev) * 0.1, torch.randn(n, device=dev), torch.randn(8, n, device=dev), torch.randn(8, device=dev)]
+        sizes.append(2)
+    got = mlp._first_layers_shared_input(x, sizes, params)
+    assert got is not None
+    for i, n in enumerate(Ns):
+        w, b = params[4 * i], params[4 * i + 1]
+        a_ref = torch.empty(M, n, device=dev)
+        z_ref = mlp.linear_ex(x, w, b, mlp.EPI_GELU_DUAL, y2=a_ref)
+        z64 = x.double() @ w.double().t() + b.double()
+        assert (got[i][0].double() - z64).abs().max().item() <= 2e-6 * z64.abs().max().item()
+        assert torch.equal(got[i][0], z_ref) and torch.equal(got[i][1], a_ref)
+    # the module path end to end (forward values and every gradient) with and without the two fused launches
+    chains = [[torch.nn.Linear(192, n).to(dev), torch.nn.Linear(n, 8).to(dev)] for n in Ns]
+    gs = [torch.randn(M, 8, device=dev) for _ in Ns]
+
+    def run():
+        xx = x.clone().requires_grad_(True)
+        for c in chains:
+            for l in c:
+                l.zero_grad()
+        outs = mlp.seq_gelu_many(xx, chains)
+        torch.autograd.backward(outs, gs)
+        return [o.detach() for o in outs], xx.grad, [p.grad.clone() for c in chains for l in c for p in l.parameters()]
+    o1, g1, p1 = run()
+    os.environ["GSVC_NO_SHARED_INPUT"] = os.environ["GSVC_NO_ACCUM_MANY"] = "1"
+    try:
+        o0, g0, p0 = run()
+    finally:
+        del os.environ["GSVC_NO_SHARED_INPUT"], os.environ["GSVC_NO_ACCUM_MANY"]
+    assert all(torch.equal(a, b) for a, b in zip(o1, o0))
+    assert (g1 - g0).abs().max().item() <= 2e-6 * g0.abs().max().item()
+    assert all(torch.equal(a, b) for a, b in zip(p1, p0))
