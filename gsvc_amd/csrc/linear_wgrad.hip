@@ -245,6 +245,9 @@ __device__ __forceinline__ void wg_block_tiles(int tiles, int blocks, int b, int
     count = base + (b < rem ? 1 : 0);
 }
 
+// floats of one output block's LDS image in the 16-column kernel: 64 columns x 16 rows per tile of its widest n-block
+__host__ __device__ inline int wgt_block_floats(int N, int BN) { return 64 * 16 * ((((N + 15) >> 4) + BN - 1) / BN); }
+
 // wg of nwg: this workgroup's index among the workgroups that work on this product (a launch may carry several products:
 // k_linear_wgrad_many below)
 __device__ __forceinline__ void wgrad_t_body(const float *__restrict__ G, const float *__restrict__ X, float *__restrict__ part, int want_db,
@@ -305,7 +308,10 @@ __device__ __forceinline__ void wgrad_t_body(const float *__restrict__ G, const 
     }
     // sum the row splits of each block in LDS (one wave per block and round), then this workgroup's partial dW (and db) goes
     // to its slot of `part`
-    float *blk = sm + pair * 4096;
+    // a block's LDS image: 16 x (largest tile count of an n-block) rows of 64 floats — 12 blocks of 3 x 4 tiles (N = 150, K = 192)
+    // are 144 KB where twelve 64 x 64 images would not fit
+    const int PB = wgt_block_floats(N, BN);
+    float *blk = sm + pair * PB;
     for (int round = 0; round < RS; round++) {
         if (rs == round) {
 #pragma unroll
@@ -334,8 +340,8 @@ __device__ __forceinline__ void wgrad_t_body(const float *__restrict__ G, const 
         s_blk[tid][0] = 16 * f; s_blk[tid][1] = 16 * c; s_blk[tid][2] = 16 * g; s_blk[tid][3] = 16 * e;
     }
     __syncthreads();
-    for (int i = tid; i < pairs * 4096; i += blockDim.x) {
-        const int pr = i >> 12, nl = (i >> 6) & 63, kl = i & 63;
+    for (int i = tid; i < pairs * PB; i += blockDim.x) {
+        const int pr = i / PB, rem = i - pr * PB, nl = rem >> 6, kl = rem & 63;
         const int n = s_blk[pr][0] + nl, k = s_blk[pr][2] + kl;
         if (nl < s_blk[pr][1] && kl < s_blk[pr][3] && n < N && k < K) out[(size_t)n * K + k] = sm[i];
     }
@@ -489,7 +495,7 @@ static int launch_wgrad_t(const float *G, const float *X, float *dW, float *db, 
     // of rows that are only 8-byte aligned is split by the memory pipeline: K = 50 ran 20 % slower than with two 8-byte loads)
     const int BN = ((N + 15) / 16 + max_tn - 1) / max_tn, BK = ((K + 15) / 16 + max_tk - 1) / max_tk, pairs = BN * BK;
     const int RS = pairs >= WG_MAX_WAVES ? 1 : WG_MAX_WAVES / pairs;
-    const size_t lds = (size_t)pairs * 4096 * sizeof(float);
+    const size_t lds = (size_t)pairs * wgt_block_floats(N, BN) * sizeof(float);
     if (lds > 150 * 1024) {      // never dispatch a workgroup the CU cannot hold (the caller checks; this is the last line)
         set_error("linear_wgrad: %d output blocks do not fit one workgroup's LDS", pairs);
         return -1;
@@ -549,7 +555,7 @@ static int wgrad_launch(const float *G, const float *X, float *dW, float *db, bo
     // memory pipeline (K = 50 ran 20 % slower than with two 8-byte loads); 12- and 8-byte loads are fine at 4-byte alignment
     const int mt_g = vg == 4 ? 4 : 3, mt_x = vx == 4 ? 4 : 3;
     const int bn_t = ((N + 15) / 16 + mt_g - 1) / mt_g, bk_t = ((K + 15) / 16 + mt_x - 1) / mt_x;
-    if (!old_kernel && bn_t * bk_t <= 9) {        // 9 blocks x 16 KiB of LDS: the limit of one workgroup (as in the 64 x 64 kernel)
+    if (!old_kernel && bn_t * bk_t <= WG_MAX_WAVES && (size_t)bn_t * bk_t * wgt_block_floats(N, bn_t) * sizeof(float) <= 150 * 1024) {      // the blocks' LDS images: the limit of one workgroup
         used = launch_wgrad_t(G, X, dW, db, want_db, workspace, (int)slots, M, N, K, mt_g, mt_x, s);
         if (used < 0) return GSVC_E_UNSUPPORTED;
         if (slots_used) *slots_used = used;
@@ -601,7 +607,8 @@ extern "C" int gsvc_linear_wgrad_partial_many(gsvc_wgrad_partial_job *jobs, int3
         double total = 0;
         for (int i = 0; i < nb; i++) total += batch[i].work;
         // workgroups per product in proportion to its MFMA work, at least one, at most its slots / its 16-row chunks
-        int wgs[WG_MANY], sum = 0, max_pairs = 1;
+        int wgs[WG_MANY], sum = 0;
+        size_t max_lds = 0;
         for (int i = 0; i < nb; i++) {
             const gsvc_wgrad_partial_job &q = jobs[batch[i].job];
             const long long per_slot = (long long)q.N * q.K + (q.want_db ? q.N : 0);
@@ -614,7 +621,8 @@ extern "C" int gsvc_linear_wgrad_partial_many(gsvc_wgrad_partial_job *jobs, int3
             if (w > cap) w = (int)cap;
             wgs[i] = w;
             sum += w;
-            if (batch[i].pairs > max_pairs) max_pairs = batch[i].pairs;
+            const size_t need = (size_t)batch[i].pairs * wgt_block_floats(q.N, batch[i].BN) * sizeof(float);
+            if (need > max_lds) max_lds = need;
         }
         while (sum > 256) {      // rounding: take from the largest
             int big = 0;
@@ -650,7 +658,7 @@ extern "C" int gsvc_linear_wgrad_partial_many(gsvc_wgrad_partial_job *jobs, int3
             fprintf(stderr, "\n");
         }
         ProfScope _prof("k_linear_wgrad", s);
-        hipLaunchKernelGGL(k_linear_wgrad_many, dim3(at), dim3(64 * WG_MAX_WAVES), (size_t)max_pairs * 4096 * sizeof(float), s, t);
+        hipLaunchKernelGGL(k_linear_wgrad_many, dim3(at), dim3(64 * WG_MAX_WAVES), max_lds, s, t);
         nb = 0;
         return check_launch("linear_wgrad_partial_many");
     };
@@ -662,7 +670,8 @@ extern "C" int gsvc_linear_wgrad_partial_many(gsvc_wgrad_partial_job *jobs, int3
         const int mt_g = vg == 4 ? 4 : 3, mt_x = vx == 4 ? 4 : 3;
         const int BN = ((q.N + 15) / 16 + mt_g - 1) / mt_g, BK = ((q.K + 15) / 16 + mt_x - 1) / mt_x, pairs = BN * BK;
         const long long per_slot = (long long)q.N * q.K + (q.want_db ? q.N : 0);
-        const bool fits = q.N <= LIN_NT_MAX * 16 && q.K <= LIN_NT_MAX * 16 && pairs <= 9 && WG_MAX_WAVES % pairs == 0 &&
+        const bool fits = q.N <= LIN_NT_MAX * 16 && q.K <= LIN_NT_MAX * 16 && pairs <= WG_MAX_WAVES && WG_MAX_WAVES % pairs == 0 &&
+                          (size_t)pairs * wgt_block_floats(q.N, BN) * sizeof(float) <= 150 * 1024 &&
                           q.workspace_floats >= per_slot && !getenv("GSVC_WGRAD_BLOCK64");
         if (single || !fits) {
             if (int rc = flush()) return rc;
