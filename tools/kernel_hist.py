@@ -42,9 +42,9 @@ per = collections.Counter()
 for g in gaps:
     per[int(g[3])] += g[0]
 print("idle us per ms of the step:", " ".join(f"{int(per[k] / 1e3)}" for k in range(int((seg[-1][1] - seg[0][0]) / 1e6) + 1)))
-# optional second argument: a substring — every launch of the matching kernels in that step, in order, with its duration
+# optional second argument: a regular expression — every launch of the matching kernels in that step, in order, with its duration
 if len(sys.argv) > 2:
     print(f"launches matching '{sys.argv[2]}':")
     for s, e, n in seg:
-        if sys.argv[2] in n:
+        if re.search(sys.argv[2], n):
             print(f"  +{(s - seg[0][0]) / 1e6:6.2f} ms  {(e - s) / 1e3:8.1f} us  {short(n)}")
