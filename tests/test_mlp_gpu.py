@@ -398,3 +398,45 @@ def test_first_layers_with_a_shared_input_in_one_launch(M):
     assert all(torch.equal(a, b) for a, b in zip(o1, o0))
     assert (g1 - g0).abs().max().item() <= 2e-6 * g0.abs().max().item()
     assert all(torch.equal(a, b) for a, b in zip(p1, p0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,Ns", [(3000, 100, [100, 30, 160]), (777, 64, [16, 48]), (20000, 192, [12, 1, 150])])
+def test_shared_input_and_accumulate_entries_at_other_shapes(M, K, Ns):
+    """The two multi-product entries through the C-ABI at shapes the entropy networks do not use (K < 192, N not a multiple of 16
+    or of 4, a product without the GELU pair, an output narrower than 192)."""
+    from gsvc_amd import _lib
+    torch.manual_seed(M + K)
+    dev = torch.device("cuda")
+    L = _lib.lib()
+    x = torch.randn(M, K, device=dev)
+    Ws = [torch.randn(n, K, device=dev) * 0.2 for n in Ns]
+    bs = [torch.randn(n, device=dev) for n in Ns]
+    Ys = [torch.full((M, n), float("nan"), device=dev) for n in Ns]
+    Y2 = [torch.full((M, n), float("nan"), device=dev) if i % 2 == 0 else None for i, n in enumerate(Ns)]
+    jobs = (_lib.SharedInputJobC * len(Ns))()
+    for i, n in enumerate(Ns):
+        jobs[i] = _lib.SharedInputJobC(Ws[i].data_ptr(), bs[i].data_ptr() if i != 1 else None, Ys[i].data_ptr(),
+                                       Y2[i].data_ptr() if Y2[i] is not None else None, n, 0)
+    _lib.check(L.gsvc_linear_forward_shared_input(_lib.ptr(x), M, K, jobs, len(Ns), _lib.current_stream(dev)), "shared_input")
+    for i, n in enumerate(Ns):
+        ref = x.double() @ Ws[i].double().t() + (bs[i].double() if i != 1 else 0.0)
+        tol = 3e-6 * max(ref.abs().max().item(), 1.0)
+        assert (Ys[i].double() - ref).abs().max().item() <= tol
+        if Y2[i] is not None:
+            assert (Y2[i].double() - F.gelu(ref)).abs().max().item() <= 2 * tol
+    # accumulate: sum of X_p W_p into an [M, N] output with N = Ns[0]
+    N = Ns[0]
+    Kp = [K, 50, 2]
+    pairs = [(torch.randn(M, k, device=dev), torch.randn(k, N, device=dev) * 0.3) for k in Kp]
+    out = torch.full((M, N), float("nan"), device=dev)
+    aj = (_lib.AccumJobC * len(pairs))()
+    for i, (g, w) in enumerate(pairs):
+        aj[i] = _lib.AccumJobC(g.data_ptr(), w.data_ptr(), g.shape[1], 0)
+    _lib.check(L.gsvc_linear_accumulate_many(aj, len(pairs), _lib.ptr(out), M, N, _lib.current_stream(dev)), "accumulate_many")
+    ref = sum(g.double() @ w.double() for g, w in pairs)
+    assert (out.double() - ref).abs().max().item() <= 3e-6 * max(ref.abs().max().item(), 1.0)
+    # refusals: too many rows, an odd K
+    assert L.gsvc_linear_accumulate_many(aj, len(pairs), _lib.ptr(out), 65537, N, _lib.current_stream(dev)) != 0
+    bad = (_lib.AccumJobC * 1)(_lib.AccumJobC(pairs[0][0].data_ptr(), pairs[0][1].data_ptr(), 51, 0))
+    assert L.gsvc_linear_accumulate_many(bad, 1, _lib.ptr(out), M, N, _lib.current_stream(dev)) != 0
