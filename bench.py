@@ -431,8 +431,7 @@ def run_train_step(args, rank, world, dev):
                                    "submitted un-compacted (K per visible anchor), both means over the timed steps",
                    "parallelism": f"frame-shard x{world} + gradient all-reduce" if world > 1 else "single GPU"},
         "effective_batch": world,      # frame pairs per optimizer step: loss = mean over ranks (the reference steps on one pair)
-        "dp_anchor_optimizer": ("reduce-scatter + sharded Adam + all-gather" if trainer.sharded is not None else
-                                ("all-reduce + replicated Adam" if world > 1 else None)),
+        "dp_anchor_optimizer": ("row-sparse / all-reduce exchange + replicated Adam" if world > 1 else None),
         "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
         "dist_backend": (dist.get_backend() if world > 1 else None),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -287,6 +287,43 @@ def encode_anchors(anchors_q: np.ndarray, positions: np.ndarray | None = None, v
     return b"".join(head) + extra + _encode_octree(uniq, bits)
 
 
+MAX_ANCHORS = 1 << 31      # sanity cap on the header's 64-bit counts (a stream is untrusted input: StreamPack.load)
+
+
+def _read_extra(raw: bytes, mode: int, n: int, n_uniq: int, n_dup: int, n_exc: int):
+    """The zlib section of an anchor stream — (index, multiplicity) pairs of the repeated points and, in lattice mode, the
+    exception list — inflated with an output limit and validated BEFORE anything indexes with it: on the device an out-of-range
+    index is an assert that poisons the context, and a huge multiplicity an enormous allocation.  Returns (dup [k, 2] int64,
+    exc [n_exc, 3] int64)."""
+    if n > MAX_ANCHORS or n_uniq > n or n_dup > n_uniq or n_exc > n:
+        raise ValueError("anchor_codec: corrupt header (counts)")
+    limit = 16 * n_dup + 6 * n_exc if mode == 1 else 16 * n_uniq
+    z = zlib.decompressobj()
+    try:
+        extra = z.decompress(raw, limit + 1)
+    except zlib.error as e:
+        raise ValueError(f"anchor_codec: corrupt stream (multiplicity section: {e})") from None
+    if len(extra) > limit or z.unconsumed_tail or not z.eof:
+        raise ValueError("anchor_codec: corrupt stream (multiplicity section larger than its header allows)")
+    if mode == 1:
+        if len(extra) != limit:
+            raise ValueError("anchor_codec: corrupt stream (multiplicity section size)")
+        dup = np.frombuffer(extra, dtype="<i8", count=2 * n_dup).reshape(-1, 2)
+        exc = np.frombuffer(extra, dtype="<u2", offset=16 * n_dup, count=3 * n_exc).reshape(-1, 3).astype(np.int64)
+    else:
+        if len(extra) % 16:
+            raise ValueError("anchor_codec: corrupt stream (multiplicity section size)")
+        dup = np.frombuffer(extra, dtype="<i8").reshape(-1, 2)
+        exc = np.zeros((0, 3), np.int64)
+    if dup.shape[0]:
+        i, c = dup[:, 0], dup[:, 1]
+        if i[0] < 0 or i[-1] >= n_uniq or (np.diff(i) <= 0).any() or (c < 2).any() or (c > n).any():
+            raise ValueError("anchor_codec: corrupt stream (multiplicity entries)")
+    if int((dup[:, 1] - 1).sum()) + n_uniq + exc.shape[0] != n:
+        raise ValueError("anchor_codec: corrupt stream (anchor count)")
+    return dup, exc
+
+
 def decode_anchors(data: bytes) -> np.ndarray:
     """uint16 [n, 3], sorted by (x, y, z)."""
     buf = memoryview(data)
@@ -296,16 +333,16 @@ def decode_anchors(data: bytes) -> np.ndarray:
     at = 5 + struct.calcsize("<BQQBI")
     if mode not in (0, 1) or bits < 1 or bits > 16 or n_uniq > n:
         raise ValueError("anchor_codec: corrupt header")
+    n_dup = n_exc = 0
     if mode == 1:
         n_dup, n_exc, ox, oy, oz, voxel, i0, i1, i2, m0, m1, m2 = struct.unpack_from("<QQ3qd3f3f", buf, at)
         at += struct.calcsize("<QQ3qd3f3f")
-    extra = zlib.decompress(bytes(buf[at:at + n_extra]))
+    dup, exc = _read_extra(bytes(buf[at:at + n_extra]), mode, int(n), int(n_uniq), int(n_dup), int(n_exc))
     at += n_extra
     if n == 0:
         return np.zeros((0, 3), np.uint16)
     pts, at = _decode_octree(buf, at, int(n_uniq), int(bits))
     if mode == 0:
-        dup = np.frombuffer(extra, dtype="<i8").reshape(-1, 2)
         out = pts
         if dup.size:                                           # multiplicities are indexed in np.unique's (lexicographic) order
             rep = np.ones(pts.shape[0], dtype=np.int64)
@@ -313,8 +350,6 @@ def decode_anchors(data: bytes) -> np.ndarray:
             rep[dup[:, 0]] = dup[:, 1]
             out = np.repeat(pts, rep, axis=0)
     else:
-        dup = np.frombuffer(extra, dtype="<i8", count=2 * n_dup).reshape(-1, 2)
-        exc = np.frombuffer(extra, dtype="<u2", offset=16 * n_dup, count=3 * n_exc).reshape(-1, 3).astype(np.int64)
         if n_dup:                                              # multiplicities are indexed in np.unique's (lexicographic) order
             pts = _lex(pts)
             rep = np.ones(pts.shape[0], dtype=np.int64)
@@ -360,10 +395,11 @@ def decode_anchors_gpu(data: bytes, device="cuda"):
     at = 5 + struct.calcsize("<BQQBI")
     if mode not in (0, 1) or bits < 1 or bits > 16 or n_uniq > n:
         raise ValueError("anchor_codec: corrupt header")
+    n_dup = n_exc = 0
     if mode == 1:
         n_dup, n_exc, ox, oy, oz, voxel, i0, i1, i2, m0, m1, m2 = struct.unpack_from("<QQ3qd3f3f", buf, at)
         at += struct.calcsize("<QQ3qd3f3f")
-    extra = zlib.decompress(bytes(buf[at:at + n_extra]))
+    dup, exc = _read_extra(bytes(buf[at:at + n_extra]), mode, int(n), int(n_uniq), int(n_dup), int(n_exc))      # before the device
     at += n_extra
     dev = torch.device(device)
     if n == 0:
@@ -442,11 +478,8 @@ def decode_anchors_gpu(data: bytes, device="cuda"):
         return torch.repeat_interleave(p, rep, dim=0)
 
     if mode == 0:
-        dup = np.frombuffer(extra, dtype="<i8").reshape(-1, 2)
         out = with_multiplicity(pts, dup)
     else:
-        dup = np.frombuffer(extra, dtype="<i8", count=2 * n_dup).reshape(-1, 2)
-        exc = np.frombuffer(extra, dtype="<u2", offset=16 * n_dup, count=3 * n_exc).reshape(-1, 3).astype(np.int64)
         idx = with_multiplicity(pts, dup) + torch.tensor([ox, oy, oz], dtype=torch.int64, device=dev)
         # Quantize_anchor's grid value of the lattice point, in the float32 arithmetic of _grid_of
         a = (idx.to(torch.float64) * float(voxel)).to(torch.float32)

@@ -1,6 +1,6 @@
 """Multi-GPU data parallelism for the fitting loop: frames of one video shard across the GPUs of a node,
-parameters are replicated, gradients are summed with one RCCL all-reduce per step over xGMI — or, for the per-anchor tensors,
-reduce-scattered over anchor ranges with the Adam update sharded and the updated ranges all-gathered (ShardedAnchorAdam).
+parameters are replicated, gradients are summed over the ranks with RCCL over xGMI: the hash tables and MLPs by all-reduce, the
+per-anchor tensors as (row index, row) lists of each rank's distinct visible anchors while that moves fewer bytes (GradReducer).
 
 The reference is single-GPU (no torch.distributed / NCCL anywhere); this layer is new.
 One process per GPU (torchrun / torch.distributed.run), backend "nccl" (= RCCL on ROCm) on GPUs and "gloo" in
@@ -59,6 +59,21 @@ def plan_group():
     return _plan_group
 
 
+class _NoopPlan:
+    def __init__(self, t, work):
+        self._gmax, self._gmax_work = t, work
+
+
+def plan_group_noop(device):
+    """One collective on the plan group that carries nothing (MAX of a zero count, the shape a StepPlan exchanges): issued by a
+    rank that has no plan to drop in a step every rank repeats, so that the ranks' plan-group sequences stay paired
+    (Trainer.step).  Returns a holder whose ``_gmax_work`` the caller waits for."""
+    if world_size() == 1:
+        return None
+    t = torch.zeros(1, dtype=torch.int64, device=device)
+    return _NoopPlan(t, dist.all_reduce(t, op=dist.ReduceOp.MAX, group=plan_group(), async_op=True))
+
+
 def frame_shard(num_frames: int, rank_: int | None = None, world: int | None = None):
     """Contiguous block [lo, hi) of first-frame indices a rank samples pairs (i, i+1) from.  The blocks
     partition [0, num_frames-1) — every adjacent pair belongs to exactly one rank."""
@@ -105,9 +120,8 @@ class GradReducer:
 
     SMALL = 1 << 18     # elements; below this a tensor joins the flat bucket
 
-    def __init__(self, average: bool = True, sharded: "ShardedAnchorAdam | None" = None):
+    def __init__(self, average: bool = True):
         self.average = average
-        self.sharded = sharded      # per-anchor tensors: reduce-scatter + sharded Adam + all-gather instead of all-reduce
         self.enabled = True         # False: no exchange at all (bench.py measures the step without it; replicas diverge)
         self._hooked = {}           # id(param) -> (param, handle of the hook)
         self._pending = []          # (work, grad) of the collectives in flight
@@ -149,7 +163,7 @@ class GradReducer:
         for k in [k for k in self._hooked if k not in live]:
             self._hooked.pop(k)[1].remove()
         for p in self._params:
-            if id(p) not in self._hooked and (p.numel() >= self.SMALL or (self.sharded is not None and self.sharded.owns(p))):
+            if id(p) not in self._hooked and p.numel() >= self.SMALL:
                 self._hooked[id(p)] = (p, p.register_post_accumulate_grad_hook(self._on_grad))
         self._hook_list = [p for p in self._params if id(p) in self._hooked]
         key = tuple(p.numel() for p in self._hook_list)
@@ -162,10 +176,7 @@ class GradReducer:
         self._armed = True
 
     def _launch(self, p):
-        if self.sharded is not None and self.sharded.owns(p):
-            self.sharded.start(p)          # reduce-scatter of this gradient; its Adam step + all-gather follow in step()
-            self.bytes_sent += 4 * p.numel()
-        elif self._sparse is not None and id(p) in self._sparse[3]:
+        if self._sparse is not None and id(p) in self._sparse[3]:
             self._launch_sparse(p)
         else:
             self._pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p.grad))
@@ -212,11 +223,15 @@ class GradReducer:
         work, p, got = entry
         self._sparse_idx_work.wait()
         work.wait()
-        me = rank()
+        # the SAME fp32 summation order on every rank (((0 + g_0) + g_1) + ... + g_{W-1}): this rank's own rows are cleared and
+        # come back through its gathered list like everybody else's.  Keeping them in place and adding the others in rank order
+        # gave rank 2 of three (g2 + g0) + g1 where ranks 0 and 1 had (g0 + g1) + g2: replicas one ulp apart, which voxel
+        # rounding in adjust_anchor can turn into different anchor counts.  Padding rows are zeros added to row 0.
+        idx, n, _, _ = self._sparse
         g2 = p.grad.reshape(p.shape[0], -1)
+        g2.index_fill_(0, idx[:n], 0.0)
         for r, rows in enumerate(got):
-            if r != me:          # padding rows are zeros added to row 0
-                g2.index_add_(0, self._sparse_idx_all[r], rows)
+            g2.index_add_(0, self._sparse_idx_all[r], rows)
 
     def _launch_ready(self):
         while self._order is not None and self._next < len(self._order) and self._order[self._next] in self._ready:
@@ -247,8 +262,6 @@ class GradReducer:
             if i in self._ready:
                 self._launch(self._ready[i])
         done = {id(g) for _, g in self._pending} | {id(p.grad) for _, p, _ in self._sparse_pending}
-        if self.sharded is not None:
-            done |= {id(p.grad) for p in self._hook_list if p.grad is not None and self.sharded.owns(p)}
         small = [p.grad for p in self._params if p.grad is not None and id(p.grad) not in done]
         n = sum(g.numel() for _, g in self._pending)
         if small:
@@ -276,159 +289,28 @@ class GradReducer:
         return n
 
 
-class ShardedAnchorAdam:
-    """the per-anchor tensors (``_offset``, ``_mask``, ``_anchor_feat``, ``_scaling``: 96 floats per anchor, ~95 % of
-    the gradient bytes) are exchanged by REDUCE-SCATTER over anchor ranges, each rank runs Adam on its own range only (it holds
-    the Adam moments of that range only) and the updated ranges are ALL-GATHERED — instead of an all-reduce followed by W
-    identical Adam updates of everything.  Same bytes on the links (a ring all-reduce is a reduce-scatter + an all-gather), 1/W of
-    the optimizer work and of its state per rank, same numbers as the replicated update (tests/test_dist_cpu.py).
+def sparse_rows_pay(world: int, anchors: int, cap: int) -> bool:
+    """The row-sparse exchange of the per-anchor gradients (GradReducer.set_sparse) against the dense all-reduce: every rank
+    receives the other W - 1 ranks' row lists, each padded to ``cap`` = the largest distinct-visible-anchor count over the ranks,
+    while a ring all-reduce of the dense tensors moves 2 (W - 1) / W of the ``anchors`` rows per rank.  Rows pay while
+    (W - 1) cap < 2 (W - 1) A / W, i.e. cap < 2 A / W: always at two ranks, at eight only when a rank sees less than a quarter
+    of the anchors.  A pure function of numbers every rank holds identically (cap is their agreed maximum)."""
+    return world > 1 and (world - 1) * int(cap) < 2 * (world - 1) * int(anchors) // world
 
-    Range r of a tensor with A rows = rows [r S, min(A, (r + 1) S)), S = ceil(A / W).  The moments live here, not in the wrapped
-    optimizer (whose step skips these parameters: their .grad is cleared); ``gather_state`` puts full-size moments into
-    ``optimizer.state`` for code that edits them (anchor growing / pruning, checkpoints), ``adopt_state`` takes them back."""
 
-    NAMES = ("offset", "mask", "anchor_feat", "scaling")
-
-    def __init__(self, optimizer, names=NAMES):
-        self.optimizer, self.names = optimizer, tuple(names)
-        self._state = {}        # id(param) -> dict(step, m, v, S)
-        self._work = {}         # id(param) -> (param, work handle, padded gradient buffer, reduced shard)
-        optimizer._gsvc_sharded = self      # checkpoint writers find the moments through full_optimizer_state_dict()
-        self.adopt_state()
-
-    # ---- which parameters
-    def _groups(self):
-        return [g for g in self.optimizer.param_groups if g.get("name") in self.names]
-
-    def params(self):
-        return [p for g in self._groups() for p in g["params"]]
-
-    def owns(self, p) -> bool:
-        return any(p is q for q in self.params())
-
-    @staticmethod
-    def _geometry(p):
-        A = p.shape[0]
-        w = p.numel() // max(A, 1)
-        W, r = world_size(), rank()
-        S = (A + W - 1) // W
-        lo = min(A, r * S)
-        hi = min(A, lo + S)
-        return A, w, S, lo, hi
-
-    # ---- per step
-    def start(self, p):
-        """Queue the reduce-scatter of p.grad (from the gradient hook: overlaps the rest of the backward)."""
-        if id(p) in self._work:
-            return
-        A, w, S, lo, hi = self._geometry(p)
-        W = world_size()
-        buf = torch.zeros(S * W, w, device=p.device, dtype=p.dtype)
-        buf[:A].copy_(p.grad.reshape(A, w))
-        out = torch.empty(S, w, device=p.device, dtype=p.dtype)
-        work = dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, async_op=True)
-        self._work[id(p)] = (p, work, buf, out)
-
-    def step(self, average: bool = True, skip_update: bool = False):
-        """Adam on this rank's range of every started tensor, then all-gather of the updated ranges; clears the .grad of the
-        sharded parameters (the wrapped optimizer must not step them).  ``skip_update``: only complete the collectives (the
-        parameters were replaced by anchor growing / pruning after the backward: as in the reference, that iteration's
-        gradient is dropped)."""
-        W = world_size()
-        lr_of = {id(p): float(g["lr"]) for g in self._groups() for p in g["params"]}
-        hp = {id(p): (g["betas"], float(g["eps"])) for g in self._groups() for p in g["params"]}
-        jobs = []
-        for key, (p, work, buf, out) in list(self._work.items()):
-            work.wait()
-            if skip_update or key not in lr_of:
-                continue
-            A, w, S, lo, hi = self._geometry(p)
-            st = self._state.get(key)
-            if st is None or st["S"] != S or st["m"].shape[1] != w:
-                st = self._state[key] = {"step": 0, "S": S, "m": torch.zeros(S, w, device=p.device, dtype=p.dtype),
-                                         "v": torch.zeros(S, w, device=p.device, dtype=p.dtype)}
-            st["step"] += 1
-            g = out.div_(W) if average else out
-            jobs.append((p, g, st, lr_of[key], hp[key], (A, w, S, lo, hi)))
-        self._work.clear()
-        if jobs:
-            self._adam(jobs)
-            for p, g, st, lr, _, (A, w, S, lo, hi) in jobs:
-                shard = torch.zeros(S, w, device=p.device, dtype=p.dtype)
-                shard[:hi - lo].copy_(p.data.reshape(A, w)[lo:hi])
-                full = torch.empty(S * W, w, device=p.device, dtype=p.dtype)
-                dist.all_gather_into_tensor(full, shard)
-                p.data.reshape(A, w).copy_(full[:A])
-        for p in self.params():
-            p.grad = None
-
-    def _adam(self, jobs):
-        """torch.optim.Adam's update (no weight decay / amsgrad) on each job's row range; one multi-tensor launch on the GPU."""
-        p0 = jobs[0][0]
-        if p0.is_cuda:
-            from . import _lib
-            jobs = [j for j in jobs if j[5][4] > j[5][3]]            # (a rank whose range is empty has nothing to update)
-            if not jobs:
-                return
-            arr = (_lib.AdamTensorC * len(jobs))()
-            keep = []
-            b1 = b2 = eps = None
-            for e, (p, g, st, lr, ((bb1, bb2), ee), (A, w, S, lo, hi)) in zip(arr, jobs):
-                if b1 is None:
-                    b1, b2, eps = float(bb1), float(bb2), ee
-                elif (float(bb1), float(bb2), ee) != (b1, b2, eps):
-                    raise NotImplementedError("ShardedAnchorAdam: one (betas, eps) for all groups")
-                rows = p.data.reshape(A, w)[lo:hi]
-                n = (hi - lo) * w
-                gg, m, v = g[:hi - lo].contiguous(), st["m"], st["v"]
-                keep.append(gg)
-                e.param, e.grad, e.exp_avg, e.exp_avg_sq = rows.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr()
-                e.n, e.lr = n, lr
-                e.bias_correction1, e.bias_correction2 = 1.0 - b1 ** st["step"], 1.0 - b2 ** st["step"]
-            _lib.check(_lib.lib().gsvc_adam_step(len(jobs), arr, b1, b2, eps, _lib.current_stream(p0.device)), "gsvc_adam_step")
-            return
-        for p, g, st, lr, ((b1, b2), eps), (A, w, S, lo, hi) in jobs:
-            n = hi - lo
-            if n <= 0:
-                continue
-            rows, gg, m, v = p.data.reshape(A, w)[lo:hi], g[:n], st["m"][:n], st["v"][:n]
-            m.lerp_(gg, 1 - b1)
-            v.mul_(b2).addcmul_(gg, gg, value=1 - b2)
-            bc1, bc2 = 1 - b1 ** st["step"], 1 - b2 ** st["step"]
-            denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
-            rows.addcdiv_(m, denom, value=-lr / bc1)
-
-    # ---- full-size state for code that edits it
-    def gather_state(self):
-        """Full-size ``exp_avg`` / ``exp_avg_sq`` / ``step`` of the sharded parameters into ``optimizer.state`` (all ranks)."""
-        W = world_size()
-        for p in self.params():
-            st = self._state.get(id(p))
-            A, w, S, lo, hi = self._geometry(p)
-            full = {}
-            for k in ("m", "v"):
-                shard = st[k] if st is not None else torch.zeros(S, w, device=p.device, dtype=p.dtype)
-                buf = torch.empty(S * W, w, device=p.device, dtype=p.dtype)
-                dist.all_gather_into_tensor(buf, shard.contiguous())
-                full[k] = buf[:A].reshape(p.shape).clone()
-            self.optimizer.state[p] = {"step": torch.tensor(float(st["step"] if st is not None else 0)),
-                                       "exp_avg": full["m"], "exp_avg_sq": full["v"]}
-
-    def adopt_state(self):
-        """Take this rank's range of whatever full-size moments ``optimizer.state`` holds for the sharded parameters (after
-        anchor growing / pruning, a checkpoint load, or at start) and drop the full-size copies."""
-        self._state = {}
-        for p in self.params():
-            full = self.optimizer.state.get(p)
-            if not full or "exp_avg" not in full:
-                continue
-            A, w, S, lo, hi = self._geometry(p)
-            st = {"step": int(float(full["step"])), "S": S, "m": torch.zeros(S, w, device=p.device, dtype=p.dtype),
-                  "v": torch.zeros(S, w, device=p.device, dtype=p.dtype)}
-            st["m"][:hi - lo].copy_(full["exp_avg"].reshape(A, w)[lo:hi])
-            st["v"][:hi - lo].copy_(full["exp_avg_sq"].reshape(A, w)[lo:hi])
-            self._state[id(p)] = st
-            del self.optimizer.state[p]
+def adjust_anchor_replicated(pc, iteration: int, **kw):
+    """``pc.adjust_anchor(**kw)`` with every rank taking the same decisions: the densification statistics are summed over the
+    ranks first (each rank only saw its own frames), the random thinning of anchor_growing draws from a per-iteration seed, and
+    afterwards only rank 0 carries the surviving accumulator rows into the next interval — the others restart from zero, so that
+    the next sum is (old global + every rank's new observations) and not world_size copies of the survivors."""
+    if world_size() == 1:
+        return pc.adjust_anchor(**kw)
+    allreduce_statistics(pc)
+    devices = [pc.device] if pc.device.type == "cuda" else []
+    with torch.random.fork_rng(devices=devices):
+        torch.manual_seed(977 + iteration)
+        pc.adjust_anchor(**kw)
+    keep_statistics_on_rank0(pc)
 
 
 def allreduce_statistics(pc):
@@ -485,20 +367,6 @@ def any_rank_finish(handle, local_flag: bool) -> bool:
     if ev is not None:
         ev.synchronize()
     return bool(host.item() > 0) or bool(local_flag)
-
-
-def full_optimizer_state_dict(optimizer):
-    """``optimizer.state_dict()`` with the Adam moments of the per-anchor tensors at full size also when a ShardedAnchorAdam holds
-    them range by range (collective in that case: every rank must call it) — what ``capture()`` / ``save_checkpoint`` write.
-    Reading ``optimizer.state_dict()`` directly under GSVC_DP_SHARD would silently drop those moments."""
-    sharded = getattr(optimizer, "_gsvc_sharded", None)
-    if sharded is None or world_size() == 1:
-        return optimizer.state_dict()
-    sharded.gather_state()
-    try:
-        return optimizer.state_dict()
-    finally:
-        sharded.adopt_state()
 
 
 def broadcast_parameters(module, src: int = 0):

@@ -235,9 +235,7 @@ def load_ply_sparse_gaussian(pc, path):
 
 # ------------------------------------------------------------------------------------------------ checkpoints
 def _optimizer_state(optimizer):
-    """Optimizer state with the sharded per-anchor moments gathered (gsvc_amd.dist.full_optimizer_state_dict)."""
-    from .dist import full_optimizer_state_dict
-    return full_optimizer_state_dict(optimizer)
+    return optimizer.state_dict()
 
 
 def _plain(obj):

@@ -292,21 +292,27 @@ class _RasterizeMany(torch.autograd.Function):
         L = _lib.lib()
         side = _side_streams(dev, len(ctx.states))
         main = torch.cuda.current_stream(dev)
-        for sd in side:
-            sd.wait_stream(main)
-        scratches = []              # alive until the join below
-        for r, st in enumerate(ctx.states):
-            a, b = ctx.bounds[r], ctx.bounds[r + 1]
-            g = grads[r]
-            stream = C.c_void_p(side[r % len(side)].cuda_stream) if side else _lib.current_stream(dev)
+        # everything the side streams read is produced / allocated on the main stream BEFORE the fork: an image gradient that is
+        # not contiguous fp32 (an expanded gradient of images[r].sum(), autocast) is converted by a copy kernel on main, and the
+        # scratch rows are allocated there — converting after the fork left the side stream's backward reading the copy's
+        # destination with nothing ordering the two
+        gs = [None if g is None else _as_f32(g, "grad_image") for g in grads[:len(ctx.states)]]
+        scratches = [None if g is None else torch.empty(backward_scratch_floats(st.P, st.max_instances), device=dev)
+                     for g, st in zip(gs, ctx.states)]              # alive until the join below
+        for r, g in enumerate(gs):
             if g is None:           # a render nothing was computed from: its Gaussians get no gradient
+                a, b = ctx.bounds[r], ctx.bounds[r + 1]
                 for t in (d3, d2, dc, do, ds, dq):
                     t[a:b].zero_()
+        for sd in side:
+            sd.wait_stream(main)
+        for r, st in enumerate(ctx.states):
+            a, b = ctx.bounds[r], ctx.bounds[r + 1]
+            g, scratch = gs[r], scratches[r]
+            if g is None:
                 continue
-            g = _as_f32(g, "grad_image")
+            stream = C.c_void_p(side[r % len(side)].cuda_stream) if side else _lib.current_stream(dev)
             P = st.P
-            scratch = torch.empty(backward_scratch_floats(P, st.max_instances), device=dev)
-            scratches.append((scratch, g))
             _lib.check(L.gsvc_raster_backward(
                 C.byref(st.cs), P, st.max_instances, _lib.ptr(means3D[a:b]), _lib.ptr(colors[a:b]), _lib.ptr(opacities[a:b]),
                 _lib.ptr(scales[a:b]), _lib.ptr(rotations[a:b]), _lib.ptr(st.radii), _lib.ptr(st.geom), _lib.ptr(st.binning),
@@ -314,7 +320,7 @@ class _RasterizeMany(torch.autograd.Function):
                 _lib.ptr(ds[a:b]), _lib.ptr(dq[a:b]), _lib.ptr(scratch), stream), "gsvc_raster_backward")
         for sd in side:
             main.wait_stream(sd)
-        del scratches
+        del scratches, gs
         return d3, d2, dc, do, ds, dq, None, None, None
 
 

@@ -47,9 +47,7 @@ def evaluate(pc, dataset, pipe, bg_color, frame_ids=None, batch: int = 8) -> dic
 
 
 def _optimizer_state(optimizer):
-    """Optimizer state with the sharded per-anchor moments gathered (gsvc_amd.dist.full_optimizer_state_dict)."""
-    from .dist import full_optimizer_state_dict
-    return full_optimizer_state_dict(optimizer)
+    return optimizer.state_dict()
 
 
 def _plain(obj):

@@ -100,8 +100,7 @@ def _mean_over_selected(values, r):
 
 
 class Trainer:
-    def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0, batched: bool = True, prefetch: bool = True,
-                 shard_optimizer: bool = False):
+    def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0, batched: bool = True, prefetch: bool = True):
         self.batched = batched
         # prefetch: the next step's frame pair is drawn, its visibility test run and every data-dependent index list of its
         # generation pass queued at the END of a step (gsvc_amd.generate.StepPlan): the next step then starts with one wait
@@ -119,33 +118,10 @@ class Trainer:
         # changes nothing, so the batched step does not compute it unless a non-zero rate is configured
         self.anchor_grad = bool(getattr(opt, "position_lr_init", 0.0) or getattr(opt, "position_lr_final", 0.0))
         gaussians.anchor_static = not self.anchor_grad      # the quantised anchors may be cached between steps (prefilter_geometry)
-        # GSVC_DP_SHARD=1 (or shard_optimizer=True): reduce-scatter + sharded Adam + all-gather for the per-anchor tensors
-        #  instead of all-reduce + replicated Adam; same parameters after the step (tests/test_dist_cpu.py)
-        self.sharded = None
-        if ((shard_optimizer or os.environ.get("GSVC_DP_SHARD", "0") not in ("", "0")) and gdist.world_size() > 1
-                and gaussians.optimizer is not None):
-            self.sharded = gdist.ShardedAnchorAdam(gaussians.optimizer)
-        self.reducer = gdist.GradReducer(sharded=self.sharded)
+        self.reducer = gdist.GradReducer()
         gdist.plan_group()      # created HERE, where every rank stands at the same point (creating a group is itself collective)
         self._mask_reg_weight = 0.0
         self._ovf_handle = None
-
-    def full_optimizer_state(self):
-        """Context manager around code that reads or edits ``pc.optimizer.state`` of the per-anchor tensors (checkpoints,
-        ``capture()``): under GSVC_DP_SHARD the Adam moments live range by range on the ranks; inside the block every rank
-        holds them full size (collective: all ranks must enter)."""
-        import contextlib
-
-        @contextlib.contextmanager
-        def scope():
-            if self.sharded is not None:
-                self.sharded.gather_state()
-            try:
-                yield self.pc.optimizer
-            finally:
-                if self.sharded is not None:
-                    self.sharded.adopt_state()
-        return scope()
 
     def _two_views(self, frame, mode, retain_grad):
         f = render(frame, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode)
@@ -161,16 +137,30 @@ class Trainer:
         out = self._step(iteration, frame_idx)
         if out is None:      # a rasterizer instance buffer overflowed (capacity now raised): repeat the step
             self.repeated_steps = getattr(self, "repeated_steps", 0) + 1
+            dropped = None
             if self._early is not None:
                 # the guarded early update saw the overflow word and wrote nothing: only its step counts moved.  The plan it
                 # queued is for the NEXT frame pair; the repeat draws its own lists.
                 self.pc.optimizer.rewind(self._early[0])
+                dropped = self._early[3]          # its count exchange is in flight: the tensors stay alive until the repeat is done
                 self._early = None
-                self._plan = None
+            elif self.prefetch and self.pc._anchor.is_cuda and gdist.world_size() > 1:
+                # Whether the early tail ran is a rank-LOCAL fact (its row threshold and reducer.complete() depend on the rank's
+                # own views), and it queued a plan = one collective on the plan group.  A rank that did not run it answers with a
+                # matching no-op exchange, so that every rank has issued exactly ONE plan-group collective per attempted step:
+                # otherwise the repeat's end-of-step plan on this rank would pair with the other rank's dropped one and every
+                # later distinct_cap would be one step out of phase between the ranks.
+                dropped = gdist.plan_group_noop(self.pc._anchor.device)
+            # the repeat draws its own index lists on EVERY rank (no plan -> dense gradient exchange everywhere): a rank that kept
+            # its plan would exchange rows while a rank that dropped its early plan all-reduces
+            self._plan = None
             self.pc.optimizer.zero_grad(set_to_none=True)
             out = self._step(iteration, frame_idx if frame_idx is not None else self._last_idx, early=False)     # the same frame pair again
             if out is None:
                 raise RuntimeError("rasterizer instance buffer overflowed twice in a row")
+            if dropped is not None and getattr(dropped, "_gmax_work", None) is not None:
+                dropped._gmax_work.wait()
+            del dropped
         self.controller.step()
         if self._early is not None:          # the next step's plan was queued from inside the backward (_early_tail)
             _, self._plan_idx, self._plan_mode, self._plan = self._early
@@ -230,14 +220,14 @@ class Trainer:
     def _sparse_dp(self, plan):
         """Row-sparse gradient exchange of the per-anchor tensors: needs the step plan (the rank's distinct visible anchors and the
         largest such count over the ranks) and the replicated Adam; GSVC_DP_SPARSE=0 keeps the dense all-reduce."""
-        if not (plan is not None and gdist.world_size() > 1 and self.sharded is None and self.reducer.enabled and not self.anchor_grad
+        if not (plan is not None and gdist.world_size() > 1 and self.reducer.enabled and not self.anchor_grad
                 and getattr(plan, "distinct_cap", None) is not None and os.environ.get("GSVC_DP_SPARSE", "1") != "0"):
             return False
         # every rank receives the other ranks' row lists (all-gather, padded to the largest): worth it while those rows are fewer
         # than what a ring all-reduce of the dense tensors moves (2 (W - 1) / W of the anchors) — two ranks always, eight ranks
         # only when a rank sees less than a quarter of the anchors.  The same decision on every rank (cap is their maximum).
-        W, A = gdist.world_size(), int(self.pc._anchor.shape[0])
-        return os.environ.get("GSVC_DP_SPARSE") == "1" or (W - 1) * plan.distinct_cap < 2 * (W - 1) * A // W
+        return os.environ.get("GSVC_DP_SPARSE") == "1" or gdist.sparse_rows_pay(gdist.world_size(), int(self.pc._anchor.shape[0]),
+                                                                                  plan.distinct_cap)
 
     def _views(self, frame_idx):
         """The step's four views: (frame, frame seen from the opposite side) of the two adjacent frames."""
@@ -252,21 +242,9 @@ class Trainer:
     def _adjust_anchor(self, iteration):
         """Densify / prune (reference pipeline/train.py:567-569).  Under data parallelism every rank must take the same
         decisions: the statistics are summed over ranks first and the random thinning uses a per-iteration seed."""
-        opt, pc = self.opt, self.pc
-        if gdist.world_size() > 1:
-            gdist.allreduce_statistics(pc)
-            devices = [pc.device] if pc.device.type == "cuda" else []
-            with torch.random.fork_rng(devices=devices):
-                torch.manual_seed(977 + iteration)
-                pc.adjust_anchor(check_interval=opt.update_interval, success_threshold=opt.success_threshold,
-                                 grad_threshold=opt.densify_grad_threshold, min_opacity=opt.min_opacity)
-            # the accumulators now hold the GLOBAL sums on every rank, and adjust_anchor keeps the rows that did not cross
-            # its thresholds: only rank 0 carries them into the next interval, the other ranks restart from zero, so that
-            # the next all-reduce yields (old global sum + every rank's new observations) and not world_size copies of it
-            gdist.keep_statistics_on_rank0(pc)
-        else:
-            pc.adjust_anchor(check_interval=opt.update_interval, success_threshold=opt.success_threshold,
-                             grad_threshold=opt.densify_grad_threshold, min_opacity=opt.min_opacity)
+        opt = self.opt
+        gdist.adjust_anchor_replicated(self.pc, iteration, check_interval=opt.update_interval, success_threshold=opt.success_threshold,
+                                       grad_threshold=opt.densify_grad_threshold, min_opacity=opt.min_opacity)
 
     def _step(self, iteration: int, frame_idx: int | None = None, early: bool = True):
         for g in grid_tables(self.pc):
@@ -353,7 +331,7 @@ class Trainer:
         else:
             self.reducer.set_sparse(None, 0, [])
         handles = []
-        if (early and self.batched and self.prefetch and pc._anchor.is_cuda and self.sharded is None
+        if (early and self.batched and self.prefetch and pc._anchor.is_cuda
                 and (gdist.world_size() == 1 or (self.reducer.enabled and self.reducer._order is not None))
                 and not self.anchor_grad      # a trained anchor tensor moves behind the early plan's visibility test
                 and mode == GenerateMode.TRAINING_ENTROPY and iteration < opt.iterations and not self.controller.gaussian_adjust_anchor
@@ -383,11 +361,6 @@ class Trainer:
             # the only host synchronisation of the step after the visibility test: the 4 renders' instance counters
             _, overflowed = resolve_deferred([r.raster_state for r in renders])
             if gdist.any_rank_finish(ovf_handle, overflowed):      # replicas repeat the step together (their collectives must pair up)
-                if self.sharded is not None:
-                    # the reduce-scatters this backward started carry gradients the rasterizer declares invalid: wait for
-                    # them and drop them, so that the repeated step's hooks start fresh ones (start() skips a parameter
-                    # that still has one outstanding, and step() would then run Adam on the stale shards)
-                    self.sharded.step(skip_update=True)
                 return None
             for r in renders:
                 r.num_rendered = r.raster_state.counters()[0]
@@ -400,18 +373,10 @@ class Trainer:
                         pc.training_statis(r)
             adjusted = False
             if self.controller.gaussian_adjust_anchor:
-                if self.sharded is not None:
-                    self.sharded.gather_state()           # anchor growing / pruning edits full-size Adam moments
                 self._adjust_anchor(iteration)
                 adjusted = True
             if self.controller.clean_denorm:
                 pc.opacity_accum = pc.offset_gradient_accum = pc.offset_denom = None
-            if self.sharded is not None:
-                # the reduce-scatters started in the backward complete here; after an adjust_anchor the parameters are new
-                # tensors without a gradient (the reference drops that iteration's update for them as well)
-                self.sharded.step(skip_update=adjusted or not iteration < opt.iterations)
-                if adjusted:
-                    self.sharded.adopt_state()
             if iteration < opt.iterations:
                 pc.optimizer.step()
                 pc.optimizer.zero_grad(set_to_none=True)

@@ -35,11 +35,6 @@ def main():
         assert np.isfinite(float(out.loss))
         counts.append(pc._anchor.shape[0])
     torch.cuda.synchronize()
-    if tr.sharded is not None:                  # GSVC_DP_SHARD=1: the moments live range by range on the ranks
-        assert pc._anchor_feat not in pc.optimizer.state
-        tr.sharded.gather_state()
-    else:
-        assert not os.environ.get("GSVC_DP_SHARD")
     st = pc.optimizer.state[pc._anchor_feat]
     sig = torch.tensor([float(pc._anchor.shape[0]), float(pc._anchor.double().sum()), float(pc._anchor_feat.double().abs().sum()),
                         float(pc._offset.double().abs().sum()), float(st["exp_avg_sq"].double().sum()),
@@ -50,7 +45,7 @@ def main():
         assert len(set(counts)) > 1 and counts[-1] != a0, counts
         for g in gathered[1:]:
             assert torch.allclose(g, gathered[0], rtol=1e-9, atol=0.0), (gathered[0].tolist(), g.tolist())
-        print("DP_DENSIFY_OK", counts[0], "->", counts[-1], "sharded" if tr.sharded is not None else "replicated", flush=True)
+        print("DP_DENSIFY_OK", counts[0], "->", counts[-1], flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

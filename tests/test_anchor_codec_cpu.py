@@ -82,3 +82,46 @@ def test_corrupt_streams_are_refused():
         assert not np.array_equal(out, q[np.lexsort((q[:, 2], q[:, 1], q[:, 0]))])
     except ValueError:
         pass
+
+
+def _with_extra(data: bytes, pairs: np.ndarray, n=None) -> bytes:
+    """The grid-mode stream ``data`` with its multiplicity section replaced by ``pairs`` (and optionally the anchor count)."""
+    import struct
+    import zlib
+    head = struct.calcsize("<BQQBI")
+    mode, n0, n_uniq, bits, n_extra = struct.unpack_from("<BQQBI", data, 5)
+    assert mode == 0
+    extra = zlib.compress(np.asarray(pairs, dtype="<i8").tobytes(), 9)
+    return data[:5] + struct.pack("<BQQBI", mode, n0 if n is None else n, n_uniq, bits, len(extra)) + extra + data[5 + head + n_extra:]
+
+
+@pytest.mark.parametrize("decoder", ["host", "gpu"])
+def test_hostile_multiplicity_sections_are_refused_before_they_index_anything(decoder):
+    """the (index, count) pairs of an untrusted anchor.b went straight into rep[idx] = cnt / repeat_interleave.
+    The GPU decoder must refuse them on the host (an out-of-range index on the device is an assert that poisons the context):
+    this test runs it WITHOUT a GPU — every case raises before the first device call."""
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 4096, (2000, 3)).astype(np.uint16)
+    q[100:110] = q[0]                                                 # one point eleven times
+    data = ac.encode_anchors(q)
+    dec = ac.decode_anchors if decoder == "host" else (lambda b: ac.decode_anchors_gpu(b, device="cpu"))
+    n_uniq = np.unique(q, axis=0).shape[0]
+    for pairs, n in (([[n_uniq, 11]], None),                          # index past the unique points
+                     ([[-1, 11]], None),                              # negative index
+                     ([[0, 1 << 40]], None),                          # a multiplicity that would allocate terabytes
+                     ([[0, 1]], None),                                # multiplicity below 2
+                     ([[3, 6], [3, 6]], None),                        # the same point listed twice
+                     ([[0, 12]], None),                               # counts that do not add up to n
+                     ([[0, 11]], 1 << 40)):                           # an absurd anchor count in the header
+        with pytest.raises(ValueError, match="anchor_codec"):
+            dec(_with_extra(data, np.array(pairs, dtype=np.int64), n))
+    import struct
+    import zlib
+    bomb = zlib.compress(bytes(64 << 20), 9)                          # 64 MiB of zeros in 64 KiB: inflated only up to the header's limit
+    head = struct.calcsize("<BQQBI")
+    mode, n0, nu, bits, n_extra = struct.unpack_from("<BQQBI", data, 5)
+    with pytest.raises(ValueError, match="larger than its header allows"):
+        dec(data[:5] + struct.pack("<BQQBI", mode, n0, nu, bits, len(bomb)) + bomb + data[5 + head + n_extra:])
+    if decoder == "host":
+        want = q[np.lexsort((q[:, 2], q[:, 1], q[:, 0]))]
+        assert np.array_equal(ac.decode_anchors(data), want)

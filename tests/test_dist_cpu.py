@@ -132,96 +132,6 @@ def test_two_rank_gloo():
     assert w0 == w1                                   # broadcast made the replicas identical
 
 
-def _sharded_worker(rank, world, port, q):
-    """ShardedAnchorAdam (reduce-scatter over anchor ranges + sharded Adam + all-gather) against a single-process torch Adam
-    on the rank-averaged gradients: same parameters on every rank after every step, same moments when gathered."""
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    from gsvc_amd import dist as gd
-    gd.init_from_env("gloo")
-    A = 7                                             # not a multiple of the world size: the last range is short
-    shapes = {"offset": (A, 2, 3), "mask": (A, 2, 1), "anchor_feat": (A, 5), "scaling": (A, 6), "mlp": (4, 3)}
-    lrs = {"offset": 0.01, "mask": 0.02, "anchor_feat": 0.0075, "scaling": 0.007, "mlp": 0.005}
-
-    def build():
-        torch.manual_seed(1)
-        ps = {k: torch.nn.Parameter(torch.randn(*sh)) for k, sh in shapes.items()}
-        opt = torch.optim.Adam([{"params": [ps[k]], "lr": lrs[k], "name": k} for k in shapes], lr=0.0, eps=1e-15)
-        return ps, opt
-
-    def coeff(k, r, step):                            # d loss / d p on rank r at `step`
-        g = torch.Generator().manual_seed(100 * step + 10 * r + len(k))
-        return torch.randn(*shapes[k], generator=g)
-
-    ps, opt = build()
-    ref_ps, ref_opt = build()
-    sh = gd.ShardedAnchorAdam(opt)
-    red = gd.GradReducer(sharded=sh)
-    assert sorted(n for n in shapes if sh.owns(ps[n])) == ["anchor_feat", "mask", "offset", "scaling"]
-    for step in range(1, 5):
-        red.arm(list(ps.values()))
-        sum((ps[k] * coeff(k, rank, step)).sum() for k in shapes).backward()
-        red.finish()
-        assert torch.allclose(ps["mlp"].grad, sum(coeff("mlp", r, step) for r in range(world)) / world, atol=1e-6)
-        if step == 3:                                 # state round trip through the wrapped optimizer (what anchor growing edits)
-            sh.gather_state()
-            for k in ("offset", "scaling"):
-                assert torch.allclose(opt.state[ps[k]]["exp_avg"], ref_opt.state[ref_ps[k]]["exp_avg"], atol=1e-7)
-                assert torch.allclose(opt.state[ps[k]]["exp_avg_sq"], ref_opt.state[ref_ps[k]]["exp_avg_sq"], atol=1e-9)
-            sh.adopt_state()
-            assert ps["offset"] not in opt.state
-        sh.step()
-        assert all(ps[k].grad is None for k in ("offset", "mask", "anchor_feat", "scaling"))
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        for k in shapes:
-            ref_ps[k].grad = sum(coeff(k, r, step) for r in range(world)) / world
-        ref_opt.step()
-        for k in shapes:
-            assert torch.allclose(ps[k], ref_ps[k], atol=2e-7), (step, k, (ps[k] - ref_ps[k]).abs().max().item())
-            other = [torch.zeros_like(ps[k]) for _ in range(world)]
-            dist.all_gather(other, ps[k].data)
-            assert torch.equal(other[0], other[1]), (step, k)       # replicas stay identical
-    # a step whose parameters were replaced after the backward completes its collectives and updates nothing
-    before = {k: ps[k].detach().clone() for k in shapes}
-    red.arm(list(ps.values()))
-    sum((ps[k] * coeff(k, rank, 9)).sum() for k in shapes).backward()
-    red.finish()
-    sh.step(skip_update=True)
-    assert all(torch.equal(ps[k], before[k]) for k in ("offset", "mask", "anchor_feat", "scaling"))
-    # ... which is also what Trainer does with a step whose rasterizer buffers overflowed (its gradients are invalid) before it
-    # repeats the step: the repeat's hooks must start FRESH reduce-scatters, and its update must come from the repeat's
-    # gradients alone (a collective left in flight made start() skip the parameter and Adam run on the stale shards)
-    opt.zero_grad(set_to_none=True)
-    red.arm(list(ps.values()))
-    sum((ps[k] * coeff(k, rank, 10)).sum() for k in shapes).backward()
-    red.finish()
-    sh.step()
-    opt.step()
-    opt.zero_grad(set_to_none=True)
-    for k in shapes:
-        ref_ps[k].grad = sum(coeff(k, r, 10) for r in range(world)) / world
-    ref_opt.step()
-    for k in shapes:
-        assert torch.allclose(ps[k], ref_ps[k], atol=2e-7), ("after the dropped step", k, (ps[k] - ref_ps[k]).abs().max().item())
-    dist.barrier()
-    dist.destroy_process_group()
-    q.put((rank, "ok"))
-
-
-def test_sharded_anchor_adam_two_rank_gloo():
-    world, port = 2, 29500 + (os.getpid() + 7) % 400
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=180)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    assert sorted(q.get(timeout=5)[0] for _ in range(world)) == [0, 1]
-
-
 def test_frame_shard_partitions():
     from gsvc_amd.dist import frame_shard
     with pytest.raises(ValueError, match="adjacent-frame pairs"):
@@ -235,3 +145,154 @@ def test_frame_shard_partitions():
         assert max(sizes) - min(sizes) <= 1
     from gsvc_amd import dist as gd
     assert gd.world_size() == 1 and gd.rank() == 0 and gd.allreduce_gradients([]) == 0
+
+
+def _many_rank_worker(rank, world, port, q):
+    """What two ranks cannot show (a + b is commutative): one summation order on every rank of the row-sparse exchange, the
+    agreed collective order with every rank finishing its gradients in another order, the sparse / dense decision on both sides
+    of cap = 2 A / W, and densification from unevenly sharded statistics."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import numpy as np
+    from gsvc_amd import dist as gd
+    gd.init_from_env("gloo")
+    W = world
+
+    def same_on_all_ranks(t, what):
+        got = [torch.zeros_like(t) for _ in range(W)]
+        dist.all_gather(got, t.contiguous())
+        for r in range(1, W):
+            assert torch.equal(got[0], got[r]), (what, "rank", r, float((got[0] - got[r]).abs().max()))
+        return got
+
+    # ---- 1. row-sparse exchange: mean of the ranks' gradients, the SAME BITS on every rank, replicas stay identical under Adam
+    A = 257
+    shapes = {"offset": (A, 2, 3), "mask": (A, 2, 1), "anchor_feat": (A, 5), "scaling": (A, 6)}
+    torch.manual_seed(5)
+    ps = {k: torch.nn.Parameter(torch.randn(*sh)) for k, sh in shapes.items()}
+    mlp = torch.nn.Parameter(torch.randn(4, 3))
+    opt = torch.optim.Adam([{"params": [p], "lr": 0.01} for p in list(ps.values()) + [mlp]], eps=1e-15)
+    red = gd.GradReducer()
+    red.SMALL = 16
+    for step in range(1, 4):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        n = int(torch.randint(20, 120, (1,), generator=g))                 # this rank's distinct visible anchors: its own count
+        idx = torch.randperm(A, generator=g)[:n].sort().values
+        capt = torch.tensor([n])
+        dist.all_reduce(capt, op=dist.ReduceOp.MAX)
+        cap = int(capt)
+        coef = {k: torch.zeros(*sh) for k, sh in shapes.items()}
+        for k in shapes:                                                   # values spread over many binades: fp32 sums depend on the order
+            v = torch.randn(n, *shapes[k][1:], generator=g) * torch.exp2(torch.randint(-12, 12, (n,), generator=g).float()).view(
+                n, *([1] * (len(shapes[k]) - 1)))
+            coef[k][idx] = v
+        cm = torch.randn(4, 3, generator=g)
+        opt.zero_grad(set_to_none=True)
+        red.arm(list(ps.values()) + [mlp])
+        red.set_sparse(idx, cap, list(ps.values()))
+        (sum((ps[k] * coef[k]).sum() for k in shapes) + (mlp * cm).sum()).backward()
+        red.finish()
+        assert red._sparse is not None
+        for k in shapes:
+            locals_ = [torch.zeros_like(coef[k]) for _ in range(W)]
+            dist.all_gather(locals_, coef[k])
+            want = torch.stack(locals_).double().sum(0) / W
+            scale = float(want.abs().max())
+            assert float((ps[k].grad.double() - want).abs().max()) <= 1e-6 * scale, (step, k)
+            same_on_all_ranks(ps[k].grad, f"sparse grad {k} step {step}")
+        opt.step()
+        for k in shapes:
+            same_on_all_ranks(ps[k].data, f"parameter {k} after step {step}")
+        same_on_all_ranks(mlp.data, "mlp")
+
+    # ---- 2. one agreed launch order although every rank completes its gradients in its own order
+    red2 = gd.GradReducer()
+    red2.SMALL = 16
+    big = [torch.nn.Parameter(torch.ones(8, 4) * (k + 1)) for k in range(5)]
+    for it in range(3):
+        for p in big:
+            p.grad = None
+        red2.arm(big)
+        x = torch.ones(1, requires_grad=True)
+        perm = torch.randperm(5, generator=torch.Generator().manual_seed(rank)).tolist()     # later-created nodes run first
+        loss = x.sum() * 0
+        for k in perm:
+            loss = loss + (big[k] * float(rank + 1 + k)).sum() * (x * 0 + 1).sum()
+        loss.backward()
+        red2.finish()
+        assert red2._seen == perm[::-1], (rank, red2._seen, perm)
+        order = torch.tensor(red2._order)
+        same_on_all_ranks(order, "agreed order")
+        for k, p in enumerate(big):
+            want = sum(r + 1 + k for r in range(W)) / W
+            assert torch.allclose(p.grad, torch.full_like(p, want)), (rank, it, k)
+
+    # ---- 3. rows or dense: the same answer on every rank, on both sides of cap = 2 A / W
+    A3 = 100_800                                                          # divisible by 3 and by 8: the edge is an integer
+    edge = 2 * A3 // W
+    mine = torch.tensor([edge - 1 - 17 * rank])                            # every rank sees another count; the largest decides
+    for shift, want in ((0, True), (1, False), (5000, False), (-5000, True)):
+        t = mine + shift
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ans = gd.sparse_rows_pay(W, A3, int(t))
+        assert ans is want, (W, int(t), edge, ans)
+        same_on_all_ranks(torch.tensor([int(ans)]), "sparse / dense decision")
+    assert gd.sparse_rows_pay(1, A3, 1) is False and gd.sparse_rows_pay(2, A3, A3 - 1) is True
+
+    # ---- 4. densification from statistics that live unevenly on the ranks: same anchors everywhere, and the anchors a single
+    # process gets from the summed statistics under the same seed
+    from test_densify_cpu import T, _model
+    g = np.load(os.path.join(ROOT, "tests", "golden", "densify.npz"))
+    kw = dict(check_interval=100, success_threshold=0.8, grad_threshold=0.0005, min_opacity=0.005)
+
+    def build():
+        pc = _model(g)
+        pc.update_learning_rate(2000)
+        for nm in ("_offset", "_mask", "_anchor_feat", "_scaling"):
+            getattr(pc, nm).grad = T(g["grad::" + nm])
+        pc.optimizer.step()
+        return pc
+    pc = build()
+    full = {nm: T(g["stat::" + nm]) for nm in ("offset_denom", "offset_gradient_accum", "anchor_demon", "opacity_accum")}
+    for nm, t in full.items():
+        rows = t.shape[0]
+        cuts = [0] + sorted(torch.randperm(rows - 1, generator=torch.Generator().manual_seed(3))[:W - 1].add(1).tolist()) + [rows]
+        part = torch.zeros_like(t)                                         # rank r observed rows [cuts[r], cuts[r + 1]): uneven blocks
+        part[cuts[rank]:cuts[rank + 1]] = t[cuts[rank]:cuts[rank + 1]]
+        setattr(pc, nm, part)
+    gd.adjust_anchor_replicated(pc, 700, **kw)
+    assert pc._anchor.shape[0] != g["in::_anchor"].shape[0]
+    for nm in ("_anchor", "_offset", "_mask", "_anchor_feat", "_scaling"):
+        same_on_all_ranks(getattr(pc, nm).data, "after adjust_anchor: " + nm)
+    st = pc.optimizer.state[pc._anchor_feat]
+    same_on_all_ranks(st["exp_avg_sq"], "Adam moments after adjust_anchor")
+    single = build()
+    for nm, t in full.items():
+        setattr(single, nm, t.clone())
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(977 + 700)
+        single.adjust_anchor(**kw)
+    for nm in ("_anchor", "_offset", "_anchor_feat"):
+        assert torch.equal(getattr(pc, nm).data, getattr(single, nm).data), nm
+    for nm in full:        # survivors are carried by rank 0 alone: the next interval's sum counts them once
+        mine_ = getattr(pc, nm)
+        assert torch.equal(mine_, getattr(single, nm)) if rank == 0 else not mine_.any(), nm
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_many_rank_gloo(world):
+    port = 29500 + (os.getpid() + 31 * world) % 400
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_many_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(world)) == list(range(world))

@@ -773,26 +773,18 @@ def test_two_rank_step_averages_gradients_over_rccl():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sharded", [False, True])
-def test_two_ranks_keep_identical_anchors_through_densification(sharded):
+def test_two_ranks_keep_identical_anchors_through_densification():
     """Data-parallel densification: statistics summed over ranks + a per-iteration seed for the random thinning keep the
-    replicas' anchor sets, parameters and Adam moments identical across adjust_anchor (tests/_dp_densify_worker.py) — with
-    the replicated Adam behind an all-reduce, and with GSVC_DP_SHARD=1 (reduce-scatter over anchor ranges, sharded Adam,
-    all-gather: gsvc_amd.dist.ShardedAnchorAdam), whose moments are gathered around every adjust_anchor."""
+    replicas' anchor sets, parameters and Adam moments identical across adjust_anchor (tests/_dp_densify_worker.py)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29900 + (os.getpid() + int(sharded)) % 90
+    port = 29900 + os.getpid() % 90
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "_dp_densify_worker.py")]
-    env = dict(os.environ)
-    env.pop("GSVC_DP_SHARD", None)
-    if sharded:
-        env["GSVC_DP_SHARD"] = "1"
-    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
+    out = subprocess.run(cmd, cwd=root, env=dict(os.environ), capture_output=True, text=True, timeout=420)
     assert out.returncode == 0 and "DP_DENSIFY_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
-    assert ("sharded" if sharded else "replicated") in out.stdout
 
 
 @pytest.mark.gpu
