@@ -67,8 +67,81 @@ def _oracle_gridencoder_module():
     return m
 
 
-def install():
-    """Install stubs + patches; returns the CpuMode context to wrap reference calls in."""
+def _oracle_rasterizer_module():
+    """`diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer` backed by oracle/raster_oracle.c: the settings type with the
+    fields the reference's call sites construct it from (renderer.py:63-83, preprocess.py:58-83), the rasterizer as an autograd
+    node (image, radii, num_rendered; means2D receives the screen-space gradient) and visible_filter.  With this in the slot
+    the UNMODIFIED reference render() / prefilter_voxel() run on PyTorch-CPU (make_golden_prod.py)."""
+    from typing import NamedTuple
+    import oracle
+    m = types.ModuleType("diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer")
+
+    class GaussianRasterizationSettings(NamedTuple):
+        image_height: int
+        image_width: int
+        x_min: float
+        y_min: float
+        scale: float
+        threshold: float
+        bg: torch.Tensor
+        scale_modifier: float
+        viewmatrix: torch.Tensor
+        sh_degree: int
+        campos: torch.Tensor
+        prefiltered: bool
+        debug: bool
+
+    def _settings(rs):
+        return oracle.make_settings(rs.image_height, rs.image_width, rs.x_min, rs.y_min, rs.scale, rs.threshold,
+                                    rs.viewmatrix.detach().contiguous().numpy(), bg=[float(v) for v in rs.bg],
+                                    scale_modifier=rs.scale_modifier)
+
+    class _Rasterize(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, rs, holder):
+            st = _settings(rs)
+            a = [t.detach().contiguous().numpy() for t in (means3D, colors, opacities, scales, rotations)]
+            fwd = oracle.raster_forward(st, *a)
+            ctx.st, ctx.arrays, ctx.fwd = st, a, fwd
+            holder["forward"] = fwd
+            radii = torch.from_numpy(fwd.radii.copy())
+            ctx.mark_non_differentiable(radii)
+            return torch.from_numpy(fwd.image.copy()), radii
+
+        @staticmethod
+        def backward(ctx, g_image, _g_radii):
+            b = oracle.raster_backward(ctx.st, *ctx.arrays, ctx.fwd, g_image.detach().contiguous().numpy())
+            t = torch.from_numpy
+            return t(b.means3D), t(b.means2D), t(b.colors), t(b.opacities), t(b.scales), t(b.rotations), None, None
+
+    class GaussianRasterizer(torch.nn.Module):
+        last = {}                                  # the oracle's forward state of the most recent call (borderline mask)
+
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
+            assert cov3D_precomp is None
+            radii, _, _ = oracle.raster_preprocess(_settings(self.raster_settings), means3D.detach().contiguous().numpy(),
+                                                   scales.detach().contiguous().numpy(), rotations.detach().contiguous().numpy())
+            return torch.from_numpy(radii.copy())
+
+        def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                    cov3D_precomp=None):
+            assert shs is None and cov3D_precomp is None
+            image, radii = _Rasterize.apply(means3D, means2D, colors_precomp, opacities, scales, rotations, self.raster_settings,
+                                            GaussianRasterizer.last)
+            return image, radii, GaussianRasterizer.last["forward"].num_rendered
+
+    m.GaussianRasterizationSettings = GaussianRasterizationSettings
+    m.GaussianRasterizer = GaussianRasterizer
+    return m
+
+
+def install(rasterizer: bool = False):
+    """Install stubs + patches; returns the CpuMode context to wrap reference calls in.  ``rasterizer``: fill the rasterizer slot
+    with the oracle (the reference's render() / prefilter_voxel() then run); otherwise it stays a permissive stub."""
     if REF not in sys.path:
         sys.path.insert(0, REF)
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -109,6 +182,10 @@ def install():
     sys.modules["diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer"].GaussianRasterizationSettings = _Any
     sys.modules["diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer"].GaussianRasterizer = _Any
     sys.modules["_gridencoder"] = _oracle_gridencoder_module()
+    if rasterizer:
+        sys.modules["diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer"] = _oracle_rasterizer_module()
+        sys.modules["glm"].vec3 = _Any                      # frame_cube/frame.py is imported for its Frame dataclass only
+        sys.modules["glm"].lookAt = _Any()
 
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self

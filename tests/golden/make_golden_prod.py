@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Production-dimension fixture: the reference's UNMODIFIED ``render()`` / ``prefilter_voxel()`` / ``generate_neural_gaussians()``
+/ ``calc_entropy_context()`` (ortho_gaussian_renderer/renderer.py:14-119, preprocess.py:30-118, guassian.py:134-310,
+scene/gaussian_model.py:1569-1597) run on PyTorch-CPU at feat_dim 50 / K 10 / 192-wide hash-grid feature with more than 4 096
+visible anchors — the sizes at which gsvc_amd takes its whole-network chain kernels (csrc/mlp_chain.hip), the shared-input entropy
+kernels (csrc/linear_accum.hip) and the batched weight-gradient kernels.  The native slots are filled by oracle/ (grid + rasterizer:
+tests/golden/_ref_import.py).  Model parameters, anchors, dL/dimage and the random draws are regenerated from seeds on both sides
+(tests/golden/seeded.py); the fixture holds expected outputs only: every 16th / 32nd row of the large tensors, bit-packed masks,
+strided rows + float64 sums of every gradient.
+
+Runs in the build container only (needs /root/reference).  Usage:  python tests/golden/make_golden_prod.py
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from tests.golden import _ref_import, seeded  # noqa: E402
+from tests.golden.make_golden_common import save  # noqa: E402
+
+mode_ctx = _ref_import.install(rasterizer=True)
+
+GRAD_ROW_STRIDE = 5          # rows of a weight-gradient matrix kept (coprime to the kernels' 16-row tiles)
+ROW_STRIDE = 16
+WIDE_STRIDE = 32
+RATE_WEIGHT = 50.0           # weight of bit_per_param in the entropy case's scalar
+
+
+def grads_of(named_params, out, pre, rows=True):
+    """Every parameter's gradient: strided rows of the matrices, small tensors whole, float64 sum / abs-sum of all of it."""
+    for name, p in named_params:
+        g = p.grad
+        if g is None:
+            continue
+        g = g.detach()
+        out[f"{pre}sum::{name}"] = np.array([float(g.double().sum()), float(g.double().abs().sum()), float(g.abs().max())])
+        if not rows:
+            continue
+        if name.startswith("_"):                                  # per-anchor tensors: every 16th anchor
+            out[f"{pre}grad::{name}"] = g[::ROW_STRIDE]
+        elif name.endswith("params"):                             # hash tables: every 4th row
+            out[f"{pre}grad::{name}"] = g[::4]
+        elif g.dim() == 2 and g.numel() > 2048:
+            out[f"{pre}grad::{name}"] = g[::GRAD_ROW_STRIDE]
+        else:
+            out[f"{pre}grad::{name}"] = g
+
+
+with mode_ctx:
+    import arguments as A
+    import scene.gaussian_model as GM
+    import ortho_gaussian_renderer as OGR
+    from ortho_gaussian_renderer import GenerateMode
+    from frame_cube.frame import Frame
+
+    sc = seeded.SCENE
+    fn = seeded.frame_numbers(sc["H"], sc["W"], sc["T"], sc["frame"])
+    mp = A.ModelParams()
+    mp.threshold = sc["threshold"]
+    P = seeded.PROD
+    torch.manual_seed(0)
+    ref = GM.GaussianModel(mp, feat_dim=P["feat_dim"], n_offsets=P["n_offsets"], voxel_size=0.001, update_depth=3,
+                           update_init_factor=16, update_hierachy_factor=4, use_feat_bank=False,
+                           n_features_per_level=P["n_features_per_level"], log2_hashmap_size=P["log2_hashmap_size"],
+                           log2_hashmap_size_2D=P["log2_hashmap_size_2D"], resolutions_list=P["resolutions_list"],
+                           resolutions_list_2D=P["resolutions_list_2D"])
+    ref.update_anchor_bound(fn["x_min"], fn["y_min"], fn["z_min"])
+    for name, t in seeded.anchors(sc["A"], fn, sc["threshold"], sc["seed"]).items():
+        setattr(ref, name, nn.Parameter(t, requires_grad=name not in ("_rotation", "_opacity")))
+    seeded.fill_parameters(ref, sc["seed"])
+    assert ref.encoding_xyz.output_dim == 192
+
+    def frame_for(view: str) -> Frame:
+        vm, vms = (fn["view_matrix"], fn["view_matrix_s"]) if view == "f" else (fn["view_matrix_s"], fn["view_matrix"])
+        return Frame(image_id=sc["frame"], plane="xy", image=None, x_min=fn["x_min"], y_min=fn["y_min"], z=fn["z"],
+                     image_width=sc["W"], image_height=sc["H"], view_matrix=vm.clone(), view_matrix_s=vms.clone(),
+                     scale=fn["scale"], cam_pos=fn["cam_pos"].clone())
+
+    pipe = SimpleNamespace(debug=False, compute_cov3D_python=False)
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    Ras = sys.modules["diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer"].GaussianRasterizer
+    out = {"meta::A": np.int64(sc["A"]), "meta::rate_weight": np.float64(RATE_WEIGHT),
+           "meta::strides": np.array([ROW_STRIDE, WIDE_STRIDE, GRAD_ROW_STRIDE])}
+
+    cases = (("f0", "f", GenerateMode.TRAINING_FULL_PRECISION), ("b0", "b", GenerateMode.TRAINING_FULL_PRECISION),
+             ("f2", "f", GenerateMode.TRAINING_ENTROPY))
+    dL_full = seeded.image_weights(sc["H"], sc["W"], sc["seed"])
+    for tag, view, md in cases:
+        pre = tag + "::"
+        frame = frame_for(view)
+        ref.zero_grad()
+        with seeded.SeededDraws(1000 * md.value + 17) as draws:
+            res = OGR.render(frame, ref, pipe, bg, retain_grad=True, mode=md)
+        out[pre + "n_draws"] = np.int64(draws.count)
+        assert torch.equal(OGR.prefilter_voxel(frame, ref, pipe, bg), res.visible_mask)
+        fwd = Ras.last["forward"]
+        V = int(res.visible_mask.sum())
+        assert V >= 4096, V
+        gs = res.generated_gaussians
+        print(tag, "visible anchors", V, "Gaussians", gs.xyz.shape[0], "active", int(res.active_gaussains), "instances", res.num_rendered,
+              "borderline px", int(fwd.borderline.sum()))
+        out[pre + "visible_mask"] = np.packbits(res.visible_mask.numpy())
+        out[pre + "selection_mask"] = np.packbits(res.selection_mask.numpy())
+        out[pre + "radii"] = res.radii.numpy().astype(np.int16)
+        out[pre + "counts"] = np.array([V, gs.xyz.shape[0], int(res.active_gaussains), int(res.num_rendered)], dtype=np.int64)
+        out[pre + "image"] = res.rendered_image
+        out[pre + "borderline"] = np.packbits(fwd.borderline.astype(bool))
+        out[pre + "neural_opacity"] = res.neural_opacity[::ROW_STRIDE]
+        out[pre + "scaling"] = res.scaling[::ROW_STRIDE]
+        if view == "f":                                           # the generation does not depend on the view direction
+            out[pre + "concatenated_all"] = gs.concatenated_all[::WIDE_STRIDE]
+            out[pre + "xyz"], out[pre + "rot"] = gs.xyz[::ROW_STRIDE], gs.rot[::ROW_STRIDE]
+            out[pre + "color"], out[pre + "opacity"] = gs.color[::ROW_STRIDE], gs.opacity[::ROW_STRIDE]
+        dL = dL_full * torch.from_numpy((fwd.borderline == 0)).to(torch.float32)
+        loss = (res.rendered_image * dL).sum()
+        if res.bit_per_param is not None:
+            for nm in ("bit_per_param", "bit_per_feat_param", "bit_per_scaling_param", "bit_per_offsets_param"):
+                out[pre + nm] = getattr(res, nm)
+            loss = loss + RATE_WEIGHT * res.bit_per_param
+        loss.backward()
+        out[pre + "loss"] = loss
+        out[pre + "viewspace_grad"] = res.viewspace_points.grad[::ROW_STRIDE]
+        out[pre + "viewspace_grad_sum"] = np.array([float(res.viewspace_points.grad.double().abs().sum())])
+        grads_of(ref.named_parameters(), out, pre, rows=view == "f")      # the opposite view: sums only
+
+    # the entropy context on its own (no draws): every 16th visible row
+    visible = torch.from_numpy(np.unpackbits(out["f0::visible_mask"])[:sc["A"]].astype(bool))
+    with torch.no_grad():
+        ec = ref.calc_entropy_context(ref.get_anchor[visible])
+        for nm in ("mean_feat", "scale_feat", "mean_scaling", "scale_scaling", "mean_offsets", "scale_offsets",
+                   "Q_feat_adj", "Q_scaling_adj", "Q_offsets_adj"):
+            out["ec::" + nm] = getattr(ec, nm)[::ROW_STRIDE]
+        out["ec::interp_feat"] = ref.calc_interp_feat(ref.get_anchor[visible])[::2 * WIDE_STRIDE]
+    # a handful of parameter checksums: both sides must have built the same model
+    for name, t in sorted(ref.state_dict().items()):
+        if t.is_floating_point() and t.numel():
+            out["param_sum::" + name] = np.array([float(t.double().sum()), float(t.double().abs().sum())])
+    save("prod_render", **out)
+print("done")
