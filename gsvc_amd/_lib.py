@@ -147,8 +147,8 @@ _SIGNATURES = {
     "gsvc_octree_popcount": (C.c_int, [_vp, _i64, _vp, _vp]),
     "gsvc_octree_expand": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "gsvc_morton_decode": (C.c_int, [_vp, _i64, _vp, _vp]),
-    "gsvc_q_rows_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i64, _vp, _vp]),
-    "gsvc_q_rows_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i64, _i64, _vp, _vp]),
+    "gsvc_q_rows_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i64, C.c_int32, _vp, _vp]),
+    "gsvc_q_rows_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _i64, _i64, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "gsvc_plan_scans_scratch_bytes": (_i64, [C.c_int32, _i64]),
     "gsvc_plan_scans": (C.c_int, [_vp, _vp, _vp, C.c_int32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_film_row_maps": (C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -445,33 +445,47 @@ __global__ void __launch_bounds__(256) k_film_rows(const long long *__restrict__
 // gaussian_renderer/guassian.py:250-262: Q_feat * Q_feat_adj etc.; the entropy context is evaluated once per DISTINCT anchor, so
 // its step adjustments are gathered by ctx_row).  One launch instead of three gathers and three products; the backward
 // scatter-adds the rows' gradients onto the distinct anchors (one launch instead of three products, three fills, three index_adds).
+// raw != 0: a0..a2 are the quant_step networks' RAW outputs q and the adjustment exp(clamp(q, -10, 10)) (reference
+// scene/gaussian_model.py:1586-1596) is applied here, its derivative adj * [|q| <= 10] in the backward — the training step then
+// never materialises the three adjustment vectors.
+__device__ __forceinline__ float q_adj(float q) { return expf(fminf(fmaxf(q, -10.0f), 10.0f)); }
+
 __global__ void __launch_bounds__(256) k_q_rows_fwd(const float *__restrict__ a0, const float *__restrict__ a1, const float *__restrict__ a2,
                                                     const long long *__restrict__ ctx_row, float q0, float q1, float q2, long long rows,
-                                                    float *__restrict__ out)
+                                                    int raw, float *__restrict__ out)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows) return;
     const long long d = ctx_row ? ctx_row[i] : i;
-    out[i] = q0 * a0[d];
-    out[rows + i] = q1 * a1[d];
-    out[2 * rows + i] = q2 * a2[d];
+    const float v0 = a0[d], v1 = a1[d], v2 = a2[d];
+    out[i] = q0 * (raw ? q_adj(v0) : v0);
+    out[rows + i] = q1 * (raw ? q_adj(v1) : v1);
+    out[2 * rows + i] = q2 * (raw ? q_adj(v2) : v2);
 }
 
 __global__ void __launch_bounds__(256) k_q_rows_bwd(const float *__restrict__ g0, const float *__restrict__ g1, const float *__restrict__ g2,
                                                     const long long *__restrict__ ctx_row, float q0, float q1, float q2, long long rows,
-                                                    long long D, float *__restrict__ gadj)
+                                                    long long D, const float *__restrict__ a0, const float *__restrict__ a1,
+                                                    const float *__restrict__ a2, int raw, float *__restrict__ gadj)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows) return;
+    const long long d = ctx_row ? ctx_row[i] : i;
+    float f0 = q0, f1 = q1, f2 = q2;
+    if (raw) {
+        const float v0 = a0[d], v1 = a1[d], v2 = a2[d];
+        f0 = (v0 >= -10.0f && v0 <= 10.0f) ? q0 * expf(v0) : 0.0f;
+        f1 = (v1 >= -10.0f && v1 <= 10.0f) ? q1 * expf(v1) : 0.0f;
+        f2 = (v2 >= -10.0f && v2 <= 10.0f) ? q2 * expf(v2) : 0.0f;
+    }
     if (ctx_row) {
-        const long long d = ctx_row[i];
-        if (g0) atomicAdd(gadj + d, q0 * g0[i]);
-        if (g1) atomicAdd(gadj + D + d, q1 * g1[i]);
-        if (g2) atomicAdd(gadj + 2 * D + d, q2 * g2[i]);
+        if (g0) atomicAdd(gadj + d, f0 * g0[i]);
+        if (g1) atomicAdd(gadj + D + d, f1 * g1[i]);
+        if (g2) atomicAdd(gadj + 2 * D + d, f2 * g2[i]);
     } else {
-        gadj[i] = g0 ? q0 * g0[i] : 0.f;
-        gadj[D + i] = g1 ? q1 * g1[i] : 0.f;
-        gadj[2 * D + i] = g2 ? q2 * g2[i] : 0.f;
+        gadj[i] = g0 ? f0 * g0[i] : 0.f;
+        gadj[D + i] = g1 ? f1 * g1[i] : 0.f;
+        gadj[2 * D + i] = g2 ? f2 * g2[i] : 0.f;
     }
 }
 
@@ -824,30 +838,34 @@ extern "C" int gsvc_film_row_maps(const int64_t *vis, const int64_t *row_bounds_
 }
 
 extern "C" int gsvc_q_rows_forward(const float *adj_feat, const float *adj_scaling, const float *adj_offsets, const int64_t *ctx_row,
-                                   float q_feat, float q_scaling, float q_offsets, int64_t rows, float *out3, void *stream)
+                                   float q_feat, float q_scaling, float q_offsets, int64_t rows, int32_t raw, float *out3, void *stream)
 {
     GSVC_REQUIRE(rows >= 0, "q_rows_forward: bad shape");
     if (rows == 0) return GSVC_OK;
     GSVC_REQUIRE(adj_feat && adj_scaling && adj_offsets && out3, "q_rows_forward: NULL pointer");
+    gsvc::ProfScope _prof("k_q_rows", (hipStream_t)stream);
     hipLaunchKernelGGL(gsvc::k_q_rows_fwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, adj_feat, adj_scaling,
-                       adj_offsets, (const long long *)ctx_row, q_feat, q_scaling, q_offsets, (long long)rows, out3);
+                       adj_offsets, (const long long *)ctx_row, q_feat, q_scaling, q_offsets, (long long)rows, (int)raw, out3);
     return gsvc::check_launch("q_rows_forward");
 }
 
 extern "C" int gsvc_q_rows_backward(const float *g_feat, const float *g_scaling, const float *g_offsets, const int64_t *ctx_row,
-                                    float q_feat, float q_scaling, float q_offsets, int64_t rows, int64_t D, float *grad_adj3, void *stream)
+                                    float q_feat, float q_scaling, float q_offsets, int64_t rows, int64_t D, const float *adj_feat,
+                                    const float *adj_scaling, const float *adj_offsets, int32_t raw, float *grad_adj3, void *stream)
 {
     GSVC_REQUIRE(rows >= 0 && D >= 0 && (ctx_row || D == rows), "q_rows_backward: bad shape");
     if (D == 0) return GSVC_OK;
-    GSVC_REQUIRE(grad_adj3, "q_rows_backward: NULL pointer");
+    GSVC_REQUIRE(grad_adj3 && (!raw || (adj_feat && adj_scaling && adj_offsets)), "q_rows_backward: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     if (ctx_row && hipMemsetAsync(grad_adj3, 0, sizeof(float) * 3 * (size_t)D, s) != hipSuccess) {
         gsvc::set_error("q_rows_backward: hipMemsetAsync failed");
         return GSVC_E_LAUNCH;
     }
     if (rows == 0) return GSVC_OK;
+    gsvc::ProfScope _prof("k_q_rows_bwd", s);
     hipLaunchKernelGGL(gsvc::k_q_rows_bwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, g_feat, g_scaling, g_offsets,
-                       (const long long *)ctx_row, q_feat, q_scaling, q_offsets, (long long)rows, (long long)D, grad_adj3);
+                       (const long long *)ctx_row, q_feat, q_scaling, q_offsets, (long long)rows, (long long)D, adj_feat, adj_scaling,
+                       adj_offsets, (int)raw, grad_adj3);
     return gsvc::check_launch("q_rows_backward");
 }
 

@@ -708,10 +708,11 @@ class _SampledRate(torch.autograd.Function):
 
 class _QRows(torch.autograd.Function):
     """(Q_feat, Q_scaling, Q_offsets) per row = base step x the entropy context's adjustment of the row's anchor (csrc/generate.hip
-    k_q_rows_fwd / _bwd), three [rows, 1] tensors carved from one buffer."""
+    k_q_rows_fwd / _bwd), three [rows, 1] tensors carved from one buffer.  ``raw``: the three inputs are the quant_step networks'
+    raw outputs and the adjustment exp(clamp(q, -10, 10)) is applied inside (forward and backward)."""
 
     @staticmethod
-    def forward(ctx, adj_f, adj_s, adj_o, ctx_row, q_f, q_s, q_o):
+    def forward(ctx, adj_f, adj_s, adj_o, ctx_row, q_f, q_s, q_o, raw=False):
         from . import _lib
         adj = [a.contiguous().view(-1) for a in (adj_f, adj_s, adj_o)]
         D, dev = adj[0].shape[0], adj[0].device
@@ -719,24 +720,26 @@ class _QRows(torch.autograd.Function):
         rows = ctx_row.shape[0] if ctx_row is not None else D
         out = torch.empty(3, rows, 1, dtype=torch.float32, device=dev)
         _lib.check(_lib.lib().gsvc_q_rows_forward(_lib.ptr(adj[0]), _lib.ptr(adj[1]), _lib.ptr(adj[2]), _lib.ptr(ctx_row), float(q_f), float(q_s),
-                                                  float(q_o), rows, _lib.ptr(out), _lib.current_stream(dev)), "gsvc_q_rows_forward")
-        ctx.save_for_backward(ctx_row)
-        ctx.q, ctx.rows, ctx.D, ctx.shapes = (float(q_f), float(q_s), float(q_o)), rows, D, (adj_f.shape, adj_s.shape, adj_o.shape)
+                                                  float(q_o), rows, int(raw), _lib.ptr(out), _lib.current_stream(dev)), "gsvc_q_rows_forward")
+        ctx.save_for_backward(ctx_row, *(adj if raw else ()))
+        ctx.q, ctx.rows, ctx.D, ctx.shapes, ctx.raw = (float(q_f), float(q_s), float(q_o)), rows, D, (adj_f.shape, adj_s.shape, adj_o.shape), bool(raw)
         ctx.set_materialize_grads(False)
         return out[0], out[1], out[2]
 
     @staticmethod
     def backward(ctx, g_f, g_s, g_o):
         from . import _lib
-        (ctx_row,) = ctx.saved_tensors
+        ctx_row, *adj = ctx.saved_tensors
         gs = [None if g is None else g.contiguous() for g in (g_f, g_s, g_o)]
         dev = next(g.device for g in gs if g is not None) if any(g is not None for g in gs) else None
         if dev is None:
-            return (None,) * 7
+            return (None,) * 8
+        adj = adj if ctx.raw else [None, None, None]
         gadj = torch.empty(3, ctx.D, dtype=torch.float32, device=dev)
         _lib.check(_lib.lib().gsvc_q_rows_backward(_lib.ptr(gs[0]), _lib.ptr(gs[1]), _lib.ptr(gs[2]), _lib.ptr(ctx_row), *ctx.q, ctx.rows, ctx.D,
-                                                   _lib.ptr(gadj), _lib.current_stream(dev)), "gsvc_q_rows_backward")
-        return gadj[0].view(ctx.shapes[0]), gadj[1].view(ctx.shapes[1]), gadj[2].view(ctx.shapes[2]), None, None, None, None
+                                                   _lib.ptr(adj[0]), _lib.ptr(adj[1]), _lib.ptr(adj[2]), int(ctx.raw), _lib.ptr(gadj),
+                                                   _lib.current_stream(dev)), "gsvc_q_rows_backward")
+        return gadj[0].view(ctx.shapes[0]), gadj[1].view(ctx.shapes[1]), gadj[2].view(ctx.shapes[2]), None, None, None, None, None
 
 
 class _RateNorm(torch.autograd.Function):
@@ -778,6 +781,18 @@ class _RateNorm(torch.autograd.Function):
         return gS, None, None, None, None, None
 
 
+_IOTA = {}
+
+
+def _iota(dev, n):
+    """arange(n) int64 on ``dev`` as a view of a cached, growing tensor (no launch per step)."""
+    key = (dev.type, dev.index)
+    t = _IOTA.get(key)
+    if t is None or t.shape[0] < n:
+        t = _IOTA[key] = torch.arange(max(n, 1 << 16), dtype=torch.int64, device=dev)
+    return t[:n]
+
+
 def _param_means(pc):
     """(mean(_anchor_feat), mean(get_scaling), mean(_offset)) over ALL anchors as one float32 [3] tensor (csrc/rate.hip
     k_param_means: one pass; the torch expression is three reductions + an exp pass)."""
@@ -807,13 +822,18 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
     K, R, dev = pc.n_offsets, seg.R, feat.device
     fused = (feat.is_cuda and R <= 16 and all(isinstance(q, torch.Tensor) and q.numel() == feat.shape[0] for q in (Q_feat, Q_scaling, Q_offsets))
              and not os.environ.get("GSVC_NO_FUSED_RATE"))
+    compact = hasattr(ec, "rows")        # SampledEntropyContext: mean / scale exist for the sampled rows only, row i = i-th sampled row
     if fused and sel is not None and offset_masks.dtype == torch.float32:
         # everything on the device in a dozen launches: the parameter means, the sampled bits summed per render (k_rate_sample),
         # and their normalisation with the keep rates and sample sizes (k_rate_normalise)
         sel_ec = sel if ec_row is None else ec_row.index_select(0, sel)
+        if compact:
+            ec, sel_ctx = ec.rows(sel_ec), _iota(dev, sel.shape[0])
+        else:
+            sel_ctx = None if ec_row is None else sel_ec
         S = _SampledRate.apply(feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec.mean_feat, ec.scale_feat,
                                ec.mean_scaling, ec.scale_scaling, ec.mean_offsets, ec.scale_offsets, sel,
-                               None if ec_row is None else sel_ec, _param_means(pc), seg.bounds, K)
+                               sel_ctx, _param_means(pc), seg.bounds, K)
         out, total = _RateNorm.apply(S, offset_masks, sel, seg.bounds, (float(feat.shape[1]), float(grid_scaling.shape[1]), float(3 * K)), K)
         packs = [RatePack(bit_per_param=out[r, 0], bit_per_feat_param=out[r, 1], bit_per_scaling_param=out[r, 2],
                           bit_per_offsets_param=out[r, 3]) for r in range(R)]
@@ -830,12 +850,16 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
         edges = torch.searchsorted(sel, seg.bounds_t)
         n_sel = (edges[1:] - edges[:-1]).to(torch.float32)
     sel_ec = sel if ec_row is None else ec_row.index_select(0, sel)
+    sel_ctx = None if ec_row is None else sel_ec
+    if compact:
+        ec = ec.rows(sel_ec)
+        sel_ec = sel_ctx = _iota(dev, sel.shape[0])
     if fused:
         # fused path (csrc/rate.hip k_rate_sample): gathers, per-render clamp bounds, offset mask and per-render sums in one launch
         xm = _param_means(pc)
         S = _SampledRate.apply(feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec.mean_feat, ec.scale_feat,
                                ec.mean_scaling, ec.scale_scaling, ec.mean_offsets, ec.scale_offsets, sel,
-                               None if ec_row is None else sel_ec, xm, seg.bounds, K)
+                               sel_ctx, xm, seg.bounds, K)
         dims = host_values([float(feat.shape[1]), float(grid_scaling.shape[1]), float(3 * K)], dev)
         N = n_sel.unsqueeze(1) * dims
         per = S / N * kr.unsqueeze(1)
@@ -865,7 +889,7 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
                      bit_per_offsets_param=per[r, 2]) for r in range(R)]
 
 
-def _entropy_context_distinct(pc, anchor_all, vis, plan=None):
+def _entropy_context_distinct(pc, anchor_all, vis, plan=None, sampled=False):
     """Entropy context of the batch's rows, evaluated once per DISTINCT anchor.
 
     The context (hash-grid lookup + the three EntropyParamsNets, reference scene/gaussian_model.py:1569-1597) is a
@@ -874,21 +898,23 @@ def _entropy_context_distinct(pc, anchor_all, vis, plan=None):
     on the distinct anchors and gathering rows from that (the per-row step sizes) or composing indices (the 5 % rate
     sample) is the same arithmetic on a quarter of the rows; the gradients of the duplicates meet in the gathers'
     backward.  Returns (context over the distinct anchors, row -> distinct index), or (context, None) when nothing
-    repeats."""
+    repeats.  ``sampled``: the training form (gsvc_amd.model.SampledEntropyContext: quantisation steps on every row, the
+    priors' mean / scale deferred to the rows of the rate sample)."""
+    calc = pc.calc_entropy_context_sampled if sampled else pc.calc_entropy_context
     A = anchor_all.shape[0]
     if vis.numel() == 0:
-        return pc.calc_entropy_context(anchor_all.index_select(0, vis)), None
+        return calc(anchor_all.index_select(0, vis)), None
     if plan is not None:           # the distinct list and the anchor -> row map were computed with the visibility test
         if plan.distinct.shape[0] == vis.shape[0]:
-            return pc.calc_entropy_context(anchor_all.index_select(0, vis)), None
-        return pc.calc_entropy_context(anchor_all.index_select(0, plan.distinct)), plan.pos.index_select(0, vis)
+            return calc(anchor_all.index_select(0, vis)), None
+        return calc(anchor_all.index_select(0, plan.distinct)), plan.pos.index_select(0, vis)
     present = torch.zeros(A, dtype=torch.bool, device=vis.device)
     present[vis] = True
     distinct = present.nonzero(as_tuple=False).squeeze(1)
     if distinct.shape[0] == vis.shape[0]:
-        return pc.calc_entropy_context(anchor_all.index_select(0, vis)), None
+        return calc(anchor_all.index_select(0, vis)), None
     pos = torch.cumsum(present, dim=0) - 1
-    return pc.calc_entropy_context(anchor_all.index_select(0, distinct)), pos.index_select(0, vis)
+    return calc(anchor_all.index_select(0, distinct)), pos.index_select(0, vis)
 
 
 def _embed_rows(pc, frames, anchor, seg):
@@ -1040,10 +1066,15 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
         grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets, seg)
     elif mode == GenerateMode.TRAINING_ENTROPY:
+        # the priors' mean / scale are read at the rate sample's rows only (reference guassian.py:99-113): their networks run on
+        # those rows (SampledEntropyContext); GSVC_CTX_ALL_ROWS=1 keeps the all-rows form (A/B timing, the equivalence test)
+        sampled_ctx = feat.is_cuda and not os.environ.get("GSVC_CTX_ALL_ROWS")
         with region('gen.entropy_context'):
-            ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan)
+            ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan, sampled=sampled_ctx)
         with region('gen.noise_quant'):
-            if (feat.is_cuda and all(isinstance(q, (int, float)) for q in (Q_feat, Q_scaling, Q_offsets))
+            if sampled_ctx and all(isinstance(q, (int, float)) for q in (Q_feat, Q_scaling, Q_offsets)) and all(a.dtype == torch.float32 for a in ec.q_raw):
+                Q_feat, Q_scaling, Q_offsets = _QRows.apply(ec.q_raw[0], ec.q_raw[1], ec.q_raw[2], ec_row, Q_feat, Q_scaling, Q_offsets, True)
+            elif (feat.is_cuda and all(isinstance(q, (int, float)) for q in (Q_feat, Q_scaling, Q_offsets))
                     and all(a.dtype == torch.float32 and a.numel() == ec.Q_feat_adj.numel() for a in (ec.Q_feat_adj, ec.Q_scaling_adj, ec.Q_offsets_adj))):
                 Q_feat, Q_scaling, Q_offsets = _QRows.apply(ec.Q_feat_adj, ec.Q_scaling_adj, ec.Q_offsets_adj, ec_row, Q_feat, Q_scaling, Q_offsets)
             else:
@@ -1067,7 +1098,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         if not late_rows:
             rows_quant_and_rate()
     elif mode == GenerateMode.TRAININ_STE_ENTROPY:
-        ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan)
+        ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan, sampled=feat.is_cuda and not os.environ.get("GSVC_CTX_ALL_ROWS"))
         rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
         Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj).detach(), Q_scaling * rows_of(ec.Q_scaling_adj).detach(),
                                         Q_offsets * rows_of(ec.Q_offsets_adj).detach())

@@ -104,9 +104,9 @@ class WgradBatch:
         self.off, self.jobs, self.keep = 0, [], []
 
 
-def usable(x, *linears):
+def usable(x, *linears, min_rows=MIN_ROWS):
     """The fused path needs a tall fp32 CUDA matrix and layers that fit the weight-stationary kernel."""
-    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= MIN_ROWS and
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= min_rows and
             all(l.in_features <= MFMA_MAX_DIM and l.out_features <= MFMA_MAX_DIM and l.bias is not None for l in linears))
 
 

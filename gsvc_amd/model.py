@@ -44,6 +44,60 @@ class EntropyContext:
     Q_offsets_adj: torch.Tensor
 
 
+class SampledEntropyContext:
+    """The entropy context in the form the TRAINING rate needs it (reference ortho_gaussian_renderer/guassian.py:99-113,183-199):
+    the quantisation-step adjustments of EVERY row — they scale the noise of every visible anchor — but the priors' mean / scale
+    only on the rows the 5 % rate sample chose: ``calc_sampled_rate`` reads ``mean_* / scale_*`` at ``choose_idx`` and nowhere else,
+    so the three ``dist_net``s (112 k of an EntropyParamsNet triple's 141 k multiply-adds per anchor) evaluated on the other rows
+    produce numbers, and receive gradients, that are identically unused.  Exact, not an approximation: the same values and the
+    same parameter gradients as the all-rows form (tests/test_train_gpu.py).
+
+    ``q_raw``: the three quant_step networks' raw outputs [D, 1] (the adjustment exp(clamp(q, -10, 10)) is applied by the
+    consumer's kernel: gsvc_q_rows_forward(raw = 1)); ``rows(idx)``: an EntropyContext whose mean / scale tensors hold row i =
+    context row idx[i] (its Q_*_adj are None)."""
+
+    MIN_ROWS = 256      # below this the module path (torch GEMMs) answers
+
+    def __init__(self, pc, feature, q_raw):
+        self.pc, self.feature, self.q_raw = pc, feature, q_raw
+
+    @property
+    def Q_feat_adj(self):
+        return torch.exp(torch.clamp(self.q_raw[0], min=-10, max=10))
+
+    @property
+    def Q_scaling_adj(self):
+        return torch.exp(torch.clamp(self.q_raw[1], min=-10, max=10))
+
+    @property
+    def Q_offsets_adj(self):
+        return torch.exp(torch.clamp(self.q_raw[2], min=-10, max=10))
+
+    def rows(self, idx) -> EntropyContext:
+        from . import mlp
+        pc = self.pc
+        x = self.feature.index_select(0, idx)
+        nets = (pc.mlp_feature_enet, pc.mlp_scaling_enet, pc.mlp_offset_enet)
+        chains = [list(net.dist_net)[0::2] for net in nets]
+        if (x.is_cuda and x.shape[0] >= self.MIN_ROWS and all(isinstance(net.dist_net, GeluSequential) for net in nets)
+                and all(mlp.usable(x, *c, min_rows=self.MIN_ROWS) for c in chains) and not os.environ.get("GSVC_NO_MLP_CHAIN")):
+            raw = mlp.seq_gelu_many(x, chains)
+        else:
+            raw = [net.dist_net(x) for net in nets]
+        out = []
+        if x.is_cuda and not os.environ.get("GSVC_NO_FUSED_CTX"):
+            # split + max(scale, 1e-9) as one launch each way per network (gsvc_ctx_post_*; its step output is computed of a dummy)
+            q0 = torch.zeros(x.shape[0], 1, device=x.device, dtype=torch.float32)
+            for p in raw:
+                out += list(_CtxPost.apply(p, q0))[:2]
+        else:
+            for p in raw:
+                half = p.shape[1] // 2
+                mean, scale = p.split([half, p.shape[1] - half], dim=1)
+                out += [mean, torch.clamp(scale, 1e-9)]
+        return EntropyContext(*out, None, None, None)
+
+
 @dataclass
 class BitInfo:
     """Estimated size of the coded model in bits, per stream (reference scene/gaussian_model.py:55-65)."""
@@ -634,6 +688,20 @@ class GaussianModel(nn.Module):
         adj = lambda q: torch.exp(torch.clamp(q, min=-10, max=10))  # noqa: E731
         return EntropyContext(mean_f, torch.clamp(scale_f, 1e-9), mean_s, torch.clamp(scale_s, 1e-9),
                               mean_o, torch.clamp(scale_o, 1e-9), adj(q_f), adj(q_s), adj(q_o))
+
+    def calc_entropy_context_sampled(self, anchor) -> SampledEntropyContext:
+        """``calc_entropy_context`` for the training rate: hash-grid feature + the three quant_step networks on every row, the
+        dist networks deferred to the sampled rows (SampledEntropyContext.rows)."""
+        from . import mlp
+        ctx = self.calc_interp_feat(anchor)
+        nets = (self.mlp_feature_enet, self.mlp_scaling_enet, self.mlp_offset_enet)
+        chains = [list(net.quant_step_net)[0::2] for net in nets]
+        if (ctx.is_cuda and all(isinstance(net.quant_step_net, GeluSequential) for net in nets) and all(mlp.usable(ctx, *c) for c in chains)
+                and not os.environ.get("GSVC_NO_MLP_CHAIN")):
+            q_raw = mlp.seq_gelu_many(ctx, chains)          # the three first layers read ctx in one launch
+        else:
+            q_raw = tuple(net.quant_step_net(ctx) for net in nets)
+        return SampledEntropyContext(self, ctx, q_raw)
 
     # ------------------------------------------------------------------ bit accounting (SURVEY section 8f-3)
     def get_mlp_size(self, digit=32):

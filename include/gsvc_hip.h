@@ -463,11 +463,15 @@ int gsvc_plan_masks(const uint8_t *const *visible_host, int32_t R, int64_t A, co
                     const float *u, float rate, uint8_t *M, uint8_t *present, uint8_t *chosen, void *stream);
 /* Per-row quantisation steps: out3 [3, rows], out3[g][i] = q_g adj_g[ctx_row ? ctx_row[i] : i] for the features, scalings and
  * offsets (reference gaussian_renderer/guassian.py:250-262, Q * Q_adj of the entropy context; ctx_row maps a row to its row of a
- * context evaluated once per distinct anchor).  backward: grad_adj3 [3, D] = scatter-add of q_g g_g[i] (any g_g may be NULL). */
+ * context evaluated once per distinct anchor).  raw != 0: adj_g holds the quant_step networks' raw outputs q and the adjustment
+ * exp(clamp(q, -10, 10)) (reference scene/gaussian_model.py:1586-1596) is applied here.
+ * backward: grad_adj3 [3, D] = scatter-add of q_g g_g[i] (any g_g may be NULL), times adj_g [|q| <= 10] when raw (the gradient
+ * w.r.t. the raw outputs; adj_* are read only then). */
 int gsvc_q_rows_forward(const float *adj_feat, const float *adj_scaling, const float *adj_offsets, const int64_t *ctx_row,
-                        float q_feat, float q_scaling, float q_offsets, int64_t rows, float *out3, void *stream);
+                        float q_feat, float q_scaling, float q_offsets, int64_t rows, int32_t raw, float *out3, void *stream);
 int gsvc_q_rows_backward(const float *g_feat, const float *g_scaling, const float *g_offsets, const int64_t *ctx_row, float q_feat,
-                         float q_scaling, float q_offsets, int64_t rows, int64_t D, float *grad_adj3, void *stream);
+                         float q_scaling, float q_offsets, int64_t rows, int64_t D, const float *adj_feat, const float *adj_scaling,
+                         const float *adj_offsets, int32_t raw, float *grad_adj3, void *stream);
 
 /* Scans and compactions of a step plan in three launches.  view_masks [R, A] (bytes, 0 / 1), chosen [R, A] (a subset of
  * view_masks: the rate sample, or NULL), present [A] (the union of the views).  Outputs: scan [R A] = inclusive scan of the

@@ -294,3 +294,55 @@ def test_dense_planned_two_view_step_path_matches_the_reference_renders(prod):
         assert abs(float(p.grad.double().sum()) - want) <= 1e-3 * want_abs, (name, float(p.grad.double().sum()), want, want_abs)
         checked += 1
     assert checked >= 40, checked
+
+
+@pytest.mark.parametrize("mode_value", [2, 3])
+def test_priors_on_the_sampled_rows_equal_the_all_rows_context(prod, monkeypatch, mode_value):
+    """The training rate reads the priors' mean / scale at the 5 % sample only (reference ortho_gaussian_renderer/guassian.py:
+    99-113), so the three dist_nets run on those rows (gsvc_amd.model.SampledEntropyContext): the rates, the images and EVERY
+    parameter gradient must equal the form that evaluates them on all distinct anchors (GSVC_CTX_ALL_ROWS=1) — same draws, same
+    arithmetic per row, only rows whose results nothing reads are left out."""
+    from gsvc_amd.generate import GenerateMode
+    from gsvc_amd.ortho_gaussian_renderer import plan_views, render_many
+    from gsvc_amd.rasterizer import resolve_deferred
+    from tests.golden import seeded
+    pc, g, fn = prod
+    sc = seeded.SCENE
+    fn2 = seeded.frame_numbers(sc["H"], sc["W"], sc["T"], sc["frame"] + 1)
+    frames = [_frame(fn, "f"), _frame(fn, "b"), _frame(fn2, "f"), _frame(fn2, "b")]
+    pipe = SimpleNamespace(debug=False, compute_cov3D_python=False)
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    mode = GenerateMode(mode_value)
+    dL = seeded.image_weights(sc["H"], sc["W"], sc["seed"]).cuda()
+
+    def run(all_rows):
+        if all_rows:
+            monkeypatch.setenv("GSVC_CTX_ALL_ROWS", "1")
+        else:
+            monkeypatch.delenv("GSVC_CTX_ALL_ROWS", raising=False)
+        pc.zero_grad()
+        torch.manual_seed(11)
+        with torch.no_grad():
+            plan = plan_views(frames, pc, pipe, bg, mode) if mode_value == 2 else None
+        res = render_many(frames, pc, pipe, bg, retain_grad=True, mode=mode, dense=True, anchor_grad=False, plan=plan)
+        _, overflowed = resolve_deferred([r.raster_state for r in res])
+        assert not overflowed
+        rates = torch.stack([r.bit_per_param for r in res])
+        loss = sum((r.rendered_image * dL).sum() for r in res) + 50.0 * rates.sum()
+        loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in pc.named_parameters() if p.grad is not None}
+        return float(loss), rates.detach().clone(), [r.rendered_image.detach().clone() for r in res], grads
+
+    la, ra, ia, ga = run(all_rows=True)
+    ls, rs_, is_, gs = run(all_rows=False)
+    assert torch.allclose(ra, rs_, rtol=1e-6, atol=0) and abs(la - ls) <= 1e-6 * abs(la), (ra.tolist(), rs_.tolist())
+    for a, b in zip(ia, is_):
+        assert torch.equal(a, b)                     # the quantisation steps, hence the noise and the Gaussians, are the same numbers
+    for n in set(ga) ^ set(gs):                      # a tensor one form leaves without a gradient carries zeros in the other
+        assert float((ga.get(n, gs.get(n))).abs().max()) == 0.0, n        # (STE mode detaches the steps: nothing reaches the quant_step nets)
+    assert any("dist_net" in n for n in gs) and any(n.endswith("params") for n in gs)
+    assert mode_value != 2 or any("quant_step_net" in n for n in gs)
+    for n in set(ga) & set(gs):
+        scale = float(ga[n].abs().max())
+        err = float((ga[n] - gs[n]).abs().max())
+        assert err <= 2e-6 * scale + 1e-30, (n, err, scale)
