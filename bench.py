@@ -252,6 +252,29 @@ def run_stream_decode(args, dev, height=2160, width=3840, frames=300, gaussians_
             "render_fps_note": PAIR_NOTE}
 
 
+_AFFINITY0 = _AFFINITY_GPU = None
+
+
+def _gpu_cores():
+    """Back onto the GPU's NUMA node after a CPU leg."""
+    if _AFFINITY_GPU is not None:
+        try:
+            os.sched_setaffinity(0, _AFFINITY_GPU)
+        except OSError:
+            pass
+
+
+def _all_cores() -> int:
+    """The CPU baseline runs on every core the process was started with: undo the GPU-side NUMA binding for it."""
+    if _AFFINITY0 is not None:
+        try:
+            os.sched_setaffinity(0, _AFFINITY0)
+            return len(_AFFINITY0)
+        except OSError:
+            pass
+    return os.cpu_count() or 1
+
+
 # ------------------------------------------------------------------------------------------------ train_step
 def run_train_step(args, rank, world, dev):
     """BASELINE.json configs[2]; frames shard over ranks with one gradient all-reduce per step."""
@@ -500,7 +523,7 @@ def run_train_step(args, rank, world, dev):
         fr = cube.get_dummy_frame(out.frame_idx)
         st = oracle.make_settings(H, W, fr.x_min, fr.y_min, fr.scale, mp_.threshold, fr.view_matrix.permute(1, 0).contiguous().numpy())
         arrs = [t.detach().cpu().numpy() for t in (gs.xyz, gs.color, gs.opacity, gs.scaling, gs.rot)]
-        cores = os.cpu_count() or 1
+        cores = _all_cores()
         t0 = time.perf_counter()
         fwd = oracle.raster_forward(st, *arrs, num_threads=cores)
         oracle.raster_backward(st, *arrs, fwd, np.ones((3, H, W), np.float32))
@@ -510,6 +533,7 @@ def run_train_step(args, rank, world, dev):
                                          "(scalar) of ONE of the timed step's 4 renders, same Gaussians; the MLPs, hash grid, rate "
                                          "and image losses of the step are NOT in the CPU sample (it does less work per Gaussian)",
                                "seconds": round(tc, 3)}
+        _gpu_cores()
     return res
 
 
@@ -522,7 +546,7 @@ def cpu_baseline_raster(sc, workload):
     s = sc["settings"]
     st = oracle.make_settings(s["H"], s["W"], s["x_min"], s["y_min"], s["scale"], s["threshold"], s["viewmatrix"],
                               bg=s["bg"], scale_modifier=s["scale_modifier"])
-    cores = os.cpu_count() or 1
+    cores = _all_cores()
     t0 = time.perf_counter()
     fwd = oracle.raster_forward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"],
                                 num_threads=cores)
@@ -543,6 +567,7 @@ def cpu_baseline_raster(sc, workload):
         oracle.raster_backward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"], fwd, dL)
         units, t = n_vis, t_f / reps + (time.perf_counter() - t0)
         sample += " (mean) + 1 scalar backward pass"
+    _gpu_cores()
     return {"value": units / t, "unit": "Gaussians/s", "cores": cores, "kind": "port", "sample": sample, "seconds": round(t, 3)}
 
 
@@ -730,6 +755,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one rank per GPU, on the CPU cores of that GPU's NUMA node (gsvc_amd/hostbind.py: the small-shape steps are host-bound and
+    # 10-15 % slower from the far socket); the CPU baseline legs take the whole machine back (_all_cores)
+    global _AFFINITY0, _AFFINITY_GPU
+    _AFFINITY0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    from gsvc_amd.hostbind import bind_to_device
+    if bind_to_device(local_rank):
+        _AFFINITY_GPU = os.sched_getaffinity(0)
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("GSVC_DIST_BACKEND", "nccl")

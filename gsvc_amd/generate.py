@@ -364,13 +364,40 @@ class StepPlan:
         return self
 
 
+HOST_TIMES = {}        # region -> [calls, seconds] of HOST time, filled when GSVC_HOST_TIMES=1 (tools/scratch/host_regions.py)
+_REGION_MODE = 2 if os.environ.get("GSVC_HOST_TIMES") else (1 if os.environ.get("GSVC_REGIONS") else 0)
+
+
+class _HostTimer:
+    __slots__ = ("name", "t0")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        e = HOST_TIMES.setdefault(self.name, [0, 0.0])
+        e[0] += 1
+        e[1] += time.perf_counter() - self.t0
+
+
+_NULL = None
+
+
 def region(name):
-    """Named range for torch.profiler when GSVC_REGIONS=1 (diagnostics), otherwise a no-op context."""
-    import contextlib
-    import os
-    if os.environ.get("GSVC_REGIONS"):
-        return torch.profiler.record_function(name)
-    return contextlib.nullcontext()
+    """Named range: torch.profiler ranges when GSVC_REGIONS=1, host wall-clock per region when GSVC_HOST_TIMES=1 (both read once,
+    at import: diagnostics), otherwise a shared no-op context."""
+    global _NULL
+    if _REGION_MODE == 0:
+        if _NULL is None:
+            import contextlib
+            _NULL = contextlib.nullcontext()
+        return _NULL
+    if _REGION_MODE == 2:
+        return _HostTimer(name)
+    return torch.profiler.record_function(name)
 
 
 class _GenTail(torch.autograd.Function):

@@ -9,7 +9,7 @@ import os
 import torch
 
 from ..common.base import RenderResults
-from ..generate import GenerateMode, generate_neural_gaussians, generate_neural_gaussians_many, generator_trunks
+from ..generate import GenerateMode, generate_neural_gaussians, generate_neural_gaussians_many, generator_trunks, region
 from ..rasterizer import GaussianRasterizer, raster_forward, rasterize_many, settings_to_c
 from .preprocess import prefilter_geometry, prefilter_voxel, prefilter_voxels_many, raster_settings_for
 
@@ -68,8 +68,9 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
     else:
         geometry = prefilter_geometry(pc)
         visible = prefilter_voxels_many(frames, pc, pipe, bg_color, geometry=geometry)
-    gss_list = generate_neural_gaussians_many(frames, pc, visible, mode, dense=dense,
-                                              anchors=None if anchor_grad else geometry[0], plan=plan)
+    with region('render.generate'):
+        gss_list = generate_neural_gaussians_many(frames, pc, visible, mode, dense=dense,
+                                                  anchors=None if anchor_grad else geometry[0], plan=plan)
     results = []
     batch = getattr(gss_list[0], "batch", None) if (dense and gss_list) else None
     if batch is not None and getattr(batch, "xyz", None) is not None and len(batch.seg_offsets) == len(frames) + 1:
@@ -78,8 +79,9 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
         bounds = batch.seg_offsets
         leaf = torch.empty(bounds[-1], 3, dtype=pc._anchor.dtype, device=batch.xyz.device, requires_grad=True)   # value never read
         cs_list = [settings_to_c(raster_settings_for(f, pc, pipe, bg_color, scaling_modifier)) for f in frames]
-        images, radii_all, states = rasterize_many(cs_list, bounds, batch.xyz, leaf, batch.color, batch.neural_opacity, batch.scaling,
-                                                   batch.rot)
+        with region('render.rasterize_many'):
+            images, radii_all, states = rasterize_many(cs_list, bounds, batch.xyz, leaf, batch.color, batch.neural_opacity, batch.scaling,
+                                                       batch.rot)
         seen_all = radii_all > 0
         batch.viewspace, batch.seen = leaf, seen_all
         for r, (frame, visible_mask, gss) in enumerate(zip(frames, visible, gss_list)):

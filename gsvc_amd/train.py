@@ -108,6 +108,9 @@ class Trainer:
         self.prefetch = prefetch and batched and not os.environ.get("GSVC_NO_PREFETCH")      # env: A/B timing only
         self._plan = self._plan_idx = self._plan_mode = None
         self.pc, self.dataset, self.opt, self.pipe, self.mp = gaussians, dataset, opt, pipe, model_params
+        if gaussians._anchor.is_cuda:
+            from .hostbind import bind_to_device
+            bind_to_device(gaussians._anchor.device)      # the step is host-bound at small sizes: stay on the GPU's NUMA node
         self.controller = TrainingController(opt)
         self.controller.step()  # iterations are 1-based
         self.rng = random.Random(seed + gdist.rank())
@@ -168,7 +171,7 @@ class Trainer:
             return out
         self._plan = self._plan_idx = None
         if self.prefetch and self.pc._anchor.is_cuda:
-            with torch.no_grad():
+            with torch.no_grad(), region('step.plan'):
                 self._plan_idx = self.rng.randint(self.lo, max(self.lo, self.hi - 1))
                 self._plan_mode = self.controller.render_mode
                 self._plan = plan_views(self._views(self._plan_idx), self.pc, self.pipe, self.background, self._plan_mode)
@@ -272,8 +275,9 @@ class Trainer:
                                   self._plan.matches(pc)) else None
             views = plan.frames if plan is not None else self._views(frame_idx)
             frame1, frame2 = views[0], views[2]
-            r1f, r1b, r2f, r2b = render_many(views, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode,
-                                             dense=True, anchor_grad=self.anchor_grad, plan=plan)
+            with region('step.render_many'):
+                r1f, r1b, r2f, r2b = render_many(views, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode,
+                                                 dense=True, anchor_grad=self.anchor_grad, plan=plan)
             image1 = image2 = None         # the two-view frames are formed inside the SSIM kernels below (ssim_l1_pair)
             # replicas: "did any rank's instance buffer overflow" is reduced right behind the forward kernels, so that
             # the end-of-step check does not have to wait for the backward (overflow word = second int32 of a binning blob)
@@ -354,12 +358,14 @@ class Trainer:
         finally:
             for h in handles:
                 h.remove()
-        self.reducer.finish()
-        self._add_mask_reg()
+        with region('step.reducer_finish'):
+            self.reducer.finish()
+            self._add_mask_reg()
 
         if self.batched:
             # the only host synchronisation of the step after the visibility test: the 4 renders' instance counters
-            _, overflowed = resolve_deferred([r.raster_state for r in renders])
+            with region('step.resolve_counters'):
+                _, overflowed = resolve_deferred([r.raster_state for r in renders])
             if gdist.any_rank_finish(ovf_handle, overflowed):      # replicas repeat the step together (their collectives must pair up)
                 return None
             for r in renders:
@@ -367,7 +373,8 @@ class Trainer:
         with torch.no_grad():
             if self.controller.gaussian_statis:
                 if self.batched:
-                    pc.training_statis_many(renders)
+                    with region('step.statis'):
+                        pc.training_statis_many(renders)
                 else:
                     for r in renders:
                         pc.training_statis(r)
@@ -378,8 +385,9 @@ class Trainer:
             if self.controller.clean_denorm:
                 pc.opacity_accum = pc.offset_gradient_accum = pc.offset_denom = None
             if iteration < opt.iterations:
-                pc.optimizer.step()
-                pc.optimizer.zero_grad(set_to_none=True)
+                with region('step.optimizer'):
+                    pc.optimizer.step()
+                    pc.optimizer.zero_grad(set_to_none=True)
         active = sum(r.active_gaussains for r in renders)
         return StepOutput(loss=loss.detach(), image1=image1.detach(), image2=image2.detach(), renders=renders,
                           active_gaussians=active, frame_idx=frame_idx)

@@ -1,16 +1,15 @@
-"""A/B of an environment switch inside ONE process (same model trajectory): alternating timed segments of fitting steps.
-usage: python tools/scratch/ab_env.py VAR valueA valueB"""
-import os, sys, time
+"""cProfile of the fitting step on BOTH host threads: the main thread (forward, optimizer) and the autograd engine's thread (the
+custom backward functions), by cumulative and by own time.  usage: python tools/scratch/host_prof2.py [cfg3]"""
+import cProfile, os, pstats, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gsvc_amd.arguments import cfg_20240919
 from gsvc_amd.frame import SyntheticFrameCube
 from gsvc_amd.model import GaussianModel
 from gsvc_amd.train import Trainer
-var, va, vb = sys.argv[1:4]
 dev = torch.device("cuda:0")
 mp_, opt, pipe = cfg_20240919()
-CFG3 = "cfg3" in sys.argv[1:] or bool(os.environ.get("GSVC_AB_CFG3"))      # BASELINE configs[3] per-GPU shape: yaml as is
+CFG3 = "cfg3" in sys.argv[1:]
 cube = SyntheticFrameCube(1080, 1920, 600 if CFG3 else 64, seed=1234, device=dev).materialize()
 if not CFG3:
     mp_.threshold = 8.0 / cube.scale
@@ -27,25 +26,27 @@ pc.create_from_points(rng.uniform(lim, -lim, (100_000 if CFG3 else 245_000, 3)),
 pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
 pc.training_setup(opt)
 tr = Trainer(pc, cube, opt, pipe, mp_, seed=0)
-it = 0
-for _ in range(150):
-    it += 1; tr.step(it)
-res = {va: [], vb: []}
-for rep in range(5):
-    for v in (va, vb):
-        if v == "unset":
-            os.environ.pop(var, None)
-        else:
-            os.environ[var] = v
-        for _ in range(3):
-            it += 1; tr.step(it)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        act = torch.zeros((), device=dev, dtype=torch.float64)
-        for _ in range(25):
-            it += 1; act += tr.step(it).active_gaussians
-        torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / 25
-        res[v].append((ms, float(act) / 100))
-for v, r in res.items():
-    ms = np.array([x[0] for x in r]); a = np.array([x[1] for x in r])
-    print(f"{var}={v}: {ms.mean():.3f} ms/step (min {ms.min():.3f}, max {ms.max():.3f}), active per render {a.mean():.0f}, us per 1000 active {1e3 * ms.mean() / (4 * a.mean() / 1e3):.2f}")
+for i in range(1, 41):
+    tr.step(i)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(41, 91):
+    tr.step(i)
+torch.cuda.synchronize()
+print(f"free running: {1e3 * (time.perf_counter() - t0) / 50:.2f} ms/step")
+prm, prb = cProfile.Profile(), cProfile.Profile()
+orig = torch.Tensor.backward
+def bw(self, *a, **k):
+    self.register_hook(lambda g: (prb.enable(), None)[1])      # runs first on the engine's thread
+    return orig(self, *a, **k)
+torch.Tensor.backward = bw
+N = 30
+prm.enable()
+for i in range(91, 91 + N):
+    tr.step(i)
+prm.disable(); torch.cuda.synchronize()
+torch.Tensor.backward = orig
+for name, pr in (("MAIN THREAD", prm), ("AUTOGRAD THREAD", prb)):
+    for key in ("cumulative", "tottime"):
+        print(f"==== {name} by {key} (ms per step = seconds * {1e3 / N:.1f})")
+        pstats.Stats(pr).sort_stats(key).print_stats(28 if key == "cumulative" else 22)

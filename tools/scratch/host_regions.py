@@ -1,16 +1,17 @@
-"""A/B of an environment switch inside ONE process (same model trajectory): alternating timed segments of fitting steps.
-usage: python tools/scratch/ab_env.py VAR valueA valueB"""
+"""Host wall-clock per region of the fitting step (GSVC_HOST_TIMES=1: gsvc_amd.generate.region), free-running steps.
+usage: GSVC_HOST_TIMES=1 python tools/scratch/host_regions.py [cfg3]"""
 import os, sys, time
+os.environ["GSVC_HOST_TIMES"] = "1"
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from gsvc_amd import generate as G
 from gsvc_amd.arguments import cfg_20240919
 from gsvc_amd.frame import SyntheticFrameCube
 from gsvc_amd.model import GaussianModel
 from gsvc_amd.train import Trainer
-var, va, vb = sys.argv[1:4]
 dev = torch.device("cuda:0")
 mp_, opt, pipe = cfg_20240919()
-CFG3 = "cfg3" in sys.argv[1:] or bool(os.environ.get("GSVC_AB_CFG3"))      # BASELINE configs[3] per-GPU shape: yaml as is
+CFG3 = "cfg3" in sys.argv[1:]
 cube = SyntheticFrameCube(1080, 1920, 600 if CFG3 else 64, seed=1234, device=dev).materialize()
 if not CFG3:
     mp_.threshold = 8.0 / cube.scale
@@ -27,25 +28,21 @@ pc.create_from_points(rng.uniform(lim, -lim, (100_000 if CFG3 else 245_000, 3)),
 pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
 pc.training_setup(opt)
 tr = Trainer(pc, cube, opt, pipe, mp_, seed=0)
-it = 0
-for _ in range(150):
-    it += 1; tr.step(it)
-res = {va: [], vb: []}
-for rep in range(5):
-    for v in (va, vb):
-        if v == "unset":
-            os.environ.pop(var, None)
-        else:
-            os.environ[var] = v
-        for _ in range(3):
-            it += 1; tr.step(it)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        act = torch.zeros((), device=dev, dtype=torch.float64)
-        for _ in range(25):
-            it += 1; act += tr.step(it).active_gaussians
-        torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / 25
-        res[v].append((ms, float(act) / 100))
-for v, r in res.items():
-    ms = np.array([x[0] for x in r]); a = np.array([x[1] for x in r])
-    print(f"{var}={v}: {ms.mean():.3f} ms/step (min {ms.min():.3f}, max {ms.max():.3f}), active per render {a.mean():.0f}, us per 1000 active {1e3 * ms.mean() / (4 * a.mean() / 1e3):.2f}")
+for i in range(1, 61):
+    tr.step(i)
+torch.cuda.synchronize()
+if os.environ.get("NOGC"):
+    import gc
+    gc.collect(); gc.freeze(); gc.disable()
+G.HOST_TIMES.clear()
+N = 100
+t0 = time.perf_counter()
+th = 0.0
+for i in range(61, 61 + N):
+    a = time.perf_counter()
+    tr.step(i)
+    th += time.perf_counter() - a
+torch.cuda.synchronize()
+print(f"free running: {1e3 * (time.perf_counter() - t0) / N:.3f} ms/step; host inside Trainer.step {1e3 * th / N:.3f} ms/step")
+for k, (c, s) in sorted(G.HOST_TIMES.items(), key=lambda kv: -kv[1][1]):
+    print(f"  {k:28s} {1e3 * s / N:7.3f} ms/step  ({c / N:.1f} calls/step)")

@@ -9,8 +9,10 @@ from gsvc_amd.model import GaussianModel
 from gsvc_amd.train import Trainer
 dev = torch.device("cuda:0")
 mp_, opt, pipe = cfg_20240919()
-cube = SyntheticFrameCube(1080, 1920, 64, seed=1234, device=dev).materialize()
-mp_.threshold = 8.0 / cube.scale
+CFG3 = "cfg3" in sys.argv[1:] or bool(os.environ.get("GSVC_AB_CFG3"))      # BASELINE configs[3] per-GPU shape: yaml as is
+cube = SyntheticFrameCube(1080, 1920, 600 if CFG3 else 64, seed=1234, device=dev).materialize()
+if not CFG3:
+    mp_.threshold = 8.0 / cube.scale
 opt.full_precision_training_total, opt.quantized_training_total = 0, 0
 opt.entropy_constrained_train_total = 10 ** 9
 opt.start_stat, opt.update_until = 0, 10 ** 9
@@ -21,7 +23,7 @@ pc = GaussianModel(mp_, mp_.anchor_feature_dim, mp_.n_offsets, mp_.voxel_size, m
                    log2_hashmap_size=mp_.log2, log2_hashmap_size_2D=mp_.log2_2D, device=dev)
 rng = np.random.default_rng(0)
 lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
-pc.create_from_points(rng.uniform(lim, -lim, (245_000, 3)), spatial_lr_scale=1.0)
+pc.create_from_points(rng.uniform(lim, -lim, (100_000 if CFG3 else 245_000, 3)), spatial_lr_scale=1.0)
 pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
 pc.training_setup(opt)
 tr = Trainer(pc, cube, opt, pipe, mp_, seed=0)
