@@ -116,8 +116,23 @@ def spawn_ranks(args) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ helpers
+def csrc_fingerprint():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (tools/pmc_extract.py writes the same
+    number next to the counters it extracts)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gsvc_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload, kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC extract (tools/pmc_extract.py) + where it came from."""
+    """HBM bytes per launch from the committed rocprofv3 PMC extract (tools/pmc_extract.py) + where it came from.  The counters
+    cannot be collected inside this process (rocprofv3 wraps the command), so the number is only as good as the file: when the
+    kernel sources have changed since the counters were taken the traffic is REFUSED (None + the reason), not reported stale."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         data = json.load(open(path))
@@ -126,9 +141,47 @@ def pmc_traffic(workload, kernel):
         src = {"measured_live": False, "file": "profiles/pmc_latest.json", "valu": valu,
                "binary": data.get("_binary", {}).get(workload, "unknown"),
                "passes": data.get("_source", {}).get(workload, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")}
+        taken, now = data.get("_csrc_sha16", {}).get(workload), csrc_fingerprint()
+        if taken != now:
+            src["valu"] = None
+            src["refused"] = (f"gsvc_amd/csrc has changed since these counters were taken (sources then {taken}, now {now}): "
+                              f"re-run tools/profile_round.sh")
+            return None, src
         return val, src
     except Exception:  # noqa: BLE001
         return None, {"measured_live": False, "file": None}
+
+
+# instruction prices of the compositing backward (csrc/raster_bwd.hip): a straight-line replay of one list entry over one 8x8
+# quadrant is 36 vector instructions + 3 LDS reads of the entry's record, the nine-sum reduction 74 cross-lane instructions per
+# four entries; a wave-instruction holds a SIMD's issue slot for 1.5 ns (fma) to 3.5 ns (exp, rcp, permlane swap), 1.8 ns on this
+# kernel's mix (tools/micro/valu_rate.hip, profiles/r03/microbench_valu_rate.txt); 256 CUs x 4 SIMDs
+REPLAY_INSTS, REDUCE_INSTS_PER_ENTRY, NS_PER_WAVE_INST, SIMDS = 36 + 3, 18.5, 1.8, 256 * 4
+
+
+def roofline_valu(probe, kern_dom, one_stream_us, traffic_src):
+    """The roof k_blend_bwd_tile is really under: vector-instruction issue.  ``probe`` = [replays, valid lanes, entries, launches]
+    counted by the kernel itself on the timed scene (gsvc_profile_enable bit 1)."""
+    replays, lanes, entries, launches = probe
+    if not launches or not replays:
+        return None
+    rep, ent = replays / launches, entries / launches
+    model_us = (rep * REPLAY_INSTS + ent * REDUCE_INSTS_PER_ENTRY) * NS_PER_WAVE_INST / SIMDS * 1e-3
+    valu = (traffic_src or {}).get("valu") or {}
+    out = {"kernel": "k_blend_bwd", "bound": "valu", "measured_live": True,
+           "entries_replayed_per_launch": ent, "quadrant_replays_per_launch": rep, "replays_per_entry": rep / max(ent, 1.0),
+           "valid_lane_frac": lanes / (64.0 * replays),
+           "insts_per_entry_pixel": {"replay": REPLAY_INSTS, "reduction_per_entry": REDUCE_INSTS_PER_ENTRY,
+                                     "per_useful_pixel": REPLAY_INSTS / max(lanes / (64.0 * replays), 1e-9) / 64.0},
+           "issue_model_us": model_us,
+           "issue_model": f"(replays x {REPLAY_INSTS} + entries x {REDUCE_INSTS_PER_ENTRY}) wave-instructions x {NS_PER_WAVE_INST} ns "
+                          f"/ {SIMDS} SIMDs; list walking, culling tests and the row stores are not in it",
+           "avg_launch_us_one_stream": one_stream_us, "avg_launch_us": None if kern_dom is None else kern_dom["avg_us"],
+           "frac_of_issue_model": None if not one_stream_us else model_us / one_stream_us,
+           "valu_issue_share_pmc": valu.get("valu_issue_share_at_2p4GHz"), "valu_insts_per_launch_pmc": valu.get("valu_insts_per_launch"),
+           "note": "probe counters come from the kernel's diagnostic instantiation on the timed scene; the *_pmc entries are the SQ "
+                   "counters of profiles/pmc_latest.json (null when the kernel sources changed since)"}
+    return out
 
 
 def timed(torch, dist, world, fn, steps):
@@ -395,6 +448,22 @@ def run_train_step(args, rank, world, dev):
             os.environ.pop("GSVC_RASTER_STREAMS", None)
         else:
             os.environ["GSVC_RASTER_STREAMS"] = old_streams
+    # the compositing backward's replay counters, live on the timed scene (gsvc_profile_enable bit 1: its diagnostic instantiation
+    # adds, per launch, the (entry, quadrant) replays, the lanes of those replays that held a contributing pixel and the entries
+    # replayed to spare words of the render's counters block, which the forward zeroes)
+    probe = [0, 0, 0, 0]
+    _lib.profile_enable(2)
+    try:
+        for _ in range(2):
+            o = step()
+            torch.cuda.synchronize()
+            for r in o.renders:
+                c = r.raster_state.binning[64:88].view(torch.int64).tolist()
+                for i in range(3):
+                    probe[i] += c[i]
+                probe[3] += 1
+    finally:
+        _lib.profile_enable(False)
     out = last[0]
 
     # decoder loop (reference utils/report_utils.py:297-319: per frame the visibility test, the anchor -> Gaussian
@@ -469,6 +538,7 @@ def run_train_step(args, rank, world, dev):
                                              "duration while it shares the chip with the other stream's kernels (what rocprofv3 reports for "
                                              "the same command); this is the same kernel with the renders on one stream "
                                              "(GSVC_RASTER_STREAMS=1): its exclusive duration"})},
+        "roofline_valu": roofline_valu(probe, kern.get("k_blend_bwd"), one_stream.get("k_blend_bwd"), traffic_src),
         "gsvc_kernel_us_per_step": kernel_us,
         "timed_region": timed_region,
         "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] / args.steps} for k, v in kern.items()},

@@ -280,8 +280,9 @@ def current_stream(device=None):
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
 
 
-def profile_enable(on: bool):
-    check(lib().gsvc_profile_enable(1 if on else 0), "gsvc_profile_enable")
+def profile_enable(on):
+    """bool, or the bit set of include/gsvc_hip.h (1 = per-kernel timing, 2 = the compositing backward's replay counters)."""
+    check(lib().gsvc_profile_enable(int(on)), "gsvc_profile_enable")
 
 
 def profile_collect(max_kernels: int = 64):

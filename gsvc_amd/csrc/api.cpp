@@ -24,11 +24,13 @@ struct ProfRec {
     hipEvent_t a, b;
 };
 static bool g_prof_on = false;
+static bool g_bwd_probe = false;
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_pool;
 
 bool profile_enabled() { return g_prof_on; }
+bool bwd_probe_enabled() { return g_bwd_probe; }
 
 static hipEvent_t get_event()
 {
@@ -61,7 +63,8 @@ void profile_end(hipStream_t s)
 extern "C" int gsvc_profile_enable(int on)
 {
     std::lock_guard<std::mutex> lk(gsvc::g_prof_mu);
-    gsvc::g_prof_on = on != 0;
+    gsvc::g_prof_on = (on & 1) != 0;
+    gsvc::g_bwd_probe = (on & 2) != 0;
     for (auto &r : gsvc::g_prof) { gsvc::g_pool.push_back(r.a); gsvc::g_pool.push_back(r.b); }
     gsvc::g_prof.clear();
     return GSVC_OK;

@@ -6,7 +6,7 @@
 //   B1 blend_bwd     one wave per 16x16 tile (lane l owns pixel l of each 8x8 quadrant) walks the tile's sorted list
 //                    back to front in chunks of 64 entries: bbox + exact ellipse test per quadrant, replay of the alpha
 //                    compositing per pixel, per Gaussian nine sums (moments of h = G dL/dalpha and the colour
-//                    gradients) reduced over the wave with permlane swaps + DPP (two entries per pass), written per chunk
+//                    gradients) reduced over the wave with permlane swaps + DPP (four entries per pass), written per chunk
 //                    as whole 64-byte rows — one per (tile, Gaussian) instance, at the row index the sort kernel left in
 //                    gslot — with plain stores: no atomics, no zero-fill pass, deterministic.
 //   B2 gaussian_bwd  one lane per Gaussian: adds up the Gaussian's rows (contiguous, one per tile of its rectangle), then
@@ -17,118 +17,6 @@
 #include <cstdlib>
 
 namespace gsvc {
-
-// Nine per-Gaussian sums over the wave in 24 cross-lane instructions (a plain DPP butterfly needs 54): values 0..7 are
-// reduced "transposed" — every halving step also halves the number of live registers (v_permlane32_swap / v_permlane16_swap move half of one register into the
-// idle half of its partner, one add then reduces two values at once) — so that afterwards a0 holds, in lane group
-// g = lane / 8, the wave total of value g; the ninth value is reduced the classic way into lane 63.
-__device__ __forceinline__ void wave_sum9_spread(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
-                                                 float &a6, float &a7, float &a8)
-{
-    const unsigned long long odd_half_rows = 0xFF00FF00FF00FF00ull;
-    asm volatile("s_nop 1\n"
-                 "v_permlane32_swap_b32 %0, %4\n"
-                 "v_permlane32_swap_b32 %1, %5\n"
-                 "v_permlane32_swap_b32 %2, %6\n"
-                 "v_permlane32_swap_b32 %3, %7\n"
-                 "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32 %0, %0, %4\n"
-                 "v_add_f32 %1, %1, %5\n"
-                 "v_add_f32 %2, %2, %6\n"
-                 "v_add_f32 %3, %3, %7\n"
-                 "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_permlane16_swap_b32 %0, %2\n"
-                 "v_permlane16_swap_b32 %1, %3\n"
-                 "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32 %0, %0, %2\n"
-                 "v_add_f32 %1, %1, %3\n"
-                 "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_cndmask_b32_e64 %0, %0, %1, %9\n"
-                 "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8)
-                 : "s"(odd_half_rows));
-}
-
-// The same reduction for TWO list entries at once: the two dependent chains are issued stage by stage side by side, so
-// each chain's cross-lane latency (and the wait states between a VALU write and a DPP read) is covered by the other's
-// instructions.  The two ninth values share one chain: a permlane32 swap + add leaves A's in the lower and B's in the
-// upper 32 lanes of a8, five DPP steps finish both.  Afterwards: a0 / b0 hold, in lane group g = lane / 8, the total
-// of value g of entry A / B; a8 holds A's ninth total in lane 31 and B's in lane 63.  61 instructions for two entries.
-__device__ __forceinline__ void wave_sum9_spread_x2(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
-                                                    float &a6, float &a7, float &a8, float &b0, float &b1, float &b2,
-                                                    float &b3, float &b4, float &b5, float &b6, float &b7, float &b8)
-{
-    const unsigned long long odd_half_rows = 0xFF00FF00FF00FF00ull;
-    asm volatile("s_nop 1\n"
-                 "v_permlane32_swap_b32 %0, %4\n"
-                 "v_permlane32_swap_b32 %1, %5\n"
-                 "v_permlane32_swap_b32 %2, %6\n"
-                 "v_permlane32_swap_b32 %3, %7\n"
-                 "v_permlane32_swap_b32 %9, %13\n"
-                 "v_permlane32_swap_b32 %10, %14\n"
-                 "v_permlane32_swap_b32 %11, %15\n"
-                 "v_permlane32_swap_b32 %12, %16\n"
-                 "v_permlane32_swap_b32 %8, %17\n"
-                 "s_nop 1\n"
-                 "v_add_f32 %0, %0, %4\n"
-                 "v_add_f32 %1, %1, %5\n"
-                 "v_add_f32 %2, %2, %6\n"
-                 "v_add_f32 %3, %3, %7\n"
-                 "v_add_f32 %9, %9, %13\n"
-                 "v_add_f32 %10, %10, %14\n"
-                 "v_add_f32 %11, %11, %15\n"
-                 "v_add_f32 %12, %12, %16\n"
-                 "v_add_f32 %8, %8, %17\n"
-                 "s_nop 1\n"
-                 "v_permlane16_swap_b32 %0, %2\n"
-                 "v_permlane16_swap_b32 %1, %3\n"
-                 "v_permlane16_swap_b32 %9, %11\n"
-                 "v_permlane16_swap_b32 %10, %12\n"
-                 "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32 %0, %0, %2\n"
-                 "v_add_f32 %1, %1, %3\n"
-                 "v_add_f32 %9, %9, %11\n"
-                 "v_add_f32 %10, %10, %12\n"
-                 "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %9, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %10, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_cndmask_b32_e64 %0, %0, %1, %18\n"
-                 "v_cndmask_b32_e64 %9, %9, %10, %18\n"
-                 "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %9, %9, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                 "s_nop 1\n"
-                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
-                 "v_add_f32_dpp %9, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xf\n"
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(b0),
-                   "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7), "+v"(b8)
-                 : "s"(odd_half_rows));
-}
 
 __device__ __forceinline__ int sext16b(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 
@@ -156,6 +44,95 @@ struct PixState {
 struct Sums9 {
     float h, x, y, xx, xy, yy, r, g, b;
 };
+
+// Nine sums of FOUR list entries in one pass: 74 cross-lane instructions per four entries (18.5 per entry; rounds 1-3 reduced
+// two entries per pass in 61: 30.5 per entry).  Every halving stage pairs registers of DIFFERENT entries, so each stage halves the number of live
+// registers as well as the number of lanes per value:
+//   stage 32  (A, B) and (C, D): v_permlane32_swap + add per value leaves A's 32 half-sums in the lower and B's in the upper half
+//   stage 16  (AB, CD): v_permlane16_swap + add -> nine registers whose 16-lane rows hold the partial sums of entry A | C | B | D
+//   stage 8/4 row_ror:8 and row_half_mirror adds whose bank_mask writes only half of the destination's banks: two registers merge
+//             into one per stage without a select (9 -> 5 -> 3 registers)
+//   stage 2/1 quad_perm adds: afterwards every lane of the quad (row r, bank b) of q.xx holds the total of value {0,2,1,3}[b] of
+//             row r's entry, of q.g value {4,6,5,7}[b], and every lane of row r of q.b the ninth.
+__device__ __forceinline__ void r4_pair(Sums9 &a, Sums9 &b, const bool rows16)
+{
+    if (!rows16)
+        asm volatile("s_nop 1\n"
+                     "v_permlane32_swap_b32 %0, %9\n"
+                     "v_permlane32_swap_b32 %1, %10\n"
+                     "v_permlane32_swap_b32 %2, %11\n"
+                     "v_permlane32_swap_b32 %3, %12\n"
+                     "v_permlane32_swap_b32 %4, %13\n"
+                     "v_permlane32_swap_b32 %5, %14\n"
+                     "v_permlane32_swap_b32 %6, %15\n"
+                     "v_permlane32_swap_b32 %7, %16\n"
+                     "v_permlane32_swap_b32 %8, %17\n"
+                     "s_nop 1\n"
+                     "v_add_f32 %0, %0, %9\n"
+                     "v_add_f32 %1, %1, %10\n"
+                     "v_add_f32 %2, %2, %11\n"
+                     "v_add_f32 %3, %3, %12\n"
+                     "v_add_f32 %4, %4, %13\n"
+                     "v_add_f32 %5, %5, %14\n"
+                     "v_add_f32 %6, %6, %15\n"
+                     "v_add_f32 %7, %7, %16\n"
+                     "v_add_f32 %8, %8, %17\n"
+                     : "+v"(a.h), "+v"(a.x), "+v"(a.y), "+v"(a.xx), "+v"(a.xy), "+v"(a.yy), "+v"(a.r), "+v"(a.g), "+v"(a.b), "+v"(b.h),
+                       "+v"(b.x), "+v"(b.y), "+v"(b.xx), "+v"(b.xy), "+v"(b.yy), "+v"(b.r), "+v"(b.g), "+v"(b.b));
+    else
+        asm volatile("s_nop 1\n"
+                     "v_permlane16_swap_b32 %0, %9\n"
+                     "v_permlane16_swap_b32 %1, %10\n"
+                     "v_permlane16_swap_b32 %2, %11\n"
+                     "v_permlane16_swap_b32 %3, %12\n"
+                     "v_permlane16_swap_b32 %4, %13\n"
+                     "v_permlane16_swap_b32 %5, %14\n"
+                     "v_permlane16_swap_b32 %6, %15\n"
+                     "v_permlane16_swap_b32 %7, %16\n"
+                     "v_permlane16_swap_b32 %8, %17\n"
+                     "s_nop 1\n"
+                     "v_add_f32 %0, %0, %9\n"
+                     "v_add_f32 %1, %1, %10\n"
+                     "v_add_f32 %2, %2, %11\n"
+                     "v_add_f32 %3, %3, %12\n"
+                     "v_add_f32 %4, %4, %13\n"
+                     "v_add_f32 %5, %5, %14\n"
+                     "v_add_f32 %6, %6, %15\n"
+                     "v_add_f32 %7, %7, %16\n"
+                     "v_add_f32 %8, %8, %17\n"
+                     : "+v"(a.h), "+v"(a.x), "+v"(a.y), "+v"(a.xx), "+v"(a.xy), "+v"(a.yy), "+v"(a.r), "+v"(a.g), "+v"(a.b), "+v"(b.h),
+                       "+v"(b.x), "+v"(b.y), "+v"(b.xx), "+v"(b.xy), "+v"(b.yy), "+v"(b.r), "+v"(b.g), "+v"(b.b));
+}
+
+// q0..q8 = h x y xx xy yy r g b.  A DPP read of a register needs two wait states after the VALU write: the order below keeps two
+// other instructions between every write and its dependent read.
+__device__ __forceinline__ void r4_tail(Sums9 &q)
+{
+    asm volatile("s_nop 1\n"
+                 "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+                 "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+                 "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+                 "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+                 "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %1, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+                 "v_add_f32_dpp %3, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+                 "v_add_f32_dpp %5, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+                 "v_add_f32_dpp %7, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+                 "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n"
+                 "v_add_f32_dpp %7, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n"
+                 "v_add_f32_dpp %3, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n"
+                 "v_add_f32_dpp %7, %5, %5 row_half_mirror row_mask:0xf bank_mask:0x5\n"
+                 "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 0\n"
+                 "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 : "+v"(q.h), "+v"(q.x), "+v"(q.y), "+v"(q.xx), "+v"(q.xy), "+v"(q.yy), "+v"(q.r), "+v"(q.g), "+v"(q.b));
+}
+
 
 // One list entry at one pixel, straight-line: a pixel the entry did not contribute to (behind the pixel's last
 // contributor, alpha < 1/255, power > 0, outside the image) runs the same instructions with alpha = 0 and G = 0, which
@@ -198,7 +175,7 @@ __device__ __forceinline__ bool bwd_pixel(PixState &p, float dx, float dy, const
 // partial-sum buffer (row index from the sort: gslot); entries nothing reached get a row of zeros.  B2 then adds up
 // each Gaussian's rows (they are contiguous and in tile order: the sum order is fixed, the backward is deterministic).
 #ifndef GSVC_BWD_WAVES
-#define GSVC_BWD_WAVES 4
+#define GSVC_BWD_WAVES 5      // 96 VGPRs: the four-entry reduction's 27 live sums fit without a spill
 #endif
 // DBG: the timing experiments / lane-efficiency probe selected by the run-time word `dbg` (GSVC_BWD_DEBUG); the production
 // instantiation (DBG = false) carries none of their code or registers
@@ -334,8 +311,8 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
                     qm &= ~(1 << q);
         }
         const unsigned long long mask = __ballot(qm != 0);
+        const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
         if (qm != 0) {
-            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
             s_f0[pos] = make_float4(r0.x, r0.y, (0.5f * 1.44269504088896340736f) * r0.z, 1.44269504088896340736f * r0.w);
             s_f1[pos] = make_float4((0.5f * 1.44269504088896340736f) * r1.x, r1.y, r1.z, r1.w);
             s_f2[pos] = make_float2(r2x, __int_as_float(lane | (qm << 8) | ((k - beg + 1) << 12)));
@@ -365,26 +342,33 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
                     }
                 }
         };
-        // after a reduction lane 8g holds the total of value g (g < 8) in the first register, lane 63 the total of the ninth
-        int j = 0;
-        for (; j + 2 <= cnt; j += 2) {
-            Sums9 sa, sb;
-            int ea, eb;
-            replay(j, sa, ea);
-            replay(j + 1, sb, eb);
-            if (!(dbg & 2))                                   // timing experiment only: no reduction
-                wave_sum9_spread_x2(sa.h, sa.x, sa.y, sa.xx, sa.xy, sa.yy, sa.r, sa.g, sa.b, sb.h, sb.x, sb.y, sb.xx, sb.xy,
-                                    sb.yy, sb.r, sb.g, sb.b);
-            if ((lane & 7) == 0) { s_out[ea][lane >> 3] = sa.h; s_out[eb][lane >> 3] = sb.h; }
-            if ((lane & 31) == 31) s_out[lane == 31 ? ea : eb][8] = sa.b;
-        }
-        if (j < cnt) {
-            Sums9 sa;
-            int ea;
-            replay(j, sa, ea);
-            wave_sum9_spread(sa.h, sa.x, sa.y, sa.xx, sa.xy, sa.yy, sa.r, sa.g, sa.b);
-            if ((lane & 7) == 0) s_out[ea][lane >> 3] = sa.h;
-            if (lane == 63) s_out[ea][8] = sa.b;
+        // four entries per reduction pass (r4_pair / r4_tail above); rows of the reduced registers = entries j, j + 2, j + 1, j + 3.
+        // Lane (row r, bank b, t): t = 0 stores value {0,2,1,3}[b], t = 1 value {4,6,5,7}[b], (b, t) = (0, 2) the ninth, into the
+        // sums of chunk position j + {0,2,1,3}[r]; a group's missing entries (cnt not a multiple of 4) contribute zeros.
+        {
+            const int r = lane >> 4, bk = (lane >> 2) & 3, t = lane & 3;
+            const int perm_r = ((r & 1) << 1) | (r >> 1), perm_b = ((bk & 1) << 1) | (bk >> 1);
+            const bool wr = t < 2 || (t == 2 && bk == 0);
+            const int off = perm_r * 9 + (t == 0 ? perm_b : (t == 1 ? 4 + perm_b : 8));
+            float *so = &s_out[0][0];
+            for (int j = 0; j < cnt; j += 4) {
+                Sums9 sa, sb, sc, sd;
+                int e_;
+                replay(j, sa, e_);
+                if (j + 1 < cnt) replay(j + 1, sb, e_); else sb.h = sb.x = sb.y = sb.xx = sb.xy = sb.yy = sb.r = sb.g = sb.b = 0.f;
+                if (!(dbg & 2)) r4_pair(sa, sb, false);      // (dbg & 2: timing experiment only, no reduction)
+                if (j + 2 < cnt) replay(j + 2, sc, e_); else sc.h = sc.x = sc.y = sc.xx = sc.xy = sc.yy = sc.r = sc.g = sc.b = 0.f;
+                if (j + 3 < cnt) replay(j + 3, sd, e_); else sd.h = sd.x = sd.y = sd.xx = sd.xy = sd.yy = sd.r = sd.g = sd.b = 0.f;
+                if (!(dbg & 2)) {
+                    r4_pair(sc, sd, false);
+                    r4_pair(sa, sc, true);
+                    r4_tail(sa);
+                } else {
+                    sa.h += sb.h + sc.h + sd.h;
+                }
+                const float v = t == 0 ? sa.xx : (t == 1 ? sa.g : sa.b);
+                if (wr) so[j * 9 + off] = v;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -394,7 +378,7 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
         if (k >= beg && bbox_hits_tile(bb.x, bb.y, tx0, ty0) && !(dbg & 16)) {
             float v[9];
 #pragma unroll
-            for (int c = 0; c < 9; c++) v[c] = qm != 0 ? s_out[lane][c] : 0.f;
+            for (int c = 0; c < 9; c++) v[c] = qm != 0 ? s_out[pos][c] : 0.f;      // sums by chunk position
             float4 *row = reinterpret_cast<float4 *>(rows + (size_t)gs * ROW_FLOATS);
             row[0] = make_float4(v[0], v[1], v[2], v[3]);
             row[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -565,7 +549,8 @@ extern "C" int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_
     auto *final_T = (const float *)((const char *)image_state + L.off_final_T);
     auto *n_contrib = (const int32_t *)((const char *)image_state + L.off_n_contrib);
     auto *gslot = (const int32_t *)(bin + L.off_gslot);
-    static const int dbg = getenv("GSVC_BWD_DEBUG") ? atoi(getenv("GSVC_BWD_DEBUG")) : 0;   // kernel-timing experiments
+    static const int dbg_env = getenv("GSVC_BWD_DEBUG") ? atoi(getenv("GSVC_BWD_DEBUG")) : 0;   // kernel-timing experiments
+    const int dbg = dbg_env | (bwd_probe_enabled() ? 128 : 0);     // gsvc_profile_enable(2): the lane-efficiency probe, at run time
     {
         ProfScope _prof("k_blend_bwd", s);
 #define GSVC_BWD_LAUNCH(CS, DB) hipLaunchKernelGGL((k_blend_bwd_tile<CS, DB>), dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, \

@@ -44,7 +44,10 @@ const char *gsvc_version(void);
 /* Per-kernel timing for bench.py (not a drop-in entry point).  While enabled, every kernel launch made by
  * this library is bracketed by hipEvents on its own stream.  gsvc_profile_collect synchronises those events
  * and returns, per kernel name, the launch count and total milliseconds since the last collect/enable.
- * names_out: `max_kernels` slots of 64 bytes.  Returns the number of kernels written (<0 on error). */
+ * names_out: `max_kernels` slots of 64 bytes.  Returns the number of kernels written (<0 on error).
+ * `on` is a bit set: 1 = the per-kernel timing; 2 = the compositing backward runs its diagnostic instantiation and adds, per
+ * launch, three uint64 to bytes 64..87 of the render's counters block (the start of the binning blob): (entry, quadrant) replays,
+ * lanes of those replays that held a contributing pixel, list entries replayed — bench.py's roofline_valu reads them. */
 int gsvc_profile_enable(int on);
 int gsvc_profile_collect(char *names_out_host, int32_t *launches_out_host, float *total_ms_out_host, int max_kernels);
 

@@ -76,6 +76,18 @@ def valu_summary(sq_csv):
     return out
 
 
+def csrc_fingerprint():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from — the same function as bench.py's."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gsvc_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     if sys.argv[1] == "--stats":
         return shorten_stats(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 60)
@@ -91,6 +103,7 @@ def main():
     if workload == "raster_fwdbwd":              # the forward kernels of the same launches
         data["raster_fwd"] = {k: v for k, v in data[workload].items() if "bwd" not in k}
     data.setdefault("_binary", {})[workload] = tag
+    data.setdefault("_csrc_sha16", {})[workload] = csrc_fingerprint()      # bench.py refuses the numbers of another kernel source
     data.setdefault("_source", {})[workload] = (f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python3 bench.py "
                                                 f"--workload {workload}; CSVs: {os.path.basename(fetch_csv)}, {os.path.basename(write_csv)}")
     if workload == "raster_fwdbwd":
