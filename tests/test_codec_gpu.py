@@ -314,3 +314,45 @@ def test_anchor_geometry_decodes_on_the_gpu_lattice_mode_and_refuses_corrupt_str
         assert not np.array_equal(out.cpu().numpy().astype(np.uint16), want)
     except ValueError:
         pass
+
+
+def _oracle_case(seed, n, smin, smax, clamp_sigma):
+    rng = np.random.default_rng(seed)
+    mu = rng.normal(0, min(30.0, smax / 4), n).astype(np.float32)
+    sigma = rng.uniform(0.25, 6.0, n).astype(np.float32)
+    if clamp_sigma:                       # a third of the symbols at the context model's 1e-9 scale clamp (sigma = 1e-9 / Q)
+        sigma[::3] = np.float32(1e-9 / 0.001)
+    sym = np.clip(np.rint(mu.astype(np.float64) + sigma.astype(np.float64) * rng.normal(0, 1, n)), smin, smax).astype(np.int32)
+    sym[:2] = [smin, smax][:min(n, 2)]
+    return sym, mu, sigma
+
+
+@pytest.mark.parametrize("seed,n,seg_len,smin,smax,clamp_sigma", [
+    (0, 3000, 512, -40, 40, False), (1, 4097, 4096, -15000, 15000, False), (2, 2500, 1024, -15000, 15000, True),
+    (3, 1, 512, -2, 2, False), (4, 5000, 2048, 0, 255, True)])
+def test_hip_coder_writes_the_bytes_of_the_independent_host_statement(seed, n, seg_len, smin, smax, clamp_sigma):
+    """gsvc_ans_encode against oracle/ans_oracle.py (plain Python integers / doubles from the written specification, no code
+    shared with csrc/ans.hip): the SAME BYTES, header included; the oracle decodes the HIP stream, the HIP decoder the oracle's.
+    An encode -> decode round trip on the same kernels cannot see a symmetric bug or a format drift; this does."""
+    from gsvc_amd import codec
+    from oracle import ans_oracle
+    sym, mu, sigma = _oracle_case(seed, n, smin, smax, clamp_sigma)
+    want = ans_oracle.encode(sym, mu, sigma, smin, smax, seg_len=seg_len)
+    got = codec.ans_encode(torch.from_numpy(sym).cuda(), torch.from_numpy(mu).cuda(), torch.from_numpy(sigma).cuda(), smin, smax,
+                           seg_len=seg_len)
+    assert got == want, (len(got), len(want), next(i for i, (a, b) in enumerate(zip(got, want)) if a != b) if len(got) == len(want) else None)
+    assert np.array_equal(ans_oracle.decode(got, mu, sigma), sym)
+    back = codec.ans_decode(want, torch.from_numpy(mu).cuda(), torch.from_numpy(sigma).cuda())
+    assert np.array_equal(back.cpu().numpy(), sym)
+
+
+def test_committed_stream_keeps_the_format_from_drifting():
+    """tests/golden/ans_stream.npz (written by tests/golden/make_golden_ans.py with the oracle): the HIP encoder reproduces its
+    2 465 bytes and the HIP decoder reads them back — a change of the table, the frequency formula, the renormalisation or the
+    container shows up here even if encoder and decoder change together."""
+    from gsvc_amd import codec
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ans_stream.npz"))
+    sym, mu, sigma = torch.from_numpy(g["sym"]).cuda(), torch.from_numpy(g["mu"]).cuda(), torch.from_numpy(g["sigma"]).cuda()
+    got = codec.ans_encode(sym, mu, sigma, int(g["smin"]), int(g["smax"]), seg_len=int(g["seg_len"]))
+    assert got == g["stream"].tobytes()
+    assert torch.equal(codec.ans_decode(g["stream"].tobytes(), mu, sigma).to(torch.int32), sym)
