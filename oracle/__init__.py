@@ -45,6 +45,7 @@ def lib():
         _lib.gsvc_oracle_raster_preprocess.restype = C.c_int64
         _lib.gsvc_oracle_raster_forward.restype = C.c_int64
         _lib.gsvc_oracle_raster_backward.restype = None
+        _lib.gsvc_oracle_raster_backward_mt.restype = None
         _lib.gsvc_oracle_grid_forward.restype = C.c_int
         _lib.gsvc_oracle_grid_backward.restype = C.c_int
     return _lib
@@ -153,7 +154,10 @@ class RasterBackward:
 
 
 def raster_backward(st: RasterSettings, means3D, colors, opacities, scales, rotations, fwd: RasterForward,
-                    dL_dimage) -> RasterBackward:
+                    dL_dimage, num_threads: int = 1) -> RasterBackward:
+    """``num_threads`` 1 (default): the serial statement every fixture was generated with.  > 1: tiles in parallel with one
+    accumulator per (tile, Gaussian) instance, added per Gaussian in tile order (bench.py's CPU baseline; the same result for any
+    thread count, a few 1e-16 relative from the serial sums)."""
     means3D, colors, opacities = _f32(means3D), _f32(colors), _f32(opacities).reshape(-1)
     scales, rotations, dL = _f32(scales), _f32(rotations), _f32(dL_dimage)
     P = means3D.shape[0]
@@ -164,10 +168,10 @@ def raster_backward(st: RasterSettings, means3D, colors, opacities, scales, rota
     gs = np.zeros((P, 3), np.float32)
     gq = np.zeros((P, 4), np.float32)
     plist = np.ascontiguousarray(fwd.point_list if fwd.point_list.size else np.zeros(1, np.int32))
-    lib().gsvc_oracle_raster_backward(
+    lib().gsvc_oracle_raster_backward_mt(
         C.byref(st), C.c_int64(P), _p(means3D), _p(colors), _p(opacities), _p(scales), _p(rotations),
         _p(fwd.radii, C.c_int32), _p(fwd.tile_ranges, C.c_int32), _p(plist, C.c_int32), _p(fwd.final_T),
-        _p(fwd.n_contrib, C.c_int32), _p(dL), _p(g3), _p(g2), _p(gc), _p(go), _p(gs), _p(gq))
+        _p(fwd.n_contrib, C.c_int32), _p(dL), _p(g3), _p(g2), _p(gc), _p(go), _p(gs), _p(gq), C.c_int(int(num_threads)))
     return RasterBackward(g3, g2, gc, go, gs, gq)
 
 

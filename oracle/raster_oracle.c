@@ -224,6 +224,12 @@ int64_t gsvc_oracle_raster_forward(const oracle_raster_settings *st, int64_t P, 
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     pre_t *pre = (pre_t *)malloc(sizeof(pre_t) * (size_t)(P > 0 ? P : 1));
     int64_t total = 0;
+#ifdef _OPENMP
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+#endif
+    (void)num_threads;
+    /* every Gaussian on its own: the same numbers whatever the number of threads */
+#pragma omp parallel for schedule(static) reduction(+ : total)
     for (int64_t i = 0; i < P; i++) {
         /* opacity <= 0 can never reach alpha >= 1/255: culled (radius 0), so un-compacted sets may be passed */
         int r = 0;
@@ -241,32 +247,46 @@ int64_t gsvc_oracle_raster_forward(const oracle_raster_settings *st, int64_t P, 
     }
     if (total > list_capacity) { free(pre); return -1; }
 
+    /* The instances ordered by (tile, depth bits, Gaussian index): bucketed by tile (two linear passes), then every tile's
+       bucket sorted on its own, in parallel — the same total order as one sort of all instances (the key is unique). */
+    const int n_tiles = gx * gy;
     inst_t *inst = (inst_t *)malloc(sizeof(inst_t) * (size_t)(total > 0 ? total : 1));
-    int64_t n = 0;
+    int64_t *cursor = (int64_t *)calloc((size_t)n_tiles + 1, sizeof(int64_t));
     for (int64_t i = 0; i < P; i++) {
         if (!radii[i]) continue;
-        uint32_t db = order_bits((st->flags & F_DEPTH_DESCENDING) ? -pre[i].depth : pre[i].depth);
         for (int ty = pre[i].rect[1]; ty < pre[i].rect[3]; ty++)
-            for (int tx = pre[i].rect[0]; tx < pre[i].rect[2]; tx++) {
-                inst[n].tile = (uint32_t)(ty * gx + tx);
-                inst[n].depth_bits = db;
-                inst[n].id = (uint32_t)i;
-                n++;
-            }
+            for (int tx = pre[i].rect[0]; tx < pre[i].rect[2]; tx++) cursor[ty * gx + tx + 1]++;
     }
-    qsort(inst, (size_t)n, sizeof(inst_t), inst_cmp);
-    for (int t = 0; t < gx * gy; t++) { tile_ranges[2 * t] = 0; tile_ranges[2 * t + 1] = 0; }
-    for (int64_t k = 0; k < n; k++) {
-        point_list[k] = (int32_t)inst[k].id;
-        if (k == 0 || inst[k].tile != inst[k - 1].tile) tile_ranges[2 * inst[k].tile] = (int32_t)k;
-        if (k == n - 1 || inst[k].tile != inst[k + 1].tile) tile_ranges[2 * inst[k].tile + 1] = (int32_t)(k + 1);
+    for (int t = 0; t < n_tiles; t++) {
+        cursor[t + 1] += cursor[t];
+        tile_ranges[2 * t] = cursor[t + 1] > cursor[t] ? (int32_t)cursor[t] : 0;
+        tile_ranges[2 * t + 1] = cursor[t + 1] > cursor[t] ? (int32_t)cursor[t + 1] : 0;
     }
+    const int64_t n = cursor[n_tiles];
+    {
+        int64_t *at = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_tiles > 0 ? n_tiles : 1));
+        memcpy(at, cursor, sizeof(int64_t) * (size_t)n_tiles);
+        for (int64_t i = 0; i < P; i++) {
+            if (!radii[i]) continue;
+            uint32_t db = order_bits((st->flags & F_DEPTH_DESCENDING) ? -pre[i].depth : pre[i].depth);
+            for (int ty = pre[i].rect[1]; ty < pre[i].rect[3]; ty++)
+                for (int tx = pre[i].rect[0]; tx < pre[i].rect[2]; tx++) {
+                    inst_t *e = &inst[at[ty * gx + tx]++];
+                    e->tile = (uint32_t)(ty * gx + tx);
+                    e->depth_bits = db;
+                    e->id = (uint32_t)i;
+                }
+        }
+        free(at);
+    }
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int t = 0; t < n_tiles; t++)
+        if (cursor[t + 1] - cursor[t] > 1) qsort(inst + cursor[t], (size_t)(cursor[t + 1] - cursor[t]), sizeof(inst_t), inst_cmp);
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < n; k++) point_list[k] = (int32_t)inst[k].id;
+    free(cursor);
     free(inst);
 
-#ifdef _OPENMP
-    if (num_threads > 0) omp_set_num_threads(num_threads);
-#endif
-    (void)num_threads;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int t = 0; t < gx * gy; t++) {
         int tx = t % gx, ty = t / gx;
@@ -317,21 +337,38 @@ int64_t gsvc_oracle_raster_forward(const oracle_raster_settings *st, int64_t P, 
  * (NDC-scaled screen gradient: (dL/du*0.5*W, dL/dv*0.5*H, 0)), dL_dcolors[P,3], dL_dopacity[P,1],
  * dL_dscales[P,3], dL_drotations[P,4].  Per-Gaussian sums are accumulated in double.
  */
-void gsvc_oracle_raster_backward(const oracle_raster_settings *st, int64_t P, const float *means3D,
-                                 const float *colors, const float *opacities, const float *scales,
-                                 const float *rotations, const int32_t *radii, const int32_t *tile_ranges,
-                                 const int32_t *point_list, const float *final_T, const int32_t *n_contrib,
-                                 const float *dL_dimage, float *dL_dmeans3D, float *dL_dmeans2D,
-                                 float *dL_dcolors, float *dL_dopacity, float *dL_dscales, float *dL_drotations)
+/* num_threads <= 1: the serial statement (one accumulator per Gaussian, contributions added tile after tile, pixel after
+ * pixel: the numbers every fixture was generated with).  num_threads > 1 (bench.py's CPU baseline): the tiles are processed in
+ * parallel into one accumulator per (tile, Gaussian) INSTANCE, and a Gaussian's instances are then added in tile order — the
+ * same contributions in the same order within a tile, associated per tile instead of one by one (differences of a few 1e-16
+ * relative in the double sums, the same result whatever the number of threads). */
+void gsvc_oracle_raster_backward_mt(const oracle_raster_settings *st, int64_t P, const float *means3D,
+                                    const float *colors, const float *opacities, const float *scales,
+                                    const float *rotations, const int32_t *radii, const int32_t *tile_ranges,
+                                    const int32_t *point_list, const float *final_T, const int32_t *n_contrib,
+                                    const float *dL_dimage, float *dL_dmeans3D, float *dL_dmeans2D,
+                                    float *dL_dcolors, float *dL_dopacity, float *dL_dscales, float *dL_drotations,
+                                    int num_threads)
 {
     const int H = st->image_height, W = st->image_width;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int mt = num_threads > 1;
+#ifdef _OPENMP
+    const int threads_before = omp_get_max_threads();      /* restored below: the setting is process-wide */
+    omp_set_num_threads(mt ? num_threads : 1);
+#endif
     pre_t *pre = (pre_t *)malloc(sizeof(pre_t) * (size_t)(P > 0 ? P : 1));
     /* per-Gaussian accumulators: du dv dA dB dC dopacity dcol[3] */
     double *acc = (double *)calloc((size_t)(P > 0 ? P : 1) * 9, sizeof(double));
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < P; i++)
         preprocess_one(st, means3D + 3 * i, scales + 3 * i, rotations + 4 * i, gx, gy, &pre[i]);
+    int64_t n_inst = 0;
+    for (int t = 0; t < gx * gy; t++)
+        if (tile_ranges[2 * t + 1] > n_inst) n_inst = tile_ranges[2 * t + 1];
+    double *iacc = mt ? (double *)calloc((size_t)(n_inst > 0 ? n_inst : 1) * 9, sizeof(double)) : NULL;
 
+#pragma omp parallel for schedule(dynamic, 4)
     for (int t = 0; t < gx * gy; t++) {
         int tx = t % gx, ty = t / gx;
         int s0 = tile_ranges[2 * t];
@@ -361,7 +398,7 @@ void gsvc_oracle_raster_backward(const oracle_raster_settings *st, int64_t P, co
                     float w = alpha * T;
                     const float *c = colors + 3 * id;
                     float dL_dalpha = 0.0f;
-                    double *a = acc + 9 * (int64_t)id;
+                    double *a = mt ? iacc + 9 * (int64_t)k : acc + 9 * (int64_t)id;
                     for (int ch = 0; ch < 3; ch++) {
                         behind[ch] = last_alpha * last_col[ch] + (1.0f - last_alpha) * behind[ch];
                         last_col[ch] = c[ch];
@@ -391,7 +428,24 @@ void gsvc_oracle_raster_backward(const oracle_raster_settings *st, int64_t P, co
             }
     }
 
+    if (mt) {
+        /* a Gaussian's instances in list order = tile order: CSR of the instance indices per Gaussian, then one sum each */
+        int64_t *off = (int64_t *)calloc((size_t)P + 2, sizeof(int64_t));
+        for (int64_t k = 0; k < n_inst; k++) off[point_list[k] + 2]++;
+        for (int64_t i = 0; i < P; i++) off[i + 2] += off[i + 1];
+        int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_inst > 0 ? n_inst : 1));
+        for (int64_t k = 0; k < n_inst; k++) idx[off[point_list[k] + 1]++] = k;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < P; i++)
+            for (int64_t j = off[i]; j < off[i + 1]; j++)
+                for (int c = 0; c < 9; c++) acc[9 * i + c] += iacc[9 * idx[j] + c];
+        free(idx);
+        free(off);
+        free(iacc);
+    }
+
     const float *M = st->viewmatrix;
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < P; i++) {
         float *gm3 = dL_dmeans3D + 3 * i, *gm2 = dL_dmeans2D + 3 * i, *gc = dL_dcolors + 3 * i;
         float *gs = dL_dscales + 3 * i, *gq = dL_drotations + 4 * i;
@@ -458,4 +512,19 @@ void gsvc_oracle_raster_backward(const oracle_raster_settings *st, int64_t P, co
     }
     free(acc);
     free(pre);
+#ifdef _OPENMP
+    omp_set_num_threads(threads_before);
+#endif
+}
+
+void gsvc_oracle_raster_backward(const oracle_raster_settings *st, int64_t P, const float *means3D,
+                                 const float *colors, const float *opacities, const float *scales,
+                                 const float *rotations, const int32_t *radii, const int32_t *tile_ranges,
+                                 const int32_t *point_list, const float *final_T, const int32_t *n_contrib,
+                                 const float *dL_dimage, float *dL_dmeans3D, float *dL_dmeans2D,
+                                 float *dL_dcolors, float *dL_dopacity, float *dL_dscales, float *dL_drotations)
+{
+    gsvc_oracle_raster_backward_mt(st, P, means3D, colors, opacities, scales, rotations, radii, tile_ranges, point_list, final_T,
+                                   n_contrib, dL_dimage, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales,
+                                   dL_drotations, 1);
 }
