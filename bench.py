@@ -998,6 +998,11 @@ def main():
     else:
         res = run_raster(args, rank, world, dev, args.workload, cpu_baseline=cpu)
     if rank == 0:
+        # a line that claims N GPUs must come from N ranks of one process group (RCCL unless the test knob says otherwise)
+        if res.get("n_gpus") != args.gpus or (world > 1 and res.get("rccl_ranks") != args.gpus):
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the line reports n_gpus={res.get('n_gpus')} rccl_ranks={res.get('rccl_ranks')}\n")
+            print(json.dumps(res), flush=True)
+            sys.exit(3)
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist

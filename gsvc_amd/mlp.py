@@ -26,6 +26,11 @@ from . import _lib
 
 MFMA_MAX_DIM = 192
 MIN_ROWS = 4096
+# rows from which the multi-product launches (gsvc_linear_forward_shared_input / gsvc_linear_accumulate_many) are used: they hold a
+# wave's row fragments / accumulators across the products but re-stage every product's weight image per workgroup — a fixed cost
+# that a few thousand rows do not amortise (the rate sample's ~10 k rows: 124 us against 3 x 16 us as layer launches; same-process
+# A/B of the fitting step 7.36 -> 7.28 ms)
+MANY_MIN_ROWS = int(__import__("os").environ.get("GSVC_MANY_MIN_ROWS", "24576"))
 
 # epilogue codes of gsvc_linear_forward_ex (include/gsvc_hip.h)
 EPI_NONE, EPI_RELU, EPI_GELU_DUAL, EPI_TANH, EPI_SIGMOID, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK, EPI_FILM, EPI_FILM_GRAD, EPI_ADD = range(10)
@@ -231,7 +236,8 @@ def _first_layers_shared_input(x, sizes, params):
     shapes are not the kernel's (the caller then runs layer by layer)."""
     import os
     M, K = x.shape
-    if (os.environ.get("GSVC_NO_SHARED_INPUT") or not (2 <= len(sizes) <= 8) or any(n < 2 for n in sizes) or not 0 < M <= 65536
+    if (os.environ.get("GSVC_NO_SHARED_INPUT") or not (2 <= len(sizes) <= 8) or any(n < 2 for n in sizes)
+            or not MANY_MIN_ROWS <= M <= 65536
             or K > MFMA_MAX_DIM or K % 4 or x.data_ptr() % 16):
         return None
     ws, at = [], 0
@@ -259,7 +265,7 @@ def _sum_of_products(pairs, N):
     import os
     g0 = pairs[0][0]
     M = g0.shape[0]
-    if (2 <= len(pairs) <= 8 and 0 < M <= 65536 and N <= MFMA_MAX_DIM and not os.environ.get("GSVC_NO_ACCUM_MANY")
+    if (2 <= len(pairs) <= 8 and MANY_MIN_ROWS <= M <= 65536 and N <= MFMA_MAX_DIM and not os.environ.get("GSVC_NO_ACCUM_MANY")
             and all(g.shape[1] <= MFMA_MAX_DIM and g.shape[1] % 2 == 0 and g.is_contiguous() and w.is_contiguous()
                     and g.data_ptr() % 8 == 0 for g, w in pairs)):
         out = torch.empty(M, N, device=g0.device, dtype=torch.float32)

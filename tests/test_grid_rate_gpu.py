@@ -190,11 +190,15 @@ def test_rate_kernels_match_reference_and_oracle():
     bits = eg(x, mean, scale, Q, C(g["x_mean"]))
     b = bits.detach().cpu().numpy()
     assert np.array_equal(b == 16.0, g["bits"] == 16.0)
-    assert np.abs(b - g["bits"]).max() < 2e-3
+    if os.environ.get("GSVC_PRINT_ERRORS"):
+        print(f"RATE_ERR bits {np.abs(b - g['bits']).max():.3e} of {np.abs(g['bits']).max():.3e}")
+    assert np.abs(b - g["bits"]).max() < 2e-4            # measured 6e-5 (of 16 bits: the fp32 erfc difference near the 2^-16 floor)
     (bits * C(g["gout"])).sum().backward()
     for t, nm in ((x, "dx"), (mean, "dmean"), (scale, "dscale"), (Q, "dQ")):
         ref = g[nm]
-        assert np.abs(t.grad.cpu().numpy() - ref).max() < 2e-3 * np.abs(ref).max(), nm
+        if os.environ.get("GSVC_PRINT_ERRORS"):
+            print(f"RATE_ERR {nm} {np.abs(t.grad.cpu().numpy() - ref).max() / np.abs(ref).max():.3e}")
+        assert np.abs(t.grad.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max(), nm          # measured 9e-6
     assert np.all(mean.grad.cpu().numpy()[g["bits"] == 16.0] == 0)   # Low_bound net rule
     assert x.grad[2, 0].item() == 0                                       # clamped x gets no gradient
     # scalar Q, x_mean taken from x

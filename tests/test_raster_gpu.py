@@ -5,6 +5,8 @@ gradients within 1e-4 relative-to-scale (float atomics reorder sums).  Pixels wh
 within float rounding of a boundary (oracle `borderline` mask: alpha vs 1/255, T vs 1e-4, power vs 0) are
 excluded and must stay a negligible fraction: exp() differs in the last ulp between libm and the GPU.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -37,7 +39,7 @@ def _oracle_settings(oracle, s, view="viewmatrix", bg=None):
                                 flags=s.get("flags", 0), low_pass=s.get("low_pass", 0.0))
 
 
-def _compare_forward(oracle, sc, view="viewmatrix", bg=(0.0, 0.0, 0.0), max_borderline=2e-3):
+def _compare_forward(oracle, sc, view="viewmatrix", bg=(0.0, 0.0, 0.0), max_borderline=5e-4):
     s = sc["settings"]
     d = _to_dev(sc)
     r = _rasterizer(s, view, bg)
@@ -62,6 +64,8 @@ def _compare_forward(oracle, sc, view="viewmatrix", bg=(0.0, 0.0, 0.0), max_bord
     assert np.array_equal(vf.cpu().numpy()[live], ref.radii[live]) and not ref.radii[~live].any()
     # pixels
     ok = ref.borderline == 0
+    if os.environ.get("GSVC_PRINT_ERRORS"):
+        print(f"BORDERLINE {(~ok).mean():.3e} (max {max_borderline:g}) P={sc['means3D'].shape[0]}")
     assert (~ok).mean() < max_borderline, (~ok).mean()
     img = image.cpu().numpy()
     err = np.abs(img - ref.image)[:, ok]
@@ -95,7 +99,7 @@ def test_forward_long_tile_lists(oracle_lib):
         sc = synthetic.raster_scene(P, H=48, W=48, T=64, seed=7, window_frames=8, sigma_px=(0.5, 2.0), opacity=(0.01, 0.05))
         sc["means3D"][:, :2] *= 0.3
         sc["means3D"][P // 2:] = sc["means3D"][:P - P // 2]  # exact depth ties
-        _compare_forward(oracle_lib, sc, max_borderline=2e-2)
+        _compare_forward(oracle_lib, sc, max_borderline=5e-3)
 
 
 @pytest.mark.parametrize("P,ties", [(700, "none"), (700, "pairs"), (1100, "runs"), (900, "clustered"), (2200, "none")])
@@ -115,7 +119,7 @@ def test_forward_medium_tile_lists_bucket_sort(oracle_lib, P, ties):
     elif ties == "clustered":
         zc = float(np.median(z))
         sc["means3D"][: 3 * P // 4, 2] = zc + (z[: 3 * P // 4] - zc) * 1e-4
-    _compare_forward(oracle_lib, sc, max_borderline=2e-2)
+    _compare_forward(oracle_lib, sc, max_borderline=5e-3)
 
 
 def test_forward_edge_cases(oracle_lib):
@@ -168,6 +172,8 @@ def _grad_close(a, b, name, tol=1e-4):
     b = np.asarray(b, np.float64)
     scale = max(np.abs(b).max(), 1e-20)
     err = np.abs(a - b).max() / scale
+    if os.environ.get("GSVC_PRINT_ERRORS"):
+        print(f"GRAD_ERR {name} {err:.3e} (tol {tol:g})")
     assert err < tol, (name, err, scale)
 
 
@@ -194,8 +200,8 @@ def test_backward_parity(oracle_lib, P, H, W, seed, view):
     _grad_close(d["opacities"].grad.cpu().numpy(), rb.opacities, "opacities")
     _grad_close(d["means3D"].grad.cpu().numpy(), rb.means3D, "means3D")
     _grad_close(means2D.grad.cpu().numpy(), rb.means2D, "means2D")
-    _grad_close(d["scales"].grad.cpu().numpy(), rb.scales, "scales", tol=5e-4)
-    _grad_close(d["rotations"].grad.cpu().numpy(), rb.rotations, "rotations", tol=5e-4)
+    _grad_close(d["scales"].grad.cpu().numpy(), rb.scales, "scales")
+    _grad_close(d["rotations"].grad.cpu().numpy(), rb.rotations, "rotations")
     # culled Gaussians get exactly zero
     culled = ref.radii == 0
     assert torch.all(d["means3D"].grad[torch.tensor(culled, device="cuda")] == 0)
@@ -337,8 +343,8 @@ def test_backward_parity_full_size_cfg2(oracle_lib):
     _grad_close(d["opacities"].grad.cpu().numpy(), rb.opacities, "opacities")
     _grad_close(d["means3D"].grad.cpu().numpy(), rb.means3D, "means3D")
     _grad_close(means2D.grad.cpu().numpy(), rb.means2D, "means2D")
-    _grad_close(d["scales"].grad.cpu().numpy(), rb.scales, "scales", tol=5e-4)
-    _grad_close(d["rotations"].grad.cpu().numpy(), rb.rotations, "rotations", tol=5e-4)
+    _grad_close(d["scales"].grad.cpu().numpy(), rb.scales, "scales")
+    _grad_close(d["rotations"].grad.cpu().numpy(), rb.rotations, "rotations")
 
 
 def test_forward_parity_4k_large_lds_histogram(oracle_lib):
@@ -397,7 +403,7 @@ def test_tile_grid_beyond_the_lds_histogram(oracle_lib):
     _, means2D = _run_backward(r, d, torch.tensor(dL, device="cuda"))
     _grad_close(d["colors"].grad.cpu().numpy(), rb.colors, "colors")
     _grad_close(means2D.grad.cpu().numpy(), rb.means2D, "means2D")
-    _grad_close(d["scales"].grad.cpu().numpy(), rb.scales, "scales", tol=5e-4)
+    _grad_close(d["scales"].grad.cpu().numpy(), rb.scales, "scales")
 
 
 def test_large_footprints_take_the_heavy_extras_path(oracle_lib):
@@ -420,8 +426,8 @@ def test_large_footprints_take_the_heavy_extras_path(oracle_lib):
     _grad_close(d["colors"].grad.cpu().numpy(), rb.colors, "colors")
     _grad_close(d["opacities"].grad.cpu().numpy(), rb.opacities, "opacities")
     _grad_close(means2D.grad.cpu().numpy(), rb.means2D, "means2D")
-    _grad_close(d["scales"].grad.cpu().numpy(), rb.scales, "scales", tol=5e-4)
-    _grad_close(d["rotations"].grad.cpu().numpy(), rb.rotations, "rotations", tol=5e-4)
+    _grad_close(d["scales"].grad.cpu().numpy(), rb.scales, "scales")
+    _grad_close(d["rotations"].grad.cpu().numpy(), rb.rotations, "rotations")
 
 
 @pytest.mark.parametrize("flags,low_pass", [(1, 0.0), (2, 0.0), (4, 0.0), (8, 0.0), (16, 0.0), (32, 0.0), (0, 0.1),
@@ -448,8 +454,8 @@ def test_convention_switches_keep_parity(oracle_lib, flags, low_pass):
     _grad_close(d["opacities"].grad.cpu().numpy(), rb.opacities, "opacities")
     _grad_close(d["means3D"].grad.cpu().numpy(), rb.means3D, "means3D")
     _grad_close(means2D.grad.cpu().numpy(), rb.means2D, "means2D")
-    _grad_close(d["scales"].grad.cpu().numpy(), rb.scales, "scales", tol=5e-4)
-    _grad_close(d["rotations"].grad.cpu().numpy(), rb.rotations, "rotations", tol=5e-4)
+    _grad_close(d["scales"].grad.cpu().numpy(), rb.scales, "scales")
+    _grad_close(d["rotations"].grad.cpu().numpy(), rb.rotations, "rotations")
     if flags & 3:      # the fused two-view pass is not defined under these conventions: refused, not silently wrong
         from gsvc_amd import _lib, rasterizer
         with pytest.raises(_lib.GsvcError, match="raster_forward_pair"):

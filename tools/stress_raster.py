@@ -31,7 +31,7 @@ def run(n_cases=40, seed=123, verbose=True):
         view = "viewmatrix" if rng.random() < 0.5 else "viewmatrix_s"
         bg = tuple(float(v) for v in rng.uniform(0, 1, 3))
         try:
-            r, ref, d = T._compare_forward(oracle, sc, view=view, bg=bg, max_borderline=5e-2)
+            r, ref, d = T._compare_forward(oracle, sc, view=view, bg=bg, max_borderline=5e-3)
             # backward on the same scene
             s = sc["settings"]
             dL = rng.standard_normal((3, H, W)).astype(np.float32)
