@@ -99,6 +99,10 @@ class DeformNetC(C.Structure):
     _fields_ = [("W", C.c_void_p * 5), ("b", C.c_void_p * 5)] + [(n, C.c_int32) for n in ("feat_dim", "cond_dim", "hidden_dim", "out_dim")]
 
 
+class QuantStepNetC(C.Structure):
+    _fields_ = [("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p)]
+
+
 class DeformGradsC(C.Structure):
     _fields_ = [("W", C.c_void_p * 5), ("b", C.c_void_p * 5)]
 
@@ -210,6 +214,10 @@ _SIGNATURES = {
     "gsvc_generator_forward": (C.c_int, [C.POINTER(GeneratorNetC), _vp, _vp, _i64, _vp, _vp, _vp]),
     "gsvc_generator_backward": (C.c_int, [C.POINTER(GeneratorNetC), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int32,
                                           C.POINTER(GeneratorGradsC), _vp]),
+    "gsvc_quant_step_nets_forward": (C.c_int, [C.POINTER(QuantStepNetC), _vp, _i64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]),
+    "gsvc_quant_step_nets_backward": (C.c_int, [C.POINTER(QuantStepNetC), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i64, C.c_int32,
+                                                C.c_int32, C.POINTER(C.c_void_p), _vp, _vp]),
     "gsvc_deform_saved_floats": (_i64, [C.POINTER(DeformNetC), _i64]),
     "gsvc_deform_scratch_floats": (_i64, [C.POINTER(DeformNetC), _i64]),
     "gsvc_deform_forward": (C.c_int, [C.POINTER(DeformNetC), _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -1011,6 +1011,124 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_deform_a_bwd(const float *__r
     }
 }
 
+// ======================================================================================================= quant_step nets
+// The three quant_step networks of the EntropyParamsNets (reference scene/gaussian_model.py:198-232: Linear(192 -> 50), GELU,
+// Linear(50 -> 1)) read the same hash-grid feature row and produce one number each.  Layer by layer that was one multi-product
+// launch for the first layers, three layer launches with a one-column output (a 16 x 16 MFMA tile for one useful column) and,
+// backward, three more plus a multi-product launch — ~210 us per fitting step for 0.03 GFLOP per thousand rows.  Here a wave
+// carries a 16-row block through all three networks: the feature fragments are read once, each first layer is 192 MFMAs against
+// its weight image in LDS (all three resident: 3 x 51 KB), GELU on the accumulators, the second layer a dot product with the
+// lane's 16 columns and two cross-lane adds.  The backward forms dz = dq w2 GELU'(z) in the same tile layout — which is the
+// B fragment of dX += dz W1 — against the three transposed images (row stride 56: 3 x 43 KB) and writes dX once.
+struct QuantFwd {
+    const float *W1[3], *b1[3], *W2[3], *b2[3];
+    float *z[3], *a[3], *q[3];
+};
+struct QuantBwd {
+    const float *W1[3], *W2[3], *z[3], *dq[3];
+    float *dz[3], *dX;
+};
+
+template <int IN, int HQ>
+struct QuantLds {
+    static constexpr int LD = cl_ld(IN), NT = cl_kg(HQ), IMG = NT * 16 * LD;
+    static constexpr int o_b1 = 3 * IMG, o_w2 = o_b1 + 3 * NT * 16, FLOATS = o_w2 + 3 * NT * 16;
+    static constexpr int LDT = 16 * (cl_kg(HQ) - 1) + 8, NTI = cl_kg(IN), IMGT = NTI * 16 * LDT;      // transposed: [IN][hidden], stride 56
+    static constexpr int o_w2t = 3 * IMGT, FLOATS_T = o_w2t + 3 * NT * 16 + 16;
+};
+
+template <int IN, int HQ, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_quant_nets_fwd(const float *__restrict__ X, QuantFwd p, long long M)
+{
+    extern __shared__ float lds[];
+    using S = QuantLds<IN, HQ>;
+    const Lane L;
+    zero_lds(lds, S::FLOATS, L.tid, CHAIN_THREADS);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        stage_block<false>(p.W1[i], IN, HQ, 0, IN, lds + i * S::IMG, S::LD, 0, L.tid, CHAIN_THREADS);
+        stage_bias(p.b1[i], HQ, lds + S::o_b1 + i * S::NT * 16, S::NT * 16, L.tid, CHAIN_THREADS);
+        stage_bias(p.W2[i], HQ, lds + S::o_w2 + i * S::NT * 16, S::NT * 16, L.tid, CHAIN_THREADS);
+    }
+    __syncthreads();
+    long long rb, RB, stride;
+    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    for (; rb < RB; rb += stride) {
+        const long long row = rb * 16 + L.fr;
+        // (a wave has one or two blocks: the block's fragments are requested here, not a block ahead — the workgroup's other
+        // seven waves cover the round trip)
+        v4f x[cl_kg(IN)];
+        load_frags<IN>(x, X, rb, RB, M, L);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            v4f u[S::NT];
+            init_bias(u, lds + S::o_b1 + i * S::NT * 16, L);
+            chain_mm<IN, S::NT, S::LD>(u, x, lds + i * S::IMG, L);
+            const Tiles<HQ> tz(p.z[i], rb, RB, M, L), ta(p.a[i], rb, RB, M, L);
+            const float *w2 = lds + S::o_w2 + i * S::NT * 16 + 4 * L.kq;
+            float part = 0.f;
+#pragma unroll
+            for (int t = 0; t < S::NT; t++) {
+                tz.store(t, u[t]);
+                const v4f g = v_gelu(u[t]);
+                ta.store(t, g);
+                const float4 w = *reinterpret_cast<const float4 *>(w2 + 16 * t);
+                part = fmaf(g[0], w.x, fmaf(g[1], w.y, fmaf(g[2], w.z, fmaf(g[3], w.w, part))));
+            }
+            // the row's 64 (padded) columns live in the four lanes fr, fr + 16, fr + 32, fr + 48
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (L.kq == 0 && row < M) p.q[i][row] = part + p.b2[i][0];
+        }
+    }
+}
+
+template <int IN, int HQ, int CHAIN_THREADS>
+__global__ void __launch_bounds__(CHAIN_THREADS) k_quant_nets_bwd(QuantBwd p, long long M)
+{
+    extern __shared__ float lds[];
+    using S = QuantLds<IN, HQ>;
+    const Lane L;
+    zero_lds(lds, S::FLOATS_T, L.tid, CHAIN_THREADS);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        // imgT[k][n] = W1[n][k]: contraction over the hidden index n, output = the feature column k
+        stage_block<true>(p.W1[i], IN, HQ, 0, IN, lds + i * S::IMGT, S::LDT, 0, L.tid, CHAIN_THREADS);
+        stage_bias(p.W2[i], HQ, lds + S::o_w2t + i * S::NT * 16, S::NT * 16, L.tid, CHAIN_THREADS);
+    }
+    __syncthreads();
+    long long rb, RB, stride;
+    row_blocks<CHAIN_THREADS / 64>(M, L, rb, RB, stride);
+    for (; rb < RB; rb += stride) {
+        const long long row = rb * 16 + L.fr;
+        v4f gx[S::NTI];
+        init_zero(gx);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const Tiles<HQ> tz(p.z[i], rb, RB, M, L), td(p.dz[i], rb, RB, M, L);
+            const float dq = (p.dq[i] && row < M) ? p.dq[i][row] : 0.f;      // an output nobody used: zeros
+            const float *w2 = lds + S::o_w2t + i * S::NT * 16 + 4 * L.kq;
+            v4f d[S::NT];
+#pragma unroll
+            for (int t = 0; t < S::NT; t++) {
+                const v4f gg = v_gelu_grad(tz.load(t));
+                const float4 w = *reinterpret_cast<const float4 *>(w2 + 16 * t);      // zero past the hidden width: so is dz there
+                d[t] = (v4f){dq * w.x * gg[0], dq * w.y * gg[1], dq * w.z * gg[2], dq * w.w * gg[3]};
+                td.store(t, d[t]);
+            }
+            // the image's row stride (56) is shorter than the last k-group's 16-column read: the lanes kq > 0 of that group read into
+            // the next row (finite numbers) against dz columns >= 52, which are zero
+            chain_mm<HQ, S::NTI, S::LDT>(gx, d, lds + i * S::IMGT, L);
+        }
+        const Tiles<IN> tx(p.dX, rb, RB, M, L);
+#pragma unroll
+        for (int t = 0; t < S::NTI; t++) tx.store(t, gx[t]);
+    }
+}
+
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 // One launch of a chain kernel: persistent grid (one workgroup per CU), 512 threads = 2 waves per SIMD with up to 256 VGPRs each
 // (the operands a wave keeps in flight across its products need 140-240 of them; 1024-thread builds of the first version,
@@ -1449,4 +1567,61 @@ extern "C" int gsvc_deform_backward(const gsvc_deform_net *n, const float *feat,
                                hipMemcpyDeviceToDevice, s);
     }
     return check_launch("deform_backward");
+}
+
+// ---- quant_step nets ----------------------------------------------------------------------------------------------------------
+namespace gsvc {
+namespace {
+constexpr int Q_IN = 192, Q_HID = 50;
+}
+}
+
+extern "C" int gsvc_quant_step_nets_forward(const gsvc_quant_step_net *nets, const float *X, int64_t M, int32_t in_dim, int32_t hidden,
+                                            float *const *z, float *const *a, float *const *q, void *stream)
+{
+    GSVC_REQUIRE(nets && z && a && q && M >= 0, "quant_step_nets_forward: bad arguments");
+    if (in_dim != Q_IN || hidden != Q_HID) {
+        set_error("quant_step_nets: instantiated for %d -> %d -> 1 (got %d -> %d)", Q_IN, Q_HID, in_dim, hidden);
+        return GSVC_E_UNSUPPORTED;
+    }
+    if (M == 0) return GSVC_OK;
+    GSVC_REQUIRE(X, "quant_step_nets_forward: NULL pointer");
+    QuantFwd p;
+    for (int i = 0; i < 3; i++) {
+        GSVC_REQUIRE(nets[i].W1 && nets[i].b1 && nets[i].W2 && nets[i].b2 && z[i] && a[i] && q[i], "quant_step_nets_forward: NULL pointer (net %d)", i);
+        if (!aligned16({nets[i].W1, X, z[i], a[i]}) || (reinterpret_cast<uintptr_t>(nets[i].W2) & 7)) {
+            set_error("quant_step_nets_forward: matrices must be 16-byte aligned");
+            return GSVC_E_UNSUPPORTED;
+        }
+        p.W1[i] = nets[i].W1; p.b1[i] = nets[i].b1; p.W2[i] = nets[i].W2; p.b2[i] = nets[i].b2;
+        p.z[i] = z[i]; p.a[i] = a[i]; p.q[i] = q[i];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    chain_launch("k_quant_nets_fwd", &k_quant_nets_fwd<Q_IN, Q_HID, CHAIN_T>, (size_t)QuantLds<Q_IN, Q_HID>::FLOATS * 4, M, 1, s, X, p, (long long)M);
+    return check_launch("quant_step_nets_forward");
+}
+
+extern "C" int gsvc_quant_step_nets_backward(const gsvc_quant_step_net *nets, const float *const *z, const float *const *dq, int64_t M,
+                                             int32_t in_dim, int32_t hidden, float *const *dz, float *dX, void *stream)
+{
+    GSVC_REQUIRE(nets && z && dq && dz && M >= 0, "quant_step_nets_backward: bad arguments");
+    if (in_dim != Q_IN || hidden != Q_HID) {
+        set_error("quant_step_nets: instantiated for %d -> %d -> 1 (got %d -> %d)", Q_IN, Q_HID, in_dim, hidden);
+        return GSVC_E_UNSUPPORTED;
+    }
+    if (M == 0) return GSVC_OK;
+    GSVC_REQUIRE(dX, "quant_step_nets_backward: NULL pointer");
+    QuantBwd p;
+    for (int i = 0; i < 3; i++) {
+        GSVC_REQUIRE(nets[i].W1 && nets[i].W2 && z[i] && dz[i], "quant_step_nets_backward: NULL pointer (net %d)", i);
+        if (!aligned16({nets[i].W1, z[i], dz[i], dX}) || (reinterpret_cast<uintptr_t>(nets[i].W2) & 7)) {
+            set_error("quant_step_nets_backward: matrices must be 16-byte aligned");
+            return GSVC_E_UNSUPPORTED;
+        }
+        p.W1[i] = nets[i].W1; p.W2[i] = nets[i].W2; p.z[i] = z[i]; p.dq[i] = dq[i]; p.dz[i] = dz[i];
+    }
+    p.dX = dX;
+    hipStream_t s = (hipStream_t)stream;
+    chain_launch("k_quant_nets_bwd", &k_quant_nets_bwd<Q_IN, Q_HID, CHAIN_T>, (size_t)QuantLds<Q_IN, Q_HID>::FLOATS_T * 4, M, 1, s, p, (long long)M);
+    return check_launch("quant_step_nets_backward");
 }

@@ -284,6 +284,91 @@ def _sum_of_products(pairs, N):
     return gx
 
 
+class _QuantStepNets(torch.autograd.Function):
+    """The three quant_step networks (Linear -> GELU -> Linear(. -> 1)) on the same rows as one chain launch each way
+    (csrc/mlp_chain.hip k_quant_nets_fwd / _bwd); their six weight gradients as one batch.  params = (W1, b1, W2, b2) x 3."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        import ctypes as C
+        x = x.contiguous()
+        params = [p.contiguous() for p in params]
+        M, dev = x.shape[0], x.device
+        H = params[0].shape[0]
+        per = (M * H + 3) // 4 * 4                                                       # every matrix starts 16-byte aligned
+        buf = torch.empty(6 * per + 3 * M, device=dev, dtype=torch.float32)              # z, a [M, H] x 3, q [M] x 3
+        zs = [buf[i * per:i * per + M * H].view(M, H) for i in range(3)]
+        as_ = [buf[(3 + i) * per:(3 + i) * per + M * H].view(M, H) for i in range(3)]
+        qs = [buf[6 * per + i * M:6 * per + (i + 1) * M].view(M, 1) for i in range(3)]
+        nets = (_lib.QuantStepNetC * 3)()
+        for i in range(3):
+            nets[i] = _lib.QuantStepNetC(*[t.data_ptr() for t in params[4 * i:4 * i + 4]])
+        _lib.check(_lib.lib().gsvc_quant_step_nets_forward(nets, _lib.ptr(x), M, x.shape[1], H, _ptr_array(zs), _ptr_array(as_), _ptr_array(qs),
+                                                           _lib.current_stream(dev)), "gsvc_quant_step_nets_forward")
+        ctx.save_for_backward(x, buf, *params)
+        ctx.geom = (M, H, per)
+        ctx.set_materialize_grads(False)
+        return tuple(qs)
+
+    @staticmethod
+    def backward(ctx, *gq):
+        x, buf, *params = ctx.saved_tensors
+        M, H, per = ctx.geom
+        dev = x.device
+        if all(g is None for g in gq):
+            return (None,) * (1 + len(params))
+        zs = [buf[i * per:i * per + M * H].view(M, H) for i in range(3)]
+        as_ = [buf[(3 + i) * per:(3 + i) * per + M * H].view(M, H) for i in range(3)]
+        gq = [None if g is None else g.contiguous().view(M, 1) for g in gq]
+        dbuf = torch.empty(3 * per, device=dev, dtype=torch.float32)
+        dzs = [dbuf[i * per:i * per + M * H].view(M, H) for i in range(3)]
+        dX = torch.empty_like(x)
+        nets = (_lib.QuantStepNetC * 3)()
+        for i in range(3):
+            nets[i] = _lib.QuantStepNetC(*[t.data_ptr() for t in params[4 * i:4 * i + 4]])
+        import ctypes as C
+        dq = (C.c_void_p * 3)(*[None if g is None else g.data_ptr() for g in gq])
+        _lib.check(_lib.lib().gsvc_quant_step_nets_backward(nets, _ptr_array(zs), dq, M, x.shape[1], H, _ptr_array(dzs), _lib.ptr(dX),
+                                                            _lib.current_stream(dev)), "gsvc_quant_step_nets_backward")
+        grads = [None] * len(params)
+        wg = WgradBatch(dev)
+        for i in range(3):
+            if gq[i] is None:
+                continue
+            if ctx.needs_input_grad[1 + 4 * i]:
+                grads[4 * i], grads[4 * i + 1] = wg.add(dzs[i], x)
+            if ctx.needs_input_grad[3 + 4 * i]:
+                grads[4 * i + 2], grads[4 * i + 3] = wg.add(gq[i], as_[i])
+        wg.flush()
+        return (dX if ctx.needs_input_grad[0] else None, *grads)
+
+
+def quant_step_nets_usable(x, nets):
+    """The fused kernels are instantiated for 192 -> 50 -> 1 with biases, on a tall contiguous fp32 CUDA matrix."""
+    import os
+    if os.environ.get("GSVC_NO_QUANT_CHAIN") or os.environ.get("GSVC_NO_MLP_CHAIN") or len(nets) != 3:
+        return False
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= MIN_ROWS and x.shape[1] == 192):
+        return False
+    for seq in nets:
+        mods = list(seq)
+        if len(mods) != 3 or not isinstance(mods[0], torch.nn.Linear) or not isinstance(mods[1], torch.nn.GELU) or not isinstance(mods[2], torch.nn.Linear):
+            return False
+        l1, l2 = mods[0], mods[2]
+        if (l1.in_features, l1.out_features, l2.in_features, l2.out_features) != (192, 50, 50, 1) or l1.bias is None or l2.bias is None:
+            return False
+    return True
+
+
+def quant_step_nets(x, nets):
+    """(q_0, q_1, q_2) [M, 1]: the raw outputs of the three quant_step networks on the rows x."""
+    params = []
+    for seq in nets:
+        mods = list(seq)
+        params += [mods[0].weight, mods[0].bias, mods[2].weight, mods[2].bias]
+    return _QuantStepNets.apply(x, *params)
+
+
 def seq_gelu_many(x, chains):
     """chains: lists of nn.Linear (Linear -> GELU -> ... -> Linear each); returns one output per chain."""
     params = []

@@ -696,7 +696,9 @@ class GaussianModel(nn.Module):
         ctx = self.calc_interp_feat(anchor)
         nets = (self.mlp_feature_enet, self.mlp_scaling_enet, self.mlp_offset_enet)
         chains = [list(net.quant_step_net)[0::2] for net in nets]
-        if (ctx.is_cuda and all(isinstance(net.quant_step_net, GeluSequential) for net in nets) and all(mlp.usable(ctx, *c) for c in chains)
+        if mlp.quant_step_nets_usable(ctx, [net.quant_step_net for net in nets]):
+            q_raw = mlp.quant_step_nets(ctx, [net.quant_step_net for net in nets])      # one chain launch each way for all three
+        elif (ctx.is_cuda and all(isinstance(net.quant_step_net, GeluSequential) for net in nets) and all(mlp.usable(ctx, *c) for c in chains)
                 and not os.environ.get("GSVC_NO_MLP_CHAIN")):
             q_raw = mlp.seq_gelu_many(ctx, chains)          # the three first layers read ctx in one launch
         else:

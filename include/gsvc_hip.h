@@ -464,6 +464,21 @@ int gsvc_gather_rows_backward_ranked(const float *scaling_p, const float *mask_p
  * stored 0 / 1 values when decoded; reference scene/gaussian_model.py get_mask_anchor), u [R*A] uniform draws of the caller. */
 int gsvc_plan_masks(const uint8_t *const *visible_host, int32_t R, int64_t A, const float *mask_raw, int32_t K, int32_t decoded,
                     const float *u, float rate, uint8_t *M, uint8_t *present, uint8_t *chosen, void *stream);
+/* The three quant_step networks of the EntropyParamsNets (reference scene/gaussian_model.py:198-232: Linear(in -> hidden), GELU,
+ * Linear(hidden -> 1), evaluated at :1569-1597) on the same input rows X [M, in] in ONE launch each way (instantiated for
+ * 192 -> 50 -> 1; other widths: GSVC_E_UNSUPPORTED, the caller keeps the layer kernels).  forward: z[i] [M, hidden] = the first
+ * layer's pre-activation, a[i] = GELU(z[i]) (the operands of the backward and of the weight gradients), q[i] [M] = the raw output.
+ * backward: dz[i] [M, hidden] = dq[i] W2_i GELU'(z[i]) (dq[i] NULL = zeros) and dX [M, in] = sum_i dz[i] W1_i; the weight
+ * gradients are the products dz[i]^T X, dq[i]^T a[i] (gsvc_linear_wgrad_*). */
+typedef struct gsvc_quant_step_net {
+    const float *W1, *b1; /* [hidden][in], [hidden] */
+    const float *W2, *b2; /* [1][hidden], [1] */
+} gsvc_quant_step_net;
+int gsvc_quant_step_nets_forward(const gsvc_quant_step_net *nets3, const float *X, int64_t M, int32_t in_dim, int32_t hidden,
+                                 float *const *z3, float *const *a3, float *const *q3, void *stream);
+int gsvc_quant_step_nets_backward(const gsvc_quant_step_net *nets3, const float *const *z3, const float *const *dq3, int64_t M,
+                                  int32_t in_dim, int32_t hidden, float *const *dz3, float *dX, void *stream);
+
 /* Per-row quantisation steps: out3 [3, rows], out3[g][i] = q_g adj_g[ctx_row ? ctx_row[i] : i] for the features, scalings and
  * offsets (reference gaussian_renderer/guassian.py:250-262, Q * Q_adj of the entropy context; ctx_row maps a row to its row of a
  * context evaluated once per distinct anchor).  raw != 0: adj_g holds the quant_step networks' raw outputs q and the adjustment

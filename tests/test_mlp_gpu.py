@@ -356,10 +356,11 @@ def test_sum_of_products_in_one_launch_matches_the_accumulate_epilogue(M):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [1, 4097, 52481])
-def test_first_layers_with_a_shared_input_in_one_launch(M):
+def test_first_layers_with_a_shared_input_in_one_launch(M, monkeypatch):
     """gsvc_linear_forward_shared_input (csrc/linear_accum.hip) against the layer kernel it replaces for the entropy networks' six
     first layers (same bits: the same MFMA order per output) and against float64."""
     from gsvc_amd import mlp
+    monkeypatch.setattr(mlp, "MANY_MIN_ROWS", 1)      # the product path takes these launches from 24 576 rows; the kernels take any M
     torch.manual_seed(M)
     dev = torch.device("cuda")
     Ns = [150, 50, 100, 50, 150, 50]
@@ -440,3 +441,38 @@ def test_shared_input_and_accumulate_entries_at_other_shapes(M, K, Ns):
     assert L.gsvc_linear_accumulate_many(aj, len(pairs), _lib.ptr(out), 65537, N, _lib.current_stream(dev)) != 0
     bad = (_lib.AccumJobC * 1)(_lib.AccumJobC(pairs[0][0].data_ptr(), pairs[0][1].data_ptr(), 51, 0))
     assert L.gsvc_linear_accumulate_many(bad, 1, _lib.ptr(out), M, N, _lib.current_stream(dev)) != 0
+
+
+@pytest.mark.parametrize("M,unused", [(4096, None), (53011, None), (7777, 1), (16, None)])
+def test_quant_step_nets_in_one_launch_match_torch(M, unused):
+    """gsvc_quant_step_nets_forward / _backward (csrc/mlp_chain.hip): the three Linear(192 -> 50) -> GELU -> Linear(50 -> 1)
+    networks on the same rows against plain PyTorch fp32 modules — outputs, the input gradient and all twelve parameter
+    gradients; ``unused``: an output nobody consumed (its gradient arrives as None)."""
+    from gsvc_amd import mlp
+    torch.manual_seed(M)
+    nets = [torch.nn.Sequential(torch.nn.Linear(192, 50), torch.nn.GELU(), torch.nn.Linear(50, 1)).cuda() for _ in range(3)]
+    x = torch.randn(M, 192, device="cuda", requires_grad=True)
+    w = [torch.randn(M, 1, device="cuda") for _ in range(3)]
+    got = mlp._QuantStepNets.apply(x, *[p for n in nets for p in (n[0].weight, n[0].bias, n[2].weight, n[2].bias)])
+    sum((got[i] * w[i]).sum() for i in range(3) if i != unused).backward()
+    g_x = x.grad.clone()
+    g_p = [p.grad.clone() if p.grad is not None else None for n in nets for p in n.parameters()]
+    x.grad = None
+    for n in nets:
+        n.zero_grad()
+    want = [n(x) for n in nets]
+    sum((want[i] * w[i]).sum() for i in range(3) if i != unused).backward()
+    for i in range(3):
+        assert (got[i] - want[i]).abs().max().item() <= 2e-5 * max(1.0, want[i].abs().max().item()), i
+    assert (g_x - x.grad).abs().max().item() <= 1e-4 * x.grad.abs().max().item()
+    k = 0
+    for ni, n in enumerate(nets):
+        for name, p in n.named_parameters():
+            if ni == unused:
+                assert g_p[k] is None or float(g_p[k].abs().max()) == 0.0, (ni, name)
+            else:
+                scale = p.grad.abs().max().item()
+                assert (g_p[k] - p.grad).abs().max().item() <= 1e-3 * scale + 1e-12, (ni, name, (g_p[k] - p.grad).abs().max().item(), scale)
+            k += 1
+    if M >= 4096:
+        assert mlp.quant_step_nets_usable(x.detach(), nets)
