@@ -459,6 +459,8 @@ def run_train_step(args, rank, world, dev):
     one_stream = {}
     old_streams = os.environ.get("GSVC_RASTER_STREAMS")
     os.environ["GSVC_RASTER_STREAMS"] = "1"
+    from gsvc_amd import switches
+    switches.reload()
     try:
         _lib.profile_enable(True)
         for _ in range(max(args.steps // 4, 5)):
@@ -471,6 +473,7 @@ def run_train_step(args, rank, world, dev):
             os.environ.pop("GSVC_RASTER_STREAMS", None)
         else:
             os.environ["GSVC_RASTER_STREAMS"] = old_streams
+        switches.reload()
     # the compositing backward's replay counters, live on the timed scene (gsvc_profile_enable bit 1: its diagnostic instantiation
     # adds, per launch, the (entry, quadrant) replays, the lanes of those replays that held a contributing pixel and the entries
     # replayed to spare words of the render's counters block, which the forward zeroes)

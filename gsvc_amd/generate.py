@@ -19,6 +19,7 @@ from enum import Enum
 
 import torch
 
+from . import switches
 from .encodings import STE_multistep
 
 
@@ -199,10 +200,10 @@ def _gather_rows(pc, vis, ranks=None, parts="all"):
     three late in its forward, so that their backward — the last contribution to the gradients of _offset / _scaling / _mask —
     runs early (autograd runs later-created nodes first)."""
     fused = (pc._anchor_feat.is_cuda and vis.dtype == torch.int64 and pc._mask.dim() == 3 and pc._mask.shape[2] == 1
-             and pc._offset.dim() == 3 and pc._offset.shape[2] == 3 and not os.environ.get("GSVC_NO_FUSED_GATHER"))
+             and pc._offset.dim() == 3 and pc._offset.shape[2] == 3 and not switches.NO_FUSED_GATHER)
     out = ()
     if fused:
-        use = ranks is not None and ranks[0].numel() <= 8 * pc._anchor_feat.shape[0] and not os.environ.get("GSVC_NO_RANKED_GATHER")
+        use = ranks is not None and ranks[0].numel() <= 8 * pc._anchor_feat.shape[0] and not switches.NO_RANKED_GATHER
         seen, rank = ranks if use else (None, None)      # the ranked kernel holds at most 8 views
         if parts != "rows":
             out += (_GatherFeat.apply(pc._anchor_feat, vis, seen, rank),)
@@ -254,7 +255,7 @@ class StepPlan:
         # the R views side by side: ONE scan gives every view's ranks and count, ONE compaction of the flattened [R, A] mask
         # every view's index list (view r's list is the segment behind the r earlier views' counts, minus r * A)
         fused = (dev.type == "cuda" and R <= 16 and all(m.dtype == torch.bool and m.is_contiguous() for m in visible_masks)
-                 and pc._mask.is_contiguous() and pc._mask.dtype == torch.float32 and not os.environ.get("GSVC_NO_FUSED_PLAN"))
+                 and pc._mask.is_contiguous() and pc._mask.dtype == torch.float32 and not switches.NO_FUSED_PLAN)
         chosen = None
         if fused:
             # the masks of the plan in one launch (csrc/generate.hip k_plan_masks): views side by side, their union, the rate sample
@@ -848,7 +849,7 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
     from .entropy_models import CLAMP_STEPS, _GaussianBits
     K, R, dev = pc.n_offsets, seg.R, feat.device
     fused = (feat.is_cuda and R <= 16 and all(isinstance(q, torch.Tensor) and q.numel() == feat.shape[0] for q in (Q_feat, Q_scaling, Q_offsets))
-             and not os.environ.get("GSVC_NO_FUSED_RATE"))
+             and not switches.NO_FUSED_RATE)
     compact = hasattr(ec, "rows")        # SampledEntropyContext: mean / scale exist for the sampled rows only, row i = i-th sampled row
     if fused and sel is not None and offset_masks.dtype == torch.float32:
         # everything on the device in a dozen launches: the parameter means, the sampled bits summed per render (k_rate_sample),
@@ -974,7 +975,7 @@ def _film_rows(pc, frames, plan, vis, seg, anchor_all):
     (frame, distinct visible anchor) instead of one per (view, anchor).  Returns (cond_film, row_of, src_a, src_b) for
     gsvc_amd.mlp.generate_all, or None (no plan, an odd number of views, views that are not such pairs, or GSVC_NO_FILM_SHARE)."""
     R = seg.R
-    if (plan is None or R % 2 != 0 or plan.distinct is None or os.environ.get("GSVC_NO_FILM_SHARE")
+    if (plan is None or R % 2 != 0 or plan.distinct is None or switches.NO_FILM_SHARE
             or any(float(frames[2 * i].cam_pos[-1]) != float(frames[2 * i + 1].cam_pos[-1]) for i in range(R // 2))):
         return None
     dev = vis.device
@@ -1052,7 +1053,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         ranks = plan.ranks if plan is not None else None
         # TRAINING_ENTROPY gathers (offsets, scaling, masks) behind the generators' forward: see _gather_rows
         # (data parallel too since round 3: the reducer launches its collectives in an order the ranks agree on)
-        late_rows = mode == GenerateMode.TRAINING_ENTROPY and trunks is None and not os.environ.get("GSVC_NO_LATE_ROWS")
+        late_rows = mode == GenerateMode.TRAINING_ENTROPY and trunks is None and not switches.NO_LATE_ROWS
         if late_rows:
             (feat,) = _gather_rows(pc, vis, ranks, parts="feat")
             grid_offsets = grid_scaling = offset_masks = None
@@ -1074,7 +1075,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     deform_linears = deform_mods[0::2]
     # (decoding hands in the cached feature-only half of the generators: with the production widths the forward-only chain kernels,
     # which read the features once and keep a row block in registers through all layers, are faster per frame and are preferred)
-    chain = ((trunks is None or (not torch.is_grad_enabled() and not os.environ.get("GSVC_NO_DECODE_CHAIN")))
+    chain = ((trunks is None or (not torch.is_grad_enabled() and not switches.NO_DECODE_CHAIN))
              and all(hasattr(g, "film") and hasattr(g, "out_linear") for g in gens)
              and all(isinstance(m, torch.nn.Linear) for m in deform_linears) and all(isinstance(m, torch.nn.GELU) for m in deform_mods[1::2])
              and _mlp.chain_usable(feat, pe, gens, deform_linears))
@@ -1095,7 +1096,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     elif mode == GenerateMode.TRAINING_ENTROPY:
         # the priors' mean / scale are read at the rate sample's rows only (reference guassian.py:99-113): their networks run on
         # those rows (SampledEntropyContext); GSVC_CTX_ALL_ROWS=1 keeps the all-rows form (A/B timing, the equivalence test)
-        sampled_ctx = feat.is_cuda and not os.environ.get("GSVC_CTX_ALL_ROWS")
+        sampled_ctx = feat.is_cuda and not switches.CTX_ALL_ROWS
         with region('gen.entropy_context'):
             ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan, sampled=sampled_ctx)
         with region('gen.noise_quant'):
@@ -1125,7 +1126,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         if not late_rows:
             rows_quant_and_rate()
     elif mode == GenerateMode.TRAININ_STE_ENTROPY:
-        ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan, sampled=feat.is_cuda and not os.environ.get("GSVC_CTX_ALL_ROWS"))
+        ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan, sampled=feat.is_cuda and not switches.CTX_ALL_ROWS)
         rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
         Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj).detach(), Q_scaling * rows_of(ec.Q_scaling_adj).detach(),
                                         Q_offsets * rows_of(ec.Q_offsets_adj).detach())

@@ -22,15 +22,14 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib
+from . import _lib, switches
 
 MFMA_MAX_DIM = 192
 MIN_ROWS = 4096
 # rows from which the multi-product launches (gsvc_linear_forward_shared_input / gsvc_linear_accumulate_many) are used: they hold a
 # wave's row fragments / accumulators across the products but re-stage every product's weight image per workgroup — a fixed cost
 # that a few thousand rows do not amortise (the rate sample's ~10 k rows: 124 us against 3 x 16 us as layer launches; same-process
-# A/B of the fitting step 7.36 -> 7.28 ms)
-MANY_MIN_ROWS = int(__import__("os").environ.get("GSVC_MANY_MIN_ROWS", "24576"))
+# A/B of the fitting step 7.36 -> 7.28 ms): switches.MANY_MIN_ROWS, default 24 576
 
 # epilogue codes of gsvc_linear_forward_ex (include/gsvc_hip.h)
 EPI_NONE, EPI_RELU, EPI_GELU_DUAL, EPI_TANH, EPI_SIGMOID, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK, EPI_FILM, EPI_FILM_GRAD, EPI_ADD = range(10)
@@ -234,10 +233,9 @@ def _first_layers_shared_input(x, sizes, params):
     """The chains' first layers (Linear + GELU, every chain has a second layer) read the same x: one launch that keeps the rows'
     fragments in registers across the layers (gsvc_linear_forward_shared_input).  Returns [(z, a)] per chain, or None when the
     shapes are not the kernel's (the caller then runs layer by layer)."""
-    import os
     M, K = x.shape
-    if (os.environ.get("GSVC_NO_SHARED_INPUT") or not (2 <= len(sizes) <= 8) or any(n < 2 for n in sizes)
-            or not MANY_MIN_ROWS <= M <= 65536
+    if (switches.NO_SHARED_INPUT or not (2 <= len(sizes) <= 8) or any(n < 2 for n in sizes)
+            or not switches.MANY_MIN_ROWS <= M <= 65536
             or K > MFMA_MAX_DIM or K % 4 or x.data_ptr() % 16):
         return None
     ws, at = [], 0
@@ -262,10 +260,9 @@ def _first_layers_shared_input(x, sizes, params):
 def _sum_of_products(pairs, N):
     """sum over (g [M, K], W [K, N]) of g W: one launch that keeps the rows' accumulators in registers across the products
     (gsvc_linear_accumulate_many: at most 8 products, M <= 65536), else product by product with the accumulate epilogue."""
-    import os
     g0 = pairs[0][0]
     M = g0.shape[0]
-    if (2 <= len(pairs) <= 8 and MANY_MIN_ROWS <= M <= 65536 and N <= MFMA_MAX_DIM and not os.environ.get("GSVC_NO_ACCUM_MANY")
+    if (2 <= len(pairs) <= 8 and switches.MANY_MIN_ROWS <= M <= 65536 and N <= MFMA_MAX_DIM and not switches.NO_ACCUM_MANY
             and all(g.shape[1] <= MFMA_MAX_DIM and g.shape[1] % 2 == 0 and g.is_contiguous() and w.is_contiguous()
                     and g.data_ptr() % 8 == 0 for g, w in pairs)):
         out = torch.empty(M, N, device=g0.device, dtype=torch.float32)
@@ -345,8 +342,7 @@ class _QuantStepNets(torch.autograd.Function):
 
 def quant_step_nets_usable(x, nets):
     """The fused kernels are instantiated for 192 -> 50 -> 1 with biases, on a tall contiguous fp32 CUDA matrix."""
-    import os
-    if os.environ.get("GSVC_NO_QUANT_CHAIN") or os.environ.get("GSVC_NO_MLP_CHAIN") or len(nets) != 3:
+    if switches.NO_QUANT_CHAIN or switches.NO_MLP_CHAIN or len(nets) != 3:
         return False
     if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= MIN_ROWS and x.shape[1] == 192):
         return False
@@ -522,8 +518,7 @@ def _act_code(net):
 def chain_usable(feat, cond, gens, deform_linears):
     """The chain kernels exist for the production widths only (feature 50, condition 66, hidden 100, outputs 10 / 30 / 70 and
     30) and need tall contiguous fp32 CUDA matrices; the condition must not require a gradient."""
-    import os
-    if os.environ.get("GSVC_NO_MLP_CHAIN") or os.environ.get("GSVC_NO_MLP_FUSED"):
+    if switches.NO_MLP_CHAIN or switches.NO_MLP_FUSED:
         return False
     if not (feat.is_cuda and cond.is_cuda and feat.dim() == cond.dim() == 2 and feat.dtype == cond.dtype == torch.float32
             and feat.shape[0] == cond.shape[0] >= MIN_ROWS and not cond.requires_grad):

@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 
 from .encodings import GridEncoder, Quantize_anchor, STE_binary, UniformQuantizer
+from . import switches
 from .entropy_models import EntropyGaussian
 from .time_util import get_embedder
 
@@ -80,12 +81,12 @@ class SampledEntropyContext:
         nets = (pc.mlp_feature_enet, pc.mlp_scaling_enet, pc.mlp_offset_enet)
         chains = [list(net.dist_net)[0::2] for net in nets]
         if (x.is_cuda and x.shape[0] >= self.MIN_ROWS and all(isinstance(net.dist_net, GeluSequential) for net in nets)
-                and all(mlp.usable(x, *c, min_rows=self.MIN_ROWS) for c in chains) and not os.environ.get("GSVC_NO_MLP_CHAIN")):
+                and all(mlp.usable(x, *c, min_rows=self.MIN_ROWS) for c in chains) and not switches.NO_MLP_CHAIN):
             raw = mlp.seq_gelu_many(x, chains)
         else:
             raw = [net.dist_net(x) for net in nets]
         out = []
-        if x.is_cuda and not os.environ.get("GSVC_NO_FUSED_CTX"):
+        if x.is_cuda and not switches.NO_FUSED_CTX:
             # split + max(scale, 1e-9) as one launch each way per network (gsvc_ctx_post_*; its step output is computed of a dummy)
             q0 = torch.zeros(x.shape[0], 1, device=x.device, dtype=torch.float32)
             for p in raw:
@@ -137,13 +138,13 @@ class Mix3d2dEncoding(nn.Module):
 
     def forward(self, x):
         if (x.is_cuda and x.dim() == 2 and x.shape[1] == 3 and x.dtype == torch.float32 and not x.requires_grad
-                and not os.environ.get("GSVC_NO_FUSED_GRID")
+                and not switches.NO_FUSED_GRID
                 and all(g.ste_binary for g in (self.encoding_xyz, self.encoding_xy, self.encoding_xz, self.encoding_yz))):
             # the four grids write their column blocks of the [N, 192] matrix and read the gradient from them (gsvc_grid_*_ex):
             # no coordinate slices, no [L, N, C] -> [N, L C] permutes, no cat — on either pass
             grids = (self.encoding_xyz, self.encoding_xy, self.encoding_xz, self.encoding_yz)
             if (not torch.is_grad_enabled() and all(g.n_features == 8 and g.params.is_contiguous() for g in grids)
-                    and not os.environ.get("GSVC_NO_PACKED_GRID")):
+                    and not switches.NO_PACKED_GRID):
                 # inference (evaluation, the decoder): the tables as the bitstream carries them — one sign bit per entry, one byte
                 # per row of 8 features — packed on the fly (one pass over the float tables) and looked up as bytes
                 return _mix_grid_packed(x, grids)
@@ -157,7 +158,7 @@ def _mix_grid_packed(x, grids):
     """Mix3d2dEncoding without autograd through bit-packed tables (csrc/grid.hip gsvc_pack_sign_bits + gsvc_grid_forward_packed):
     the same numbers as the lookup in the {-1, +1} float tables, from 1/32 of the table bytes."""
     import ctypes as C
-    from . import _lib
+    from . import _lib, switches
     x = x.contiguous()
     N = x.shape[0]
     total = sum(g.n_levels * g.n_features for g in grids)
@@ -337,7 +338,7 @@ class GeluSequential(nn.Sequential):
         mods = list(self)
         linears = mods[0::2]
         if (all(isinstance(m, nn.Linear) for m in linears) and all(isinstance(m, nn.GELU) for m in mods[1::2])
-                and len(mods) % 2 == 1 and mlp.usable(x, *linears) and not os.environ.get("GSVC_NO_MLP_CHAIN")):
+                and len(mods) % 2 == 1 and mlp.usable(x, *linears) and not switches.NO_MLP_CHAIN):
             return mlp.seq_gelu(x, linears)
         return super().forward(x)
 
@@ -378,7 +379,7 @@ class GeneratorNet(nn.Module):
 
     def _fusable(self, feature):
         from . import mlp
-        return (type(self.out_act).__name__ in ("Tanh", "Sigmoid", "Identity") and not os.environ.get("GSVC_NO_MLP_CHAIN")
+        return (type(self.out_act).__name__ in ("Tanh", "Sigmoid", "Identity") and not switches.NO_MLP_CHAIN
                 and mlp.usable(feature, self.linear1, self.linear2, self.out_linear))
 
     def film_nets(self, condition):
@@ -386,7 +387,7 @@ class GeneratorNet(nn.Module):
         not apply.  They depend on the condition only: a caller may evaluate them ahead and pass ``film=`` to forward."""
         from . import mlp
         f = self.film
-        if (not os.environ.get("GSVC_NO_MLP_CHAIN")
+        if (not switches.NO_MLP_CHAIN
                 and mlp.usable(condition, f.fc_gamma0, f.fc_gamma1, f.fc_beta0, f.fc_beta1)):
             return mlp.film_nets(f, condition)
         return None
@@ -665,14 +666,14 @@ class GaussianModel(nn.Module):
 
     def calc_entropy_context(self, anchor) -> EntropyContext:
         ctx = self.calc_interp_feat(anchor)
-        if ctx.is_cuda and not os.environ.get("GSVC_NO_FUSED_CTX"):
+        if ctx.is_cuda and not switches.NO_FUSED_CTX:
             # split, scale clamp and step activation of each network's raw outputs as one launch each way (csrc/generate.hip)
             out = []
             nets = (self.mlp_feature_enet, self.mlp_scaling_enet, self.mlp_offset_enet)
             from . import mlp
             chains = [list(s)[0::2] for net in nets for s in (net.dist_net, net.quant_step_net)]
             if (all(isinstance(s, GeluSequential) for net in nets for s in (net.dist_net, net.quant_step_net))
-                    and all(mlp.usable(ctx, *c) for c in chains) and not os.environ.get("GSVC_NO_MLP_CHAIN")):
+                    and all(mlp.usable(ctx, *c) for c in chains) and not switches.NO_MLP_CHAIN):
                 # the six sub-networks read the same feature matrix: one autograd function (gsvc_amd.mlp._SeqGeluMany)
                 raw = mlp.seq_gelu_many(ctx, chains)
                 for i in range(3):
@@ -699,7 +700,7 @@ class GaussianModel(nn.Module):
         if mlp.quant_step_nets_usable(ctx, [net.quant_step_net for net in nets]):
             q_raw = mlp.quant_step_nets(ctx, [net.quant_step_net for net in nets])      # one chain launch each way for all three
         elif (ctx.is_cuda and all(isinstance(net.quant_step_net, GeluSequential) for net in nets) and all(mlp.usable(ctx, *c) for c in chains)
-                and not os.environ.get("GSVC_NO_MLP_CHAIN")):
+                and not switches.NO_MLP_CHAIN):
             q_raw = mlp.seq_gelu_many(ctx, chains)          # the three first layers read ctx in one launch
         else:
             q_raw = tuple(net.quant_step_net(ctx) for net in nets)
@@ -905,7 +906,7 @@ class GaussianModel(nn.Module):
             seen, g = torch.cat([r.visibility_filter for r in renders]), torch.cat([r.viewspace_points.grad for r in renders])
         accs = (self.opacity_accum, self.anchor_demon, self.offset_gradient_accum, self.offset_denom)
         if (vi.is_cuda and seen.dtype == torch.bool and g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1
-                and all(a.dtype == torch.float32 and a.is_contiguous() for a in accs) and not os.environ.get("GSVC_NO_FUSED_STATIS")):
+                and all(a.dtype == torch.float32 and a.is_contiguous() for a in accs) and not switches.NO_FUSED_STATIS):
             # one launch (csrc/rate.hip k_training_statis) for the clamp, the sums, the gradient norms and the four scatters
             from . import _lib
             op = op_all.detach().contiguous()

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, switches
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -238,8 +238,7 @@ _SIDE = {}
 def _side_streams(device, renders):
     """Two side streams per device for the independent renders of a step (GSVC_RASTER_STREAMS=1: everything on the current
     stream)."""
-    import os
-    n = int(os.environ.get("GSVC_RASTER_STREAMS", "2"))
+    n = switches.RASTER_STREAMS
     if n <= 1 or renders < 2 or torch.device(device).type != "cuda":
         return []
     key = (torch.device(device).index, n)

@@ -16,6 +16,7 @@ from dataclasses import dataclass
 import torch
 
 from . import dist as gdist
+from . import switches
 from .generate import GenerateMode, region
 from .loss_utils import calc_optical_loss, render_regs, ssim_l1, ssim_l1_pair
 from .optim import FusedAdam
@@ -105,7 +106,7 @@ class Trainer:
         # prefetch: the next step's frame pair is drawn, its visibility test run and every data-dependent index list of its
         # generation pass queued at the END of a step (gsvc_amd.generate.StepPlan): the next step then starts with one wait
         # for nine counts instead of six device round trips with an idle GPU
-        self.prefetch = prefetch and batched and not os.environ.get("GSVC_NO_PREFETCH")      # env: A/B timing only
+        self.prefetch = prefetch and batched and not switches.NO_PREFETCH      # env: A/B timing only
         self._plan = self._plan_idx = self._plan_mode = None
         self.pc, self.dataset, self.opt, self.pipe, self.mp = gaussians, dataset, opt, pipe, model_params
         if gaussians._anchor.is_cuda:
@@ -224,12 +225,12 @@ class Trainer:
         """Row-sparse gradient exchange of the per-anchor tensors: needs the step plan (the rank's distinct visible anchors and the
         largest such count over the ranks) and the replicated Adam; GSVC_DP_SPARSE=0 keeps the dense all-reduce."""
         if not (plan is not None and gdist.world_size() > 1 and self.reducer.enabled and not self.anchor_grad
-                and getattr(plan, "distinct_cap", None) is not None and os.environ.get("GSVC_DP_SPARSE", "1") != "0"):
+                and getattr(plan, "distinct_cap", None) is not None and switches.DP_SPARSE != "0"):
             return False
         # every rank receives the other ranks' row lists (all-gather, padded to the largest): worth it while those rows are fewer
         # than what a ring all-reduce of the dense tensors moves (2 (W - 1) / W of the anchors) — two ranks always, eight ranks
         # only when a rank sees less than a quarter of the anchors.  The same decision on every rank (cap is their maximum).
-        return os.environ.get("GSVC_DP_SPARSE") == "1" or gdist.sparse_rows_pay(gdist.world_size(), int(self.pc._anchor.shape[0]),
+        return switches.DP_SPARSE == "1" or gdist.sparse_rows_pay(gdist.world_size(), int(self.pc._anchor.shape[0]),
                                                                                   plan.distinct_cap)
 
     def _views(self, frame_idx):
@@ -339,11 +340,11 @@ class Trainer:
                 and (gdist.world_size() == 1 or (self.reducer.enabled and self.reducer._order is not None))
                 and not self.anchor_grad      # a trained anchor tensor moves behind the early plan's visibility test
                 and mode == GenerateMode.TRAINING_ENTROPY and iteration < opt.iterations and not self.controller.gaussian_adjust_anchor
-                and isinstance(pc.optimizer, FusedAdam) and not os.environ.get("GSVC_NO_EARLY_PLAN")
+                and isinstance(pc.optimizer, FusedAdam) and not switches.NO_EARLY_PLAN
                 and pc._scaling.requires_grad and pc._mask.requires_grad
                 # it pays when the GPU, not the host, bounds the step (the hook's work costs ~1 ms of host time more on the
                 # autograd thread than at the end of the step: a 6 k-row step went 8.3 -> 9.7 ms, the 200 k-row step 11.95 -> 11.3)
-                and (os.environ.get("GSVC_EARLY_PLAN") or sum(int(r.visible_index.shape[0]) for r in
+                and (switches.EARLY_PLAN or sum(int(r.visible_index.shape[0]) for r in
                                                                (x.generated_gaussians for x in renders)) >= EARLY_PLAN_MIN_ROWS)):
             pending = [2]
 

@@ -17,3 +17,27 @@ def oracle_lib():
     import oracle
     oracle.build()
     return oracle
+
+
+def pytest_runtest_setup(item):
+    # the package reads its GSVC_* switches once, at import (gsvc_amd/switches.py): every test starts from the environment as it is now
+    from gsvc_amd import switches
+    switches.reload()
+
+
+@pytest.fixture(autouse=True)
+def _switches_follow_the_environment(monkeypatch):
+    """``monkeypatch.setenv`` / ``delenv`` of a GSVC_* switch inside a test takes effect at once (the switches are re-read)."""
+    from gsvc_amd import switches
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def _setenv(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        switches.reload()
+
+    def _delenv(name, *a, **k):
+        delenv(name, *a, **k)
+        switches.reload()
+
+    monkeypatch.setenv, monkeypatch.delenv = _setenv, _delenv
+    yield

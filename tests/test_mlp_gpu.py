@@ -9,6 +9,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from gsvc_amd import switches
+
 pytestmark = pytest.mark.gpu
 
 
@@ -328,11 +330,12 @@ def test_entropy_sub_networks_as_one_function_match_torch():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [1, 4097, 52481, 65536])
-def test_sum_of_products_in_one_launch_matches_the_accumulate_epilogue(M):
+def test_sum_of_products_in_one_launch_matches_the_accumulate_epilogue(M, monkeypatch):
     """gsvc_linear_accumulate_many (csrc/linear_accum.hip): Y = sum_p G_p W_p for the six first-layer input gradients of the entropy
     networks (reference scene/gaussian_model.py:198-232 read by 1569-1597) against float64 and against the product-by-product path."""
     import torch
     from gsvc_amd import mlp
+    monkeypatch.setenv("GSVC_MANY_MIN_ROWS", "1")      # (the product path takes the one-launch form from 24 576 rows)
     torch.manual_seed(M)
     dev = torch.device("cuda")
     Ks = [150, 50, 100, 50, 150, 50]
@@ -342,10 +345,12 @@ def test_sum_of_products_in_one_launch_matches_the_accumulate_epilogue(M):
     scale = ref.abs().max().item()
     assert (got.double() - ref).abs().max().item() <= 2e-6 * scale
     os.environ["GSVC_NO_ACCUM_MANY"] = "1"
+    switches.reload()
     try:
         old = mlp._sum_of_products(pairs, 192)
     finally:
         del os.environ["GSVC_NO_ACCUM_MANY"]
+        switches.reload()
     assert (got - old).abs().max().item() <= 2e-6 * scale
     assert torch.equal(got, mlp._sum_of_products(pairs, 192))         # fixed order
     # a product the fused kernel does not take (odd K): the fallback answers
@@ -360,7 +365,7 @@ def test_first_layers_with_a_shared_input_in_one_launch(M, monkeypatch):
     """gsvc_linear_forward_shared_input (csrc/linear_accum.hip) against the layer kernel it replaces for the entropy networks' six
     first layers (same bits: the same MFMA order per output) and against float64."""
     from gsvc_amd import mlp
-    monkeypatch.setattr(mlp, "MANY_MIN_ROWS", 1)      # the product path takes these launches from 24 576 rows; the kernels take any M
+    monkeypatch.setenv("GSVC_MANY_MIN_ROWS", "1")      # the product path takes these launches from 24 576 rows; the kernels take any M
     torch.manual_seed(M)
     dev = torch.device("cuda")
     Ns = [150, 50, 100, 50, 150, 50]
@@ -392,10 +397,12 @@ def test_first_layers_with_a_shared_input_in_one_launch(M, monkeypatch):
         return [o.detach() for o in outs], xx.grad, [p.grad.clone() for c in chains for l in c for p in l.parameters()]
     o1, g1, p1 = run()
     os.environ["GSVC_NO_SHARED_INPUT"] = os.environ["GSVC_NO_ACCUM_MANY"] = "1"
+    switches.reload()
     try:
         o0, g0, p0 = run()
     finally:
         del os.environ["GSVC_NO_SHARED_INPUT"], os.environ["GSVC_NO_ACCUM_MANY"]
+        switches.reload()
     assert all(torch.equal(a, b) for a, b in zip(o1, o0))
     assert (g1 - g0).abs().max().item() <= 2e-6 * g0.abs().max().item()
     assert all(torch.equal(a, b) for a, b in zip(p1, p0))

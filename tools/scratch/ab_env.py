@@ -37,6 +37,8 @@ for rep in range(5):
             os.environ.pop(var, None)
         else:
             os.environ[var] = v
+        from gsvc_amd import switches
+        switches.reload()
         for _ in range(3):
             it += 1; tr.step(it)
         torch.cuda.synchronize(); t0 = time.perf_counter()
