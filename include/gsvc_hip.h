@@ -13,6 +13,25 @@
  *                                                    call sites reference utils/encodings.py:529-553,582-610
  *   utils/entropy_models.py EntropyGaussian (+Low_bound)           reference utils/entropy_models.py:32-68,159-175
  *
+ * TWO KINDS OF ENTRY POINTS.  A maintainer who swaps GSVC's native extensions for this library binds the FIFTEEN marked
+ * [BOUNDARY] — they have the shape of the calls GSVC makes today — and can ignore the rest:
+ *
+ *   rasterizer   gsvc_raster_sizes_query, gsvc_raster_visible_filter, gsvc_raster_forward, gsvc_raster_backward_scratch_bytes,
+ *                gsvc_raster_backward   (+ gsvc_raster_forward_pair: the decoder's two-view frame of report_utils.py:297-319 in one pass)
+ *   hash grid    gsvc_grid_forward, gsvc_grid_backward                      (= grid_encode_forward / grid_encode_backward)
+ *   rate         gsvc_rate_forward, gsvc_rate_backward                      (= EntropyGaussian.forward + Low_bound's backward)
+ *   codec        gsvc_ans_segments, gsvc_ans_scratch_bytes, gsvc_ans_encode, gsvc_ans_decode_scratch_bytes, gsvc_ans_decode
+ *                                                                             (= gsvc_cuda_ans.ANSCoder behind encoder_gaussian / decoder_gaussian)
+ *   init         gsvc_knn3_mean_dist2                                         (= simple_knn._C.distCUDA2)
+ *   always       gsvc_last_error, gsvc_version
+ *
+ * Everything else is [INTERNAL]: fusion entries that gsvc_amd's own host code (gsvc_amd/*.py) calls to run the fitting step and
+ * the decoder loop in ~170 launches instead of ~2 000 — batched / un-compacted forms of the same arithmetic (several views, whole
+ * MLPs, the step's loss terms, the optimizer, the step plan), each with a parity test against the tensor expression or reference
+ * function it replaces (cited at the declaration).  They are exported because the host side is Python over ctypes; their
+ * signatures follow gsvc_amd's needs, not GSVC's API, and may change between rounds.  INTEGRATION.md section 1 has the same map
+ * with the reference call site of every [BOUNDARY] entry.
+ *
  * Conventions
  *   - plain pointers and sizes only; every pointer is DEVICE memory unless its name ends in _host;
  *   - the caller owns every buffer (outputs, scratch blobs); nothing is allocated or freed inside, nothing
@@ -52,7 +71,7 @@ int gsvc_profile_enable(int on);
 int gsvc_profile_collect(char *names_out_host, int32_t *launches_out_host, float *total_ms_out_host, int max_kernels);
 
 /* ------------------------------------------------------------------------------------------------------
- * Orthographic sliding-window rasterizer
+ * Orthographic sliding-window rasterizer   [BOUNDARY; gsvc_raster_visible_masks and the two *_layout queries are INTERNAL]
  * ---------------------------------------------------------------------------------------------------- */
 
 /* Fields of GaussianRasterizationSettings the extension reads (reference renderer.py:63-83).
@@ -159,7 +178,8 @@ int gsvc_raster_image_layout(const gsvc_raster_settings *settings, uint64_t *fin
                              uint64_t *n_contrib_byte_off_host);
 
 /* ------------------------------------------------------------------------------------------------------
- * Multi-resolution hash grid (replaces _gridencoder.grid_encode_forward / grid_encode_backward)
+ * Multi-resolution hash grid (replaces _gridencoder.grid_encode_forward / grid_encode_backward)   [BOUNDARY; the _ex / _packed
+ * forms and gsvc_pack_sign_bits are INTERNAL]
  * ---------------------------------------------------------------------------------------------------- */
 
 /* inputs[N,D] in [0,1]; embeddings[rows,C]; offsets[L+1], resolutions[L] (int32, device, already sliced to
@@ -199,7 +219,8 @@ int gsvc_grid_forward_packed(const float *inputs, const uint8_t *table_bits, con
                              float *outputs, uint32_t N, uint32_t D, uint32_t L, const gsvc_grid_io *layout, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Entropy-rate estimator (replaces utils/entropy_models.py EntropyGaussian.forward + Low_bound backward)
+ * Entropy-rate estimator (replaces utils/entropy_models.py EntropyGaussian.forward + Low_bound backward)   [BOUNDARY: gsvc_rate_forward /
+ * _backward; the sampled-rate entries below them are INTERNAL]
  * ---------------------------------------------------------------------------------------------------- */
 
 /* bits[n,c] = -log2(max(Phi((x+Q/2-mu)/sigma) - Phi((x-Q/2-mu)/sigma), 2^-16)) with x clamped to
@@ -261,7 +282,7 @@ int gsvc_training_statis(const int64_t *vis, const float *opacity, const uint8_t
                          void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Image distortion of the fitting step (replaces utils/loss_utils.py l1_loss_func + ssim_func and their autograd)
+ * Image distortion of the fitting step (replaces utils/loss_utils.py l1_loss_func + ssim_func and their autograd)   [INTERNAL]
  * ---------------------------------------------------------------------------------------------------- */
 
 /* img1, img2: [C,H,W].  workspace: 2048 floats of scratch.  sums[2] (device): sums[0] = sum of the SSIM map (11x11 Gaussian window,
@@ -298,7 +319,7 @@ int gsvc_ste_binary_backward_many(const float *const *x, const float *const *gra
 int gsvc_table_bits(const float *counts, int32_t tables, int64_t total, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Per-Gaussian loss terms of the fitting step over UN-COMPACTED renders (every visible anchor contributes its K
+ * [INTERNAL] Per-Gaussian loss terms of the fitting step over UN-COMPACTED renders (every visible anchor contributes its K
  * Gaussians; mask[i] = opacity_i > 0)
  * ---------------------------------------------------------------------------------------------------- */
 
@@ -377,7 +398,7 @@ int gsvc_gen_tail_backward(const float *opacity_raw, const float *offset_mask, c
                            float *d_grid_scaling, float *d_anchor, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Optimizer (reference scene/gaussian_model.py:1034-1058: torch.optim.Adam(eps=1e-15), 15 parameter groups)
+ * Optimizer (reference scene/gaussian_model.py:1034-1058: torch.optim.Adam(eps=1e-15), 15 parameter groups)   [INTERNAL]
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct gsvc_adam_tensor {
     float *param;             /* updated in place */
@@ -399,7 +420,7 @@ int gsvc_adam_step_guarded(int32_t n_tensors, const gsvc_adam_tensor *tensors_ho
                            const int32_t *const *guards_host, int32_t n_guards, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Model creation: mean squared distance to the 3 nearest neighbours (replaces
+ * [BOUNDARY] Model creation: mean squared distance to the 3 nearest neighbours (replaces
  * simple_knn._C.distCUDA2, reference simple-knn.zip simple_knn.cu:185-220, call sites scene/gaussian_model.py:762,784).
  * The caller bins the points into a uniform grid: points_by_cell[n,3] sorted by cell index ((z * gy + y) * gx + x, cell of
  * a point = floor((p - origin) / cell_edge) clamped to the grid), cell_start[gx*gy*gz + 1].  out[n] in the sorted order.
@@ -408,7 +429,8 @@ int gsvc_knn3_mean_dist2(const float *points_by_cell, const int32_t *cell_start,
                          int32_t gx, int32_t gy, int32_t gz, int64_t n, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Entropy coding of quantised attributes with the learned Gaussian model (replaces the external
+ * [BOUNDARY; gsvc_ans_decode_many and gsvc_ans_table_checksum are INTERNAL] Entropy coding of quantised attributes with the learned
+ * Gaussian model (replaces the external
  * gsvc_cuda_ans.ANSCoder the reference calls through utils/encodings.py:102-245 encoder_gaussian / decoder_gaussian:
  * integer symbols in [min_symbol, max_symbol], one Normal(mu, sigma) per symbol in symbol units).
  * rANS, 20-bit frequencies from the model itself (no tables), independent segments of seg_len symbols; the byte layout
@@ -554,7 +576,7 @@ typedef struct gsvc_ans_decode_job {
 int gsvc_ans_decode_many(const gsvc_ans_decode_job *jobs, int32_t n_jobs, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Linear layers of the generator / deformation / entropy-parameter MLPs (reference scene/gaussian_model.py:
+ * [INTERNAL] Linear layers of the generator / deformation / entropy-parameter MLPs (reference scene/gaussian_model.py:
  * 150-232: every nn.Linear applied to the [anchors, features] matrix)
  * ---------------------------------------------------------------------------------------------------- */
 
@@ -645,7 +667,7 @@ typedef struct gsvc_wgrad_partial_job {
 int gsvc_linear_wgrad_partial_many(gsvc_wgrad_partial_job *jobs, int32_t n_jobs, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Whole-network chain kernels of the generator and deformation MLPs (csrc/mlp_chain.hip): a 16-row block's activations stay
+ * [INTERNAL] Whole-network chain kernels of the generator and deformation MLPs (csrc/mlp_chain.hip): a 16-row block's activations stay
  * in registers from the network's input to its output; weights resident in LDS; fp32 MFMA.
  * Replaces, per anchor row: GeneratorNet.forward = out_act(out_linear(film(linear2(GELU(linear1(feature))), condition)))
  * with FiLM = gamma(c) * x + beta(c), gamma / beta = fc_*1(ReLU(fc_*0(c))) (reference scene/gaussian_model.py:150-196, used at
@@ -722,7 +744,7 @@ int gsvc_deform_backward(const gsvc_deform_net *net, const float *feat, const fl
                          const gsvc_deform_grads *grads, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Anchor geometry decode (the G-PCC tmc3 step of reference utils/encodings.py:780-826 decode_anchor; coder and bitstream are this
+ * [INTERNAL] Anchor geometry decode (the G-PCC tmc3 step of reference utils/encodings.py:780-826 decode_anchor; coder and bitstream are this
  * library's own: gsvc_amd/anchor_codec.py).  An occupancy octree over the integer anchor lattice, one 8-bit mask per node,
  * per level a static 12-bit model and an interleaved rANS stream (32-bit states, 16-bit words, symbol i in lane i % lanes).
  * gsvc_anchor_rans_decode: all levels' symbols in one launch (one workgroup per level); error: OR of 1 bad table, 2 truncated,
