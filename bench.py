@@ -156,7 +156,8 @@ def pmc_traffic(workload, kernel):
 # quadrant is 36 vector instructions + 3 LDS reads of the entry's record, the nine-sum reduction 74 cross-lane instructions per
 # four entries; a wave-instruction holds a SIMD's issue slot for 1.5 ns (fma) to 3.5 ns (exp, rcp, permlane swap), 1.8 ns on this
 # kernel's mix (tools/micro/valu_rate.hip, profiles/r03/microbench_valu_rate.txt); 256 CUs x 4 SIMDs
-REPLAY_INSTS, REDUCE_INSTS_PER_ENTRY, NS_PER_WAVE_INST, SIMDS = 36 + 3, 18.5, 1.8, 256 * 4
+# vector instructions of the polynomial replay loop in the built kernel: 592 per four entries with all quadrants = 16 x 32.4 + 74
+REPLAY_INSTS, REDUCE_INSTS_PER_ENTRY, NS_PER_WAVE_INST, SIMDS = 32.4, 18.5, 1.8, 256 * 4
 
 
 def roofline_valu(probe, kern_dom, one_stream_us, traffic_src):

@@ -138,7 +138,7 @@ __device__ __forceinline__ void r4_tail(Sums9 &q)
 // contributor, alpha < 1/255, power > 0, outside the image) runs the same instructions with alpha = 0 and G = 0, which
 // leaves T and bd unchanged (rcp(1) = 1, 0 * cd + 1 * bd = bd) and adds zeros.  No EXEC-mask branches: the compiler's
 // branchy form spent a third of its instructions on zero-filling the nine sums on every path.
-template <bool CLAMP_STOP>
+template <bool CLAMP_STOP, bool ZERO_BG>
 __device__ __forceinline__ bool bwd_pixel(PixState &p, float dx, float dy, const float4 &a, const float4 &b, float cb,
                                           int contributor, Sums9 &s)
 {
@@ -158,13 +158,52 @@ __device__ __forceinline__ bool bwd_pixel(PixState &p, float dx, float dy, const
     p.T *= inv;
     const float w = alpha * p.T;
     s.r = fmaf(w, p.d0, s.r); s.g = fmaf(w, p.d1, s.g); s.b = fmaf(w, p.d2, s.b);
-    const float dLda = fmaf(cd - p.bd, p.T, -(p.tb * inv));
+    // ZERO_BG (black background, the reference's default): the background's share T_final (bg . d) / (1 - alpha) is zero
+    const float dLda = ZERO_BG ? (cd - p.bd) * p.T : fmaf(cd - p.bd, p.T, -(p.tb * inv));
     p.bd = fmaf(alpha, cd, oma * p.bd);
     // moments of h = G * dL/dalpha; the conic / opacity factors are applied once per Gaussian in B2
     const float h = G * dLda;
     const float hx = h * dx, hy = h * dy;
     s.h += h; s.x += hx; s.y += hy;
     s.xx = fmaf(hx, dx, s.xx); s.xy = fmaf(hx, dy, s.xy); s.yy = fmaf(hy, dy, s.yy);
+    return valid;
+}
+
+// The same step with the entry's log2(alpha) as a POLYNOMIAL in the pixel's offset (x, y) from the tile centre (|x|, |y| <= 7.5):
+//   t = n0 + n1 x + n2 y + n3 x^2 + n4 y^2 + n5 xy = log2(o) - [A'(U - x)^2 + C'(V - y)^2 + B'(U - x)(V - y)],  (U, V) = centre - tile centre
+// (the forward's compositing loop does the same per quadrant: csrc/raster_fwd.hip blend_pass).  x, y and their products are
+// per-lane CONSTANTS, so the power costs five multiply-adds (was: two subtractions for dx, dy + five), the opacity rides in n0
+// (no o * G product) and the six moments are multiply-adds against the same constants: sums of h', h' x, h' y, h' x^2, h' xy,
+// h' y^2 with h' = o G dL/dalpha — moments about the TILE centre, which the row's writer shifts to the Gaussian's centre and
+// divides by o once per (tile, Gaussian) (k_blend_bwd_tile's flush).  33 vector instructions per (entry, quadrant), was 39.
+// Only for conics that are positive definite with a margin (the forward's rule): "power > 0" cannot occur there.
+template <bool CLAMP_STOP, bool ZERO_BG>
+__device__ __forceinline__ bool bwd_pixel_poly(PixState &p, float x, float y, float x2, float y2, float xy, const float4 &a,
+                                               const float4 &b, float cb, int contributor, Sums9 &s)
+{
+    float t = fmaf(b.y, xy, a.x);
+    t = fmaf(a.y, x, t);
+    t = fmaf(a.z, y, t);
+    t = fmaf(a.w, x2, t);
+    t = fmaf(b.x, y2, t);
+    const float oG = __builtin_amdgcn_exp2f(t);            // opacity x Gaussian
+    const float araw = fminf(ALPHA_MAX, oG);
+    const bool valid = (contributor <= p.last) & !(araw < ALPHA_MIN);
+    const float alpha = valid ? araw : 0.0f;
+    const float Gh = (CLAMP_STOP ? (valid & !(oG > ALPHA_MAX)) : valid) ? oG : 0.0f;
+    const float cd = fmaf(cb, p.d2, fmaf(b.w, p.d1, b.z * p.d0));   // colour . dL/dpixel
+    const float oma = 1.0f - alpha;
+    const float inv = __builtin_amdgcn_rcpf(oma);
+    p.T *= inv;
+    const float w = alpha * p.T;
+    s.r = fmaf(w, p.d0, s.r); s.g = fmaf(w, p.d1, s.g); s.b = fmaf(w, p.d2, s.b);
+    // ZERO_BG (black background, the reference's default): the background's share T_final (bg . d) / (1 - alpha) is zero
+    const float dLda = ZERO_BG ? (cd - p.bd) * p.T : fmaf(cd - p.bd, p.T, -(p.tb * inv));
+    p.bd = fmaf(alpha, cd, oma * p.bd);
+    const float h = Gh * dLda;
+    s.h += h;
+    s.x = fmaf(h, x, s.x); s.y = fmaf(h, y, s.y);
+    s.xx = fmaf(h, x2, s.xx); s.xy = fmaf(h, xy, s.xy); s.yy = fmaf(h, y2, s.yy);
     return valid;
 }
 
@@ -175,11 +214,12 @@ __device__ __forceinline__ bool bwd_pixel(PixState &p, float dx, float dy, const
 // partial-sum buffer (row index from the sort: gslot); entries nothing reached get a row of zeros.  B2 then adds up
 // each Gaussian's rows (they are contiguous and in tile order: the sum order is fixed, the backward is deterministic).
 #ifndef GSVC_BWD_WAVES
-#define GSVC_BWD_WAVES 5      // 96 VGPRs: the four-entry reduction's 27 live sums fit without a spill
+#define GSVC_BWD_WAVES 4      // 115-120 VGPRs (27 live sums of the four-entry reduction + 28 of pixel state + the 12 per-lane
+                              // polynomial constants); at 5 waves (96) the spills cost more than the fifth wave gives (measured)
 #endif
 // DBG: the timing experiments / lane-efficiency probe selected by the run-time word `dbg` (GSVC_BWD_DEBUG); the production
 // instantiation (DBG = false) carries none of their code or registers
-template <bool CLAMP_STOP, bool DBG>
+template <bool CLAMP_STOP, bool DBG, bool ZERO_BG>
 __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterParams st, const int32_t *__restrict__ tile_offsets,
                                                        const int32_t *__restrict__ point_list,
                                                        const uint2 *__restrict__ inst_bbox,
@@ -195,12 +235,19 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
     __shared__ float4 s_f1[64];     // C' opacity r g
     __shared__ float2 s_f2[64];     // b, tag = chunk entry | quadrant mask << 8 | list position << 12
     __shared__ float s_out[64][9];  // per chunk entry: sum h, h dx, h dy, h dx^2, h dx dy, h dy^2, w d0, w d1, w d2
+    __shared__ float s_park[5][64]; // per lane, across the replay loop: what the flush needs of the lane's own entry (registers
+                                    // are what bounds the waves per SIMD here; these six would be live through the whole loop)
     const int lane = threadIdx.x;
     const int tx0 = blockIdx.x * TILE, ty0 = blockIdx.y * TILE;
     const int tile = blockIdx.y * st.gx + blockIdx.x;
     const int HW = st.H * st.W;
     PixState ps[4];
-    const float fx0 = (float)(tx0 + (lane & 7)), fy0 = (float)(ty0 + (lane >> 3));
+    // the lane's pixel of quadrant q relative to the tile centre: x = (q & 1 ? xb : xa), y = (q >> 1 ? yb : ya), and the products
+    const float xa = (float)(lane & 7) - 7.5f, xb = xa + 8.0f, ya = (float)(lane >> 3) - 7.5f, yb = ya + 8.0f;
+    const float px_[4] = {xa, xb, xa, xb}, py_[4] = {ya, ya, yb, yb};
+    const float px2_[4] = {xa * xa, xb * xb, xa * xa, xb * xb}, py2_[4] = {ya * ya, ya * ya, yb * yb, yb * yb};
+    const float pxy_[4] = {xa * ya, xb * ya, xa * yb, xb * yb};
+    const float tcx = (float)tx0 + 7.5f, tcy = (float)ty0 + 7.5f;
     int wl[4];
     // every load of the prologue is issued before anything is waited for (one memory round trip): the tile's list bounds,
     // the forward's per-pixel state (tile-major: coalesced) and dL/dpixel — the latter as one 16-byte load per lane and
@@ -249,7 +296,7 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         PixState &p = ps[q];
-        p.tb = Tf[q] * (st.bg0 * p.d0 + st.bg1 * p.d1 + st.bg2 * p.d2);
+        p.tb = ZERO_BG ? 0.f : Tf[q] * (st.bg0 * p.d0 + st.bg1 * p.d1 + st.bg2 * p.d2);
         p.T = Tf[q];
         p.bd = 0.f;
         int m = p.last;
@@ -312,12 +359,33 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
         }
         const unsigned long long mask = __ballot(qm != 0);
         const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        // conic positive definite with a margin and opacity > 0 (the forward's rule): the chunk takes the polynomial replay; a chunk
+        // that holds any other entry (NaN / indefinite conics) the literal one
+        const bool safe = r0.z > 0.f && r1.x > 0.f && r0.z * r1.x >= 1.002f * (r0.w * r0.w) && r1.y > 0.f;
+        const bool generic = DBG || __ballot(qm != 0 && !safe) != 0ull;
         if (qm != 0) {
-            s_f0[pos] = make_float4(r0.x, r0.y, (0.5f * 1.44269504088896340736f) * r0.z, 1.44269504088896340736f * r0.w);
-            s_f1[pos] = make_float4((0.5f * 1.44269504088896340736f) * r1.x, r1.y, r1.z, r1.w);
+            const float Ap = (0.5f * 1.44269504088896340736f) * r0.z, Bp = 1.44269504088896340736f * r0.w,
+                        Cp = (0.5f * 1.44269504088896340736f) * r1.x;
+            if (generic) {
+                s_f0[pos] = make_float4(r0.x, r0.y, Ap, Bp);
+                s_f1[pos] = make_float4(Cp, r1.y, r1.z, r1.w);
+            } else {
+                const float U = r0.x - tcx, V = r0.y - tcy;
+                const float n0 = __builtin_amdgcn_logf(r1.y) - (Ap * U * U + Cp * V * V + Bp * U * V);
+                s_f0[pos] = make_float4(n0, 2.0f * Ap * U + Bp * V, 2.0f * Cp * V + Bp * U, -Ap);
+                s_f1[pos] = make_float4(-Cp, -Bp, r1.z, r1.w);
+            }
             s_f2[pos] = make_float2(r2x, __int_as_float(lane | (qm << 8) | ((k - beg + 1) << 12)));
         }
         const int cnt = (dbg & 8) ? 0 : __popcll(mask);      // timing experiment only: chunk overhead without entries
+        {
+            const bool fl = k >= beg && bbox_hits_tile(bb.x, bb.y, tx0, ty0) && !(dbg & 16);      // this lane writes a row
+            s_park[0][lane] = __int_as_float(fl ? gs : -1);
+            s_park[1][lane] = __int_as_float(qm != 0 ? pos : -1);
+            s_park[2][lane] = r0.x - tcx;
+            s_park[3][lane] = r0.y - tcy;
+            s_park[4][lane] = qm != 0 ? 1.0f / r1.y : 0.f;
+        }
         probe_entries += cnt;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -330,17 +398,30 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
             const int contributor = tag >> 12, quads = (tag >> 8) & 0xf;
             e = tag & 0xff;
             s.h = s.x = s.y = s.xx = s.xy = s.yy = s.r = s.g = s.b = 0.f;
-            const float dxb = a.x - fx0, dyb = a.y - fy0;
+            const float dxb = a.x - (tcx + xa), dyb = a.y - (tcy + ya);      // exact: small integers + halves
             if (dbg & 1) { s.h = dxb; s.x = dyb; return; }     // timing experiment only (GSVC_BWD_DEBUG): no replay
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (quads & (1 << q)) {
-                    const bool v = bwd_pixel<CLAMP_STOP>(ps[q], dxb - (float)(8 * (q & 1)), dyb - (float)(8 * (q >> 1)), a, b, c.x, contributor, s);
+                    const bool v = bwd_pixel<CLAMP_STOP, ZERO_BG>(ps[q], dxb - (float)(8 * (q & 1)), dyb - (float)(8 * (q >> 1)), a, b, c.x, contributor, s);
                     if (dbg & 128) {      // lane-efficiency probe (tools/bwd_lane_efficiency.py): replays and the lanes they were for
                         probe_replays++;
                         probe_lanes += __popcll(__ballot(v));
                     }
                 }
+        };
+        auto replay_poly = [&](int j, Sums9 &s, int &e) {
+            const float4 a = s_f0[j];
+            const float4 b = s_f1[j];
+            const float2 c = s_f2[j];
+            const int tag = __builtin_amdgcn_readfirstlane(__float_as_int(c.y));
+            const int contributor = tag >> 12, quads = (tag >> 8) & 0xf;
+            e = tag & 0xff;
+            s.h = s.x = s.y = s.xx = s.xy = s.yy = s.r = s.g = s.b = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (quads & (1 << q))
+                    bwd_pixel_poly<CLAMP_STOP, ZERO_BG>(ps[q], px_[q], py_[q], px2_[q], py2_[q], pxy_[q], a, b, c.x, contributor, s);
         };
         // four entries per reduction pass (r4_pair / r4_tail above); rows of the reduced registers = entries j, j + 2, j + 1, j + 3.
         // Lane (row r, bank b, t): t = 0 stores value {0,2,1,3}[b], t = 1 value {4,6,5,7}[b], (b, t) = (0, 2) the ninth, into the
@@ -351,6 +432,7 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
             const bool wr = t < 2 || (t == 2 && bk == 0);
             const int off = perm_r * 9 + (t == 0 ? perm_b : (t == 1 ? 4 + perm_b : 8));
             float *so = &s_out[0][0];
+            auto pass = [&](auto &&replay) {
             for (int j = 0; j < cnt; j += 4) {
                 Sums9 sa, sb, sc, sd;
                 int e_;
@@ -369,17 +451,31 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
                 const float v = t == 0 ? sa.xx : (t == 1 ? sa.g : sa.b);
                 if (wr) so[j * 9 + off] = v;
             }
+            };
+            if (generic) pass(replay); else pass(replay_poly);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // flush: every entry of the chunk whose alpha box touches the tile writes its whole row (replayed entries their sums,
         // the others zeros)
-        if (k >= beg && bbox_hits_tile(bb.x, bb.y, tx0, ty0) && !(dbg & 16)) {
+        const int gs_f = __float_as_int(s_park[0][lane]), pos_f = __float_as_int(s_park[1][lane]);
+        if (gs_f >= 0) {
             float v[9];
 #pragma unroll
-            for (int c = 0; c < 9; c++) v[c] = qm != 0 ? s_out[pos][c] : 0.f;      // sums by chunk position
-            float4 *row = reinterpret_cast<float4 *>(rows + (size_t)gs * ROW_FLOATS);
+            for (int c = 0; c < 9; c++) v[c] = pos_f >= 0 ? s_out[pos_f][c] : 0.f;      // sums by chunk position
+            if (!generic) {
+                // the polynomial replay's moments are of o h about the tile centre: shift to the Gaussian's centre, take o out
+                const float U = s_park[2][lane], V = s_park[3][lane], io = s_park[4][lane];
+                const float m0 = v[0], mx = v[1], my = v[2], mxx = v[3], mxy = v[4], myy = v[5];
+                v[0] = m0 * io;
+                v[1] = fmaf(U, m0, -mx) * io;
+                v[2] = fmaf(V, m0, -my) * io;
+                v[3] = fmaf(U, fmaf(U, m0, -2.0f * mx), mxx) * io;
+                v[4] = (fmaf(U, fmaf(V, m0, -my), mxy) - V * mx) * io;
+                v[5] = fmaf(V, fmaf(V, m0, -2.0f * my), myy) * io;
+            }
+            float4 *row = reinterpret_cast<float4 *>(rows + (size_t)gs_f * ROW_FLOATS);
             row[0] = make_float4(v[0], v[1], v[2], v[3]);
             row[1] = make_float4(v[4], v[5], v[6], v[7]);
             row[2] = make_float4(v[8], 0.f, 0.f, 0.f);
@@ -553,11 +649,13 @@ extern "C" int gsvc_raster_backward(const gsvc_raster_settings *settings, int64_
     const int dbg = dbg_env | (bwd_probe_enabled() ? 128 : 0);     // gsvc_profile_enable(2): the lane-efficiency probe, at run time
     {
         ProfScope _prof("k_blend_bwd", s);
-#define GSVC_BWD_LAUNCH(CS, DB) hipLaunchKernelGGL((k_blend_bwd_tile<CS, DB>), dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, \
+#define GSVC_BWD_LAUNCH(CS, DB, ZB) hipLaunchKernelGGL((k_blend_bwd_tile<CS, DB, ZB>), dim3(L.gx, L.gy), dim3(64), 0, s, p, tile_offsets, point_list, \
             inst_bbox, gslot, (const GeomRec *)geom, final_T, n_contrib, dL_dimage, (float *)scratch, counters, dbg)
         const bool cs = p.flags & GSVC_RASTER_CLAMP_STOPS_GRADIENT;
-        if (dbg) { if (cs) GSVC_BWD_LAUNCH(true, true); else GSVC_BWD_LAUNCH(false, true); }
-        else { if (cs) GSVC_BWD_LAUNCH(true, false); else GSVC_BWD_LAUNCH(false, false); }
+        const bool zb = p.bg0 == 0.f && p.bg1 == 0.f && p.bg2 == 0.f;
+        if (dbg) { if (cs) GSVC_BWD_LAUNCH(true, true, false); else GSVC_BWD_LAUNCH(false, true, false); }
+        else if (zb) { if (cs) GSVC_BWD_LAUNCH(true, false, true); else GSVC_BWD_LAUNCH(false, false, true); }
+        else { if (cs) GSVC_BWD_LAUNCH(true, false, false); else GSVC_BWD_LAUNCH(false, false, false); }
 #undef GSVC_BWD_LAUNCH
     }
     {

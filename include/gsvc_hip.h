@@ -25,7 +25,7 @@
  *   init         gsvc_knn3_mean_dist2                                         (= simple_knn._C.distCUDA2)
  *   always       gsvc_last_error, gsvc_version
  *
- * Everything else is [INTERNAL]: fusion entries that gsvc_amd's own host code (gsvc_amd/*.py) calls to run the fitting step and
+ * Everything else is [INTERNAL]: fusion entries that gsvc_amd's own host code (gsvc_amd/ *.py) calls to run the fitting step and
  * the decoder loop in ~170 launches instead of ~2 000 — batched / un-compacted forms of the same arithmetic (several views, whole
  * MLPs, the step's loss terms, the optimizer, the step plan), each with a parity test against the tensor expression or reference
  * function it replaces (cited at the declaration).  They are exported because the host side is Python over ctypes; their

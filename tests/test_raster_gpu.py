@@ -347,6 +347,42 @@ def test_backward_parity_full_size_cfg2(oracle_lib):
     _grad_close(d["rotations"].grad.cpu().numpy(), rb.rotations, "rotations")
 
 
+@pytest.mark.parametrize("bg", [(0.0, 0.0, 0.0), (0.3, 0.1, 0.6)])
+def test_backward_polynomial_and_literal_replay_both_hold_the_oracle(oracle_lib, bg):
+    """k_blend_bwd_tile replays chunks of positive-definite conics with log2(alpha) as a polynomial about the tile centre and
+    shifts the moments to the Gaussian's centre afterwards; the literal per-pixel (dx, dy) loop stays for other chunks and is
+    what the probe instantiation (gsvc_profile_enable(2)) always runs.  Same scene through both — 1080p, footprints from half
+    a pixel to 12 px with free anisotropy, where the shift subtracts moments that grow with the distance to the tile centre —
+    and each is held to the oracle's backward at the parity tolerance.  (Against each other the two differ by up to 2e-4 of
+    the largest gradient on needles of 40 px x 0.6 px, where every float32 form of the exponent cancels terms of 1e4.)"""
+    from gsvc_amd import _lib
+    sc = synthetic.raster_scene(30_000, seed=31, sigma_px=(0.5, 12.0))
+    s = sc["settings"]
+    st = _oracle_settings(oracle_lib, s, bg=bg)
+    ref = oracle_lib.raster_forward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"], num_threads=16)
+    dL = np.random.default_rng(3).standard_normal((3, s["H"], s["W"])).astype(np.float32)
+    dL[:, ref.borderline != 0] = 0
+    rb = oracle_lib.raster_backward(st, sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"], ref, dL,
+                                    num_threads=16)
+    d = {k: v.requires_grad_(True) for k, v in _to_dev(sc).items()}
+    r = _rasterizer(s, bg=bg)
+    for probe in (0, 2):
+        _lib.profile_enable(probe)
+        try:
+            _, m2 = _run_backward(r, d, torch.tensor(dL, device="cuda"))
+        finally:
+            _lib.profile_enable(0)
+        tag = "literal " if probe else "poly "
+        _grad_close(d["colors"].grad.cpu().numpy(), rb.colors, tag + "colors")
+        _grad_close(d["opacities"].grad.cpu().numpy(), rb.opacities, tag + "opacities")
+        _grad_close(d["means3D"].grad.cpu().numpy(), rb.means3D, tag + "means3D")
+        _grad_close(m2.grad.cpu().numpy(), rb.means2D, tag + "means2D")
+        _grad_close(d["scales"].grad.cpu().numpy(), rb.scales, tag + "scales")
+        # needles (70:1 axes) are in this scene: the quaternion gradient's own conditioning in k_gaussian_bwd, equal for both
+        # replays (measured 0.6-1.2e-4 literal, 0.8-0.9e-4 polynomial; the other five: literal 1e-6, polynomial 4-6e-6)
+        _grad_close(d["rotations"].grad.cpu().numpy(), rb.rotations, tag + "rotations", tol=3e-4)
+
+
 def test_forward_parity_4k_large_lds_histogram(oracle_lib):
     """3840x2160 (32 400 tiles): the tile histogram of k_preprocess / k_scatter_lds needs 127 KiB of dynamic LDS, beyond the
     48 KiB a launch gets by default — the launch path no 1080p test reaches.  250 000 Gaussians, full parity."""
