@@ -1051,9 +1051,11 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         anchor_all = pc.get_anchor if anchors is None else anchors
         anchor = anchor_all.index_select(0, vis)
         ranks = plan.ranks if plan is not None else None
-        # TRAINING_ENTROPY gathers (offsets, scaling, masks) behind the generators' forward: see _gather_rows
+        # a fitting step gathers (offsets, scaling, masks) behind the generators' forward, in every phase: see _gather_rows
         # (data parallel too since round 3: the reducer launches its collectives in an order the ranks agree on)
-        late_rows = mode == GenerateMode.TRAINING_ENTROPY and trunks is None and not switches.NO_LATE_ROWS
+        late_rows = (mode in (GenerateMode.TRAINING_ENTROPY, GenerateMode.TRAINING_FULL_PRECISION, GenerateMode.TRAINING_QUANTIZED,
+                              GenerateMode.TRAININ_STE_ENTROPY)
+                     and trunks is None and torch.is_grad_enabled() and not switches.NO_LATE_ROWS)
         if late_rows:
             (feat,) = _gather_rows(pc, vis, ranks, parts="feat")
             grid_offsets = grid_scaling = offset_masks = None
@@ -1087,12 +1089,16 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
                 net = getattr(pc, name)
                 films[name] = net.film_nets(pe) if hasattr(net, "film_nets") else None
 
+    rows_work = None       # the phase's work on (offsets, scaling, masks) rows: behind the generators when they are gathered late
     if mode in (GenerateMode.TRAINING_FULL_PRECISION, GenerateMode.DECODING_AS_IS):
         pass
     elif mode == GenerateMode.TRAINING_QUANTIZED:
         feat = _seg_noise_quant(feat, Q_feat, seg)
-        grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
-        grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets, seg)
+
+        def rows_work():      # the draws keep their order (features, scalings, offsets): nothing in between draws
+            nonlocal grid_offsets, grid_scaling
+            grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
+            grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets, seg)
     elif mode == GenerateMode.TRAINING_ENTROPY:
         # the priors' mean / scale are read at the rate sample's rows only (reference guassian.py:99-113): their networks run on
         # those rows (SampledEntropyContext); GSVC_CTX_ALL_ROWS=1 keeps the all-rows form (A/B timing, the equivalence test)
@@ -1111,31 +1117,40 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
                                                 Q_offsets * rows_of(ec.Q_offsets_adj))
             feat = _seg_noise_quant(feat, Q_feat, seg)
 
-        def rows_quant_and_rate():
+        def rows_work():
             # the same noise draws in the same order (features, scalings, offsets) wherever this runs: nothing between the
             # features' quantisation and this draws from the generator
-            nonlocal grid_offsets, grid_scaling, offset_masks, rates
-            if late_rows:
-                grid_offsets, grid_scaling, offset_masks = _gather_rows(pc, vis, ranks, parts="rows")
+            nonlocal grid_offsets, grid_scaling, rates
             with region('gen.noise_quant'):
                 grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
                 grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets.unsqueeze(1), seg)
             with region('gen.rate'):
                 rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row,
                                    sel=plan.sel if plan is not None else None)
-        if not late_rows:
-            rows_quant_and_rate()
     elif mode == GenerateMode.TRAININ_STE_ENTROPY:
         ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan, sampled=feat.is_cuda and not switches.CTX_ALL_ROWS)
         rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
         Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj).detach(), Q_scaling * rows_of(ec.Q_scaling_adj).detach(),
                                         Q_offsets * rows_of(ec.Q_offsets_adj).detach())
         feat = _seg_ste(feat, Q_feat, seg, pc._anchor_feat.mean())
-        grid_scaling = _seg_ste(grid_scaling, Q_scaling, seg, pc.get_scaling.mean())
-        grid_offsets = _seg_ste(grid_offsets, Q_offsets.unsqueeze(1), seg, pc._offset.mean())
-        rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row)
+
+        def rows_work():
+            nonlocal grid_offsets, grid_scaling, rates
+            grid_scaling = _seg_ste(grid_scaling, Q_scaling, seg, pc.get_scaling.mean())
+            grid_offsets = _seg_ste(grid_offsets, Q_offsets.unsqueeze(1), seg, pc._offset.mean())
+            rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row,
+                               sel=plan.sel if plan is not None else None)
     else:
         raise ValueError(f"Unknown mode {mode}")
+
+    def rows_now():
+        nonlocal grid_offsets, grid_scaling, offset_masks
+        if late_rows:
+            grid_offsets, grid_scaling, offset_masks = _gather_rows(pc, vis, ranks, parts="rows")
+        if rows_work is not None:
+            rows_work()
+    if not late_rows:
+        rows_now()
 
     rows = seg.rows
     with region('gen.mlps'):
@@ -1157,7 +1172,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         if not chain:
             neural_offset = pc.get_deform_mlp(torch.cat([feat, pe], dim=1)).reshape(rows * K, 3)
     if late_rows:
-        rows_quant_and_rate()
+        rows_now()
     if dense:
         # opacity mask, sigmoid scaling, normalised rotation, world position, bound clamp: one kernel (csrc/generate.hip)
         neural_opacity, mask, scaling, rot, world, xyz = _GenTail.apply(

@@ -45,7 +45,7 @@ def plan_views(frames, pc, pipe, bg_color: torch.Tensor, mode=GenerateMode.TRAIN
     from ..generate import StepPlan
     geometry = prefilter_geometry(pc)
     visible = prefilter_voxels_many(frames, pc, pipe, bg_color, geometry=geometry)
-    return StepPlan(frames, pc, visible, geometry, sample=(mode == GenerateMode.TRAINING_ENTROPY))
+    return StepPlan(frames, pc, visible, geometry, sample=mode in (GenerateMode.TRAINING_ENTROPY, GenerateMode.TRAININ_STE_ENTROPY))
 
 
 def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, retain_grad=False,

@@ -193,8 +193,9 @@ class Trainer:
                     pc._mask.grad.add_(reg)
             self._mask_reg_weight = 0.0
 
-    def _early_tail(self, renders):
-        """Called from inside the backward, the moment the gradients of ``_scaling`` and ``_mask`` are complete (the last
+    def _early_tail(self, renders, params):
+        """Called from inside the backward, the moment the gradients of ``params`` — ``_scaling`` and ``_mask``, those of the two
+        that this phase's step gives a gradient — are complete (the last
         contribution is the late row gather's backward: gsvc_amd.generate._gather_rows): these two tensors are all the next
         step's visibility test and rate sample read that this step changes, so they are updated NOW and the next step's plan
         is queued behind them — its counts reach the host ~2 ms before the GPU finishes this step, and the host, which runs
@@ -204,7 +205,6 @@ class Trainer:
         from .train_util import render_mode_at
         pc = self.pc
         with torch.no_grad():
-            params = [pc._scaling, pc._mask]
             guards = [r.raster_state.binning[4:8].view(torch.int32) for r in renders]
             if gdist.world_size() > 1:
                 # data parallel: the two gradients are final once their collectives (launched by the reducer's hooks, which run
@@ -339,20 +339,23 @@ class Trainer:
         if (early and self.batched and self.prefetch and pc._anchor.is_cuda
                 and (gdist.world_size() == 1 or (self.reducer.enabled and self.reducer._order is not None))
                 and not self.anchor_grad      # a trained anchor tensor moves behind the early plan's visibility test
-                and mode == GenerateMode.TRAINING_ENTROPY and iteration < opt.iterations and not self.controller.gaussian_adjust_anchor
+                and mode is not None and iteration < opt.iterations and not self.controller.gaussian_adjust_anchor
                 and isinstance(pc.optimizer, FusedAdam) and not switches.NO_EARLY_PLAN
                 and pc._scaling.requires_grad and pc._mask.requires_grad
                 # it pays when the GPU, not the host, bounds the step (the hook's work costs ~1 ms of host time more on the
                 # autograd thread than at the end of the step: a 6 k-row step went 8.3 -> 9.7 ms, the 200 k-row step 11.95 -> 11.3)
                 and (switches.EARLY_PLAN or sum(int(r.visible_index.shape[0]) for r in
                                                                (x.generated_gaussians for x in renders)) >= EARLY_PLAN_MIN_ROWS)):
-            pending = [2]
+            # STE_ENTROPY renders from detached attributes (reference guassian.py:205-207): _scaling receives no gradient there,
+            # is not changed by the step, and its hook would never run
+            waited = [pc._mask] if mode == GenerateMode.TRAININ_STE_ENTROPY else [pc._scaling, pc._mask]
+            pending = [len(waited)]
 
             def arrived(_p):
                 pending[0] -= 1
                 if pending[0] == 0:
-                    self._early_tail(renders)
-            handles = [pc._scaling.register_post_accumulate_grad_hook(arrived), pc._mask.register_post_accumulate_grad_hook(arrived)]
+                    self._early_tail(renders, waited)
+            handles = [p.register_post_accumulate_grad_hook(arrived) for p in waited]
         try:
             with region('step.backward'):
                 loss.backward()

@@ -297,11 +297,14 @@ def test_step_plan_matches_the_per_view_index_lists(monkeypatch):
     assert 0 < a.sel.numel() < 0.1 * vis.numel() and bool(live[vis[a.sel]].all()) and bool((a.sel[1:] > a.sel[:-1]).all())
 
 
-def test_early_plan_steps_equal_plain_steps(monkeypatch):
-    """TRAINING_ENTROPY steps with the next step's plan queued from inside the backward (late row gather, early guarded Adam of
-    _scaling / _mask: Trainer._early_tail) against the same steps with everything at the end of the step: the same frames, the
-    same random draws, the same parameters after four steps (sums of <= 3 gradient terms may be taken in another order)."""
+@pytest.mark.parametrize("phase", ["entropy", "full", "quantized", "ste"])
+def test_early_plan_steps_equal_plain_steps(monkeypatch, phase):
+    """Steps of every phase of the schedule with the next step's plan queued from inside the backward (late row gather, early
+    guarded Adam of _scaling / _mask — of _mask alone in the STE phase, whose attributes are detached: Trainer._early_tail) against
+    the same steps with everything at the end of the step: the same frames, the same random draws in the same order, the same
+    parameters after four steps (sums of <= 3 gradient terms may be taken in another order)."""
     import gsvc_amd.train as T
+    totals = {"full": (1000, 0, 0, 0), "quantized": (0, 1000, 0, 0), "entropy": (0, 0, 1000, 0), "ste": (0, 0, 0, 1000)}[phase]
     res = []
     for early in (True, False):
         if early:
@@ -313,8 +316,8 @@ def test_early_plan_steps_equal_plain_steps(monkeypatch):
             monkeypatch.setenv("GSVC_NO_EARLY_PLAN", "1")
             monkeypatch.setenv("GSVC_NO_LATE_ROWS", "1")
         pc, cube, opt, pipe, mp, Trainer = _setup(anchors=6000, seed=4)
-        opt.full_precision_training_total = opt.quantized_training_total = 0
-        opt.entropy_constrained_train_total = 1000
+        (opt.full_precision_training_total, opt.quantized_training_total, opt.entropy_constrained_train_total,
+         opt.ste_entropy_constrained_train_total) = totals
         opt.start_stat, opt.update_until, opt.pause_densification = 0, 10 ** 9, 0
         opt.update_from = 10 ** 9                       # no densification in these steps
         pc.training_setup(opt)
@@ -322,7 +325,7 @@ def test_early_plan_steps_equal_plain_steps(monkeypatch):
         tr = Trainer(pc, cube, opt, pipe, mp)
         calls = []
         orig = tr._early_tail
-        tr._early_tail = lambda renders: (calls.append(1), orig(renders))[1]
+        tr._early_tail = lambda renders, params: (calls.append(1), orig(renders, params))[1]
         losses = [float(tr.step(i + 1).loss) for i in range(4)]
         assert len(calls) == (4 if early else 0)
         assert tr._plan is not None
@@ -375,7 +378,7 @@ def test_overflowing_step_with_early_plan_changes_nothing_before_its_repeat(monk
             seen.append({n: p.detach().clone() for n, p in pc.named_parameters()})
         return out
     tr._step = spy
-    tr._early_tail = lambda renders: (early.append(1), tail(renders))[1]
+    tr._early_tail = lambda renders, params: (early.append(1), tail(renders, params))[1]
     out = tr.step(2)
     assert getattr(tr, "repeated_steps", 0) == 1 and len(seen) == 1 and len(early) == 1 and small[0] == 0
     for n, p in seen[0].items():
