@@ -726,6 +726,66 @@ def run_train_step_light(args, dev, anchors, steps, pretrain, warmup=5):
             "repeated_steps": int(getattr(trainer, "repeated_steps", 0))}
 
 
+def run_train_step_phases(args, dev, anchors=245_000, steps=30, pretrain=100, warmup=6):
+    """The fitting step in each phase of the reference's schedule (utils/train_util.py:8-92: FULL_PRECISION 10 k iterations,
+    QUANTIZED 5 k, TRAINING_ENTROPY 20 k, STE_ENTROPY 5 k) on one fresh model of the headline's shape, in schedule order (the
+    controller's entropy flag is sticky, as the reference's).  The headline `value` is the TRAINING_ENTROPY phase."""
+    import numpy as np
+    import torch
+    from gsvc_amd.arguments import cfg_20240919
+    from gsvc_amd.frame import SyntheticFrameCube
+    from gsvc_amd.model import GaussianModel
+    from gsvc_amd.train import Trainer
+    H, W, T = args.height, args.width, args.train_frames
+    mp_, opt, pipe = cfg_20240919()
+    share = {"TRAINING_FULL_PRECISION": opt.full_precision_training_total, "TRAINING_QUANTIZED": opt.quantized_training_total,
+             "TRAINING_ENTROPY": opt.entropy_constrained_train_total, "STE_ENTROPY": opt.ste_entropy_constrained_train_total}
+    cube = SyntheticFrameCube(H, W, T, seed=1234, device=dev).materialize()
+    mp_.threshold = 8.0 / cube.scale
+    opt.start_stat, opt.update_until, opt.pause_densification, opt.update_from = 0, 10 ** 9, 0, 10 ** 9
+    B = 10 ** 9
+    (opt.full_precision_training_total, opt.quantized_training_total, opt.entropy_constrained_train_total,
+     opt.ste_entropy_constrained_train_total) = B, 0, 0, 0
+    torch.manual_seed(0)
+    np.random.seed(0)
+    pc = GaussianModel(mp_, mp_.anchor_feature_dim, mp_.n_offsets, mp_.voxel_size, mp_.update_depth, mp_.update_init_factor,
+                       mp_.update_hierarchy_factor, mp_.use_feat_bank, n_features_per_level=mp_.grid_feature_dim,
+                       log2_hashmap_size=mp_.log2, log2_hashmap_size_2D=mp_.log2_2D, device=dev)
+    rng = np.random.default_rng(0)
+    lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
+    pc.create_from_points(rng.uniform(lim, -lim, (anchors, 3)), spatial_lr_scale=1.0)
+    pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+    pc.training_setup(opt)
+    trainer = Trainer(pc, cube, opt, pipe, mp_, seed=0)
+    it = 0
+    for _ in range(pretrain):
+        it += 1
+        trainer.step(it)
+    out = {}
+    for name, totals in (("TRAINING_FULL_PRECISION", (B, 0, 0, 0)), ("TRAINING_QUANTIZED", (0, B, 0, 0)),
+                         ("TRAINING_ENTROPY", (0, 0, B, 0)), ("STE_ENTROPY", (0, 0, 0, B))):
+        (opt.full_precision_training_total, opt.quantized_training_total, opt.entropy_constrained_train_total,
+         opt.ste_entropy_constrained_train_total) = totals
+        for _ in range(warmup):
+            it += 1
+            trainer.step(it)
+        active = torch.zeros((), device=dev, dtype=torch.float64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            it += 1
+            active += trainer.step(it).active_gaussians
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out[name] = {"ms_per_step": 1e3 * el / steps, "gaussians_per_s": float(active.item()) / el,
+                     "iterations_in_the_reference_schedule": share[name]}
+    total = sum(share.values())
+    out["schedule_weighted_ms_per_step"] = sum(out[n]["ms_per_step"] * share[n] for n in share) / total
+    out["note"] = (f"{anchors} anchors, {H}x{W}, {T} frames, 16-frame slab; {pretrain} untimed full-precision steps, then per phase {warmup} warm-up + "
+                   f"{steps} timed steps; early plan and late row gather in every phase")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ raster
 def cpu_baseline_raster(sc, workload):
     """Oracle (CPU port of the same algorithm) on the host cores of this box, same scene, bounded sample."""
@@ -986,6 +1046,13 @@ def main():
                     res["train_step_500k_active"] = run_train_step_light(args, dev, anchors=870_000, steps=10, pretrain=40)
                 except Exception as e:  # noqa: BLE001
                     res["train_step_500k_active"] = {"error": f"{type(e).__name__}: {e}"}
+            # the other phases of the schedule (the headline is the TRAINING_ENTROPY phase: 20 k of the 40 k iterations)
+            if rank == 0 and not os.environ.get("GSVC_BENCH_NO_PHASES"):
+                try:
+                    torch.cuda.empty_cache()
+                    res["train_step_by_phase"] = run_train_step_phases(args, dev, anchors=args.anchors)
+                except Exception as e:  # noqa: BLE001
+                    res["train_step_by_phase"] = {"error": f"{type(e).__name__}: {e}"}
             # stream_decode fps at the BASELINE.json configs[4] shape (4K, ~2 M Gaussians per frame); same rule for failures
             if rank == 0 and not os.environ.get("GSVC_BENCH_NO_4K"):
                 try:

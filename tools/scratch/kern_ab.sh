@@ -8,7 +8,7 @@ for v in "$@"; do
   OUT=$REPO/gpurun_out/kab_$v; mkdir -p $OUT
   for wl in cfg2 step; do
     if [ $wl = cfg2 ]; then ARGS="--workload raster_fwdbwd --no-cpu-baseline"; else ARGS="--workload train_step --steps 10 --warmup 2 --pretrain 30 --no-cpu-baseline"; fi
-    (cd /tmp && GSVC_BENCH_NO_500K=1 GSVC_BENCH_NO_4K=1 GSVC_RASTER_STREAMS=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python3 $REPO/bench.py $ARGS > $OUT/run_$wl.log 2>&1)
+    (cd /tmp && GSVC_BENCH_NO_500K=1 GSVC_BENCH_NO_4K=1 GSVC_BENCH_NO_PHASES=1 GSVC_RASTER_STREAMS=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python3 $REPO/bench.py $ARGS > $OUT/run_$wl.log 2>&1)
     f=$(find $OUT/raw -name "*kernel_stats.csv" | head -1)
     echo "variant=$v $wl:"; python3 -c "
 import csv,re
