@@ -782,7 +782,7 @@ def run_train_step_phases(args, dev, anchors=245_000, steps=30, pretrain=100, wa
     total = sum(share.values())
     out["schedule_weighted_ms_per_step"] = sum(out[n]["ms_per_step"] * share[n] for n in share) / total
     out["note"] = (f"{anchors} anchors, {H}x{W}, {T} frames, 16-frame slab; {pretrain} untimed full-precision steps, then per phase {warmup} warm-up + "
-                   f"{steps} timed steps; early plan and late row gather in every phase")
+                   f"{steps} timed steps; early plan and late row gather in every phase, generation once per (frame, anchor) in the two phases without per-render noise")
     return out
 
 

@@ -156,6 +156,7 @@ _SIGNATURES = {
     "gsvc_plan_scans_scratch_bytes": (_i64, [C.c_int32, _i64]),
     "gsvc_plan_scans": (C.c_int, [_vp, _vp, _vp, C.c_int32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_film_row_maps": (C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gsvc_pair_rows_sum": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, _vp, _vp]),
     "gsvc_ste_binary_count_many": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, _vp]),
     "gsvc_ste_binary_backward_many": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, C.c_int32, _vp, _vp]),
     "gsvc_table_bits": (C.c_int, [_vp, C.c_int32, _i64, _vp, _vp]),

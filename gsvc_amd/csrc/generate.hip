@@ -820,6 +820,33 @@ extern "C" int gsvc_film_backward(const float *g, const float *h, const float *g
     return gsvc::check_launch("film_backward");
 }
 
+namespace gsvc {
+// out[j][c] = g[src_a[j]][c] + g[src_b[j]][c] (a source of -1: zeros); one lane per output element, consecutive lanes along c
+__global__ void __launch_bounds__(256) k_pair_rows_sum(const float *__restrict__ g, const int32_t *__restrict__ src_a,
+                                                       const int32_t *__restrict__ src_b, long long n, int C, float *__restrict__ out)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const long long j = e / C;
+    const int c = (int)(e - j * C);
+    const int a = src_a[j], b = src_b[j];
+    const float va = a >= 0 ? g[(long long)a * C + c] : 0.f;
+    const float vb = b >= 0 ? g[(long long)b * C + c] : 0.f;
+    out[e] = va + vb;
+}
+}  // namespace gsvc
+
+extern "C" int gsvc_pair_rows_sum(const float *g, const int32_t *src_a, const int32_t *src_b, int64_t rows_u, int32_t C, float *out, void *stream)
+{
+    GSVC_REQUIRE(rows_u >= 0 && C > 0 && rows_u * (int64_t)C < ((int64_t)1 << 40), "pair_rows_sum: bad shape");
+    if (rows_u == 0) return GSVC_OK;
+    GSVC_REQUIRE(g && src_a && src_b && out, "pair_rows_sum: NULL pointer");
+    const long long n = rows_u * (long long)C;
+    gsvc::ProfScope _prof("k_pair_rows_sum", (hipStream_t)stream);
+    hipLaunchKernelGGL(gsvc::k_pair_rows_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, src_a, src_b, n, (int)C, out);
+    return gsvc::check_launch("pair_rows_sum");
+}
+
 extern "C" int gsvc_film_row_maps(const int64_t *vis, const int64_t *row_bounds_host, int32_t R, const int64_t *pos, int64_t D, int64_t A,
                               const uint8_t *view_masks, const int64_t *scan, const int64_t *distinct, int32_t *row_of, int32_t *src_a,
                               int32_t *src_b, void *stream)

@@ -969,6 +969,30 @@ def _embed_rows(pc, frames, anchor, seg):
     return torch.cat([pc.embed_time_fn(cam_z_row), pc.embed_fn(ob_view)], dim=1)
 
 
+class _ViewRows(torch.autograd.Function):
+    """Rows of (frame, distinct anchor) -> rows of (view, visible anchor): what the generators computed once per frame, handed to
+    the frame's two opposite views.  ``row_of[r]`` = frame row of view row r; ``src_a[j]`` / ``src_b[j]`` = the view rows behind
+    frame row j (-1: that view does not see the anchor) — the maps of _film_rows.  The backward adds the two views' gradients
+    (a gather per frame row, no atomics: csrc/generate.hip gsvc_pair_rows_sum)."""
+
+    @staticmethod
+    def forward(ctx, t, row_of, src_a, src_b):
+        ctx.save_for_backward(src_a, src_b)
+        ctx.rows_u = t.shape[0]
+        return t.index_select(0, row_of)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        src_a, src_b = ctx.saved_tensors
+        g = g.contiguous()
+        C = g[0].numel() if g.shape[0] else 1
+        out = torch.empty((ctx.rows_u,) + tuple(g.shape[1:]), device=g.device, dtype=torch.float32)
+        _lib.check(_lib.lib().gsvc_pair_rows_sum(_lib.ptr(g), _lib.ptr(src_a), _lib.ptr(src_b), ctx.rows_u, C, _lib.ptr(out),
+                                                 _lib.current_stream(g.device)), "gsvc_pair_rows_sum")
+        return out, None, None, None
+
+
 def _film_rows(pc, frames, plan, vis, seg, anchor_all):
     """Rows of the generators' FiLM networks when the step's views come in opposite pairs (frame f seen from both sides: same
     camera z, so the same condition for the same anchor — reference frame_cube/frame.py:18-43, guassian.py:225-230): one row per
@@ -1056,7 +1080,36 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         late_rows = (mode in (GenerateMode.TRAINING_ENTROPY, GenerateMode.TRAINING_FULL_PRECISION, GenerateMode.TRAINING_QUANTIZED,
                               GenerateMode.TRAININ_STE_ENTROPY)
                      and trunks is None and torch.is_grad_enabled() and not switches.NO_LATE_ROWS)
-        if late_rows:
+        # FULL_PRECISION / STE_ENTROPY draw nothing per render, and the two opposite views of a frame share the camera position:
+        # their generators see the same row for the same anchor (reference guassian.py:225-273 evaluates them once per view, with
+        # equal results).  The features, the conditioning and the four networks then run once per (frame, distinct visible anchor)
+        # — the rows the FiLM networks already use (_film_rows: the two sides of a frame see all but ~0.2 % of the same anchors,
+        # adjacent frames ~94 %) —; _ViewRows hands the outputs to the views' rows and adds the two views' gradients.
+        share = None
+        if (late_rows and mode in (GenerateMode.TRAINING_FULL_PRECISION, GenerateMode.TRAININ_STE_ENTROPY) and vis.is_cuda
+                and plan is not None and plan.distinct is not None and plan.distinct.shape[0] != vis.shape[0] and not switches.NO_VIEW_SHARE):
+            share = _film_rows(pc, frames, plan, vis, seg, anchor_all)
+    from . import mlp as _mlp
+    gens = [getattr(pc, n) for n in ("get_opacity_mlp", "get_color_mlp", "get_cov_mlp")]
+    deform_mods = list(pc.get_deform_mlp) if isinstance(pc.get_deform_mlp, torch.nn.Sequential) else []
+    deform_linears = deform_mods[0::2]
+    seg_u = feat_u = pe_u = None
+    if share is not None:
+        pe_u, row_of, src_a, src_b = share
+        row_of = row_of.long()
+        F_, D_ = R // 2, int(plan.distinct.shape[0])
+        with region('gen.gather'):
+            (feat_u,) = _gather_rows(pc, plan.distinct.repeat(F_), None, parts="feat")
+        if (all(hasattr(g, "film") and hasattr(g, "out_linear") for g in gens)
+                and all(isinstance(m, torch.nn.Linear) for m in deform_linears) and all(isinstance(m, torch.nn.GELU) for m in deform_mods[1::2])
+                and _mlp.chain_usable(feat_u, pe_u, gens, deform_linears)):
+            seg_u = _Segments([D_] * F_, dev)
+        else:
+            share = feat_u = pe_u = None          # not the production widths: per view, layer by layer
+    with region('gen.gather'):
+        if seg_u is not None:
+            feat = grid_offsets = grid_scaling = offset_masks = None
+        elif late_rows:
             (feat,) = _gather_rows(pc, vis, ranks, parts="feat")
             grid_offsets = grid_scaling = offset_masks = None
         else:
@@ -1067,20 +1120,16 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
     # the conditioning input and the generators' FiLM networks depend on the anchors' z only: issued FIRST, their twelve large
     # GEMMs keep the GPU busy while the host queues the entropy context's many small launches (a step starts host-bound)
     with region('gen.embed'):
-        pe = _embed_rows(pc, frames, anchor, seg)
+        pe = _embed_rows(pc, frames, anchor, seg) if seg_u is None else None
     films = {}
     # the three generators + mlp_deform as whole-network chain kernels (gsvc_amd.mlp.generate_all) when the widths are the
     # production ones: then nothing is issued ahead (8 forward launches in all)
-    from . import mlp as _mlp
-    gens = [getattr(pc, n) for n in ("get_opacity_mlp", "get_color_mlp", "get_cov_mlp")]
-    deform_mods = list(pc.get_deform_mlp) if isinstance(pc.get_deform_mlp, torch.nn.Sequential) else []
-    deform_linears = deform_mods[0::2]
     # (decoding hands in the cached feature-only half of the generators: with the production widths the forward-only chain kernels,
     # which read the features once and keep a row block in registers through all layers, are faster per frame and are preferred)
     chain = ((trunks is None or (not torch.is_grad_enabled() and not switches.NO_DECODE_CHAIN))
              and all(hasattr(g, "film") and hasattr(g, "out_linear") for g in gens)
              and all(isinstance(m, torch.nn.Linear) for m in deform_linears) and all(isinstance(m, torch.nn.GELU) for m in deform_mods[1::2])
-             and _mlp.chain_usable(feat, pe, gens, deform_linears))
+             and (seg_u is not None or _mlp.chain_usable(feat, pe, gens, deform_linears)))
     if chain:
         trunks = None
     if trunks is None and not chain:
@@ -1128,11 +1177,18 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
                 rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row,
                                    sel=plan.sel if plan is not None else None)
     elif mode == GenerateMode.TRAININ_STE_ENTROPY:
-        ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan, sampled=feat.is_cuda and not switches.CTX_ALL_ROWS)
+        ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan, sampled=vis.is_cuda and not switches.CTX_ALL_ROWS)
         rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
         Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj).detach(), Q_scaling * rows_of(ec.Q_scaling_adj).detach(),
                                         Q_offsets * rows_of(ec.Q_offsets_adj).detach())
-        feat = _seg_ste(feat, Q_feat, seg, pc._anchor_feat.mean())
+        if seg_u is None:
+            feat = _seg_ste(feat, Q_feat, seg, pc._anchor_feat.mean())
+        else:
+            # the step of (frame, anchor) is the anchor's; the clamp's integer bounds (mean / mean step -+ 15000, truncated) come from
+            # the frame's rows instead of each view's (they differ by an anchor in 500): the same integers unless the centre sits
+            # within 1e-3 of an integer, and the clamp only acts 15000 steps from the mean
+            feat_u = _seg_ste(feat_u, (BASE_Q_FEAT * ec.Q_feat_adj.detach()).repeat(R // 2, 1), seg_u, pc._anchor_feat.mean())
+            feat = feat_u.index_select(0, row_of)      # (detached: the rate reads it per view row)
 
         def rows_work():
             nonlocal grid_offsets, grid_scaling, rates
@@ -1161,7 +1217,11 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
             color = pc.get_color_mlp.head(trunks["get_color_mlp"].index_select(0, vis), pe).reshape(rows * K, 3)
             scale_rot = pc.get_cov_mlp.head(trunks["get_cov_mlp"].index_select(0, vis), pe).reshape(rows * K, 7)
         elif chain:
-            op_raw, color, scale_rot, neural_offset = _mlp.generate_all(gens, deform_linears, feat, pe, film=_film_rows(pc, frames, plan, vis, seg, anchor_all))
+            if seg_u is not None:
+                op_raw, color, scale_rot, neural_offset = (_ViewRows.apply(o, row_of, src_a, src_b)
+                                                           for o in _mlp.generate_all(gens, deform_linears, feat_u, pe_u, film=None))
+            else:
+                op_raw, color, scale_rot, neural_offset = _mlp.generate_all(gens, deform_linears, feat, pe, film=_film_rows(pc, frames, plan, vis, seg, anchor_all))
             color, scale_rot, neural_offset = color.reshape(rows * K, 3), scale_rot.reshape(rows * K, 7), neural_offset.reshape(rows * K, 3)
         else:
             gen = lambda name: (getattr(pc, name)(feat, pe, film=films[name]) if films.get(name) is not None  # noqa: E731

@@ -531,6 +531,12 @@ int gsvc_film_row_maps(const int64_t *vis, const int64_t *row_bounds_host, int32
                    const uint8_t *view_masks, const int64_t *scan, const int64_t *distinct, int32_t *row_of, int32_t *src_a,
                    int32_t *src_b, void *stream);
 
+/* out [rows_u, C] = g[src_a[j], :] + g[src_b[j], :] per row j, a source of -1 counting as zeros: the gradient of the generators'
+ * outputs computed once per (frame, anchor) from the gradients of the frame's two opposite views (FULL_PRECISION / STE_ENTROPY
+ * steps: both views see the same Gaussians, reference gaussian_renderer/guassian.py:225-273 evaluates the networks per view);
+ * src_a / src_b as gsvc_film_row_maps writes them.  A gather per output row: no atomics, a fixed order of the two terms. */
+int gsvc_pair_rows_sum(const float *g, const int32_t *src_a, const int32_t *src_b, int64_t rows_u, int32_t C, float *out, void *stream);
+
 /* out[scan[i] - 1] = (value ? value[i] + value_bias : i) for every i with mask[i] != 0, `scan` = inclusive scan of the mask
  * (int64): the index lists of the step plan in one elementwise pass each; entries of `out` past the count are not written. */
 int gsvc_compact_by_scan(const uint8_t *mask, const int64_t *scan, const int64_t *value, int64_t value_bias, int64_t n, int64_t *out,

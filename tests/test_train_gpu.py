@@ -837,3 +837,76 @@ def test_evaluate_and_checkpoint_round_trip(tmp_path):
     opt2.full_precision_training_total = 1000
     out = Trainer(pc2, cube2, opt2, pipe2, mp2).step(9)
     assert np.isfinite(float(out.loss))
+
+
+@pytest.mark.parametrize("phase", ["full", "ste"])
+def test_generation_once_per_frame_equals_generation_per_view(monkeypatch, phase):
+    """FULL_PRECISION and STE_ENTROPY draw nothing per render and the two opposite views of a frame share the camera position, so
+    their generators see the same rows (reference guassian.py:225-273 evaluates them per view, with equal results): the batched
+    step runs features, conditioning and the four networks once per (frame, distinct visible anchor) and hands the rows to the two
+    views (gsvc_amd/generate.py _ViewRows; the two sides see all but ~0.2 % of the same anchors).  Against GSVC_NO_VIEW_SHARE=1
+    (per view): same loss, image, statistics and gradients at BASELINE.json configs[2] size — the two views' gradients are added
+    at another point of the graph."""
+    from gsvc_amd.arguments import cfg_20240919
+    from gsvc_amd.frame import SyntheticFrameCube
+    from gsvc_amd.model import GaussianModel
+    from gsvc_amd.train import Trainer
+    import gsvc_amd.generate as G
+    res = []
+    for share in (True, False):
+        if share:
+            monkeypatch.delenv("GSVC_NO_VIEW_SHARE", raising=False)
+        else:
+            monkeypatch.setenv("GSVC_NO_VIEW_SHARE", "1")
+        mp_, opt, pipe = cfg_20240919()
+        cube = SyntheticFrameCube(1080, 1920, 64, seed=1234, device="cuda").materialize()
+        mp_.threshold = 8.0 / cube.scale
+        opt.full_precision_training_total = opt.quantized_training_total = opt.entropy_constrained_train_total = 0
+        opt.ste_entropy_constrained_train_total = 0
+        if phase == "full":
+            opt.full_precision_training_total = 100
+        else:
+            opt.ste_entropy_constrained_train_total = 100
+        opt.start_stat, opt.pause_densification, opt.iterations = 0, 0, 10
+        torch.manual_seed(0)
+        np.random.seed(0)
+        pc = GaussianModel(mp_, mp_.anchor_feature_dim, mp_.n_offsets, mp_.voxel_size, mp_.update_depth, mp_.update_init_factor,
+                           mp_.update_hierarchy_factor, mp_.use_feat_bank, n_features_per_level=mp_.grid_feature_dim,
+                           log2_hashmap_size=mp_.log2, log2_hashmap_size_2D=mp_.log2_2D, device="cuda")
+        rng = np.random.default_rng(0)
+        lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
+        pc.create_from_points(rng.uniform(lim, -lim, (245_000, 3)), spatial_lr_scale=1.0)
+        pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+        pc.training_setup(opt)
+        from gsvc_amd import _lib
+        torch.manual_seed(5)
+        tr = Trainer(pc, cube, opt, pipe, mp_)
+        tr.step(1, frame_idx=30)                              # (no plan yet: per view either way; it queues the plan of step 2)
+        _lib.profile_enable(True)
+        try:
+            out = tr.step(2)
+            prof = _lib.profile_collect()
+        finally:
+            _lib.profile_enable(False)
+        grads = {n: p.grad.clone() for n, p in pc.named_parameters() if p.grad is not None}
+        # shared: the four networks' output gradients were formed per (frame, anchor) row from the two views' (one launch each)
+        assert prof.get("k_pair_rows_sum", (0, 0.0))[0] == (4 if share else 0), prof.get("k_pair_rows_sum")
+        assert prof["k_trunk_fwd"][0] == 1
+        trunk_ms = prof["k_trunk_fwd"][1]
+        out2 = tr.step(3)
+        res.append((float(out.loss), grads, out.image1.clone(), [r.num_rendered for r in out.renders], pc.offset_gradient_accum.clone(),
+                    pc.opacity_accum.clone(), float(out2.loss), trunk_ms))
+        del pc, cube, out, out2, tr
+        torch.cuda.empty_cache()
+    (la, ga, ia, na, ofa, oa, l2a, ta), (lb, gb, ib, nb, ofb, ob, l2b, tb) = res
+    assert ta < 0.7 * tb, (ta, tb)              # the generators' trunk kernel ran on about half the rows
+    assert abs(la - lb) < 1e-5 * max(1.0, abs(lb)) and abs(l2a - l2b) < 1e-4 * max(1.0, abs(l2b)), (la, lb, l2a, l2b)
+    assert all(abs(a - b) <= 2e-5 * b for a, b in zip(na, nb)), (na, nb)
+    diff = (ia - ib).abs()
+    assert diff.max().item() < 5e-3 and (diff > 5e-5).float().mean().item() < 1e-4
+    assert torch.allclose(oa, ob, rtol=1e-5, atol=1e-6)
+    assert (ofa - ofb).abs().max().item() <= 2e-3 * ofb.abs().max().item()
+    assert set(ga) == set(gb)
+    for n in ga:
+        scale = gb[n].abs().max().item()
+        assert (ga[n] - gb[n]).abs().max().item() <= 1e-3 * scale + 1e-12, (n, (ga[n] - gb[n]).abs().max().item(), scale)
