@@ -784,6 +784,28 @@ def test_two_rank_step_averages_gradients_over_rccl():
 
 
 @pytest.mark.gpu
+def test_two_ranks_through_every_phase_at_the_headline_shape():
+    """Two data-parallel ranks (gloo, both on device 0) through FULL_PRECISION, QUANTIZED, TRAINING_ENTROPY and STE_ENTROPY steps at
+    BASELINE.json configs[2] size, where the plan of the next step is queued from inside the backward in every phase and the
+    generation runs once per frame in the two phases without noise: no rank waits for a collective another rank never launches,
+    every loss is finite and the replicas' parameters stay identical (tests/_dp_phases_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29400 + os.getpid() % 150
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_dp_phases_worker.py")]
+    out = subprocess.run(cmd, cwd=root, env=dict(os.environ, GSVC_DIST_BACKEND="gloo", GSVC_SHARE_GPU="1"), capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "DP_PHASES_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DP_PHASE ")]
+    assert len(lines) == 4 and all("replicas_identical True" in l for l in lines), lines
+    # the early plan ran in the phases whose step gives _scaling and _mask a gradient (STE waits for the sparse exchange's other rows)
+    assert all("early_steps 0" not in l for l in lines[:3]), lines
+
+
+@pytest.mark.gpu
 def test_two_ranks_keep_identical_anchors_through_densification():
     """Data-parallel densification: statistics summed over ranks + a per-iteration seed for the random thinning keep the
     replicas' anchor sets, parameters and Adam moments identical across adjust_anchor (tests/_dp_densify_worker.py)."""
