@@ -82,6 +82,11 @@ class GridIOC(C.Structure):
     _fields_ = [("feat_level_stride", C.c_int64), ("feat_point_stride", C.c_int64), ("in_stride", C.c_int32), ("in_col", C.c_int32 * 3)]
 
 
+class GridManyJobC(C.Structure):
+    _fields_ = [("embeddings", C.c_void_p), ("features", C.c_void_p), ("grad_embeddings", C.c_void_p), ("offsets", C.c_void_p),
+                ("resolutions", C.c_void_p), ("D", C.c_uint32), ("L", C.c_uint32), ("layout", GridIOC)]
+
+
 class GeneratorNetC(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3", "Wg0", "bg0", "Wg1", "bg1", "Wb0", "bb0", "Wb1", "bb1")] + \
                [(n, C.c_int32) for n in ("feat_dim", "cond_dim", "hidden_dim", "out_dim", "out_act")]
@@ -136,6 +141,8 @@ _SIGNATURES = {
     "gsvc_grid_forward_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, C.POINTER(GridIOC), _vp]),
     "gsvc_grid_forward_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, C.POINTER(GridIOC), _vp]),
     "gsvc_grid_backward_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, C.POINTER(GridIOC), _vp]),
+    "gsvc_grid_forward_many": (C.c_int, [_vp, C.POINTER(GridManyJobC), C.c_int32, _u32, _u32, _vp]),
+    "gsvc_grid_backward_many": (C.c_int, [_vp, C.POINTER(GridManyJobC), C.c_int32, _u32, _u32, _vp]),
     "gsvc_rate_forward": (C.c_int, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_int32, _i64, _i64, _vp, _vp, _vp]),
     "gsvc_ssim_l1_forward": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_ssim_l1_backward": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),

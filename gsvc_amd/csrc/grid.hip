@@ -148,14 +148,11 @@ __device__ __forceinline__ void load_row_bits(const uint8_t *__restrict__ p, uin
 }
 
 template <uint32_t D, uint32_t C, bool PACKED = false>
-__global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inputs, const float *__restrict__ grid,
-                                                  const int32_t *__restrict__ offsets,
-                                                  const int32_t *__restrict__ resolutions, float *__restrict__ outputs,
-                                                  uint32_t N, uint32_t L, float *__restrict__ dy_dx, GridIO io)
+__device__ __forceinline__ void grid_fwd_point(const float *__restrict__ inputs, const float *__restrict__ grid,
+                                               const int32_t *__restrict__ offsets, const int32_t *__restrict__ resolutions,
+                                               float *__restrict__ outputs, uint32_t L, float *__restrict__ dy_dx, const GridIO &io,
+                                               uint32_t b, uint32_t level)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= N) return;
-    const uint32_t level = blockIdx.y;
     const uint8_t *bits = reinterpret_cast<const uint8_t *>(grid) + (uint32_t)offsets[level];      // PACKED: one byte per row
     grid += (size_t)(uint32_t)offsets[level] * C;
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
@@ -230,6 +227,53 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inpu
     }
 }
 
+template <uint32_t D, uint32_t C, bool PACKED = false>
+__global__ void __launch_bounds__(256) k_grid_fwd(const float *__restrict__ inputs, const float *__restrict__ grid,
+                                                  const int32_t *__restrict__ offsets,
+                                                  const int32_t *__restrict__ resolutions, float *__restrict__ outputs,
+                                                  uint32_t N, uint32_t L, float *__restrict__ dy_dx, GridIO io)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    grid_fwd_point<D, C, PACKED>(inputs, grid, offsets, resolutions, outputs, L, dy_dx, io, b, blockIdx.y);
+}
+
+// Several grids over the same points in ONE launch (Mix3d2dEncoding: one 3-D and three 2-D grids, reference
+// scene/gaussian_model.py:81-147): blockIdx.y runs over the grids' levels one grid after the other.
+constexpr int GRID_MANY = 4;
+struct GridManyJob {
+    const float *table;             // forward: embeddings; backward: unused
+    const float *grad;              // backward: the gradient's column block
+    const int32_t *offsets, *resolutions;
+    float *out;                     // forward: outputs' column block; backward: the table's gradient
+    uint32_t D, L, first, chunks, chunk;      // first: the grid's first level in blockIdx.y; chunks x chunk points (backward)
+    GridIO io;
+};
+struct GridManyJobs {
+    int n;
+    GridManyJob j[GRID_MANY];
+};
+__device__ __forceinline__ int grid_many_pick(const GridManyJobs &t, uint32_t y)
+{
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < GRID_MANY; q++)
+        if (q < t.n && y >= t.j[q].first) k = q;
+    return k;
+}
+
+template <uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_fwd_many(const float *__restrict__ inputs, GridManyJobs t, uint32_t N)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    const int k = grid_many_pick(t, blockIdx.y);
+    const GridManyJob &g = t.j[k];
+    const uint32_t level = blockIdx.y - g.first;
+    if (g.D == 3) grid_fwd_point<3, C>(inputs, g.table, g.offsets, g.resolutions, g.out, g.L, nullptr, g.io, b, level);
+    else grid_fwd_point<2, C>(inputs, g.table, g.offsets, g.resolutions, g.out, g.L, nullptr, g.io, b, level);
+}
+
 // Table backward with the level's table privatised in LDS.  GSVC's tables are small (2^13 rows per 3-D level, 2^15
 // per 2-D level in cfg_20240919) and every visible anchor adds into 2^D rows of every level: with global atomics
 // that is N*L*2^D scattered memory-side requests (~17 G requests/s on MI355X: 1.0 ms for 181k points x 12 levels;
@@ -257,12 +301,13 @@ __device__ float g_grid_absmax[ABSMAX_RING][ABSMAX_BLOCKS];
 
 // largest |grad| of each level: gridDim = (blocks per level, L), block maxima to g_grid_absmax[slot][level * bpl + block]
 template <uint32_t C>
-__global__ void __launch_bounds__(256) k_grid_absmax(const float *__restrict__ grad, uint32_t N, GridIO io, uint32_t slot)
+__device__ __forceinline__ void grid_absmax_body(const float *__restrict__ grad, uint32_t N, const GridIO &io, uint32_t slot, uint32_t level,
+                                                 uint32_t slot_level)
 {
     __shared__ float red[4];
     float m = 0.f;
     bool bad = false;
-    const float *gl = grad + (size_t)blockIdx.y * io.feat_level_stride;
+    const float *gl = grad + (size_t)level * io.feat_level_stride;
     for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < N; b += gridDim.x * 256) {
         float g[C];
         load_row<C>(gl + (size_t)b * io.feat_point_stride, g);
@@ -278,7 +323,20 @@ __global__ void __launch_bounds__(256) k_grid_absmax(const float *__restrict__ g
     for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) g_grid_absmax[slot][blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) g_grid_absmax[slot][slot_level * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+template <uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_absmax(const float *__restrict__ grad, uint32_t N, GridIO io, uint32_t slot)
+{
+    grid_absmax_body<C>(grad, N, io, slot, blockIdx.y, blockIdx.y);
+}
+
+template <uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_absmax_many(GridManyJobs t, uint32_t N, uint32_t slot)
+{
+    const GridManyJob &g = t.j[grid_many_pick(t, blockIdx.y)];
+    grid_absmax_body<C>(g.grad, N, g.io, slot, blockIdx.y - g.first, blockIdx.y);
 }
 
 // x = value * 2^e, |x| < 2^51 -> nearest 64-bit integer: adding 1.5 * 2^52 in double leaves the integer in the low mantissa
@@ -372,24 +430,24 @@ __device__ __forceinline__ void bwd_accumulate(const BwdPoint<D> &pt, uint32_t m
 // that flush, not the accumulation, was the kernel's time.  A workgroup walks its chunk 1024 points at a time; the loop is
 // software-pipelined over two points per thread (A / B): the positions of the next point and the gradient row of the
 // current one are in flight while the previous point's corners are added.
+// level: the level inside its grid; slot_level: its row of the absmax slot (= level, or the launch's running level when several
+// grids share a launch); chunk_idx / slice: the workgroup's chunk of points and table slice
 template <uint32_t D, uint32_t C>
-__global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__restrict__ grad, const float *__restrict__ inputs,
-                                                              const int32_t *__restrict__ offsets,
-                                                              const int32_t *__restrict__ resolutions,
-                                                              float *__restrict__ grad_grid, uint32_t N, uint32_t chunk, GridIO io,
-                                                              uint32_t slot, uint32_t absmax_bpl)
+__device__ __forceinline__ void grid_bwd_lds_body(const float *__restrict__ grad, const float *__restrict__ inputs,
+                                                  const int32_t *__restrict__ offsets, const int32_t *__restrict__ resolutions,
+                                                  float *__restrict__ grad_grid, uint32_t N, uint32_t chunk, const GridIO &io,
+                                                  uint32_t slot, uint32_t absmax_bpl, uint32_t chunk_idx, uint32_t level,
+                                                  uint32_t slot_level, long long *acc, float *s_max)
 {
-    extern __shared__ long long acc[];
-    __shared__ float s_max[BWD_THREADS / 64];
     constexpr uint32_t CP = C > 1 ? C + 1 : 1;
     constexpr uint32_t SLICE_ROWS = BWD_SLICE_BYTES / (8 * CP);
-    const uint32_t level = blockIdx.y, slice = blockIdx.z, tid = threadIdx.x;
+    const uint32_t slice = blockIdx.z, tid = threadIdx.x;
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
     const uint32_t resolution = (uint32_t)resolutions[level];
     const uint32_t slices = (hashmap_size + SLICE_ROWS - 1) / SLICE_ROWS;
-    const uint32_t p0 = blockIdx.x * chunk, p1 = min(N, p0 + chunk);
+    const uint32_t p0 = chunk_idx * chunk, p1 = min(N, p0 + chunk);
     // largest |grad| of this level (block maxima of k_grid_absmax)
-    float gmax = tid < absmax_bpl ? g_grid_absmax[slot][level * absmax_bpl + tid] : 0.f;
+    float gmax = tid < absmax_bpl ? g_grid_absmax[slot][slot_level * absmax_bpl + tid] : 0.f;
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, k, 64));
     if ((tid & 63) == 0) s_max[tid >> 6] = gmax;
@@ -479,6 +537,36 @@ __global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__res
     }
 }
 
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds(const float *__restrict__ grad, const float *__restrict__ inputs,
+                                                              const int32_t *__restrict__ offsets,
+                                                              const int32_t *__restrict__ resolutions,
+                                                              float *__restrict__ grad_grid, uint32_t N, uint32_t chunk, GridIO io,
+                                                              uint32_t slot, uint32_t absmax_bpl)
+{
+    extern __shared__ long long acc[];
+    __shared__ float s_max[BWD_THREADS / 64];
+    grid_bwd_lds_body<D, C>(grad, inputs, offsets, resolutions, grad_grid, N, chunk, io, slot, absmax_bpl, blockIdx.x, blockIdx.y,
+                            blockIdx.y, acc, s_max);
+}
+
+template <uint32_t C>
+__global__ void __launch_bounds__(BWD_THREADS) k_grid_bwd_lds_many(const float *__restrict__ inputs, GridManyJobs t, uint32_t N,
+                                                                   uint32_t slot, uint32_t absmax_bpl)
+{
+    extern __shared__ long long acc[];
+    __shared__ float s_max[BWD_THREADS / 64];
+    const GridManyJob &g = t.j[grid_many_pick(t, blockIdx.y)];
+    if (blockIdx.x >= g.chunks) return;                  // (workgroup-uniform) the grids differ in their number of chunks
+    const uint32_t level = blockIdx.y - g.first;
+    if (g.D == 3)
+        grid_bwd_lds_body<3, C>(g.grad, inputs, g.offsets, g.resolutions, g.out, N, g.chunk, g.io, slot, absmax_bpl, blockIdx.x, level,
+                                blockIdx.y, acc, s_max);
+    else
+        grid_bwd_lds_body<2, C>(g.grad, inputs, g.offsets, g.resolutions, g.out, N, g.chunk, g.io, slot, absmax_bpl, blockIdx.x, level,
+                                blockIdx.y, acc, s_max);
+}
+
 // grad_inputs[b,d] = sum_l sum_c grad[l,b,c] * dy_dx[b,l,d,c]
 template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(256) k_grid_input_bwd(const float *__restrict__ grad, const float *__restrict__ dy_dx,
@@ -498,6 +586,8 @@ __global__ void __launch_bounds__(256) k_grid_input_bwd(const float *__restrict_
     }
     grad_inputs[t] = r;
 }
+
+static std::atomic<uint32_t> g_absmax_ring{0};      // slot of g_grid_absmax a backward launch uses (single-grid and multi-grid alike)
 
 template <uint32_t D, uint32_t C>
 static void launch_fwd(const float *inputs, const float *emb, const int32_t *off, const int32_t *res, float *out,
@@ -527,8 +617,7 @@ static void launch_bwd(const float *grad, const float *inputs, const int32_t *of
         chunks = std::min(chunks, (N + 2047) / 2048);              // at least 2048 points per workgroup
         if (chunks == 0) chunks = 1;
         const uint32_t chunk = (N + chunks - 1) / chunks;
-        static std::atomic<uint32_t> ring{0};
-        const uint32_t slot = ring.fetch_add(1) % ABSMAX_RING;
+        const uint32_t slot = g_absmax_ring.fetch_add(1) % ABSMAX_RING;
         const uint32_t bpl = std::max(1u, std::min(std::min(ABSMAX_BLOCKS / L, 64u), (N + 1023) / 1024));
         ProfScope _prof("k_grid_bwd", s);
         if (L <= ABSMAX_BLOCKS)
@@ -661,6 +750,91 @@ extern "C" int gsvc_grid_backward_ex(const float *grad, const float *inputs, con
     GridIO io;
     if (int rc = grid_io_from(layout, D, C, io, "grid_backward_ex")) return rc;
     return grid_backward_impl(grad, inputs, offsets, resolutions, grad_embeddings, N, D, C, L, nullptr, nullptr, stream, io);
+}
+
+// ---- several grids over the same points, one launch each way
+static int grid_many_fill(const char *what, const gsvc_grid_many_job *jobs, int32_t n, uint32_t C, bool backward, GridManyJobs &t, uint32_t &levels)
+{
+    GSVC_REQUIRE(jobs && n >= 1 && n <= GRID_MANY, "%s: 1..%d grids", what, GRID_MANY);
+    t.n = n;
+    levels = 0;
+    for (int k = 0; k < n; k++) {
+        const gsvc_grid_many_job &j = jobs[k];
+        GSVC_REQUIRE((j.D == 2 || j.D == 3) && j.L >= 1, "%s: grids of 2 or 3 dimensions with at least one level", what);
+        GSVC_REQUIRE(j.offsets && j.resolutions && j.features && (backward ? j.grad_embeddings != nullptr : j.embeddings != nullptr), "%s: NULL pointer", what);
+        GridManyJob &g = t.j[k];
+        if (int rc = grid_io_from(&j.layout, j.D, C, g.io, what)) return rc;
+        g.table = j.embeddings; g.grad = j.features; g.out = backward ? j.grad_embeddings : j.features;
+        g.offsets = j.offsets; g.resolutions = j.resolutions; g.D = j.D; g.L = j.L; g.first = levels; g.chunks = g.chunk = 0;
+        levels += j.L;
+    }
+    for (int k = n; k < GRID_MANY; k++) t.j[k] = t.j[0];
+    return GSVC_OK;
+}
+
+extern "C" int gsvc_grid_forward_many(const float *inputs, const gsvc_grid_many_job *jobs, int32_t n_jobs, uint32_t N, uint32_t C, void *stream)
+{
+    GridManyJobs t;
+    uint32_t levels = 0;
+    if (int rc = grid_many_fill("grid_forward_many", jobs, n_jobs, C, false, t, levels)) return rc;
+    if (N == 0) return GSVC_OK;
+    GSVC_REQUIRE(inputs, "grid_forward_many: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope _prof("k_grid_fwd_many", s);
+    const dim3 grid((N + 255) / 256, levels);
+    switch (C) {
+        case 2: hipLaunchKernelGGL((k_grid_fwd_many<2>), grid, dim3(256), 0, s, inputs, t, N); break;
+        case 4: hipLaunchKernelGGL((k_grid_fwd_many<4>), grid, dim3(256), 0, s, inputs, t, N); break;
+        case 8: hipLaunchKernelGGL((k_grid_fwd_many<8>), grid, dim3(256), 0, s, inputs, t, N); break;
+        default: set_error("grid_forward_many: 2, 4 or 8 features per level"); return GSVC_E_UNSUPPORTED;
+    }
+    return check_launch("grid_forward_many");
+}
+
+template <uint32_t C>
+static void launch_bwd_many(const float *inputs, GridManyJobs &t, uint32_t levels, uint32_t N, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grid_bwd_lds_many<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)BWD_SLICE_BYTES);
+        attr_set = true;
+    }
+    // every grid gets the chunks it would get in a launch of its own (one round of workgroups on the chip per grid: launch_bwd)
+    static const uint32_t want_wgs = getenv("GSVC_GRID_BWD_WGS") ? (uint32_t)atoi(getenv("GSVC_GRID_BWD_WGS")) : 256;
+    uint32_t max_chunks = 1;
+    for (int k = 0; k < t.n; k++) {
+        GridManyJob &g = t.j[k];
+        const uint32_t slices_guess = g.D == 3 ? 4 : 16;
+        uint32_t chunks = std::max(1u, want_wgs / (g.L * slices_guess));
+        chunks = std::max(1u, std::min(chunks, (N + 2047) / 2048));
+        g.chunks = chunks;
+        g.chunk = (N + chunks - 1) / chunks;
+        max_chunks = std::max(max_chunks, chunks);
+    }
+    const uint32_t slot = g_absmax_ring.fetch_add(1) % ABSMAX_RING;
+    const uint32_t bpl = std::max(1u, std::min(std::min(ABSMAX_BLOCKS / levels, 64u), (N + 1023) / 1024));
+    ProfScope _prof("k_grid_bwd_many", s);
+    hipLaunchKernelGGL((k_grid_absmax_many<C>), dim3(bpl, levels), dim3(256), 0, s, t, N, slot);
+    hipLaunchKernelGGL((k_grid_bwd_lds_many<C>), dim3(max_chunks, levels, BWD_MAX_SLICES), dim3(BWD_THREADS), BWD_SLICE_BYTES, s, inputs, t, N,
+                       slot, bpl);
+}
+
+extern "C" int gsvc_grid_backward_many(const float *inputs, const gsvc_grid_many_job *jobs, int32_t n_jobs, uint32_t N, uint32_t C, void *stream)
+{
+    GridManyJobs t;
+    uint32_t levels = 0;
+    if (int rc = grid_many_fill("grid_backward_many", jobs, n_jobs, C, true, t, levels)) return rc;
+    if (N == 0) return GSVC_OK;
+    GSVC_REQUIRE(inputs && levels <= ABSMAX_BLOCKS, "grid_backward_many: NULL pointer / too many levels");
+    hipStream_t s = (hipStream_t)stream;
+    switch (C) {
+        case 2: launch_bwd_many<2>(inputs, t, levels, N, s); break;
+        case 4: launch_bwd_many<4>(inputs, t, levels, N, s); break;
+        case 8: launch_bwd_many<8>(inputs, t, levels, N, s); break;
+        default: set_error("grid_backward_many: 2, 4 or 8 features per level"); return GSVC_E_UNSUPPORTED;
+    }
+    return check_launch("grid_backward_many");
 }
 
 extern "C" int gsvc_pack_sign_bits(const float *x, int64_t rows, uint8_t *bits, void *stream)

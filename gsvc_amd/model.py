@@ -196,6 +196,25 @@ class _MixGridEncode(torch.autograd.Function):
         return out
 
     @staticmethod
+    def _many(grids):
+        return (not switches.NO_GRID_MANY and 1 <= len(grids) <= 4 and all(g.num_dim in (2, 3) for g in grids)
+                and grids[0].n_features in (2, 4, 8) and all(g.n_features == grids[0].n_features for g in grids))
+
+    @staticmethod
+    def _jobs(grids, x, total, embs, feat_ptr, grad_embs):
+        """gsvc_grid_many_job[len(grids)]: ``feat_ptr`` = the shared [N, total] matrix (outputs forward, gradient backward)."""
+        from . import _lib
+        jobs = (_lib.GridManyJobC * len(grids))()
+        for k, (g, (io, c0)) in enumerate(zip(grids, _MixGridEncode._layout(grids, x, total))):
+            j = jobs[k]
+            j.embeddings = embs[k].data_ptr() if embs is not None else None
+            j.features = feat_ptr + 4 * c0
+            j.grad_embeddings = grad_embs[k].data_ptr() if grad_embs is not None else None
+            j.offsets, j.resolutions = g.offsets_list.data_ptr(), g.resolutions_list.data_ptr()
+            j.D, j.L, j.layout = g.num_dim, g.n_levels, io
+        return jobs
+
+    @staticmethod
     def forward(ctx, x, grids, *embs):
         import ctypes as C
         from . import _lib
@@ -205,10 +224,15 @@ class _MixGridEncode(torch.autograd.Function):
         out = torch.empty(N, total, device=x.device, dtype=torch.float32)
         embs = [e.contiguous() for e in embs]
         st = _lib.current_stream(x.device)
-        for g, e, (io, c0) in zip(grids, embs, _MixGridEncode._layout(grids, x, total)):
-            _lib.check(_lib.lib().gsvc_grid_forward_ex(_lib.ptr(x), _lib.ptr(e), _lib.ptr(g.offsets_list), _lib.ptr(g.resolutions_list),
-                                                       C.c_void_p(out.data_ptr() + 4 * c0), N, g.num_dim, g.n_features, g.n_levels,
-                                                       C.byref(io), st), "gsvc_grid_forward_ex")
+        if _MixGridEncode._many(grids):
+            # the four grids in ONE launch (blockIdx.y runs over their 12 + 3 x 4 levels)
+            jobs = _MixGridEncode._jobs(grids, x, total, embs, out.data_ptr(), None)
+            _lib.check(_lib.lib().gsvc_grid_forward_many(_lib.ptr(x), jobs, len(grids), N, grids[0].n_features, st), "gsvc_grid_forward_many")
+        else:
+            for g, e, (io, c0) in zip(grids, embs, _MixGridEncode._layout(grids, x, total)):
+                _lib.check(_lib.lib().gsvc_grid_forward_ex(_lib.ptr(x), _lib.ptr(e), _lib.ptr(g.offsets_list), _lib.ptr(g.resolutions_list),
+                                                           C.c_void_p(out.data_ptr() + 4 * c0), N, g.num_dim, g.n_features, g.n_levels,
+                                                           C.byref(io), st), "gsvc_grid_forward_ex")
         ctx.save_for_backward(x, *embs)
         ctx.grids, ctx.total = grids, total
         return out
@@ -226,6 +250,11 @@ class _MixGridEncode(torch.autograd.Function):
         # the tables' gradients: slices of one zeroed buffer (one fill, not one per grid)
         sizes = [e.numel() if ctx.needs_input_grad[2 + k] else 0 for k, e in enumerate(embs)]
         zeros = torch.zeros(sum(sizes), device=x.device, dtype=torch.float32).split(sizes)
+        if _MixGridEncode._many(grids) and all(ctx.needs_input_grad[2 + k] for k in range(len(grids))):
+            ges = [zeros[k].view(e.shape) for k, e in enumerate(embs)]
+            jobs = _MixGridEncode._jobs(grids, x, total, None, grad.data_ptr(), ges)
+            _lib.check(_lib.lib().gsvc_grid_backward_many(_lib.ptr(x), jobs, len(grids), N, grids[0].n_features, st), "gsvc_grid_backward_many")
+            return (None, None, *ges)
         for k, (g, e, (io, c0)) in enumerate(zip(grids, embs, _MixGridEncode._layout(grids, x, total))):
             if not ctx.needs_input_grad[2 + k]:
                 outs.append(None)

@@ -210,6 +210,22 @@ int gsvc_grid_backward_ex(const float *grad, const float *inputs, const int32_t 
                           float *grad_embeddings, uint32_t N, uint32_t D, uint32_t C, uint32_t L, const gsvc_grid_io *layout,
                           void *stream);
 
+/* Several grids over the SAME points in one launch each way (Mix3d2dEncoding: one 3-D + three 2-D grids, reference
+ * scene/gaussian_model.py:81-147 calls the four encoders one after the other): `features` is the grid's column block of the shared
+ * [N, sum L C] matrix (forward: written; backward: the gradient, read), `layout` as for gsvc_grid_forward_ex.  Same arithmetic per
+ * (grid, level, point) as the single-grid entries — the tables' gradients are added into grad_embeddings (zero them first); 1..4
+ * grids of 2 or 3 dimensions, C in {2, 4, 8} features per level for all of them. */
+typedef struct gsvc_grid_many_job {
+    const float *embeddings;        /* forward: the table; backward: unused (may be NULL) */
+    float *features;                /* forward: output block; backward: gradient block (read only) */
+    float *grad_embeddings;         /* backward: the table's gradient (accumulated) */
+    const int32_t *offsets, *resolutions;
+    uint32_t D, L;
+    gsvc_grid_io layout;
+} gsvc_grid_many_job;
+int gsvc_grid_forward_many(const float *inputs, const gsvc_grid_many_job *jobs, int32_t n_jobs, uint32_t N, uint32_t C, void *stream);
+int gsvc_grid_backward_many(const float *inputs, const gsvc_grid_many_job *jobs, int32_t n_jobs, uint32_t N, uint32_t C, void *stream);
+
 /* Lookup in BIT-PACKED binarised tables (8 features per row: one byte per row, bit f set = +1, clear = -1 — the {-1, +1} tables of
  * reference utils/encodings.py:375-392 STE_binary as the bitstream carries them: 1/32 of the float tables).  Same interpolation,
  * same results bit for bit as gsvc_grid_forward_ex on the float tables; layout may be NULL (default layout).  Inference only.

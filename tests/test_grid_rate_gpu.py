@@ -811,20 +811,32 @@ def test_mix_encoding_strided_layout_equals_the_module_path(monkeypatch):
     x[1] = 1.0
     x[2, 1] = -0.2                                   # outside the cube: zero features, no gradient
     w = torch.randn(N, enc.output_dim, device="cuda")
+    from gsvc_amd import _lib
     res = []
-    for fused in (True, False):
-        if fused:
-            monkeypatch.delenv("GSVC_NO_FUSED_GRID", raising=False)
-        else:
+    # the four grids in one launch each way (gsvc_grid_*_many) | one launch per grid (gsvc_grid_*_ex) | the per-grid modules
+    for form in ("many", "per_grid", "modules"):
+        monkeypatch.delenv("GSVC_NO_FUSED_GRID", raising=False)
+        monkeypatch.delenv("GSVC_NO_GRID_MANY", raising=False)
+        if form == "per_grid":
+            monkeypatch.setenv("GSVC_NO_GRID_MANY", "1")
+        elif form == "modules":
             monkeypatch.setenv("GSVC_NO_FUSED_GRID", "1")
         enc.zero_grad()
-        y = enc(x)
-        assert ("MixGridEncode" in type(y.grad_fn).__name__) == fused
-        (y * w).sum().backward()
+        _lib.profile_enable(True)
+        try:
+            y = enc(x)
+            assert ("MixGridEncode" in type(y.grad_fn).__name__) == (form != "modules")
+            (y * w).sum().backward()
+            prof = _lib.profile_collect()
+        finally:
+            _lib.profile_enable(False)
+        launches = {k: v[0] for k, v in prof.items() if k.startswith("k_grid")}
+        assert launches == ({"k_grid_fwd_many": 1, "k_grid_bwd_many": 1} if form == "many" else {"k_grid_fwd": 4, "k_grid_bwd": 4}), launches
         res.append((y.detach().clone(), [p.grad.clone() for p in enc.parameters()]))
-    assert res[0][0].shape == (N, 192) and torch.equal(res[0][0], res[1][0])
-    for a, b in zip(res[0][1], res[1][1]):
-        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-9        # float atomics reorder the sums
+    assert res[0][0].shape == (N, 192) and torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][0], res[2][0])
+    for other in (res[1][1], res[2][1]):
+        for a, b in zip(res[0][1], other):
+            assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-9        # float atomics reorder the sums
 
 
 @pytest.mark.gpu
