@@ -553,15 +553,18 @@ __device__ __forceinline__ void trunk_fwd_body(int blk, int nblk, const float *_
 // gfeat (+)= gz1 W1.  go, gx3, d gamma, gh, gz1 are written out: they are the G operands of the seven weight gradients.
 template <int FEAT, int HID, int OUT>
 struct TrunkBwdLds {
-    static constexpr int LD3 = cl_ld(OUT), LDH = cl_ld(HID), NTH = cl_kg(HID), NTF = cl_kg(FEAT);
+    static constexpr int LD3 = cl_ld(OUT), LDH = cl_ld(HID), NTH = cl_kg(HID), NTF = cl_kg(FEAT), LD1 = cl_ld(FEAT);
     static constexpr int o_w3 = 0, o_w2 = NTH * 16 * LD3, o_w1 = o_w2 + NTH * 16 * LDH;
-    static constexpr int FLOATS = o_w1 + NTF * 16 * LDH;
+    // + the forward image of W1 and b1: z1 = W1 feat + b1 is formed again here (the same products in the same order as the forward,
+    // bit for bit) instead of travelling through HBM — 400 of the ~3.3 KB a row of a generator moved each way
+    static constexpr int o_w1f = o_w1 + NTF * 16 * LDH, o_b1 = o_w1f + NTH * 16 * LD1;
+    static constexpr int FLOATS = o_b1 + NTH * 16;
 };
 
 template <int FEAT, int HID, int OUT, int CHAIN_THREADS>
 __device__ __forceinline__ void trunk_bwd_body(int blk, int nblk, const float *__restrict__ gy, const float *__restrict__ y, int act,
                                                              const float *__restrict__ h, const float *__restrict__ gamma,
-                                                             const float *__restrict__ z1, TrunkW w, float *__restrict__ go,
+                                                             const float *__restrict__ feat, TrunkW w, float *__restrict__ go,
                                                              float *__restrict__ gbeta, float *__restrict__ ggamma,
                                                              float *__restrict__ gh, float *__restrict__ gz1,
                                                              float *__restrict__ gfeat, int accumulate, long long M,
@@ -575,10 +578,15 @@ __device__ __forceinline__ void trunk_bwd_body(int blk, int nblk, const float *_
     stage_block<true>(w.W3, HID, OUT, 0, HID, lds + S::o_w3, S::LD3, 0, L.tid, CHAIN_THREADS);
     stage_block<true>(w.W2, HID, HID, 0, HID, lds + S::o_w2, S::LDH, 0, L.tid, CHAIN_THREADS);
     stage_block<true>(w.W1, FEAT, HID, 0, FEAT, lds + S::o_w1, S::LDH, 0, L.tid, CHAIN_THREADS);
+    stage_block<false>(w.W1, FEAT, HID, 0, FEAT, lds + S::o_w1f, S::LD1, 0, L.tid, CHAIN_THREADS);
+    float *sb1 = lds + S::o_b1;
+    stage_bias(w.b1, HID, sb1, S::NTH * 16, L.tid, CHAIN_THREADS);
     __syncthreads();
     long long rb, RB, stride;
     row_blocks<CHAIN_THREADS / 64>(M, L, blk, nblk, rb, RB, stride);
     constexpr int NTO = cl_kg(OUT);
+    v4f f[cl_kg(FEAT)];
+    load_frags<FEAT>(f, feat, rb, RB, M, L);
     v4f g0[NTO], yv[NTO];
     {
         const Tiles<OUT> tg(gy, rb, RB, M, L), ty(y, rb, RB, M, L);
@@ -589,11 +597,11 @@ __device__ __forceinline__ void trunk_bwd_body(int blk, int nblk, const float *_
     for (; rb < RB; rb += stride) {
         // everything this block reads later (h, gamma, z1, the running feature gradient) is requested up front and lands while
         // the products run; the next block's (gy, y) are requested once this block's have been consumed
-        v4f hh[S::NTH], gg[S::NTH], zz[S::NTH], pf[S::NTF];
+        v4f hh[S::NTH], gg[S::NTH], pf[S::NTF];
         {
-            const Tiles<HID> th(h, rb, RB, M, L), tz(z1, rb, RB, M, L);
+            const Tiles<HID> th(h, rb, RB, M, L);
 #pragma unroll
-            for (int t = 0; t < S::NTH; t++) { hh[t] = th.load(t); zz[t] = tz.load(t); }
+            for (int t = 0; t < S::NTH; t++) hh[t] = th.load(t);
             if (film_row) {
                 const int fr_ = fr_next;
                 fr_next = map_row(film_row, rb + stride, RB, M, L);
@@ -649,6 +657,11 @@ __device__ __forceinline__ void trunk_bwd_body(int blk, int nblk, const float *_
         v4f ga[S::NTH];
         init_zero(ga);
         chain_mm<HID, S::NTH, S::LDH>(ga, gx, lds + S::o_w2, L);
+        // z1 of this block, as the forward formed it; the next block's feature rows are requested behind it
+        v4f zz[S::NTH];
+        init_bias(zz, sb1, L);
+        chain_mm<FEAT, S::NTH, S::LD1>(zz, f, lds + S::o_w1f, L);
+        load_frags<FEAT>(f, feat, rb + stride, RB, M, L);
         {
             const Tiles<HID> oz(gz1, rb, RB, M, L);
 #pragma unroll
@@ -726,7 +739,8 @@ struct TrunkBwdBatch {
     int n;
     int out[MAX_NETS], act[MAX_NETS], accumulate[MAX_NETS];
     TrunkW w[MAX_NETS];
-    const float *gy[MAX_NETS], *y[MAX_NETS], *h[MAX_NETS], *gamma[MAX_NETS], *z1[MAX_NETS];
+    const float *gy[MAX_NETS], *y[MAX_NETS], *h[MAX_NETS], *gamma[MAX_NETS];
+    const float *feat;             // the generators' shared input: z1 is formed from it again
     float *go[MAX_NETS], *gbeta[MAX_NETS], *ggamma[MAX_NETS], *gh[MAX_NETS], *gz1[MAX_NETS], *gfeat[MAX_NETS];
     const int *film_row;
     long long film_rows;
@@ -737,7 +751,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) k_trunk_bwd(TrunkBwdBatch b, lo
     const NetOfBlock nb(b.n);
     const int i = nb.net;
 #define GSVC_TRUNK_BWD(OUT) trunk_bwd_body<FEAT, HID, OUT, CHAIN_THREADS>(nb.blk, nb.nblk, pick(b.gy, i), pick(b.y, i), pick(b.act, i), pick(b.h, i), \
-        pick(b.gamma, i), pick(b.z1, i), pick(b.w, i), pick(b.go, i), pick(b.gbeta, i), pick(b.ggamma, i), pick(b.gh, i), pick(b.gz1, i), \
+        pick(b.gamma, i), b.feat, pick(b.w, i), pick(b.go, i), pick(b.gbeta, i), pick(b.ggamma, i), pick(b.gh, i), pick(b.gz1, i), \
         pick(b.gfeat, i), pick(b.accumulate, i), M, b.film_row, b.film_rows)
     switch (pick(b.out, i)) {
         case 10: GSVC_TRUNK_BWD(10); break;
@@ -1170,7 +1184,7 @@ inline float *take(float *&cur, long long count)
 }
 
 // per-row floats of the tensors a generator's forward leaves for its backward, in order: cg, cb [COND], gamma [HID],
-// z1, a1, h, x3 [HID]; beta (a forward intermediate) lives behind them
+// a1, h, x3 [HID] (z1 is not kept: the backward forms it again from the features); beta (a forward intermediate) lives behind them
 struct GenSaved {
     float *cg, *cb, *gamma, *z1, *a1, *h, *x3, *beta;
     GenSaved(float *base, long long M, long long Mf, bool inference = false)      // Mf: rows of the FiLM networks (= M unless the views share them)
@@ -1182,10 +1196,11 @@ struct GenSaved {
             return;
         }
         cg = take(cur, Mf * COND); cb = take(cur, Mf * COND);
-        z1 = take(cur, M * HID); a1 = take(cur, M * HID); h = take(cur, M * HID); x3 = take(cur, M * HID);
+        z1 = nullptr;
+        a1 = take(cur, M * HID); h = take(cur, M * HID); x3 = take(cur, M * HID);
     }
 };
-constexpr long long GEN_SAVED_PER_ROW = 4 * HID, GEN_SAVED_PER_FILM_ROW = 2 * COND + 2 * HID;
+constexpr long long GEN_SAVED_PER_ROW = 3 * HID, GEN_SAVED_PER_FILM_ROW = 2 * COND + 2 * HID;
 
 // backward scratch of a generator: go [OUT], gbeta, ggamma, gh, gz1 [HID] per chain row; gcg, gcb [COND] and (shared FiLM rows)
 // the two views' summed gbeta / ggamma [HID] per FiLM row; then the wgrad partial sums
@@ -1256,6 +1271,7 @@ int generators_backward(const gsvc_generator_net *nets, int n, const float *feat
     TrunkBwdBatch tb;
     FilmBwdBatch fb;
     tb.n = fb.n = n;
+    tb.feat = feat;
     tb.film_row = fr.row_of;
     tb.film_rows = fr.rows;
     fb.src_a = fr.src_a; fb.src_b = fr.src_b; fb.src_rows = M;
@@ -1274,7 +1290,7 @@ int generators_backward(const gsvc_generator_net *nets, int n, const float *feat
         const GenScratch sc(sbase[j], M, fr.rows, g.out_dim, fr.shared);
         tb.out[i] = g.out_dim; tb.act[i] = g.out_act; tb.accumulate[i] = accumulate ? accumulate[j] : 0;
         tb.w[i] = TrunkW{g.W1, g.b1, g.W2, g.b2, g.W3, g.b3};
-        tb.gy[i] = gy[j]; tb.y[i] = y[j]; tb.h[i] = sv.h; tb.gamma[i] = sv.gamma; tb.z1[i] = sv.z1;
+        tb.gy[i] = gy[j]; tb.y[i] = y[j]; tb.h[i] = sv.h; tb.gamma[i] = sv.gamma;
         tb.go[i] = sc.go; tb.gbeta[i] = sc.gbeta; tb.ggamma[i] = sc.ggamma; tb.gh[i] = sc.gh; tb.gz1[i] = sc.gz1; tb.gfeat[i] = gfeat[j];
         fb.ggamma[i] = sc.ggamma; fb.gbeta[i] = sc.gbeta; fb.cg[i] = sv.cg; fb.cb[i] = sv.cb; fb.Wg1[i] = g.Wg1; fb.Wb1[i] = g.Wb1;
         fb.gcg[i] = sc.gcg; fb.gcb[i] = sc.gcb; fb.ggamma_sum[i] = sc.ggamma_sum; fb.gbeta_sum[i] = sc.gbeta_sum;
