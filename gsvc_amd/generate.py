@@ -917,6 +917,40 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
                      bit_per_offsets_param=per[r, 2]) for r in range(R)]
 
 
+_RATE_STREAM = {}
+
+
+def finish_deferred_rate(gss_list):
+    """The sampled rate of a batched TRAINING_ENTROPY generation pass whose caller asked for it late (``defer_rate``): issued now —
+    the caller has queued the rasterizer's launches — on a stream of its own that waits only for what the rate reads (the event
+    recorded behind the noise quantisation).  The current stream waits for the result; the rate's autograd nodes belong to that
+    stream, so their backward (the first nodes of the step's backward) runs next to the rasterizer's backward instead of in
+    front of it.  Fills the renders' ``bit_per_*`` and the batch's ``bit_per_param_sum``; no-op when nothing was deferred."""
+    batch = getattr(gss_list[0], "batch", None) if gss_list else None
+    pending = getattr(batch, "deferred_rate", None)
+    if pending is None:
+        return
+    rate, ready = pending
+    batch.deferred_rate = None
+    dev = gss_list[0].xyz.device
+    main = torch.cuda.current_stream(dev)
+    rs = _RATE_STREAM.get(dev.index)
+    if rs is None:
+        rs = _RATE_STREAM[dev.index] = torch.cuda.Stream(device=dev)
+    rs.wait_event(ready)
+    with torch.cuda.stream(rs):
+        packs = rate()
+    main.wait_stream(rs)
+    total = getattr(packs[0], "bit_per_param_sum", None)
+    for t in [total] + [v for p in packs for v in (p.bit_per_param, p.bit_per_feat_param, p.bit_per_scaling_param, p.bit_per_offsets_param)]:
+        if isinstance(t, torch.Tensor):
+            t.record_stream(main)            # allocated on the rate stream, read by the loss on this one
+    for gs, p in zip(gss_list, packs):
+        gs.bit_per_param, gs.bit_per_feat_param = p.bit_per_param, p.bit_per_feat_param
+        gs.bit_per_scaling_param, gs.bit_per_offsets_param = p.bit_per_scaling_param, p.bit_per_offsets_param
+    batch.bit_per_param_sum = total
+
+
 def _entropy_context_distinct(pc, anchor_all, vis, plan=None, sampled=False):
     """Entropy context of the batch's rows, evaluated once per DISTINCT anchor.
 
@@ -1055,7 +1089,7 @@ def generator_trunks(pc):
 
 
 def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.TRAINING_FULL_PRECISION, dense=False,
-                                   anchors=None, trunks=None, plan=None):
+                                   anchors=None, trunks=None, plan=None, defer_rate=False):
     """`generate_neural_gaussians` for R renders at once; returns a list of R GeneratedGaussians.
 
     ``dense=True`` skips the "opacity > 0" compaction: every visible anchor contributes all K Gaussians, ``mask``
@@ -1115,6 +1149,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         else:
             feat, grid_offsets, grid_scaling, offset_masks = _gather_rows(pc, vis, ranks)
     rates = [RatePack() for _ in range(R)]
+    deferred = []
     Q_feat, Q_scaling, Q_offsets = BASE_Q_FEAT, BASE_Q_SCALING, BASE_Q_OFFSETS
     time_sub = 0
     # the conditioning input and the generators' FiLM networks depend on the anchors' z only: issued FIRST, their twelve large
@@ -1173,9 +1208,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
             with region('gen.noise_quant'):
                 grid_scaling = _seg_noise_quant(grid_scaling, Q_scaling, seg)
                 grid_offsets = _seg_noise_quant(grid_offsets, Q_offsets.unsqueeze(1), seg)
-            with region('gen.rate'):
-                rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row,
-                                   sel=plan.sel if plan is not None else None)
+            rates = rate_now_or_later()
     elif mode == GenerateMode.TRAININ_STE_ENTROPY:
         ec, ec_row = _entropy_context_distinct(pc, anchor_all, vis, plan, sampled=vis.is_cuda and not switches.CTX_ALL_ROWS)
         rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
@@ -1194,10 +1227,24 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
             nonlocal grid_offsets, grid_scaling, rates
             grid_scaling = _seg_ste(grid_scaling, Q_scaling, seg, pc.get_scaling.mean())
             grid_offsets = _seg_ste(grid_offsets, Q_offsets.unsqueeze(1), seg, pc._offset.mean())
-            rates = _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row,
-                               sel=plan.sel if plan is not None else None)
+            rates = rate_now_or_later()
     else:
         raise ValueError(f"Unknown mode {mode}")
+
+    def rate_now_or_later():
+        """The sampled rate of the two entropy phases (runs once the row tensors are in their final form)."""
+        def rate():
+            with region('gen.rate'):
+                return _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row,
+                                  sel=plan.sel if plan is not None else None)
+        if (defer_rate and dense and late_rows and plan is not None and plan.sel is not None and vis.is_cuda
+                and not switches.NO_RATE_OVERLAP):
+            # the sampled rate — three small networks on ~10 k rows and a dozen reductions, launch-bound — is issued by the caller
+            # BEHIND the rasterizer's launches, on its own stream (finish_deferred_rate): it runs under the compositing kernels
+            # forward and, its autograd nodes living on that stream, under the rasterizer's backward
+            deferred.append((rate, torch.cuda.current_stream(vis.device).record_event()))
+            return rates
+        return rate()
 
     def rows_now():
         nonlocal grid_offsets, grid_scaling, offset_masks
@@ -1244,7 +1291,8 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         from types import SimpleNamespace
         batch = SimpleNamespace(scaling=scaling, neural_opacity=neural_opacity, mask=mask, seg_offsets=[b * K for b in seg.bounds], vis=vis,
                                 xyz=xyz, color=color, rot=rot, world=world,      # the un-split tensors: rasterize_many works on their row ranges
-                                bit_per_param_sum=getattr(rates[0], "bit_per_param_sum", None))
+                                bit_per_param_sum=getattr(rates[0], "bit_per_param_sum", None),
+                                deferred_rate=deferred[0] if deferred else None)
         out = []
         for r, gs in enumerate(seg.slices(K)):
             out.append(GeneratedGaussians(

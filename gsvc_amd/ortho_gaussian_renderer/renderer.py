@@ -9,7 +9,8 @@ import os
 import torch
 
 from ..common.base import RenderResults
-from ..generate import GenerateMode, generate_neural_gaussians, generate_neural_gaussians_many, generator_trunks, region
+from ..generate import (GenerateMode, finish_deferred_rate, generate_neural_gaussians, generate_neural_gaussians_many, generator_trunks,
+                        region)
 from ..rasterizer import GaussianRasterizer, raster_forward, rasterize_many, settings_to_c
 from .preprocess import prefilter_geometry, prefilter_voxel, prefilter_voxels_many, raster_settings_for
 
@@ -70,7 +71,7 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
         visible = prefilter_voxels_many(frames, pc, pipe, bg_color, geometry=geometry)
     with region('render.generate'):
         gss_list = generate_neural_gaussians_many(frames, pc, visible, mode, dense=dense,
-                                                  anchors=None if anchor_grad else geometry[0], plan=plan)
+                                                  anchors=None if anchor_grad else geometry[0], plan=plan, defer_rate=dense)
     results = []
     batch = getattr(gss_list[0], "batch", None) if (dense and gss_list) else None
     if batch is not None and getattr(batch, "xyz", None) is not None and len(batch.seg_offsets) == len(frames) + 1:
@@ -82,6 +83,7 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
         with region('render.rasterize_many'):
             images, radii_all, states = rasterize_many(cs_list, bounds, batch.xyz, leaf, batch.color, batch.neural_opacity, batch.scaling,
                                                        batch.rot)
+        finish_deferred_rate(gss_list)       # the sampled rate, behind the rasterizer's launches on its own stream (generate.py)
         seen_all = radii_all > 0
         batch.viewspace, batch.seen = leaf, seen_all
         for r, (frame, visible_mask, gss) in enumerate(zip(frames, visible, gss_list)):
@@ -95,6 +97,7 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
                 entropy_constrained=(gss.bit_per_param is not None), generated_gaussians=gss, time_sub=gss.time_sub,
                 dense=dense, visible_index=gss.visible_index, raster_state=states[r]))
         return results
+    finish_deferred_rate(gss_list)
     for frame, visible_mask, gss in zip(frames, visible, gss_list):
         # the tensor whose .grad receives the screen-space gradient: a leaf (the reference's ``zeros_like(...) + 0`` with
         # retain_grad() holds the same numbers through two more kernels); pc._anchor.dtype, not pc.get_anchor.dtype — the

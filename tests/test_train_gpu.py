@@ -343,6 +343,46 @@ def test_early_plan_steps_equal_plain_steps(monkeypatch, phase):
         assert off < 5e-3, (n, off)
 
 
+def test_rate_on_its_own_stream_equals_the_rate_inside_the_generation_pass(monkeypatch):
+    """TRAINING_ENTROPY steps with the sampled rate issued behind the rasterizer's launches on a stream of its own
+    (gsvc_amd/generate.py finish_deferred_rate: its kernels run under the compositing kernels, forward and backward) against
+    GSVC_NO_RATE_OVERLAP=1 (inside the generation pass, on the step's stream): the same draws, losses and parameters after four
+    steps (as in test_early_plan_steps_equal_plain_steps: Adam turns rounding noise in a near-zero gradient into a whole step).  A missing wait between the streams would show as a different loss or as NaN."""
+    res = []
+    for overlap in (True, False):
+        if overlap:
+            monkeypatch.delenv("GSVC_NO_RATE_OVERLAP", raising=False)
+        else:
+            monkeypatch.setenv("GSVC_NO_RATE_OVERLAP", "1")
+        monkeypatch.setenv("GSVC_EARLY_PLAN", "1")
+        pc, cube, opt, pipe, mp, Trainer = _setup(anchors=6000, seed=4)
+        opt.full_precision_training_total = opt.quantized_training_total = 0
+        opt.entropy_constrained_train_total = 1000
+        opt.start_stat, opt.update_until, opt.pause_densification, opt.update_from = 0, 10 ** 9, 0, 10 ** 9
+        pc.training_setup(opt)
+        torch.manual_seed(7)
+        tr = Trainer(pc, cube, opt, pipe, mp)
+        import gsvc_amd.generate as G
+        calls = []
+        real = G.finish_deferred_rate
+        import gsvc_amd.ortho_gaussian_renderer.renderer as RR
+        monkeypatch.setattr(RR, "finish_deferred_rate", lambda gss: (calls.append(getattr(gss[0].batch, "deferred_rate", None) is not None), real(gss))[1])
+        outs = [tr.step(i + 1) for i in range(4)]
+        losses = [float(o.loss) for o in outs]
+        assert all(np.isfinite(losses))
+        assert all(o.renders[0].entropy_constrained and o.renders[0].bit_per_param is not None for o in outs)
+        # the first step has no plan (no planned sample): inline; from the second on the rate is deferred when overlap is on
+        assert calls[1:] == [overlap] * 3, calls
+        res.append((losses, {n: p.detach().clone() for n, p in pc.named_parameters()}))
+    (la, pa), (lb, pb) = res
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 1e-5 * max(1.0, abs(y)), (la, lb)
+    for n in pa:
+        scale = max(1e-6, pb[n].abs().max().item())
+        off = ((pa[n] - pb[n]).abs() > 1e-4 * scale).float().mean().item()
+        assert off < 5e-3, (n, off)
+
+
 def test_overflowing_step_with_early_plan_changes_nothing_before_its_repeat(monkeypatch):
     """A step whose rasterizer instance buffers overflow is repeated (gsvc_amd/train.py step()).  With the early plan its
     guarded Adam launch of _scaling / _mask has already been queued when the overflow is read back: the kernel sees the
