@@ -920,6 +920,16 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
 _RATE_STREAM = {}
 
 
+def small_work_stream(dev):
+    """The stream on which a fitting step issues the small launch-bound pieces that do not read the rasterizer's output (the sampled
+    rate here, the regularisers / optical-flow term / table bits in gsvc_amd/train.py), so that they run under the compositing
+    kernels instead of in front of or behind them."""
+    rs = _RATE_STREAM.get(dev.index)
+    if rs is None:
+        rs = _RATE_STREAM[dev.index] = torch.cuda.Stream(device=dev)
+    return rs
+
+
 def finish_deferred_rate(gss_list):
     """The sampled rate of a batched TRAINING_ENTROPY generation pass whose caller asked for it late (``defer_rate``): issued now —
     the caller has queued the rasterizer's launches — on a stream of its own that waits only for what the rate reads (the event
@@ -934,9 +944,7 @@ def finish_deferred_rate(gss_list):
     batch.deferred_rate = None
     dev = gss_list[0].xyz.device
     main = torch.cuda.current_stream(dev)
-    rs = _RATE_STREAM.get(dev.index)
-    if rs is None:
-        rs = _RATE_STREAM[dev.index] = torch.cuda.Stream(device=dev)
+    rs = small_work_stream(dev)
     rs.wait_event(ready)
     with torch.cuda.stream(rs):
         packs = rate()

@@ -80,6 +80,10 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
         bounds = batch.seg_offsets
         leaf = torch.empty(bounds[-1], 3, dtype=pc._anchor.dtype, device=batch.xyz.device, requires_grad=True)   # value never read
         cs_list = [settings_to_c(raster_settings_for(f, pc, pipe, bg_color, scaling_modifier)) for f in frames]
+        if batch.xyz.is_cuda:
+            # everything the generation pass produced is queued by now: work that reads only that (the sampled rate, the loss's
+            # regularisers) may start behind this event on another stream while the rasterizer runs
+            batch.generated_event = torch.cuda.current_stream(batch.xyz.device).record_event()
         with region('render.rasterize_many'):
             images, radii_all, states = rasterize_many(cs_list, bounds, batch.xyz, leaf, batch.color, batch.neural_opacity, batch.scaling,
                                                        batch.rot)

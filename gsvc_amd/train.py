@@ -13,6 +13,8 @@ import os
 import random
 from dataclasses import dataclass
 
+import contextlib
+
 import torch
 
 from . import dist as gdist
@@ -300,29 +302,45 @@ class Trainer:
         # one tiny kernel per +, *, and their backward nodes)
         terms, weights, const = [l1_1, l1_2, ssim1, ssim2], [1.0 - opt.lambda_dssim] * 2 + [-opt.lambda_dssim] * 2, 2.0 * opt.lambda_dssim
         batch = getattr(r1f.generated_gaussians, "batch", None) if self.batched else None
-        if batch is not None:
-            regs = render_regs(batch.scaling, batch.neural_opacity, batch.mask, batch.seg_offsets)
-            terms += [regs[0], regs[1]]
-        else:
-            terms += [sum(_mean_over_selected(r.scaling.prod(dim=1), r) for r in renders),
-                      sum((1 - r.neural_opacity).mean() for r in renders)]
-        weights += [opt.scaling_reg, opt.opacity_reg]
-        if opt.optical_lambda != 0:
-            flow = self.dataset.get_optical_flow(frame_idx)
-            terms.append(calc_optical_loss(r1f, r1b, r2f, r2b, flow, self.dataset.x_min, self.dataset.y_min,
-                                           self.dataset.scale, self.dataset.width, self.dataset.height, pc.n_offsets))
-            weights.append(opt.optical_lambda)
-        if self.controller.entropy_constrained:
-            assert all(r.entropy_constrained for r in renders)
-            denom = pc._anchor.shape[0] * (pc.feat_dim + 6 + 3 * pc.n_offsets)
-            # sparse data-parallel exchange (below): the regulariser's dense gradient is added after the exchange (_add_mask_reg)
-            sparse_dp = self._sparse_dp(plan if self.batched else None)
-            self._mask_reg_weight = 5e-4 if sparse_dp else 0.0
-            rate_sum = getattr(batch, "bit_per_param_sum", None)
-            # the renders' rates enter with one weight: their sum, when the batched generation already formed it, is one term
-            terms += ([rate_sum] if rate_sum is not None else [r.bit_per_param for r in renders]) + \
-                     [hash_grid_bits(pc), torch.mean(torch.sigmoid(pc._mask.detach() if sparse_dp else pc._mask))]
-            weights += [opt.lmbda] * (1 if rate_sum is not None else 4) + [opt.lmbda / denom, 5e-4]
+        # the terms below read the generation pass's tensors and parameters, not the images: a dozen small launches each way, issued
+        # on the small-work stream behind the generation pass's event so that they run under the compositing kernels (their backward
+        # too: autograd runs a node on its forward's stream) instead of behind the image losses
+        side = None
+        if batch is not None and getattr(batch, "generated_event", None) is not None and not switches.NO_RATE_OVERLAP:
+            from .generate import small_work_stream
+            side = small_work_stream(dev)
+            side.wait_event(batch.generated_event)
+        n_image_terms = len(terms)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if batch is not None:
+                regs = render_regs(batch.scaling, batch.neural_opacity, batch.mask, batch.seg_offsets)
+                terms += [regs[0], regs[1]]
+            else:
+                terms += [sum(_mean_over_selected(r.scaling.prod(dim=1), r) for r in renders),
+                          sum((1 - r.neural_opacity).mean() for r in renders)]
+            weights += [opt.scaling_reg, opt.opacity_reg]
+            if opt.optical_lambda != 0:
+                flow = self.dataset.get_optical_flow(frame_idx)
+                terms.append(calc_optical_loss(r1f, r1b, r2f, r2b, flow, self.dataset.x_min, self.dataset.y_min,
+                                               self.dataset.scale, self.dataset.width, self.dataset.height, pc.n_offsets))
+                weights.append(opt.optical_lambda)
+            if self.controller.entropy_constrained:
+                assert all(r.entropy_constrained for r in renders)
+                denom = pc._anchor.shape[0] * (pc.feat_dim + 6 + 3 * pc.n_offsets)
+                # sparse data-parallel exchange (below): the regulariser's dense gradient is added after the exchange (_add_mask_reg)
+                sparse_dp = self._sparse_dp(plan if self.batched else None)
+                self._mask_reg_weight = 5e-4 if sparse_dp else 0.0
+                rate_sum = getattr(batch, "bit_per_param_sum", None)
+                # the renders' rates enter with one weight: their sum, when the batched generation already formed it, is one term
+                terms += ([rate_sum] if rate_sum is not None else [r.bit_per_param for r in renders]) + \
+                         [hash_grid_bits(pc), torch.mean(torch.sigmoid(pc._mask.detach() if sparse_dp else pc._mask))]
+                weights += [opt.lmbda] * (1 if rate_sum is not None else 4) + [opt.lmbda / denom, 5e-4]
+        if side is not None:
+            main_stream = torch.cuda.current_stream(dev)
+            main_stream.wait_stream(side)
+            for t in terms[n_image_terms:]:
+                if t.is_cuda:
+                    t.record_stream(main_stream)       # allocated on the small-work stream, combined on this one
         key = tuple(weights)
         if getattr(self, "_w_key", None) != key:      # the weights change only with the training phase
             from .generate import host_values
