@@ -423,6 +423,19 @@ def run_train_step(args, rank, world, dev):
                     "repeated_steps": int(getattr(trainer, "repeated_steps", 0) - rep0),
                     "reserved_GiB": round(mem1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2)}
     total_units, elapsed = reduce_sum_max(torch, dist, world, dev, active.item(), elapsed)
+    if os.environ.get("GSVC_BENCH_AB"):        # diagnostic: alternate a switch on this trainer, same process (stderr)
+        from gsvc_amd import switches
+        var = os.environ["GSVC_BENCH_AB"]
+        for rep in range(3):
+            for val in (None, "1"):
+                os.environ.pop(var, None) if val is None else os.environ.__setitem__(var, val)
+                switches.reload()
+                for _ in range(3):
+                    step()
+                e = timed(torch, dist, world, step, 30)
+                sys.stderr.write(f"AB {var}={val}: {1e3 * e / 30:.3f} ms/step\n")
+        os.environ.pop(var, None)
+        switches.reload()
 
     # exposed communication: the same K steps with the gradient exchange switched off (replicas diverge: last thing
     # measured on the model's gradients; parameters are re-broadcast afterwards)

@@ -927,6 +927,11 @@ def small_work_stream(dev):
     rs = _RATE_STREAM.get(dev.index)
     if rs is None:
         rs = _RATE_STREAM[dev.index] = torch.cuda.Stream(device=dev)
+        # a parameter that both this stream's nodes and the step's stream's nodes use gets its gradient from two streams: intended
+        # (the engine orders them), so the engine's one-time warning about it says nothing here
+        warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if warn_off is not None:
+            warn_off(False)
     return rs
 
 

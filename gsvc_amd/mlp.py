@@ -38,9 +38,10 @@ _workspaces = {}
 
 
 def _workspace(dev, floats):
-    """One weight-gradient workspace per device, grown on demand (the launches of a stream run in order, so they can
-    share it)."""
-    key = (dev.type, dev.index)
+    """One weight-gradient workspace per device AND stream, grown on demand: the launches of a stream run in order, so they can
+    share it — two streams cannot (the entropy networks' backward runs on the small-work stream next to the generators' on the
+    step's stream: gsvc_amd/generate.py finish_deferred_rate)."""
+    key = (dev.type, dev.index, _lib.current_stream(dev).value)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < floats:
         ws = torch.empty(max(floats, 1 << 22), device=dev, dtype=torch.float32)

@@ -8,6 +8,10 @@ from gsvc_amd.frame import SyntheticFrameCube
 from gsvc_amd.model import GaussianModel
 from gsvc_amd.train import Trainer
 var, va, vb = sys.argv[1:4]
+if os.environ.get("GSVC_AB_BIND_EARLY"):
+    torch.cuda.set_device(0)
+    from gsvc_amd.hostbind import bind_to_device
+    print("bound early:", bind_to_device(0), len(os.sched_getaffinity(0)))
 dev = torch.device("cuda:0")
 mp_, opt, pipe = cfg_20240919()
 CFG3 = "cfg3" in sys.argv[1:] or bool(os.environ.get("GSVC_AB_CFG3"))      # BASELINE configs[3] per-GPU shape: yaml as is
@@ -28,10 +32,14 @@ pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
 pc.training_setup(opt)
 tr = Trainer(pc, cube, opt, pipe, mp_, seed=0)
 it = 0
-for _ in range(150):
+if os.environ.get('GSVC_AB_PRE_OFF'):
+    os.environ[var] = os.environ['GSVC_AB_PRE_OFF']
+    from gsvc_amd import switches as _sw
+    _sw.reload()
+for _ in range(int(os.environ.get('GSVC_AB_PRE', '150'))):
     it += 1; tr.step(it)
 res = {va: [], vb: []}
-for rep in range(5):
+for rep in range(int(os.environ.get('GSVC_AB_REPS', '5'))):
     for v in (va, vb):
         if v == "unset":
             os.environ.pop(var, None)
@@ -43,11 +51,11 @@ for rep in range(5):
             it += 1; tr.step(it)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         act = torch.zeros((), device=dev, dtype=torch.float64)
-        for _ in range(25):
-            it += 1; act += tr.step(it).active_gaussians
+        for _ in range(int(os.environ.get('GSVC_AB_SEG', '25'))):
+            it += 1; keep = tr.step(it) if os.environ.get("GSVC_AB_KEEP") else None; act += (keep if keep is not None else tr.step(it)).active_gaussians
         torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / 25
-        res[v].append((ms, float(act) / 100))
+        ms = 1e3 * (time.perf_counter() - t0) / int(os.environ.get('GSVC_AB_SEG', '25'))
+        res[v].append((ms, float(act) / (4 * int(os.environ.get('GSVC_AB_SEG', '25')))))
 for v, r in res.items():
     ms = np.array([x[0] for x in r]); a = np.array([x[1] for x in r])
     print(f"{var}={v}: {ms.mean():.3f} ms/step (min {ms.min():.3f}, max {ms.max():.3f}), active per render {a.mean():.0f}, us per 1000 active {1e3 * ms.mean() / (4 * a.mean() / 1e3):.2f}")

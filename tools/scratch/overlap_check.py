@@ -1,0 +1,73 @@
+"""Gradients of one fitting step with the small work on its own stream against the same step with everything on the step's stream:
+same model, same frame pair, same plan, same draws; repeated, to catch an intermittent cross-stream race."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ["GSVC_NO_EARLY_PLAN"] = "1"
+from gsvc_amd import switches
+from gsvc_amd.arguments import cfg_20240919
+from gsvc_amd.frame import SyntheticFrameCube
+from gsvc_amd.model import GaussianModel
+from gsvc_amd.train import Trainer
+from gsvc_amd.ortho_gaussian_renderer.renderer import plan_views
+dev = torch.device("cuda:0")
+mp_, opt, pipe = cfg_20240919()
+cube = SyntheticFrameCube(1080, 1920, 64, seed=1234, device=dev).materialize()
+mp_.threshold = 8.0 / cube.scale
+opt.full_precision_training_total, opt.quantized_training_total = 0, 0
+opt.entropy_constrained_train_total = 10 ** 9
+opt.start_stat, opt.update_until, opt.pause_densification, opt.update_from = 0, 10 ** 9, 0, 10 ** 9
+torch.manual_seed(0); np.random.seed(0)
+pc = GaussianModel(mp_, mp_.anchor_feature_dim, mp_.n_offsets, mp_.voxel_size, mp_.update_depth, mp_.update_init_factor,
+                   mp_.update_hierarchy_factor, mp_.use_feat_bank, n_features_per_level=mp_.grid_feature_dim,
+                   log2_hashmap_size=mp_.log2, log2_hashmap_size_2D=mp_.log2_2D, device=dev)
+rng = np.random.default_rng(0)
+lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
+pc.create_from_points(rng.uniform(lim, -lim, (245_000, 3)), spatial_lr_scale=1.0)
+pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+pc.training_setup(opt)
+tr = Trainer(pc, cube, opt, pipe, mp_, seed=0)
+it = 0
+for _ in range(60):
+    it += 1; tr.step(it)
+captured = {}
+real_step = pc.optimizer.step
+def capture(*a, **k):
+    captured.clear()
+    for g in pc.optimizer.param_groups:
+        for i, p in enumerate(g["params"]):
+            if p.grad is not None:
+                captured[f"{g['name']}.{i}"] = p.grad.detach().clone()
+pc.optimizer.step = capture
+mode = tr.controller.render_mode
+worst_all = {}
+for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
+    f = 5 + 3 * trial
+    res = {}
+    for m in ("off", "on", "off2"):
+        if m == "on":
+            os.environ.pop("GSVC_NO_RATE_OVERLAP", None)
+        else:
+            os.environ["GSVC_NO_RATE_OVERLAP"] = "1"
+        switches.reload()
+        torch.manual_seed(1000 + trial)
+        tr._plan = plan_views(tr._views(f), pc, pipe, tr.background, mode)
+        tr._plan_idx, tr._plan_mode = f, mode
+        torch.manual_seed(2000 + trial)
+        it += 1
+        out = tr.step(it, frame_idx=f)
+        torch.cuda.synchronize()
+        res[m] = (float(out.loss), dict(captured))
+    line = []
+    for a, b in (("on", "off"), ("off2", "off")):
+        worst, wk = 0.0, None
+        for k, v in res[b][1].items():
+            s = float(v.abs().max())
+            if s == 0: continue
+            e = float((res[a][1][k] - v).abs().max()) / s
+            if e > worst: worst, wk = e, k
+        line.append(f"{a} vs {b}: loss {res[a][0]:.6f} / {res[b][0]:.6f} worst rel grad diff {worst:.2e} ({wk})")
+        if a == "on":
+            worst_all[wk] = max(worst_all.get(wk, 0), worst)
+    print(f"trial {trial} frame {f}: " + " | ".join(line), flush=True)
+print("worst by tensor (on vs off):", worst_all)
