@@ -918,6 +918,8 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
 
 
 _RATE_STREAM = {}
+SMALL_WORK_MIN_ROWS = 150_000      # visible anchor rows of a step from which the small-work stream is used: below, the step is
+                                   # host-bound (configs[3]: 58 k rows) and the extra events / stream switches only cost host time
 
 
 def small_work_stream(dev):
@@ -1251,7 +1253,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
                 return _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row,
                                   sel=plan.sel if plan is not None else None)
         if (defer_rate and dense and late_rows and plan is not None and plan.sel is not None and vis.is_cuda
-                and not switches.NO_RATE_OVERLAP):
+                and seg.rows >= SMALL_WORK_MIN_ROWS and not switches.NO_RATE_OVERLAP):
             # the sampled rate — three small networks on ~10 k rows and a dozen reductions, launch-bound — is issued by the caller
             # BEHIND the rasterizer's launches, on its own stream (finish_deferred_rate): it runs under the compositing kernels
             # forward and, its autograd nodes living on that stream, under the rasterizer's backward
@@ -1305,7 +1307,8 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         batch = SimpleNamespace(scaling=scaling, neural_opacity=neural_opacity, mask=mask, seg_offsets=[b * K for b in seg.bounds], vis=vis,
                                 xyz=xyz, color=color, rot=rot, world=world,      # the un-split tensors: rasterize_many works on their row ranges
                                 bit_per_param_sum=getattr(rates[0], "bit_per_param_sum", None),
-                                deferred_rate=deferred[0] if deferred else None)
+                                deferred_rate=deferred[0] if deferred else None,
+                                small_work=bool(vis.is_cuda and seg.rows >= SMALL_WORK_MIN_ROWS and not switches.NO_RATE_OVERLAP))
         out = []
         for r, gs in enumerate(seg.slices(K)):
             out.append(GeneratedGaussians(

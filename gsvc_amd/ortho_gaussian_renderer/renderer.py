@@ -80,7 +80,7 @@ def render_many(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, 
         bounds = batch.seg_offsets
         leaf = torch.empty(bounds[-1], 3, dtype=pc._anchor.dtype, device=batch.xyz.device, requires_grad=True)   # value never read
         cs_list = [settings_to_c(raster_settings_for(f, pc, pipe, bg_color, scaling_modifier)) for f in frames]
-        if batch.xyz.is_cuda:
+        if batch.xyz.is_cuda and getattr(batch, "small_work", False):
             # everything the generation pass produced is queued by now: work that reads only that (the sampled rate, the loss's
             # regularisers) may start behind this event on another stream while the rasterizer runs
             batch.generated_event = torch.cuda.current_stream(batch.xyz.device).record_event()

@@ -355,6 +355,8 @@ def test_rate_on_its_own_stream_equals_the_rate_inside_the_generation_pass(monke
         else:
             monkeypatch.setenv("GSVC_NO_RATE_OVERLAP", "1")
         monkeypatch.setenv("GSVC_EARLY_PLAN", "1")
+        import gsvc_amd.generate as G
+        monkeypatch.setattr(G, "SMALL_WORK_MIN_ROWS", 0)      # a step this small does not use the third stream by itself
         pc, cube, opt, pipe, mp, Trainer = _setup(anchors=6000, seed=4)
         opt.full_precision_training_total = opt.quantized_training_total = 0
         opt.entropy_constrained_train_total = 1000
@@ -362,7 +364,6 @@ def test_rate_on_its_own_stream_equals_the_rate_inside_the_generation_pass(monke
         pc.training_setup(opt)
         torch.manual_seed(7)
         tr = Trainer(pc, cube, opt, pipe, mp)
-        import gsvc_amd.generate as G
         calls = []
         real = G.finish_deferred_rate
         import gsvc_amd.ortho_gaussian_renderer.renderer as RR
