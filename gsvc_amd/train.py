@@ -404,7 +404,7 @@ class Trainer:
         finally:
             for h in handles:
                 h.remove()
-        if dev.type == "cuda":
+        if dev.type == "cuda" and (side is not None or getattr(batch, "small_work", False)):
             # backward() returns with every node's kernels queued on the node's forward stream.  A parameter that only the small-work
             # stream touched (the priors' networks: used by the deferred rate alone) has its gradient accumulated THERE, and nothing in
             # the engine orders that before what this stream does next — the optimizer, the reducer, the statistics.  Without this
@@ -442,6 +442,7 @@ class Trainer:
                     pc.optimizer.step()
                     pc.optimizer.zero_grad(set_to_none=True)
         active = sum(r.active_gaussains for r in renders)
-        _release_graph(renders)
+        if getattr(batch, "small_work", False):
+            _release_graph(renders)
         return StepOutput(loss=loss.detach(), image1=image1.detach(), image2=image2.detach(), renders=renders,
                           active_gaussians=active, frame_idx=frame_idx)
