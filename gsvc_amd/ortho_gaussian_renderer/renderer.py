@@ -182,34 +182,51 @@ def render_frames(frames, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0
         if int(f.image_width) % 16 != 0 or (int(getattr(pipe, "raster_flags", 0) or 0) & 3):
             raise ValueError("render_frames: the two-view pass needs an image width that is a multiple of 16 and the symmetric-slab / "
                              "pixel-centre conventions (use render_pair)")
+    from ..rasterizer import _side_streams
+    dev = pc._anchor.device
+
+    def launch(chunk, trunks):
+        """Generation of the chunk's frames on the current stream, their two-view passes on the side streams; nothing is waited for."""
+        geometry = prefilter_geometry(pc)
+        visible = prefilter_voxels_many(chunk, pc, pipe, bg_color, geometry=geometry)
+        gss_list = generate_neural_gaussians_many(chunk, pc, visible, mode, dense=True, anchors=geometry[0], trunks=trunks)
+        images, states = [], []
+        # the frames of a batch are independent pipelines: dealt to two side streams (rasterizer._side_streams), one frame's
+        # kernel boundaries and tails are filled by the next frame's kernels
+        side = _side_streams(dev, len(chunk))
+        main = torch.cuda.current_stream(dev) if side else None
+        args = [(gss.xyz.contiguous(), gss.color.contiguous(), gss.opacity.contiguous(), gss.scaling.contiguous(), gss.rot.contiguous())
+                for gss in gss_list]
+        for sd in side:
+            sd.wait_stream(main)
+        for k, (f, a) in enumerate(zip(chunk, args)):
+            cs = settings_to_c(raster_settings_for(f, pc, pipe, bg_color, scaling_modifier))
+            image, _, state = raster_forward(cs, *a, pair=True, sync=False, readback=True, side_stream=side[k % len(side)] if side else None)
+            images.append(image)
+            states.append(state)
+        done = [sd.record_event() for sd in side]
+        return chunk, images, states, done, args          # (args: the side streams read them; alive until the batch is finished)
+
+    def finish(job, trunks):
+        """The batch's images, once its passes have run and its instance counters say nothing overflowed (else: once more, alone)."""
+        while True:
+            chunk, images, states, done, _args = job
+            for ev in done:
+                torch.cuda.current_stream(dev).wait_event(ev)      # whoever reads the images does so on the current stream
+            if not resolve_deferred(states)[1]:
+                return images
+            job = launch(chunk, trunks)      # an instance buffer overflowed, the capacity hint is raised: once more
+
     with torch.no_grad():
         # the generators' feature-only half does not depend on the frame: once per call for all anchors
         trunks = generator_trunks(pc) if mode in (GenerateMode.DECODING_AS_IS, GenerateMode.TRAINING_FULL_PRECISION) else None
+        # software pipeline over the batches: batch i + 1's generation (MFMA / HBM: the current stream) is queued before batch i's
+        # counters are waited for, so it runs next to batch i's compositing (vector ALU: the side streams)
+        pending = None
         for i in range(0, len(frames), batch):
-            chunk = frames[i:i + batch]
-            while True:
-                geometry = prefilter_geometry(pc)
-                visible = prefilter_voxels_many(chunk, pc, pipe, bg_color, geometry=geometry)
-                gss_list = generate_neural_gaussians_many(chunk, pc, visible, mode, dense=True, anchors=geometry[0],
-                                                          trunks=trunks)
-                images, states = [], []
-                # the frames of a batch are independent pipelines: dealt to two side streams (rasterizer._side_streams), one frame's
-                # kernel boundaries and tails are filled by the next frame's kernels
-                from ..rasterizer import _side_streams
-                dev = pc._anchor.device
-                side = _side_streams(dev, len(chunk))
-                main = torch.cuda.current_stream(dev) if side else None
-                args = [(gss.xyz.contiguous(), gss.color.contiguous(), gss.opacity.contiguous(), gss.scaling.contiguous(), gss.rot.contiguous())
-                        for gss in gss_list]
-                for sd in side:
-                    sd.wait_stream(main)
-                for k, (f, a) in enumerate(zip(chunk, args)):
-                    cs = settings_to_c(raster_settings_for(f, pc, pipe, bg_color, scaling_modifier))
-                    image, _, state = raster_forward(cs, *a, pair=True, sync=False, side_stream=side[k % len(side)] if side else None)
-                    images.append(image)
-                    states.append(state)
-                for sd in side:
-                    main.wait_stream(sd)
-                if not resolve_deferred(states)[1]:
-                    break              # else: an instance buffer overflowed, the capacity hint is raised: once more
-            yield from images
+            job = launch(frames[i:i + batch], trunks)
+            if pending is not None:
+                yield from finish(pending, trunks)
+            pending = job
+        if pending is not None:
+            yield from finish(pending, trunks)
