@@ -174,6 +174,7 @@ _SIGNATURES = {
     "gsvc_noise_quant_forward": (C.c_int, [_vp, _vp, C.c_float, _vp, C.POINTER(C.c_int64), C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "gsvc_noise_quant_backward": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, _vp, C.POINTER(C.c_int64), C.c_int32, C.c_int32, _vp, _vp,
                                             _vp]),
+    "gsvc_ste_quant_forward": (C.c_int, [_vp, _vp, C.c_float, _vp, C.POINTER(C.c_int64), C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "gsvc_gen_tail_forward": (C.c_int, [_vp] * 7 + [C.POINTER(C.c_float), C.POINTER(C.c_float), _i64, C.c_int32] + [_vp] * 7),
     "gsvc_gen_tail_backward": (C.c_int, [_vp] * 7 + [C.POINTER(C.c_float), C.POINTER(C.c_float), _i64, C.c_int32] + [_vp] * 12),
     "gsvc_gather_rows_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),

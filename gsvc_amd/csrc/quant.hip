@@ -252,9 +252,64 @@ __global__ void __launch_bounds__(256) k_ste_binary_bwd_many(SteTables t, const 
     }
 }
 
+// STE_multistep of a render's rows (reference utils/encodings.py:395-420 as guassian.py:205-207 calls it: the centre's numerator is
+// the mean of the WHOLE parameter, handed in; the bounds are truncated to integers): bounds[r] = trunc(x_mean / mean_r(q) -+ 15000)
+__global__ void __launch_bounds__(256) k_ste_bounds(const float *__restrict__ part, int nbx, QSeg seg, int has_q, float q_scalar,
+                                                    const float *__restrict__ x_mean, float *__restrict__ bounds)
+{
+    __shared__ float red[4];
+    for (int r = 0; r < seg.R; r++) {
+        float sq = 0.f;
+        for (int b = threadIdx.x; b < nbx; b += 256) sq += part[((size_t)r * nbx + b) * 2 + 1];
+        sq = q_block_sum(sq, red);
+        if (threadIdx.x == 0) {
+            const float rows = (float)(seg.off[r + 1] - seg.off[r]);
+            const float qm = has_q ? sq / fmaxf(rows, 1.f) : q_scalar;
+            const float c = x_mean[0] / qm;
+            bounds[2 * r] = truncf(c - Q_CLAMP_STEPS);
+            bounds[2 * r + 1] = truncf(c + Q_CLAMP_STEPS);
+        }
+    }
+}
+
+// y = x1 + (round(x1 / Q) Q - x1), x1 = clamp(x / Q, lo_r, hi_r) Q — the expression of the tensor form, operation by operation
+__global__ void __launch_bounds__(256) k_ste_fwd(const float *__restrict__ x, const float *__restrict__ q, float q_scalar,
+                                                 const float *__restrict__ bounds, QSeg seg, int C, float *__restrict__ y)
+{
+#pragma clang fp contract(off)
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = seg.off[seg.R] * C;
+    if (e >= n) return;
+    const long long row = e / C;
+    const int r = q_render_of(seg, row);
+    const float Q = q ? q[row] : q_scalar;
+    const float x1 = fminf(fmaxf(x[e] / Q, bounds[2 * r]), bounds[2 * r + 1]) * Q;
+    const float rq = rintf(x1 / Q) * Q;
+    y[e] = x1 + (rq - x1);
+}
+
 }  // namespace gsvc
 
 using namespace gsvc;
+
+extern "C" int gsvc_ste_quant_forward(const float *x, const float *q_rows, float q_scalar, const float *x_mean,
+                                      const int64_t *row_offsets_host, int32_t R, int32_t C, float *scratch, float *bounds, float *y,
+                                      void *stream)
+{
+    QSeg seg;
+    GSVC_REQUIRE(row_offsets_host && q_fill(row_offsets_host, R, seg) && C > 0, "ste_quant_forward: 1..8 renders, C > 0");
+    GSVC_REQUIRE(scratch && bounds && x_mean, "ste_quant_forward: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const long long rows = seg.off[R];
+    GSVC_REQUIRE(rows == 0 || (x && y), "ste_quant_forward: NULL pointer");
+    const int nbx = q_nbx(seg);
+    ProfScope _p("k_ste_quant", s);
+    if (q_rows) hipLaunchKernelGGL(k_quant_sums, dim3(nbx, R), dim3(256), 0, s, x, q_rows, seg, C, scratch);
+    hipLaunchKernelGGL(k_ste_bounds, dim3(1), dim3(256), 0, s, scratch, nbx, seg, q_rows ? 1 : 0, q_scalar, x_mean, bounds);
+    if (rows)
+        hipLaunchKernelGGL(k_ste_fwd, dim3((unsigned)((rows * C + 255) / 256)), dim3(256), 0, s, x, q_rows, q_scalar, bounds, seg, C, y);
+    return check_launch("ste_quant_forward");
+}
 
 extern "C" int64_t gsvc_noise_quant_scratch_floats(const int64_t *row_offsets_host, int32_t R)
 {

@@ -655,6 +655,26 @@ def _seg_noise_quant(x, Q, seg):
 
 
 def _seg_ste(x, Q, seg, x_mean):
+    if (x.is_cuda and x.dtype == torch.float32 and x.shape[0] > 0 and x[0].numel() <= 256 and 1 <= seg.R <= 8
+            and isinstance(x_mean, torch.Tensor) and x_mean.is_cuda and x_mean.numel() == 1 and x_mean.dtype == torch.float32
+            and (not isinstance(Q, torch.Tensor) or (Q.dtype == torch.float32 and Q.numel() == x.shape[0])) and not switches.NO_FUSED_STE):
+        # three launches (the step's per-render mean, the truncated bounds, the quantiser) instead of a dozen tensor operations;
+        # the same expression operation by operation (csrc/quant.hip k_ste_fwd).  The result carries no graph: the reference
+        # detaches it (guassian.py:205-207)
+        import ctypes as C
+        from . import _lib
+        with torch.no_grad():
+            x2 = x.detach().reshape(x.shape[0], -1).contiguous()
+            q = Q.detach().reshape(-1).contiguous() if isinstance(Q, torch.Tensor) else None
+            R = seg.R
+            offs = (C.c_int64 * (R + 1))(*[int(v) for v in seg.bounds])
+            L = _lib.lib()
+            scratch = torch.empty(max(int(L.gsvc_noise_quant_scratch_floats(offs, R)), 1) + 2 * R, dtype=torch.float32, device=x.device)
+            y = torch.empty_like(x2)
+            _lib.check(L.gsvc_ste_quant_forward(_lib.ptr(x2), _lib.ptr(q), 0.0 if q is not None else float(Q), _lib.ptr(x_mean.detach()), offs, R,
+                                                x2.shape[1], _lib.ptr(scratch), C.c_void_p(scratch.data_ptr() + 4 * (scratch.numel() - 2 * R)),
+                                                _lib.ptr(y), _lib.current_stream(x.device)), "gsvc_ste_quant_forward")
+        return y.view(x.shape)
     lo, hi = _seg_bounds(x, Q, seg, x_mean)
     x = torch.clamp(x / Q, min=torch.trunc(lo), max=torch.trunc(hi)) * Q
     return (x + (torch.round(x / Q) * Q - x).detach()).detach()

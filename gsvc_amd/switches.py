@@ -11,7 +11,7 @@ Code reads the module attributes (``switches.NO_MLP_CHAIN``); a process that cha
     GSVC_NO_SHARED_INPUT / GSVC_NO_ACCUM_MANY   no multi-product linear launches;  GSVC_MANY_MIN_ROWS  rows from which they are used
     GSVC_NO_DECODE_CHAIN   the decoder loop through cached trunks + per-layer heads
     GSVC_CTX_ALL_ROWS      the entropy context's dist networks on every distinct anchor (not only the rate sample's rows)
-    GSVC_NO_FUSED_CTX / _GRID / _STATIS / _RATE / _GATHER / _PLAN, GSVC_NO_RANKED_GATHER, GSVC_NO_PACKED_GRID   tensor forms of those pieces
+    GSVC_NO_FUSED_CTX / _GRID / _STATIS / _RATE / _GATHER / _PLAN / _STE, GSVC_NO_RANKED_GATHER, GSVC_NO_PACKED_GRID   tensor forms of those pieces
     GSVC_NO_GRID_MANY      Mix3d2dEncoding's four hash grids as four launches each way (one launch otherwise)
     GSVC_NO_FILM_SHARE     FiLM networks per (view, anchor) instead of per (frame, anchor)
     GSVC_NO_VIEW_SHARE     FULL_PRECISION / STE_ENTROPY steps: the generators per (view, anchor) although the two opposite views of a frame
@@ -25,7 +25,7 @@ Code reads the module attributes (``switches.NO_MLP_CHAIN``); a process that cha
 import os
 
 _FLAGS = ("NO_MLP_CHAIN", "NO_MLP_FUSED", "NO_QUANT_CHAIN", "NO_SHARED_INPUT", "NO_ACCUM_MANY", "NO_DECODE_CHAIN", "CTX_ALL_ROWS",
-          "NO_FUSED_CTX", "NO_FUSED_GRID", "NO_FUSED_STATIS", "NO_FUSED_RATE", "NO_FUSED_GATHER", "NO_FUSED_PLAN", "NO_RANKED_GATHER",
+          "NO_FUSED_CTX", "NO_FUSED_GRID", "NO_FUSED_STATIS", "NO_FUSED_RATE", "NO_FUSED_GATHER", "NO_FUSED_PLAN", "NO_FUSED_STE", "NO_RANKED_GATHER",
           "NO_PACKED_GRID", "NO_GRID_MANY", "NO_FILM_SHARE", "NO_VIEW_SHARE", "NO_LATE_ROWS", "NO_RATE_OVERLAP", "NO_PREFETCH", "NO_EARLY_PLAN", "EARLY_PLAN")
 
 

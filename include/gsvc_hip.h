@@ -395,6 +395,13 @@ int gsvc_noise_quant_backward(const float *grad_y, const float *x, const float *
                               const float *centre, const int64_t *row_offsets_host, int32_t R, int32_t C, float *grad_x,
                               float *grad_q_rows, void *stream);
 
+/* STE_multistep over the rows of R renders (reference utils/encodings.py:395-420 with input_mean given, as ortho_gaussian_renderer/
+ * guassian.py:205-207 calls it): y = x1 + (round(x1 / Q) Q - x1), x1 = clamp(x / Q, trunc(c_r - 15000), trunc(c_r + 15000)) Q,
+ * c_r = x_mean / (mean of Q over render r's rows); x_mean: one float on the device (the whole parameter's mean).  No backward: the
+ * caller detaches the result, as the reference does.  scratch: gsvc_noise_quant_scratch_floats floats; bounds: 2 R floats (out). */
+int gsvc_ste_quant_forward(const float *x, const float *q_rows, float q_scalar, const float *x_mean, const int64_t *row_offsets_host,
+                           int32_t R, int32_t C, float *scratch, float *bounds, float *y, void *stream);
+
 /* Tail of the anchor -> neural-Gaussian generation for un-compacted renders (reference
  * ortho_gaussian_renderer/guassian.py:262-296: opacity mask, sigmoid scaling, normalised rotation, world position, bound
  * clamp), n = rows*K Gaussians, Gaussian i belongs to anchor row i / K.  Inputs: opacity_raw[n], offset_mask[n],

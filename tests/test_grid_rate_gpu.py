@@ -868,3 +868,33 @@ def test_bit_packed_tables_give_the_float_tables_lookup(monkeypatch):
     monkeypatch.delenv("GSVC_NO_PACKED_GRID")
     y = enc(x)                                      # with autograd the float tables are used (their gradient is needed)
     assert "MixGridEncode" in type(y.grad_fn).__name__ and torch.equal(y.detach(), packed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,per_row_q", [((20000, 50), True), ((20000, 6), True), ((12000, 10, 3), True), ((9000, 50), False)])
+def test_fused_ste_quantiser_equals_the_tensor_expression(monkeypatch, shape, per_row_q):
+    """gsvc_ste_quant_forward (STE_multistep over the rows of the step's renders: per-render mean step, truncated bounds, clamp, round)
+    against the tensor expression it replaces (gsvc_amd/generate.py _seg_ste; reference utils/encodings.py:395-420): bit for bit, with
+    rows beyond the 15 000-step bound in the data (the clamp is active) and both forms of the step (per row / one number)."""
+    import gsvc_amd.generate as G
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(shape, device="cuda", generator=g) * 3.0
+    rows = shape[0]
+    Q = (torch.rand(rows, device="cuda", generator=g) * 0.5 + 1e-3).view([rows] + [1] * (len(shape) - 1)) if per_row_q else 0.2
+    x[5] = 3.0e4          # far beyond mean / mean(Q) + 15000 steps for small steps
+    x[7] = -3.0e4
+    x_mean = x.mean()
+    seg = G._Segments([rows // 4, rows // 3, 0, rows - rows // 4 - rows // 3], x.device)
+    res = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("GSVC_NO_FUSED_STE", raising=False)
+        else:
+            monkeypatch.setenv("GSVC_NO_FUSED_STE", "1")
+        res.append(G._seg_ste(x, Q, seg, x_mean))
+    a, b = res
+    assert a.shape == b.shape == x.shape and not a.requires_grad
+    assert torch.equal(a, b), ((a - b).abs().max().item(), (a != b).float().mean().item())
+    # the clamp acted where the data asked for it
+    q5 = Q[5].item() if per_row_q else Q
+    assert abs(a[5].reshape(-1)[0].item()) < 3.0e4 or q5 * 15000 > 3.0e4
