@@ -1249,19 +1249,23 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
         rows_of = (lambda t: t) if ec_row is None else (lambda t: t.index_select(0, ec_row))  # noqa: E731
         Q_feat, Q_scaling, Q_offsets = (Q_feat * rows_of(ec.Q_feat_adj).detach(), Q_scaling * rows_of(ec.Q_scaling_adj).detach(),
                                         Q_offsets * rows_of(ec.Q_offsets_adj).detach())
+        # the three parameters' means in one pass (gsvc_param_means: what the rate's clamp reads too) instead of three reductions
+        # and an exp pass over every anchor; they only place the +-15 000-step bounds
+        pm = _param_means(pc) if (vis.is_cuda and not switches.NO_FUSED_STE) else None
+        mean_feat = pm[0:1] if pm is not None else pc._anchor_feat.mean()
         if seg_u is None:
-            feat = _seg_ste(feat, Q_feat, seg, pc._anchor_feat.mean())
+            feat = _seg_ste(feat, Q_feat, seg, mean_feat)
         else:
             # the step of (frame, anchor) is the anchor's; the clamp's integer bounds (mean / mean step -+ 15000, truncated) come from
             # the frame's rows instead of each view's (they differ by an anchor in 500): the same integers unless the centre sits
             # within 1e-3 of an integer, and the clamp only acts 15000 steps from the mean
-            feat_u = _seg_ste(feat_u, (BASE_Q_FEAT * ec.Q_feat_adj.detach()).repeat(R // 2, 1), seg_u, pc._anchor_feat.mean())
+            feat_u = _seg_ste(feat_u, (BASE_Q_FEAT * ec.Q_feat_adj.detach()).repeat(R // 2, 1), seg_u, mean_feat)
             feat = feat_u.index_select(0, row_of)      # (detached: the rate reads it per view row)
 
         def rows_work():
             nonlocal grid_offsets, grid_scaling, rates
-            grid_scaling = _seg_ste(grid_scaling, Q_scaling, seg, pc.get_scaling.mean())
-            grid_offsets = _seg_ste(grid_offsets, Q_offsets.unsqueeze(1), seg, pc._offset.mean())
+            grid_scaling = _seg_ste(grid_scaling, Q_scaling, seg, pm[1:2] if pm is not None else pc.get_scaling.mean())
+            grid_offsets = _seg_ste(grid_offsets, Q_offsets.unsqueeze(1), seg, pm[2:3] if pm is not None else pc._offset.mean())
             rates = rate_now_or_later()
     else:
         raise ValueError(f"Unknown mode {mode}")
