@@ -18,6 +18,31 @@ def save(name, **arrays):
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+GRAD_ROW_STRIDE = 5          # rows of a weight-gradient matrix kept (coprime to the kernels' 16-row tiles)
+ROW_STRIDE = 16
+WIDE_STRIDE = 32
+
+
+def grads_of(named_params, out, pre, rows=True):
+    """Every parameter's gradient: strided rows of the matrices, small tensors whole, float64 sum / abs-sum of all of it."""
+    for name, p in named_params:
+        g = p.grad
+        if g is None:
+            continue
+        g = g.detach()
+        out[f"{pre}sum::{name}"] = np.array([float(g.double().sum()), float(g.double().abs().sum()), float(g.abs().max())])
+        if not rows:
+            continue
+        if name.startswith("_"):                                  # per-anchor tensors: every 16th anchor
+            out[f"{pre}grad::{name}"] = g[::ROW_STRIDE]
+        elif name.endswith("params"):                             # hash tables: every 4th row
+            out[f"{pre}grad::{name}"] = g[::4]
+        elif g.dim() == 2 and g.numel() > 2048:
+            out[f"{pre}grad::{name}"] = g[::GRAD_ROW_STRIDE]
+        else:
+            out[f"{pre}grad::{name}"] = g
+
+
 class RandomTape:
     """Records every tensor produced by torch.rand_like / Tensor.uniform_ so GPU tests can replay them."""
 

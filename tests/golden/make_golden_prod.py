@@ -22,34 +22,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from tests.golden import _ref_import, seeded  # noqa: E402
-from tests.golden.make_golden_common import save  # noqa: E402
+from tests.golden.make_golden_common import GRAD_ROW_STRIDE, ROW_STRIDE, WIDE_STRIDE, grads_of, save  # noqa: E402
 
 mode_ctx = _ref_import.install(rasterizer=True)
 
-GRAD_ROW_STRIDE = 5          # rows of a weight-gradient matrix kept (coprime to the kernels' 16-row tiles)
-ROW_STRIDE = 16
-WIDE_STRIDE = 32
 RATE_WEIGHT = 50.0           # weight of bit_per_param in the entropy case's scalar
-
-
-def grads_of(named_params, out, pre, rows=True):
-    """Every parameter's gradient: strided rows of the matrices, small tensors whole, float64 sum / abs-sum of all of it."""
-    for name, p in named_params:
-        g = p.grad
-        if g is None:
-            continue
-        g = g.detach()
-        out[f"{pre}sum::{name}"] = np.array([float(g.double().sum()), float(g.double().abs().sum()), float(g.abs().max())])
-        if not rows:
-            continue
-        if name.startswith("_"):                                  # per-anchor tensors: every 16th anchor
-            out[f"{pre}grad::{name}"] = g[::ROW_STRIDE]
-        elif name.endswith("params"):                             # hash tables: every 4th row
-            out[f"{pre}grad::{name}"] = g[::4]
-        elif g.dim() == 2 and g.numel() > 2048:
-            out[f"{pre}grad::{name}"] = g[::GRAD_ROW_STRIDE]
-        else:
-            out[f"{pre}grad::{name}"] = g
 
 
 with mode_ctx:
@@ -89,7 +66,10 @@ with mode_ctx:
            "meta::strides": np.array([ROW_STRIDE, WIDE_STRIDE, GRAD_ROW_STRIDE])}
 
     cases = (("f0", "f", GenerateMode.TRAINING_FULL_PRECISION), ("b0", "b", GenerateMode.TRAINING_FULL_PRECISION),
-             ("f2", "f", GenerateMode.TRAINING_ENTROPY))
+             ("f2", "f", GenerateMode.TRAINING_ENTROPY),
+             # the other two phases at production widths (guassian.py:172-176 fixed-step noise, :197-221 straight-through rounding
+             # of detached attributes + the sampled rate)
+             ("f1", "f", GenerateMode.TRAINING_QUANTIZED), ("f3", "f", GenerateMode.TRAININ_STE_ENTROPY))
     dL_full = seeded.image_weights(sc["H"], sc["W"], sc["seed"])
     for tag, view, md in cases:
         pre = tag + "::"

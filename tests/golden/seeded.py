@@ -105,5 +105,24 @@ def image_weights(H: int, W: int, seed: int) -> torch.Tensor:
     return torch.randn(3, H, W, generator=_gen("dL_dimage", seed))
 
 
+def gt_image(H: int, W: int, idx: int, seed: int) -> torch.Tensor:
+    """Ground-truth picture [3, H, W] of frame ``idx`` in [0, 1]: a coarse random grid bilinearly enlarged (smooth, so that the
+    structural-similarity term is not degenerate) plus a little fine noise."""
+    g = _gen(f"gt_image_{idx}", seed)
+    coarse = torch.rand(1, 3, max(2, H // 12), max(2, W // 12), generator=g)
+    img = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=True)[0]
+    return (img + 0.05 * torch.randn(3, H, W, generator=g)).clamp(0, 1).contiguous()
+
+
+def optical_flow(H: int, W: int, idx: int, seed: int) -> torch.Tensor:
+    """Backward optical flow [2, H, W] in pixels per frame between frames ``idx`` and ``idx + 1`` (what the reference's
+    FrameCubeDataset.get_optical_flow hands to calc_optical_loss)."""
+    return torch.randn(2, H, W, generator=_gen(f"flow_{idx}", seed)) * 1.5
+
+
+STEP = dict(lmbda=0.004, opacity_reg=0.003,            # opacity_reg is 0 by default: non-zero here so that its weight is pinned too
+            iterations={0: 1601, 1: 12001, 2: 16001, 3: 35001})      # one iteration inside each phase of the default schedule
+
+
 def rows(t: torch.Tensor, stride: int):
     return t[::stride]

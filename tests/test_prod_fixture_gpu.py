@@ -29,43 +29,15 @@ def _load():
 
 @pytest.fixture(scope="module")
 def prod():
-    from tests.golden import seeded
-    from gsvc_amd.arguments import ModelParams
-    from gsvc_amd.frame import SyntheticFrameCube
-    from gsvc_amd.model import GaussianModel
+    from tests import _prod_model
     g = _load()
-    sc, P = seeded.SCENE, seeded.PROD
-    fn = seeded.frame_numbers(sc["H"], sc["W"], sc["T"], sc["frame"])
-    mp = ModelParams()
-    mp.threshold = sc["threshold"]
-    pc = GaussianModel(mp, feat_dim=P["feat_dim"], n_offsets=P["n_offsets"], voxel_size=0.001, update_depth=3, update_init_factor=16,
-                       update_hierachy_factor=4, use_feat_bank=False, n_features_per_level=P["n_features_per_level"],
-                       log2_hashmap_size=P["log2_hashmap_size"], log2_hashmap_size_2D=P["log2_hashmap_size_2D"],
-                       resolutions_list=P["resolutions_list"], resolutions_list_2D=P["resolutions_list_2D"], device="cuda")
-    pc.update_anchor_bound(fn["x_min"], fn["y_min"], fn["z_min"])
-    for name, t in seeded.anchors(sc["A"], fn, sc["threshold"], sc["seed"]).items():
-        setattr(pc, name, torch.nn.Parameter(t.cuda(), requires_grad=name not in ("_rotation", "_opacity")))
-    seeded.fill_parameters(pc, sc["seed"])
-    # the same model as the reference's: same state_dict keys, same numbers in them
-    sums = {k[len("param_sum::"):]: g[k] for k in g.files if k.startswith("param_sum::")}
-    mine = {k: v for k, v in pc.state_dict().items() if v.is_floating_point() and v.numel()}
-    assert set(mine) == set(sums), set(mine) ^ set(sums)
-    for k, v in mine.items():
-        assert abs(float(v.double().sum()) - sums[k][0]) <= 1e-9 * max(1.0, sums[k][1]), k
-    # the frame's numbers: SyntheticFrameCube follows the same formulas (reference frame_cube/frame.py:92-101,156-190)
-    fr = SyntheticFrameCube(sc["H"], sc["W"], sc["T"]).get_dummy_frame(sc["frame"])
-    assert (fr.x_min, fr.y_min, fr.scale, fr.z) == (fn["x_min"], fn["y_min"], fn["scale"], fn["z"])
-    assert torch.equal(fr.view_matrix.cpu(), fn["view_matrix"]) and torch.equal(fr.view_matrix_s.cpu(), fn["view_matrix_s"])
+    pc, _, fn = _prod_model.build(g)
     return pc, g, fn
 
 
 def _frame(fn, view):
-    from tests.golden import seeded
-    sc = seeded.SCENE
-    vm, vms = (fn["view_matrix"], fn["view_matrix_s"]) if view == "f" else (fn["view_matrix_s"], fn["view_matrix"])
-    return SimpleNamespace(image_id=sc["frame"], plane="xy", image=None, x_min=fn["x_min"], y_min=fn["y_min"], z=fn["z"],
-                           image_width=sc["W"], image_height=sc["H"], view_matrix=vm.clone(), view_matrix_s=vms.clone(),
-                           scale=fn["scale"], cam_pos=fn["cam_pos"].clone())
+    from tests import _prod_model
+    return _prod_model.frame(fn, view)
 
 
 def _bits(packed, n):
@@ -79,7 +51,7 @@ def _close(got, want, tol, what):
     assert got.shape == want.shape and err <= tol, (what, err, scale)
 
 
-CASES = {"f0": ("f", 0), "b0": ("b", 0), "f2": ("f", 2)}
+CASES = {"f0": ("f", 0), "b0": ("b", 0), "f2": ("f", 2), "f1": ("f", 1), "f3": ("f", 3)}
 
 
 def _check(pc, g, fn, tag, res, draws, via_chain):
@@ -114,6 +86,9 @@ def _check(pc, g, fn, tag, res, draws, via_chain):
         want_r = g[pre + "radii"].astype(np.int32)
         off = radii != want_r                  # ceil(3 sqrt(lambda)) of a Gaussian whose covariance differs in the last bits
         assert off.mean() <= 1e-3 and (np.abs(radii - want_r)[off] <= 1).all(), (int(off.sum()), P)
+        # the integers are bit-exact for identical inputs (tests/test_raster_gpu.py); here the Gaussians come from CPU / GPU MLPs
+        print(f"[{tag}] radii differing by one: {int(off.sum())} of {P} rows; num_rendered {int(res.num_rendered)} vs {instances}; "
+              f"active {int(res.active_gaussains)} vs {active}")
         assert abs(int(res.active_gaussains) - active) <= max(2, int(1e-3 * active))
         assert abs(int(res.num_rendered) - instances) <= max(4, int(1e-3 * instances)), (int(res.num_rendered), instances)
         assert torch.equal(res.visibility_filter, res.radii > 0)
@@ -121,7 +96,7 @@ def _check(pc, g, fn, tag, res, draws, via_chain):
     ok = ~_bits(g[pre + "borderline"], H * W).reshape(H, W)
     err = np.abs(img - g[pre + "image"])[:, ok]
     assert (err > 1e-4).mean() <= 2e-3 and err.max() < 5e-2, (float((err > 1e-4).mean()), float(err.max()))
-    if mode_value == 2:
+    if mode_value in (2, 3):
         assert res.entropy_constrained
         for nm in ("bit_per_param", "bit_per_feat_param", "bit_per_scaling_param", "bit_per_offsets_param"):
             want = float(g[pre + nm])
@@ -129,7 +104,7 @@ def _check(pc, g, fn, tag, res, draws, via_chain):
     # ---- backward of the fixture's scalar
     dL = (seeded.image_weights(H, W, sc["seed"]) * torch.from_numpy(ok).float()).cuda()
     loss = (res.rendered_image * dL).sum()
-    if mode_value == 2:
+    if mode_value in (2, 3):
         loss = loss + float(g["meta::rate_weight"]) * res.bit_per_param
     pc.zero_grad()
     loss.backward()
@@ -173,10 +148,10 @@ def _check(pc, g, fn, tag, res, draws, via_chain):
             assert got.shape == want.shape, name
             assert float(np.abs(got - want).max()) <= 1e-3 * smax, (name, float(np.abs(got - want).max()), smax)
         checked += 1
-    assert checked >= (40 if mode_value == 0 else 60), checked
+    assert checked >= {0: 40, 1: 40, 2: 60, 3: 50}[mode_value], checked
 
 
-@pytest.mark.parametrize("tag", ["f0", "b0", "f2"])
+@pytest.mark.parametrize("tag", ["f0", "b0", "f2", "f1", "f3"])
 def test_render_matches_the_reference_render(prod, tag):
     """gsvc_amd.ortho_gaussian_renderer.render (prefilter_voxel -> generate_neural_gaussians -> rasterizer: the reference-shaped
     per-render path) against the reference's render()."""
@@ -195,7 +170,7 @@ def test_render_matches_the_reference_render(prod, tag):
     _check(pc, g, fn, tag, res, draws, via_chain=False)
 
 
-@pytest.mark.parametrize("tag", ["f0", "f2"])
+@pytest.mark.parametrize("tag", ["f0", "f2", "f1", "f3"])
 def test_chain_kernels_match_the_reference_render(prod, tag):
     """The batched generation pass (render_many, one view, compacted like the reference) takes the whole-network chain kernels
     at these sizes — asserted through the library's per-kernel launch counters — and must reproduce the same fixture: this is
@@ -224,8 +199,9 @@ def test_chain_kernels_match_the_reference_render(prod, tag):
     for k in ("k_trunk_fwd", "k_film_nets_fwd", "k_deform_a_fwd", "k_deform_b_fwd", "k_trunk_bwd", "k_film_nets_bwd", "k_deform_a_bwd",
               "k_deform_b_bwd"):
         assert any(name.startswith(k) and n > 0 for name, (n, _) in launched.items()), (k, sorted(launched))
-    if mode_value == 2:      # the three quant_step networks as one chain launch each way
-        assert launched.get("k_quant_nets_fwd", (0, 0))[0] > 0 and launched.get("k_quant_nets_bwd", (0, 0))[0] > 0, sorted(launched)
+    if mode_value in (2, 3):      # the three quant_step networks as one chain launch each way (STE: the steps are detached, forward only)
+        assert launched.get("k_quant_nets_fwd", (0, 0))[0] > 0, sorted(launched)
+        assert mode_value == 3 or launched.get("k_quant_nets_bwd", (0, 0))[0] > 0, sorted(launched)
 
 
 def test_entropy_context_matches_the_reference_at_production_widths(prod):
