@@ -365,7 +365,7 @@ class StepPlan:
         return self
 
 
-HOST_TIMES = {}        # region -> [calls, seconds] of HOST time, filled when GSVC_HOST_TIMES=1 (tools/scratch/host_regions.py)
+HOST_TIMES = {}        # region -> [calls, seconds] of HOST time, filled when GSVC_HOST_TIMES=1 (tools/ab/host_regions.py)
 _REGION_MODE = 2 if os.environ.get("GSVC_HOST_TIMES") else (1 if os.environ.get("GSVC_REGIONS") else 0)
 
 

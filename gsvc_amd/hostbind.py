@@ -2,7 +2,7 @@
 
 The fitting step is ~170 kernel launches issued from Python; at BASELINE configs[3] sizes the GPU needs 4.4 ms for them and the
 interpreter 5-6 ms, so the step time IS the host's time.  On the two-socket hosts of this pool a process the scheduler left on the
-far socket ran the same step 10-15 % slower (5.7-6.1 vs 5.0-5.3 ms, tools/scratch/host_regions.py under taskset) — every doorbell
+far socket ran the same step 10-15 % slower (5.7-6.1 vs 5.0-5.3 ms, tools/ab/host_regions.py under taskset) — every doorbell
 write, pinned-memory read-back and allocation crosses the socket link.  One rank per GPU binds itself to its GPU's node (what
 ``numactl --cpunodebind`` does from outside; here without a launcher hop, which rocprofv3 forbids on this pool).
 """

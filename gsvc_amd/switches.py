@@ -1,7 +1,7 @@
 """Run-time switches of the hot path, read from the environment ONCE (at import) — not on every call.
 
 Every switch is a diagnostic: it selects the slower / reference-shaped path of one fused piece so that the two can be compared
-(tests, same-process A/B timing: tools/scratch/ab_env.py), or it sizes a resource.  The product runs with none of them set.
+(tests, same-process A/B timing: tools/ab/ab_env.py), or it sizes a resource.  The product runs with none of them set.
 Code reads the module attributes (``switches.NO_MLP_CHAIN``); a process that changes ``os.environ`` afterwards calls ``reload()``
 (tests/conftest.py does after every ``monkeypatch.setenv`` / ``delenv``).
 

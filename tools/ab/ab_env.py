@@ -1,5 +1,5 @@
 """A/B of an environment switch inside ONE process (same model trajectory): alternating timed segments of fitting steps.
-usage: python tools/scratch/ab_env.py VAR valueA valueB"""
+usage: python tools/ab/ab_env.py VAR valueA valueB"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

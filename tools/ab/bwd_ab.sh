@@ -1,8 +1,8 @@
-# k_blend_bwd_tile per launch at cfg-2 and in the fitting step for the library variants given (names of tools/scratch/libgsvc_*.so; "main" = the tree's)
+# k_blend_bwd_tile per launch at cfg-2 and in the fitting step for the library variants given (names of tools/ab/libgsvc_*.so; "main" = the tree's)
 export TMPDIR=/tmp
 REPO=$PWD
 for v in "$@"; do
-  if [ "$v" = main ]; then unset GSVC_LIB_PATH; else export GSVC_LIB_PATH=$REPO/tools/scratch/libgsvc_$v.so; fi
+  if [ "$v" = main ]; then unset GSVC_LIB_PATH; else export GSVC_LIB_PATH=$REPO/tools/ab/libgsvc_$v.so; fi
   OUT=$REPO/gpurun_out/bwdab_$v; mkdir -p $OUT
   (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python3 $REPO/bench.py --workload raster_fwdbwd --no-cpu-baseline > $OUT/run.log 2>&1)
   f=$(find $OUT/raw -name "*kernel_stats.csv" | head -1)

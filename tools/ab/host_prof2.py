@@ -1,5 +1,5 @@
 """cProfile of the fitting step on BOTH host threads: the main thread (forward, optimizer) and the autograd engine's thread (the
-custom backward functions), by cumulative and by own time.  usage: python tools/scratch/host_prof2.py [cfg3]"""
+custom backward functions), by cumulative and by own time.  usage: python tools/ab/host_prof2.py [cfg3]"""
 import cProfile, os, pstats, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,10 +1,10 @@
 # per-launch averages of the kernels matching PATTERN at cfg-2 and in the one-stream fitting step, for library variants:
-#   bash tools/scratch/kern_ab.sh 'k_preprocess|k_scatter|k_sort' main varA varB      ("main" = the tree's library)
+#   bash tools/ab/kern_ab.sh 'k_preprocess|k_scatter|k_sort' main varA varB      ("main" = the tree's library)
 export TMPDIR=/tmp
 REPO=$PWD
 PAT=$1; shift
 for v in "$@"; do
-  if [ "$v" = main ]; then unset GSVC_LIB_PATH; else export GSVC_LIB_PATH=$REPO/tools/scratch/libgsvc_$v.so; fi
+  if [ "$v" = main ]; then unset GSVC_LIB_PATH; else export GSVC_LIB_PATH=$REPO/tools/ab/libgsvc_$v.so; fi
   OUT=$REPO/gpurun_out/kab_$v; mkdir -p $OUT
   for wl in cfg2 step; do
     if [ $wl = cfg2 ]; then ARGS="--workload raster_fwdbwd --no-cpu-baseline"; else ARGS="--workload train_step --steps 10 --warmup 2 --pretrain 30 --no-cpu-baseline"; fi

@@ -1,4 +1,4 @@
-# per-launch durations of the kernels matching PATTERN in one fitting step (one raster stream): bash tools/scratch/kt_filter.sh PATTERN
+# per-launch durations of the kernels matching PATTERN in one fitting step (one raster stream): bash tools/ab/kt_filter.sh PATTERN
 PAT=$1
 REPO=$PWD; OUT=$REPO/gpurun_out/ktf; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp

@@ -1,4 +1,4 @@
-# kernel trace of the train step only (no PMC): bash tools/scratch/kt_step.sh <tag>
+# kernel trace of the train step only (no PMC): bash tools/ab/kt_step.sh <tag>
 TAG=${1:-dev}
 REPO=$PWD; OUT=$REPO/gpurun_out/kt_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp

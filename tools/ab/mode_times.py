@@ -1,5 +1,5 @@
 """Fitting-step time per phase of the schedule (FULL_PRECISION, QUANTIZED, TRAINING_ENTROPY, STE_ENTROPY) at the headline shape,
-one process, same model.  usage: python tools/scratch/mode_times.py [cfg3]"""
+one process, same model.  usage: python tools/ab/mode_times.py [cfg3]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
