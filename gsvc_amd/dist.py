@@ -152,9 +152,12 @@ class GradReducer:
         pad[:n] = idx
         self._sparse = (pad, n, int(cap), {id(p) for p in params})
 
-    def arm(self, params):
+    def arm(self, params, phase=None):
         """Call before backward with the step's parameters (new Parameter objects, e.g. after densification, get hooks;
-        hooks of parameters that are gone are dropped)."""
+        hooks of parameters that are gone are dropped).  ``phase``: anything that changes WHICH parameters receive a gradient
+        (the generation mode: TRAININ_STE_ENTROPY renders from detached attributes, so _scaling / _offset / _anchor_feat get
+        none) — part of the order's key, so that a new phase agrees on a new order in its first step; an order carried over
+        from a phase where such a parameter came early would stall every launch behind a hook that never fires."""
         self._params = [p for p in params if p.requires_grad]
         if world_size() == 1 or not self.enabled:
             self._armed = False
@@ -166,8 +169,8 @@ class GradReducer:
             if id(p) not in self._hooked and p.numel() >= self.SMALL:
                 self._hooked[id(p)] = (p, p.register_post_accumulate_grad_hook(self._on_grad))
         self._hook_list = [p for p in self._params if id(p) in self._hooked]
-        key = tuple(p.numel() for p in self._hook_list)
-        if key != self._order_key:          # another set of large parameters (densification changes their sizes): agree again
+        key = (tuple(p.numel() for p in self._hook_list), phase)
+        if key != self._order_key:          # another set of large parameters (densification changes their sizes) or phase: agree again
             self._order, self._order_key = None, key
         self._index = {id(p): i for i, p in enumerate(self._hook_list)}
         self._pending, self._ready, self._seen, self._next = [], {}, [], 0

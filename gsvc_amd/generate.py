@@ -833,8 +833,10 @@ _IOTA = {}
 
 
 def _iota(dev, n):
-    """arange(n) int64 on ``dev`` as a view of a cached, growing tensor (no launch per step)."""
-    key = (dev.type, dev.index)
+    """arange(n) int64 on ``dev`` as a view of a cached, growing tensor (no launch per step), one per stream: the tensor is created
+    by, and when it grows freed to the pool of, the stream that asked — handing one stream's to another would need record_stream
+    bookkeeping for nothing."""
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).stream_id if dev.type == "cuda" else 0)
     t = _IOTA.get(key)
     if t is None or t.shape[0] < n:
         t = _IOTA[key] = torch.arange(max(n, 1 << 16), dtype=torch.int64, device=dev)
@@ -949,12 +951,50 @@ def small_work_stream(dev):
     rs = _RATE_STREAM.get(dev.index)
     if rs is None:
         rs = _RATE_STREAM[dev.index] = torch.cuda.Stream(device=dev)
-        # a parameter that both this stream's nodes and the step's stream's nodes use gets its gradient from two streams: intended
-        # (the engine orders them), so the engine's one-time warning about it says nothing here
-        warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-        if warn_off is not None:
-            warn_off(False)
     return rs
+
+
+class two_stream_backward:
+    """Scope of a backward whose graph has nodes on the small-work stream: a parameter that both that stream's nodes and the step's
+    stream's nodes use gets its gradient from two streams — intended (the engine orders them), so the engine's warning about it
+    is switched off for the duration of THIS backward only (it was switched off process-wide at first use)."""
+
+    def __enter__(self):
+        self._set = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if self._set is not None:
+            self._set(False)
+
+    def __exit__(self, *exc):
+        if self._set is not None:
+            self._set(True)
+
+
+def record_on(stream, *objs):
+    """``record_stream(stream)`` on every CUDA tensor in ``objs`` (tensors, lists / tuples of them, objects whose attributes hold
+    them; None is skipped).  A tensor allocated on the step's stream and READ on the small-work stream must tell the caching
+    allocator so: autograd releases saved tensors as soon as a node's backward is enqueued, and a block returned to the step's
+    pool while the other stream's kernel is still queued could be handed to — and overwritten by — the next main-stream kernel
+    (ADVICE round 4).  The allocator then holds the block back until the work queued on ``stream`` at the time of the free is done."""
+    seen = set()
+
+    def walk(o, depth):
+        if o is None or id(o) in seen:
+            return
+        seen.add(id(o))
+        if isinstance(o, torch.Tensor):
+            if o.is_cuda:
+                o.record_stream(stream)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                walk(v, depth)
+        elif isinstance(o, dict):
+            for v in o.values():
+                walk(v, depth)
+        elif depth > 0 and hasattr(o, "__dict__") and not isinstance(o, torch.nn.Module):
+            for v in vars(o).values():
+                walk(v, depth - 1)
+    for o in objs:
+        walk(o, 1)
 
 
 def finish_deferred_rate(gss_list):
@@ -967,12 +1007,13 @@ def finish_deferred_rate(gss_list):
     pending = getattr(batch, "deferred_rate", None)
     if pending is None:
         return
-    rate, ready = pending
+    rate, ready, reads = pending
     batch.deferred_rate = None
     dev = gss_list[0].xyz.device
     main = torch.cuda.current_stream(dev)
     rs = small_work_stream(dev)
     rs.wait_event(ready)
+    record_on(rs, *reads)                    # allocated on this stream, read (and saved for a backward that runs) on that one
     with torch.cuda.stream(rs):
         packs = rate()
     main.wait_stream(rs)
@@ -1281,7 +1322,8 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
             # the sampled rate — three small networks on ~10 k rows and a dozen reductions, launch-bound — is issued by the caller
             # BEHIND the rasterizer's launches, on its own stream (finish_deferred_rate): it runs under the compositing kernels
             # forward and, its autograd nodes living on that stream, under the rasterizer's backward
-            deferred.append((rate, torch.cuda.current_stream(vis.device).record_event()))
+            reads = [feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec_row, plan.sel, ec]
+            deferred.append((rate, torch.cuda.current_stream(vis.device).record_event(), reads))
             return rates
         return rate()
 

@@ -11,6 +11,7 @@ from __future__ import annotations
 import os
 
 _BOUND = {}
+_PREVIOUS = {}      # device index -> the affinity mask bind_to_device replaced (what unbind() puts back)
 
 
 def _cpulist(text: str):
@@ -39,7 +40,12 @@ def device_cpus(device_index: int):
 def bind_to_device(device=None) -> bool:
     """Restrict the calling process (this thread and the threads it creates from now on — the autograd engine's among them) to the
     CPUs of the GPU's NUMA node.  Never widens an affinity mask that is already narrower (a launcher's own binding wins); does
-    nothing under GSVC_NO_CPU_BIND=1, off Linux, or when sysfs does not say.  Returns True when a mask was set."""
+    nothing under GSVC_NO_CPU_BIND=1, off Linux, or when sysfs does not say.  Returns True when a mask was set.
+
+    The mask stays until ``unbind()`` (``Trainer.close()`` / leaving ``with Trainer(...)``) puts the previous one back: anything
+    else the process runs meanwhile — entropy coding, OpenMP code, DataLoader workers created later — is limited to that node's
+    cores, and threads that already existed when this was called (an autograd engine thread from an earlier backward) keep
+    their own mask."""
     import torch
     if os.environ.get("GSVC_NO_CPU_BIND") or not hasattr(os, "sched_setaffinity") or not torch.cuda.is_available():
         return False
@@ -54,8 +60,26 @@ def bind_to_device(device=None) -> bool:
             want = have & local
             if want and want != have:
                 os.sched_setaffinity(0, want)
+                _PREVIOUS[idx] = have
                 ok = True
         except OSError:
             ok = False
     _BOUND[idx] = ok
     return ok
+
+
+def unbind(device=None) -> bool:
+    """Put back the affinity mask ``bind_to_device`` replaced (calling thread; threads created while bound keep the narrow mask)."""
+    import torch
+    if not _PREVIOUS:
+        return False
+    idx = next(iter(_PREVIOUS)) if device is None else (device if isinstance(device, int) else (torch.device(device).index or 0))
+    have = _PREVIOUS.pop(idx, None)
+    _BOUND.pop(idx, None)
+    if have is None:
+        return False
+    try:
+        os.sched_setaffinity(0, have)
+        return True
+    except OSError:
+        return False

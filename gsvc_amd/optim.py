@@ -86,8 +86,18 @@ class FusedAdam(torch.optim.Adam):
         cache = self.__dict__.get("_row_cache")
         if cache is not None and cache[0] == sig:
             rows = cache[1]
-            # the moments are replaced together with the parameter (densify.py), or by load_state_dict (same parameter objects)
-            if all((st.get("exp_avg") is r[8] and st.get("step") is r[7]) if (st := self.state.get(r[0])) else r[8] is None for r in rows):
+            # the moments are replaced together with the parameter (densify.py), or by load_state_dict (same parameter objects);
+            # a storage swap under the same Parameter object (module.to(), ``p.data = ...``) or under a moment moves data_ptr():
+            # the raw addresses the kernel writes through are compared too (one integer compare per row), as is
+            # the set of trainable parameters (a requires_grad toggle changes which rows exist)
+            if (all(p.requires_grad for p in (r[0] for r in rows))
+                    and sum(1 for g in self.param_groups for p in g["params"] if p.requires_grad) == len(rows)
+                    and all(r[0].data_ptr() == r[1] and
+                            ((st.get("exp_avg") is r[8] and st.get("step") is r[7] and r[8].data_ptr() == r[2]
+                              and st["exp_avg_sq"].data_ptr() == r[3])
+                             if (st := self.state.get(r[0])) else r[8] is None) for r in rows)
+                    # nobody else moved a step count: the shared host tensor still sums to the rows' own counts
+                    and float(self._step_base.sum()) == float(sum(r[6] for r in rows))):
                 return rows
         rows, beta_key = [], None
         for group in self.param_groups:

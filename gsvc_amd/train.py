@@ -32,6 +32,8 @@ EARLY_PLAN_MIN_ROWS = 150_000      # visible anchor rows of a step's views from 
 
 @dataclass
 class StepOutput:
+    """What a step hands back — all of it graph-free: the loss and images are detached, and so are the tensors inside ``renders``
+    (their backward has run; ``_release_graph``).  Differentiate through ``render()`` / ``render_many()`` directly instead."""
     loss: torch.Tensor
     image1: torch.Tensor
     image2: torch.Tensor
@@ -127,7 +129,12 @@ def _mean_over_selected(values, r):
 
 
 class Trainer:
-    def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0, batched: bool = True, prefetch: bool = True):
+    def __init__(self, gaussians, dataset, opt, pipe, model_params, seed: int = 0, batched: bool = True, prefetch: bool = True,
+                 shard_optimizer=None):
+        if shard_optimizer is not None:      # removed in round 4 (the index-range sharded Adam): accepted and ignored for one release
+            import warnings
+            warnings.warn("Trainer(shard_optimizer=...) is ignored: the optimizer is replicated (gsvc_amd/dist.py)", DeprecationWarning,
+                          stacklevel=2)
         self.batched = batched
         # prefetch: the next step's frame pair is drawn, its visibility test run and every data-dependent index list of its
         # generation pass queued at the END of a step (gsvc_amd.generate.StepPlan): the next step then starts with one wait
@@ -152,6 +159,19 @@ class Trainer:
         gdist.plan_group()      # created HERE, where every rank stands at the same point (creating a group is itself collective)
         self._mask_reg_weight = 0.0
         self._ovf_handle = None
+
+    def close(self):
+        """Give the calling thread its CPU affinity back (``__init__`` narrowed it to the GPU's NUMA node: gsvc_amd/hostbind.py;
+        GSVC_NO_CPU_BIND=1 never narrows it)."""
+        if self.pc._anchor.is_cuda:
+            from .hostbind import unbind
+            unbind(self.pc._anchor.device)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def _two_views(self, frame, mode, retain_grad):
         f = render(frame, self.pc, self.pipe, self.background, retain_grad=retain_grad, mode=mode)
@@ -360,6 +380,10 @@ class Trainer:
                          [hash_grid_bits(pc), torch.mean(torch.sigmoid(pc._mask.detach() if sparse_dp else pc._mask))]
                 weights += [opt.lmbda] * (1 if rate_sum is not None else 4) + [opt.lmbda / denom, 5e-4]
         if side is not None:
+            # what the terms above read of the step's stream's allocations (and saved for their backward on the small-work stream)
+            from .generate import record_on
+            record_on(side, batch.scaling, batch.neural_opacity, batch.mask, getattr(batch, "world", None), getattr(batch, "vis", None),
+                      [g.step_cache for g in grid_tables(pc)], flow if opt.optical_lambda != 0 else None)
             main_stream = torch.cuda.current_stream(dev)
             main_stream.wait_stream(side)
             for t in terms[n_image_terms:]:
@@ -371,7 +395,7 @@ class Trainer:
             self._w_key, self._w = key, host_values(weights, dev, torch.float32)
         w = self._w
         loss = torch.dot(torch.stack([t.reshape(()) for t in terms]), w) + const
-        self.reducer.arm([p for g in pc.optimizer.param_groups for p in g["params"]])
+        self.reducer.arm([p for g in pc.optimizer.param_groups for p in g["params"]], phase=mode)
         if self.batched and self._sparse_dp(plan):
             # the per-anchor gradients are non-zero only in the rows of this rank's distinct visible anchors: exchanged as rows
             self.reducer.set_sparse(plan.distinct, plan.distinct_cap, [pc._offset, pc._mask, pc._anchor_feat, pc._scaling])
@@ -399,7 +423,9 @@ class Trainer:
                     self._early_tail(renders, waited)
             handles = [p.register_post_accumulate_grad_hook(arrived) for p in waited]
         try:
-            with region('step.backward'):
+            from .generate import two_stream_backward
+            with region('step.backward'), (two_stream_backward() if (side is not None or getattr(batch, "small_work", False))
+                                           else contextlib.nullcontext()):
                 loss.backward()
         finally:
             for h in handles:
@@ -442,7 +468,6 @@ class Trainer:
                     pc.optimizer.step()
                     pc.optimizer.zero_grad(set_to_none=True)
         active = sum(r.active_gaussains for r in renders)
-        if getattr(batch, "small_work", False):
-            _release_graph(renders)
+        _release_graph(renders)      # at every size: a StepOutput never carries the step's autograd graph (see _release_graph)
         return StepOutput(loss=loss.detach(), image1=image1.detach(), image2=image2.detach(), renders=renders,
                           active_gaussians=active, frame_idx=frame_idx)
