@@ -6,7 +6,7 @@ restatement of that package's published algorithm (Wang et al. 2003 as implement
 sigma 1.5 applied separably WITHOUT padding, 5 scales halved by 2x2 average pooling, contrast-structure terms of the
 first four scales and the full SSIM of the last, exponents 0.0448 / 0.2856 / 0.3001 / 0.2363 / 0.1333, negative terms
 clipped to 0) — parity unpinned, checked against an independent NumPy / SciPy implementation in tests/test_golden_host.py.
-LPIPS (a pretrained VGG) is not built.  Plain torch ops: these run a few times per evaluation, not per step.
+LPIPS: gsvc_amd/lpips.py (needs a weights file).  Plain torch ops: these run a few times per evaluation, not per step.
 """
 from __future__ import annotations
 

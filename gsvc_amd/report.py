@@ -3,7 +3,8 @@
 ``evaluate`` reports what reference utils/report_utils.py:268-390 logs for a fitted model — mean L1, PSNR, SSIM and MS-SSIM
 of the two-view frames against the ground truth, and the frame rate — but renders through the decoder loop
 (``render_frames``: batched generation, one two-view pass per frame) instead of two ``render`` calls, a flip and an
-average per frame.  LPIPS is not built (a pretrained VGG).  ``save_checkpoint`` / ``load_checkpoint`` keep a model and
+average per frame.  LPIPS (``lpips_fn``: gsvc_amd.lpips.LPIPS built from a weights file — the pretrained numbers are not in this
+image) is reported when handed in, as the reference calls it (``lpips_fn(image, gt, normalize=True)``, report_utils.py:154).  ``save_checkpoint`` / ``load_checkpoint`` keep a model and
 its optimizer in one ``torch.save`` file (the reference scatters this over ply / pkl files with third-party readers).
 """
 from __future__ import annotations
@@ -18,7 +19,7 @@ from .ortho_gaussian_renderer import render_frames
 
 
 @torch.no_grad()
-def evaluate(pc, dataset, pipe, bg_color, frame_ids=None, batch: int = 8) -> dict:
+def evaluate(pc, dataset, pipe, bg_color, frame_ids=None, batch: int = 8, lpips_fn=None) -> dict:
     """Mean L1 / PSNR / SSIM / MS-SSIM (MS-SSIM only for frames at least 160 pixels high and large enough for 5 scales) of the
     rendered two-view frames, clamped to [0, 1], against ``dataset[i].image``; ``fps`` counts the whole loop's wall time,
     metrics excluded."""
@@ -31,7 +32,7 @@ def evaluate(pc, dataset, pipe, bg_color, frame_ids=None, batch: int = 8) -> dic
     images = [torch.clamp(img, 0.0, 1.0) for img in render_frames(frames, pc, pipe, bg_color, batch=batch)]
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    sums = {"l1": 0.0, "psnr": 0.0, "ssim": 0.0, "msssim": 0.0}
+    sums = {"l1": 0.0, "psnr": 0.0, "ssim": 0.0, "msssim": 0.0, "lpips": 0.0}
     n_ms = 0
     for fr, img in zip(frames, images):
         gt = torch.clamp(fr.image.to(img.device), 0.0, 1.0).permute(0, 2, 1).contiguous()
@@ -41,9 +42,11 @@ def evaluate(pc, dataset, pipe, bg_color, frame_ids=None, batch: int = 8) -> dic
         if min(img.shape[-2:]) > 160:
             sums["msssim"] += float(msssim_fn(img.unsqueeze(0), gt.unsqueeze(0)))
             n_ms += 1
+        if lpips_fn is not None:
+            sums["lpips"] += float(lpips_fn(img, gt, normalize=True))
     n = max(len(frames), 1)
     return {"frames": len(frames), "l1": sums["l1"] / n, "psnr": sums["psnr"] / n, "ssim": sums["ssim"] / n,
-            "msssim": sums["msssim"] / n_ms if n_ms else float("nan"), "fps": len(frames) / elapsed if elapsed > 0 else float("inf")}
+            "msssim": sums["msssim"] / n_ms if n_ms else float("nan"), "lpips": sums["lpips"] / n if lpips_fn is not None else None, "fps": len(frames) / elapsed if elapsed > 0 else float("inf")}
 
 
 def _optimizer_state(optimizer):
