@@ -152,36 +152,62 @@ def pmc_traffic(workload, kernel):
         return None, {"measured_live": False, "file": None}
 
 
-# instruction prices of the compositing backward (csrc/raster_bwd.hip): a straight-line replay of one list entry over one 8x8
-# quadrant is 36 vector instructions + 3 LDS reads of the entry's record, the nine-sum reduction 74 cross-lane instructions per
-# four entries; a wave-instruction holds a SIMD's issue slot for 1.5 ns (fma) to 3.5 ns (exp, rcp, permlane swap), 1.8 ns on this
-# kernel's mix (tools/micro/valu_rate.hip, profiles/r03/microbench_valu_rate.txt); 256 CUs x 4 SIMDs
-# vector instructions of the polynomial replay loop in the built kernel: 592 per four entries with all quadrants = 16 x 32.4 + 74
-REPLAY_INSTS, REDUCE_INSTS_PER_ENTRY, NS_PER_WAVE_INST, SIMDS = 32.4, 18.5, 1.8, 256 * 4
+# Instruction census and prices of the compositing backward (csrc/raster_bwd.hip), settled in round 5 with measurements whose answer
+# is known (tools/micro/valu_issue.hip -> profiles/r05/microbench_valu_issue_allcu.txt, microbench_valu_issue_pmc_SQ.csv):
+#   * the polynomial replay of one list entry over one 8x8 quadrant is 33 vector instructions in the built kernel (32.4 on average
+#     over the quadrants of an entry): 26 plain all-register fma / fmac / mul / sub ("fast"), 5 that read the constant bus, a literal
+#     or VCC (v_min literal, two v_cmp against SGPRs, two v_cndmask: "slow"), 2 transcendental (v_exp_f32, v_rcp_f32: "quarter");
+#   * the nine-sum reduction is 74 cross-lane instructions per four entries: 27 permlane swaps ("quarter"), 27 adds ("fast"),
+#     20 DPP adds ("slow").
+# What one SIMD sustains per wave-instruction at this kernel's 4 waves per SIMD with every CU busy (ns; cycles at the clock the
+# chip then holds, 1.95-2.4 GHz): fast 1.33 ns (2.7 cycles; 2.4 at 8 waves: the guide's 2-cycle issue is approached only by
+# all-register plain instructions at 8 waves per SIMD), slow 1.90 ns (4.5 cycles at 4 and at 8 waves), quarter 3.54 ns (8.4 cycles).
+# GUIDE_NS: MI355X_MICROARCH.md's price, 2 cycles per wave64 instruction at 2.4 GHz (transcendentals 4x), for comparison.
+REPLAY_CLASSES = {"fast": 25.5, "slow": 4.9, "quarter": 2.0}                  # per (entry, quadrant) replay: 32.4 instructions
+REDUCE_CLASSES = {"fast": 6.75, "slow": 5.0, "quarter": 6.75}                 # per entry: 18.5 instructions
+CLASS_NS = {"fast": 1.33, "slow": 1.90, "quarter": 3.54}
+GUIDE_NS = {"fast": 2 / 2.4, "slow": 2 / 2.4, "quarter": 8 / 2.4}
+REPLAY_INSTS, REDUCE_INSTS_PER_ENTRY, SIMDS = sum(REPLAY_CLASSES.values()), sum(REDUCE_CLASSES.values()), 256 * 4
 
 
 def roofline_valu(probe, kern_dom, one_stream_us, traffic_src):
     """The roof k_blend_bwd_tile is really under: vector-instruction issue.  ``probe`` = [replays, valid lanes, entries, launches]
-    counted by the kernel itself on the timed scene (gsvc_profile_enable bit 1)."""
+    counted by the kernel itself on the timed scene (gsvc_profile_enable bit 1).  The issue time is priced twice: with the
+    per-class rates measured on this chip (``issue_model_us``) and with the guide's 2 cycles per instruction at 2.4 GHz
+    (``issue_guide_us``: a rate this instruction mix cannot reach — see the census above)."""
     replays, lanes, entries, launches = probe
     if not launches or not replays:
         return None
     rep, ent = replays / launches, entries / launches
-    model_us = (rep * REPLAY_INSTS + ent * REDUCE_INSTS_PER_ENTRY) * NS_PER_WAVE_INST / SIMDS * 1e-3
+
+    def issue_us(prices):
+        per_rep = sum(n * prices[c] for c, n in REPLAY_CLASSES.items())
+        per_ent = sum(n * prices[c] for c, n in REDUCE_CLASSES.items())
+        return (rep * per_rep + ent * per_ent) / SIMDS * 1e-3
+    model_us, guide_us = issue_us(CLASS_NS), issue_us(GUIDE_NS)
     valu = (traffic_src or {}).get("valu") or {}
     out = {"kernel": "k_blend_bwd", "bound": "valu", "measured_live": True,
            "entries_replayed_per_launch": ent, "quadrant_replays_per_launch": rep, "replays_per_entry": rep / max(ent, 1.0),
            "valid_lane_frac": lanes / (64.0 * replays),
            "insts_per_entry_pixel": {"replay": REPLAY_INSTS, "reduction_per_entry": REDUCE_INSTS_PER_ENTRY,
                                      "per_useful_pixel": REPLAY_INSTS / max(lanes / (64.0 * replays), 1e-9) / 64.0},
+           "instruction_classes": {"replay": REPLAY_CLASSES, "reduction_per_entry": REDUCE_CLASSES,
+                                   "ns_per_wave_instruction_and_simd": CLASS_NS,
+                                   "source": "tools/micro/valu_issue.hip at 4 waves per SIMD, every CU busy (profiles/r05/microbench_valu_issue_allcu.txt)"},
            "issue_model_us": model_us,
-           "issue_model": f"(replays x {REPLAY_INSTS} + entries x {REDUCE_INSTS_PER_ENTRY}) wave-instructions x {NS_PER_WAVE_INST} ns "
-                          f"/ {SIMDS} SIMDs; list walking, culling tests and the row stores are not in it",
+           "issue_model": "(replays x replay classes + entries x reduction classes) x measured ns per class / 1024 SIMDs; list walking, "
+                          "culling tests, the entries' LDS reads and the row stores are not in it",
+           "issue_guide_us": guide_us,
+           "issue_guide": "the same instruction counts at MI355X_MICROARCH.md's 2 cycles per wave64 instruction and 2.4 GHz (8 cycles for "
+                          "transcendentals and permlane swaps)",
            "avg_launch_us_one_stream": one_stream_us, "avg_launch_us": None if kern_dom is None else kern_dom["avg_us"],
            "frac_of_issue_model": None if not one_stream_us else model_us / one_stream_us,
+           "frac_of_guide_issue": None if not one_stream_us else guide_us / one_stream_us,
            "valu_issue_share_pmc": valu.get("valu_issue_share_at_2p4GHz"), "valu_insts_per_launch_pmc": valu.get("valu_insts_per_launch"),
            "note": "probe counters come from the kernel's diagnostic instantiation on the timed scene; the *_pmc entries are the SQ "
-                   "counters of profiles/pmc_latest.json (null when the kernel sources changed since)"}
+                   "counters of profiles/pmc_latest.json (null when the kernel sources changed since).  SQ_ACTIVE_INST_VALU is a static "
+                   "count (1 per plain, 2 per transcendental instruction: exactly 1.000 / 1.091 per instruction on the microbenchmark "
+                   "at every occupancy), not a measure of issue-port occupancy"}
     return out
 
 
