@@ -129,6 +129,22 @@ def csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
+def reference_step_cpu(which):
+    """The REFERENCE's own step body (pipeline/train.py:348-462) timed on PyTorch-CPU with oracle/ in the native slots, from the
+    committed record (tests/golden/time_reference_step_cpu.py -> profiles/r05/reference_step_cpu_timing.json): it was measured in
+    the build container — /root/reference does not exist on the GPU box — so the host is stated with it.  Same work as the
+    headline step minus the optimizer; None when the record is missing."""
+    try:
+        data = json.load(open(os.path.join(ROOT, "profiles", "r05", "reference_step_cpu_timing.json")))
+        case = next(c for c in data["cases"] if c["case"].startswith(which))
+        return {"value": case["gaussians_per_s"], "unit": "Gaussians/s", "kind": "reference", "cores": data["host"]["cpus"],
+                "seconds_per_step": case["seconds_per_step"]["median"], "active_gaussians_per_step": case["active_gaussians_per_step"],
+                "host": data["host"]["where"], "what": data["what"], "case": case["case"], "measured_live": False,
+                "file": "profiles/r05/reference_step_cpu_timing.json"}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC extract (tools/pmc_extract.py) + where it came from.  The counters
     cannot be collected inside this process (rocprofv3 wraps the command), so the number is only as good as the file: when the
@@ -463,6 +479,28 @@ def run_train_step(args, rank, world, dev):
         os.environ.pop(var, None)
         switches.reload()
 
+    # cold ground truth: the same K steps with the video in pinned HOST memory and the step's two frames + flow uploaded per step
+    # (what the reference's own step timer includes: pipeline/train.py:332,407-408,464), one step ahead on a copy stream
+    cold = None
+    if world == 1:
+        try:
+            from gsvc_amd.frame import HostResidentCube
+            host_cube = HostResidentCube(cube, dev)
+            trainer.dataset = host_cube
+            for _ in range(3):
+                step()
+            up0 = host_cube.uploads
+            e_cold = timed(torch, dist, world, step, args.steps)
+            cold = {"ms_per_step_cold": 1e3 * e_cold / args.steps, "uploads_per_step": (host_cube.uploads - up0) / args.steps,
+                    "bytes_per_upload": int(2 * host_cube._images[0].numel() * 4 + host_cube._flows[0].numel() * 4),
+                    "note": "ground-truth frames + flow in pinned host memory, uploaded per step on a copy stream one step ahead "
+                            "(gsvc_amd.frame.HostResidentCube); `value` / ms_per_step above keep the video resident in HBM"}
+        except Exception as e:  # noqa: BLE001
+            cold = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            trainer.dataset = cube
+            del host_cube
+
     # exposed communication: the same K steps with the gradient exchange switched off (replicas diverge: last thing
     # measured on the model's gradients; parameters are re-broadcast afterwards)
     comm = None
@@ -573,7 +611,14 @@ def run_train_step(args, rank, world, dev):
     dom_bytes = alg[dom]
     achieved = dom_bytes / (kern[dom]["avg_us"] * 1e-6) / 1e9
     kernel_us = sum(v["avg_us"] * v["launches"] for v in kern.values()) / args.steps
-    traffic, traffic_src = pmc_traffic("train_step", dom)
+    default_shape = (not args.cfg3 and args.anchors == 245_000 and args.train_frames == 64 and (H, W) == (1080, 1920) and world == 1)
+    if default_shape:
+        traffic, traffic_src = pmc_traffic("train_step", dom)
+    else:
+        # the PMC passes were taken on the default headline shape (245 k anchors, 64 frames, one GPU): no counter traffic is quoted
+        # for any other workload until it has its own pass
+        traffic, traffic_src = None, {"measured_live": False, "file": None,
+                                      "refused": "profiles/pmc_latest.json holds counters of the default train_step shape only"}
     res = {
         "metric": METRIC, "value": total_units / elapsed, "unit": "Gaussians/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -613,6 +658,10 @@ def run_train_step(args, rank, world, dev):
         "render_frames_fps_end_to_end": frames_fps,
         "render_fps_note": PAIR_NOTE,
     }
+    if cold is not None:
+        res["cold_ground_truth"] = cold
+        if "ms_per_step_cold" in cold:
+            res["ms_per_step_cold"] = cold["ms_per_step_cold"]
     if comm is not None:
         res["gradient_exchange"] = comm
     if world == 1:
@@ -682,6 +731,9 @@ def run_train_step(args, rank, world, dev):
                                             "the gradient threshold so that anchors are added"}
         except Exception as e:  # noqa: BLE001
             res["adjust_anchor"] = {"error": f"{type(e).__name__}: {e}"}
+    ref_cpu = reference_step_cpu("configs[3]" if args.cfg3 else "configs[2]")
+    if ref_cpu is not None:
+        res["cpu_baseline_reference_python"] = ref_cpu
     if world == 1 and not args.no_cpu_baseline:
         import oracle
         oracle.build()

@@ -1323,7 +1323,19 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
             # BEHIND the rasterizer's launches, on its own stream (finish_deferred_rate): it runs under the compositing kernels
             # forward and, its autograd nodes living on that stream, under the rasterizer's backward
             reads = [feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec_row, plan.sel, ec]
-            deferred.append((rate, torch.cuda.current_stream(vis.device).record_event(), reads))
+            ready = torch.cuda.current_stream(vis.device).record_event()
+            if switches.RATE_EARLY:
+                # issued NOW (still on its own stream, so it runs beside whatever follows): the rate's autograd nodes are then
+                # OLDER than the rasterizer's, and the engine — which runs younger nodes first — launches the rasterizer's backward
+                # before the rate's ~40 small launches instead of behind them
+                rs = small_work_stream(vis.device)
+                rs.wait_event(ready)
+                record_on(rs, *reads)
+                with torch.cuda.stream(rs):
+                    packs = rate()
+                deferred.append((lambda: packs, ready, ()))
+                return rates
+            deferred.append((rate, ready, reads))
             return rates
         return rate()
 

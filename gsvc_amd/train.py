@@ -220,9 +220,17 @@ class Trainer:
         if self.prefetch and self.pc._anchor.is_cuda:
             with torch.no_grad(), region('step.plan'):
                 self._plan_idx = self.rng.randint(self.lo, max(self.lo, self.hi - 1))
+                self._prefetch_frames(self._plan_idx)
                 self._plan_mode = self.controller.render_mode
                 self._plan = plan_views(self._views(self._plan_idx), self.pc, self.pipe, self.background, self._plan_mode)
         return out
+
+    def _prefetch_frames(self, idx):
+        """A dataset that keeps its pictures in host memory (gsvc_amd.frame.HostResidentCube) starts uploading the next step's pair
+        now, on its copy stream (reference pipeline/train.py:407-408 uploads them inside the step)."""
+        pf = getattr(self.dataset, "prefetch", None)
+        if pf is not None:
+            pf(idx)
 
     def _add_mask_reg(self):
         """Sparse data-parallel exchange: the mask regulariser 5e-4 * mean(sigmoid(_mask)) touches EVERY row of ``_mask`` with the
@@ -263,6 +271,7 @@ class Trainer:
             pc.optimizer.step(only=params, guards=guards)
             self.early_steps = getattr(self, "early_steps", 0) + 1
             idx = self.rng.randint(self.lo, max(self.lo, self.hi - 1))
+            self._prefetch_frames(idx)
             mode = render_mode_at(self.controller.current_iteration + 1, self.opt)
             plan = plan_views(self._views(idx), pc, self.pipe, self.background, mode) if mode is not None else None
             self._early = (params, idx, mode, plan)
@@ -437,6 +446,10 @@ class Trainer:
             # wait Adam occasionally read those gradients half written (seen as run-to-run drift of the rate model, not as a crash).
             from .generate import small_work_stream
             torch.cuda.current_stream(dev).wait_stream(small_work_stream(dev))
+        done = getattr(self.dataset, "step_done", None)
+        if done is not None:
+            done()      # every reader of the ground-truth slots (image losses, optical term — forward and backward, this stream and the
+                        # small-work stream, which this one has just waited for) is queued: the slots' next upload may start behind here
         with region('step.reducer_finish'):
             self.reducer.finish()
             self._add_mask_reg()

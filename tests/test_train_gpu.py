@@ -978,3 +978,25 @@ def test_generation_once_per_frame_equals_generation_per_view(monkeypatch, phase
     for n in ga:
         scale = gb[n].abs().max().item()
         assert (ga[n] - gb[n]).abs().max().item() <= 1e-3 * scale + 1e-12, (n, (ga[n] - gb[n]).abs().max().item(), scale)
+
+
+@pytest.mark.gpu
+def test_host_resident_video_steps_equal_device_resident_steps():
+    """gsvc_amd.frame.HostResidentCube (pictures + flow in pinned host memory, uploaded one step ahead on a copy stream — what the
+    reference's step does inside its own timer, pipeline/train.py:407-408) feeds the fitting step the same numbers as the
+    device-resident cube: identical losses step by step, one upload per step once the prefetch is running."""
+    from gsvc_amd.frame import HostResidentCube
+    losses = []
+    for host in (False, True):
+        pc, cube, opt, pipe, mp, Trainer = _setup(anchors=4000, H=96, W=160, T=12, seed=3)
+        opt.full_precision_training_total, opt.quantized_training_total = 2, 1
+        opt.entropy_constrained_train_total = 100
+        pc.training_setup(opt)
+        cube.materialize()
+        ds = HostResidentCube(cube, "cuda") if host else cube
+        tr = Trainer(pc, ds, opt, pipe, mp, seed=5)
+        losses.append([float(tr.step(it).loss) for it in range(1, 8)])
+        if host:
+            assert 7 <= ds.uploads <= 8, ds.uploads          # one per step (the first step's happens at use)
+        tr.close()
+    assert losses[0] == losses[1], losses
