@@ -1109,6 +1109,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        from gsvc_amd.dist import log_ranks
+        log_ranks()
     cpu = world == 1 and not args.no_cpu_baseline
     if args.workload in ("headline", "train_step"):
         res = run_train_step(args, rank, world, dev)

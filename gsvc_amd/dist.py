@@ -32,7 +32,19 @@ def init_from_env(backend: str | None = None):
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)
         dist.init_process_group(backend, **kw)
+        log_ranks()
     return rank, world, local
+
+
+def log_ranks():
+    """One stderr line on rank 0 naming the communicator the step's collectives will run on ("nccl" IS RCCL on ROCm), so that a
+    scaling record can confirm how many ranks really took part."""
+    if world_size() > 1 and rank() == 0:
+        import sys
+        b = dist.get_backend()
+        sys.stderr.write(f"gsvc_amd.dist: {'RCCL' if b == 'nccl' else b} ranks = {world_size()} (backend {b}; one rank per GPU, frames sharded "
+                         f"by contiguous blocks, gradients: per-anchor tensors as rows or dense by sparse_rows_pay, tables + MLPs dense)\n")
+        sys.stderr.flush()
 
 
 def world_size() -> int:

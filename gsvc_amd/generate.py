@@ -1200,6 +1200,8 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
                 and plan is not None and plan.distinct is not None and plan.distinct.shape[0] != vis.shape[0] and not switches.NO_VIEW_SHARE):
             share = _film_rows(pc, frames, plan, vis, seg, anchor_all)
     from . import mlp as _mlp
+    # few rows: the step's time is the host's (SMALL_WORK_MIN_ROWS) -> the MLP layer launches prefer fewer, multi-product launches
+    _mlp.host_bound_step = bool(vis.is_cuda and torch.is_grad_enabled() and seg.rows < SMALL_WORK_MIN_ROWS and "GSVC_MANY_MIN_ROWS" not in os.environ)
     gens = [getattr(pc, n) for n in ("get_opacity_mlp", "get_color_mlp", "get_cov_mlp")]
     deform_mods = list(pc.get_deform_mlp) if isinstance(pc.get_deform_mlp, torch.nn.Sequential) else []
     deform_linears = deform_mods[0::2]

@@ -29,7 +29,15 @@ MIN_ROWS = 4096
 # rows from which the multi-product launches (gsvc_linear_forward_shared_input / gsvc_linear_accumulate_many) are used: they hold a
 # wave's row fragments / accumulators across the products but re-stage every product's weight image per workgroup — a fixed cost
 # that a few thousand rows do not amortise (the rate sample's ~10 k rows: 124 us against 3 x 16 us as layer launches; same-process
-# A/B of the fitting step 7.36 -> 7.28 ms): switches.MANY_MIN_ROWS, default 24 576
+# A/B of the fitting step 7.36 -> 7.28 ms): switches.MANY_MIN_ROWS, default 24 576.  A HOST-bound step (few visible rows: the host,
+# not the GPU, sets its time — gsvc_amd.generate sets ``host_bound_step`` per generation pass) takes them at any size: there a
+# launch saved is worth more than the microseconds its kernel loses (configs[3]: 4.86 -> 4.66 ms per step, round 5)
+host_bound_step = False
+
+
+def _many_min_rows():
+    return 0 if host_bound_step else switches.MANY_MIN_ROWS
+
 
 # epilogue codes of gsvc_linear_forward_ex (include/gsvc_hip.h)
 EPI_NONE, EPI_RELU, EPI_GELU_DUAL, EPI_TANH, EPI_SIGMOID, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK, EPI_FILM, EPI_FILM_GRAD, EPI_ADD = range(10)
@@ -236,7 +244,7 @@ def _first_layers_shared_input(x, sizes, params):
     shapes are not the kernel's (the caller then runs layer by layer)."""
     M, K = x.shape
     if (switches.NO_SHARED_INPUT or not (2 <= len(sizes) <= 8) or any(n < 2 for n in sizes)
-            or not switches.MANY_MIN_ROWS <= M <= 65536
+            or not _many_min_rows() <= M <= 65536
             or K > MFMA_MAX_DIM or K % 4 or x.data_ptr() % 16):
         return None
     ws, at = [], 0
@@ -263,7 +271,7 @@ def _sum_of_products(pairs, N):
     (gsvc_linear_accumulate_many: at most 8 products, M <= 65536), else product by product with the accumulate epilogue."""
     g0 = pairs[0][0]
     M = g0.shape[0]
-    if (2 <= len(pairs) <= 8 and switches.MANY_MIN_ROWS <= M <= 65536 and N <= MFMA_MAX_DIM and not switches.NO_ACCUM_MANY
+    if (2 <= len(pairs) <= 8 and _many_min_rows() <= M <= 65536 and N <= MFMA_MAX_DIM and not switches.NO_ACCUM_MANY
             and all(g.shape[1] <= MFMA_MAX_DIM and g.shape[1] % 2 == 0 and g.is_contiguous() and w.is_contiguous()
                     and g.data_ptr() % 8 == 0 for g, w in pairs)):
         out = torch.empty(M, N, device=g0.device, dtype=torch.float32)

@@ -405,11 +405,17 @@ class Trainer:
         w = self._w
         loss = torch.dot(torch.stack([t.reshape(()) for t in terms]), w) + const
         self.reducer.arm([p for g in pc.optimizer.param_groups for p in g["params"]], phase=mode)
-        if self.batched and self._sparse_dp(plan):
+        use_rows = bool(self.batched and self._sparse_dp(plan))
+        if use_rows:
             # the per-anchor gradients are non-zero only in the rows of this rank's distinct visible anchors: exchanged as rows
             self.reducer.set_sparse(plan.distinct, plan.distinct_cap, [pc._offset, pc._mask, pc._anchor_feat, pc._scaling])
         else:
             self.reducer.set_sparse(None, 0, [])
+        if gdist.world_size() > 1 and gdist.rank() == 0 and getattr(self, "_logged_exchange", None) != use_rows and plan is not None:
+            import sys
+            self._logged_exchange = use_rows
+            sys.stderr.write(f"gsvc_amd.train: per-anchor gradient exchange = {'rows of the distinct visible anchors (cap ' + str(plan.distinct_cap) + ')' if use_rows else 'dense all-reduce'}"
+                             f" at {int(pc._anchor.shape[0])} anchors, {gdist.world_size()} ranks\n")
         handles = []
         if (early and self.batched and self.prefetch and pc._anchor.is_cuda
                 and (gdist.world_size() == 1 or (self.reducer.enabled and self.reducer._order is not None))
