@@ -150,7 +150,8 @@ class HostResidentCube:
     (frame_cube/frame.py:141-152: CPU tensors; the step uploads its two ground-truth frames every iteration, inside its own step
     timer: pipeline/train.py:332,407-408,464).  Uploads run on a copy stream ONE STEP AHEAD: ``prefetch(idx)`` — which the fitting
     step calls as soon as it has drawn the next frame pair — queues the pair's pictures and flow into one of two device slots, and
-    ``__getitem__`` hands out frames whose ``image`` is that slot's tensor behind a stream wait, so the copy (2 x 24.9 MB + 16.6 MB
+    ``__getitem__`` hands out frames whose ``image`` is that slot's tensor (the reader queues the wait with ``ready(i)`` just before its
+    first use), so the copy (2 x 24.9 MB + 16.6 MB
     at 1080p: ~1.2 ms of PCIe 5 x16) runs under the previous step's kernels instead of in front of this step's.  Without a
     prefetch (the first step, or a caller that names its own frame) the copy is issued at use."""
 
@@ -205,12 +206,17 @@ class HostResidentCube:
             s["free"] = ev
 
     def __getitem__(self, i):
+        """The frame with ``image`` = its device slot.  No wait is queued here — a step fetches its frames first and reads the
+        pictures last (image losses, behind generation and compositing): the reader calls ``ready(i)`` just before."""
         import copy
         s = self._slot_of(i)
-        torch.cuda.current_stream(self.device).wait_event(s["ready"])
         fr = copy.copy(self.cube.get_dummy_frame(i))
         fr.image = s["img"][i - s["idx"]]
         return fr
+
+    def ready(self, i):
+        """Make the current stream wait for the upload of frame i's picture (a no-op once it has landed)."""
+        torch.cuda.current_stream(self.device).wait_event(self._slot_of(i)["ready"])
 
     def get_dummy_frame(self, i):
         return self.cube.get_dummy_frame(i)

@@ -343,6 +343,10 @@ class Trainer:
             r1f, r1b, image1 = self._two_views(frame1, mode, retain_grad)
             r2f, r2b, image2 = self._two_views(frame2, mode, retain_grad)
         renders = (r1f, r1b, r2f, r2b)
+        ready = getattr(self.dataset, "ready", None)
+        if ready is not None:          # pictures uploaded on a copy stream (HostResidentCube): their first readers come now
+            ready(frame_idx)
+            ready(frame_idx + 1)
         gt1 = frame1.image.to(dev).permute(0, 2, 1)
         gt2 = frame2.image.to(dev).permute(0, 2, 1)
         if image1 is None:
