@@ -25,6 +25,14 @@ for w in $WL; do
   timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/pmc_${w}_SQ -- python3 $REPO/bench.py $ARGS > $OUT/pmc_${w}_SQ.log 2>&1
   f=$(find $OUT/pmc_${w}_SQ -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && grep -E "Kernel_Name|gsvc::k_(blend|preprocess|sort|scatter|gaussian)" $f > $OUT/${w}_${TAG}_pmc_SQ.csv
+  if [ $w = train_step ]; then
+    # the MLP kernels: matrix-pipe occupancy (what bounds the chain / layer / weight-gradient kernels), with durations from the same pass
+    timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_${w}_MFMA -- python3 $REPO/bench.py $ARGS > $OUT/pmc_${w}_MFMA.log 2>&1
+    f=$(find $OUT/pmc_${w}_MFMA -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && grep -E "Kernel_Name|gsvc::.*k_(trunk|film|deform|quant_nets|linear)" $f > $OUT/${w}_${TAG}_pmc_MFMA.csv
+    [ -n "$f" ] && python3 $REPO/tools/mfma_util.py $OUT/${w}_${TAG}_pmc_MFMA.csv > $OUT/${w}_${TAG}_mfma_utilisation.csv
+    rm -rf $OUT/pmc_${w}_MFMA
+  fi
   python3 $REPO/tools/pmc_extract.py $w $OUT/${w}_${TAG}_pmc_FETCH_SIZE.csv $OUT/${w}_${TAG}_pmc_WRITE_SIZE.csv $TAG $OUT/${w}_${TAG}_pmc_SQ.csv > $OUT/pmc_extract_$w.log 2>&1
   rm -rf $OUT/kt_$w $OUT/pmc_${w}_FETCH_SIZE $OUT/pmc_${w}_WRITE_SIZE $OUT/pmc_${w}_SQ
 done
