@@ -45,8 +45,8 @@ def shorten_stats(path, rows):
             if i > rows:
                 break
             n = row[0]
-            m = re.search(r"(gsvc::k_\w+(<[^>(]*>)?)", n)
-            row[0] = m.group(1) if m else re.sub(r"\(.*", "", re.sub(r"^void ", "", n))[:110]
+            m = re.search(r"(gsvc::(?:\(anonymous namespace\)::)?k_\w+(<[^>(]*>)?)", n)
+            row[0] = m.group(1).replace("(anonymous namespace)::", "") if m else re.sub(r"\(.*", "", re.sub(r"^void ", "", n))[:110]
             w.writerow(row)
 
 
