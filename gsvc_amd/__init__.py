@@ -11,7 +11,7 @@ __version__ = "0.1.0"
 def _check_compiled_host():
     """The host modules of the fitting step may be compiled in place (``python setup_host.py build_ext --inplace``: Cython, the .py
     files stay the source).  The import system prefers the compiled module, so one built from an OLDER .py would silently run old
-    code: refuse that.  ``compiled_host()`` lists what is loaded."""
+    code: such a module is removed (a build artefact; the .py is then imported).  ``compiled_host()`` lists what is loaded."""
     import glob
     import hashlib
     import json
@@ -34,8 +34,19 @@ def _check_compiled_host():
         else:
             ok[mod.replace(os.sep, "/")] = now
     if stale:
-        raise ImportError(f"gsvc_amd: compiled host modules {stale} were built from other sources than the .py files beside them: "
-                          f"run `python setup_host.py build_ext --inplace` (or `python setup_host.py clean_host` to run the .py files)")
+        # a build artefact that no longer matches its source: take it out of the way (the .py beside it is then what is imported)
+        import importlib
+        import sys
+        try:
+            for so in built:
+                if os.path.relpath(so, here).split(".cpython-")[0] in stale:
+                    os.remove(so)
+            importlib.invalidate_caches()
+            sys.stderr.write(f"gsvc_amd: removed compiled host modules built from older sources ({', '.join(sorted(stale))}): running the .py "
+                             f"files; `python setup_host.py build_ext --inplace` compiles them again\n")
+        except OSError as e:
+            raise ImportError(f"gsvc_amd: compiled host modules {stale} were built from other sources than the .py files beside them and "
+                              f"cannot be removed ({e}): run `python setup_host.py build_ext --inplace` or `python setup_host.py clean_host`")
     return ok
 
 

@@ -41,3 +41,20 @@ def _switches_follow_the_environment(monkeypatch):
 
     monkeypatch.setenv, monkeypatch.delenv = _setenv, _delenv
     yield
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Every skip with its reason at the end of the run, whatever the verbosity (`-q` shows a skip as a bare "s"), and which host
+    modules ran compiled: a record of the run should say why something did not run and what did."""
+    skipped = terminalreporter.stats.get("skipped", [])
+    if skipped:
+        terminalreporter.write_sep("-", "skipped (reason)")
+        for rep in skipped:
+            reason = rep.longrepr[2] if isinstance(rep.longrepr, tuple) and len(rep.longrepr) == 3 else str(rep.longrepr)
+            terminalreporter.write_line(f"{rep.nodeid}: {reason}")
+    try:
+        import gsvc_amd
+        ch = gsvc_amd.compiled_host()
+        terminalreporter.write_line(f"gsvc_amd host modules compiled: {len(ch)} ({', '.join(sorted(ch)) if ch else 'plain Python'})")
+    except Exception:  # noqa: BLE001
+        pass
