@@ -88,6 +88,26 @@ __global__ void __launch_bounds__(1024) k_issue(int iters, float xs, float ys, u
         } else if (KIND == 13) {
             for (int i = 0; i < 8; i++) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[i + 8]));
             for (int i = 0; i < 8; i++) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[i + 8]));
+        } else if (KIND == 14) {         // compare, registers only, into VCC
+#define X(i) asm volatile("v_cmp_ngt_f32 vcc, %1, %0" : : "v"(a[i]), "v"(yv) : "vcc");
+            REP16(X)
+#undef X
+        } else if (KIND == 15) {         // compare against an SGPR into VCC
+#define X(i) asm volatile("v_cmp_ngt_f32 vcc, %1, %0" : : "v"(a[i]), "s"(ys) : "vcc");
+            REP16(X)
+#undef X
+        } else if (KIND == 16) {         // compare, registers only, into an SGPR pair (VOP3 form)
+#define X(i) asm volatile("v_cmp_ngt_f32 s[20:21], %1, %0" : : "v"(a[i]), "v"(yv) : "s20", "s21");
+            REP16(X)
+#undef X
+        } else if (KIND == 17) {         // select on VCC, registers only
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(xv));
+            REP16(X)
+#undef X
+        } else if (KIND == 18) {         // min against a register (instead of a literal)
+#define X(i) asm volatile("v_min_f32 %0, %1, %0" : "+v"(a[i]) : "v"(xv));
+            REP16(X)
+#undef X
         } else if (KIND == 5) {
 #define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(xs), "v"(yv));
             REP16(X) REP16(X) REP16(X) REP16(X) REP16(X) REP16(X)
@@ -154,6 +174,11 @@ int main(int argc, char **argv)
     run<11>("v_rcp_f32", 16, wg, dc, d);
     run<12>("v_add_f32_dpp row_ror:8 bank_mask:0xc", 16, wg, dc, d);
     run<13>("v_permlane32_swap / v_permlane16_swap", 16, wg, dc, d);
+    run<14>("v_cmp_ngt_f32 vcc,v,v", 16, wg, dc, d);
+    run<15>("v_cmp_ngt_f32 vcc,s,v", 16, wg, dc, d);
+    run<16>("v_cmp_ngt_f32 s[..],v,v (VOP3)", 16, wg, dc, d);
+    run<17>("v_cndmask_b32 v,v,v,vcc", 16, wg, dc, d);
+    run<18>("v_min_f32 v,v,v", 16, wg, dc, d);
     run<5>("backward mix (96 fma 48 dpp 16 cnd 8 exp 8 swap)", 176, wg, dc, d);
     return 0;
 }
