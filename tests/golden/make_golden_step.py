@@ -85,8 +85,12 @@ def main():
         out = {"meta::A": np.int64(sc["A"]), "meta::lmbda": np.float64(opt.lmbda), "meta::opacity_reg": np.float64(opt.opacity_reg),
                "meta::weights": np.array([opt.lambda_dssim, opt.scaling_reg, opt.opacity_reg, opt.optical_lambda, opt.lmbda], dtype=np.float64)}
 
-        for mode_value, iteration in sorted(ST["iterations"].items()):
-            pre = f"m{mode_value}::"
+        # (mode, iteration, white background): the four phases on black, and the full-precision phase once more on a WHITE background
+        # (reference pipeline/train.py:327 `bg_color = [1, 1, 1] if model_params.white_background`): out = C + T bg and the
+        # background's share of dL/dalpha (the compositing backward's non-zero-background form) inside a whole step
+        cases = [(m, it, False) for m, it in sorted(ST["iterations"].items())] + [(0, ST["iterations"][0], True)]
+        for mode_value, iteration, white in cases:
+            pre = f"m{mode_value}w::" if white else f"m{mode_value}::"
             ref.training_setup(opt)                                   # fresh optimiser + zeroed densification accumulators
             for p in ref.parameters():
                 p.grad = None
@@ -94,7 +98,8 @@ def main():
             controller.current_iteration = iteration
             assert controller.render_mode == GenerateMode(mode_value), (controller.render_mode, mode_value)
             ns = dict(render=OGR.render, frame1=frame_of(fn1, idx), frame2=frame_of(fn2, idx + 1), gaussians=ref,
-                      pipe=SimpleNamespace(debug=False, compute_cov3D_python=False, model_path=None), background=torch.tensor([0.0, 0.0, 0.0]),
+                      pipe=SimpleNamespace(debug=False, compute_cov3D_python=False, model_path=None),
+                      background=torch.tensor([1.0, 1.0, 1.0] if white else [0.0, 0.0, 0.0]),
                       controller=controller, opt=opt, iteration=iteration, torch=torch, l1_loss_func=l1_loss_func, ssim_func=ssim_func,
                       calc_optical_loss=calc_optical_loss, get_binary_vxl_size=get_binary_vxl_size,
                       optical_flow=seeded.optical_flow(H, W, idx, sc["seed"]), frame_cube=SimpleNamespace(dataset=dataset))
@@ -118,7 +123,7 @@ def main():
                                              int(r.num_rendered)] for r in rr], dtype=np.int64)
             out[pre + "visible_masks"] = np.stack([np.packbits(r.visible_mask.numpy()) for r in rr])
             out[pre + "retain_grad"] = np.bool_(ns["retain_grad"])
-            grads_of(ref.named_parameters(), out, pre, rows=mode_value in (0, 2))          # modes 1 and 3: sums only (fixture size)
+            grads_of(ref.named_parameters(), out, pre, rows=mode_value in (0, 2) and not white)      # modes 1, 3 and the white case: sums only (fixture size)
             with torch.no_grad():
                 exec(statis_code, ns)
             out[pre + "gaussian_statis"] = np.bool_(controller.gaussian_statis)

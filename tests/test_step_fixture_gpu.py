@@ -116,7 +116,7 @@ def _bits(packed, n):
     return np.unpackbits(packed)[:n].astype(bool)
 
 
-def _run_step(fix, mode_value, batched, planned=False):
+def _run_step(fix, mode_value, batched, planned=False, white=False):
     from tests.golden import seeded
     from gsvc_amd.arguments import OptimizationParams, PipelineParams
     from gsvc_amd.generate import GenerateMode
@@ -124,7 +124,7 @@ def _run_step(fix, mode_value, batched, planned=False):
     from gsvc_amd.train import Trainer
     pc, mp, fn, g = fix
     sc, ST = seeded.SCENE, seeded.STEP
-    pre = f"m{mode_value}::"
+    pre = f"m{mode_value}w::" if white else f"m{mode_value}::"
     opt = OptimizationParams()
     opt.lmbda, opt.opacity_reg = ST["lmbda"], ST["opacity_reg"]
     assert np.allclose([opt.lambda_dssim, opt.scaling_reg, opt.opacity_reg, opt.optical_lambda, opt.lmbda], g["meta::weights"], rtol=0, atol=0)
@@ -141,7 +141,10 @@ def _run_step(fix, mode_value, batched, planned=False):
             if p.grad is not None:
                 grads[n] = p.grad.detach().clone()
     pc.optimizer.step = snapshot
-    tr = Trainer(pc, _Dataset(), opt, PipelineParams(), mp, batched=batched, prefetch=False)
+    import copy
+    mp_run = copy.copy(mp)
+    mp_run.white_background = bool(white)          # reference pipeline/train.py:327
+    tr = Trainer(pc, _Dataset(), opt, PipelineParams(), mp_run, batched=batched, prefetch=False)
     tr.controller.current_iteration = iteration
     assert tr.controller.render_mode == GenerateMode(mode_value)
     A = sc["A"]
@@ -256,3 +259,13 @@ def test_production_step_matches_the_reference_step(fix, mode_value, planned):
     checked, worst = _compare(pc, g, pre, out, grads, mode_value, batched=True)
     print(f"[m{mode_value} production{' planned' if planned else ''}] loss {float(out.loss):.7f} vs {float(g[pre + 'loss']):.7f}; "
           f"{checked} gradients, worst row error {worst[0]:.2e} ({worst[1]})")
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_step_on_a_white_background_matches_the_reference_step(fix, batched):
+    """The full-precision step once more with ``white_background`` (reference pipeline/train.py:327): the composite C + T bg and
+    the background's share of dL/dalpha — the compositing backward's general (non-black) instantiation — inside a whole step."""
+    pc, g, pre, out, grads, _ = _run_step(fix, 0, batched=batched, white=True)
+    assert pre == "m0w::" and abs(float(g[pre + "loss"]) - float(g["m0::loss"])) > 1e-3       # the background matters in this scene
+    checked, worst = _compare(pc, g, pre, out, grads, 0, batched=batched)
+    print(f"[m0 white {'production' if batched else 'per-render'}] loss {float(out.loss):.7f} vs {float(g[pre + 'loss']):.7f}; {checked} gradients")
