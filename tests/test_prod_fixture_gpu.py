@@ -337,3 +337,25 @@ def test_priors_on_the_sampled_rows_equal_the_all_rows_context(prod, monkeypatch
     for n in set(gf) & set(gs):
         scale = float(gs[n].abs().max())
         assert float((gf[n] - gs[n]).abs().max()) <= 1e-3 * scale + 1e-30, n
+
+
+def test_two_view_frame_matches_the_reference_renders(prod):
+    """The evaluation / decoder frame (reference utils/report_utils.py:297-319: render(view), render(opposite view), flip, average) from
+    ONE generation and ONE compositing pass (render_pair -> gsvc_raster_forward_pair) against the average of the reference's two
+    separate render() calls of the fixture (cases f0 and b0), and the batched decoder loop (render_frames) against the same."""
+    from gsvc_amd.generate import GenerateMode
+    from gsvc_amd.ortho_gaussian_renderer import render_frames, render_pair
+    from tests.golden import seeded
+    pc, g, fn = prod
+    sc = seeded.SCENE
+    H, W = sc["H"], sc["W"]
+    want = 0.5 * (g["f0::image"] + g["b0::image"][:, :, ::-1])
+    ok = ~_bits(g["f0::borderline"], H * W).reshape(H, W) & ~_bits(g["b0::borderline"], H * W).reshape(H, W)[:, ::-1]
+    pipe = SimpleNamespace(debug=False, compute_cov3D_python=False)
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    with torch.no_grad():
+        pair = render_pair(_frame(fn, "f"), pc, pipe, bg, mode=GenerateMode.TRAINING_FULL_PRECISION).rendered_image.cpu().numpy()
+        loop = next(iter(render_frames([_frame(fn, "f")], pc, pipe, bg, mode=GenerateMode.TRAINING_FULL_PRECISION))).cpu().numpy()
+    for name, img in (("render_pair", pair), ("render_frames", loop)):
+        err = np.abs(img - want)[:, ok]
+        assert (err > 1e-4).mean() <= 2e-3 and err.max() < 5e-2, (name, float((err > 1e-4).mean()), float(err.max()))
