@@ -359,3 +359,31 @@ def test_two_view_frame_matches_the_reference_renders(prod):
     for name, img in (("render_pair", pair), ("render_frames", loop)):
         err = np.abs(img - want)[:, ok]
         assert (err > 1e-4).mean() <= 2e-3 and err.max() < 5e-2, (name, float((err > 1e-4).mean()), float(err.max()))
+
+
+@pytest.mark.parametrize("tag", ["fixed", "auto"])
+def test_model_creation_matches_the_reference(tag):
+    """GaussianModel.create_from_pcd (reference scene/gaussian_model.py:748-800) with a float64 brute-force 3-NN in the external
+    simple_knn slot (tests/golden/make_golden_init.py): the same anchors after voxel down-sampling (row order included: np.unique
+    sorts), the initial scaling from csrc/knn.hip's exact 3-NN, and the other per-anchor tensors; ``auto`` = voxel size taken from
+    the median 3-NN distance of the input points."""
+    from gsvc_amd.arguments import ModelParams
+    from gsvc_amd.model import GaussianModel
+    g = np.load(os.path.join(HERE, "golden", "model_init.npz"))
+    pc = GaussianModel(ModelParams(), feat_dim=50, n_offsets=10, voxel_size=0.001 if tag == "fixed" else 0.0, update_depth=3,
+                       update_init_factor=16, update_hierachy_factor=4, use_feat_bank=False, n_features_per_level=2, log2_hashmap_size=9,
+                       log2_hashmap_size_2D=9, resolutions_list=(18, 24), resolutions_list_2D=(130, 258), device="cuda")
+    pc.update_anchor_bound(-1.0, -0.5625, -0.03125)
+    np.random.seed(5)
+    pc.create_from_pcd(SimpleNamespace(points=g["points"].copy()), spatial_lr_scale=2.0)
+    pre = tag + "::"
+    assert abs(pc.voxel_size - float(g[pre + "voxel_size"])) <= 1e-6 * float(g[pre + "voxel_size"])
+    assert pc.spatial_lr_scale == float(g[pre + "spatial_lr_scale"])
+    for nm in ("_anchor", "_offset", "_mask", "_anchor_feat", "_rotation", "_opacity"):
+        got, want = getattr(pc, nm).detach().cpu().numpy(), g[pre + nm]
+        assert got.shape == want.shape, (nm, got.shape, want.shape)
+        assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), nm
+    got, want = pc._scaling.detach().cpu().numpy(), g[pre + "_scaling"]
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), float(np.abs(got - want).max())
+    names = ("_anchor", "_offset", "_mask", "_anchor_feat", "_scaling", "_rotation", "_opacity")
+    assert [bool(getattr(pc, nm).requires_grad) for nm in names] == [bool(v) for v in g[pre + "requires_grad"]]
