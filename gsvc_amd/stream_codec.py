@@ -46,16 +46,31 @@ def _lexsort(cols):
 
 def reorder_and_split(anchor, interval=0.01):
     """Order anchors by (z, x, y) and cut the order into z slabs of ``interval`` (reference utils/encodings.py:827-862).
-    Returns (selection, [(start, end), ...]); slabs without an anchor are left out (the reference assumes there are none)."""
+    Returns (selection, [(start, end), ...]).
+
+    The slab boundaries are the reference's, bit for bit: it walks ``lb += interval; ub += interval`` on float32 scalars from
+    ``lb = -ceil(|z_min| / interval) * interval`` while ``ub <= ceil(|z_max| / interval) * interval``, so boundary k is a float32
+    ACCUMULATION (not k * interval) — which side of a boundary an anchor with z = 0.01 or 0.02 falls on depends on it — and an anchor
+    belongs to the first slab whose ``ub`` exceeds its z.  Where the reference's walk leaves anchors out (its accumulated ``ub`` can
+    pass the rounded maximum one slab early, and ub_k / lb_(k+1) can differ by an ulp) it silently drops them from every slab;
+    here they join the slab that follows the gap (or the last one), so the slabs always cover all anchors.  Empty slabs (the
+    reference assumes there are none) are left out."""
     sel = _lexsort([anchor[:, 2], anchor[:, 0], anchor[:, 1]])
     z = anchor[sel, 2]
-    z_min, z_max = z.min(), z.max()
+    z_min, z_max = z.min().float().cpu(), z.max().float().cpu()
     assert z_min < 0 and z_max > 0
-    # slab k = [lb + k * interval, lb + (k + 1) * interval), lb = -ceil(|z_min| / interval) * interval; the reference steps a
-    # float32 accumulator (lb += interval), whose rounding can end the walk one slab early and drop that slab's
-    # anchors — here the slab index of every anchor is computed directly, so the slabs always cover all anchors
-    lb = -float(torch.ceil(z_min.abs().double() / interval)) * interval
-    k = torch.floor((z.double() - lb) / interval).to(torch.int64)        # non-decreasing along the z order
+    lb = -torch.ceil(z_min.abs() / interval) * interval            # float32 scalars on the host, the reference's expressions
+    z_max_round = torch.ceil(z_max.abs() / interval) * interval + 1e-10
+    ub = lb + interval
+    ubs = []
+    while ub <= z_max_round:
+        ubs.append(float(ub))
+        lb += interval
+        ub += interval
+    if not ubs:
+        ubs = [float(ub)]
+    ub_t = torch.tensor(ubs, dtype=torch.float32, device=z.device)
+    k = torch.searchsorted(ub_t, z.float().contiguous(), right=True).clamp_(max=len(ubs) - 1)      # non-decreasing along the z order
     change = torch.ones_like(k, dtype=torch.bool)
     change[1:] = k[1:] != k[:-1]
     starts = change.nonzero(as_tuple=False).squeeze(1).tolist()
