@@ -50,6 +50,15 @@ def anchors(A: int, fn: dict, threshold: float, seed: int) -> dict:
             "_rotation": rot, "_opacity": torch.zeros(A, 1)}
 
 
+def anchors_uniform(A: int, fn: dict, seed: int) -> dict:
+    """Per-anchor parameters with z uniform over the whole cube (every 0.01 z-slab of the stream codec is populated: the
+    reference's encoder fails on an empty slab) and a third of the offset masks switched off."""
+    d = anchors(A, fn, 1.0, seed + 1)
+    g = _gen("anchors_uniform", seed)
+    d["_anchor"][:, 2] = (torch.rand(A, generator=g) * 2 - 1) * (-fn["z_min"]) * 0.98
+    return d
+
+
 def fill_parameters(module, seed: int):
     """Every floating-point tensor of ``module.state_dict()`` that is not a per-anchor tensor, filled from a generator seeded by
     its NAME (the two implementations share the state_dict keys, not the construction order): linear weights U(+-1.7/sqrt(fan_in)),

@@ -356,3 +356,76 @@ def test_committed_stream_keeps_the_format_from_drifting():
     got = codec.ans_encode(sym, mu, sigma, int(g["smin"]), int(g["smax"]), seg_len=int(g["seg_len"]))
     assert got == g["stream"].tobytes()
     assert torch.equal(codec.ans_decode(g["stream"].tobytes(), mu, sigma).to(torch.int32), sym)
+
+
+def test_stream_encoder_feeds_its_coders_what_the_reference_feeds_its_own():
+    """tests/golden/stream_encode.npz (make_golden_encode.py): the reference's UNMODIFIED conduct_stream_encoding (scene/gaussian_model.py:
+    2313-2604) with spies in the slots of its external coders, on the production-dimension model.  gsvc_amd.stream_codec must hand
+    its own coders the same things in the same order: per z-slab and attribute the symbol range, the integer symbols, the model
+    (mu = mean / Q, sigma = scale / Q); the binary streams' probabilities and bits.  (The coders themselves differ — the reference's
+    are external packages — so the BYTES are not comparable; everything in front of them is.)"""
+    import os
+    from tests.golden import seeded
+    from gsvc_amd import stream_codec as SC
+    from gsvc_amd.arguments import ModelParams
+    from gsvc_amd.model import GaussianModel
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stream_encode.npz"))
+    sc, P = seeded.SCENE, seeded.PROD
+    fn = seeded.frame_numbers(sc["H"], sc["W"], sc["T"], sc["frame"])
+    mp = ModelParams()
+    mp.threshold = sc["threshold"]
+    pc = GaussianModel(mp, feat_dim=P["feat_dim"], n_offsets=P["n_offsets"], voxel_size=0.001, update_depth=3, update_init_factor=16,
+                       update_hierachy_factor=4, use_feat_bank=False, n_features_per_level=P["n_features_per_level"],
+                       log2_hashmap_size=P["log2_hashmap_size"], log2_hashmap_size_2D=P["log2_hashmap_size_2D"],
+                       resolutions_list=P["resolutions_list"], resolutions_list_2D=P["resolutions_list_2D"], device="cuda")
+    pc.update_anchor_bound(fn["x_min"], fn["y_min"], fn["z_min"])
+    for name, t in seeded.anchors_uniform(sc["A"], fn, sc["seed"]).items():
+        setattr(pc, name, torch.nn.Parameter(t.cuda(), requires_grad=name not in ("_rotation", "_opacity")))
+    seeded.fill_parameters(pc, sc["seed"])
+    calls, binary = [], []
+    real_gauss, real_bin = SC.encoder_gaussian, SC.encode_binary
+
+    def spy_gauss(x, mean, scale, Q, lo, hi, file_name=None):
+        if not isinstance(Q, torch.Tensor):
+            Q = torch.full_like(mean, float(Q))
+        calls.append((x.detach().reshape(-1).cpu(), (mean / Q).detach().reshape(-1).cpu(), (scale / Q).detach().reshape(-1).cpu()))
+        return real_gauss(x, mean, scale, Q, lo, hi, file_name)
+
+    def spy_bin(x01, p_one):
+        binary.append((x01.detach().reshape(-1).cpu(), float(p_one)))
+        return real_bin(x01, p_one)
+    SC.encoder_gaussian, SC.encode_binary = spy_gauss, spy_bin
+    try:
+        pack = SC.conduct_stream_encoding(pc)
+    finally:
+        SC.encoder_gaussian, SC.encode_binary = real_gauss, real_bin
+    assert pack.n == int(g["meta::anchor_num"]) and pack.n_full == int(g["meta::total_anchor_num"])
+    assert abs(pack.prob_hash - float(g["meta::prob_hash"])) < 1e-7 and abs(pack.prob_masks - float(g["meta::prob_masks"])) < 1e-7
+    stride, n_calls = int(g["meta::stride"]), int(g["meta::n_calls"])
+    assert len(calls) == n_calls == 3 * len(pack.slabs)
+    flips = total = 0
+    for i, (sym, mu, sg) in enumerate(calls):
+        pre = f"call{i}::"
+        lo, hi, n = [int(v) for v in g[pre + "range"]]
+        assert sym.numel() == n, (i, str(g[pre + "name"]), sym.numel(), n)
+        want = g[pre + "symbols"]
+        got = sym[::stride].numpy().astype(np.int32)
+        d = got != want
+        assert (np.abs(got - want)[d] <= 1).all(), i           # a rounding decision on a half-integer may fall the other way: by one
+        flips += int(d.sum())
+        total += want.size
+        s = g[pre + "sums"]
+        assert abs(float(sym.double().sum()) - s[0]) <= 1e-3 * max(1.0, s[1]) + 4, (i, float(sym.double().sum()), s[0])
+        mu_w, sg_w = g[pre + "mu"], g[pre + "sigma"]
+        assert np.abs(mu[::stride].numpy() - mu_w).max() <= 1e-4 * max(1.0, np.abs(mu_w).max()), i
+        assert np.abs(sg[::stride].numpy() - sg_w).max() <= 1e-4 * max(1e-6, np.abs(sg_w).max()), i
+        got_lo, got_hi = int(sym.min()), int(sym.max())
+        assert abs(got_lo - lo) <= 1 and abs((got_hi if got_hi != got_lo else got_hi + 1) - hi) <= 1, (i, got_lo, got_hi, lo, hi)
+    assert flips <= max(3, int(2e-4 * total)), (flips, total)
+    # binary streams: the reference codes the hash tables first, then the masks; here the masks are handed over first
+    (m_bits, m_p), (h_bits, h_p) = binary
+    for k, (bits, p_one) in ((0, (h_bits, h_p)), (1, (m_bits, m_p))):
+        assert bits.numel() == int(g[f"binary{k}::n"]) and int((bits > 0).sum()) == int(g[f"binary{k}::ones"])
+        assert abs((1.0 - p_one) - float(g[f"binary{k}::p_zero"])) < 1e-6
+        assert np.array_equal(np.packbits((bits[:4096] > 0).numpy()), g[f"binary{k}::bits"])
+    print(f"stream encode: {n_calls} coder calls, {total} sampled symbols, {flips} differ by one")
