@@ -358,7 +358,7 @@ def test_committed_stream_keeps_the_format_from_drifting():
     assert torch.equal(codec.ans_decode(g["stream"].tobytes(), mu, sigma).to(torch.int32), sym)
 
 
-def test_stream_encoder_feeds_its_coders_what_the_reference_feeds_its_own():
+def test_stream_codec_feeds_its_coders_what_the_reference_feeds_its_own_and_rebuilds_the_same_model():
     """tests/golden/stream_encode.npz (make_golden_encode.py): the reference's UNMODIFIED conduct_stream_encoding (scene/gaussian_model.py:
     2313-2604) with spies in the slots of its external coders, on the production-dimension model.  gsvc_amd.stream_codec must hand
     its own coders the same things in the same order: per z-slab and attribute the symbol range, the integer symbols, the model
@@ -429,3 +429,19 @@ def test_stream_encoder_feeds_its_coders_what_the_reference_feeds_its_own():
         assert abs((1.0 - p_one) - float(g[f"binary{k}::p_zero"])) < 1e-6
         assert np.array_equal(np.packbits((bits[:4096] > 0).numpy()), g[f"binary{k}::bits"])
     print(f"stream encode: {n_calls} coder calls, {total} sampled symbols, {flips} differ by one")
+    # the decoder's half: our decoder on our stream rebuilds what the reference's conduct_stream_decoding (scene/gaussian_model.py:
+    # 2625-2804, its coder slots handing back the encoder's symbols) rebuilds
+    import copy
+    dec = SC.conduct_stream_decoding(copy.deepcopy(pc), pack)
+    assert bool(dec.decoded_version) == bool(g["decoded::decoded_version"])
+    for nm in ("_anchor", "_anchor_feat", "_offset", "_scaling", "_mask"):
+        got = getattr(dec, nm).detach()
+        want = g["decoded::" + nm]
+        s0, s1 = [float(v) for v in g["decoded_sum::" + nm]]
+        assert got[::5].shape == want.shape, nm
+        d = np.abs(got[::5].cpu().numpy() - want)
+        scale = max(1e-9, float(np.abs(want).max()))
+        # a symbol that differs by one moves an attribute by one quantisation step: at most a handful of entries
+        assert (d > 1e-4 * scale).sum() <= max(3, int(2e-4 * d.size)), (nm, int((d > 1e-4 * scale).sum()), d.size)
+        assert abs(float(got.double().abs().sum()) - s1) <= 1e-4 * s1 + 1e-6, (nm, float(got.double().abs().sum()), s1)
+    assert int((dec.get_encoding_params() > 0).sum()) == int(g["decoded::hash_ones"])
