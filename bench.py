@@ -157,7 +157,9 @@ def pmc_traffic(workload, kernel):
         src = {"measured_live": False, "file": "profiles/pmc_latest.json", "valu": valu,
                "binary": data.get("_binary", {}).get(workload, "unknown"),
                "passes": data.get("_source", {}).get(workload, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")}
-        taken, now = data.get("_csrc_sha16", {}).get(workload), csrc_fingerprint()
+        # (the forward kernels' counters of `raster_fwd` are the ones of the raster_fwdbwd pass: same launches, same fingerprint entry)
+        sha = data.get("_csrc_sha16", {})
+        taken, now = sha.get(workload, sha.get("raster_fwdbwd") if workload == "raster_fwd" else None), csrc_fingerprint()
         if taken != now:
             src["valu"] = None
             src["refused"] = (f"gsvc_amd/csrc has changed since these counters were taken (sources then {taken}, now {now}): "
