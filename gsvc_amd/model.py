@@ -224,6 +224,10 @@ class _MixGridEncode(torch.autograd.Function):
         out = torch.empty(N, total, device=x.device, dtype=torch.float32)
         embs = [e.contiguous() for e in embs]
         st = _lib.current_stream(x.device)
+        if N == 0:                    # a view without a visible anchor: nothing to look up (and an empty tensor has no address to hand over)
+            ctx.save_for_backward(x, *embs)
+            ctx.grids, ctx.total = grids, total
+            return out
         if _MixGridEncode._many(grids):
             # the four grids in ONE launch (blockIdx.y runs over their 12 + 3 x 4 levels)
             jobs = _MixGridEncode._jobs(grids, x, total, embs, out.data_ptr(), None)
@@ -250,6 +254,8 @@ class _MixGridEncode(torch.autograd.Function):
         # the tables' gradients: slices of one zeroed buffer (one fill, not one per grid)
         sizes = [e.numel() if ctx.needs_input_grad[2 + k] else 0 for k, e in enumerate(embs)]
         zeros = torch.zeros(sum(sizes), device=x.device, dtype=torch.float32).split(sizes)
+        if N == 0:
+            return (None, None, *[zeros[k].view(e.shape) if ctx.needs_input_grad[2 + k] else None for k, e in enumerate(embs)])
         if _MixGridEncode._many(grids) and all(ctx.needs_input_grad[2 + k] for k in range(len(grids))):
             ges = [zeros[k].view(e.shape) for k, e in enumerate(embs)]
             jobs = _MixGridEncode._jobs(grids, x, total, None, grad.data_ptr(), ges)

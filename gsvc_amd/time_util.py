@@ -27,7 +27,7 @@ class Embedder:
         f = self.freq_bands.to(device=x.device, dtype=x.dtype)
         xf = x.unsqueeze(-2) * f.view(-1, 1)                       # [..., F, d]
         sc = torch.stack([torch.sin(xf), torch.cos(xf)], dim=-2)   # [..., F, 2, d]
-        sc = sc.reshape(*x.shape[:-1], -1)
+        sc = sc.reshape(*x.shape[:-1], 2 * f.numel() * x.shape[-1])      # (explicit: -1 is ambiguous for an empty batch)
         return torch.cat([x, sc], dim=-1) if self.include_input else sc
 
 
