@@ -1051,5 +1051,13 @@ def test_views_without_a_visible_anchor():
             _, overflowed = resolve_deferred([m.raster_state for m in many])
             assert not overflowed and int(many[0].visible_mask.sum()) > 0 and int(many[1].visible_mask.sum()) == 0
             assert torch.allclose(many[1].rendered_image, bg.cuda().view(3, 1, 1).expand_as(many[1].rendered_image))
+    # the decoder's loop over a run of frames that starts and ends outside the anchors' slabs
+    from gsvc_amd.ortho_gaussian_renderer import render_frames, render_pair
+    with torch.no_grad():
+        p = render_pair(empty_fr, pc, pipe, bg, mode=GenerateMode.DECODING_AS_IS).rendered_image
+        assert torch.allclose(p, bg.cuda().view(3, 1, 1).expand_as(p))
+        imgs = list(render_frames([empty_fr, full_fr, cube.get_dummy_frame(11)], pc, pipe, bg))
+        assert len(imgs) == 3 and torch.allclose(imgs[0], bg.cuda().view(3, 1, 1).expand_as(imgs[0])) and torch.equal(imgs[0], imgs[2])
+        assert not torch.allclose(imgs[1], imgs[0])
     # (the LOSS of a step with an empty view is NaN in the reference too — its regularisers and rates are means over empty
     # selections, pipeline/train.py:415-436, guassian.py:110-132 — and is not defined here either: GSVC's anchors cover every frame)
