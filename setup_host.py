@@ -34,6 +34,15 @@ if __name__ == "__main__":
     setup(name="gsvc_amd_host", packages=[],
           ext_modules=cythonize(exts, language_level=3, build_dir="build/cython", nthreads=0,
                                 compiler_directives={"binding": True, "always_allow_keywords": True, "annotation_typing": False}))
+    # the generated C sources and objects are intermediates (4 MB of machine-written C per module): gone once the modules exist
+    import shutil
+    for d in glob.glob(os.path.join(ROOT, "build", "cython")) + glob.glob(os.path.join(ROOT, "build", "temp.*")) + \
+            glob.glob(os.path.join(ROOT, "build", "lib.*")):
+        shutil.rmtree(d, ignore_errors=True)
+    try:
+        os.rmdir(os.path.join(ROOT, "build"))
+    except OSError:
+        pass
     # what each compiled module was built from: gsvc_amd/__init__.py refuses to run a compiled module whose .py has changed since
     import hashlib
     import json
