@@ -5,7 +5,7 @@ already quantised to integers, the context model's ``mean`` / ``scale`` and the 
 — the coder behind them is this library's rANS instead of the external ``gsvc_cuda_ans.ANSCoder``, and a stream is a
 ``bytes`` object (optionally also written to ``file_name``) instead of a file only.
 
-Stream layout (little endian): magic ``GSA3`` | Phi-table checksum (u32) | n (u64) | seg_len (u32) | min (i32) | max (i32) | n_seg (u64) |
+Stream layout (little endian): magic ``GSA4`` | Phi-table checksum (u32) | n (u64) | seg_len (u32) | min (i32) | max (i32) | n_seg (u64) |
 seg_bytes[n_seg] (u32) | the segments back to back.
 """
 from __future__ import annotations
@@ -17,7 +17,8 @@ import torch
 
 from . import _lib
 
-MAGIC = b"GSA3"          # GSA1 / GSA2: Phi from double erfc; GSA3: Phi from the fixed-point table (checksum in the header)
+MAGIC = b"GSA4"          # GSA1 / GSA2: Phi from double erfc; GSA3: Phi from the fixed-point table (checksum in the header); GSA4: frequency
+                         # floor 2^-16 per symbol (the rate model's likelihood floor) instead of 2^-20
 SEG_LEN = 4096          # symbols per independent segment: 64 bits of state + size per segment = 0.016 bit per symbol
 _HEADER = struct.Struct("<4sIQIiiQ")
 

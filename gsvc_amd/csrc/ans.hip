@@ -7,8 +7,8 @@
 // P(s) = Phi((s + 1/2 - mu) / sigma) - Phi((s - 1/2 - mu) / sigma), tails folded into min and max.
 //
 // Coder: range-ANS, 32-bit state in [2^23, 2^31), byte renormalisation, 20-bit probabilities.  The cumulative
-// frequency of symbol s is  C(s) = floor(Phi((s - 1/2 - mu) / sigma) * (2^20 - R)) + (s - min),  R = max - min + 1, C(min) = 0,
-// C(max + 1) = 2^20: every symbol keeps a frequency >= 1 whatever the model says, and encoder and decoder evaluate the
+// frequency of symbol s is  C(s) = floor(Phi((s - 1/2 - mu) / sigma) * (2^20 - F R)) + F (s - min),  R = max - min + 1, F = ans_floor(R)
+// (16 for alphabets up to 512 symbols), C(min) = 0, C(max + 1) = 2^20: every symbol keeps a frequency >= F whatever the model says, and encoder and decoder evaluate the
 // same exactly specified expression (Phi from a fixed-point table, see ans_cdf; no table of R entries per symbol).  The symbols are cut into segments of `seg_len`;
 // one lane codes one segment sequentially (rANS is serial), segments are independent streams: [4-byte final state]
 // [renormalisation bytes in the order the decoder reads them].  K1 codes into a fixed-stride scratch (from the end of
@@ -43,6 +43,16 @@ __device__ __forceinline__ void load_phi_table(uint32_t *lds, int tid, int nthre
     __syncthreads();
 }
 
+// Frequency floor of every symbol, in units of 2^-20: 16 (= 2^-16, the likelihood floor the rate model is trained and priced with:
+// reference utils/entropy_models.py Low_bound, `likelihood >= 2^-16`) while the floors of the whole alphabet take at most 1/128 of the
+// probability mass, down to 1 for very wide alphabets.  With a floor of 2^-20 (GSA3) a symbol in the model's far tail cost 20 bits
+// where the estimate charges 16: 1-3 % of a fitted model's attribute bytes, 7 % after a long fit (round 5, profiles/r05).
+__host__ __device__ inline uint32_t ans_floor(uint32_t R)
+{
+    const uint32_t f = (ANS_M >> 7) / (R ? R : 1u);
+    return f > 16u ? 16u : (f < 1u ? 1u : f);
+}
+
 // C(s) for s in [min, max + 1]; inv_sigma = 1.0 / sigma, computed once per symbol by encoder and decoder alike
 __device__ __forceinline__ uint32_t ans_cdf(const uint32_t *__restrict__ phi, int s, double mu, double inv_sigma, int smin, int smax)
 {
@@ -61,8 +71,9 @@ __device__ __forceinline__ uint32_t ans_cdf(const uint32_t *__restrict__ phi, in
         const uint32_t a = phi[i], b = phi[i + 1];
         p32 = a + (uint32_t)(((uint64_t)(b - a) * f) >> 16);
     }
-    const uint32_t c = (uint32_t)(((uint64_t)p32 * (uint64_t)(ANS_M - R)) >> 32);
-    return c + (uint32_t)(s - smin);
+    const uint32_t F = ans_floor(R);
+    const uint32_t c = (uint32_t)(((uint64_t)p32 * (uint64_t)(ANS_M - F * R)) >> 32);
+    return c + F * (uint32_t)(s - smin);
 }
 
 __global__ void __launch_bounds__(64) k_ans_encode(const int32_t *__restrict__ sym, const float *__restrict__ mu,

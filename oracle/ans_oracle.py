@@ -12,13 +12,13 @@ restates that specification in plain Python integers / IEEE doubles, sharing no 
              its FNV-1a checksum (over the entries' little-endian bytes) travels in the stream header
   C(s)       0 for s <= min, 2^20 for s > max, otherwise with z = ((double) s - 0.5 - mu) * (1.0 / sigma), t = (z + 8) * 256:
              p32 = table[floor t] + (((table[floor t + 1] - table[floor t]) * floor((t - floor t) 65536)) >> 16)
-             (0 for t <= 0 — 2^31 for a NaN z —, 2^32 - 1 for t >= 4096);  C = ((p32 * (2^20 - R)) >> 32) + (s - min)
+             (0 for t <= 0 — 2^31 for a NaN z —, 2^32 - 1 for t >= 4096);  C = ((p32 * (2^20 - F R)) >> 32) + F (s - min), F = floor_of(R) = min(16, max(1, 2^13 // R))
   coder      rANS, 32-bit state x in [2^23, 2^31), 20-bit frequencies, byte renormalisation.  A segment of seg_len symbols is coded
              from its LAST symbol to its first: while x >= 2048 freq: emit x & 255, x >>= 8;  x = (x // freq) << 20 | ... + start.
              Segment bytes = final state (big endian) followed by the emitted bytes in REVERSE order of emission (= the order the
              decoder consumes them).  Decoder: slot = x & (2^20 - 1), s = the symbol with C(s) <= slot < C(s + 1),
              x = freq (x >> 20) + slot - start, then while x < 2^23: x = x << 8 | next byte.
-  container  "GSA3" | checksum u32 | n u64 | seg_len u32 | min i32 | max i32 | n_seg u64 | seg_bytes u32[n_seg] | segments  (little endian)
+  container  "GSA4" | checksum u32 | n u64 | seg_len u32 | min i32 | max i32 | n_seg u64 | seg_bytes u32[n_seg] | segments  (little endian)
 """
 from __future__ import annotations
 
@@ -31,7 +31,7 @@ SCALE_BITS = 20
 M = 1 << SCALE_BITS
 L = 1 << 23
 PHI_STEPS = 4096
-MAGIC = b"GSA3"
+MAGIC = b"GSA4"
 HEADER = struct.Struct("<4sIQIiiQ")
 
 
@@ -59,6 +59,12 @@ _TAB = phi_table()
 CHECKSUM = table_checksum(_TAB)
 
 
+def floor_of(R: int) -> int:
+    """Frequency floor of every symbol in units of 2^-20: 16 (the 2^-16 likelihood floor of the rate model) while the alphabet's
+    floors take at most 1/128 of the mass, down to 1 for very wide alphabets (csrc/ans.hip ans_floor)."""
+    return min(16, max(1, (M >> 7) // max(R, 1)))
+
+
 def cdf(s: int, mu: np.float64, inv_sigma: np.float64, smin: int, smax: int) -> int:
     if s <= smin:
         return 0
@@ -77,7 +83,8 @@ def cdf(s: int, mu: np.float64, inv_sigma: np.float64, smin: int, smax: int) -> 
         f = int((t - np.float64(i)) * np.float64(65536.0))
         a, b = _TAB[i], _TAB[i + 1]
         p32 = a + (((b - a) * f) >> 16)
-    return ((p32 * (M - R)) >> 32) + (s - smin)
+    F = floor_of(R)
+    return ((p32 * (M - F * R)) >> 32) + F * (s - smin)
 
 
 def _model(mu, sigma):
@@ -153,7 +160,7 @@ def decode_segment(buf: bytes, mu, inv, smin, smax):
 def decode(stream: bytes, mu, sigma) -> np.ndarray:
     magic, crc, n, seg_len, smin, smax, n_seg = HEADER.unpack_from(stream, 0)
     if magic != MAGIC:
-        raise ValueError("ans_oracle: not a GSA3 stream")
+        raise ValueError("ans_oracle: not a GSA4 stream")
     if crc != CHECKSUM:
         raise ValueError("ans_oracle: the stream was coded with another Phi table")
     if seg_len <= 0 or n_seg != ((n + seg_len - 1) // seg_len if n > 0 else 0):

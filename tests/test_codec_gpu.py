@@ -20,7 +20,8 @@ def _ideal_bits(sym, mu, sigma, smin, smax):
 
     def C(v):
         p = 0.5 * erfc(-((v - 0.5 - m) / sg) * 0.7071067811865476)
-        c = np.floor(np.clip(p, 0, 1) * (M - R)) + (v - smin)
+        F = min(16, max(1, (M >> 7) // R))          # csrc/ans.hip ans_floor
+        c = np.floor(np.clip(p, 0, 1) * (M - F * R)) + F * (v - smin)
         c = np.where(v <= smin, 0.0, c)
         return np.where(v > smax, float(M), c)
 
@@ -118,7 +119,9 @@ def test_encoder_decoder_gaussian_interface():
     back = decoder_gaussian(mean, scale, Q, stream=stream)
     assert torch.equal(back, x * Q)
     est = EntropyGaussian()(x, mean, scale, Q[:, :1], quantized=True).sum().item()
-    assert abs(bits - est) <= 0.015 * est, (bits, est)
+    # (the model's ideal code length is within 0.02 % of the estimate on this data; the rest is framing: 9 bytes per 2 048-symbol
+    # segment at ~2 bits per symbol = 1.7 %)
+    assert abs(bits - est) <= 0.02 * est, (bits, est)
 
 
 def _fitted_like_model(dev, anchors=20000):

@@ -21,7 +21,8 @@ def test_fit_encode_decode_evaluate_small(tmp_path):
                         "--slab-frames", "8", "--densify-grad-threshold", "2e-5", "--payload-tol", "0.12", "--json", str(out)])
     log = json.loads(out.read_text())
     assert [p["mode"] for p in log["phases"]] == ["TRAINING_FULL_PRECISION", "TRAINING_QUANTIZED", "TRAINING_ENTROPY", "TRAININ_STE_ENTROPY"]
-    assert log["checks"]["decoded_equals_ste_phase_dB"] <= 0.03
+    assert log["checks"]["decoded_equals_quantised_model_dB"] <= 0.01
+    assert abs(log["checks"]["ste_phase_minus_decoded_dB"]) <= 0.2
     assert log["decoded_8bit_mlp"]["psnr"] > 20.0 and 0.0 < log["bpp"] < 5.0      # (24 small frames: the 0.37 MB MLP file dominates)
     assert log["anchors_coded"] <= log["anchors_final"] and len(log.get("adjust_anchor", [])) >= 3      # densification did act
     # at this size the rANS payload is a few per cent off the estimate either way (a 240-step model: heavy tails, where the estimate's

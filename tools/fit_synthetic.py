@@ -8,8 +8,13 @@ statistics from 500, densification 1 500 .. 25 000 every 100, paused 1 000 itera
 ``--steps`` iterations with the same proportions.  Reports PSNR / SSIM / MS-SSIM of the decoded video, bits per pixel of the
 written streams (anchor geometry + attributes + masks + hash tables + 8-bit MLP file), and checks the two identities the codec is
 built on:
-  * the decoder renders what the straight-through phase trained on: decoded PSNR == STE-phase PSNR (same MLPs) within 0.03 dB
-    (measured 0.001-0.002 dB at 39 dB, 0.02 dB at 46 dB: isolated rounding flips, see ``ste_vs_decoded_one_frame``);
+  * the decoder reproduces the straight-through model: the decoded model (pruned, reordered, entropy-coded) renders what the fitted
+    model renders with its attributes replaced by their straight-through values (same MLPs) — PSNR within 0.01 dB; in the 1080p
+    runs of profiles/r05 the SAME PIXELS bit for bit (``decoded_vs_quantised_model_max_abs`` 0.0), at the test's toy size 0.3 % of
+    the pixels differ (whole-step flips of isolated attributes: the quantisation steps come from the networks run over all anchors
+    here and per z-slab in the codec).  The STE-phase render of the live model is 0.001-0.06 dB away from both (39-47 dB): the
+    anchor-level visibility test reads the unquantised scalings while training and the decoded ones afterwards — in the reference
+    too (``ste_vs_decoded_one_frame`` counts the anchors that are in one visible set only);
   * the streams are as long as the entropy model says: the attribute streams' coded payload within 2 % of ``estimate_final_bits``
     (payload = stream bytes minus the framing that buys the decoder its parallelism: 36-byte header + 9 bytes per independently
     decodable segment, gsvc_amd/codec.py — at ~0.3 bit per symbol that framing is itself ~5 % and is reported beside it).
@@ -42,6 +47,7 @@ def main(argv=None):
     ap.add_argument("--densify-grad-threshold", type=float, default=None, help="default: the reference's 5e-4")
     ap.add_argument("--payload-tol", type=float, default=0.02, help="allowed |coded payload / estimate_final_bits - 1| of the attribute streams")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--dump-coder-inputs", default=None, help="npz of what the first slabs hand to the entropy coder (symbols, mu, sigma)")
     ap.add_argument("--lpips-weights", default=None, help="backbone (+ --lpips-lin-weights) file for gsvc_amd.lpips.LPIPS")
     ap.add_argument("--lpips-lin-weights", default=None)
     args = ap.parse_args(argv)
@@ -133,17 +139,53 @@ def main(argv=None):
         log["psnr_ste_phase"] = psnr_of(pc, GenerateMode.TRAININ_STE_ENTROPY)
         _, est = pc.estimate_final_bits()
         # (a) the streams under the trained fp32 MLPs: what the two identities are checked on
+        if args.dump_coder_inputs:
+            from gsvc_amd import stream_codec as SC
+            real, dump = SC.encoder_gaussian, {}
+
+            def spy(x, mean, scale, Q, lo, hi, file_name=None):
+                i = len(dump) // 3
+                if i < 12:
+                    dump[f"sym{i}"] = x.detach().reshape(-1).cpu().numpy().astype(np.int32)
+                    dump[f"mu{i}"] = (mean / Q).detach().reshape(-1).cpu().numpy()
+                    dump[f"sigma{i}"] = (scale / Q).detach().reshape(-1).cpu().numpy()
+                return real(x, mean, scale, Q, lo, hi, file_name)
+            SC.encoder_gaussian = spy
+            try:
+                pack = conduct_stream_encoding(pc)
+            finally:
+                SC.encoder_gaussian = real
+            np.savez_compressed(args.dump_coder_inputs, **dump)
         pack = conduct_stream_encoding(pc)
         dec = conduct_stream_decoding(copy.deepcopy(pc), pack)
         log["psnr_decoded"] = psnr_of(dec, GenerateMode.DECODING_AS_IS)
-        # where the two differ at all: a rounding decision round(x / Q) whose x / Q sits on a half-integer within the last bits of
-        # the two evaluations of Q (per visible set in the STE render, per slab in the codec) moves one attribute by a whole step:
-        # isolated Gaussians, not a drift of the picture
+        # Exactly what does the decoder reproduce?  The model whose attributes are replaced by their straight-through values (what the
+        # STE phase computes per step: reference guassian.py:197-221) and stored as a decoded model — same anchors, same order, nothing
+        # pruned.  The decoded model (pruned by the masks, reordered by the geometry codec and the z-slabs) must render the same
+        # picture (0.01 dB; bit for bit in the 1080p runs).  The STE-phase render itself differs from both by its anchor-level visibility test, which reads the
+        # UNquantised scalings while training and the decoded ones afterwards (reference ortho_gaussian_renderer/preprocess.py:99-104
+        # on pc.get_scaling): a few hundred anchors at the slab's edge are in one set and not the other.
+        from gsvc_amd.encodings import STE_multistep
+        ec_all = pc.calc_entropy_context(pc.get_anchor)
+        qm = copy.deepcopy(pc)
+        qm._anchor_feat = torch.nn.Parameter(STE_multistep.apply(pc._anchor_feat, 1 * ec_all.Q_feat_adj, pc._anchor_feat.mean()))
+        qm._offset = torch.nn.Parameter(STE_multistep.apply(pc._offset, (0.2 * ec_all.Q_offsets_adj).unsqueeze(1), pc._offset.mean()))
+        qm._scaling = torch.nn.Parameter(STE_multistep.apply(pc.get_scaling, 0.001 * ec_all.Q_scaling_adj, pc.get_scaling.mean()))
+        qm._anchor, qm._mask = torch.nn.Parameter(pc.get_anchor.clone()), torch.nn.Parameter(pc.get_mask.clone())
+        qm.decoded_version = True
+        log["psnr_quantised_model"] = psnr_of(qm, GenerateMode.DECODING_AS_IS)
         fr0 = cube[eval_ids[len(eval_ids) // 2]]
-        d_img = (render_pair(fr0, pc, pipe, bg, mode=GenerateMode.TRAININ_STE_ENTROPY).rendered_image -
-                 render_pair(fr0, dec, pipe, bg, mode=GenerateMode.DECODING_AS_IS).rendered_image).abs()
+        img_q = render_pair(fr0, qm, pipe, bg, mode=GenerateMode.DECODING_AS_IS).rendered_image
+        img_d = render_pair(fr0, dec, pipe, bg, mode=GenerateMode.DECODING_AS_IS).rendered_image
+        img_s = render_pair(fr0, pc, pipe, bg, mode=GenerateMode.TRAININ_STE_ENTROPY).rendered_image
+        log["decoded_vs_quantised_model_max_abs"] = float((img_q - img_d).abs().max())
+        d_img = (img_s - img_d).abs()
+        from gsvc_amd.ortho_gaussian_renderer import prefilter_voxel
+        v_train, v_dec = prefilter_voxel(fr0, pc, pipe, bg), prefilter_voxel(fr0, qm, pipe, bg)
         log["ste_vs_decoded_one_frame"] = {"pixels_over_1e-3": int((d_img.amax(dim=0) > 1e-3).sum()), "max_abs": float(d_img.max()),
-                                           "mean_abs": float(d_img.mean()), "pixels": int(d_img[0].numel())}
+                                           "mean_abs": float(d_img.mean()), "pixels": int(d_img[0].numel()),
+                                           "visible_anchors_training_test": int(v_train.sum()), "visible_anchors_decoded_test": int(v_dec.sum()),
+                                           "anchors_in_one_set_only": int((v_train != v_dec).sum())}
         bits = pack.bits()
         from gsvc_amd.codec import _HEADER, _parse
         framing = 8 * sum(_HEADER.size + 9 * _parse(st)[0][4] for grp in (pack.feat, pack.scaling, pack.offsets) for st in grp if len(st))
@@ -172,13 +214,15 @@ def main(argv=None):
         log["total_bytes"] = int(total_bytes)
         log["bpp"] = 8.0 * total_bytes / (H * W * T)
         log["anchors_final"], log["anchors_coded"] = int(pc._anchor.shape[0]), int(pack.n)
-    d_psnr = abs(log["psnr_decoded"] - log["psnr_ste_phase"])
-    log["checks"] = {"decoded_equals_ste_phase_dB": d_psnr, "attribute_payload_within_2pct": abs(log["attribute_payload_vs_estimate"] - 1.0)}
+    d_psnr = abs(log["psnr_decoded"] - log["psnr_quantised_model"])
+    log["checks"] = {"decoded_equals_quantised_model_dB": d_psnr, "decoded_vs_quantised_model_max_abs": log["decoded_vs_quantised_model_max_abs"],
+                     "ste_phase_minus_decoded_dB": log["psnr_ste_phase"] - log["psnr_decoded"], "attribute_payload_within_2pct": abs(log["attribute_payload_vs_estimate"] - 1.0)}
     print(json.dumps(log))
     if args.json:
         with open(args.json, "w") as f:
             json.dump(log, f, indent=1)
-    assert d_psnr <= 0.03, f"decoded PSNR {log['psnr_decoded']:.4f} vs STE-phase PSNR {log['psnr_ste_phase']:.4f}"
+    assert d_psnr <= 0.01, \
+        f"decoded PSNR {log['psnr_decoded']:.5f} vs the quantised model's {log['psnr_quantised_model']:.5f}, max pixel difference {log['decoded_vs_quantised_model_max_abs']:.2e}"
     assert abs(log["attribute_payload_vs_estimate"] - 1.0) <= args.payload_tol, (log["attribute_payload_vs_estimate"], log["attribute_bytes_vs_estimate"])
     print(f"RD point: {log['decoded_8bit_mlp']['psnr']:.2f} dB PSNR, MS-SSIM {log['decoded_8bit_mlp']['msssim']:.4f} at {log['bpp']:.4f} bpp "
           f"({total_bytes / 2 ** 20:.2f} MiB for {T} frames {W}x{H}); fit {log['fit_seconds']:.1f} s")
