@@ -508,6 +508,9 @@ def run_train_step(args, rank, world, dev):
     comm = None
     if world > 1:
         sent_bytes, sparse_used = trainer.reducer.bytes_sent, trainer.reducer._sparse is not None
+        zown = getattr(trainer, "_zown", None)
+        if zown is not None:      # GSVC_DP_ZOWN=1: halo rows of gradients to their owners + the owners' updated rows back
+            sent_bytes += zown.bytes_sent
         early_steps = getattr(trainer, "early_steps", 0)
         trainer.reducer.enabled = False
         for _ in range(3):
@@ -522,7 +525,9 @@ def run_train_step(args, rank, world, dev):
                 # visible anchors (index + row lists, padded to the largest count over the ranks), hash tables and MLPs dense
                 "gradient_bytes_per_step": int(sent_bytes),
                 "dense_gradient_bytes": 4 * sum(p.numel() for g in pc.optimizer.param_groups for p in g["params"] if p.requires_grad),
-                "per_anchor_exchange": "rows of the distinct visible anchors (all-gather + scatter-add)" if sparse_used else "dense all-reduce",
+                "per_anchor_exchange": ("z-range ownership: halo rows of gradients to their owners, updated rows back (all_to_all between neighbours)"
+                                        if zown is not None else
+                                        "rows of the distinct visible anchors (all-gather + scatter-add)" if sparse_used else "dense all-reduce"),
                 "early_plan_steps": early_steps}
 
     # per-kernel pass: same K steps with HIP events around every launch on the launch stream

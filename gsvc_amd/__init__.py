@@ -40,7 +40,10 @@ def _check_compiled_host():
         try:
             for so in built:
                 if os.path.relpath(so, here).split(".cpython-")[0] in stale:
-                    os.remove(so)
+                    try:
+                        os.remove(so)
+                    except FileNotFoundError:      # another rank of the same launch was faster (every rank imports the package)
+                        pass
             importlib.invalidate_caches()
             sys.stderr.write(f"gsvc_amd: removed compiled host modules built from older sources ({', '.join(sorted(stale))}): running the .py "
                              f"files; `python setup_host.py build_ext --inplace` compiles them again\n")

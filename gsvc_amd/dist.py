@@ -39,7 +39,7 @@ def init_from_env(backend: str | None = None):
 def log_ranks():
     """One stderr line on rank 0 naming the communicator the step's collectives will run on ("nccl" IS RCCL on ROCm), so that a
     scaling record can confirm how many ranks really took part."""
-    if world_size() > 1 and rank() == 0:
+    if active() and rank() == 0:
         import sys
         b = dist.get_backend()
         sys.stderr.write(f"gsvc_amd.dist: {'RCCL' if b == 'nccl' else b} ranks = {world_size()} (backend {b}; one rank per GPU, frames sharded "
@@ -49,6 +49,15 @@ def log_ranks():
 
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def active() -> bool:
+    """Is the data-parallel machinery on?  More than one rank — or GSVC_DP_FORCE=1 with an initialised process group of ONE rank
+    (test knob: every collective of the step then runs, as the identity, on a real one-rank RCCL communicator of a single-GPU
+    box: device / dtype / contiguity rules of the backend, stream ordering, group creation)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("GSVC_DP_FORCE") == "1"
 
 
 def rank() -> int:
@@ -64,7 +73,7 @@ def plan_group():
     tail runs, after it otherwise) — on the default group that would break the one order every rank must issue collectives in;
     a communicator of its own only needs ITS sequence to agree."""
     global _plan_group
-    if world_size() == 1:
+    if not active():
         return None
     if _plan_group is None:
         _plan_group = dist.new_group()
@@ -80,7 +89,7 @@ def plan_group_noop(device):
     """One collective on the plan group that carries nothing (MAX of a zero count, the shape a StepPlan exchanges): issued by a
     rank that has no plan to drop in a step every rank repeats, so that the ranks' plan-group sequences stay paired
     (Trainer.step).  Returns a holder whose ``_gmax_work`` the caller waits for."""
-    if world_size() == 1:
+    if not active():
         return None
     t = torch.zeros(1, dtype=torch.int64, device=device)
     return _NoopPlan(t, dist.all_reduce(t, op=dist.ReduceOp.MAX, group=plan_group(), async_op=True))
@@ -106,7 +115,7 @@ def allreduce_gradients(params, average: bool = True):
     bucket.  Every rank must hold gradients for the same parameters (true for a given GenerateMode)."""
     w = world_size()
     grads = [p.grad for p in params if p.grad is not None]
-    if w == 1 or not grads:
+    if not active() or not grads:
         return 0
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -156,7 +165,7 @@ class GradReducer:
         BASELINE configs[2] step.  ``idx=None``: dense.  Every rank must make the same choice in the same step (it follows from
         the step plan, whose availability does not depend on data)."""
         self._sparse_idx_all = None
-        if idx is None or world_size() == 1:
+        if idx is None or not active():
             self._sparse = None
             return
         n = int(idx.shape[0])
@@ -171,7 +180,7 @@ class GradReducer:
         none) — part of the order's key, so that a new phase agrees on a new order in its first step; an order carried over
         from a phase where such a parameter came early would stall every launch behind a hook that never fires."""
         self._params = [p for p in params if p.requires_grad]
-        if world_size() == 1 or not self.enabled:
+        if not active() or not self.enabled:
             self._armed = False
             return
         live = {id(p) for p in self._params}
@@ -264,7 +273,7 @@ class GradReducer:
         """Call after backward: launches what the hooks could not (first step: everything), reduces the small parameters, waits for
         everything, averages.  Returns the number of gradient elements reduced."""
         w = world_size()
-        if w == 1 or not self.enabled:
+        if not active() or not self.enabled:
             return 0
         self._armed = False
         # large parameters not launched from their hooks, in the agreed order (or parameter-list order while there is none);
@@ -318,7 +327,7 @@ def adjust_anchor_replicated(pc, iteration: int, **kw):
     ranks first (each rank only saw its own frames), the random thinning of anchor_growing draws from a per-iteration seed, and
     afterwards only rank 0 carries the surviving accumulator rows into the next interval — the others restart from zero, so that
     the next sum is (old global + every rank's new observations) and not world_size copies of the survivors."""
-    if world_size() == 1:
+    if not active():
         return pc.adjust_anchor(**kw)
     allreduce_statistics(pc)
     devices = [pc.device] if pc.device.type == "cuda" else []
@@ -330,7 +339,7 @@ def adjust_anchor_replicated(pc, iteration: int, **kw):
 
 def allreduce_statistics(pc):
     """Sum the densification accumulators across ranks (each rank only sees its own frames)."""
-    if world_size() == 1:
+    if not active():
         return
     for name in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
         t = getattr(pc, name, None)
@@ -340,7 +349,7 @@ def allreduce_statistics(pc):
 
 def keep_statistics_on_rank0(pc):
     """After an all-reduced adjust_anchor: ranks other than 0 zero their densification accumulators (see Trainer._adjust_anchor)."""
-    if world_size() == 1 or rank() == 0:
+    if not active() or rank() == 0:
         return
     for name in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
         t = getattr(pc, name, None)
@@ -351,7 +360,7 @@ def keep_statistics_on_rank0(pc):
 def any_rank(flag: bool, device) -> bool:
     """True on every rank if `flag` is True on at least one (a one-element MAX all-reduce; identity on one rank).
     Used for decisions all replicas must take together, e.g. repeating a step whose rasterizer buffer overflowed."""
-    if world_size() == 1:
+    if not active():
         return bool(flag)
     t = torch.tensor([1.0 if flag else 0.0], device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -362,7 +371,7 @@ def any_rank_start(flags_dev):
     """Non-blocking form of any_rank for flags that already live on the device (the rasterizers' overflow words): the
     MAX all-reduce and the copy of its result to the host are queued NOW — behind the kernels that produce the flags, not
     behind whatever is launched afterwards — and any_rank_finish() waits for that copy only.  None on a single rank."""
-    if world_size() == 1:
+    if not active():
         return None
     t = torch.stack([f.reshape(-1)[0] for f in flags_dev]).max().to(torch.float32).reshape(1)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -386,7 +395,196 @@ def any_rank_finish(handle, local_flag: bool) -> bool:
 
 def broadcast_parameters(module, src: int = 0):
     """Make every rank start from rank `src`'s parameters and buffers."""
-    if world_size() == 1:
+    if not active():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)
+
+
+# ------------------------------------------------------------------------------------------------ z-range ownership
+# SURVEY.md section 8(e) "Collective": "reduce-scatter by z-sorted anchor range + all-gather of updated params (each rank owns the
+# optimiser state of a z-range)".  Built as a HALO EXCHANGE, the shape xGMI's point-to-point links favour: the video's z axis is cut
+# between the ranks' frame blocks, every anchor belongs to the rank whose block holds its z (anchor positions have learning rate 0:
+# the owner of an existing anchor never changes), and a rank only ever READS the anchors inside its block widened by the slab
+# half-width on both sides.  Per step and rank:
+#   1. gradient rows of the halo — the anchors it can see but does not own — go to their owners (static row lists, one
+#      all_to_all_single = grouped sends / receives between neighbours; no index lists travel, no counts are agreed);
+#   2. the owner adds what arrived to its own rows in rank order (the same fp32 order as the replicated row exchange), averages,
+#      adds the mask regulariser's closed form and runs Adam: owned rows hold the one true value of the model;
+#   3. the owner sends the updated rows back along the same lists: every rank's block + halo is fresh before its next step.
+# Rows outside a rank's block + halo go stale there; nothing of the step reads them (the slab test is exact on the anchor's z) except
+# whole-tensor reductions, which become owner partial sums + one small all-reduce (param_means).  sync_full() makes every replica
+# whole again: before densification (every update_interval steps), before evaluation / encoding / checkpoints.
+# At configs[3] (100 k anchors, 8 ranks x 75 frames, slab +-48 frames) a rank sends 2 x 7.3 k halo rows of gradients and receives
+# as many rows of parameters: 11 MB per step against 41 MB of row lists or 67 MB of ring all-reduce (DESIGN section 6).
+PER_ANCHOR = ("_anchor_feat", "_offset", "_scaling", "_mask")
+
+
+def zrange_enabled() -> bool:
+    """GSVC_DP_ZOWN=1 under data parallelism (off by default: RCCL has not measured it yet)."""
+    return active() and os.environ.get("GSVC_DP_ZOWN") == "1"
+
+
+def _all_to_all_rows(out, inp, out_splits, in_splits):
+    """Rows to / from every peer by count (RCCL: one group of point-to-point sends and receives).  gloo has no CUDA all_to_all:
+    the tests' shared-GPU ranks stage through the host."""
+    if inp.is_cuda and dist.get_backend() == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host, inp.cpu(), out_splits, in_splits)
+        out.copy_(host)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits)
+    return out
+
+
+class ZRangeOwnership:
+    def __init__(self, num_frames: int, scale: float, threshold: float):
+        self.W, self.r = world_size(), rank()
+        T = int(num_frames)
+        shards = [frame_shard(T, q, self.W) for q in range(self.W)]
+
+        def z_of(t):          # reference frame_cube/frame.py:156-190: z = (id - T/2) / scale
+            return (t - T / 2) / scale
+        margin = 1e-4 * threshold + 1e-6          # the slab test runs in fp32 on view-space z: the read range errs on the wide side
+        # rank q renders frames lo .. hi (pairs (i, i + 1), i in [lo, hi)): it can see anchors within the slab of any of them
+        self.read = [(z_of(lo) - threshold - margin, z_of(hi) + threshold + margin) for lo, hi in shards]
+        self.cuts = [z_of(shards[q][0] - 0.5) for q in range(1, self.W)]      # owner(z) = number of cuts <= z
+        self._key = None
+        self.bytes_sent = 0          # payload this rank handed to the two exchanges in the last step
+        self.means = None
+
+    def ensure(self, pc):
+        a = pc._anchor
+        key = (id(a), int(a.shape[0]), a._version)
+        if key != self._key:
+            self.build(a)
+            self._key = key
+
+    def build(self, anchor):
+        """Row lists from the anchors' z — identical arithmetic on identical replicas: every rank derives every list it shares
+        with a peer by itself (rows ascending), nothing is exchanged."""
+        W, r = self.W, self.r
+        z = anchor.detach()[:, 2].float().contiguous()
+        dev, A = z.device, int(z.shape[0])
+        owner = (torch.bucketize(z, torch.tensor(self.cuts, dtype=z.dtype, device=dev), right=True) if self.cuts
+                 else torch.zeros(A, dtype=torch.int64, device=dev))
+        inr = [(z >= lo) & (z <= hi) for lo, hi in self.read]
+        own = owner == r
+        self.A, self.own_mask = A, own
+        self.own_idx = torch.nonzero(own).squeeze(1)
+        empty = torch.zeros(0, dtype=torch.int64, device=dev)
+        self.send_idx = [torch.nonzero((owner == q) & inr[r]).squeeze(1) if q != r else empty for q in range(W)]
+        self.recv_idx = [torch.nonzero(own & inr[q]).squeeze(1) if q != r else empty for q in range(W)]
+        t = torch.zeros(A, dtype=torch.bool, device=dev)
+        for idx in self.recv_idx:
+            t[idx] = True
+        self.touched = torch.nonzero(t).squeeze(1)          # owned rows some peer can see
+        # one dummy row in the rank's own slot keeps every message non-empty (a one-rank RCCL communicator still runs the call)
+        dummy = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.in_splits = [int(self.send_idx[q].shape[0]) if q != r else 1 for q in range(W)]
+        self.out_splits = [int(self.recv_idx[q].shape[0]) if q != r else 1 for q in range(W)]
+        self.send_all = torch.cat([self.send_idx[q] if q != r else dummy for q in range(W)])
+        self.recv_all = torch.cat([self.recv_idx[q] if q != r else dummy for q in range(W)])
+
+    def halo_rows(self):
+        """(rows sent as gradients / received as parameters, rows received as gradients / sent as parameters) per step."""
+        return sum(self.in_splits) - 1, sum(self.out_splits) - 1
+
+    @staticmethod
+    def _tensors(pc, names):
+        ts = [getattr(pc, n) for n in names]
+        assert all(p.is_contiguous() for p in ts)
+        return ts
+
+    def exchange_grads(self, pc, names=PER_ANCHOR):
+        """Step 1 + 2 above.  Afterwards the OWNED rows of every ``names`` gradient hold the mean over the ranks; other rows hold
+        local leftovers that the parameter refresh makes irrelevant."""
+        self.ensure(pc)
+        W, r, A = self.W, self.r, self.A
+        ts = self._tensors(pc, names)
+        for p in ts:
+            if p.grad is None:          # a rank whose views touched nothing still takes part
+                p.grad = torch.zeros_like(p)
+        g2 = [p.grad.view(A, -1) for p in ts]
+        widths = [int(g.shape[1]) for g in g2]
+        if os.environ.get("GSVC_DP_ZOWN_CHECK"):          # diagnostics: a gradient outside block + halo would be dropped silently
+            seen = torch.zeros(A, dtype=torch.bool, device=g2[0].device)
+            seen[self.own_idx] = True
+            seen[self.send_all] = True
+            for n, g in zip(names, g2):
+                bad = (g != 0).any(dim=1) & ~seen
+                if bool(bad.any()):
+                    raise RuntimeError(f"ZRangeOwnership: {int(bad.sum())} rows of {n}.grad lie outside this rank's block + halo")
+        inp = torch.cat([g.index_select(0, self.send_all) for g in g2], dim=1)
+        out = torch.empty(int(self.recv_all.shape[0]), sum(widths), dtype=inp.dtype, device=inp.device)
+        _all_to_all_rows(out, inp, self.out_splits, self.in_splits)
+        self.bytes_sent = 4 * (inp.shape[0] - 1) * inp.shape[1]
+        U, c0 = self.touched, 0
+        for g, w in zip(g2, widths):
+            if U.numel():
+                # ((0 + g_0) + g_1) + ... + g_{W-1}: the order GradReducer._finish_sparse uses, this rank's own rows in its place
+                mine = g.index_select(0, U)
+                g.index_fill_(0, U, 0.0)
+                off = 0
+                for q in range(W):
+                    n = self.out_splits[q]
+                    if q == r:
+                        g.index_add_(0, U, mine)
+                    elif n:
+                        g.index_add_(0, self.recv_idx[q], out[off:off + n, c0:c0 + w])
+                    off += n
+            c0 += w
+            g.div_(float(W))
+
+    def refresh_params(self, pc, names=PER_ANCHOR):
+        """Step 3: the owners' updated rows travel back along the same lists."""
+        self.ensure(pc)
+        W, r, A = self.W, self.r, self.A
+        ts = self._tensors(pc, names)
+        with torch.no_grad():
+            p2 = [p.view(A, -1) for p in ts]
+            widths = [int(p.shape[1]) for p in p2]
+            inp = torch.cat([p.index_select(0, self.recv_all) for p in p2], dim=1)
+            out = torch.empty(int(self.send_all.shape[0]), sum(widths), dtype=inp.dtype, device=inp.device)
+            _all_to_all_rows(out, inp, self.in_splits, self.out_splits)
+            self.bytes_sent += 4 * (inp.shape[0] - 1) * inp.shape[1]
+            c0 = 0
+            for p, w in zip(p2, widths):
+                off = 0
+                for q in range(W):
+                    n = self.in_splits[q]
+                    if q != r and n:
+                        p.index_copy_(0, self.send_idx[q], out[off:off + n, c0:c0 + w])
+                    off += n
+                c0 += w
+
+    def sync_full(self, pc, moments: bool = True):
+        """Every replica whole again: each row from its owner (zeros elsewhere, summed: x + 0 + ... + 0 is exact).  With
+        ``moments`` the Adam moments too (a checkpoint must hold the owners')."""
+        self.ensure(pc)
+        keep = self.own_mask.unsqueeze(1)
+        with torch.no_grad():
+            for n in PER_ANCHOR:
+                p = getattr(pc, n)
+                tensors = [p]
+                st = pc.optimizer.state.get(p, {}) if (moments and getattr(pc, "optimizer", None) is not None) else {}
+                tensors += [st[k] for k in ("exp_avg", "exp_avg_sq") if isinstance(st.get(k), torch.Tensor)]
+                for t in tensors:
+                    v = t.view(self.A, -1)
+                    v.masked_fill_(~keep, 0.0)
+                    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+
+    def update_means(self, pc):
+        """[mean(_anchor_feat), mean(get_scaling), mean(_offset)] — the clamp centres of the rate model and of the straight-through
+        quantiser (gsvc_amd.generate._param_means) — from the owners' partial sums: a replica's own whole-tensor mean would read
+        stale rows.  Once per step, before the forward (every rank the same number of collectives)."""
+        self.ensure(pc)
+        with torch.no_grad():
+            own = self.own_idx
+            parts = [pc._anchor_feat.detach().index_select(0, own), pc.get_scaling.detach().index_select(0, own),
+                     pc._offset.detach().index_select(0, own)]
+            s = torch.stack([t.sum(dtype=torch.float32) for t in parts])
+            dist.all_reduce(s, op=dist.ReduceOp.SUM)
+            n = torch.tensor([float(pc._anchor_feat.numel()), float(pc.get_scaling.numel()), float(pc._offset.numel())], device=s.device)
+            self.means = s / n
+        return self.means

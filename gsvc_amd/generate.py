@@ -272,7 +272,8 @@ class StepPlan:
         else:
             M = torch.stack(visible_masks)                               # [R, A] bool
             present = M.any(dim=0)
-        self._dp = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        from . import dist as gdist
+        self._dp = gdist.active()
         self._gmax = self._gmax_work = None
         self._A, self._sel_flat, self._ends = A, None, fused
         if fused:
@@ -846,6 +847,10 @@ def _iota(dev, n):
 def _param_means(pc):
     """(mean(_anchor_feat), mean(get_scaling), mean(_offset)) over ALL anchors as one float32 [3] tensor (csrc/rate.hip
     k_param_means: one pass; the torch expression is three reductions + an exp pass)."""
+    zo = getattr(pc, "_zown", None)
+    if zo is not None and zo.means is not None:      # z-range ownership: the owners' means (a replica's own rows are partly stale)
+        return zo.means
+
     from . import _lib
     f, sc, o = pc._anchor_feat, getattr(pc, "_scaling", None), pc._offset
     if sc is None or not (f.is_cuda and f.dtype == sc.dtype == o.dtype == torch.float32 and f.is_contiguous() and sc.is_contiguous() and o.is_contiguous()):

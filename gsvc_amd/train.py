@@ -157,6 +157,13 @@ class Trainer:
         gaussians.anchor_static = not self.anchor_grad      # the quantised anchors may be cached between steps (prefilter_geometry)
         self.reducer = gdist.GradReducer()
         gdist.plan_group()      # created HERE, where every rank stands at the same point (creating a group is itself collective)
+        # GSVC_DP_ZOWN=1: the per-anchor tensors are OWNED by z-range (gsvc_amd.dist.ZRangeOwnership) — gradients of the halo rows go
+        # to their owners, updated rows come back — instead of being summed on every replica
+        self._zown = None
+        if gdist.zrange_enabled() and batched and not self.anchor_grad:
+            self._zown = gdist.ZRangeOwnership(dataset.len_z_frames, dataset.scale, model_params.threshold)
+            assert abs(dataset[self.lo].z - (self.lo - dataset.len_z_frames / 2) / dataset.scale) < 1e-6, "frame z convention"
+        gaussians._zown = self._zown      # gsvc_amd.generate._param_means reads the owners' means from it
         self._mask_reg_weight = 0.0
         self._ovf_handle = None
 
@@ -194,7 +201,7 @@ class Trainer:
                 self.pc.optimizer.rewind(self._early[0])
                 dropped = self._early[3]          # its count exchange is in flight: the tensors stay alive until the repeat is done
                 self._early = None
-            elif self.prefetch and self.pc._anchor.is_cuda and gdist.world_size() > 1:
+            elif self.prefetch and self.pc._anchor.is_cuda and gdist.active():
                 # Whether the early tail ran is a rank-LOCAL fact (its row threshold and reducer.complete() depend on the rank's
                 # own views), and it queued a plan = one collective on the plan group.  A rank that did not run it answers with a
                 # matching no-op exchange, so that every rank has issued exactly ONE plan-group collective per attempted step:
@@ -224,6 +231,16 @@ class Trainer:
                 self._plan_mode = self.controller.render_mode
                 self._plan = plan_views(self._views(self._plan_idx), self.pc, self.pipe, self.background, self._plan_mode)
         return out
+
+    def sync_replicas(self, moments: bool = True):
+        """Under z-range ownership (GSVC_DP_ZOWN=1) a replica is only fresh inside its own block + halo: call this (on every rank)
+        before anything reads the whole model — evaluation, estimate_final_bits, stream encoding, a checkpoint."""
+        if self._zown is not None:
+            self._zown.sync_full(self.pc, moments=moments)
+
+    def _zown_names(self, mode):
+        # TRAININ_STE_ENTROPY renders from detached attributes: only _mask receives a gradient (and only it moves)
+        return ("_mask",) if mode == GenerateMode.TRAININ_STE_ENTROPY else gdist.PER_ANCHOR
 
     def _prefetch_frames(self, idx):
         """A dataset that keeps its pictures in host memory (gsvc_amd.frame.HostResidentCube) starts uploading the next step's pair
@@ -260,7 +277,7 @@ class Trainer:
         pc = self.pc
         with torch.no_grad():
             guards = [r.raster_state.binning[4:8].view(torch.int32) for r in renders]
-            if gdist.world_size() > 1:
+            if gdist.active():
                 # data parallel: the two gradients are final once their collectives (launched by the reducer's hooks, which run
                 # before this one) have completed; a step in which they have not gone out yet (no agreed order in the very first
                 # one) takes the ordinary end-of-step path.  "Some rank overflowed" guards the update as well.
@@ -279,7 +296,7 @@ class Trainer:
     def _sparse_dp(self, plan):
         """Row-sparse gradient exchange of the per-anchor tensors: needs the step plan (the rank's distinct visible anchors and the
         largest such count over the ranks) and the replicated Adam; GSVC_DP_SPARSE=0 keeps the dense all-reduce."""
-        if not (plan is not None and gdist.world_size() > 1 and self.reducer.enabled and not self.anchor_grad
+        if not (plan is not None and gdist.active() and self.reducer.enabled and not self.anchor_grad and self._zown is None
                 and getattr(plan, "distinct_cap", None) is not None and switches.DP_SPARSE != "0"):
             return False
         # every rank receives the other ranks' row lists (all-gather, padded to the largest): worth it while those rows are fewer
@@ -302,8 +319,12 @@ class Trainer:
         """Densify / prune (reference pipeline/train.py:567-569).  Under data parallelism every rank must take the same
         decisions: the statistics are summed over ranks first and the random thinning uses a per-iteration seed."""
         opt = self.opt
+        if self._zown is not None:
+            self._zown.sync_full(self.pc)      # the decisions read every row: whole replicas first (once per update_interval steps)
         gdist.adjust_anchor_replicated(self.pc, iteration, check_interval=opt.update_interval, success_threshold=opt.success_threshold,
                                        grad_threshold=opt.densify_grad_threshold, min_opacity=opt.min_opacity)
+        if self._zown is not None:
+            self._zown.ensure(self.pc)         # new anchors, new row lists (existing anchors keep their owner: z does not move)
 
     def _step(self, iteration: int, frame_idx: int | None = None, early: bool = True):
         for g in grid_tables(self.pc):
@@ -325,6 +346,10 @@ class Trainer:
         mode = self.controller.render_mode
         retain_grad = opt.update_until > iteration >= 0
 
+        zown = self._zown if (self._zown is not None and self.reducer.enabled) else None
+        pc._zown = zown
+        if zown is not None:
+            zown.update_means(pc)
         if self.batched:
             # one generation pass for the 4 views (frame1 f/b, frame2 f/b), then 4 rasterizations
             plan = self._plan if (self._plan is not None and self._plan_idx == frame_idx and self._plan_mode == mode and
@@ -385,7 +410,7 @@ class Trainer:
                 assert all(r.entropy_constrained for r in renders)
                 denom = pc._anchor.shape[0] * (pc.feat_dim + 6 + 3 * pc.n_offsets)
                 # sparse data-parallel exchange (below): the regulariser's dense gradient is added after the exchange (_add_mask_reg)
-                sparse_dp = self._sparse_dp(plan if self.batched else None)
+                sparse_dp = self._sparse_dp(plan if self.batched else None) or zown is not None
                 self._mask_reg_weight = 5e-4 if sparse_dp else 0.0
                 rate_sum = getattr(batch, "bit_per_param_sum", None)
                 # the renders' rates enter with one weight: their sum, when the batched generation already formed it, is one term
@@ -408,21 +433,29 @@ class Trainer:
             self._w_key, self._w = key, host_values(weights, dev, torch.float32)
         w = self._w
         loss = torch.dot(torch.stack([t.reshape(()) for t in terms]), w) + const
-        self.reducer.arm([p for g in pc.optimizer.param_groups for p in g["params"]], phase=mode)
+        owned = {id(getattr(pc, n)) for n in gdist.PER_ANCHOR} if zown is not None else ()
+        self.reducer.arm([p for g in pc.optimizer.param_groups for p in g["params"] if id(p) not in owned], phase=mode)
         use_rows = bool(self.batched and self._sparse_dp(plan))
         if use_rows:
             # the per-anchor gradients are non-zero only in the rows of this rank's distinct visible anchors: exchanged as rows
             self.reducer.set_sparse(plan.distinct, plan.distinct_cap, [pc._offset, pc._mask, pc._anchor_feat, pc._scaling])
         else:
             self.reducer.set_sparse(None, 0, [])
-        if gdist.world_size() > 1 and gdist.rank() == 0 and getattr(self, "_logged_exchange", None) != use_rows and plan is not None:
+        if zown is not None and gdist.rank() == 0 and getattr(self, "_logged_exchange", None) != "zown":
+            import sys
+            zown.ensure(pc)
+            self._logged_exchange = "zown"
+            sent, got = zown.halo_rows()
+            sys.stderr.write(f"gsvc_amd.train: per-anchor tensors owned by z-range: rank 0 owns {int(zown.own_idx.shape[0])} of {int(pc._anchor.shape[0])} "
+                             f"anchors, sends {sent} halo rows of gradients and returns {got} rows of parameters per step, {gdist.world_size()} ranks\n")
+        elif gdist.active() and gdist.rank() == 0 and getattr(self, "_logged_exchange", None) != use_rows and plan is not None:
             import sys
             self._logged_exchange = use_rows
             sys.stderr.write(f"gsvc_amd.train: per-anchor gradient exchange = {'rows of the distinct visible anchors (cap ' + str(plan.distinct_cap) + ')' if use_rows else 'dense all-reduce'}"
                              f" at {int(pc._anchor.shape[0])} anchors, {gdist.world_size()} ranks\n")
         handles = []
         if (early and self.batched and self.prefetch and pc._anchor.is_cuda
-                and (gdist.world_size() == 1 or (self.reducer.enabled and self.reducer._order is not None))
+                and (not gdist.active() or (self.reducer.enabled and self.reducer._order is not None and zown is None))
                 and not self.anchor_grad      # a trained anchor tensor moves behind the early plan's visibility test
                 and mode is not None and iteration < opt.iterations and not self.controller.gaussian_adjust_anchor
                 and isinstance(pc.optimizer, FusedAdam) and not switches.NO_EARLY_PLAN
@@ -462,6 +495,8 @@ class Trainer:
                         # small-work stream, which this one has just waited for) is queued: the slots' next upload may start behind here
         with region('step.reducer_finish'):
             self.reducer.finish()
+            if zown is not None:
+                zown.exchange_grads(pc, self._zown_names(mode))
             self._add_mask_reg()
 
         if self.batched:
@@ -490,6 +525,8 @@ class Trainer:
                 with region('step.optimizer'):
                     pc.optimizer.step()
                     pc.optimizer.zero_grad(set_to_none=True)
+                    if zown is not None:
+                        zown.refresh_params(pc, self._zown_names(mode))
         active = sum(r.active_gaussains for r in renders)
         _release_graph(renders)      # at every size: a StepOutput never carries the step's autograd graph (see _release_graph)
         return StepOutput(loss=loss.detach(), image1=image1.detach(), image2=image2.detach(), renders=renders,

@@ -1,7 +1,9 @@
 """Worker of tests/test_train_gpu.py::test_two_rank_step_averages_gradients (run under torch.distributed.run, 2 ranks):
 one data-parallel fitting step — each rank on a frame pair of its own shard, gradients exchanged by the overlapped
 reducer (gsvc_amd/dist.py) — must leave on every rank the MEAN of the two single-process gradients of those two pairs.
-Backend from GSVC_DIST_BACKEND: "nccl" (= RCCL, one GPU per rank) or "gloo" with GSVC_SHARE_GPU=1 (both ranks on device 0)."""
+Backend from GSVC_DIST_BACKEND: "nccl" (= RCCL, one GPU per rank) or "gloo" with GSVC_SHARE_GPU=1 (both ranks on device 0).
+GSVC_DP_FORCE=1 with ONE rank: the same collectives as the identity on a one-rank communicator (RCCL on a single-GPU box).
+GSVC_DP_ZOWN=1: the per-anchor tensors are owned by z-range — their gradients are compared on the rows this rank owns."""
 import faulthandler
 import os as _os
 faulthandler.dump_traceback_later(int(_os.environ.get("GSVC_HANG_DUMP", "300")), exit=True)      # a deadlocked rank prints its stacks and exits
@@ -64,12 +66,20 @@ def main():
     tr = Trainer(pc, cube, opt, pipe, mp, seed=3)
     captured = {}
 
+    per_anchor = {}
+
     def capture_instead_of_update():
         captured.clear()
         for g in pc.optimizer.param_groups:
             for i, p in enumerate(g["params"]):
                 if p.grad is not None:
                     captured[f"{g['name']}.{i}"] = p.grad.detach().clone()
+                    if any(p is getattr(pc, n) for n in gd.PER_ANCHOR):
+                        per_anchor[f"{g['name']}.{i}"] = True
+
+    def rows(k, t):
+        """What the exchange promises of tensor k: under z-range ownership the rows this rank owns."""
+        return t[tr._zown.own_idx] if (tr._zown is not None and k in per_anchor) else t
     pc.optimizer.step = capture_instead_of_update      # parameters stay as they are: every step below sees the same model
 
     mine = torch.tensor([tr.lo], device="cuda" if backend == "nccl" else "cpu")
@@ -92,9 +102,9 @@ def main():
     for k, v in ref.items():
         scale = float(v.abs().max())
         if scale == 0.0:
-            assert float(dp[k].abs().max()) == 0.0, k
+            assert float(rows(k, dp[k]).abs().max()) == 0.0, k
             continue
-        err = float((dp[k] - v).abs().max()) / scale
+        err = float((rows(k, dp[k]) - rows(k, v)).abs().max()) / scale
         worst = max(worst, err)
         assert err < 2e-4, (k, err, scale)
     # a second data-parallel step, this one on the frame pair the trainer drew itself with the step plan it queued at the end of
@@ -119,14 +129,15 @@ def main():
     for k, v in ref2.items():
         scale = float(v.abs().max())
         if scale == 0.0:
-            assert float(dp2[k].abs().max()) == 0.0, k
+            assert float(rows(k, dp2[k]).abs().max()) == 0.0, k
             continue
-        err = float((dp2[k] - v).abs().max()) / scale
+        err = float((rows(k, dp2[k]) - rows(k, v)).abs().max()) / scale
         worst2 = max(worst2, err)
         assert err < 2e-4, ("planned step", k, err, scale)
     if dist.get_rank() == 0:
         print(f"DP_GRAD_OK backend={dist.get_backend()} ranks={dist.get_world_size()} tensors={len(ref)} worst={worst:.2e} "
-              f"planned={planned} sparse={sparse_used} worst_planned={worst2:.2e} bytes_sent={tr.reducer.bytes_sent}", flush=True)
+              f"planned={planned} sparse={sparse_used} worst_planned={worst2:.2e} bytes_sent={tr.reducer.bytes_sent} "
+              f"zown={tr._zown is not None} zown_bytes={tr._zown.bytes_sent if tr._zown is not None else 0} per_anchor={len(per_anchor)}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

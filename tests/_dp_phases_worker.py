@@ -46,6 +46,7 @@ for name, totals in (("FULL", (B, 0, 0, 0)), ("QUANT", (0, B, 0, 0)), ("ENTROPY"
         it += 1
         losses.append(float(tr.step(it).loss))
     torch.cuda.synchronize()
+    tr.sync_replicas()      # GSVC_DP_ZOWN=1: a replica is fresh inside its block + halo only until it is made whole (no-op otherwise)
     # replicas identical: the checksum of every parameter agrees across ranks
     cs = torch.stack([p.detach().double().sum() for p in pc.parameters()])
     lo, hi = cs.clone(), cs.clone()
@@ -53,7 +54,10 @@ for name, totals in (("FULL", (B, 0, 0, 0)), ("QUANT", (0, B, 0, 0)), ("ENTROPY"
     same = bool(torch.equal(lo, hi))
     if dist.get_rank() == 0:
         print(f"DP_PHASE {name}: losses {['%.4f' % l for l in losses]} early_steps {getattr(tr, 'early_steps', 0) - e0} replicas_identical {same} "
-              f"sparse {tr.reducer._sparse is not None} {(time.perf_counter() - t0) / STEPS:.2f} s/step", flush=True)
+              f"sparse {tr.reducer._sparse is not None} zown {tr._zown is not None} checksum {float(cs.sum()).hex()} "
+              f"{(time.perf_counter() - t0) / STEPS:.2f} s/step", flush=True)
+    if dist.get_rank() == 0 and os.environ.get("GSVC_DP_PHASE_CS"):
+        print("DP_CS " + name + " " + " ".join(f"{n}={float(v).hex()}" for (n, _), v in zip(pc.named_parameters(), cs)), flush=True)
     assert all(np.isfinite(losses)) and same
 if dist.get_rank() == 0:
     print("DP_PHASES_OK", flush=True)

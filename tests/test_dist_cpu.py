@@ -296,3 +296,124 @@ def test_many_rank_gloo(world):
         p.join(timeout=300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert sorted(q.get(timeout=5)[0] for _ in range(world)) == list(range(world))
+
+
+# ------------------------------------------------------------------------------------------------ z-range ownership
+class _FakeModel:
+    """The per-anchor tensors of a GaussianModel (shapes scaled down) with a plain Adam: what gsvc_amd.dist.ZRangeOwnership touches."""
+
+    def __init__(self, A, z_lim, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        P = torch.nn.Parameter
+        anchor = torch.rand(A, 3, generator=g) * 2 - 1
+        anchor[:, 2] *= z_lim
+        self._anchor = P(anchor, requires_grad=False)
+        self._anchor_feat = P(torch.randn(A, 5, generator=g))
+        self._offset = P(torch.randn(A, 2, 3, generator=g))
+        self._scaling = P(torch.randn(A, 6, generator=g) * 0.1)
+        self._mask = P(torch.randn(A, 2, 1, generator=g))
+        self.optimizer = torch.optim.Adam([self._anchor_feat, self._offset, self._scaling, self._mask], lr=1e-2, eps=1e-15)
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+
+def _zown_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      GSVC_DP_ZOWN="1")
+    from gsvc_amd import dist as gd
+    gd.init_from_env("gloo")
+    assert gd.zrange_enabled()
+    T, scale = 64, 32.0
+    thr = (10.0 if world > 2 else 6.0) / scale          # eight ranks: blocks of 7-8 frames, a halo that reaches two neighbours a side
+    A = 600
+    names = gd.PER_ANCHOR
+    own, ref = _FakeModel(A, 1.1 * T / 2 / scale), _FakeModel(A, 1.1 * T / 2 / scale)      # ref: the replicated form, every rank the whole sum
+    zo = gd.ZRangeOwnership(T, scale, thr)
+    zo.ensure(own)
+    z = own._anchor.detach()[:, 2]
+    lo, hi = gd.frame_shard(T)
+    in_read = (z >= zo.read[rank][0]) & (z <= zo.read[rank][1])
+    sent, got = zo.halo_rows()
+    tot = torch.tensor([float(sent), float(got)])
+    dist.all_reduce(tot)
+    assert tot[0] == tot[1] and (world == 1 or tot[0] > 0)          # what the ranks send is what the owners receive
+    owners = torch.zeros(A)
+    owners[zo.own_idx] = 1.0
+    dist.all_reduce(owners)
+    assert torch.all(owners == 1.0)                                  # every anchor has exactly one owner
+    rng = torch.Generator().manual_seed(100 + rank)
+    for step in range(1, 7):
+        f = int(torch.randint(lo, max(lo + 1, hi), (1,), generator=rng))
+        zf = [(t - T / 2) / scale for t in (f, f + 1)]
+        vis = ((z - zf[0]).abs() <= thr) | ((z - zf[1]).abs() <= thr)
+        assert torch.all(in_read[vis])                               # a rank only sees rows of its block + halo
+        vis &= torch.rand(A, generator=rng) < 0.7
+        only_mask = step == 5                                        # the STE phase's shape: one tensor has a gradient
+        use = ("_mask",) if only_mask else names
+        mean_ref = torch.stack([ref._anchor_feat.mean(), ref.get_scaling.mean(), ref._offset.mean()]).detach()
+        m = zo.update_means(own)
+        assert torch.allclose(m, mean_ref, rtol=1e-5, atol=1e-7), (m, mean_ref)
+        ms = [torch.zeros_like(m) for _ in range(world)]
+        dist.all_gather(ms, m)
+        assert all(torch.equal(ms[0], x) for x in ms)                # the same bits on every rank
+        for n in names:
+            getattr(own, n).grad = None
+            getattr(ref, n).grad = None
+        for n in use:
+            p = getattr(own, n)
+            g = torch.randn(p.shape, generator=rng) * vis.view(-1, *([1] * (p.dim() - 1)))
+            if rank == 1 and step == 3 and n == "_offset":
+                g = None                                              # a rank whose views touched nothing of this tensor
+            p.grad = g
+            mine = g if g is not None else torch.zeros_like(p)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            total = torch.zeros_like(mine)
+            for t in every:                                           # ((0 + g_0) + g_1) + ...: GradReducer._finish_sparse's order
+                total = total + t
+            getattr(ref, n).grad = total / float(world)
+        zo.exchange_grads(own, use)
+        for n in use:
+            assert torch.equal(getattr(own, n).grad[zo.own_idx], getattr(ref, n).grad[zo.own_idx]), (step, n)
+        own.optimizer.step()
+        ref.optimizer.step()
+        zo.refresh_params(own, use)
+        for n in names:                                               # block + halo: the owners' values, bit for bit
+            assert torch.equal(getattr(own, n).data[in_read], getattr(ref, n).data[in_read]), (step, n)
+    stale = sum(int((getattr(own, n).data != getattr(ref, n).data).any()) for n in names)
+    if world > 2:
+        assert stale > 0                                              # rows outside block + halo did go stale ...
+    zo.sync_full(own)
+    for n in names:                                                   # ... and come back whole, moments included
+        assert torch.equal(getattr(own, n).data, getattr(ref, n).data), n
+        so, sr = own.optimizer.state[getattr(own, n)], ref.optimizer.state[getattr(ref, n)]
+        assert torch.equal(so["exp_avg"], sr["exp_avg"]) and torch.equal(so["exp_avg_sq"], sr["exp_avg_sq"]), n
+    # densification replaces the anchor tensor: the lists follow (existing anchors keep their owner)
+    old_owner = zo.own_mask.clone()
+    own._anchor = torch.nn.Parameter(torch.cat([own._anchor.data, own._anchor.data[:50] * 0.5]), requires_grad=False)
+    zo.ensure(own)
+    assert zo.A == A + 50 and torch.equal(zo.own_mask[:A], old_owner)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_z_range_ownership_equals_the_replicated_exchange(world):
+    """gsvc_amd.dist.ZRangeOwnership (SURVEY 8e "Collective"; GSVC_DP_ZOWN=1): gradients of the halo rows to their owners, Adam on
+    the owned rows, updated rows back — against the replicated form in which every rank adds every rank's rows in rank order and
+    updates everything: the owners' gradients, the parameters of a rank's block + halo after every step, and the whole model with
+    its Adam moments after sync_full are the same bits; the clamp centres' means are one number on every rank."""
+    port = 29500 + (os.getpid() + 57 * world) % 400
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_zown_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(world)) == list(range(world))

@@ -778,13 +778,13 @@ def test_bench_gpus_flag_starts_that_many_ranks():
         assert "GPU(s)" in out.stderr
 
 
-def _run_dp_grad_worker(env_extra):
+def _run_dp_grad_worker(env_extra, ranks=2):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29600 + os.getpid() % 300
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "_dp_grad_worker.py")]
     out = subprocess.run(cmd, cwd=root, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=420)
     assert out.returncode == 0 and "DP_GRAD_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
@@ -829,6 +829,33 @@ def test_two_rank_step_averages_gradients_over_rccl():
 
 
 @pytest.mark.gpu
+def test_one_rank_rccl_communicator_runs_every_collective_of_the_step():
+    """What a single-GPU box can show of RCCL: GSVC_DP_FORCE=1 keeps the data-parallel machinery on for a process group of ONE
+    rank, backend "nccl" — group creation (default + plan group), the hook-driven asynchronous all-reduces next to the backward, the
+    flat bucket, the agreed order's broadcast, the row lists' all-gathers, the overflow MAX, the plan's count exchange all run on a
+    real RCCL communicator (as the identity: the gradients must equal the single-process step's), with RCCL's device / dtype /
+    contiguity rules and its stream ordering.  Dense, row-sparse and z-range-owned exchange."""
+    out = _run_dp_grad_worker({"GSVC_DIST_BACKEND": "nccl", "GSVC_DP_FORCE": "1"}, ranks=1)
+    assert "backend=nccl ranks=1" in out and "planned=True sparse=False" in out, out
+    out = _run_dp_grad_worker({"GSVC_DIST_BACKEND": "nccl", "GSVC_DP_FORCE": "1", "GSVC_DP_SPARSE": "1", "GSVC_DP_MODE": "ste"}, ranks=1)
+    assert "backend=nccl ranks=1" in out and "planned=True sparse=True" in out, out
+    out = _run_dp_grad_worker({"GSVC_DIST_BACKEND": "nccl", "GSVC_DP_FORCE": "1", "GSVC_DP_ZOWN": "1"}, ranks=1)
+    assert "backend=nccl ranks=1" in out and "zown=True" in out, out
+
+
+@pytest.mark.gpu
+def test_two_rank_step_with_z_range_ownership():
+    """GSVC_DP_ZOWN=1 (gsvc_amd.dist.ZRangeOwnership, SURVEY 8e "Collective"): the per-anchor gradients of the halo rows travel to
+    their owners; on the rows a rank owns the result is the mean of the two single-process gradients, in the deterministic
+    (full-precision) step and in the entropy-constrained one (rate, mask regulariser added by the owner, the clamp centres' means
+    from the owners' partial sums)."""
+    out = _run_dp_grad_worker({"GSVC_DIST_BACKEND": "gloo", "GSVC_SHARE_GPU": "1", "GSVC_DP_ZOWN": "1"})
+    assert "zown=True" in out and "per_anchor=0" not in out, out
+    out = _run_dp_grad_worker({"GSVC_DIST_BACKEND": "gloo", "GSVC_SHARE_GPU": "1", "GSVC_DP_ZOWN": "1", "GSVC_DP_MODE": "ste"})
+    assert "zown=True" in out, out
+
+
+@pytest.mark.gpu
 def test_two_ranks_through_every_phase_at_the_headline_shape():
     """Two data-parallel ranks (gloo, both on device 0) through FULL_PRECISION, QUANTIZED, TRAINING_ENTROPY and STE_ENTROPY steps at
     BASELINE.json configs[2] size, where the plan of the next step is queued from inside the backward in every phase and the
@@ -849,6 +876,31 @@ def test_two_ranks_through_every_phase_at_the_headline_shape():
     # the early plan ran in every phase — the STE phase too, whose detached attributes give _scaling / _offset / _anchor_feat no
     # gradient: the reducer agrees on a new launch order per phase, so no launch waits behind a hook that never fires
     assert all("early_steps 0" not in l for l in lines), lines
+
+
+@pytest.mark.gpu
+def test_z_range_ownership_through_every_phase_equals_the_replicated_run():
+    """GSVC_DP_ZOWN=1 through the four phases at the headline shape (two ranks, 32-frame blocks, +-8-frame halo), with the check
+    that no gradient row lies outside a rank's block + halo: finite losses, replicas identical once made whole
+    (Trainer.sync_replicas), and the full-precision phase's losses (no noise drawn) equal to the replicated run's row exchange to the
+    printed digits.  (Bit equality of the exchange itself is tests/test_dist_cpu.py's; two runs of the SAME configuration differ in
+    the last bits of the MLP gradients here, so the runs' parameters are not compared bit for bit.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29400 + os.getpid() % 150
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_dp_phases_worker.py")]
+    full = {}
+    for tag, extra in (("zown", {"GSVC_DP_ZOWN": "1", "GSVC_DP_ZOWN_CHECK": "1"}), ("rows", {"GSVC_DP_SPARSE": "1"})):
+        out = subprocess.run(cmd, cwd=root, env=dict(os.environ, GSVC_DIST_BACKEND="gloo", GSVC_SHARE_GPU="1", GSVC_DP_PHASE_STEPS="3", **extra),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "DP_PHASES_OK" in out.stdout, (tag, out.stdout[-1500:], out.stderr[-2500:])
+        lines = [l for l in out.stdout.splitlines() if l.startswith("DP_PHASE ")]
+        assert len(lines) == 4 and all("replicas_identical True" in l and f"zown {tag == 'zown'}" in l for l in lines), lines
+        full[tag] = lines[0].split("losses ")[1].split("]")[0]
+    assert full["zown"] == full["rows"], full
 
 
 @pytest.mark.gpu
