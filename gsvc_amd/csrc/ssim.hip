@@ -30,6 +30,21 @@ struct SsimWindow {
     float w[11];
 };
 
+// The eleven window taps as VECTOR registers.  Passed by value they live in SGPRs, and a multiply-add that reads an SGPR issues at
+// 4.5 cycles per wave where the register-only form issues at 2.7 (four waves per SIMD; DESIGN section 4b, tools/micro/valu_issue.hip)
+// — and these kernels are nothing but such multiply-adds (434 of the forward's 717 vector arithmetic instructions).  The compiler
+// keeps a uniform value in an SGPR whenever it can see that it is uniform: the move is hidden from it.
+struct WinRegs {
+    float w[11];
+};
+__device__ __forceinline__ WinRegs window_in_vgprs(const SsimWindow &win)
+{
+    WinRegs r;
+#pragma unroll
+    for (int k = 0; k < 11; k++) asm volatile("v_mov_b32 %0, %1" : "=v"(r.w[k]) : "s"(win.w[k]));
+    return r;
+}
+
 __device__ __forceinline__ float block_sum_256(float v, float *smem)
 {
 #pragma unroll
@@ -43,7 +58,7 @@ __device__ __forceinline__ float block_sum_256(float v, float *smem)
 
 // img1b != NULL: the first image is the two-view frame 0.5 * (img1 + flip_W(img1b)) (reference pipeline/train.py:368-375), formed
 // on load (and stored to avg_out where the caller wants it) instead of by three elementwise launches each way.
-__global__ void __launch_bounds__(256) k_ssim_fwd(SsimWindow win, const float *__restrict__ img1, const float *__restrict__ img1b,
+__global__ void __launch_bounds__(256) k_ssim_fwd(SsimWindow win_s, const float *__restrict__ img1, const float *__restrict__ img1b,
                                                   float *__restrict__ avg_out,
                                                   const float *__restrict__ img2, int H, int W,
                                                   float *__restrict__ partials /* [SS_SLOTS][2]: ssim, l1 */,
@@ -54,6 +69,7 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(SsimWindow win, const float *_
     __shared__ __attribute__((aligned(16))) float sy[SS_HALO][SS_LD];
     __shared__ float hb[5][SS_HALO][SS_HLD];  // horizontally blurred moments
     __shared__ float red[4];
+    const WinRegs win = window_in_vgprs(win_s);
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * SS_TILE, y0 = blockIdx.y * SS_TILE;
     const size_t plane = (size_t)blockIdx.z * H * W;
@@ -177,7 +193,7 @@ __global__ void __launch_bounds__(256) k_ssim_finalize(const float *__restrict__
 
 // dL/dimg1 = conv(g*dm_dmu1) + 2 x conv(g*dm_de11) + y conv(g*dm_de12) + g_l1 * sign(x - y),
 // g = grads[0] / (C*H*W) (mean of the map), g_l1 = grads[1] / (C*H*W)
-__global__ void __launch_bounds__(256) k_ssim_bwd(SsimWindow win, const float *__restrict__ img1, const float *__restrict__ img1b,
+__global__ void __launch_bounds__(256) k_ssim_bwd(SsimWindow win_s, const float *__restrict__ img1, const float *__restrict__ img1b,
                                                   float *__restrict__ dL_dimg1b,
                                                   const float *__restrict__ img2, int H, int W, float inv_count,
                                                   const float *__restrict__ grads, const float *__restrict__ dm_dmu1,
@@ -186,6 +202,7 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(SsimWindow win, const float *_
 {
     __shared__ __attribute__((aligned(16))) float sm[3][SS_HALO][SS_LD];
     __shared__ float hb[3][SS_HALO][SS_HLD];
+    const WinRegs win = window_in_vgprs(win_s);
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * SS_TILE, y0 = blockIdx.y * SS_TILE;
     const size_t plane = (size_t)blockIdx.z * H * W;

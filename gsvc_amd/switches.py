@@ -22,6 +22,8 @@ Code reads the module attributes (``switches.NO_MLP_CHAIN``); a process that cha
     GSVC_NO_PREFETCH / GSVC_NO_EARLY_PLAN / GSVC_EARLY_PLAN   step plan off / never from inside the backward / always
     GSVC_RASTER_STREAMS    side streams the step's renders are dealt to (default 2; 1 = all on the current stream)
     GSVC_DP_SPARSE         data parallel: 0 = dense all-reduce always, 1 = row-sparse exchange always (default: whichever moves less)
+    GSVC_DP_ZOWN / GSVC_DP_ZOWN_CHECK / GSVC_DP_FORCE   read by gsvc_amd/dist.py where the process group is known: per-anchor tensors owned by
+                           z-range (halo exchange), its dropped-gradient check, the data-parallel path on a one-rank group (tests)
 """
 import os
 

@@ -65,8 +65,11 @@ def main():
             small[0] = 4
         out = tr.step(it)
         assert np.isfinite(float(out.loss)), it
-        log.append((it, int(tr.reducer.bytes_sent), tr.reducer._sparse is not None, int(pc._anchor.shape[0]), int(getattr(tr, "repeated_steps", 0))))
+        zb = int(tr._zown.bytes_sent) if tr._zown is not None else 0          # GSVC_DP_ZOWN=1: halo rows of gradients out + parameter rows back
+        log.append((it, int(tr.reducer.bytes_sent) + zb, "owned" if tr._zown is not None else tr.reducer._sparse is not None,
+                    int(pc._anchor.shape[0]), int(getattr(tr, "repeated_steps", 0))))
     torch.cuda.synchronize()
+    tr.sync_replicas()          # z-range ownership: a replica is whole again only after this (no-op otherwise)
     sig = torch.tensor([float(pc._anchor.shape[0])] + [float(p.detach().double().sum()) for p in pc.parameters()], dtype=torch.float64)
     lo, hi = sig.clone(), sig.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -75,7 +78,7 @@ def main():
     dist.all_reduce(rep, op=dist.ReduceOp.MIN)
     if rank == 0:
         for it, sent, sparse, anchors, reps in log:
-            print(f"DRYRUN step {it}: {sent} bytes to the collectives, per-anchor gradients {'as rows' if sparse else 'dense'}, "
+            print(f"DRYRUN step {it}: {sent} bytes to the collectives, per-anchor gradients {'to their z-range owners' if sparse == 'owned' else 'as rows' if sparse else 'dense'}, "
                   f"{anchors} anchors, repeated steps so far {reps}", flush=True)
         assert torch.equal(lo, hi), "replicas differ"
         assert log[-1][3] != a0, "adjust_anchor did not change the anchor set"

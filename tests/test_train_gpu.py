@@ -1056,7 +1056,8 @@ def test_host_resident_video_steps_equal_device_resident_steps():
 
 
 @pytest.mark.gpu
-def test_four_rank_dry_run_at_the_configs3_shape():
+@pytest.mark.parametrize("exchange", ["replicated", "zown"])
+def test_four_rank_dry_run_at_the_configs3_shape(exchange):
     """BASELINE.json configs[3] rehearsed on one GPU: four data-parallel ranks (gloo, device 0: the pool's process guard allows 6
     on a card, not the 8 of the real run) step the reference's own configuration through 20 iterations with one densification and
     one step that every rank repeats because a single rank overflowed; replicas identical at the end; rank 0 logs the exchange
@@ -1068,11 +1069,14 @@ def test_four_rank_dry_run_at_the_configs3_shape():
     port = 29250 + os.getpid() % 100
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "_dp_dryrun_worker.py")]
-    out = subprocess.run(cmd, cwd=root, env=dict(os.environ, GSVC_DIST_BACKEND="gloo", GSVC_SHARE_GPU="1"), capture_output=True, text=True,
-                         timeout=900)
+    # "zown": the same rehearsal with the per-anchor tensors owned by z-range (GSVC_DP_ZOWN=1): the densification makes the replicas
+    # whole first, the row lists follow the new anchors, the repeated step repeats its exchanges on every rank
+    env = dict(os.environ, GSVC_DIST_BACKEND="gloo", GSVC_SHARE_GPU="1", **({"GSVC_DP_ZOWN": "1", "GSVC_DP_ZOWN_CHECK": "1"} if exchange == "zown" else {}))
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "DP_DRYRUN_OK ranks=4" in out.stdout, (out.stdout[-2500:], out.stderr[-3000:])
     steps = [l for l in out.stdout.splitlines() if l.startswith("DRYRUN step")]
     assert len(steps) == 20 and "ranks = 4" in out.stdout + out.stderr
+    assert all(("to their z-range owners" in l) == (exchange == "zown") for l in steps), steps[:2]
     print("\n".join(steps[:3] + steps[-3:]))
 
 
