@@ -455,7 +455,7 @@ class ZRangeOwnership:
 
     def ensure(self, pc):
         a = pc._anchor
-        key = (id(a), int(a.shape[0]), a._version)
+        key = (id(a), a.data_ptr(), int(a.shape[0]), a._version)
         if key != self._key:
             self.build(a)
             self._key = key
