@@ -237,6 +237,7 @@ class Trainer:
         before anything reads the whole model — evaluation, estimate_final_bits, stream encoding, a checkpoint."""
         if self._zown is not None:
             self._zown.sync_full(self.pc, moments=moments)
+        self.pc._zown = None      # outside a step the whole-tensor means are the model's own again (gsvc_amd.generate._param_means)
 
     def _zown_names(self, mode):
         # TRAININ_STE_ENTROPY renders from detached attributes: only _mask receives a gradient (and only it moves)
@@ -448,7 +449,7 @@ class Trainer:
             sent, got = zown.halo_rows()
             sys.stderr.write(f"gsvc_amd.train: per-anchor tensors owned by z-range: rank 0 owns {int(zown.own_idx.shape[0])} of {int(pc._anchor.shape[0])} "
                              f"anchors, sends {sent} halo rows of gradients and returns {got} rows of parameters per step, {gdist.world_size()} ranks\n")
-        elif gdist.active() and gdist.rank() == 0 and getattr(self, "_logged_exchange", None) != use_rows and plan is not None:
+        elif zown is None and gdist.active() and gdist.rank() == 0 and getattr(self, "_logged_exchange", None) != use_rows and plan is not None:
             import sys
             self._logged_exchange = use_rows
             sys.stderr.write(f"gsvc_amd.train: per-anchor gradient exchange = {'rows of the distinct visible anchors (cap ' + str(plan.distinct_cap) + ')' if use_rows else 'dense all-reduce'}"

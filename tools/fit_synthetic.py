@@ -62,8 +62,14 @@ def main(argv=None):
     from gsvc_amd.stream_codec import conduct_stream_decoding, conduct_stream_encoding
     from gsvc_amd.train import Trainer
 
-    dev = torch.device("cuda", 0)
+    # under torch.distributed.run: data-parallel fit (frames sharded over the ranks, gsvc_amd/dist.py); rank 0 encodes and evaluates.
+    # GSVC_DIST_BACKEND=gloo GSVC_SHARE_GPU=1 puts every rank on device 0 (rehearsal on one GPU)
+    from gsvc_amd import dist as gdist
+    share = bool(os.environ.get("GSVC_SHARE_GPU"))
+    local = 0 if share else int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    rank, world, _ = gdist.init_from_env(os.environ.get("GSVC_DIST_BACKEND") or None)
     H, W, T, N = args.height, args.width, args.frames, args.steps
     mp_, opt, pipe = cfg_20240919()
     cube = SyntheticFrameCube(H, W, T, seed=1234, device=dev).materialize()
@@ -91,6 +97,7 @@ def main(argv=None):
     pc.create_from_points(np.random.default_rng(0).uniform(lim, -lim, (args.anchors, 3)), spatial_lr_scale=1.0)
     pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
     pc.training_setup(opt)
+    gdist.broadcast_parameters(pc)
     trainer = Trainer(pc, cube, opt, pipe, mp_, seed=0)
     bg = trainer.background
     log = {"config": {"H": H, "W": W, "frames": T, "steps": N, "anchors_init": args.anchors, "lmbda": args.lmbda,
@@ -123,7 +130,15 @@ def main(argv=None):
     print(json.dumps(log["phases"][-1]), flush=True)
     log["fit_seconds"] = time.perf_counter() - t0
     log["repeated_steps"] = int(getattr(trainer, "repeated_steps", 0))
+    trainer.sync_replicas()          # z-range ownership (GSVC_DP_ZOWN=1): every replica whole before the model is read as a whole
+    log["data_parallel"] = {"ranks": world, "backend": torch.distributed.get_backend() if world > 1 else None,
+                            "per_anchor_exchange": "z-range ownership" if trainer._zown is not None else ("rows / dense" if world > 1 else None)}
     trainer.close()
+    if world > 1:
+        torch.distributed.barrier()
+        if rank != 0:
+            torch.distributed.destroy_process_group()
+            return
 
     @torch.no_grad()
     def psnr_of(model, mode_):
@@ -224,6 +239,8 @@ def main(argv=None):
     assert d_psnr <= 0.01, \
         f"decoded PSNR {log['psnr_decoded']:.5f} vs the quantised model's {log['psnr_quantised_model']:.5f}, max pixel difference {log['decoded_vs_quantised_model_max_abs']:.2e}"
     assert abs(log["attribute_payload_vs_estimate"] - 1.0) <= args.payload_tol, (log["attribute_payload_vs_estimate"], log["attribute_bytes_vs_estimate"])
+    if world > 1:
+        torch.distributed.destroy_process_group()
     print(f"RD point: {log['decoded_8bit_mlp']['psnr']:.2f} dB PSNR, MS-SSIM {log['decoded_8bit_mlp']['msssim']:.4f} at {log['bpp']:.4f} bpp "
           f"({total_bytes / 2 ** 20:.2f} MiB for {T} frames {W}x{H}); fit {log['fit_seconds']:.1f} s")
 
