@@ -229,17 +229,22 @@ def roofline_valu(probe, kern_dom, one_stream_us, traffic_src):
     return out
 
 
+def _dp_on(world):
+    """The data-parallel path: more than one rank, or GSVC_DP_FORCE=1 (test knob: the same collectives on a one-rank RCCL group)."""
+    return world > 1 or os.environ.get("GSVC_DP_FORCE") == "1"
+
+
 def timed(torch, dist, world, fn, steps):
     """Barrier + synchronize on both sides, max over ranks."""
     torch.cuda.synchronize()
-    if world > 1:
+    if _dp_on(world):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
-    if world > 1:
+    if _dp_on(world):
         dist.barrier()
     torch.cuda.synchronize()
     return time.perf_counter() - t0
@@ -247,7 +252,7 @@ def timed(torch, dist, world, fn, steps):
 
 def reduce_sum_max(torch, dist, world, dev, total, elapsed):
     t = torch.tensor([float(total), float(elapsed)], device=dev, dtype=torch.float64)
-    if world > 1:
+    if _dp_on(world):
         a, b = t[0:1].clone(), t[1:2].clone()
         dist.all_reduce(a, op=dist.ReduceOp.SUM)
         dist.all_reduce(b, op=dist.ReduceOp.MAX)
@@ -435,7 +440,7 @@ def run_train_step(args, rank, world, dev):
     pc.create_from_points(pts, spatial_lr_scale=1.0)
     pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
     pc.training_setup(opt)
-    if world > 1:
+    if _dp_on(world):
         gdist.broadcast_parameters(pc)       # replicas start identical (they are built from the same seeds anyway)
     trainer = Trainer(pc, cube, opt, pipe, mp_, seed=0)
     it = [0]
@@ -506,7 +511,7 @@ def run_train_step(args, rank, world, dev):
     # exposed communication: the same K steps with the gradient exchange switched off (replicas diverge: last thing
     # measured on the model's gradients; parameters are re-broadcast afterwards)
     comm = None
-    if world > 1:
+    if _dp_on(world):
         sent_bytes, sparse_used = trainer.reducer.bytes_sent, trainer.reducer._sparse is not None
         zown = getattr(trainer, "_zown", None)
         if zown is not None:      # GSVC_DP_ZOWN=1: halo rows of gradients to their owners + the owners' updated rows back
@@ -643,8 +648,8 @@ def run_train_step(args, rank, world, dev):
                    "parallelism": f"frame-shard x{world} + gradient all-reduce" if world > 1 else "single GPU"},
         "effective_batch": world,      # frame pairs per optimizer step: loss = mean over ranks (the reference steps on one pair)
         "dp_anchor_optimizer": ("row-sparse / all-reduce exchange + replicated Adam" if world > 1 else None),
-        "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
-        "dist_backend": (dist.get_backend() if world > 1 else None),
+        "rccl_ranks": (dist.get_world_size() if _dp_on(world) else 1),
+        "dist_backend": (dist.get_backend() if _dp_on(world) else None),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "note": "this kernel's binding unit is the vector ALU, not HBM: traffic_source.valu holds the SQ counters of the "
@@ -1109,8 +1114,10 @@ def main():
     from gsvc_amd.hostbind import bind_to_device
     if bind_to_device(local_rank):
         _AFFINITY_GPU = os.sched_getaffinity(0)
-    if world > 1:
+    if _dp_on(world):
         import torch.distributed as dist
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29571"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)          # a forced one-rank group outside torch.distributed.run
         backend = os.environ.get("GSVC_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -1175,7 +1182,7 @@ def main():
             print(json.dumps(res), flush=True)
             sys.exit(3)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if _dp_on(world):
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -778,6 +778,24 @@ def test_bench_gpus_flag_starts_that_many_ranks():
         assert "GPU(s)" in out.stderr
 
 
+@pytest.mark.gpu
+def test_bench_runs_its_data_parallel_path_on_a_one_rank_rccl_group():
+    """bench.py's own multi-rank code — process-group setup as the driver's command form does it (backend "nccl", device_id), the
+    parameter broadcast, the barriers around the timed region, the float64 SUM / MAX reductions of the line's numbers, the
+    exchange-off pass with the re-broadcast — on a real RCCL communicator of ONE rank (GSVC_DP_FORCE=1), replicated exchange and
+    z-range ownership: the line must say backend nccl and carry the gradient_exchange block."""
+    import json
+    small = ["--workload", "train_step", "--steps", "3", "--warmup", "1", "--pretrain", "2", "--anchors", "20000",
+             "--height", "272", "--width", "480", "--no-cpu-baseline"]
+    for extra, word in (({}, "dense"), ({"GSVC_DP_ZOWN": "1"}, "z-range")):
+        out = _run_bench({"GSVC_DP_FORCE": "1", **extra}, "--gpus", "1", *small)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert res["n_gpus"] == 1 and res["rccl_ranks"] == 1 and res["dist_backend"] == "nccl", (res["rccl_ranks"], res["dist_backend"])
+        ge = res["gradient_exchange"]
+        assert ge["gradient_bytes_per_step"] > 0 and word in ge["per_anchor_exchange"], ge
+
+
 def _run_dp_grad_worker(env_extra, ranks=2):
     import os
     import subprocess
