@@ -31,6 +31,25 @@ def test_fit_encode_decode_evaluate_small(tmp_path):
     assert log["total_bytes"] > 0 and log["bits_measured"]["bit_feat"] > 0
 
 
+def test_fit_tool_on_two_data_parallel_ranks_with_z_range_ownership(tmp_path):
+    """The same chain under torch.distributed.run: two ranks (gloo, both on device 0) fit their frame blocks with the per-anchor
+    tensors owned by z-range (GSVC_DP_ZOWN=1, dropped-gradient check on), every replica is made whole, rank 0 encodes, decodes and
+    evaluates: the decoder still reproduces the straight-through model, and the record says how the fit was run."""
+    import subprocess
+    out = tmp_path / "rd_dp.json"
+    port = 29350 + os.getpid() % 100
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tools", "fit_synthetic.py"), "--steps", "80", "--height", "272", "--width", "480", "--frames", "24", "--anchors", "8000",
+           "--eval-frames", "4", "--slab-frames", "8", "--payload-tol", "0.5", "--json", str(out)]
+    run = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, GSVC_DIST_BACKEND="gloo", GSVC_SHARE_GPU="1", GSVC_DP_ZOWN="1", GSVC_DP_ZOWN_CHECK="1"),
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "RD point" in run.stdout, (run.stdout[-1500:], run.stderr[-2500:])
+    log = json.loads(out.read_text())
+    assert log["data_parallel"] == {"ranks": 2, "backend": "gloo", "per_anchor_exchange": "z-range ownership"}
+    assert [p["mode"] for p in log["phases"]] == ["TRAINING_FULL_PRECISION", "TRAINING_QUANTIZED", "TRAINING_ENTROPY", "TRAININ_STE_ENTROPY"]
+    assert log["checks"]["decoded_equals_quantised_model_dB"] <= 0.01 and log["decoded_8bit_mlp"]["psnr"] > 15.0
+
+
 def test_lpips_on_the_device_equals_the_host():
     from gsvc_amd.lpips import LPIPS
     m = LPIPS("alex", random_init=True)
