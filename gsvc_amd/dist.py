@@ -505,6 +505,8 @@ class ZRangeOwnership:
         for p in ts:
             if p.grad is None:          # a rank whose views touched nothing still takes part
                 p.grad = torch.zeros_like(p)
+            elif not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
         g2 = [p.grad.view(A, -1) for p in ts]
         widths = [int(g.shape[1]) for g in g2]
         if os.environ.get("GSVC_DP_ZOWN_CHECK"):          # diagnostics: a gradient outside block + halo would be dropped silently

@@ -160,6 +160,10 @@ class Trainer:
         # GSVC_DP_ZOWN=1: the per-anchor tensors are OWNED by z-range (gsvc_amd.dist.ZRangeOwnership) — gradients of the halo rows go
         # to their owners, updated rows come back — instead of being summed on every replica
         self._zown = None
+        if gdist.zrange_enabled() and not (batched and not self.anchor_grad):
+            import sys
+            sys.stderr.write("gsvc_amd.train: GSVC_DP_ZOWN=1 ignored (needs the batched step and anchors with learning rate 0: an anchor that moves "
+                             "could change its owner): replicated exchange\n")
         if gdist.zrange_enabled() and batched and not self.anchor_grad:
             self._zown = gdist.ZRangeOwnership(dataset.len_z_frames, dataset.scale, model_params.threshold)
             assert abs(dataset[self.lo].z - (self.lo - dataset.len_z_frames / 2) / dataset.scale) < 1e-6, "frame z convention"
