@@ -492,6 +492,11 @@ __global__ void __launch_bounds__(64, GSVC_BWD_WAVES) k_blend_bwd_tile(RasterPar
     }
 }
 
+#ifndef GSVC_GBWD_COOP_MIN_ROWS
+#define GSVC_GBWD_COOP_MIN_ROWS 64
+#endif
+constexpr int GBWD_COOP_MIN_ROWS = GSVC_GBWD_COOP_MIN_ROWS;      // rectangles from this many tiles are added up by the whole wave
+
 __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, const float *__restrict__ means3D,
                                                       const float *__restrict__ scales,
                                                       const float *__restrict__ rotations,
@@ -504,20 +509,34 @@ __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, co
                                                       float *__restrict__ dL_dscales, float *__restrict__ dL_drotations)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    const int lane = threadIdx.x & 63;
     float g3[3] = {0, 0, 0}, g2[3] = {0, 0, 0}, gc[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, go = 0.f;
-    if (radii[i] > 0 && !counters->overflow) {
-        // this Gaussian's rows of the partial-sum buffer: one per tile of its rectangle, contiguous, added in tile order
+    const bool overflow = counters->overflow != 0;
+    const bool act = i < P && !overflow && radii[i] > 0;
+    // this Gaussian's rows of the partial-sum buffer: one per tile of its rectangle, contiguous, added in a FIXED order (tile order by
+    // the Gaussian's own lane; for a large rectangle by the whole wave: lane l adds rows l, l + 64, ... in tile order, then a fixed
+    // butterfly adds the lanes) — the backward stays bit-repeatable.  Late in a fit a Gaussian covers ~57 tiles on average and
+    // hundreds at the tail (profiles/r05 late_stage_profile): a lane walking 300 rows alone, four loads per dependent round trip, kept
+    // its 63 neighbours waiting (measured: 312 us per launch at 65 k active Gaussians and 3.7 M instances, 4.6 ms of lane-serial
+    // latency for ~140 MB of rows).
+    int n_rows = 0, tw = 1, rx0 = 0, ry0 = 0, goff = 0;
+    uint32_t abx = 0u, aby = 0u;
+    if (act) {
         const float4 w2 = reinterpret_cast<const float4 *>(geom + i)[2];
         const float4 w3 = reinterpret_cast<const float4 *>(geom + i)[3];
         const uint32_t rx = __float_as_uint(w3.x), ry = __float_as_uint(w3.y);
-        const int tw = (int)(rx >> 16) - (int)(rx & 0xffff);
-        const int n_rows = tw * ((int)(ry >> 16) - (int)(ry & 0xffff));
-        const float4 *row = reinterpret_cast<const float4 *>(rows + (size_t)__float_as_int(w2.w) * ROW_FLOATS);
-        const uint32_t abx = __float_as_uint(w2.y), aby = __float_as_uint(w2.z);      // alpha bounding box
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-        float a2 = 0.f;
-        int jx = 0, tpx = (int)(rx & 0xffff) * TILE, tpy = (int)(ry & 0xffff) * TILE;
+        rx0 = (int)(rx & 0xffff); ry0 = (int)(ry & 0xffff);
+        tw = (int)(rx >> 16) - rx0;
+        n_rows = tw * ((int)(ry >> 16) - ry0);
+        goff = __float_as_int(w2.w);
+        abx = __float_as_uint(w2.y); aby = __float_as_uint(w2.z);      // alpha bounding box
+    }
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    float a2 = 0.f;
+    const bool big = act && n_rows >= GBWD_COOP_MIN_ROWS;
+    if (act && !big) {
+        const float4 *row = reinterpret_cast<const float4 *>(rows + (size_t)goff * ROW_FLOATS);
+        int jx = 0, tpx = rx0 * TILE, tpy = ry0 * TILE;
         // four rows per round: their loads are issued together, then added in tile order (a load per iteration made the loop one
         // dependent memory round trip per tile of the rectangle)
         for (int j = 0; j < n_rows; j += 4, row += 4 * (ROW_FLOATS / 4)) {
@@ -527,7 +546,7 @@ __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, co
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 hit[u] = j + u < n_rows && bbox_hits_tile(abx, aby, tpx, tpy);     // rows exist only where the box touches the tile (B1)
-                if (++jx == tw) { jx = 0; tpx = (int)(rx & 0xffff) * TILE; tpy += TILE; } else tpx += TILE;
+                if (++jx == tw) { jx = 0; tpx = rx0 * TILE; tpy += TILE; } else tpx += TILE;
                 const float4 *r4 = row + u * (ROW_FLOATS / 4);
                 x0[u] = hit[u] ? r4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
                 x1[u] = hit[u] ? r4[1] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -541,6 +560,49 @@ __global__ void __launch_bounds__(256) k_gaussian_bwd(RasterParams st, int P, co
                 a2 += x2[u];
             }
         }
+    }
+    // large rectangles: the wave adds one Gaussian's rows together (every lane of the wave takes part, also those past P)
+    for (unsigned long long todo = __ballot(big); todo != 0ull; todo &= todo - 1ull) {
+        const int src = __builtin_ctzll(todo);
+        const int n = __shfl(n_rows, src, 64), w = __shfl(tw, src, 64), x0t = __shfl(rx0, src, 64), y0t = __shfl(ry0, src, 64);
+        const int gof = __shfl(goff, src, 64);
+        const uint32_t bx = (uint32_t)__shfl((int)abx, src, 64), by = (uint32_t)__shfl((int)aby, src, 64);
+        const float4 *row0 = reinterpret_cast<const float4 *>(rows + (size_t)gof * ROW_FLOATS);
+        float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = lane; j < n; j += 128) {          // two rows in flight per lane
+            float4 p0[2], p1[2];
+            float p2[2];
+            bool hit[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int jj = j + 64 * u;
+                const int ty = jj / w, tx = jj - ty * w;
+                hit[u] = jj < n && bbox_hits_tile(bx, by, (x0t + tx) * TILE, (y0t + ty) * TILE);
+                const float4 *r4 = row0 + (size_t)jj * (ROW_FLOATS / 4);
+                p0[u] = hit[u] ? r4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+                p1[u] = hit[u] ? r4[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                p2[u] = hit[u] ? r4[2].x : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (!hit[u]) continue;
+                v[0] += p0[u].x; v[1] += p0[u].y; v[2] += p0[u].z; v[3] += p0[u].w;
+                v[4] += p1[u].x; v[5] += p1[u].y; v[6] += p1[u].z; v[7] += p1[u].w;
+                v[8] += p2[u];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 9; c++)
+#pragma unroll
+            for (int k = 32; k >= 1; k >>= 1) v[c] += __shfl_xor(v[c], k, 64);
+        if (lane == src) {
+            a0 = make_float4(v[0], v[1], v[2], v[3]);
+            a1 = make_float4(v[4], v[5], v[6], v[7]);
+            a2 = v[8];
+        }
+    }
+    if (i >= P) return;
+    if (act) {
         float du, dv, dA, dB, dC;
         PreOut o;
         preprocess_gaussian(st, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], scales[3 * i], scales[3 * i + 1],
