@@ -36,6 +36,7 @@ class RasterSettingsC(C.Structure):
 # gsvc_raster_settings.flags (include/gsvc_hip.h)
 RASTER_SLAB_ONE_SIDED, RASTER_PIXEL_CORNER, RASTER_DEPTH_DESCENDING = 1, 2, 4
 RASTER_MEANS2D_PIXEL_UNITS, RASTER_CLAMP_STOPS_GRADIENT, RASTER_NO_LOW_PASS = 8, 16, 32
+RASTER_TIGHT_BINNING = 64      # list a Gaussian only in the tiles its alpha >= 1/255 box touches (same results, shorter lists)
 
 
 class AdamTensorC(C.Structure):

@@ -117,7 +117,7 @@ constexpr bool SORT_DEBUG_NO_BUCKET = false;
 __device__ __forceinline__ void scan_tiles_body(int T, const int32_t *__restrict__ tile_count, int32_t *__restrict__ tile_extra,
                                                 int32_t *__restrict__ tile_offsets, int32_t *__restrict__ big_list,
                                                 gsvc_raster_counters *__restrict__ counters, long long max_instances,
-                                                int *__restrict__ s_v)
+                                                int *__restrict__ s_v, int api_count_in_reserved2 = 0)
 {
     __shared__ int wave_sum[16];
     __shared__ int wave_max[16];
@@ -183,7 +183,8 @@ __device__ __forceinline__ void scan_tiles_body(int T, const int32_t *__restrict
         int mx = 0;
         for (int w = 0; w < 16; w++) mx = max(mx, wave_max[w]);
         tile_offsets[T] = carry;
-        counters->num_rendered = carry;
+        // GSVC_RASTER_TIGHT_BINNING: the lists are shorter than the API's count (the 3-sigma rectangles' tiles, summed by K1)
+        counters->num_rendered = api_count_in_reserved2 ? __hip_atomic_load(&counters->reserved[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : carry;
         counters->overflow = ((long long)carry > max_instances) ? 1 : 0;
         counters->max_tile_len = mx;
         counters->num_big_tiles = s_big;
@@ -195,10 +196,10 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int T, const int32_t *__res
                                                      int32_t *__restrict__ tile_offsets,
                                                      int32_t *__restrict__ big_list,
                                                      gsvc_raster_counters *__restrict__ counters,
-                                                     long long max_instances)
+                                                     long long max_instances, int api_count_in_reserved2)
 {
     __shared__ int s_v[SCAN_CHUNK];
-    scan_tiles_body(T, tile_count, tile_extra, tile_offsets, big_list, counters, max_instances, s_v);
+    scan_tiles_body(T, tile_count, tile_extra, tile_offsets, big_list, counters, max_instances, s_v, api_count_in_reserved2);
 }
 
 // Walk the tiles j >= BIN_SLOTS ("extras") of every lane's binning rectangle (row-major, x0 / w / y0 / nt per lane; nt = 0:
@@ -266,6 +267,10 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
     int n_extra = 0;        // this Gaussian's instances beyond BIN_SLOTS
     bool heavy = false;     // workgroup-uniform: extras go through the LDS histogram
     int bx0 = 0, bx1 = 0;   // x range of the binning rectangle (pair mode: union of the two views)
+    int by0 = 0, by1 = 0;   // its y range (the 3-sigma rectangle's, or what the alpha box leaves of it: GSVC_RASTER_TIGHT_BINNING)
+    const bool tight = !PAIR && (st.flags & GSVC_RASTER_TIGHT_BINNING);
+    uint32_t abx = pack_i16(1, 0), aby = pack_i16(1, 0);      // alpha box (empty)
+    int n3 = 0;             // tiles of the 3-sigma rectangle: what num_rendered counts whatever is listed
     bool listed = false;
     int my_tiles = 0;       // instances of this Gaussian = rows it owns in the backward's partial-sum buffer
     float rec2_b = 0.f;
@@ -286,8 +291,25 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         BinRec br;
         br.pad = 0u;
         listed = radius > 0;
+        by0 = o.y0; by1 = o.y1;
+        if (radius > 0) {
+            alpha_bbox(o.u, o.v, o.A, o.B, o.C, op, abx, aby);
+            n3 = (o.x1 - o.x0) * (o.y1 - o.y0);
+        }
         if (!PAIR) {
             bx0 = o.x0; bx1 = o.x1;
+            if (tight && radius > 0) {
+                // the tiles of the 3-sigma rectangle that the alpha box touches (bbox_hits_tile's rule: pixel interval [lo, hi] against
+                // the tile's 16 pixels); an empty box (opacity too small to ever reach 1/255) lists nothing
+                const int lx = (int)(int16_t)(abx & 0xffffu), hx = (int)(int16_t)(abx >> 16), ly = (int)(int16_t)(aby & 0xffffu), hy = (int)(int16_t)(aby >> 16);
+                if (lx > hx || ly > hy) { bx0 = bx1 = by0 = by1 = 0; }
+                else {
+                    bx0 = max(o.x0, lx >> 4); bx1 = min(o.x1, (hx >> 4) + 1);
+                    by0 = max(o.y0, ly >> 4); by1 = min(o.y1, (hy >> 4) + 1);
+                    if (bx1 <= bx0 || by1 <= by0) { bx0 = bx1 = by0 = by1 = 0; }
+                }
+                listed = (bx1 - bx0) * (by1 - by0) > 0;
+            }
         } else if (o.radius_raw > 0) {
             // opposite view: x_view' = -x_view, same y, same radius; rectangle by the same formula, then mirrored.  ub is
             // what preprocess_gaussian() computes for u under view_matrix_s (same operations, no FMA contraction): k_blend<PAIR>
@@ -313,17 +335,18 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
             rec.C = o.C; rec.opacity = op;
             rec.r = colors[3 * i + 0]; rec.g = colors[3 * i + 1]; rec.b = colors[3 * i + 2];
             rec.depth = o.depth;
-            alpha_bbox(o.u, o.v, o.A, o.B, o.C, rec.opacity, rec.bbox_x, rec.bbox_y);
+            if (PAIR && radius <= 0) alpha_bbox(o.u, o.v, o.A, o.B, o.C, rec.opacity, abx, aby);      // listed for the opposite view only
+            rec.bbox_x = abx; rec.bbox_y = aby;
             br.depth = (st.flags & GSVC_RASTER_DEPTH_DESCENDING) ? -o.depth : o.depth;      // the sort key
-            br.rect_x = radius > 0 ? ((uint32_t)o.x0 | ((uint32_t)o.x1 << 16)) : 0u;
-            br.rect_y = (uint32_t)o.y0 | ((uint32_t)o.y1 << 16);
+            br.rect_x = radius > 0 ? ((uint32_t)(PAIR ? o.x0 : bx0) | ((uint32_t)(PAIR ? o.x1 : bx1) << 16)) : 0u;
+            br.rect_y = (uint32_t)by0 | ((uint32_t)by1 << 16);
             rec.rect_x = br.rect_x; rec.rect_y = br.rect_y;
-            my_tiles = (bx1 - bx0) * (o.y1 - o.y0);
+            my_tiles = (bx1 - bx0) * (by1 - by0);
             // the first BIN_SLOTS tiles of the rectangle (row-major): rank inside the workgroup from the LDS histogram
             // (histogram word of a tile: low half = slotted instances of this workgroup, high half = its extras in the
             // heavy case; at most 1024 each: no carry).  The remaining tiles ("extras") follow below.
             int j = 0;
-            for (int ty = o.y0; ty < o.y1 && j < BIN_SLOTS; ty++)
+            for (int ty = by0; ty < by1 && j < BIN_SLOTS; ty++)
                 for (int tx = bx0; tx < bx1 && j < BIN_SLOTS; tx++, j++) {
                     const int t = ty * st.gx + tx;
                     const int r = USE_LDS ? (atomicAdd(&hist[t], 1) & 0xffff) : atomicAdd(&tile_count[t], 1);
@@ -332,7 +355,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
                     if (j == 2) slot[2] = r;
                     if (j == 3) slot[3] = r;
                 }
-            n_extra = max((bx1 - bx0) * (o.y1 - o.y0) - BIN_SLOTS, 0);
+            n_extra = max((bx1 - bx0) * (by1 - by0) - BIN_SLOTS, 0);
         } else {
             rec.u = rec.v = rec.A = rec.B = rec.C = rec.opacity = rec.r = rec.g = rec.b = rec.depth = 0.f;
             rec.bbox_x = pack_i16(1, 0); rec.bbox_y = pack_i16(1, 0);
@@ -343,7 +366,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         // the record of a Gaussian that is in no list is never read (the sort, the compositing kernels and the backward reach
         // records through list entries or behind radii > 0): a fitting render culls ~70 % of what it submits (opacity <= 0), and
         // their 64 + 16 bytes of zeros were a quarter of this kernel's stores
-        if (listed) {
+        if (listed || radius > 0) {      // (radius > 0 but in no list — tight binning: the backward reads its empty rectangle behind radii > 0)
             float4 *dst = reinterpret_cast<float4 *>(geom + i);
             const float4 *src = reinterpret_cast<const float4 *>(&rec);
             dst[0] = src[0]; dst[1] = src[1]; dst[3] = src[3];
@@ -362,8 +385,8 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
     }
     {
         // visible count: one atomic per workgroup; the workgroup's extras: one store (K3 picks its path by it)
-        __shared__ int s_vis, s_ext;
-        if (tid == 0) { s_vis = 0; s_ext = 0; }
+        __shared__ int s_vis, s_ext, s_n3;
+        if (tid == 0) { s_vis = 0; s_ext = 0; s_n3 = 0; }
         // rows of the backward's per-instance buffer: exclusive scan of the instance counts inside the workgroup; the
         // workgroup's base comes from ONE returning atomic on a global cursor (its order among workgroups is irrelevant: a
         // Gaussian's rows only have to be contiguous and its own)
@@ -383,8 +406,15 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) ne += __shfl_xor(ne, m, 64);
         if ((tid & 63) == 0 && ne != 0) atomicAdd(&s_ext, ne);
+        if (tight) {
+            int t3 = n3;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) t3 += __shfl_xor(t3, m, 64);
+            if ((tid & 63) == 0 && t3 != 0) atomicAdd(&s_n3, t3);
+        }
         __syncthreads();
         if (tid == 0 && s_vis != 0) atomicAdd(&counters->num_visible, s_vis);
+        if (tid == 0 && tight && s_n3 != 0) atomicAdd(&counters->reserved[2], s_n3);
         if (tid == 0) wg_extras[blockIdx.x] = s_ext;
         if (!PAIR) {
             int before = 0;
@@ -403,14 +433,14 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
     }
     {
         const int nt = n_extra > 0 ? n_extra + BIN_SLOTS : 0;
-        for_each_extra(tid & 63, nt, bx0, bx1 - bx0, o.y0, [](int) { return 0; }, [&](int, int ty, int tx) {
+        for_each_extra(tid & 63, nt, bx0, bx1 - bx0, by0, [](int) { return 0; }, [&](int, int ty, int tx) {
             const int t = ty * st.gx + tx;
             if (heavy) atomicAdd(&hist[t], 0x10000);
             else atomicAdd(&tile_extra[t], 1);
         });
     }
     auto store_word2 = [&]() {
-        if (i < P && listed) {
+        if (i < P && (listed || radius > 0)) {
             GeomRec r2;
             r2.b = rec2_b; r2.bbox_x = rec2_bx; r2.bbox_y = rec2_by;
             r2.goff = PAIR ? 0 : s_gbase + row_excl;
@@ -453,7 +483,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
     store_word2();
     if (i < P && listed) {
         int j = 0;
-        for (int ty = o.y0; ty < o.y1 && j < BIN_SLOTS; ty++)
+        for (int ty = by0; ty < by1 && j < BIN_SLOTS; ty++)
             for (int tx = bx0; tx < bx1 && j < BIN_SLOTS; tx++, j++) {
                 const int base = hist[ty * st.gx + tx];
                 if (j == 0) slot[0] += base;
@@ -475,7 +505,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         if (tid == 0) s_last = (atomicAdd(&counters->reserved[0], 1) == (int)gridDim.x - 1) ? 1 : 0;
         __syncthreads();
         if (!s_last) return;
-        scan_tiles_body(T, tile_count, tile_extra, tile_offsets, big_list, counters, max_instances, hist);
+        scan_tiles_body(T, tile_count, tile_extra, tile_offsets, big_list, counters, max_instances, hist, tight ? 1 : 0);
     }
 }
 
@@ -1364,7 +1394,7 @@ static int raster_forward_impl(const gsvc_raster_settings *settings, int64_t P, 
     if (P == 0 || L.tiles > LDS_HIST_MAX_TILES) {      // otherwise the scan ran inside k_preprocess (last workgroup)
         ProfScope _prof("k_scan_tiles", s);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, L.tiles, tile_count, tile_extra, tile_offsets,
-                           big_list, counters, (long long)max_instances);
+                           big_list, counters, (long long)max_instances, (int)(!pair && (p.flags & GSVC_RASTER_TIGHT_BINNING) ? 1 : 0));
     }
     if (P > 0) {
         {

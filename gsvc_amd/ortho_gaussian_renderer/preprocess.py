@@ -14,12 +14,19 @@ from ..rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 def raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier=1.0):
     """GaussianRasterizationSettings exactly as the reference builds them (renderer.py:63-83): the view matrix
     passed is ``frame.view_matrix.permute(1, 0)``.  Host tensors are kept on the host (the kernels take the
-    16 floats by value), which removes the per-render H2D copy + sync of the reference."""
+    16 floats by value), which removes the per-render H2D copy + sync of the reference.
+    One addition: GSVC_RASTER_TIGHT_BINNING (include/gsvc_hip.h) — the lists hold a Gaussian only in the tiles its alpha >= 1/255 box
+    touches; image, radii, num_rendered and gradients are those of the 3-sigma lists (tests/test_raster_gpu.py
+    test_tight_binning_*), the binning, the sort and the backward's per-instance rows shrink by the 15 % (early) to 40 % (late in a
+    fit) of instances that can contribute nothing.  GSVC_RASTER_LOOSE_BINNING=1 turns it off."""
+    from .. import switches
+    from .._lib import RASTER_TIGHT_BINNING
+    tight = 0 if switches.RASTER_LOOSE_BINNING else RASTER_TIGHT_BINNING
     return GaussianRasterizationSettings(
         image_height=int(frame.image_height), image_width=int(frame.image_width), x_min=frame.x_min, y_min=frame.y_min,
         scale=frame.scale, threshold=pc.model_config.threshold, bg=bg_color, scale_modifier=scaling_modifier,
         viewmatrix=frame.view_matrix.permute(1, 0), sh_degree=pc.model_config.sh_degree, campos=frame.cam_pos,
-        prefiltered=False, debug=getattr(pipe, "debug", False), flags=int(getattr(pipe, "raster_flags", 0) or 0),
+        prefiltered=False, debug=getattr(pipe, "debug", False), flags=int(getattr(pipe, "raster_flags", 0) or 0) | tight,
         low_pass=float(getattr(pipe, "raster_low_pass", 0.0) or 0.0))
 
 

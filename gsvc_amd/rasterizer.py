@@ -94,14 +94,17 @@ class RasterState:
         return self._counters
 
     def tile_lists(self):
-        """(tile_offsets[T+1], point_list[num_rendered]) as int32 tensors (views into the binning blob)."""
+        """(tile_offsets[T+1], point_list[instances listed]) as int32 tensors (views into the binning blob).  The lists' length is
+        tile_offsets[T]: num_rendered counts the 3-sigma rectangles' tiles, which is more under GSVC_RASTER_TIGHT_BINNING."""
         a, b = C.c_uint64(), C.c_uint64()
         _lib.check(_lib.lib().gsvc_raster_binning_layout(C.byref(self.cs), self.P, self.max_instances, C.byref(a), C.byref(b)),
                    "gsvc_raster_binning_layout")
         H, W = self.cs.image_height, self.cs.image_width
         T = ((H + 15) // 16) * ((W + 15) // 16)
-        n = self.counters()[0]
+        if self.counters()[1]:
+            raise _lib.GsvcError("tile_lists: the forward overflowed its instance buffer (no lists were written)")
         off = self.binning[a.value:a.value + 4 * (T + 1)].view(torch.int32)
+        n = int(off[T])
         pl = self.binning[b.value:b.value + 4 * n].view(torch.int32)
         return off, pl
 

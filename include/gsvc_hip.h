@@ -103,6 +103,11 @@ typedef struct gsvc_raster_settings {
 #define GSVC_RASTER_MEANS2D_PIXEL_UNITS 8u   /* dL_dmeans2D = (dL/du, dL/dv) in pixels instead of NDC units (x W/2, x H/2) */
 #define GSVC_RASTER_CLAMP_STOPS_GRADIENT 16u /* no gradient to conic / mean / opacity where the alpha <= 0.99 clamp is active */
 #define GSVC_RASTER_NO_LOW_PASS 32u          /* low_pass = 0 exactly */
+#define GSVC_RASTER_TIGHT_BINNING 64u       /* a Gaussian is LISTED only in the tiles of its 3-sigma rectangle that its alpha >= 1/255 box
+                                               touches (the other instances can contribute nothing: the compositing kernels skip them
+                                               anyway): same image, radii, num_rendered (still the 3-sigma count) and gradients (up to
+                                               the order large rectangles' rows are added in), shorter lists — late in a fit 40 % of the
+                                               3-sigma instances are such.  Single-view forward only (the pair forward ignores it) */
 
 /* Byte sizes of the three opaque state blobs of one forward call (the 3DGS-lineage "geomBuffer /
  * binningBuffer / imgBuffer" the reference extension hands back to autograd). */
