@@ -268,9 +268,10 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
     bool heavy = false;     // workgroup-uniform: extras go through the LDS histogram
     int bx0 = 0, bx1 = 0;   // x range of the binning rectangle (pair mode: union of the two views)
     int by0 = 0, by1 = 0;   // its y range (the 3-sigma rectangle's, or what the alpha box leaves of it: GSVC_RASTER_TIGHT_BINNING)
-    const bool tight = !PAIR && (st.flags & GSVC_RASTER_TIGHT_BINNING);
+    const bool tight = (st.flags & GSVC_RASTER_TIGHT_BINNING) != 0;
     uint32_t abx = pack_i16(1, 0), aby = pack_i16(1, 0);      // alpha box (empty)
     int n3 = 0;             // tiles of the 3-sigma rectangle: what num_rendered counts whatever is listed
+    uint32_t pair_fx = 0u;  // pair mode: this view's x range as the record keeps it (0 = not in this view's lists)
     bool listed = false;
     int my_tiles = 0;       // instances of this Gaussian = rows it owns in the backward's partial-sum buffer
     float rec2_b = 0.f;
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
         by0 = o.y0; by1 = o.y1;
         if (radius > 0) {
             alpha_bbox(o.u, o.v, o.A, o.B, o.C, op, abx, aby);
-            n3 = (o.x1 - o.x0) * (o.y1 - o.y0);
+            n3 = (o.x1 - o.x0) * (o.y1 - o.y0);      // (pair mode: replaced below by the union's tiles, what its 3-sigma lists hold)
         }
         if (!PAIR) {
             bx0 = o.x0; bx1 = o.x1;
@@ -323,22 +324,47 @@ __global__ void __launch_bounds__(1024) k_preprocess(RasterParams st, int P, con
             const float rf = (float)o.radius_raw;
             const int xb0 = tile_clamp((ub - rf) / (float)TILE, st.gx), xb1 = tile_clamp((ub + rf + (float)(TILE - 1)) / (float)TILE, st.gx);
             const bool vis_b = (xb1 - xb0) * (o.y1 - o.y0) > 0;
-            const int mx0 = st.gx - xb1, mx1 = st.gx - xb0;
-            if (vis_b) br.pad = (uint32_t)mx0 | ((uint32_t)mx1 << 16);
-            if (radius > 0 && vis_b) { bx0 = min(o.x0, mx0); bx1 = max(o.x1, mx1); }
-            else if (radius > 0) { bx0 = o.x0; bx1 = o.x1; }
-            else if (vis_b) { bx0 = mx0; bx1 = mx1; }
-            listed = radius > 0 || vis_b;
+            int mx0 = st.gx - xb1, mx1 = st.gx - xb0;
+            int fx0 = o.x0, fx1 = o.x1;
+            bool in_f = radius > 0, in_b = vis_b;
+            if (tight && (in_f || in_b)) {
+                // both views' rectangles against the tiles the alpha box touches (the opposite view's box is this view's, mirrored into
+                // this view's tile grid with the rectangle: one box serves both, as in k_blend<PAIR>); K3 forms the union from the two
+                // clamped x ranges it finds in the record
+                if (!in_f) alpha_bbox(o.u, o.v, o.A, o.B, o.C, op, abx, aby);
+                const int lx = (int)(int16_t)(abx & 0xffffu), hx = (int)(int16_t)(abx >> 16), ly = (int)(int16_t)(aby & 0xffffu), hy = (int)(int16_t)(aby >> 16);
+                if (lx > hx || ly > hy) in_f = in_b = false;
+                else {
+                    by0 = max(o.y0, ly >> 4); by1 = min(o.y1, (hy >> 4) + 1);
+                    fx0 = max(fx0, lx >> 4); fx1 = min(fx1, (hx >> 4) + 1);
+                    mx0 = max(mx0, lx >> 4); mx1 = min(mx1, (hx >> 4) + 1);
+                    if (by1 <= by0) in_f = in_b = false;
+                    in_f = in_f && fx1 > fx0;
+                    in_b = in_b && mx1 > mx0;
+                }
+                if (!in_f && !in_b) by0 = by1 = 0;
+            }
+            pair_fx = in_f ? ((uint32_t)fx0 | ((uint32_t)fx1 << 16)) : 0u;
+            if (in_b) br.pad = (uint32_t)mx0 | ((uint32_t)mx1 << 16);
+            if (in_f && in_b) { bx0 = min(fx0, mx0); bx1 = max(fx1, mx1); }
+            else if (in_f) { bx0 = fx0; bx1 = fx1; }
+            else if (in_b) { bx0 = mx0; bx1 = mx1; }
+            listed = in_f || in_b;
+            {
+                const int ux0 = (radius > 0 && vis_b) ? min(o.x0, st.gx - xb1) : (radius > 0 ? o.x0 : st.gx - xb1);
+                const int ux1 = (radius > 0 && vis_b) ? max(o.x1, st.gx - xb0) : (radius > 0 ? o.x1 : st.gx - xb0);
+                n3 = (radius > 0 || vis_b) ? (ux1 - ux0) * (o.y1 - o.y0) : 0;
+            }
         }
         if (listed) {
             rec.u = o.u; rec.v = o.v; rec.A = o.A; rec.B = o.B;
             rec.C = o.C; rec.opacity = op;
             rec.r = colors[3 * i + 0]; rec.g = colors[3 * i + 1]; rec.b = colors[3 * i + 2];
             rec.depth = o.depth;
-            if (PAIR && radius <= 0) alpha_bbox(o.u, o.v, o.A, o.B, o.C, rec.opacity, abx, aby);      // listed for the opposite view only
+            if (PAIR && radius <= 0 && !tight) alpha_bbox(o.u, o.v, o.A, o.B, o.C, rec.opacity, abx, aby);      // listed for the opposite view only
             rec.bbox_x = abx; rec.bbox_y = aby;
             br.depth = (st.flags & GSVC_RASTER_DEPTH_DESCENDING) ? -o.depth : o.depth;      // the sort key
-            br.rect_x = radius > 0 ? ((uint32_t)(PAIR ? o.x0 : bx0) | ((uint32_t)(PAIR ? o.x1 : bx1) << 16)) : 0u;
+            br.rect_x = PAIR ? pair_fx : (radius > 0 ? ((uint32_t)bx0 | ((uint32_t)bx1 << 16)) : 0u);
             br.rect_y = (uint32_t)by0 | ((uint32_t)by1 << 16);
             rec.rect_x = br.rect_x; rec.rect_y = br.rect_y;
             my_tiles = (bx1 - bx0) * (by1 - by0);
@@ -1394,7 +1420,7 @@ static int raster_forward_impl(const gsvc_raster_settings *settings, int64_t P, 
     if (P == 0 || L.tiles > LDS_HIST_MAX_TILES) {      // otherwise the scan ran inside k_preprocess (last workgroup)
         ProfScope _prof("k_scan_tiles", s);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, L.tiles, tile_count, tile_extra, tile_offsets,
-                           big_list, counters, (long long)max_instances, (int)(!pair && (p.flags & GSVC_RASTER_TIGHT_BINNING) ? 1 : 0));
+                           big_list, counters, (long long)max_instances, (int)((p.flags & GSVC_RASTER_TIGHT_BINNING) ? 1 : 0));
     }
     if (P > 0) {
         {

@@ -107,7 +107,7 @@ typedef struct gsvc_raster_settings {
                                                touches (the other instances can contribute nothing: the compositing kernels skip them
                                                anyway): same image, radii, num_rendered (still the 3-sigma count) and gradients (up to
                                                the order large rectangles' rows are added in), shorter lists — late in a fit 40 % of the
-                                               3-sigma instances are such.  Single-view forward only (the pair forward ignores it) */
+                                               3-sigma instances are such.  The pair forward clamps both views' rectangles by the (shared) box */
 
 /* Byte sizes of the three opaque state blobs of one forward call (the 3DGS-lineage "geomBuffer /
  * binningBuffer / imgBuffer" the reference extension hands back to autograd). */

@@ -585,3 +585,23 @@ def test_tight_binning_gives_the_three_sigma_results_from_shorter_lists(oracle_l
     assert b["num_rendered"] == ref.num_rendered and np.array_equal(b["radii"].cpu().numpy(), ref.radii)
     ok = ref.borderline == 0
     assert np.abs(b["image"].cpu().numpy() - ref.image)[:, ok].max() < 1e-4
+
+
+def test_tight_binning_pair_forward_is_the_same_two_view_frame():
+    """The pair forward under GSVC_RASTER_TIGHT_BINNING (both views' rectangles clamped by the shared alpha box): the same two-view
+    frame bit for bit, the same radii and num_rendered, shorter lists — on a scene of large, faint Gaussians (a fitted model's shape)."""
+    from gsvc_amd import rasterizer
+    sc = synthetic.raster_scene(20_000, H=544, W=960, T=64, seed=9, window_frames=8, sigma_px=(2.0, 24.0), opacity=(0.004, 0.25))
+    sc["opacities"][::5] = 0.003
+    s = dict(sc["settings"])
+    d = _to_dev(sc)
+    args = (d["means3D"], d["colors"], d["opacities"].view(-1).contiguous(), d["scales"], d["rotations"])
+    out = {}
+    for tag, flags in (("loose", 0), ("tight", _lib.RASTER_TIGHT_BINNING)):
+        s["flags"] = flags
+        img, radii, st = rasterizer.raster_forward(_rasterizer(s, "viewmatrix", (0.1, 0.2, 0.3))._c_settings(), *args, pair=True)
+        off, pl = st.tile_lists()
+        out[tag] = (img.clone(), radii.clone(), st.counters()[0], int(off[-1]), int(pl.numel()))
+    a, b = out["loose"], out["tight"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+    assert a[3] == a[2] == a[4] and b[3] == b[4] < 0.75 * a[3], (a[2:], b[2:])
