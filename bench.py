@@ -537,10 +537,13 @@ def run_train_step(args, rank, world, dev):
 
     # per-kernel pass: same K steps with HIP events around every launch on the launch stream
     _lib.profile_enable(True)
-    inst = 0
+    inst = inst_api = 0
     for _ in range(args.steps):
         out = step()
-        inst += sum(r.num_rendered for r in out.renders)
+        # the instances the kernels WORK on (the tile lists' length): the renderer lists a Gaussian only where its alpha box reaches
+        # (GSVC_RASTER_TIGHT_BINNING), num_rendered stays the 3-sigma count of the API
+        inst += sum(r.raster_state.listed_instances() for r in out.renders)
+        inst_api += sum(r.num_rendered for r in out.renders)
     torch.cuda.synchronize()
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
@@ -611,7 +614,8 @@ def run_train_step(args, rank, world, dev):
         return None
 
     HW = H * W
-    n_inst = inst / (4 * args.steps)                      # instances per render
+    n_inst = inst / (4 * args.steps)                      # instances per render (listed: what the roofline's bytes are counted on)
+    n_inst_api = inst_api / (4 * args.steps)              # num_rendered per render (tiles of the 3-sigma rectangles)
     P = submitted[0] / (4.0 * args.steps)                 # Gaussians submitted per render, mean over the timed steps
     n_vis = total_units / (4 * args.steps * world)
     kern = {k: {"launches": n, "avg_us": 1e3 * ms / max(n, 1)} for k, (n, ms) in prof.items()}
@@ -641,7 +645,9 @@ def run_train_step(args, rank, world, dev):
                                f"(lambda={opt.lmbda}, TRAINING_ENTROPY) + L1/SSIM/optical + Adam; one frame pair per rank; "
                                f"{args.pretrain} untimed fitting steps before the warmup",
                    "gaussians_per_render": P, "active_per_render": n_vis, "active_fraction": n_vis / max(P, 1.0),
-                   "instances_per_render": n_inst, "tiles_per_active_gaussian": n_inst / max(n_vis, 1.0),
+                   "instances_per_render": n_inst, "num_rendered_per_render": n_inst_api, "tiles_per_active_gaussian": n_inst / max(n_vis, 1.0),
+                   "instances_note": "instances_per_render = entries of the tile lists (a Gaussian is listed in the tiles its alpha >= 1/255 box "
+                                     "touches: GSVC_RASTER_TIGHT_BINNING); num_rendered_per_render = the API's count over the 3-sigma rectangles",
                    "visible_anchors_per_render": P / pc.n_offsets,
                    "value_counts": "Gaussians with radius > 0 (active_per_render x 4 renders x steps / s); gaussians_per_render are "
                                    "submitted un-compacted (K per visible anchor), both means over the timed steps",

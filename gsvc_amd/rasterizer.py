@@ -108,6 +108,15 @@ class RasterState:
         pl = self.binning[b.value:b.value + 4 * n].view(torch.int32)
         return off, pl
 
+    def listed_instances(self) -> int:
+        """(tile, Gaussian) instances the tile lists hold = tile_offsets[T]: what the sort, the compositing kernels and the backward's
+        rows work on.  Equal to num_rendered for the 3-sigma lists, fewer under GSVC_RASTER_TIGHT_BINNING (one 4-byte copy: synchronises)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(_lib.lib().gsvc_raster_binning_layout(C.byref(self.cs), self.P, self.max_instances, C.byref(a), C.byref(b)),
+                   "gsvc_raster_binning_layout")
+        T = ((self.cs.image_height + 15) // 16) * ((self.cs.image_width + 15) // 16)
+        return int(self.binning[a.value + 4 * T:a.value + 4 * T + 4].view(torch.int32)[0])
+
     def image_aux(self):
         a, b = C.c_uint64(), C.c_uint64()
         _lib.check(_lib.lib().gsvc_raster_image_layout(C.byref(self.cs), C.byref(a), C.byref(b)), "gsvc_raster_image_layout")
