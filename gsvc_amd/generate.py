@@ -346,7 +346,7 @@ class StepPlan:
     def resolve(self):
         """The one wait: cut the padded lists to their lengths."""
         if self.vis_list is None:
-            self._event.synchronize()
+            _blocked_wait(self._event)
             n = self._host.tolist()
             R, A = self.R, self._A
             if self._ends:                   # the fused scans report the scan at each view's end: counts are the differences
@@ -947,6 +947,26 @@ def _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, 
 _RATE_STREAM = {}
 SMALL_WORK_MIN_ROWS = 150_000      # visible anchor rows of a step from which the small-work stream is used: below, the step is
                                    # host-bound (configs[3]: 58 k rows) and the extra events / stream switches only cost host time
+# ... unless the Trainer has MEASURED which side bounds its steps (round 5): the row count says nothing about the rasterizer's load, and
+# late in a fit a 100 k-anchor model (80 k rows) spends 7 ms per step on the GPU — its Gaussians cover 57 tiles each — while the host
+# needs 5.  The host only ever blocks at the step's two waits (the plan's counts, the renders' counters): what it blocks there per step
+# is the GPU's lead over it.  None = no measurement yet (the row count decides); set by gsvc_amd.train.Trainer.
+gpu_bound_hint = None
+host_blocked_s = [0.0]             # seconds the host spent blocked in those waits since the Trainer last read it
+
+
+def gpu_bound(rows) -> bool:
+    """Should this step spend host time (events, stream switches, separate launches) to save GPU time?"""
+    # (the measurement only ever ADDS steps to the GPU-bound side: a caller that synchronises every step — float(loss) — never lets the
+    # host block in the step's own waits, and must not lose what the row count alone already grants)
+    return rows >= SMALL_WORK_MIN_ROWS or bool(gpu_bound_hint)
+
+
+def _blocked_wait(event):
+    import time
+    t0 = time.perf_counter()
+    event.synchronize()
+    host_blocked_s[0] += time.perf_counter() - t0
 
 
 def small_work_stream(dev):
@@ -1206,7 +1226,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
             share = _film_rows(pc, frames, plan, vis, seg, anchor_all)
     from . import mlp as _mlp
     # few rows: the step's time is the host's (SMALL_WORK_MIN_ROWS) -> the MLP layer launches prefer fewer, multi-product launches
-    _mlp.host_bound_step = bool(vis.is_cuda and torch.is_grad_enabled() and seg.rows < SMALL_WORK_MIN_ROWS and "GSVC_MANY_MIN_ROWS" not in os.environ)
+    _mlp.host_bound_step = bool(vis.is_cuda and torch.is_grad_enabled() and not gpu_bound(seg.rows) and "GSVC_MANY_MIN_ROWS" not in os.environ)
     gens = [getattr(pc, n) for n in ("get_opacity_mlp", "get_color_mlp", "get_cov_mlp")]
     deform_mods = list(pc.get_deform_mlp) if isinstance(pc.get_deform_mlp, torch.nn.Sequential) else []
     deform_linears = deform_mods[0::2]
@@ -1325,7 +1345,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
                 return _rate_many(pc, seg, feat, grid_scaling, grid_offsets, offset_masks, Q_feat, Q_scaling, Q_offsets, ec, ec_row,
                                   sel=plan.sel if plan is not None else None)
         if (defer_rate and dense and late_rows and plan is not None and plan.sel is not None and vis.is_cuda
-                and seg.rows >= SMALL_WORK_MIN_ROWS and not switches.NO_RATE_OVERLAP):
+                and gpu_bound(seg.rows) and not switches.NO_RATE_OVERLAP):
             # the sampled rate — three small networks on ~10 k rows and a dozen reductions, launch-bound — is issued by the caller
             # BEHIND the rasterizer's launches, on its own stream (finish_deferred_rate): it runs under the compositing kernels
             # forward and, its autograd nodes living on that stream, under the rasterizer's backward
@@ -1393,7 +1413,7 @@ def generate_neural_gaussians_many(frames, pc, visible_masks, mode=GenerateMode.
                                 xyz=xyz, color=color, rot=rot, world=world,      # the un-split tensors: rasterize_many works on their row ranges
                                 bit_per_param_sum=getattr(rates[0], "bit_per_param_sum", None),
                                 deferred_rate=deferred[0] if deferred else None,
-                                small_work=bool(vis.is_cuda and seg.rows >= SMALL_WORK_MIN_ROWS and not switches.NO_RATE_OVERLAP))
+                                small_work=bool(vis.is_cuda and gpu_bound(seg.rows) and not switches.NO_RATE_OVERLAP))
         out = []
         for r, gs in enumerate(seg.slices(K)):
             out.append(GeneratedGaussians(

@@ -191,8 +191,9 @@ def resolve_deferred(states):
     if not states:
         return [], False
     if all(getattr(st, "_event", None) is not None for st in states):
+        from .generate import _blocked_wait      # (what the host blocks here is the GPU's lead over it: Trainer's bound detector)
         for st in states:
-            st._event.synchronize()
+            _blocked_wait(st._event)
         host = [st._host.tolist() for st in states]
     else:
         host = torch.stack([st.binning[:16].view(torch.int32) for st in states]).tolist()

@@ -20,6 +20,7 @@ Code reads the module attributes (``switches.NO_MLP_CHAIN``); a process that cha
     GSVC_RATE_EARLY        the sampled rate issued (on its own stream) BEFORE the rasterizer's launches: its backward then runs behind the rasterizer's
     GSVC_NO_LATE_ROWS      gather offsets / scalings / masks with the features (not behind the generators)
     GSVC_NO_PREFETCH / GSVC_NO_EARLY_PLAN / GSVC_EARLY_PLAN   step plan off / never from inside the backward / always
+    GSVC_NO_ADAPTIVE_BOUND the step's "is the GPU or the host the bound" decisions by the row count only (not by the host's measured blocked time)
     GSVC_RASTER_LOOSE_BINNING   the renderer lists every Gaussian in all tiles of its 3-sigma rectangle (default: only where its alpha box reaches)
     GSVC_RASTER_STREAMS    side streams the step's renders are dealt to (default 2; 1 = all on the current stream)
     GSVC_DP_SPARSE         data parallel: 0 = dense all-reduce always, 1 = row-sparse exchange always (default: whichever moves less)
@@ -30,7 +31,7 @@ import os
 
 _FLAGS = ("NO_MLP_CHAIN", "NO_MLP_FUSED", "NO_QUANT_CHAIN", "NO_SHARED_INPUT", "NO_ACCUM_MANY", "NO_DECODE_CHAIN", "CTX_ALL_ROWS",
           "NO_FUSED_CTX", "NO_FUSED_GRID", "NO_FUSED_STATIS", "NO_FUSED_RATE", "NO_FUSED_GATHER", "NO_FUSED_PLAN", "NO_FUSED_STE", "NO_RANKED_GATHER",
-          "NO_PACKED_GRID", "NO_GRID_MANY", "NO_FILM_SHARE", "NO_VIEW_SHARE", "NO_LATE_ROWS", "NO_RATE_OVERLAP", "NO_PREFETCH", "NO_EARLY_PLAN", "EARLY_PLAN", "RATE_EARLY", "RASTER_LOOSE_BINNING")
+          "NO_PACKED_GRID", "NO_GRID_MANY", "NO_FILM_SHARE", "NO_VIEW_SHARE", "NO_LATE_ROWS", "NO_RATE_OVERLAP", "NO_PREFETCH", "NO_EARLY_PLAN", "EARLY_PLAN", "RATE_EARLY", "RASTER_LOOSE_BINNING", "NO_ADAPTIVE_BOUND")
 
 
 def reload():

@@ -170,6 +170,11 @@ class Trainer:
         gaussians._zown = self._zown      # gsvc_amd.generate._param_means reads the owners' means from it
         self._mask_reg_weight = 0.0
         self._ovf_handle = None
+        # which side bounds the steps, measured (gsvc_amd.generate.gpu_bound_hint): the host's blocked time per step, smoothed
+        self._blocked_ema = None
+        from . import generate as _gen
+        _gen.gpu_bound_hint = None
+        _gen.host_blocked_s[0] = 0.0
 
     def close(self):
         """Give the calling thread its CPU affinity back (``__init__`` narrowed it to the GPU's NUMA node: gsvc_amd/hostbind.py;
@@ -177,6 +182,8 @@ class Trainer:
         if self.pc._anchor.is_cuda:
             from .hostbind import unbind
             unbind(self.pc._anchor.device)
+        from . import generate as _gen
+        _gen.gpu_bound_hint = None      # a measurement of THIS trainer's steps
 
     def __enter__(self):
         return self
@@ -191,7 +198,27 @@ class Trainer:
         image = (f.rendered_image + torch.flip(b.rendered_image, dims=(-1,))) / 2
         return f, b, image
 
+    def _update_bound(self):
+        """The host blocks only at the step's two waits, and what it blocks there is how far the GPU is behind it: over ~0.4 ms per
+        step the GPU bounds the step and host-side work that shortens the GPU's (the small-work stream, the early plan, separate
+        layer launches) pays; under ~0.1 ms the host does and it does not.  In between the last decision stands (the measures
+        themselves move the balance).  The first steps (allocator growth, first launches) are not counted."""
+        from . import generate as _gen
+        b = _gen.host_blocked_s[0]
+        _gen.host_blocked_s[0] = 0.0
+        self._steps_seen = getattr(self, "_steps_seen", 0) + 1
+        if switches.NO_ADAPTIVE_BOUND or self._steps_seen <= 8:
+            return
+        self._blocked_ema = b if self._blocked_ema is None else 0.8 * self._blocked_ema + 0.2 * b
+        if self._steps_seen < 16:
+            return
+        if self._blocked_ema > 4e-4:
+            _gen.gpu_bound_hint = True
+        elif self._blocked_ema < 1e-4:
+            _gen.gpu_bound_hint = False
+
     def step(self, iteration: int, frame_idx: int | None = None) -> StepOutput:
+        self._update_bound()
         if frame_idx is None and self._plan_idx is not None:
             frame_idx = self._plan_idx              # drawn (from the same generator, in the same order) at the end of the last step
         self._early = None
@@ -309,6 +336,11 @@ class Trainer:
         # only when a rank sees less than a quarter of the anchors.  The same decision on every rank (cap is their maximum).
         return switches.DP_SPARSE == "1" or gdist.sparse_rows_pay(gdist.world_size(), int(self.pc._anchor.shape[0]),
                                                                                   plan.distinct_cap)
+
+    @staticmethod
+    def _gpu_bound(rows):
+        from . import generate as _gen
+        return rows >= EARLY_PLAN_MIN_ROWS or bool(_gen.gpu_bound_hint)
 
     def _views(self, frame_idx):
         """The step's four views: (frame, frame seen from the opposite side) of the two adjacent frames."""
@@ -467,8 +499,8 @@ class Trainer:
                 and pc._scaling.requires_grad and pc._mask.requires_grad
                 # it pays when the GPU, not the host, bounds the step (the hook's work costs ~1 ms of host time more on the
                 # autograd thread than at the end of the step: a 6 k-row step went 8.3 -> 9.7 ms, the 200 k-row step 11.95 -> 11.3)
-                and (switches.EARLY_PLAN or sum(int(r.visible_index.shape[0]) for r in
-                                                               (x.generated_gaussians for x in renders)) >= EARLY_PLAN_MIN_ROWS)):
+                and (switches.EARLY_PLAN or self._gpu_bound(sum(int(r.visible_index.shape[0]) for r in
+                                                                                (x.generated_gaussians for x in renders))))):
             # STE_ENTROPY renders from detached attributes (reference guassian.py:205-207): _scaling receives no gradient there,
             # is not changed by the step, and its hook would never run
             waited = [pc._mask] if mode == GenerateMode.TRAININ_STE_ENTROPY else [pc._scaling, pc._mask]
