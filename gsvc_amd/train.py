@@ -207,7 +207,10 @@ class Trainer:
         b = _gen.host_blocked_s[0]
         _gen.host_blocked_s[0] = 0.0
         self._steps_seen = getattr(self, "_steps_seen", 0) + 1
-        if switches.NO_ADAPTIVE_BOUND or self._steps_seen <= 8:
+        if switches.NO_ADAPTIVE_BOUND:
+            _gen.gpu_bound_hint = None
+            return
+        if self._steps_seen <= 8:
             return
         self._blocked_ema = b if self._blocked_ema is None else 0.8 * self._blocked_ema + 0.2 * b
         if self._steps_seen < 16:
