@@ -782,6 +782,66 @@ def run_train_step(args, rank, world, dev):
     return res
 
 
+def run_train_step_late(args, dev, total=3000, stop_frac=0.6, anchors=100_000, steps=40):
+    """What a step costs LATE in a fit (the headline model is 200 steps old): a 100 k-anchor model (the reference's anchor count) fitted
+    through a schedule scaled to `total` steps up to the middle of its entropy-constrained phase, then `steps` timed steps.  By then the
+    Gaussians have grown (tens of tiles each, faint): the rasterizer is most of the step, and what the round's last changes are for."""
+    import numpy as np
+    import torch
+    from gsvc_amd.arguments import cfg_20240919
+    from gsvc_amd.frame import SyntheticFrameCube
+    from gsvc_amd.model import GaussianModel
+    from gsvc_amd.train import Trainer
+    H, W, T = args.height, args.width, args.train_frames
+    mp_, opt, pipe = cfg_20240919()
+    cube = SyntheticFrameCube(H, W, T, seed=1234, device=dev).materialize()
+    mp_.threshold = 8.0 / cube.scale
+    s = total / 40_000.0
+    opt.iterations = total
+    opt.full_precision_training_total, opt.quantized_training_total = int(10_000 * s), int(5_000 * s)
+    opt.entropy_constrained_train_total = int(20_000 * s)
+    opt.ste_entropy_constrained_train_total = total - int(35_000 * s)
+    opt.start_stat, opt.update_from, opt.update_until = int(500 * s), int(1_500 * s), int(25_000 * s)
+    opt.update_interval, opt.pause_densification = max(20, int(100 * s)), int(1_000 * s)
+    for name in dir(opt):
+        if name.endswith("_max_steps"):
+            setattr(opt, name, total)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    pc = GaussianModel(mp_, mp_.anchor_feature_dim, mp_.n_offsets, mp_.voxel_size, mp_.update_depth, mp_.update_init_factor,
+                       mp_.update_hierarchy_factor, mp_.use_feat_bank, n_features_per_level=mp_.grid_feature_dim,
+                       log2_hashmap_size=mp_.log2, log2_hashmap_size_2D=mp_.log2_2D, device=dev)
+    lim = np.array([cube.x_min, cube.y_min, cube.z_min]) * 1.1
+    pc.create_from_points(np.random.default_rng(0).uniform(lim, -lim, (anchors, 3)), spatial_lr_scale=1.0)
+    pc.update_anchor_bound(cube.x_min, cube.y_min, cube.z_min)
+    pc.training_setup(opt)
+    stop = int(stop_frac * total)
+    with Trainer(pc, cube, opt, pipe, mp_, seed=0) as trainer:
+        it = 0
+        while it < stop:
+            it += 1
+            trainer.step(it)
+        active = torch.zeros((), device=dev, dtype=torch.float64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            it += 1
+            out = trainer.step(it)
+            active += out.active_gaussians
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        listed = sum(r.raster_state.listed_instances() for r in out.renders) / 4.0
+        api = sum(r.num_rendered for r in out.renders) / 4.0
+        mode = trainer.controller.render_mode.name
+    n_act = float(active.item())
+    return {"workload": f"a fitting step {stop} iterations into a {total}-step fit of the {T}-frame {H}x{W} synthetic video (schedule of the reference scaled, "
+                        f"{int(pc._anchor.shape[0])} anchors x K=10, 16-frame slab), phase {mode}; {steps} timed steps",
+            "ms_per_step": 1e3 * el / steps, "value": n_act / el, "unit": "Gaussians/s (active: radius > 0)",
+            "active_per_render": n_act / (4.0 * steps), "instances_per_render": listed, "num_rendered_per_render": api,
+            "tiles_per_active_gaussian": api / max(n_act / (4.0 * steps), 1.0),
+            "note": "instances_per_render = entries of the tile lists (tight binning), num_rendered_per_render = the 3-sigma rectangles' tiles (last timed step)"}
+
+
 def run_train_step_light(args, dev, anchors, steps, pretrain, warmup=5):
     """The configs[2] fitting step at another model size: step time and the per-render counts only (no side measurements).
     Used for the second operating point of the headline line: ~500 k ACTIVE Gaussians per render (radius > 0), where the
@@ -1159,6 +1219,13 @@ def main():
                     res["train_step_500k_active"] = run_train_step_light(args, dev, anchors=870_000, steps=10, pretrain=40)
                 except Exception as e:  # noqa: BLE001
                     res["train_step_500k_active"] = {"error": f"{type(e).__name__}: {e}"}
+            # a step late in a fit (Gaussians grown to tens of tiles each): where most of a 40 000-iteration fit's time goes
+            if rank == 0 and not os.environ.get("GSVC_BENCH_NO_LATE"):
+                try:
+                    torch.cuda.empty_cache()
+                    res["train_step_late"] = run_train_step_late(args, dev)
+                except Exception as e:  # noqa: BLE001
+                    res["train_step_late"] = {"error": f"{type(e).__name__}: {e}"}
             # the other phases of the schedule (the headline is the TRAINING_ENTROPY phase: 20 k of the 40 k iterations)
             if rank == 0 and not os.environ.get("GSVC_BENCH_NO_PHASES"):
                 try:
