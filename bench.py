@@ -680,6 +680,12 @@ def run_train_step(args, rank, world, dev):
         res["cold_ground_truth"] = cold
         if "ms_per_step_cold" in cold:
             res["ms_per_step_cold"] = cold["ms_per_step_cold"]
+    # which side bounds the step, measured: what the host blocks per step at the step's two waits (the plan's counts, the renders'
+    # counters) is the GPU's lead over it (gsvc_amd.train.Trainer._update_bound); ~0 = the host is the bound
+    if getattr(trainer, "_blocked_ema", None) is not None:
+        from gsvc_amd import generate as _gen
+        res["host_blocked_ms_per_step"] = 1e3 * trainer._blocked_ema
+        res["gpu_bound_measured"] = bool(_gen.gpu_bound_hint) if _gen.gpu_bound_hint is not None else None
     if comm is not None:
         res["gradient_exchange"] = comm
     if world == 1:
