@@ -46,7 +46,8 @@ def probe(tag, it0):
     import time
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    _lib.profile_enable(True)
+    events = not os.environ.get("LATE_NO_EVENTS")      # (the per-kernel events serialise the step's streams: off for a kernel trace)
+    _lib.profile_enable(events)
     inst = act = sub = 0
     n = 40
     for k in range(n):
