@@ -119,7 +119,8 @@ typedef struct gsvc_raster_sizes {
 
 /* counters written by forward into the first 32 bytes of the binning blob */
 typedef struct gsvc_raster_counters {
-    int32_t num_rendered; /* sum of tiles touched = instances (true count even when it overflowed) */
+    int32_t num_rendered; /* sum of the 3-sigma rectangles' tiles (true count even when it overflowed) = the lists' length, except under
+                             GSVC_RASTER_TIGHT_BINNING, where the lists are shorter: their length is tile_offsets[T] (gsvc_raster_binning_layout) */
     int32_t overflow;     /* 1 when num_rendered > max_instances: image/state are NOT valid, retry bigger */
     int32_t num_visible;  /* Gaussians with radius > 0 */
     int32_t max_tile_len; /* longest per-tile list */
