@@ -79,7 +79,24 @@ def probe(tag, it0):
     op = g[:, 5].view(torch.float32)[pl.long()]
     print(f"   instances of render 0: {pl.numel()}, alpha box misses the tile: {float(miss.float().mean()):.3f}; opacity of the listed Gaussians: "
           f"median {float(op.median()):.3f}, share below 0.05: {float((op < 0.05).float().mean()):.3f}", flush=True)
-    return it0 + n
+    # the compositing backward's own counters (its diagnostic instantiation): (entry, quadrant) replays, lanes of those replays that
+    # held a contributing pixel, entries replayed
+    pr = [0, 0, 0, 0]
+    _lib.profile_enable(2)
+    try:
+        for k in range(2):
+            o2 = tr.step(it0 + n + k)
+            torch.cuda.synchronize()
+            for r in o2.renders:
+                c = r.raster_state.binning[64:88].view(torch.int64).tolist()
+                for i in range(3):
+                    pr[i] += c[i]
+                pr[3] += r.raster_state.listed_instances()
+    finally:
+        _lib.profile_enable(False)
+    print(f"   compositing backward: {pr[2] / max(pr[3], 1):.3f} of the listed instances are replayed, {pr[0] / max(pr[2], 1):.2f} quadrant replays per replayed "
+          f"entry, {pr[1] / max(64 * pr[0], 1):.3f} of the replayed lanes hold a contributing pixel", flush=True)
+    return it0 + n + 2
 
 
 it = 1
