@@ -489,7 +489,11 @@ def run_train_step(args, rank, world, dev):
     # cold ground truth: the same K steps with the video in pinned HOST memory and the step's two frames + flow uploaded per step
     # (what the reference's own step timer includes: pipeline/train.py:332,407-408,464), one step ahead on a copy stream
     cold = None
-    if world == 1:
+    host_cube = None
+    pinned_bytes = 4 * T * (3 + 2) * H * W            # pictures + flow fields of the whole video in pinned host memory
+    if world == 1 and pinned_bytes > 24 * 2 ** 30:
+        cold = {"skipped": f"the video would take {pinned_bytes / 2 ** 30:.1f} GiB of pinned host memory (budget 24 GiB)"}
+    elif world == 1:
         try:
             from gsvc_amd.frame import HostResidentCube
             host_cube = HostResidentCube(cube, dev)
@@ -498,15 +502,23 @@ def run_train_step(args, rank, world, dev):
                 step()
             up0 = host_cube.uploads
             e_cold = timed(torch, dist, world, step, args.steps)
-            cold = {"ms_per_step_cold": 1e3 * e_cold / args.steps, "uploads_per_step": (host_cube.uploads - up0) / args.steps,
-                    "bytes_per_upload": int(2 * host_cube._images[0].numel() * 4 + host_cube._flows[0].numel() * 4),
+            # the link by itself: one pair's upload (pinned -> device, nothing else queued), so that a slow box reads as such
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for _ in range(4):
+                host_cube._upload(host_cube._new_slot(), 0)
+            host_cube._copy.synchronize()
+            h2d_s = (time.perf_counter() - th) / 4
+            nbytes = int(2 * host_cube._images[0].numel() * 4 + host_cube._flows[0].numel() * 4)
+            cold = {"ms_per_step_cold": 1e3 * e_cold / args.steps, "uploads_per_step": (host_cube.uploads - 4 - up0) / args.steps,
+                    "bytes_per_upload": nbytes, "upload_alone_ms": 1e3 * h2d_s, "h2d_GBps": nbytes / h2d_s / 1e9,
                     "note": "ground-truth frames + flow in pinned host memory, uploaded per step on a copy stream one step ahead "
                             "(gsvc_amd.frame.HostResidentCube); `value` / ms_per_step above keep the video resident in HBM"}
         except Exception as e:  # noqa: BLE001
             cold = {"error": f"{type(e).__name__}: {e}"}
         finally:
             trainer.dataset = cube
-            del host_cube
+            host_cube = None
 
     # exposed communication: the same K steps with the gradient exchange switched off (replicas diverge: last thing
     # measured on the model's gradients; parameters are re-broadcast afterwards)

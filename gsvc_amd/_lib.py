@@ -165,6 +165,8 @@ _SIGNATURES = {
     "gsvc_plan_scans": (C.c_int, [_vp, _vp, _vp, C.c_int32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_film_row_maps": (C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsvc_pair_rows_sum": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, _vp, _vp]),
+    "gsvc_set_deterministic": (C.c_int, [C.c_int]),
+    "gsvc_segment_rows_sum": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, _vp, C.c_int32, _vp]),
     "gsvc_ste_binary_count_many": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, _vp]),
     "gsvc_ste_binary_backward_many": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, C.c_int32, _vp, _vp]),
     "gsvc_table_bits": (C.c_int, [_vp, C.c_int32, _i64, _vp, _vp]),
@@ -272,7 +274,20 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        if _deterministic and hasattr(L, "gsvc_set_deterministic"):
+            L.gsvc_set_deterministic(1)
     return _lib
+
+
+_deterministic = False
+
+
+def set_deterministic(on: bool):
+    """GSVC_DETERMINISTIC (gsvc_amd.switches): told to the library now if it is loaded, else when it loads."""
+    global _deterministic
+    _deterministic = bool(on)
+    if _lib is not None and hasattr(_lib, "gsvc_set_deterministic"):
+        _lib.gsvc_set_deterministic(int(_deterministic))
 
 
 def check(rc: int, what: str):

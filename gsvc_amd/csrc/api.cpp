@@ -25,12 +25,14 @@ struct ProfRec {
 };
 static bool g_prof_on = false;
 static bool g_bwd_probe = false;
+static bool g_deterministic = false;
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_pool;
 
 bool profile_enabled() { return g_prof_on; }
 bool bwd_probe_enabled() { return g_bwd_probe; }
+bool deterministic() { return g_deterministic; }
 
 static hipEvent_t get_event()
 {
@@ -59,6 +61,12 @@ void profile_end(hipStream_t s)
 }
 
 }  // namespace gsvc
+
+extern "C" int gsvc_set_deterministic(int on)
+{
+    gsvc::g_deterministic = on != 0;
+    return GSVC_OK;
+}
 
 extern "C" int gsvc_profile_enable(int on)
 {

@@ -25,6 +25,7 @@ inline int check_launch(const char *what)
 // bench.py's per-kernel timer: brackets a launch with events on its stream when profiling is enabled
 bool profile_enabled();
 bool bwd_probe_enabled();      // gsvc_profile_enable bit 1: k_blend_bwd_tile counts its replays (diagnostic instantiation)
+bool deterministic();           // gsvc_set_deterministic: launches whose float sums depend on workgroup order take their fixed-order form
 void profile_begin(const char *name, hipStream_t s);
 void profile_end(hipStream_t s);
 

@@ -847,6 +847,40 @@ extern "C" int gsvc_pair_rows_sum(const float *g, const int32_t *src_a, const in
     return gsvc::check_launch("pair_rows_sum");
 }
 
+namespace gsvc {
+// Scatter-add of rows WITHOUT atomics (GSVC_DETERMINISTIC=1): the n source rows sorted by their target (order = stable argsort of
+// the targets, sorted_idx = the targets in that order); the thread of (run head p, channel c) adds the run's rows in list order
+// and writes (or adds to) the target row once — the same bits every run whatever the launch order of the workgroups.
+__global__ void __launch_bounds__(256) k_segment_rows_sum(const float *__restrict__ src, const long long *__restrict__ order,
+                                                          const long long *__restrict__ sorted_idx, long long n, int C,
+                                                          float *__restrict__ dst, int accumulate)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * C) return;
+    const long long p = e / C;
+    const int c = (int)(e - p * C);
+    const long long t = sorted_idx[p];
+    if (p > 0 && sorted_idx[p - 1] == t) return;
+    float acc = 0.f;
+    for (long long j = p; j < n && sorted_idx[j] == t; j++) acc += src[order[j] * C + c];
+    float *o = dst + t * C + c;
+    *o = accumulate ? *o + acc : acc;
+}
+}  // namespace gsvc
+
+extern "C" int gsvc_segment_rows_sum(const float *src, const int64_t *order, const int64_t *sorted_idx, int64_t n, int32_t C, float *dst,
+                                     int32_t accumulate, void *stream)
+{
+    GSVC_REQUIRE(n >= 0 && C > 0 && n * (int64_t)C < ((int64_t)1 << 40), "segment_rows_sum: bad shape");
+    if (n == 0) return GSVC_OK;
+    GSVC_REQUIRE(src && order && sorted_idx && dst, "segment_rows_sum: NULL pointer");
+    const long long e = n * (long long)C;
+    gsvc::ProfScope _prof("k_segment_rows_sum", (hipStream_t)stream);
+    hipLaunchKernelGGL(gsvc::k_segment_rows_sum, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (const long long *)order, (const long long *)sorted_idx, (long long)n, (int)C, dst, (int)accumulate);
+    return gsvc::check_launch("segment_rows_sum");
+}
+
 extern "C" int gsvc_film_row_maps(const int64_t *vis, const int64_t *row_bounds_host, int32_t R, const int64_t *pos, int64_t D, int64_t A,
                               const uint8_t *view_masks, const int64_t *scan, const int64_t *distinct, int32_t *row_of, int32_t *src_a,
                               int32_t *src_b, void *stream)

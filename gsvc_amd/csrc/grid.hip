@@ -615,7 +615,8 @@ static void launch_bwd(const float *grad, const float *inputs, const int32_t *of
         const uint32_t slices_guess = D == 3 ? 4 : (D == 2 ? 16 : 1);
         uint32_t chunks = std::max(1u, want_wgs / (L * slices_guess));      // rounded down: a second round of workgroups doubles the time
         chunks = std::min(chunks, (N + 2047) / 2048);              // at least 2048 points per workgroup
-        if (chunks == 0) chunks = 1;
+        if (chunks == 0 || deterministic()) chunks = 1;           // deterministic: one workgroup per (level, slice) — every table word
+                                                                   // receives ONE float add of an exact fixed-point sum
         const uint32_t chunk = (N + chunks - 1) / chunks;
         const uint32_t slot = g_absmax_ring.fetch_add(1) % ABSMAX_RING;
         const uint32_t bpl = std::max(1u, std::min(std::min(ABSMAX_BLOCKS / L, 64u), (N + 1023) / 1024));
@@ -808,6 +809,7 @@ static void launch_bwd_many(const float *inputs, GridManyJobs &t, uint32_t level
         const uint32_t slices_guess = g.D == 3 ? 4 : 16;
         uint32_t chunks = std::max(1u, want_wgs / (g.L * slices_guess));
         chunks = std::max(1u, std::min(chunks, (N + 2047) / 2048));
+        if (deterministic()) chunks = 1;                           // (as launch_bwd)
         g.chunks = chunks;
         g.chunk = (N + chunks - 1) / chunks;
         max_chunks = std::max(max_chunks, chunks);

@@ -198,11 +198,11 @@ __global__ void __launch_bounds__(256) k_rate_sample(RateSampleArgs a, const flo
                                                      float *const ds1, float *const ds2, float *const dq0, float *const dq1,
                                                      float *const dq2, float *__restrict__ dmask, int K)
 {
-    __shared__ float sacc[3][RS_MAX_R];
-    const int lane = threadIdx.x & 63;
+    __shared__ float sacc[4][RS_MAX_R];          // one row of per-render sums per WAVE (added in wave order at the end: fixed order)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = blockIdx.y;
     if (MODE == 0) {
-        if (threadIdx.x < 3 * RS_MAX_R) (&sacc[0][0])[threadIdx.x] = 0.f;
+        if (threadIdx.x < 4 * RS_MAX_R) (&sacc[0][0])[threadIdx.x] = 0.f;
         __syncthreads();
     }
     const int C = a.C[g];
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) k_rate_sample(RateSampleArgs a, const flo
         if (MODE == 0) {
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) row_acc += __shfl_xor(row_acc, m, 64);
-            if (lane == 0) atomicAdd(&sacc[g][r], row_acc);
+            if (lane == 0) sacc[wave][r] += row_acc;          // the wave's own slot, rows in the wave's loop order
         } else if (DQ) {
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) dq_acc += __shfl_xor(dq_acc, m, 64);
@@ -257,7 +257,9 @@ __global__ void __launch_bounds__(256) k_rate_sample(RateSampleArgs a, const flo
     }
     if (MODE == 0) {
         __syncthreads();
-        if (threadIdx.x < a.R) part[((size_t)blockIdx.x * 3 + g) * RS_MAX_R + threadIdx.x] = sacc[g][threadIdx.x];
+        if (threadIdx.x < a.R)
+            part[((size_t)blockIdx.x * 3 + g) * RS_MAX_R + threadIdx.x] =
+                (sacc[0][threadIdx.x] + sacc[1][threadIdx.x]) + (sacc[2][threadIdx.x] + sacc[3][threadIdx.x]);
     }
 }
 

@@ -163,10 +163,9 @@ class HostResidentCube:
         self._images = [cube[i].image.detach().to("cpu").contiguous().pin_memory() for i in range(T)]
         self._flows = [cube.get_optical_flow(i).detach().to("cpu").contiguous().pin_memory() for i in range(T - 1)]
         self._copy = torch.cuda.Stream(device=self.device)
-        img, flow = self._images[0], self._flows[0]
-        self._slots = [{"img": [torch.empty_like(img, device=self.device) for _ in range(2)], "flow": torch.empty_like(flow, device=self.device),
-                        "idx": None, "ready": None, "free": None} for _ in range(2)]
-        self._turn = 0
+        self._seq = 0
+        self._pair = None
+        self._slots = [self._new_slot() for _ in range(2)]
         self.uploads = 0
 
     def __len__(self):
@@ -176,12 +175,25 @@ class HostResidentCube:
     def len_z_frames(self):
         return self.cube.len_z_frames
 
+    def _new_slot(self):
+        img, flow = self._images[0], self._flows[0]
+        return {"img": [torch.empty_like(img, device=self.device) for _ in range(2)], "flow": torch.empty_like(flow, device=self.device),
+                "idx": None, "ready": None, "free": None, "busy": False, "seq": 0}
+
     def prefetch(self, idx):
-        """Queue the upload of the frame pair (idx, idx + 1) and the flow between them."""
+        """Queue the upload of the frame pair (idx, idx + 1) and the flow between them.  Returns False (nothing queued) when no
+        slot may be written yet: a slot handed out since the last ``step_done()`` still has readers that are not queued (the
+        image losses' backward), so no event recorded now could order the copy behind them — the pair is then uploaded at use."""
         if any(s["idx"] == idx for s in self._slots):
-            return
-        slot = self._slots[self._turn]
-        self._turn ^= 1
+            return True
+        free = [s for s in self._slots if not s["busy"]]
+        if not free:
+            return False
+        slot = min(free, key=lambda s: s["seq"])         # the slot written longest ago
+        self._upload(slot, idx)
+        return True
+
+    def _upload(self, slot, idx):
         if slot["free"] is not None:
             self._copy.wait_event(slot["free"])          # the step that last read this slot has been queued past its readers
         with torch.cuda.stream(self._copy):
@@ -190,41 +202,69 @@ class HostResidentCube:
             slot["flow"].copy_(self._flows[idx], non_blocking=True)
             slot["ready"] = self._copy.record_event()
         slot["idx"] = idx
+        self._seq += 1
+        slot["seq"] = self._seq
         self.uploads += 1
 
-    def _slot_of(self, i):
-        for s in self._slots:
-            if s["idx"] is not None and s["idx"] <= i <= s["idx"] + 1:
-                return s
-        self.prefetch(min(i, self.len_z_frames - 2))
-        return self._slot_of(i)
+    def _slot_of(self, i, pair=None):
+        """The slot frame i is read from: the slot of the PAIR being read (``pair`` = its first frame; a step reads idx and idx + 1
+        from the one slot its prefetch filled), else the slot that starts at i, else the most recently written slot that ends at i
+        ("the first slot that covers i" could be the previous step's, which the next prefetch overwrites)."""
+        cands = [s for s in self._slots if s["idx"] is not None and s["idx"] <= i <= s["idx"] + 1]
+        if pair is not None:
+            cands = [s for s in cands if s["idx"] == pair]
+        if cands:
+            s = max(cands, key=lambda s: (s["idx"] == i, s["seq"]))
+        else:
+            idx = pair if pair is not None else min(i, self.len_z_frames - 2)
+            if not self.prefetch(idx):
+                # both slots are being read by the step in flight: a fresh slot (dropped again at step_done) instead of a wait that
+                # could not cover readers that are not queued yet
+                self._slots.append(self._new_slot())
+                self._upload(self._slots[-1], idx)
+            s = next(x for x in self._slots if x["idx"] == idx)
+        s["busy"] = True
+        return s
 
     def step_done(self):
         """The step that read the current slots has been queued in full: their next upload may start behind this point."""
         ev = torch.cuda.current_stream(self.device).record_event()
         for s in self._slots:
-            s["free"] = ev
+            if s["busy"]:
+                s["free"], s["busy"] = ev, False
+        if len(self._slots) > 2:                     # extra slots of a step that read more than two pairs: their tensors stay alive
+            keep = sorted(self._slots, key=lambda s: -s["seq"])[:2]      # (caching allocator, stream-ordered) until the readers ran
+            for s in self._slots:
+                if s not in keep:
+                    for t in (*s["img"], s["flow"]):
+                        t.record_stream(torch.cuda.current_stream(self.device))
+            self._slots = keep
+
+    def _resolve(self, i):
+        # a step asks for idx, then idx + 1: the second comes from the slot the first was served from (``_pair``)
+        pair = self._pair if (self._pair is not None and i == self._pair + 1 and any(s["idx"] == self._pair for s in self._slots)) else None
+        s = self._slot_of(i, pair)
+        self._pair = s["idx"] if s["idx"] == i else None
+        return s
 
     def __getitem__(self, i):
         """The frame with ``image`` = its device slot.  No wait is queued here — a step fetches its frames first and reads the
         pictures last (image losses, behind generation and compositing): the reader calls ``ready(i)`` just before."""
         import copy
-        s = self._slot_of(i)
+        s = self._resolve(i)
         fr = copy.copy(self.cube.get_dummy_frame(i))
         fr.image = s["img"][i - s["idx"]]
         return fr
 
     def ready(self, i):
-        """Make the current stream wait for the upload of frame i's picture (a no-op once it has landed)."""
-        torch.cuda.current_stream(self.device).wait_event(self._slot_of(i)["ready"])
+        """Make the current stream wait for the upload of frame i's picture (a no-op once it has landed); called as the frames were
+        fetched (idx, then idx + 1), it resolves to the same slots and marks them as being read until ``step_done()``."""
+        torch.cuda.current_stream(self.device).wait_event(self._resolve(i)["ready"])
 
     def get_dummy_frame(self, i):
         return self.cube.get_dummy_frame(i)
 
     def get_optical_flow(self, idx):
-        s = self._slot_of(idx)
-        if s["idx"] != idx:                      # the pair (idx, idx + 1) starts another slot
-            self.prefetch(idx)
-            s = next(x for x in self._slots if x["idx"] == idx)
+        s = self._slot_of(idx, pair=idx)             # the flow between idx and idx + 1 lives in the slot of that pair
         torch.cuda.current_stream(self.device).wait_event(s["ready"])
         return s["flow"]

@@ -107,6 +107,38 @@ def _visible_scaling(pc, vis):
     return raw if pc.decoded_version else 1.0 * pc.scaling_activation(raw)
 
 
+def det_scatter_rows(idx, src, D, out=None):
+    """dst[idx[i]] += src[i] with every target's rows added in list order (GSVC_DETERMINISTIC): a stable sort of the targets, then one
+    thread per (target, channel) walks its run (csrc/generate.hip k_segment_rows_sum) — no float atomics, the same bits every run.
+    ``out``: a [D, C] tensor to add to (each touched row receives ONE add of its run's sum); else a zero-filled one is returned."""
+    from . import _lib
+    n = int(idx.shape[0])
+    src2 = src.reshape(n, -1).contiguous() if n else src.reshape(0, max(int(src[0:1].numel()), 1) if src.dim() > 1 else 1)
+    C_ = int(src2.shape[1])
+    dst = out if out is not None else torch.zeros(D, C_, device=src.device, dtype=torch.float32)
+    if n:
+        sorted_idx, order = torch.sort(idx.contiguous(), stable=True)
+        _lib.check(_lib.lib().gsvc_segment_rows_sum(_lib.ptr(src2), _lib.ptr(order), _lib.ptr(sorted_idx), n, C_, _lib.ptr(dst),
+                                                    1 if out is not None else 0, _lib.current_stream(src.device)), "gsvc_segment_rows_sum")
+    return dst
+
+
+class IndexRows(torch.autograd.Function):
+    """t.index_select(0, idx) whose backward adds the rows of a repeated index in list order (GSVC_DETERMINISTIC; torch's own
+    backward is an index_add_ with float atomics)."""
+
+    @staticmethod
+    def forward(ctx, t, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = t.shape
+        return t.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return det_scatter_rows(idx, g, ctx.shape[0]).view(ctx.shape), None
+
+
 class _GatherFeat(torch.autograd.Function):
     """feat = _anchor_feat[vis] (csrc/generate.hip k_gather_rows with the feature group only; the scatter-add is its backward).
     ``seen`` / ``rank`` (a StepPlan's flattened view masks and their inclusive scan) select the atomic-free backward."""
@@ -135,6 +167,8 @@ class _GatherFeat(torch.autograd.Function):
                                                                    None, _lib.current_stream(vis.device)),
                        "gsvc_gather_rows_backward_ranked")
             return d, None, None, None
+        if switches.DETERMINISTIC:          # rows of no plan (a step's first / repeated attempt): a sorted scatter instead of float atomics
+            return det_scatter_rows(vis, g, A), None, None, None
         d = torch.zeros(ctx.shape, device=vis.device, dtype=torch.float32)
         _lib.check(_lib.lib().gsvc_gather_rows_backward(None, None, _lib.ptr(vis), vis.shape[0], ctx.shape[1], 0, 0, 0,
                                                         _lib.ptr(g.contiguous()), None, None, None, _lib.ptr(d), None, None, None,
@@ -184,6 +218,20 @@ class _GatherRows(torch.autograd.Function):
                                                                    _lib.ptr(g_scal), _lib.ptr(g_mask), None, _lib.ptr(d_off),
                                                                    _lib.ptr(d_scal), _lib.ptr(d_mask), _lib.current_stream(dev)),
                        "gsvc_gather_rows_backward_ranked")
+            return d_off, d_scal, d_mask, None, None, None, None
+        if switches.DETERMINISTIC:
+            A = oshape[0]
+            d_off = det_scatter_rows(vis, g_off, A).view(oshape) if shapes[0] is not None else None
+            d_scal = d_mask = None
+            if shapes[1] is not None:
+                d_scal = det_scatter_rows(vis, g_scal, A).view(scaling_p.shape)
+                if not decoded:
+                    d_scal = d_scal * torch.exp(scaling_p)
+            if shapes[2] is not None:
+                d_mask = det_scatter_rows(vis, g_mask, A).view(mask_p.shape)
+                if not decoded:
+                    sg = torch.sigmoid(mask_p)
+                    d_mask = d_mask * (sg * (1.0 - sg))
             return d_off, d_scal, d_mask, None, None, None, None
         d_off, d_scal, d_mask = _zeros_many(shapes, dev)
         _lib.check(_lib.lib().gsvc_gather_rows_backward(_lib.ptr(scaling_p), _lib.ptr(mask_p), _lib.ptr(vis), vis.shape[0], 0, K, S,
@@ -784,6 +832,18 @@ class _QRows(torch.autograd.Function):
         if dev is None:
             return (None,) * 8
         adj = adj if ctx.raw else [None, None, None]
+        if switches.DETERMINISTIC and ctx_row is not None:
+            # the rows of a distinct anchor (one per view that sees it) summed in row order, then the adjustment's derivative once
+            z = torch.zeros(ctx.rows, dtype=torch.float32, device=dev)
+            gsum = det_scatter_rows(ctx_row, torch.stack([z if g is None else g.reshape(-1) for g in gs], dim=1), ctx.D)      # [D, 3]
+            outs = []
+            for k in range(3):
+                f = ctx.q[k]
+                if ctx.raw:
+                    v = adj[k]
+                    f = torch.where((v >= -10.0) & (v <= 10.0), ctx.q[k] * torch.exp(v), torch.zeros_like(v))
+                outs.append((gsum[:, k] * f).view(ctx.shapes[k]))
+            return outs[0], outs[1], outs[2], None, None, None, None, None
         gadj = torch.empty(3, ctx.D, dtype=torch.float32, device=dev)
         _lib.check(_lib.lib().gsvc_q_rows_backward(_lib.ptr(gs[0]), _lib.ptr(gs[1]), _lib.ptr(gs[2]), _lib.ptr(ctx_row), *ctx.q, ctx.rows, ctx.D,
                                                    _lib.ptr(adj[0]), _lib.ptr(adj[1]), _lib.ptr(adj[2]), int(ctx.raw), _lib.ptr(gadj),

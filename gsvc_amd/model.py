@@ -77,7 +77,11 @@ class SampledEntropyContext:
     def rows(self, idx) -> EntropyContext:
         from . import mlp
         pc = self.pc
-        x = self.feature.index_select(0, idx)
+        if switches.DETERMINISTIC and self.feature.is_cuda and self.feature.requires_grad:
+            from .generate import IndexRows
+            x = IndexRows.apply(self.feature, idx)      # (the sample names an anchor once per view that drew it: a fixed-order backward)
+        else:
+            x = self.feature.index_select(0, idx)
         nets = (pc.mlp_feature_enet, pc.mlp_scaling_enet, pc.mlp_offset_enet)
         chains = [list(net.dist_net)[0::2] for net in nets]
         if (x.is_cuda and x.shape[0] >= self.MIN_ROWS and all(isinstance(net.dist_net, GeluSequential) for net in nets)
@@ -940,6 +944,19 @@ class GaussianModel(nn.Module):
         else:
             seen, g = torch.cat([r.visibility_filter for r in renders]), torch.cat([r.viewspace_points.grad for r in renders])
         accs = (self.opacity_accum, self.anchor_demon, self.offset_gradient_accum, self.offset_denom)
+        if switches.DETERMINISTIC and vi.is_cuda:
+            # an anchor's rows (one per render that sees it) added in row order: per-row values side by side, one sorted scatter
+            from .generate import det_scatter_rows
+            op = op_all.detach().view(-1).clamp_min(0).view(-1, K)
+            w = seen.to(torch.float32).view(-1, K)
+            gn = torch.norm(g[:, :2], dim=-1).view(-1, K) * w
+            vals = torch.cat([op.sum(dim=1, keepdim=True), torch.ones_like(op[:, :1]), gn, w], dim=1)
+            tot = det_scatter_rows(vi, vals, A)
+            self.opacity_accum.add_(tot[:, 0:1])
+            self.anchor_demon.add_(tot[:, 1:2])
+            self.offset_gradient_accum.view(A, K).add_(tot[:, 2:2 + K])
+            self.offset_denom.view(A, K).add_(tot[:, 2 + K:2 + 2 * K])
+            return
         if (vi.is_cuda and seen.dtype == torch.bool and g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1
                 and all(a.dtype == torch.float32 and a.is_contiguous() for a in accs) and not switches.NO_FUSED_STATIS):
             # one launch (csrc/rate.hip k_training_statis) for the clamp, the sums, the gradient norms and the four scatters

@@ -23,6 +23,9 @@ Code reads the module attributes (``switches.NO_MLP_CHAIN``); a process that cha
     GSVC_NO_ADAPTIVE_BOUND the step's "is the GPU or the host the bound" decisions by the row count only (not by the host's measured blocked time)
     GSVC_RASTER_LOOSE_BINNING   the renderer lists every Gaussian in all tiles of its 3-sigma rectangle (default: only where its alpha box reaches)
     GSVC_RASTER_STREAMS    side streams the step's renders are dealt to (default 2; 1 = all on the current stream)
+    GSVC_DETERMINISTIC     every float sum of a fitting step in a fixed order: sort-based row scatters instead of float atomics, one workgroup
+                           per hash-table slice, per-row launch choices by the row count only (no wall-clock measurement picks a kernel) ->
+                           the same gradient bits run after run (tools/ab/determinism_check.py); the default keeps the faster forms
     GSVC_DP_SPARSE         data parallel: 0 = dense all-reduce always, 1 = row-sparse exchange always (default: whichever moves less)
     GSVC_DP_ZOWN / GSVC_DP_ZOWN_CHECK / GSVC_DP_FORCE   read by gsvc_amd/dist.py where the process group is known: per-anchor tensors owned by
                            z-range (halo exchange), its dropped-gradient check, the data-parallel path on a one-rank group (tests)
@@ -31,7 +34,7 @@ import os
 
 _FLAGS = ("NO_MLP_CHAIN", "NO_MLP_FUSED", "NO_QUANT_CHAIN", "NO_SHARED_INPUT", "NO_ACCUM_MANY", "NO_DECODE_CHAIN", "CTX_ALL_ROWS",
           "NO_FUSED_CTX", "NO_FUSED_GRID", "NO_FUSED_STATIS", "NO_FUSED_RATE", "NO_FUSED_GATHER", "NO_FUSED_PLAN", "NO_FUSED_STE", "NO_RANKED_GATHER",
-          "NO_PACKED_GRID", "NO_GRID_MANY", "NO_FILM_SHARE", "NO_VIEW_SHARE", "NO_LATE_ROWS", "NO_RATE_OVERLAP", "NO_PREFETCH", "NO_EARLY_PLAN", "EARLY_PLAN", "RATE_EARLY", "RASTER_LOOSE_BINNING", "NO_ADAPTIVE_BOUND")
+          "NO_PACKED_GRID", "NO_GRID_MANY", "NO_FILM_SHARE", "NO_VIEW_SHARE", "NO_LATE_ROWS", "NO_RATE_OVERLAP", "NO_PREFETCH", "NO_EARLY_PLAN", "EARLY_PLAN", "RATE_EARLY", "RASTER_LOOSE_BINNING", "NO_ADAPTIVE_BOUND", "DETERMINISTIC")
 
 
 def reload():
@@ -41,6 +44,8 @@ def reload():
     g["RASTER_STREAMS"] = int(os.environ.get("GSVC_RASTER_STREAMS", "2"))
     g["MANY_MIN_ROWS"] = int(os.environ.get("GSVC_MANY_MIN_ROWS", "24576"))
     g["DP_SPARSE"] = os.environ.get("GSVC_DP_SPARSE")          # None | "0" | "1"
+    from . import _lib
+    _lib.set_deterministic(g["DETERMINISTIC"])          # the library's own fixed-order forms (hash-grid backward); applied at load if not loaded yet
 
 
 reload()

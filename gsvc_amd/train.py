@@ -207,7 +207,9 @@ class Trainer:
         b = _gen.host_blocked_s[0]
         _gen.host_blocked_s[0] = 0.0
         self._steps_seen = getattr(self, "_steps_seen", 0) + 1
-        if switches.NO_ADAPTIVE_BOUND:
+        if switches.NO_ADAPTIVE_BOUND or switches.DETERMINISTIC:
+            # (deterministic mode: a wall-clock measurement must not pick between the separate and the multi-product layer launches —
+            # they round differently — so the row count alone decides, the same way in every run)
             _gen.gpu_bound_hint = None
             return
         if self._steps_seen <= 8:

@@ -566,6 +566,17 @@ int gsvc_film_row_maps(const int64_t *vis, const int64_t *row_bounds_host, int32
  * src_a / src_b as gsvc_film_row_maps writes them.  A gather per output row: no atomics, a fixed order of the two terms. */
 int gsvc_pair_rows_sum(const float *g, const int32_t *src_a, const int32_t *src_b, int64_t rows_u, int32_t C, float *out, void *stream);
 
+/* Deterministic mode (GSVC_DETERMINISTIC=1 through gsvc_amd.switches; SURVEY section 5 "deterministic-mode switch for bwd atomics").
+ * gsvc_set_deterministic(1): the launches whose float sums depend on the order workgroups retire in take a fixed-order form —
+ * the hash-grid backward gives every (level, table slice) to ONE workgroup (its 64-bit fixed-point LDS sums are exact, the single
+ * float add per table word is the only rounding), and the host routes every scatter-add of rows through gsvc_segment_rows_sum:
+ * dst[sorted_idx[p]][c] (= or +=, `accumulate`) the sum over the run of equal targets starting at p of src[order[j]][c], j in list
+ * order (order = a STABLE argsort of the rows' targets, sorted_idx the targets in that order).  Replaces the float atomics of
+ * reference-shaped scatter-adds (utils/entropy_models.py:159-175's gradient, the index_add of guassian.py:160-176's gathers). */
+int gsvc_set_deterministic(int on);
+int gsvc_segment_rows_sum(const float *src, const int64_t *order, const int64_t *sorted_idx, int64_t n, int32_t C, float *dst,
+                          int32_t accumulate, void *stream);
+
 /* out[scan[i] - 1] = (value ? value[i] + value_bias : i) for every i with mask[i] != 0, `scan` = inclusive scan of the mask
  * (int64): the index lists of the step plan in one elementwise pass each; entries of `out` past the count are not written. */
 int gsvc_compact_by_scan(const uint8_t *mask, const int64_t *scan, const int64_t *value, int64_t value_bias, int64_t n, int64_t *out,

@@ -67,8 +67,10 @@ def _oracle_gridencoder_module():
     return m
 
 
-def _oracle_rasterizer_module():
-    """`diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer` backed by oracle/raster_oracle.c: the settings type with the
+def _oracle_rasterizer_module(flags: int = 0, low_pass: float = 0.0):
+    """(``flags`` / ``low_pass``: conventions the module keeps to ITSELF — its settings type has no such fields, like the real
+    extension's — for the calibrator's self-test: tools/calibrate_conventions.py must recover them from results alone.)
+    `diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer` backed by oracle/raster_oracle.c: the settings type with the
     fields the reference's call sites construct it from (renderer.py:63-83, preprocess.py:58-83), the rasterizer as an autograd
     node (image, radii, num_rendered; means2D receives the screen-space gradient) and visible_filter.  With this in the slot
     the UNMODIFIED reference render() / prefilter_voxel() run on PyTorch-CPU (make_golden_prod.py)."""
@@ -94,7 +96,7 @@ def _oracle_rasterizer_module():
     def _settings(rs):
         return oracle.make_settings(rs.image_height, rs.image_width, rs.x_min, rs.y_min, rs.scale, rs.threshold,
                                     rs.viewmatrix.detach().contiguous().numpy(), bg=[float(v) for v in rs.bg],
-                                    scale_modifier=rs.scale_modifier)
+                                    scale_modifier=rs.scale_modifier, flags=flags, low_pass=low_pass)
 
     class _Rasterize(torch.autograd.Function):
         @staticmethod

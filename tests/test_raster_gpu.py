@@ -605,3 +605,91 @@ def test_tight_binning_pair_forward_is_the_same_two_view_frame():
     a, b = out["loose"], out["tight"]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
     assert a[3] == a[2] == a[4] and b[3] == b[4] < 0.75 * a[3], (a[2:], b[2:])
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Calibration against the real extension (tools/calibrate_conventions.py): the only road from "parity
+# unpinned" to pinned.  The extension is absent here, so what runs is (i) the calibrator's self-test — gsvc_amd.rasterizer built
+# with each of the 64 combinations of the six convention switches, hidden behind the extension's settings type, is read back from
+# results alone — and (ii) the consumer of the fixture the calibrator writes, against a fixture recorded from the oracle holding a
+# hidden convention (the stand-in for the extension) and, when a maintainer has committed one, tests/golden/raster_calibration.npz.
+def _hidden_convention_module(flags, low_pass=0.0):
+    """gsvc_amd.rasterizer behind the REFERENCE's settings fields only (renderer.py:63-83): the conventions are the module's secret."""
+    import types
+    from gsvc_amd import rasterizer as R
+
+    def settings(**kw):
+        assert "flags" not in kw and "low_pass" not in kw
+        return R.GaussianRasterizationSettings(**kw, flags=flags, low_pass=low_pass)
+    return types.SimpleNamespace(GaussianRasterizationSettings=settings, GaussianRasterizer=R.GaussianRasterizer)
+
+
+def test_calibrator_recovers_every_flag_combination():
+    from tools import calibrate_conventions as cal
+    for flags in range(64):
+        res = cal.calibrate(_hidden_convention_module(flags), device="cuda", log=lambda *_: None)
+        assert res["flags"] == flags and res["low_pass"] == 0.0, (flags, res)
+    for flags, lp in ((0, 0.55), (2 | 8, 0.1), (1 | 4 | 16, 1.5)):
+        res = cal.calibrate(_hidden_convention_module(flags, lp), device="cuda", log=lambda *_: None)
+        assert res["flags"] == flags and abs(res["low_pass"] - lp) <= 2e-3, (flags, lp, res)
+
+
+def _check_against_calibration(z):
+    """The HIP rasterizer, set to the calibrated conventions, on the fixture's inputs: radii / num_rendered bit for bit, pixels
+    1e-4 abs, the six gradients 1e-4 of their scale (north_star's bar)."""
+    from gsvc_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    H, W, x_min, y_min, scale, thr, z_cam = [float(v) for v in z["settings"]]
+    rs = GaussianRasterizationSettings(
+        image_height=int(H), image_width=int(W), x_min=x_min, y_min=y_min, scale=scale, threshold=thr,
+        bg=torch.tensor(z["bg"]), scale_modifier=1.0, viewmatrix=torch.tensor(z["viewmatrix"]), sh_degree=0,
+        campos=torch.tensor([0.0, 0.0, z_cam]), prefiltered=False, debug=False, flags=int(z["flags"]), low_pass=float(z["low_pass"]))
+    r = GaussianRasterizer(raster_settings=rs)
+    d = {k: torch.tensor(z["in_" + k], device="cuda", requires_grad=True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    means2D = torch.zeros_like(d["means3D"], requires_grad=True)
+    image, radii, num_rendered = r(means3D=d["means3D"], means2D=means2D, shs=None, colors_precomp=d["colors"], opacities=d["opacities"],
+                                   scales=d["scales"], rotations=d["rotations"], cov3D_precomp=None)
+    assert num_rendered == int(z["num_rendered"])
+    assert np.array_equal(radii.cpu().numpy(), z["radii"])
+    with torch.no_grad():
+        assert np.array_equal(r.visible_filter(means3D=d["means3D"], scales=d["scales"], rotations=d["rotations"]).cpu().numpy(),
+                              z["radii_visible_filter"])
+    err = np.abs(image.detach().cpu().numpy() - z["image"])
+    # threshold decisions within rounding of a boundary (alpha vs 1/255, T vs 1e-4) may fall either way on a handful of pixels
+    assert (err > PIX_TOL).mean() < 5e-4 and np.median(err) < 1e-6, (float(err.max()), float((err > PIX_TOL).mean()))
+    (image * torch.tensor(z["dL"], device="cuda")).sum().backward()
+    # gradients: 1e-4 of each tensor's scale; a pixel whose threshold decision fell the other way moves the few Gaussians under it
+    # by more, so the bar is on all but a vanishing share of the elements (the pixel bar's own share)
+    worst, share = {}, {}
+    for k, t in (("means2D", means2D), *d.items()):
+        ref = z["grad_" + k]
+        e = np.abs(t.grad.cpu().numpy() - ref) / max(np.abs(ref).max(), 1e-12)
+        worst[k], share[k] = float(e.max()), float((e > 1e-4).mean())
+    return worst, share
+
+
+def test_calibration_fixture_consumer_on_an_oracle_recorded_fixture(oracle_lib):
+    """The whole road on a stand-in: the oracle with a hidden convention plays the extension; calibrate -> record -> the HIP
+    rasterizer reproduces the recorded results under the calibrated flags."""
+    from tests.golden._ref_import import _oracle_rasterizer_module
+    from tools import calibrate_conventions as cal
+    for hidden, lp in ((0, 0.0), (2 | 4 | 8, 0.0), (1 | 16, 0.45)):
+        ext = _oracle_rasterizer_module(flags=hidden, low_pass=lp)
+        res = cal.calibrate(ext, device="cpu", log=lambda *_: None)
+        assert res["flags"] == hidden and abs(res["low_pass"] - lp) <= 2e-3
+        fx = cal.record_fixture(ext, device="cpu")
+        z = dict(fx, flags=np.int64(res["flags"]), low_pass=np.float64(lp))          # (the measured low-pass is good to 2e-3: exact here)
+        worst, share = _check_against_calibration(z)
+        assert all(v < 5e-4 for v in share.values()), (hidden, worst, share)
+
+
+def test_calibration_fixture_parity():
+    """tests/golden/raster_calibration.npz, written by `python tools/calibrate_conventions.py --module
+    diff_gaussian_rasterization.cuda_ortho_gaussian_rasterizer` on a box that has GSVC's real extension: from then on the HIP
+    rasterizer is held to the EXTENSION's image, radii, num_rendered and gradients.  Absent (the extension is an un-pinned external
+    package, reference README.md:52, and is not in this image): skipped, and parity stays 'unpinned' (DESIGN section 2)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raster_calibration.npz")
+    if not os.path.exists(path):
+        pytest.skip("no tests/golden/raster_calibration.npz: run tools/calibrate_conventions.py where the real extension is installed")
+    z = dict(np.load(path))
+    worst, share = _check_against_calibration(z)
+    assert all(v < 5e-4 for v in share.values()), (worst, share)

@@ -1074,6 +1074,59 @@ def test_host_resident_video_steps_equal_device_resident_steps():
 
 
 @pytest.mark.gpu
+def test_host_resident_video_with_adjacent_pairs_and_no_sync(monkeypatch):
+    """consecutive steps on ADJACENT pairs (a, a+1), (a+1, a+2), ... — frame a+1 then sits in two slots —
+    with the next step's pair prefetched from INSIDE the backward (GSVC_EARLY_PLAN=1) and no host synchronisation between steps.  A
+    step must read both its frames from the slot of ITS pair, and the prefetch must never write a slot handed out since the last
+    step_done(): the losses equal the device-resident run's, and the cube's own book-keeping never saw a busy slot overwritten."""
+    from gsvc_amd import switches
+    from gsvc_amd.frame import HostResidentCube
+    monkeypatch.setenv("GSVC_EARLY_PLAN", "1")
+    switches.reload()
+
+    class Walk:                      # the trainer's frame draw: a walk over adjacent pairs, forwards then backwards
+        def __init__(self):
+            self.seq = [2, 3, 4, 5, 4, 3, 2, 3, 3, 4, 6, 5]
+            self.k = 0
+
+        def randint(self, lo, hi):
+            v = self.seq[self.k % len(self.seq)]
+            self.k += 1
+            return v
+    try:
+        losses, written_busy = [], 0
+        for host in (False, True):
+            pc, cube, opt, pipe, mp, Trainer = _setup(anchors=4000, H=96, W=160, T=12, seed=3)
+            opt.full_precision_training_total, opt.quantized_training_total = 4, 2
+            opt.entropy_constrained_train_total = 100
+            pc.training_setup(opt)
+            cube.materialize()
+            ds = HostResidentCube(cube, "cuda") if host else cube
+            if host:
+                real_upload = ds._upload
+
+                def checked(slot, idx, _real=real_upload):
+                    nonlocal written_busy
+                    written_busy += bool(slot["busy"])
+                    return _real(slot, idx)
+                ds._upload = checked
+            tr = Trainer(pc, ds, opt, pipe, mp, seed=5)
+            tr.rng = Walk()
+            outs = [tr.step(it).loss.detach() for it in range(1, 13)]          # no float(): nothing waits for the GPU between steps
+            losses.append([float(x) for x in outs])
+            if host:
+                assert getattr(tr, "early_steps", 0) > 0, "the early tail (prefetch from inside the backward) never ran"
+                assert len(ds._slots) == 2
+            tr.close()
+        assert written_busy == 0
+        # (a wrong or half-written ground-truth picture moves the loss in its second digit; summation order moves the seventh)
+        assert np.allclose(losses[0], losses[1], rtol=2e-6, atol=0), losses
+    finally:
+        monkeypatch.delenv("GSVC_EARLY_PLAN")
+        switches.reload()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exchange", ["replicated", "zown"])
 def test_four_rank_dry_run_at_the_configs3_shape(exchange):
     """BASELINE.json configs[3] rehearsed on one GPU: four data-parallel ranks (gloo, device 0: the pool's process guard allows 6

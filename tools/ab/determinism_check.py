@@ -52,17 +52,22 @@ def capture(*a, **k):
 
 pc.optimizer.step = capture
 PHASES = {"FULL": (B, 0, 0, 0), "QUANT": (0, B, 0, 0), "ENTROPY": (0, 0, B, 0), "STE": (0, 0, 0, B)}
-VARIANTS = [("default", {}), ("one raster stream", {"GSVC_RASTER_STREAMS": "1"}), ("no small-work stream", {"GSVC_NO_RATE_OVERLAP": "1"}),
+VARIANTS = [("default", {}), ("GSVC_DETERMINISTIC=1", {"GSVC_DETERMINISTIC": "1"}),
+            ("default, planned step", {"_PLAN": "1"}), ("GSVC_DETERMINISTIC=1, planned step", {"GSVC_DETERMINISTIC": "1", "_PLAN": "1"}), ("one raster stream", {"GSVC_RASTER_STREAMS": "1"}), ("no small-work stream", {"GSVC_NO_RATE_OVERLAP": "1"}),
             ("no early plan", {"GSVC_NO_EARLY_PLAN": "1"}), ("no prefetch", {"GSVC_NO_PREFETCH": "1"}),
             ("one stream, no overlap, no prefetch", {"GSVC_RASTER_STREAMS": "1", "GSVC_NO_RATE_OVERLAP": "1", "GSVC_NO_PREFETCH": "1"}),
             ("layer-by-layer MLPs", {"GSVC_NO_MLP_CHAIN": "1"}), ("no multi-product launches", {"GSVC_NO_SHARED_INPUT": "1", "GSVC_NO_ACCUM_MANY": "1"})]
 only = os.environ.get("DET_PHASES")
+if os.environ.get("DET_VARIANTS"):          # e.g. DET_VARIANTS=default,GSVC_DETERMINISTIC=1
+    VARIANTS = [v for v in VARIANTS if any(v[0].startswith(w) for w in os.environ["DET_VARIANTS"].split(","))]
 for phase, totals in PHASES.items():
     if only and phase not in only.split(","):
         continue
     (opt.full_precision_training_total, opt.quantized_training_total, opt.entropy_constrained_train_total,
      opt.ste_entropy_constrained_train_total) = totals
     for tag, env in VARIANTS:
+        env = dict(env)
+        planned = bool(env.pop("_PLAN", None))
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         switches.reload()
@@ -74,6 +79,11 @@ for phase, totals in PHASES.items():
                 tr.rng.seed(7)
                 torch.manual_seed(1234)
                 tr.controller.current_iteration = 100
+                if planned:          # the production form: the step runs from a plan built ahead (ranked gathers, the plan's rate sample)
+                    from gsvc_amd.ortho_gaussian_renderer import plan_views
+                    with torch.no_grad():
+                        tr._plan_idx, tr._plan_mode = 20, tr.controller.render_mode
+                        tr._plan = plan_views(tr._views(20), pc, pipe, tr.background, tr._plan_mode)
                 tr.step(100, frame_idx=20)
                 torch.cuda.synchronize()
                 if rep:
@@ -94,3 +104,23 @@ for phase, totals in PHASES.items():
                 else:
                     os.environ[k] = v
             switches.reload()
+
+# what the fixed order costs: the entropy-constrained step, default against GSVC_DETERMINISTIC=1, same process
+import time
+pc.optimizer.step = real_step
+(opt.full_precision_training_total, opt.quantized_training_total, opt.entropy_constrained_train_total,
+ opt.ste_entropy_constrained_train_total) = PHASES["ENTROPY"]
+tr._plan = tr._plan_idx = None
+for tag, val in (("default", None), ("GSVC_DETERMINISTIC=1", "1"), ("default", None), ("GSVC_DETERMINISTIC=1", "1")):
+    os.environ.pop("GSVC_DETERMINISTIC", None) if val is None else os.environ.__setitem__("GSVC_DETERMINISTIC", val)
+    switches.reload()
+    for it in range(200, 206):
+        tr.step(it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(206, 236):
+        tr.step(it)
+    torch.cuda.synchronize()
+    print(f"COST {tag:24s} {1e3 * (time.perf_counter() - t0) / 30:.3f} ms per step (TRAINING_ENTROPY, {A} anchors)", flush=True)
+os.environ.pop("GSVC_DETERMINISTIC", None)
+switches.reload()
