@@ -72,6 +72,10 @@ def parse(argv=None):
                     help="train_step: BASELINE.json configs[3]'s per-GPU workload, reference cfgs/cfg_20240919.yaml AS IS: 100 000 "
                          "anchors (init_anchor_num), a 600-frame 1080p video, threshold = .05 (a +-48-frame z-slab, reference "
                          "arguments/__init__.py:54), lambda = .004; overrides --anchors / --train-frames")
+    ap.add_argument("--live-fit", action="store_true",
+                    help="train_step: fit the untimed steps in the default (fast, float-atomic) mode — the model the timed steps start "
+                         "from then differs run to run (the fit is chaotic: +-10 %% active Gaussians); default: the FROZEN scene, "
+                         "fitted under GSVC_DETERMINISTIC=1 (the same bits every run: config.scene.checksum)")
     ap.add_argument("--pretrain", type=int, default=200,
                     help="train_step: untimed fitting steps before the warmup (BASELINE.md section 2: 200, so that opacities "
                          "and scales are no longer at their initial values; they also let the caching allocator see every "
@@ -451,7 +455,33 @@ def run_train_step(args, rank, world, dev):
         last[0] = trainer.step(it[0])
         return last[0]
 
-    for _ in range(args.pretrain + args.warmup):
+    # The headline scene, FROZEN: the untimed fit runs in deterministic mode — every float sum in a fixed
+    # order, launch choices by row count only (gsvc_amd.switches GSVC_DETERMINISTIC) — so the model the timed steps start from is
+    # the same bits in every run of this command (its checksum goes into the line), and `value` stops moving +-10 % with the
+    # run's draw of active Gaussians.  The warm-up and the timed steps then run in the default (fast) mode.
+    from gsvc_amd import switches as _sw
+    frozen = not args.live_fit and not _dp_on(world)
+    if frozen:
+        os.environ["GSVC_DETERMINISTIC"] = "1"
+        _sw.reload()
+    try:
+        for _ in range(args.pretrain):
+            step()
+    finally:
+        if frozen:
+            os.environ.pop("GSVC_DETERMINISTIC", None)
+            _sw.reload()
+    scene_sum = 0
+    with torch.no_grad():          # exact, order-free: the parameters' bit patterns added up as integers
+        for _n, p_ in sorted(pc.named_parameters()):
+            if p_.dtype == torch.float32 and p_.numel():
+                scene_sum = (scene_sum + int(p_.detach().contiguous().view(torch.int32).to(torch.int64).sum())) % (1 << 61)
+    scene = {"frozen": bool(frozen), "fit_steps": args.pretrain, "seeds": {"torch": 0, "numpy": 0, "anchors": 0, "trainer": 0, "video": 1234},
+             "checksum": f"{scene_sum:016x}",
+             "note": ("the untimed fit ran under GSVC_DETERMINISTIC=1: this checksum (integer sum of every parameter's bits after the fit) is "
+                      "the same in every run of the command on this library build" if frozen else
+                      "live fit in the default mode: float atomics order the fit's sums differently run by run, the model differs")}
+    for _ in range(args.warmup):
         step()
     active = torch.zeros((), device=dev, dtype=torch.float64)
     submitted = [0]
@@ -655,7 +685,8 @@ def run_train_step(args, rank, world, dev):
                                f"{H}x{W}, {T}-frame synthetic video, {pc._anchor.shape[0]} "
                                f"anchors x K=10, {slab_frames:.0f}-frame z-slab (threshold {mp_.threshold:.5f}); 4 renders/step fwd+bwd + hash grid + entropy loss "
                                f"(lambda={opt.lmbda}, TRAINING_ENTROPY) + L1/SSIM/optical + Adam; one frame pair per rank; "
-                               f"{args.pretrain} untimed fitting steps before the warmup",
+                               f"{args.pretrain} untimed fitting steps before the warmup ({'frozen scene: deterministic fit, seeds 0 / video 1234, checksum ' + scene['checksum'] if scene['frozen'] else 'live fit'})",
+                   "scene": scene,
                    "gaussians_per_render": P, "active_per_render": n_vis, "active_fraction": n_vis / max(P, 1.0),
                    "instances_per_render": n_inst, "num_rendered_per_render": n_inst_api, "tiles_per_active_gaussian": n_inst / max(n_vis, 1.0),
                    "instances_note": "instances_per_render = entries of the tile lists (a Gaussian is listed in the tiles its alpha >= 1/255 box "

@@ -85,12 +85,17 @@ def _check(pc, g, fn, tag, res, draws, via_chain):
         radii = res.radii.cpu().numpy()
         want_r = g[pre + "radii"].astype(np.int32)
         off = radii != want_r                  # ceil(3 sqrt(lambda)) of a Gaussian whose covariance differs in the last bits
-        assert off.mean() <= 1e-3 and (np.abs(radii - want_r)[off] <= 1).all(), (int(off.sum()), P)
-        # the integers are bit-exact for identical inputs (tests/test_raster_gpu.py); here the Gaussians come from CPU / GPU MLPs
-        print(f"[{tag}] radii differing by one: {int(off.sum())} of {P} rows; num_rendered {int(res.num_rendered)} vs {instances}; "
+        rows_off = np.nonzero(off)[0]
+        # at most TWO named rows of ~18 600 (round 5 allowed 1e-3 of them = 18), each by one: the integers are bit-exact for identical
+        # inputs (test_reference_generated_gaussians_rasterize_with_zero_integer_drift below feeds the reference's own Gaussians to the
+        # HIP rasterizer: zero rows); here the Gaussians come from MLPs evaluated on the CPU (fixture) and the GPU (product)
+        assert rows_off.size <= 2 and (np.abs(radii - want_r)[off] <= 1).all(), \
+            f"[{tag}] radii differ in rows {rows_off[:10].tolist()}: got {radii[rows_off[:10]].tolist()}, fixture {want_r[rows_off[:10]].tolist()}"
+        print(f"[{tag}] radii differing by one: rows {rows_off.tolist()} of {P}; num_rendered {int(res.num_rendered)} vs {instances}; "
               f"active {int(res.active_gaussains)} vs {active}")
         assert abs(int(res.active_gaussains) - active) <= max(2, int(1e-3 * active))
-        assert abs(int(res.num_rendered) - instances) <= max(4, int(1e-3 * instances)), (int(res.num_rendered), instances)
+        # a radius off by one moves its Gaussian's tile rectangle by at most one row and one column of tiles
+        assert abs(int(res.num_rendered) - instances) <= 8 * rows_off.size, (int(res.num_rendered), instances, rows_off.tolist())
         assert torch.equal(res.visibility_filter, res.radii > 0)
     img = res.rendered_image.detach().cpu().numpy()
     ok = ~_bits(g[pre + "borderline"], H * W).reshape(H, W)
@@ -387,3 +392,44 @@ def test_model_creation_matches_the_reference(tag):
     assert got.shape == want.shape and np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), float(np.abs(got - want).max())
     names = ("_anchor", "_offset", "_mask", "_anchor_feat", "_scaling", "_rotation", "_opacity")
     assert [bool(getattr(pc, nm).requires_grad) for nm in names] == [bool(v) for v in g[pre + "requires_grad"]]
+
+
+def test_reference_generated_gaussians_rasterize_with_zero_integer_drift():
+    """tests/golden/prod_gaussians.npz holds EVERY row the reference's render() handed to its rasterizer slot
+    (renderer.py:85-98: xyz, colour, opacity, scaling, rotation of the 18 606 Gaussians its own generate_neural_gaussians made on
+    PyTorch-CPU; make_golden_prod_gaussians.py) and what came back.  Fed to the HIP rasterizer through the drop-in API, with identical
+    inputs: radii, num_rendered, the per-tile ranges and the sorted point list are the fixture's BIT FOR BIT, forward view and
+    opposite view — the +-1 radius on 1e-3 of the rows the render() fixture allows comes from the CPU- and GPU-evaluated MLPs
+    upstream, not from the rasterizer.  Pixels 1e-4."""
+    from gsvc_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prod_gaussians.npz"))
+    H, W, x_min, y_min, scale, thr, z_cam = [float(v) for v in g["meta::frame"]]
+    H, W = int(H), int(W)
+    d = {nm: torch.tensor(g["in::" + nm], device="cuda") for nm in ("xyz", "color", "opacity", "scaling", "rot")}
+    assert d["xyz"].shape[0] > 18000
+    for view in ("f", "b"):
+        pre = view + "::"
+        rs = GaussianRasterizationSettings(image_height=H, image_width=W, x_min=x_min, y_min=y_min, scale=scale, threshold=thr,
+                                           bg=torch.zeros(3), scale_modifier=1.0, viewmatrix=torch.tensor(g[pre + "viewmatrix"]),
+                                           sh_degree=0, campos=torch.tensor([0.0, 0.0, z_cam]), prefiltered=False, debug=False)
+        r = GaussianRasterizer(raster_settings=rs)
+        with torch.no_grad():
+            image, radii, num_rendered = r(means3D=d["xyz"], means2D=torch.zeros_like(d["xyz"]), shs=None, colors_precomp=d["color"],
+                                           opacities=d["opacity"], scales=d["scaling"], rotations=d["rot"], cov3D_precomp=None)
+        want_r = g[pre + "radii"].astype(np.int32)
+        got_r = radii.cpu().numpy()
+        rows = np.nonzero(got_r != want_r)[0]
+        assert rows.size == 0, f"[{view}] radii differ in rows {rows[:10].tolist()} (got {got_r[rows[:10]].tolist()}, want {want_r[rows[:10]].tolist()})"
+        assert num_rendered == int(g[pre + "num_rendered"]), (view, num_rendered, int(g[pre + "num_rendered"]))
+        off, pl = r.last_state.tile_lists()
+        off, pl = off.cpu().numpy(), pl.cpu().numpy()
+        ranges = g[pre + "tile_ranges"]
+        lens = ranges[:, 1] - ranges[:, 0]
+        assert np.array_equal(np.diff(off), lens), f"[{view}] tile list lengths differ in tiles {np.nonzero(np.diff(off) != lens)[0][:10].tolist()}"
+        assert np.array_equal(off[:-1][lens > 0], ranges[:, 0][lens > 0])
+        bad = np.nonzero(pl != g[pre + "point_list"])[0]
+        assert bad.size == 0, f"[{view}] sorted point list differs from entry {int(bad[0])} on ({bad.size} entries)"
+        ok = ~np.unpackbits(g[pre + "borderline"])[:H * W].astype(bool).reshape(H, W)
+        err = np.abs(image.cpu().numpy() - g[pre + "image"])[:, ok]
+        assert err.max() < 1e-4, (view, float(err.max()))
+        print(f"[{view}] {got_r.size} reference-generated Gaussians: 0 radii / 0 list entries / num_rendered {num_rendered} differ; max pixel error {err.max():.2e}")
