@@ -186,6 +186,7 @@ __device__ __forceinline__ void scan_tiles_body(int T, const int32_t *__restrict
         // GSVC_RASTER_TIGHT_BINNING: the lists are shorter than the API's count (the 3-sigma rectangles' tiles, summed by K1)
         counters->num_rendered = api_count_in_reserved2 ? __hip_atomic_load(&counters->reserved[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : carry;
         counters->overflow = ((long long)carry > max_instances) ? 1 : 0;
+        counters->reserved[2] = carry;      // the LISTS' length (= num_rendered for the 3-sigma lists): what max_instances must hold
         counters->max_tile_len = mx;
         counters->num_big_tiles = s_big;
     }

@@ -84,13 +84,14 @@ class RasterState:
     def __init__(self, cs, P, max_instances, geom, binning, image_state, radii):
         self.cs, self.P, self.max_instances = cs, P, max_instances
         self.geom, self.binning, self.image_state, self.radii = geom, binning, image_state, radii
-        self._counters = None
+        self._counters = self._listed = None
         self._host = self._event = None     # early asynchronous read-back of the counters (raster_forward, sync=False)
 
     def counters(self):
         """(num_rendered, overflow, num_visible, max_tile_len) — one 16-byte D2H copy (synchronises), cached."""
         if self._counters is None:
-            self._counters = tuple(int(v) for v in self.binning[:16].view(torch.int32).tolist())
+            c = self.binning[:32].view(torch.int32).tolist()
+            self._counters, self._listed = tuple(int(v) for v in c[:4]), int(c[7])
         return self._counters
 
     def tile_lists(self):
@@ -111,11 +112,9 @@ class RasterState:
     def listed_instances(self) -> int:
         """(tile, Gaussian) instances the tile lists hold = tile_offsets[T]: what the sort, the compositing kernels and the backward's
         rows work on.  Equal to num_rendered for the 3-sigma lists, fewer under GSVC_RASTER_TIGHT_BINNING (one 4-byte copy: synchronises)."""
-        a, b = C.c_uint64(), C.c_uint64()
-        _lib.check(_lib.lib().gsvc_raster_binning_layout(C.byref(self.cs), self.P, self.max_instances, C.byref(a), C.byref(b)),
-                   "gsvc_raster_binning_layout")
-        T = ((self.cs.image_height + 15) // 16) * ((self.cs.image_width + 15) // 16)
-        return int(self.binning[a.value + 4 * T:a.value + 4 * T + 4].view(torch.int32)[0])
+        if self._listed is None:          # (the counters' read-back carries it: gsvc_raster_counters.reserved[2])
+            self.counters()
+        return self._listed
 
     def image_aux(self):
         a, b = C.c_uint64(), C.c_uint64()
@@ -169,8 +168,8 @@ def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales,
             # the counters are final once the forward kernels have run: their 16 bytes start travelling to the host
             # now, behind the forward only, so that resolve_deferred() later waits for THIS copy and not for
             # everything queued after it (the whole backward of a fitting step)
-            state._host = torch.empty(4, dtype=torch.int32, pin_memory=True)
-            src = binning[:16].view(torch.int32)
+            state._host = torch.empty(8, dtype=torch.int32, pin_memory=True)
+            src = binning[:32].view(torch.int32)
             with torch.cuda.stream(side_stream) if side_stream is not None else contextlib.nullcontext():
                 state._host.copy_(src, non_blocking=True)
                 state._event = torch.cuda.Event()
@@ -178,6 +177,7 @@ def raster_forward(cs: _lib.RasterSettingsC, means3D, colors, opacities, scales,
         if not sync:
             return image, radii, state
         n, overflow, _, _ = state.counters()
+        n = state._listed or n          # the LISTS' length decides the capacity (shorter than num_rendered under tight binning: ADVICE r05)
         if not overflow:
             _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(n * 1.25) + 1024)
             return image, radii, state
@@ -196,12 +196,12 @@ def resolve_deferred(states):
             _blocked_wait(st._event)
         host = [st._host.tolist() for st in states]
     else:
-        host = torch.stack([st.binning[:16].view(torch.int32) for st in states]).tolist()
+        host = torch.stack([st.binning[:32].view(torch.int32) for st in states]).tolist()
     over = False
     for st, c in zip(states, host):
-        st._counters = tuple(int(v) for v in c)
+        st._counters, st._listed = tuple(int(v) for v in c[:4]), int(c[7])
         key = (st.cs.image_height, st.cs.image_width)
-        _capacity_hint[key] = max(_capacity_hint.get(key, 0), int(c[0] * 1.25) + 1024)
+        _capacity_hint[key] = max(_capacity_hint.get(key, 0), int((c[7] or c[0]) * 1.25) + 1024)
         over = over or bool(c[1])
     return [c[0] for c in host], over
 

@@ -121,11 +121,13 @@ typedef struct gsvc_raster_sizes {
 typedef struct gsvc_raster_counters {
     int32_t num_rendered; /* sum of the 3-sigma rectangles' tiles (true count even when it overflowed) = the lists' length, except under
                              GSVC_RASTER_TIGHT_BINNING, where the lists are shorter: their length is tile_offsets[T] (gsvc_raster_binning_layout) */
-    int32_t overflow;     /* 1 when num_rendered > max_instances: image/state are NOT valid, retry bigger */
+    int32_t overflow;     /* 1 when the lists' length (reserved[2]; = num_rendered except under GSVC_RASTER_TIGHT_BINNING) > max_instances:
+                             image/state are NOT valid, retry with max_instances >= reserved[2] */
     int32_t num_visible;  /* Gaussians with radius > 0 */
     int32_t max_tile_len; /* longest per-tile list */
     int32_t num_big_tiles; /* tiles whose list is sorted by the workgroup kernel (internal) */
-    int32_t reserved[3];
+    int32_t reserved[3];  /* [0], [1]: internal cursors; [2]: after the forward, the tile lists' length = tile_offsets[T] (true length even
+                             when it overflowed): point_list / inst_bbox / the backward's scratch rows are sized by THIS, not by num_rendered */
 } gsvc_raster_counters;
 
 int gsvc_raster_sizes_query(const gsvc_raster_settings *settings, int64_t P, int64_t max_instances,
