@@ -501,6 +501,7 @@ def run_train_step(args, rank, world, dev):
                     "alloc_retries": int(mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0)),
                     "repeated_steps": int(getattr(trainer, "repeated_steps", 0) - rep0),
                     "reserved_GiB": round(mem1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2)}
+    elapsed_local = elapsed                    # this rank's own clock over the timed steps (the line's time is the MAX over the ranks)
     total_units, elapsed = reduce_sum_max(torch, dist, world, dev, active.item(), elapsed)
     if os.environ.get("GSVC_BENCH_AB"):        # diagnostic: alternate a switch on this trainer, same process (stderr)
         from gsvc_amd import switches
@@ -564,8 +565,43 @@ def run_train_step(args, rank, world, dev):
             step()
         e2 = timed(torch, dist, world, step, args.steps)
         trainer.reducer.enabled = True
+        e2_local = e2
         _, e2 = reduce_sum_max(torch, dist, world, dev, 0.0, e2)
         gdist.broadcast_parameters(pc)
+        # every rank's own numbers (the first multi-GPU run should say per rank what the exchange cost and moved)
+        mine = {"rank": rank, "ms_per_step": 1e3 * elapsed_local / args.steps, "exposed_ms_per_step": 1e3 * (elapsed_local - e2_local) / args.steps,
+                "gradient_bytes_per_step": int(sent_bytes)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        # ... and the OTHER per-anchor exchange in the same invocation: z-range ownership (halo rows to their owners, updated rows back;
+        # gsvc_amd.dist.ZRangeOwnership) when the run used the replicated exchange, and the other way round — same model, same frames
+        other = None
+        try:
+            if zown is None:
+                trainer._zown = gdist.ZRangeOwnership(cube.len_z_frames, cube.scale, mp_.threshold)
+            else:
+                trainer.sync_replicas()
+                trainer._zown = None
+            for _ in range(3):
+                step()
+            e3_local = timed(torch, dist, world, step, args.steps)
+            _, e3 = reduce_sum_max(torch, dist, world, dev, 0.0, e3_local)
+            zo = trainer._zown
+            b3 = int(trainer.reducer.bytes_sent + (zo.bytes_sent if zo is not None else 0))
+            mine3 = {"rank": rank, "ms_per_step": 1e3 * e3_local / args.steps, "exposed_ms_per_step": 1e3 * (e3_local - e2_local) / args.steps,
+                     "gradient_bytes_per_step": b3}
+            per_rank3 = [None] * world
+            dist.all_gather_object(per_rank3, mine3)
+            other = {"per_anchor_exchange": "z-range ownership (halo exchange)" if zo is not None else "replicated (rows of the distinct visible anchors / dense all-reduce)",
+                     "ms_per_step": 1e3 * e3 / args.steps, "exposed_ms_per_step": 1e3 * (e3 - e2) / args.steps, "per_rank": per_rank3}
+        except Exception as e:  # noqa: BLE001          (the line above must not depend on the second measurement)
+            other = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            if trainer._zown is not None and zown is None:
+                trainer.sync_replicas()            # every replica whole again before the model is read as a whole below
+            trainer._zown = zown
+            pc._zown = None
+            gdist.broadcast_parameters(pc)
         comm = {"ms_per_step_without_exchange": 1e3 * e2 / args.steps,
                 "exposed_ms_per_step": 1e3 * (elapsed - e2) / args.steps,
                 # what this rank handed to the collectives in the last exchanged step: per-anchor gradients as rows of its distinct
@@ -575,7 +611,7 @@ def run_train_step(args, rank, world, dev):
                 "per_anchor_exchange": ("z-range ownership: halo rows of gradients to their owners, updated rows back (all_to_all between neighbours)"
                                         if zown is not None else
                                         "rows of the distinct visible anchors (all-gather + scatter-add)" if sparse_used else "dense all-reduce"),
-                "early_plan_steps": early_steps}
+                "early_plan_steps": early_steps, "per_rank": per_rank, "other_exchange_same_run": other}
 
     # per-kernel pass: same K steps with HIP events around every launch on the launch stream
     _lib.profile_enable(True)
@@ -728,7 +764,9 @@ def run_train_step(args, rank, world, dev):
     if getattr(trainer, "_blocked_ema", None) is not None:
         from gsvc_amd import generate as _gen
         res["host_blocked_ms_per_step"] = 1e3 * trainer._blocked_ema
-        res["gpu_bound_measured"] = bool(_gen.gpu_bound_hint) if _gen.gpu_bound_hint is not None else None
+        hint = trainer._ctx.gpu_bound_hint
+        res["gpu_bound_measured"] = bool(hint) if hint is not None else None
+        res["gpu_bound_flips"] = [{"step": s_, "gpu_bound": g_, "blocked_ms_ema": round(m_, 3)} for s_, g_, m_ in getattr(trainer, "bound_log", [])]
     if comm is not None:
         res["gradient_exchange"] = comm
     if world == 1:

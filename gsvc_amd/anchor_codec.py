@@ -183,9 +183,21 @@ def _demorton(key: np.ndarray, bits: int) -> np.ndarray:
     return np.stack([_compact(key >> np.uint64(2)), _compact(key >> np.uint64(1)), _compact(key)], axis=1).astype(np.int64)
 
 
+def _sort_keys(keys: np.ndarray) -> np.ndarray:
+    """np.sort of uint64 keys below 2^63, on the GPU when there is one and the array is large (4 M keys: 0.35 s on the host)."""
+    if keys.shape[0] >= (1 << 16):
+        try:
+            import torch
+            if torch.cuda.is_available() and int(keys.max()) < (1 << 63):
+                return torch.sort(torch.from_numpy(keys.astype(np.int64)).cuda()).values.cpu().numpy().astype(np.uint64)
+        except Exception:  # noqa: BLE001
+            pass
+    return np.sort(keys)
+
+
 def _encode_octree(pts: np.ndarray, bits: int) -> bytes:
     """pts: distinct non-negative integer points < 2^bits per axis."""
-    keys = np.sort(_morton(pts, bits))
+    keys = _sort_keys(_morton(pts, bits))
     parts = []
     for level in range(bits):
         shift = np.uint64(3 * (bits - 1 - level))
@@ -238,6 +250,31 @@ def _lex(p: np.ndarray) -> np.ndarray:
     return p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
 
 
+def _unique_rows(p: np.ndarray):
+    """(distinct rows sorted by (x, y, z), their multiplicities) of non-negative integer rows below 2^20 per column — np.unique(p,
+    axis=0, return_counts=True) through ONE packed 64-bit key per row: a plain 1-D sort instead of a lexicographic one over a
+    structured view (4.1 M anchors: 1.4 s of the 4K model's 3.1 s stream encode, round 6), on the GPU when there is one."""
+    if p.shape[0] == 0:
+        return p.reshape(0, 3), np.zeros(0, np.int64)
+    if p.min() < 0 or p.max() >= (1 << 20):
+        return np.unique(p, axis=0, return_counts=True)
+    q = p.astype(np.uint64)
+    key = ((q[:, 0] << np.uint64(40)) | (q[:, 1] << np.uint64(20)) | q[:, 2]).astype(np.int64)      # < 2^60: order-preserving as int64
+    u = c = None
+    if key.shape[0] >= (1 << 16):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                tu, tc = torch.unique(torch.from_numpy(key).cuda(), return_counts=True)              # sorted ascending
+                u, c = tu.cpu().numpy(), tc.cpu().numpy()
+        except Exception:  # noqa: BLE001  (no torch / no device: the host sort below)
+            u = c = None
+    if u is None:
+        u, c = np.unique(key, return_counts=True)
+    m = np.int64((1 << 20) - 1)
+    return np.stack([u >> np.int64(40), (u >> np.int64(20)) & m, u & m], axis=1).astype(np.int64), c.astype(np.int64)
+
+
 def _grid_of(lattice_idx: np.ndarray, voxel_size: float, interval: np.ndarray, a_min: np.ndarray) -> np.ndarray:
     """Quantize_anchor's grid value of the lattice point (float32 arithmetic, as gsvc_amd.encodings.Quantize_anchor._grid)."""
     a = (lattice_idx.astype(np.float64) * float(voxel_size)).astype(np.float32)
@@ -265,7 +302,7 @@ def encode_anchors(anchors_q: np.ndarray, positions: np.ndarray | None = None, v
         if good.mean() >= 0.9 and int(span.max()) <= (1 << 15):
             lattice = (idx, good)
     if lattice is None:
-        uniq, counts = np.unique(q, axis=0, return_counts=True) if n else (q, np.zeros(0, np.int64))
+        uniq, counts = _unique_rows(q) if n else (q, np.zeros(0, np.int64))
         bits = 16
         body = _encode_octree(uniq, bits) if n else b""
         dup = np.flatnonzero(counts > 1)
@@ -276,7 +313,7 @@ def encode_anchors(anchors_q: np.ndarray, positions: np.ndarray | None = None, v
     origin = idx[good].min(axis=0)
     rel = idx[good] - origin
     bits = max(1, int(rel.max()).bit_length())
-    uniq, counts = np.unique(rel, axis=0, return_counts=True)
+    uniq, counts = _unique_rows(rel)
     # anchors that share a lattice point share its grid value: their multiplicity is all there is to keep
     dup = np.flatnonzero(counts > 1)
     exc = _lex(q[~good])                                       # anchors kept by their grid value

@@ -104,7 +104,10 @@ def _parse(stream: bytes):
         raise _lib.GsvcError("ans_decode: truncated stream (header)")
     magic, crc, n, seg_len, smin, smax, n_seg = _HEADER.unpack_from(stream, 0)
     if magic != MAGIC:
-        raise _lib.GsvcError(f"ans_decode: not a {MAGIC.decode()} stream")
+        # GSA1-GSA3 are earlier layouts of THIS project's development rounds (the frequency floor changed with GSA4: another CDF, so an
+        # old stream cannot be decoded by this table, and nothing outside the repository ever held one): refused by name, not misread
+        raise _lib.GsvcError(f"ans_decode: not a {MAGIC.decode()} stream" + (f" (found {magic.decode(errors='replace')}: streams written before the "
+                             "GSA4 frequency floor must be re-encoded from their model, see INTEGRATION.md section 3)" if magic[:3] == b"GSA" else ""))
     if crc != int(_lib.lib().gsvc_ans_table_checksum()):
         raise _lib.GsvcError("ans_decode: the stream was coded with a different Phi table than this build's (checksum mismatch)")
     off = _HEADER.size

@@ -451,7 +451,7 @@ class ZRangeOwnership:
         self.cuts = [z_of(shards[q][0] - 0.5) for q in range(1, self.W)]      # owner(z) = number of cuts <= z
         self._key = None
         self.bytes_sent = 0          # payload this rank handed to the two exchanges in the last step
-        self.means = None
+        self.means = self.mask_sigmoid_mean = None
 
     def ensure(self, pc):
         a = pc._anchor
@@ -585,8 +585,13 @@ class ZRangeOwnership:
             own = self.own_idx
             parts = [pc._anchor_feat.detach().index_select(0, own), pc.get_scaling.detach().index_select(0, own),
                      pc._offset.detach().index_select(0, own)]
-            s = torch.stack([t.sum(dtype=torch.float32) for t in parts])
+            # (the fourth partial: sigmoid(_mask) of the owned rows — the VALUE of the mask regulariser 5e-4 * mean(sigmoid(_mask)) over
+            # ALL anchors, which a replica would otherwise take over its partly stale rows: the reported loss is then exact)
+            s = torch.stack([t.sum(dtype=torch.float32) for t in parts] +
+                            [torch.sigmoid(pc._mask.detach().index_select(0, own)).sum(dtype=torch.float32)])
             dist.all_reduce(s, op=dist.ReduceOp.SUM)
-            n = torch.tensor([float(pc._anchor_feat.numel()), float(pc.get_scaling.numel()), float(pc._offset.numel())], device=s.device)
-            self.means = s / n
+            n = torch.tensor([float(pc._anchor_feat.numel()), float(pc.get_scaling.numel()), float(pc._offset.numel()),
+                              float(pc._mask.numel())], device=s.device)
+            m = s / n
+            self.means, self.mask_sigmoid_mean = m[:3], m[3]
         return self.means

@@ -1011,22 +1011,33 @@ SMALL_WORK_MIN_ROWS = 150_000      # visible anchor rows of a step from which th
 # late in a fit a 100 k-anchor model (80 k rows) spends 7 ms per step on the GPU — its Gaussians cover 57 tiles each — while the host
 # needs 5.  The host only ever blocks at the step's two waits (the plan's counts, the renders' counters): what it blocks there per step
 # is the GPU's lead over it.  None = no measurement yet (the row count decides); set by gsvc_amd.train.Trainer.
-gpu_bound_hint = None
-host_blocked_s = [0.0]             # seconds the host spent blocked in those waits since the Trainer last read it
+class StepContext:
+    """The measurement belongs to the Trainer that made it (as module globals two Trainers of one process clobbered
+    each other's): ``gpu_bound_hint`` (None = no measurement yet: the row count decides) and the seconds the host spent blocked in the
+    step's waits since its Trainer last read them.  A Trainer makes its own context current for the duration of each of its steps
+    (``step_context``); callers without a Trainer (render loops, tests) see the neutral default."""
+    __slots__ = ("gpu_bound_hint", "host_blocked_s", "flips")
+
+    def __init__(self):
+        self.gpu_bound_hint, self.host_blocked_s, self.flips = None, 0.0, 0
+
+
+_DEFAULT_CONTEXT = StepContext()
+step_context = _DEFAULT_CONTEXT
 
 
 def gpu_bound(rows) -> bool:
     """Should this step spend host time (events, stream switches, separate launches) to save GPU time?"""
     # (the measurement only ever ADDS steps to the GPU-bound side: a caller that synchronises every step — float(loss) — never lets the
     # host block in the step's own waits, and must not lose what the row count alone already grants)
-    return rows >= SMALL_WORK_MIN_ROWS or bool(gpu_bound_hint)
+    return rows >= SMALL_WORK_MIN_ROWS or bool(step_context.gpu_bound_hint)
 
 
 def _blocked_wait(event):
     import time
     t0 = time.perf_counter()
     event.synchronize()
-    host_blocked_s[0] += time.perf_counter() - t0
+    step_context.host_blocked_s += time.perf_counter() - t0
 
 
 def small_work_stream(dev):
@@ -1044,14 +1055,21 @@ class two_stream_backward:
     stream's nodes use gets its gradient from two streams — intended (the engine orders them), so the engine's warning about it
     is switched off for the duration of THIS backward only (it was switched off process-wide at first use)."""
 
+    _depth = 0          # nested scopes (a backward inside a backward's hook): only the outermost one switches the warning back on
+
     def __enter__(self):
         self._set = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
         if self._set is not None:
+            two_stream_backward._depth += 1
             self._set(False)
 
     def __exit__(self, *exc):
         if self._set is not None:
-            self._set(True)
+            two_stream_backward._depth -= 1
+            # torch offers a setter only (no getter to save the caller's choice): a caller who has switched the warning off for the
+            # whole process says so once with GSVC_KEEP_STREAM_WARNING_OFF=1 and this scope then leaves it off
+            if two_stream_backward._depth == 0 and not os.environ.get("GSVC_KEEP_STREAM_WARNING_OFF"):
+                self._set(True)
 
 
 def record_on(stream, *objs):

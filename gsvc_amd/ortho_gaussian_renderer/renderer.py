@@ -150,9 +150,28 @@ def render_pair(frame, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, m
     if mode not in (GenerateMode.DECODING_AS_IS, GenerateMode.TRAINING_FULL_PRECISION, GenerateMode.TRAININ_STE_ENTROPY):
         raise ValueError("render_pair needs a deterministic GenerateMode")
     with torch.no_grad():
+        cs = settings_to_c(raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier))
+        pairable = int(frame.image_width) % 16 == 0 and not (cs.flags & 3)
+        if pairable and pc._anchor.is_cuda and not os.environ.get("GSVC_PAIR_PER_LAYER"):
+            # The batched generation pass on ONE frame (round 6): the whole-network chain kernels (8 launches) instead of the 26 layer
+            # launches + ~60 tensor operations of the per-frame path — a per-frame loop as the reference writes it (utils/report_utils.py:
+            # 297-319) was HOST-bound at 1.5 ms per frame against 0.5 ms of kernels —, no "opacity > 0" compaction (the rasterizer culls
+            # those itself): the per-Gaussian fields of the result cover all K slots of every visible anchor, selection_mask marks the
+            # live ones.  Same image (tests/test_train_gpu.py::test_render_frames_equals_render_pair).
+            geometry = prefilter_geometry(pc)
+            visible_mask = prefilter_voxels_many([frame], pc, pipe, bg_color, scaling_modifier, geometry=geometry)[0]
+            vis = visible_mask.nonzero(as_tuple=False).squeeze(1)          # (the one read-back of the frame besides the instance counters)
+            if vis.shape[0] > 0:
+                gss = generate_neural_gaussians_many([frame], pc, [vis], mode, dense=True, anchors=geometry[0])[0]
+                gss.visable_mask = visible_mask
+                image, radii, state = raster_forward(cs, gss.xyz.contiguous(), gss.color.contiguous(), gss.opacity.contiguous(),
+                                                     gss.scaling.contiguous(), gss.rot.contiguous(), pair=True)
+                return RenderResults(
+                    rendered_image=image, viewspace_points=None, visibility_filter=radii > 0, visible_mask=visible_mask, radii=radii,
+                    active_gaussains=(radii > 0).sum(), num_rendered=state.counters()[0], selection_mask=gss.mask,
+                    neural_opacity=gss.neural_opacity, scaling=gss.scaling, generated_gaussians=gss, time_sub=gss.time_sub)
         visible_mask = prefilter_voxel(frame, pc, pipe, bg_color)
         gss = generate_neural_gaussians(frame, pc, visible_mask, mode)
-        cs = settings_to_c(raster_settings_for(frame, pc, pipe, bg_color, scaling_modifier))
         args = (gss.xyz.contiguous(), gss.color.contiguous(), gss.opacity.contiguous(), gss.scaling.contiguous(), gss.rot.contiguous())
         if int(frame.image_width) % 16 == 0 and not (cs.flags & 3):   # (one-sided slab / pixel-corner: the views do not mirror)
             image, radii, state = raster_forward(cs, *args, pair=True)

@@ -170,11 +170,10 @@ class Trainer:
         gaussians._zown = self._zown      # gsvc_amd.generate._param_means reads the owners' means from it
         self._mask_reg_weight = 0.0
         self._ovf_handle = None
-        # which side bounds the steps, measured (gsvc_amd.generate.gpu_bound_hint): the host's blocked time per step, smoothed
+        # which side bounds the steps, measured (gsvc_amd.generate.StepContext.gpu_bound_hint): the host's blocked time per step, smoothed
         self._blocked_ema = None
         from . import generate as _gen
-        _gen.gpu_bound_hint = None
-        _gen.host_blocked_s[0] = 0.0
+        self._ctx = _gen.StepContext()      # this trainer's own measurement (made current for the duration of each of its steps)
 
     def close(self):
         """Give the calling thread its CPU affinity back (``__init__`` narrowed it to the GPU's NUMA node: gsvc_amd/hostbind.py;
@@ -183,7 +182,8 @@ class Trainer:
             from .hostbind import unbind
             unbind(self.pc._anchor.device)
         from . import generate as _gen
-        _gen.gpu_bound_hint = None      # a measurement of THIS trainer's steps
+        if _gen.step_context is self._ctx:
+            _gen.step_context = _gen._DEFAULT_CONTEXT
 
     def __enter__(self):
         return self
@@ -204,23 +204,30 @@ class Trainer:
         layer launches) pays; under ~0.1 ms the host does and it does not.  In between the last decision stands (the measures
         themselves move the balance).  The first steps (allocator growth, first launches) are not counted."""
         from . import generate as _gen
-        b = _gen.host_blocked_s[0]
-        _gen.host_blocked_s[0] = 0.0
+        ctx = self._ctx
+        _gen.step_context = ctx          # whatever this step's generation / waits read and add to is this trainer's
+        b = ctx.host_blocked_s
+        ctx.host_blocked_s = 0.0
         self._steps_seen = getattr(self, "_steps_seen", 0) + 1
         if switches.NO_ADAPTIVE_BOUND or switches.DETERMINISTIC:
             # (deterministic mode: a wall-clock measurement must not pick between the separate and the multi-product layer launches —
             # they round differently — so the row count alone decides, the same way in every run)
-            _gen.gpu_bound_hint = None
+            ctx.gpu_bound_hint = None
             return
         if self._steps_seen <= 8:
             return
         self._blocked_ema = b if self._blocked_ema is None else 0.8 * self._blocked_ema + 0.2 * b
         if self._steps_seen < 16:
             return
+        before = ctx.gpu_bound_hint
         if self._blocked_ema > 4e-4:
-            _gen.gpu_bound_hint = True
+            ctx.gpu_bound_hint = True
         elif self._blocked_ema < 1e-4:
-            _gen.gpu_bound_hint = False
+            ctx.gpu_bound_hint = False
+        if ctx.gpu_bound_hint != before:
+            # a wall-clock measurement changes which launches the step takes from here on: on record, so that runs can be compared
+            ctx.flips += 1
+            self.bound_log = getattr(self, "bound_log", [])[-31:] + [(self._steps_seen, bool(ctx.gpu_bound_hint), 1e3 * self._blocked_ema)]
 
     def step(self, iteration: int, frame_idx: int | None = None) -> StepOutput:
         self._update_bound()
@@ -345,7 +352,7 @@ class Trainer:
     @staticmethod
     def _gpu_bound(rows):
         from . import generate as _gen
-        return rows >= EARLY_PLAN_MIN_ROWS or bool(_gen.gpu_bound_hint)
+        return rows >= EARLY_PLAN_MIN_ROWS or bool(_gen.step_context.gpu_bound_hint)
 
     def _views(self, frame_idx):
         """The step's four views: (frame, frame seen from the opposite side) of the two adjacent frames."""
@@ -457,7 +464,8 @@ class Trainer:
                 rate_sum = getattr(batch, "bit_per_param_sum", None)
                 # the renders' rates enter with one weight: their sum, when the batched generation already formed it, is one term
                 terms += ([rate_sum] if rate_sum is not None else [r.bit_per_param for r in renders]) + \
-                         [hash_grid_bits(pc), torch.mean(torch.sigmoid(pc._mask.detach() if sparse_dp else pc._mask))]
+                         [hash_grid_bits(pc), (zown.mask_sigmoid_mean if (zown is not None and zown.mask_sigmoid_mean is not None) else
+                                               torch.mean(torch.sigmoid(pc._mask.detach() if sparse_dp else pc._mask)))]
                 weights += [opt.lmbda] * (1 if rate_sum is not None else 4) + [opt.lmbda / denom, 5e-4]
         if side is not None:
             # what the terms above read of the step's stream's allocations (and saved for their backward on the small-work stream)

@@ -356,6 +356,8 @@ def _zown_worker(rank, world, port, q):
         mean_ref = torch.stack([ref._anchor_feat.mean(), ref.get_scaling.mean(), ref._offset.mean()]).detach()
         m = zo.update_means(own)
         assert torch.allclose(m, mean_ref, rtol=1e-5, atol=1e-7), (m, mean_ref)
+        # the mask regulariser's VALUE over all anchors from the owners' partial sums (a replica's own mean would read stale rows)
+        assert torch.allclose(zo.mask_sigmoid_mean, torch.sigmoid(ref._mask.detach()).mean(), rtol=1e-5, atol=1e-7)
         ms = [torch.zeros_like(m) for _ in range(world)]
         dist.all_gather(ms, m)
         assert all(torch.equal(ms[0], x) for x in ms)                # the same bits on every rank

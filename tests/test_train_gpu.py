@@ -772,6 +772,12 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["dist_backend"] == "gloo"
     assert res["steps"] == 3 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["gradient_exchange"]["gradient_bytes_per_step"] > 0 and "exposed_ms_per_step" in res["gradient_exchange"]
+    # every rank's own numbers, and the other per-anchor exchange (z-range ownership) measured in the same invocation (round 6)
+    ge = res["gradient_exchange"]
+    assert [r["rank"] for r in ge["per_rank"]] == [0, 1] and all(r["gradient_bytes_per_step"] > 0 and r["ms_per_step"] > 0 for r in ge["per_rank"])
+    other = ge["other_exchange_same_run"]
+    assert "error" not in other and "z-range" in other["per_anchor_exchange"], other
+    assert [r["rank"] for r in other["per_rank"]] == [0, 1] and all(r["gradient_bytes_per_step"] > 0 for r in other["per_rank"])
     if torch.cuda.device_count() < 2:
         out = _run_bench({}, "--gpus", "2", *small)
         assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -794,6 +800,8 @@ def test_bench_runs_its_data_parallel_path_on_a_one_rank_rccl_group():
         assert res["n_gpus"] == 1 and res["rccl_ranks"] == 1 and res["dist_backend"] == "nccl", (res["rccl_ranks"], res["dist_backend"])
         ge = res["gradient_exchange"]
         assert ge["gradient_bytes_per_step"] > 0 and word in ge["per_anchor_exchange"], ge
+        other = ge["other_exchange_same_run"]          # the run's own exchange, then the other one, in one invocation
+        assert "error" not in other and ("z-range" in other["per_anchor_exchange"]) == (word != "z-range"), other
 
 
 def _run_dp_grad_worker(env_extra, ranks=2):
