@@ -113,8 +113,8 @@ def det_scatter_rows(idx, src, D, out=None):
     ``out``: a [D, C] tensor to add to (each touched row receives ONE add of its run's sum); else a zero-filled one is returned."""
     from . import _lib
     n = int(idx.shape[0])
-    src2 = src.reshape(n, -1).contiguous() if n else src.reshape(0, max(int(src[0:1].numel()), 1) if src.dim() > 1 else 1)
-    C_ = int(src2.shape[1])
+    C_ = max(int(torch.Size(src.shape[1:]).numel()), 1)          # (an empty list still has a row width)
+    src2 = src.reshape(n, C_).contiguous()
     dst = out if out is not None else torch.zeros(D, C_, device=src.device, dtype=torch.float32)
     if n:
         sorted_idx, order = torch.sort(idx.contiguous(), stable=True)

@@ -1196,3 +1196,62 @@ def test_views_without_a_visible_anchor():
         assert not torch.allclose(imgs[1], imgs[0])
     # (the LOSS of a step with an empty view is NaN in the reference too — its regularisers and rates are means over empty
     # selections, pipeline/train.py:415-436, guassian.py:110-132 — and is not defined here either: GSVC's anchors cover every frame)
+
+
+@pytest.mark.gpu
+def test_deterministic_mode_gives_the_same_fit_bit_for_bit(monkeypatch):
+    """GSVC_DETERMINISTIC=1 (SURVEY section 5 "deterministic-mode switch for bwd atomics"): every float sum
+    of a fitting step in a fixed order — sorted row scatters (csrc/generate.hip k_segment_rows_sum) instead of float atomics, one
+    workgroup per hash-table slice, no wall-clock measurement picking a launch form.  Two fits of 24 steps through all four phases
+    (densification statistics on) from the same seeds end in the SAME parameters and accumulators, bit for bit; the default mode's
+    fit stays within rounding of it early on (the same arithmetic up to summation order)."""
+    from gsvc_amd import switches
+
+    def fit(det):
+        if det:
+            monkeypatch.setenv("GSVC_DETERMINISTIC", "1")
+        else:
+            monkeypatch.delenv("GSVC_DETERMINISTIC", raising=False)
+        switches.reload()
+        try:
+            pc, cube, opt, pipe, mp, Trainer = _setup(anchors=5000, H=96, W=160, T=12, seed=11)
+            opt.full_precision_training_total, opt.quantized_training_total = 6, 6
+            opt.entropy_constrained_train_total, opt.ste_entropy_constrained_train_total = 6, 6
+            opt.start_stat, opt.update_until, opt.pause_densification = 0, 10 ** 9, 0
+            pc.training_setup(opt)
+            tr = Trainer(pc, cube, opt, pipe, mp, seed=3)
+            losses = [tr.step(it).loss.detach() for it in range(1, 25)]
+            torch.cuda.synchronize()
+            state = {n: p.detach().clone() for n, p in pc.named_parameters()}
+            state.update({n: getattr(pc, n).clone() for n in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom")})
+            tr.close()
+            return [float(x) for x in losses], state
+        finally:
+            monkeypatch.delenv("GSVC_DETERMINISTIC", raising=False)
+            switches.reload()
+    l1, s1 = fit(True)
+    l2, s2 = fit(True)
+    assert l1 == l2
+    differing = [n for n in s1 if not torch.equal(s1[n], s2[n])]
+    assert not differing, differing
+    l0, _ = fit(False)
+    assert np.allclose(l0[:8], l1[:8], rtol=2e-5, atol=0), (l0[:8], l1[:8])
+
+
+@pytest.mark.gpu
+def test_sorted_row_scatter_equals_index_add():
+    """gsvc_segment_rows_sum (the deterministic mode's scatter-add of rows): the values of index_add_ to rounding, the same bits on
+    every call, rows without a target untouched (accumulate) or zero (fresh), an empty list a no-op."""
+    from gsvc_amd.generate import det_scatter_rows
+    g = torch.Generator(device="cuda").manual_seed(2)
+    idx = torch.randint(0, 700, (20000,), device="cuda", generator=g)
+    src = torch.randn(20000, 13, device="cuda", generator=g)
+    a = det_scatter_rows(idx, src, 1000)
+    ref = torch.zeros(1000, 13, device="cuda", dtype=torch.float64).index_add_(0, idx, src.double())
+    assert float((a.double() - ref).abs().max()) < 1e-4 and float(a[700:].abs().max()) == 0.0
+    assert all(torch.equal(a, det_scatter_rows(idx, src, 1000)) for _ in range(3))
+    base = torch.randn(1000, 13, device="cuda", generator=g)
+    b = det_scatter_rows(idx, src, 1000, out=base.clone())
+    assert torch.equal(b[700:], base[700:]) and float((b.double() - (base.double() + ref)).abs().max()) < 1e-4
+    e = det_scatter_rows(idx[:0], src[:0], 10)
+    assert e.shape == (10, 13) and float(e.abs().max()) == 0.0

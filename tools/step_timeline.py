@@ -20,9 +20,11 @@ def short(n):
     return re.sub(r'void ', '', n)[:36]
 
 
-# a step ends with the full Adam launch: the k_adam launch followed by a gap to the next k_adam of more than 2 ms of other work
+# a step ends with its FULL Adam launch (every parameter: the longest k_adam launches; the guarded early updates of _scaling / _mask
+# from inside the backward are several times shorter).  Round 6: the old rule (a gap of 1.5 ms to the next k_adam) cut steps in two.
 adam = [i for i, e in enumerate(ev) if 'k_adam' in e[2]]
-ends = [i for j, i in enumerate(adam) if j + 1 == len(adam) or ev[adam[j + 1]][0] - ev[i][1] > 1_500_000]
+longest = max(ev[i][1] - ev[i][0] for i in adam)
+ends = [i for i in adam if ev[i][1] - ev[i][0] > 0.5 * longest]
 a, b = ends[-back - 1], ends[-back]
 seg = ev[a + 1:b + 1]
 t0 = seg[0][0]
@@ -48,9 +50,11 @@ tot = defaultdict(lambda: [0, 0])
 for s, e, n, q in seg:
     tot[short(n)][0] += e - s
     tot[short(n)][1] += 1
-print("family                         launches   sum_us  alone_us")
-for k, (d, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:45]:
-    print(f"{k:30s} {c:8d} {d / 1e3:8.1f} {alone[k] / 1e3:9.1f}")
+print("family                         launches   sum_us  alone_us  overlapped_us")
+for k, (d, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:60]:
+    print(f"{k:30s} {c:8d} {d / 1e3:8.1f} {alone[k] / 1e3:9.1f} {(d - alone[k]) / 1e3:10.1f}")
+print(f"alone_us summed over the families = the part of the step's {union / 1e6:.3f} busy ms during which ONE family had the chip: "
+      f"{sum(alone.values()) / 1e6:.3f} ms; the rest ({(union - sum(alone.values())) / 1e6:.3f} ms) is shared by two or more families")
 if '--list' in sys.argv:
     for s, e, n, q in seg:
         print(f"{(s - t0) / 1e6:8.3f} ms {(e - s) / 1e3:8.1f} us  q{queues.index(q)}  {short(n)}")
