@@ -195,9 +195,36 @@ def _sort_keys(keys: np.ndarray) -> np.ndarray:
     return np.sort(keys)
 
 
+def _occupancy_levels_gpu(keys: np.ndarray, bits: int):
+    """The occupancy bytes of every octree level from the sorted Morton keys, on the GPU when there is one and the set is large (the
+    host loop below takes 0.3 s at 4 M points: one flatnonzero + reduceat per level): a node's occupancy = the OR (= the sum, over the
+    level's DISTINCT cells) of 1 << child over its run of keys.  Returns a list of int64 arrays, or None (no device: the host loop)."""
+    if keys.shape[0] < (1 << 16) or (keys.shape[0] and int(keys.max()) >= (1 << 63)):
+        return None
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return None
+        k = torch.from_numpy(keys.astype(np.int64)).cuda()
+        out = []
+        for level in range(bits):
+            shift = 3 * (bits - 1 - level)
+            cell = torch.unique_consecutive(k >> shift)            # the distinct (node, child) cells of this level, in key order
+            child, node = cell & 7, cell >> 3
+            _, inv = torch.unique_consecutive(node, return_inverse=True)
+            occ = torch.zeros(int(inv[-1]) + 1, dtype=torch.int64, device=k.device).scatter_add_(0, inv, torch.ones_like(child) << child)
+            out.append(occ)
+        return [o.cpu().numpy() for o in out]
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def _encode_octree(pts: np.ndarray, bits: int) -> bytes:
     """pts: distinct non-negative integer points < 2^bits per axis."""
     keys = _sort_keys(_morton(pts, bits))
+    occ_levels = _occupancy_levels_gpu(keys, bits)
+    if occ_levels is not None:
+        return b"".join(_pack_level(occ) for occ in occ_levels)
     parts = []
     for level in range(bits):
         shift = np.uint64(3 * (bits - 1 - level))
@@ -282,6 +309,24 @@ def _grid_of(lattice_idx: np.ndarray, voxel_size: float, interval: np.ndarray, a
     return np.clip(q, 0, 65535).astype(np.int64)
 
 
+def _lattice_test_gpu(positions: np.ndarray, q: np.ndarray, voxel_size: float, interval: np.ndarray, a_min: np.ndarray):
+    """(lattice index of every anchor, "its grid value is its lattice point's") with the elementwise passes on the GPU — the same
+    IEEE operations as the host lines it replaces (round half to even in float64, _grid_of's float32 arithmetic): 0.25 s of the
+    4 M-anchor encode.  None without a device."""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return None
+        dev = torch.device("cuda")
+        idx = torch.round(torch.from_numpy(positions).to(dev) / voxel_size).to(torch.int64)
+        a = (idx.to(torch.float64) * voxel_size).to(torch.float32)
+        g = torch.floor((a - torch.from_numpy(a_min).to(dev)) / torch.from_numpy(interval).to(dev)).clamp_(0, 65535).to(torch.int64)
+        good = (g == torch.from_numpy(q).to(dev)).all(dim=1)
+        return idx.cpu().numpy(), good.cpu().numpy()
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def encode_anchors(anchors_q: np.ndarray, positions: np.ndarray | None = None, voxel_size: float | None = None,
                    interval: np.ndarray | None = None, a_min: np.ndarray | None = None) -> bytes:
     """Lossless code of the quantised anchors ``anchors_q`` (uint16-valued [n, 3]; any order, duplicates allowed).  With
@@ -295,8 +340,12 @@ def encode_anchors(anchors_q: np.ndarray, positions: np.ndarray | None = None, v
     lattice = None
     if n and positions is not None and voxel_size and interval is not None and a_min is not None:
         interval, a_min = np.asarray(interval, np.float32).reshape(3), np.asarray(a_min, np.float32).reshape(3)
-        idx = np.round(np.asarray(positions, np.float64).reshape(-1, 3) / float(voxel_size)).astype(np.int64)
-        good = (_grid_of(idx, voxel_size, interval, a_min) == q).all(axis=1)
+        on_dev = _lattice_test_gpu(np.asarray(positions, np.float64).reshape(-1, 3), q, float(voxel_size), interval, a_min) if n >= (1 << 16) else None
+        if on_dev is not None:
+            idx, good = on_dev
+        else:
+            idx = np.round(np.asarray(positions, np.float64).reshape(-1, 3) / float(voxel_size)).astype(np.int64)
+            good = (_grid_of(idx, voxel_size, interval, a_min) == q).all(axis=1)
         # worth it when almost every anchor is its lattice point's grid value and the lattice is coarser than the grid
         span = idx[good].max(axis=0) - idx[good].min(axis=0) + 1 if good.any() else np.array([1 << 20] * 3)
         if good.mean() >= 0.9 and int(span.max()) <= (1 << 15):

@@ -122,6 +122,33 @@ def main():
           f"{int(live_box.sum())} ({100.0 * int(live_box.sum()) / n:.1f} %): an exact binning would drop {n - n_live} instances "
           f"({100.0 * (n - n_live) / n:.1f} %)", flush=True)
 
+    # ---- formulation (i), its statistics: pixels an entry can reach (alpha >= 1/255: geometry only, no occlusion) against the lanes
+    # replayed for it at 8 x 8 granularity (today: the quadrants the ellipse test keeps) and at 4 x 4 granularity (ideal culling: the
+    # blocks that hold at least one reaching pixel) ------------------------------------------------------------------------------
+    keep_i = live.nonzero().squeeze(1)
+    px = torch.arange(16, device=dev, dtype=torch.float32)
+    reach_px = quads8 = blocks4 = 0
+    for c0 in range(0, int(keep_i.shape[0]), 1 << 17):
+        k_ = keep_i[c0:c0 + (1 << 17)]
+        dx = (tx0[k_].view(-1, 1, 1) + px.view(1, 1, 16)) - u[k_].view(-1, 1, 1)          # [n, 1, 16]
+        dy = (ty0[k_].view(-1, 1, 1) + px.view(1, 16, 1)) - v[k_].view(-1, 1, 1)          # [n, 16, 1]
+        power = -0.5 * (A[k_].view(-1, 1, 1) * dx * dx + Cc[k_].view(-1, 1, 1) * dy * dy) - B[k_].view(-1, 1, 1) * dx * dy
+        ok = (power <= 0) & (o[k_].view(-1, 1, 1) * torch.exp(power) >= 1.0 / 255.0)         # [n, 16, 16]
+        reach_px += int(ok.sum())
+        quads8 += int(ok.view(-1, 2, 8, 2, 8).any(dim=4).any(dim=2).sum())
+        blocks4 += int(ok.view(-1, 4, 4, 4, 4).any(dim=4).any(dim=2).sum())
+    f8, f4 = reach_px / max(64.0 * quads8, 1), reach_px / max(16.0 * blocks4, 1)
+    # instructions per reaching pixel-entry: replay 33 per group of 64 lanes; reduction 74 cross-lane per 4 entries today (one per entry),
+    # 36 DPP adds per 4 (entry, block) pairs at 16-lane granularity (one per pair)
+    today = 33.0 / (64.0 * f8) + (74.0 / 4.0) / (reach_px / max(n_live, 1))
+    blocks = 33.0 / (64.0 * f4) + 36.0 / (64.0 * f4)
+    print(f"reach statistics (geometry only): {reach_px / max(n_live, 1):.1f} reaching pixels per live instance; 8 x 8 quadrants with a reaching pixel "
+          f"{quads8 / max(n_live, 1):.2f} per instance, lane share {f8:.3f}; 4 x 4 blocks {blocks4 / max(n_live, 1):.2f} per instance, lane share {f4:.3f}", flush=True)
+    print(f"vector instructions per reaching pixel-entry: today {today:.3f} (replay {33.0 / (64.0 * f8):.3f} + reduction "
+          f"{(74.0 / 4.0) / (reach_px / max(n_live, 1)):.3f}); per-block queues {blocks:.3f} (replay {33.0 / (64.0 * f4):.3f} + 16-lane reduction "
+          f"{36.0 / (64.0 * f4):.3f}, before the per-entry sum across blocks): formulation (i) {'loses' if blocks >= today else 'wins'} by "
+          f"{100.0 * (blocks / today - 1.0):+.0f} %", flush=True)
+
     # ---- the backward on the production lists ------------------------------------------------------------------------------
     g = torch.Generator(device=dev).manual_seed(5)
     dL = torch.randn(3, H, W, device=dev, generator=g)
