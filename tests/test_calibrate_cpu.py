@@ -2,6 +2,8 @@
 API: tests/golden/_ref_import._oracle_rasterizer_module) holding a flag combination the calibrator cannot see — the settings type has
 the reference's fields only (ortho_gaussian_renderer/renderer.py:63-83) — and must read off results.  All 64 combinations of the six
 convention switches of include/gsvc_hip.h, non-default low-pass values, and the fixture it records."""
+import os
+
 import numpy as np
 import pytest
 
@@ -50,3 +52,20 @@ def test_recorded_fixture_holds_results_only(oracle_lib, tmp_path):
     z = np.load(p)
     assert all(z[k].dtype.kind in "fiuU" for k in z.files)          # floats, integers, one name string: data, not code
     assert p.stat().st_size < 2_000_000
+
+
+def test_the_one_command_writes_the_fixture(oracle_lib, tmp_path):
+    """`python tools/calibrate_conventions.py --module <dotted name>` as a maintainer runs it (here: the oracle-backed stand-in module,
+    holding flags 4 | 8, on the CPU): prints the readings, returns the flags, writes the .npz with the module's results."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "raster_calibration.npz"
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "calibrate_conventions.py"), "--module", "tests._oracle_extension_module",
+                          "--device", "cpu", "--out", str(out)], cwd=root, env=dict(os.environ, ORACLE_EXT_FLAGS="12"), capture_output=True,
+                         text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert "flags = 12 (GSVC_RASTER_DEPTH_DESCENDING | GSVC_RASTER_MEANS2D_PIXEL_UNITS)" in run.stdout and "set pipe.raster_flags = 12" in run.stdout
+    z = np.load(out)
+    assert int(z["flags"]) == 12 and float(z["low_pass"]) == 0.0 and str(z["module"]) == "tests._oracle_extension_module"
+    assert z["image"].shape == (3, 256, 256) and int(z["num_rendered"]) > 3000
