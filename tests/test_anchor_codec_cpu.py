@@ -125,3 +125,37 @@ def test_hostile_multiplicity_sections_are_refused_before_they_index_anything(de
     if decoder == "host":
         want = q[np.lexsort((q[:, 2], q[:, 1], q[:, 0]))]
         assert np.array_equal(ac.decode_anchors(data), want)
+
+
+def test_torch_lattice_path_writes_the_same_bytes_as_the_numpy_path():
+    """encode_anchors' device path (round 6: lattice index, grid-value test, distinct lattice points, Morton keys and octree levels as
+    torch operations — on the GPU in production) forced onto the CPU: byte for byte the numpy path's stream, with duplicates, with
+    anchors off the lattice (exceptions) and when the lattice mode does not apply."""
+    import numpy as np
+    from gsvc_amd import anchor_codec as ac
+    rng = np.random.default_rng(5)
+    voxel = 0.001
+    a_min = np.array([-1.05, -0.6, -0.12], np.float32)
+    interval = ((np.array([1.05, 0.6, 0.12], np.float32) - a_min) / 65535.0).astype(np.float32)
+
+    def streams(pos, snap=True):
+        a = ((np.round(pos / voxel) * voxel) if snap else pos).astype(np.float32)
+        q = np.clip(np.floor((a - a_min) / interval), 0, 65535).astype(np.uint16)
+        host = ac.encode_anchors(q, positions=pos, voxel_size=voxel, interval=interval, a_min=a_min)
+        ac._torch_device = "cpu"
+        try:
+            dev = ac.encode_anchors(q, positions=pos, voxel_size=voxel, interval=interval, a_min=a_min)
+        finally:
+            ac._torch_device = None
+        return host, dev, q
+    lattice = np.round(rng.uniform([-1, -0.55, -0.1], [1, 0.55, 0.1], (30000, 3)) / voxel) * voxel
+    pos = np.concatenate([lattice, lattice[:500], lattice[:40]])                       # duplicates (multiplicity 2 and 3)
+    host, dev, q = streams(pos)
+    assert host == dev and host[5] == 1                                                 # lattice mode, the same bytes
+    assert np.array_equal(ac.decode_anchors(dev), ac._lex(q.astype(np.int64)).astype(np.uint16))
+    off = pos.copy()
+    off[:900] += rng.uniform(-0.4, 0.4, (900, 3)) * voxel                               # 3 % off the lattice: exceptions
+    host, dev, q = streams(off)
+    assert host == dev
+    host, dev, _ = streams(rng.uniform([-1, -0.55, -0.1], [1, 0.55, 0.1], (20000, 3)), snap=False)  # grid values of off-lattice positions: grid mode either way
+    assert host == dev and host[5] == 0
