@@ -1128,7 +1128,8 @@ def test_host_resident_video_with_adjacent_pairs_and_no_sync(monkeypatch):
             tr.close()
         assert written_busy == 0
         # (a wrong or half-written ground-truth picture moves the loss in its second digit; summation order moves the seventh)
-        assert np.allclose(losses[0], losses[1], rtol=2e-6, atol=0), losses
+        # (and the entropy phase's float atomics, amplified over its six steps, the fifth: seen up to 4e-6 — two orders below the bar)
+        assert np.allclose(losses[0], losses[1], rtol=2e-4, atol=0), losses
     finally:
         monkeypatch.delenv("GSVC_EARLY_PLAN")
         switches.reload()
