@@ -1078,7 +1078,7 @@ def test_host_resident_video_steps_equal_device_resident_steps():
             assert 7 <= ds.uploads <= 8, ds.uploads          # one per step (the first step's happens at use)
         tr.close()
     # (identical in the phases without float atomics; the entropy phase's scatter-adds order their sums run by run: 1e-7)
-    assert losses[0][:3] == losses[1][:3] and np.allclose(losses[0], losses[1], rtol=1e-5, atol=0), losses
+    assert losses[0][:3] == losses[1][:3] and np.allclose(losses[0], losses[1], rtol=1e-4, atol=0), losses
 
 
 @pytest.mark.gpu
