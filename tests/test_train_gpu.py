@@ -755,6 +755,27 @@ def _run_bench(extra_env, *args, timeout=420):
 
 
 @pytest.mark.gpu
+def test_bench_headline_scene_is_frozen():
+    """bench.py fits its untimed steps under GSVC_DETERMINISTIC=1 (round 6): two separate processes end in the SAME model — the
+    checksum over every parameter's bits that the line carries — and the timed steps then see the same number of active Gaussians
+    (the default-mode steps that follow move it by single Gaussians at most, not by the +-10 % a live fit draws); `--live-fit`
+    says so in the line and `--scene-seed` names another scene."""
+    import json
+    small = ["--workload", "train_step", "--steps", "4", "--warmup", "2", "--pretrain", "24", "--anchors", "20000", "--height", "272",
+             "--width", "480", "--no-cpu-baseline", "--no-side"]
+    lines = []
+    for extra in ([], [], ["--scene-seed", "3"], ["--live-fit"]):
+        out = _run_bench({}, *small, *extra)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0]))
+    a, b, other, live = [l["config"]["scene"] for l in lines]
+    assert a["frozen"] and b["frozen"] and a["checksum"] == b["checksum"] and a["fit_steps"] == 24
+    assert abs(lines[0]["config"]["active_per_render"] - lines[1]["config"]["active_per_render"]) <= 1e-3 * lines[0]["config"]["active_per_render"]
+    assert other["frozen"] and other["checksum"] != a["checksum"] and other["seeds"]["trainer"] == 3
+    assert not live["frozen"] and "live fit" in lines[3]["config"]["workload"] and a["checksum"] in lines[0]["config"]["workload"]
+
+
+@pytest.mark.gpu
 def test_bench_gpus_flag_starts_that_many_ranks():
     """`python bench.py --gpus 2` (the driver's command form) must run TWO ranks or fail: with the single-GPU test knobs
     (both ranks on device 0, gloo) it starts torch.distributed.run as a child and relays rank 0's line with n_gpus = 2 —
