@@ -579,6 +579,8 @@ def run_train_step(args, rank, world, dev):
         # gsvc_amd.dist.ZRangeOwnership) when the run used the replicated exchange, and the other way round — same model, same frames
         other = None
         try:
+            if os.environ.get("GSVC_BENCH_ONE_EXCHANGE"):      # opt-out: only the run's own exchange
+                raise RuntimeError("skipped: GSVC_BENCH_ONE_EXCHANGE is set")
             if zown is None:
                 trainer._zown = gdist.ZRangeOwnership(cube.len_z_frames, cube.scale, mp_.threshold)
             else:
