@@ -4,9 +4,9 @@
 // off (DBG bits):
 //   1 no weight loads   2 no X loads   4 no MFMAs (one add per fragment keeps the loads alive)   8 no stores
 // and the workgroup shape varied (waves per row block).  10 000 x 192 -> 160 on MI355X: everything 17.6 us, without the weight
-// loads 11.0, without any load 9.9, without the MFMAs 17.1, nothing but the stores 3.3 (k_linear_ws: 30): the lane (row fr, k-quarter
-// kq) fragment load of a row-major weight matrix touches 16 cache lines per quarter-wave, 64 per instruction, and the texture
-// addresser takes them one per cycle — 36 such loads per wave are the kernel.  In the fitting step the form was slower, not
+// loads 11.0, without any load 9.9, without the MFMAs 17.1, nothing but the stores 3.3 (k_linear_ws: 30): every
+// row block re-reads its 123 KB of weights from L2 — 90 MB per launch through the L2 -> L1 path, which is what the 7 us of weight
+// loads are (the fragment pattern itself streams at the contiguous rate: tools/micro/frag_access.hip).  In the fitting step the form was slower, not
 // faster (6.81 / 7.15 -> 7.06 / 7.85 ms): spread over every CU it takes L2 and issue slots from the rasterizer's streams.  hipcc -O3 --offload-arch=gfx950 -I gsvc_amd/csrc
 // tools/micro/linear_small_probe.hip -o tools/micro/linear_small_probe ; usage: linear_small_probe [M K N]
 #include <hip/hip_runtime.h>
