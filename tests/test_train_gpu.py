@@ -1261,6 +1261,67 @@ def test_deterministic_mode_gives_the_same_fit_bit_for_bit(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_deterministic_mode_computes_the_default_modes_gradients(monkeypatch):
+    """The fixed-order forms behind GSVC_DETERMINISTIC=1 (sorted row scatters, one workgroup per hash-table slice, per-wave rate sums)
+    are the SAME sums in another order: one step per phase from the same parameters, seeds and frame in both modes gives every
+    parameter gradient, the loss and the densification accumulators equal to rounding (tools/ab/det_vs_default_grads.py on the
+    headline shape: 3e-7 of each tensor's scale)."""
+    import os
+    from gsvc_amd import switches
+    pc, cube, opt, pipe, mp, Trainer = _setup(anchors=5000, H=96, W=160, T=12, seed=5)
+    B = 10 ** 9
+    opt.full_precision_training_total, opt.quantized_training_total = 0, 0
+    opt.entropy_constrained_train_total, opt.ste_entropy_constrained_train_total = B, 0
+    opt.start_stat, opt.update_until, opt.pause_densification, opt.update_from = 0, B, 0, B
+    pc.training_setup(opt)
+    tr = Trainer(pc, cube, opt, pipe, mp, seed=2)
+    for it in range(1, 13):
+        tr.step(it)
+    captured = {}
+
+    def capture(*a, **k):
+        if k.get("only") is not None:
+            return None
+        captured.clear()
+        captured.update({n: p.grad.detach().clone() for n, p in pc.named_parameters() if p.grad is not None})
+    pc.optimizer.step = capture
+    accs = ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom")
+    try:
+        for phase, totals in (("full", (B, 0, 0, 0)), ("quantized", (0, B, 0, 0)), ("entropy", (0, 0, B, 0)), ("ste", (0, 0, 0, B))):
+            (opt.full_precision_training_total, opt.quantized_training_total, opt.entropy_constrained_train_total,
+             opt.ste_entropy_constrained_train_total) = totals
+            res = {}
+            for det in (False, True):
+                if det:
+                    monkeypatch.setenv("GSVC_DETERMINISTIC", "1")
+                else:
+                    monkeypatch.delenv("GSVC_DETERMINISTIC", raising=False)
+                switches.reload()
+                for n in accs:
+                    getattr(pc, n).zero_()
+                tr._plan = tr._plan_idx = None
+                tr.rng.seed(7)
+                torch.manual_seed(99)
+                tr.controller.current_iteration = 100
+                tr.controller._entropy_constrained = False      # sticky, as the reference's; the warm-up ran in the entropy phase
+                out = tr.step(100, frame_idx=5)
+                torch.cuda.synchronize()
+                res[det] = (dict(captured), float(out.loss), {n: getattr(pc, n).clone().float() for n in accs})
+            (g0, l0, a0), (g1, l1, a1) = res[False], res[True]
+            assert sorted(g0) == sorted(g1), phase
+            assert abs(l0 - l1) <= 2e-6 * abs(l0), (phase, l0, l1)
+            for n in g0:
+                scale = float(g0[n].abs().max())
+                assert float((g0[n] - g1[n]).abs().max()) <= 2e-5 * scale + 1e-30, (phase, n)
+            for n in accs:
+                assert float((a0[n] - a1[n]).abs().max()) <= 2e-5 * float(a0[n].abs().max()) + 1e-30, (phase, n)
+    finally:
+        os.environ.pop("GSVC_DETERMINISTIC", None)
+        switches.reload()
+        tr.close()
+
+
+@pytest.mark.gpu
 def test_sorted_row_scatter_equals_index_add():
     """gsvc_segment_rows_sum (the deterministic mode's scatter-add of rows): the values of index_add_ to rounding, the same bits on
     every call, rows without a target untouched (accumulate) or zero (fresh), an empty list a no-op."""
