@@ -1263,6 +1263,28 @@ int generators_forward(const gsvc_generator_net *nets, int n, const float *feat,
     return check_launch("generators_forward");
 }
 
+// The weight gradients of a backward pass read what its chain kernels wrote and nothing downstream reads THEM before the optimizer:
+// with gsvc_set_wgrad_stream they are queued on that stream behind an event of the caller's, and the caller's stream goes on with
+// the feature gradient (the quantisers', gathers' and hash grid's backward) while they run.
+hipStream_t g_wgrad_stream = nullptr;
+
+hipStream_t wgrad_stream_behind(hipStream_t s)
+{
+    if (g_wgrad_stream == nullptr || g_wgrad_stream == s) return s;
+    constexpr int POOL = 32;
+    static hipEvent_t pool[POOL];
+    static int at = -1;
+    if (at < 0) {
+        for (int i = 0; i < POOL; i++)
+            if (hipEventCreateWithFlags(&pool[i], hipEventDisableTiming) != hipSuccess) return s;
+        at = 0;
+    }
+    hipEvent_t e = pool[at];
+    at = (at + 1) % POOL;
+    if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(g_wgrad_stream, e, 0) != hipSuccess) return s;
+    return g_wgrad_stream;
+}
+
 int generators_backward(const gsvc_generator_net *nets, int n, const float *feat, const float *cond, long long M, const gsvc_film_rows *film,
                         const float *const *saved, const float *const *y, const float *const *gy, float *scratch, float *const *gfeat,
                         const int *accumulate, const gsvc_generator_grads *grads, hipStream_t s)
@@ -1325,9 +1347,10 @@ int generators_backward(const gsvc_generator_net *nets, int n, const float *feat
         }
     }
     if (nred) {
-        if (int rc = gsvc_linear_wgrad_partial_many(part, nred, s)) return rc;
+        hipStream_t ws_ = wgrad_stream_behind(s);
+        if (int rc = gsvc_linear_wgrad_partial_many(part, nred, ws_)) return rc;
         for (int i = 0; i < nred; i++) red[i].slots = part[i].slots_used;
-        return gsvc_linear_wgrad_reduce_many(red, nred, s);
+        return gsvc_linear_wgrad_reduce_many(red, nred, ws_);
     }
     return GSVC_OK;
 }
@@ -1463,6 +1486,12 @@ extern "C" int gsvc_generator_backward(const gsvc_generator_net *n, const float 
     return generators_backward(n, 1, feat, cond, M, nullptr, &saved, &y, &gy, scratch, &gfeat, &acc, grads, (hipStream_t)stream);
 }
 
+extern "C" int gsvc_set_wgrad_stream(void *stream)
+{
+    gsvc::g_wgrad_stream = (hipStream_t)stream;
+    return GSVC_OK;
+}
+
 static int deform_supported(const gsvc_deform_net *n, const char *what)
 {
     GSVC_REQUIRE(n, "%s: NULL network", what);
@@ -1572,15 +1601,16 @@ extern "C" int gsvc_deform_backward(const gsvc_deform_net *n, const float *feat,
         red[nred++] = gsvc_wgrad_reduce_job{ws, j.dW, j.db, 0, j.N, j.K};
         ws += need;
     }
+    hipStream_t wst = nred ? wgrad_stream_behind(s) : s;
     if (nred) {
-        if (int rc = gsvc_linear_wgrad_partial_many(part, nred, s)) return rc;
+        if (int rc = gsvc_linear_wgrad_partial_many(part, nred, wst)) return rc;
         for (int i = 0; i < nred; i++) red[i].slots = part[i].slots_used;
-        if (int rc = gsvc_linear_wgrad_reduce_many(red, nred, s)) return rc;
+        if (int rc = gsvc_linear_wgrad_reduce_many(red, nred, wst)) return rc;
     }
     if (want1) {
-        (void)hipMemcpy2DAsync(grads->W[0], (size_t)(FEAT + COND) * 4, stage_f, (size_t)FEAT * 4, (size_t)FEAT * 4, HID, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpy2DAsync(grads->W[0], (size_t)(FEAT + COND) * 4, stage_f, (size_t)FEAT * 4, (size_t)FEAT * 4, HID, hipMemcpyDeviceToDevice, wst);
         (void)hipMemcpy2DAsync(grads->W[0] + FEAT, (size_t)(FEAT + COND) * 4, stage_c, (size_t)COND * 4, (size_t)COND * 4, HID,
-                               hipMemcpyDeviceToDevice, s);
+                               hipMemcpyDeviceToDevice, wst);
     }
     return check_launch("deform_backward");
 }

@@ -572,6 +572,41 @@ def _film_desc(film):
     return C.byref(d)
 
 
+# ---- the weight gradients' own stream (gsvc_set_wgrad_stream) ----------------------------------------------------------------
+# Trainer.step opens ``wgrad_overlap`` around its backward: inside it _GenerateAll.backward's dW products run on a side stream
+# behind the chain kernels while the step's stream carries the feature gradient on; leaving it, the step's stream waits for them.
+_WGRAD_STREAM = {}
+_wgrad_active = None      # the side stream while a ``wgrad_overlap`` block is open
+_wgrad_calls = 0          # _GenerateAll.backward calls inside the open block: only the FIRST one's products leave the step's stream — a
+                          # second call's gradients are ADDED to the first's by autograd, on the step's stream, before the block's end
+
+
+class wgrad_overlap:
+    def __init__(self, dev):
+        self.dev = dev
+
+    def __enter__(self):
+        global _wgrad_active
+        if self.dev.type != "cuda" or switches.NO_WGRAD_OVERLAP or _wgrad_active is not None:
+            self.on = False
+            return self
+        st = _WGRAD_STREAM.get(self.dev.index)
+        if st is None:
+            st = _WGRAD_STREAM[self.dev.index] = torch.cuda.Stream(device=self.dev)
+        _lib.check(_lib.lib().gsvc_set_wgrad_stream(st.cuda_stream), "gsvc_set_wgrad_stream")
+        global _wgrad_calls
+        _wgrad_active, _wgrad_calls, self.on = st, 0, True
+        return self
+
+    def __exit__(self, *exc):
+        global _wgrad_active
+        if self.on:
+            _lib.check(_lib.lib().gsvc_set_wgrad_stream(None), "gsvc_set_wgrad_stream")
+            torch.cuda.current_stream(self.dev).wait_stream(_wgrad_active)      # the optimizer, the reducer: behind the last product
+            _wgrad_active = None
+        return False
+
+
 def _ptr_array(tensors):
     import ctypes as C
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
@@ -639,8 +674,27 @@ class _GenerateAll(torch.autograd.Function):
                 setattr(gds[g], name, v.data_ptr())
             total += (int(L.gsvc_generator_scratch_floats(C.byref(d), M, int(ctx.film[0].shape[0]) if ctx.film is not None else 0)) + 3) // 4 * 4
         dd = _deform_desc(params[42:52])
-        total = max(total, int(L.gsvc_deform_scratch_floats(C.byref(dd), M)))
-        scratch = torch.empty(total, device=dev, dtype=torch.float32)
+        side = _wgrad_active if (_wgrad_active is not None and dev.type == "cuda") else None
+        later_call = False
+        if side is not None:
+            global _wgrad_calls
+            _wgrad_calls += 1
+            if _wgrad_calls > 1:
+                # (the per-render form of a step: several generation passes) the sum of this call's and the first call's weight gradients
+                # is formed on this stream: wait for the first call's products, keep this call's here
+                torch.cuda.current_stream(dev).wait_stream(side)
+                _lib.check(L.gsvc_set_wgrad_stream(None), "gsvc_set_wgrad_stream")
+                later_call, later_side, side = True, side, None
+        if side is None:
+            total = max(total, int(L.gsvc_deform_scratch_floats(C.byref(dd), M)))      # the deformation network reuses the generators' scratch
+            scratch = scratch_d = torch.empty(total, device=dev, dtype=torch.float32)
+        else:
+            # the generators' weight gradients are still reading their scratch (on the side stream) when the deformation network's chain
+            # kernels write theirs: two buffers; and everything those products touch outlives this function on THAT stream
+            scratch = torch.empty(total, device=dev, dtype=torch.float32)
+            scratch_d = torch.empty(int(L.gsvc_deform_scratch_floats(C.byref(dd), M)), device=dev, dtype=torch.float32)
+            for x in (feat, cond, *saved, scratch, scratch_d, flat, gys[3], *((ctx.film[0],) if ctx.film is not None else ())):
+                x.record_stream(side)
         F_ = feat.shape[1]
         per = (M * F_ + 3) // 4 * 4                                                      # every buffer starts 16-byte aligned
         gflat = torch.empty(4 * per, device=dev, dtype=torch.float32)                   # three generators' + the sum
@@ -652,11 +706,13 @@ class _GenerateAll(torch.autograd.Function):
         gd = _lib.DeformGradsC()
         for i in range(5):
             gd.W[i], gd.b[i] = grads[42 + 2 * i].data_ptr(), grads[43 + 2 * i].data_ptr()
-        # the deformation network's backward runs behind the generators' (same stream): it reuses their scratch and adds their
-        # three feature gradients to its own in the pass that writes gfeat
+        # the deformation network's backward runs behind the generators' (same stream): it adds their three feature gradients to its
+        # own in the pass that writes gfeat
         _lib.check(L.gsvc_deform_backward(C.byref(dd), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(saved[3]), _lib.ptr(gys[3]),
-                                          _lib.ptr(scratch), _lib.ptr(gfeats[3]), 0, _ptr_array(gen_gf), 3, C.byref(gd), st),
+                                          _lib.ptr(scratch_d), _lib.ptr(gfeats[3]), 0, _ptr_array(gen_gf), 3, C.byref(gd), st),
                    "gsvc_deform_backward")
+        if later_call:
+            _lib.check(L.gsvc_set_wgrad_stream(later_side.cuda_stream), "gsvc_set_wgrad_stream")
         return (gfeats[3] if need[0] else None, None, None, None, *grads)
 
 

@@ -17,6 +17,8 @@ Code reads the module attributes (``switches.NO_MLP_CHAIN``); a process that cha
     GSVC_NO_VIEW_SHARE     FULL_PRECISION / STE_ENTROPY steps: the generators per (view, anchor) although the two opposite views of a frame
                            have the same Gaussians (the generation pass per (frame, anchor) otherwise)
     GSVC_NO_RATE_OVERLAP   the sampled rate inside the generation pass, on the step's stream (not behind the rasterizer's launches on its own)
+    GSVC_NO_WGRAD_OVERLAP  the generators' / mlp_deform's weight gradients on the step's stream (not on their own stream beside the feature
+                           gradient's way back through the quantisers, gathers and hash grid)
     GSVC_RATE_EARLY        the sampled rate issued (on its own stream) BEFORE the rasterizer's launches: its backward then runs behind the rasterizer's
     GSVC_NO_LATE_ROWS      gather offsets / scalings / masks with the features (not behind the generators)
     GSVC_NO_PREFETCH / GSVC_NO_EARLY_PLAN / GSVC_EARLY_PLAN   step plan off / never from inside the backward / always
@@ -34,7 +36,7 @@ import os
 
 _FLAGS = ("NO_MLP_CHAIN", "NO_MLP_FUSED", "NO_QUANT_CHAIN", "NO_SHARED_INPUT", "NO_ACCUM_MANY", "NO_DECODE_CHAIN", "CTX_ALL_ROWS",
           "NO_FUSED_CTX", "NO_FUSED_GRID", "NO_FUSED_STATIS", "NO_FUSED_RATE", "NO_FUSED_GATHER", "NO_FUSED_PLAN", "NO_FUSED_STE", "NO_RANKED_GATHER",
-          "NO_PACKED_GRID", "NO_GRID_MANY", "NO_FILM_SHARE", "NO_VIEW_SHARE", "NO_LATE_ROWS", "NO_RATE_OVERLAP", "NO_PREFETCH", "NO_EARLY_PLAN", "EARLY_PLAN", "RATE_EARLY", "RASTER_LOOSE_BINNING", "NO_ADAPTIVE_BOUND", "DETERMINISTIC")
+          "NO_PACKED_GRID", "NO_GRID_MANY", "NO_FILM_SHARE", "NO_VIEW_SHARE", "NO_LATE_ROWS", "NO_RATE_OVERLAP", "NO_WGRAD_OVERLAP", "NO_PREFETCH", "NO_EARLY_PLAN", "EARLY_PLAN", "RATE_EARLY", "RASTER_LOOSE_BINNING", "NO_ADAPTIVE_BOUND", "DETERMINISTIC")
 
 
 def reload():

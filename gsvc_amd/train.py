@@ -526,8 +526,9 @@ class Trainer:
             handles = [p.register_post_accumulate_grad_hook(arrived) for p in waited]
         try:
             from .generate import two_stream_backward
+            from .mlp import wgrad_overlap
             with region('step.backward'), (two_stream_backward() if (side is not None or getattr(batch, "small_work", False))
-                                           else contextlib.nullcontext()):
+                                           else contextlib.nullcontext()), wgrad_overlap(dev):
                 loss.backward()
         finally:
             for h in handles:

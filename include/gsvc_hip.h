@@ -576,6 +576,15 @@ int gsvc_pair_rows_sum(const float *g, const int32_t *src_a, const int32_t *src_
  * order (order = a STABLE argsort of the rows' targets, sorted_idx the targets in that order).  Replaces the float atomics of
  * reference-shaped scatter-adds (utils/entropy_models.py:159-175's gradient, the index_add of guassian.py:160-176's gathers). */
 int gsvc_set_deterministic(int on);
+
+/* The weight gradients of gsvc_generators_backward / gsvc_generator_backward / gsvc_deform_backward on ANOTHER stream: with a non-NULL
+ * stream set here those entries queue their chain kernels on the caller's stream as before, record an event there, and queue the
+ * dW = G^T X products and their reduces (reference: autograd's weight gradients of scene/gaussian_model.py:150-196, 468-489) on
+ * `stream` behind that event — so the caller's stream can go on with the feature gradient while they run.  The caller then owns
+ * the hazards: the products read feat, cond, the saved activations, the scratch (which the two entries must therefore NOT share) and
+ * gy of the deformation network, and write the gradient tensors, until `stream` has passed; the optimizer's stream must wait for
+ * it.  NULL (the default): everything on the caller's stream.  Process-wide; not for concurrent callers. */
+int gsvc_set_wgrad_stream(void *stream);
 int gsvc_segment_rows_sum(const float *src, const int64_t *order, const int64_t *sorted_idx, int64_t n, int32_t C, float *dst,
                           int32_t accumulate, void *stream);
 

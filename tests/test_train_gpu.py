@@ -1322,6 +1322,59 @@ def test_deterministic_mode_computes_the_default_modes_gradients(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("batched", [True, False])
+def test_weight_gradients_on_their_own_stream_are_the_same_gradients(monkeypatch, batched):
+    """Inside a step's backward the generators' / mlp_deform's weight-gradient products run on a side stream behind the chain kernels
+    (gsvc_set_wgrad_stream; mlp.wgrad_overlap) while the step's stream carries the feature gradient on.  The same kernels on the same
+    operands: under GSVC_DETERMINISTIC=1 every parameter's gradient has the SAME BITS with and without the side stream — in the
+    production form (one generation pass per step) and in the per-render form (four passes: only the first one's products leave the
+    step's stream, the others' are added to them by autograd on it), in the entropy and the straight-through phase, step after step."""
+    import os
+    from gsvc_amd import switches
+    monkeypatch.setenv("GSVC_DETERMINISTIC", "1")
+    switches.reload()
+    try:
+        res = {}
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("GSVC_NO_WGRAD_OVERLAP", "1")
+            else:
+                monkeypatch.delenv("GSVC_NO_WGRAD_OVERLAP", raising=False)
+            switches.reload()
+            pc, cube, opt, pipe, mp, Trainer = _setup(anchors=5000, H=96, W=160, T=12, seed=7)
+            opt.full_precision_training_total, opt.quantized_training_total = 2, 2
+            opt.entropy_constrained_train_total, opt.ste_entropy_constrained_train_total = 3, 3
+            opt.start_stat, opt.update_until, opt.pause_densification = 10 ** 9, 10 ** 9, 0
+            pc.training_setup(opt)
+            tr = Trainer(pc, cube, opt, pipe, mp, seed=4, batched=batched)
+            grads = []
+            real_step = pc.optimizer.step
+
+            def step(*a, **k):
+                if k.get("only") is None:
+                    grads.append({n: p.grad.detach().clone() for n, p in pc.named_parameters() if p.grad is not None})
+                return real_step(*a, **k)
+            pc.optimizer.step = step
+            for it in range(1, 11):
+                tr.step(it, frame_idx=3 + it % 4)
+            torch.cuda.synchronize()
+            res[off] = (grads, {n: p.detach().clone() for n, p in pc.named_parameters()})
+            tr.close()
+        (g_on, p_on), (g_off, p_off) = res[False], res[True]
+        assert len(g_on) == len(g_off) == 10
+        for i, (a, b) in enumerate(zip(g_on, g_off)):
+            assert sorted(a) == sorted(b)
+            differing = [n for n in a if not torch.equal(a[n], b[n])]
+            assert not differing, (i, differing[:5])
+        assert not [n for n in p_on if not torch.equal(p_on[n], p_off[n])]
+        assert any("mlp_opacity" in n or "mlp_cov" in n for n in g_on[0])
+    finally:
+        os.environ.pop("GSVC_DETERMINISTIC", None)
+        os.environ.pop("GSVC_NO_WGRAD_OVERLAP", None)
+        switches.reload()
+
+
+@pytest.mark.gpu
 def test_sorted_row_scatter_equals_index_add():
     """gsvc_segment_rows_sum (the deterministic mode's scatter-add of rows): the values of index_add_ to rounding, the same bits on
     every call, rows without a target untouched (accumulate) or zero (fresh), an empty list a no-op."""
