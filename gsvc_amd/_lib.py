@@ -167,6 +167,8 @@ _SIGNATURES = {
     "gsvc_pair_rows_sum": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, _vp, _vp]),
     "gsvc_set_deterministic": (C.c_int, [C.c_int]),
     "gsvc_set_wgrad_stream": (C.c_int, [_vp]),
+    "gsvc_wgrad_hold": (C.c_int, [C.c_int32]),
+    "gsvc_wgrad_flush": (C.c_int, [_vp]),
     "gsvc_segment_rows_sum": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int32, _vp, C.c_int32, _vp]),
     "gsvc_ste_binary_count_many": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, _vp]),
     "gsvc_ste_binary_backward_many": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.c_int32, _vp, C.c_int32, _vp, _vp]),

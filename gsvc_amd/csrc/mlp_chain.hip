@@ -22,8 +22,10 @@
 // Instantiated for the production widths (feat 50, condition 66, hidden 100, K = 10 offsets: outputs 10 / 30 / 70 / 30);
 // other widths return GSVC_E_UNSUPPORTED and the caller keeps the layer-by-layer path.
 #include <cstdlib>
+#include <functional>
 #include <mutex>
 #include <set>
+#include <vector>
 
 #include "linear_ws.h"
 
@@ -1268,6 +1270,25 @@ int generators_forward(const gsvc_generator_net *nets, int n, const float *feat,
 // the feature gradient (the quantisers', gathers' and hash grid's backward) while they run.
 hipStream_t g_wgrad_stream = nullptr;
 
+// gsvc_wgrad_hold(1): the entries keep their weight-gradient launches back (operands by value) until gsvc_wgrad_flush — so that a
+// caller with several chain backward passes in a row (the generators', then mlp_deform's) gets every chain kernel onto its stream
+// BEFORE the first product starts beside them: a chain workgroup needs its whole CU, a product queued in between made the second
+// network's chain kernels wait for the first network's products to retire.
+struct DeferredWgrad {
+    std::vector<gsvc_wgrad_partial_job> part;
+    std::vector<gsvc_wgrad_reduce_job> red;
+    std::function<void(hipStream_t)> tail;
+};
+bool g_wgrad_hold = false;
+std::vector<DeferredWgrad> g_wgrad_deferred;
+
+int run_wgrad(gsvc_wgrad_partial_job *part, gsvc_wgrad_reduce_job *red, int n, hipStream_t s)
+{
+    if (int rc = gsvc_linear_wgrad_partial_many(part, n, s)) return rc;
+    for (int i = 0; i < n; i++) red[i].slots = part[i].slots_used;
+    return gsvc_linear_wgrad_reduce_many(red, n, s);
+}
+
 hipStream_t wgrad_stream_behind(hipStream_t s)
 {
     if (g_wgrad_stream == nullptr || g_wgrad_stream == s) return s;
@@ -1347,10 +1368,12 @@ int generators_backward(const gsvc_generator_net *nets, int n, const float *feat
         }
     }
     if (nred) {
-        hipStream_t ws_ = wgrad_stream_behind(s);
-        if (int rc = gsvc_linear_wgrad_partial_many(part, nred, ws_)) return rc;
-        for (int i = 0; i < nred; i++) red[i].slots = part[i].slots_used;
-        return gsvc_linear_wgrad_reduce_many(red, nred, ws_);
+        if (g_wgrad_hold && g_wgrad_stream != nullptr) {
+            g_wgrad_deferred.push_back(DeferredWgrad{std::vector<gsvc_wgrad_partial_job>(part, part + nred),
+                                                     std::vector<gsvc_wgrad_reduce_job>(red, red + nred), nullptr});
+            return GSVC_OK;
+        }
+        return run_wgrad(part, red, nred, wgrad_stream_behind(s));
     }
     return GSVC_OK;
 }
@@ -1492,6 +1515,25 @@ extern "C" int gsvc_set_wgrad_stream(void *stream)
     return GSVC_OK;
 }
 
+extern "C" int gsvc_wgrad_hold(int32_t on)
+{
+    gsvc::g_wgrad_hold = on != 0;
+    return GSVC_OK;
+}
+
+extern "C" int gsvc_wgrad_flush(void *stream)
+{
+    if (gsvc::g_wgrad_deferred.empty()) return GSVC_OK;
+    hipStream_t ws = gsvc::g_wgrad_stream != nullptr ? gsvc::wgrad_stream_behind((hipStream_t)stream) : (hipStream_t)stream;
+    int rc = GSVC_OK;
+    for (auto &d : gsvc::g_wgrad_deferred) {
+        if (rc == GSVC_OK) rc = gsvc::run_wgrad(d.part.data(), d.red.data(), (int)d.part.size(), ws);
+        if (rc == GSVC_OK && d.tail) d.tail(ws);
+    }
+    gsvc::g_wgrad_deferred.clear();
+    return rc != GSVC_OK ? rc : check_launch("wgrad_flush");
+}
+
 static int deform_supported(const gsvc_deform_net *n, const char *what)
 {
     GSVC_REQUIRE(n, "%s: NULL network", what);
@@ -1601,17 +1643,21 @@ extern "C" int gsvc_deform_backward(const gsvc_deform_net *n, const float *feat,
         red[nred++] = gsvc_wgrad_reduce_job{ws, j.dW, j.db, 0, j.N, j.K};
         ws += need;
     }
+    float *const w0 = grads->W[0];
+    auto tail = [=](hipStream_t wst) {
+        if (!want1) return;
+        (void)hipMemcpy2DAsync(w0, (size_t)(FEAT + COND) * 4, stage_f, (size_t)FEAT * 4, (size_t)FEAT * 4, HID, hipMemcpyDeviceToDevice, wst);
+        (void)hipMemcpy2DAsync(w0 + FEAT, (size_t)(FEAT + COND) * 4, stage_c, (size_t)COND * 4, (size_t)COND * 4, HID, hipMemcpyDeviceToDevice, wst);
+    };
+    if (nred && g_wgrad_hold && g_wgrad_stream != nullptr) {
+        g_wgrad_deferred.push_back(DeferredWgrad{std::vector<gsvc_wgrad_partial_job>(part, part + nred),
+                                                 std::vector<gsvc_wgrad_reduce_job>(red, red + nred), tail});
+        return check_launch("deform_backward");
+    }
     hipStream_t wst = nred ? wgrad_stream_behind(s) : s;
-    if (nred) {
-        if (int rc = gsvc_linear_wgrad_partial_many(part, nred, wst)) return rc;
-        for (int i = 0; i < nred; i++) red[i].slots = part[i].slots_used;
-        if (int rc = gsvc_linear_wgrad_reduce_many(red, nred, wst)) return rc;
-    }
-    if (want1) {
-        (void)hipMemcpy2DAsync(grads->W[0], (size_t)(FEAT + COND) * 4, stage_f, (size_t)FEAT * 4, (size_t)FEAT * 4, HID, hipMemcpyDeviceToDevice, wst);
-        (void)hipMemcpy2DAsync(grads->W[0] + FEAT, (size_t)(FEAT + COND) * 4, stage_c, (size_t)COND * 4, (size_t)COND * 4, HID,
-                               hipMemcpyDeviceToDevice, wst);
-    }
+    if (nred)
+        if (int rc = run_wgrad(part, red, nred, wst)) return rc;
+    tail(wst);
     return check_launch("deform_backward");
 }
 

@@ -20,6 +20,8 @@ everything that depends on the anchor features) and the trunk.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib, switches
@@ -695,24 +697,36 @@ class _GenerateAll(torch.autograd.Function):
             scratch_d = torch.empty(int(L.gsvc_deform_scratch_floats(C.byref(dd), M)), device=dev, dtype=torch.float32)
             for x in (feat, cond, *saved, scratch, scratch_d, flat, gys[3], *((ctx.film[0],) if ctx.film is not None else ())):
                 x.record_stream(side)
+        hold = side is not None
+        if hold:
+            # both networks' chain kernels first, then every product beside what follows: a chain workgroup needs its whole CU, and the
+            # generators' products queued ahead of mlp_deform's chain kernels made those wait for them (6.81 -> 6.78 ms per step)
+            _lib.check(L.gsvc_wgrad_hold(1), "gsvc_wgrad_hold")
         F_ = feat.shape[1]
         per = (M * F_ + 3) // 4 * 4                                                      # every buffer starts 16-byte aligned
         gflat = torch.empty(4 * per, device=dev, dtype=torch.float32)                   # three generators' + the sum
         gfeats = [gflat[i * per:i * per + M * F_].view(M, F_) for i in range(4)]
         gen_gf = gfeats[:3]
-        _lib.check(L.gsvc_generators_backward(nets, 3, _lib.ptr(feat), _lib.ptr(cond), M, _film_desc(ctx.film), _ptr_array(saved[:3]),
-                                              _ptr_array(ys), _ptr_array(gys[:3]), _lib.ptr(scratch), _ptr_array(gen_gf), gds, st),
-                   "gsvc_generators_backward")
-        gd = _lib.DeformGradsC()
-        for i in range(5):
-            gd.W[i], gd.b[i] = grads[42 + 2 * i].data_ptr(), grads[43 + 2 * i].data_ptr()
-        # the deformation network's backward runs behind the generators' (same stream): it adds their three feature gradients to its
-        # own in the pass that writes gfeat
-        _lib.check(L.gsvc_deform_backward(C.byref(dd), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(saved[3]), _lib.ptr(gys[3]),
-                                          _lib.ptr(scratch_d), _lib.ptr(gfeats[3]), 0, _ptr_array(gen_gf), 3, C.byref(gd), st),
-                   "gsvc_deform_backward")
-        if later_call:
-            _lib.check(L.gsvc_set_wgrad_stream(later_side.cuda_stream), "gsvc_set_wgrad_stream")
+        try:
+            _lib.check(L.gsvc_generators_backward(nets, 3, _lib.ptr(feat), _lib.ptr(cond), M, _film_desc(ctx.film), _ptr_array(saved[:3]),
+                                                  _ptr_array(ys), _ptr_array(gys[:3]), _lib.ptr(scratch), _ptr_array(gen_gf), gds, st),
+                       "gsvc_generators_backward")
+            gd = _lib.DeformGradsC()
+            for i in range(5):
+                gd.W[i], gd.b[i] = grads[42 + 2 * i].data_ptr(), grads[43 + 2 * i].data_ptr()
+            # the deformation network's backward runs behind the generators' (same stream): it adds their three feature gradients to
+            # its own in the pass that writes gfeat
+            _lib.check(L.gsvc_deform_backward(C.byref(dd), _lib.ptr(feat), _lib.ptr(cond), M, _lib.ptr(saved[3]), _lib.ptr(gys[3]),
+                                              _lib.ptr(scratch_d), _lib.ptr(gfeats[3]), 0, _ptr_array(gen_gf), 3, C.byref(gd), st),
+                       "gsvc_deform_backward")
+        finally:
+            if hold:      # (also after an error: nothing stays held, the library leaves the hold)
+                rc = L.gsvc_wgrad_flush(st)
+                L.gsvc_wgrad_hold(0)
+            if later_call:
+                L.gsvc_set_wgrad_stream(later_side.cuda_stream)
+        if hold:
+            _lib.check(rc, "gsvc_wgrad_flush")
         return (gfeats[3] if need[0] else None, None, None, None, *grads)
 
 

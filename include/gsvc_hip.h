@@ -585,6 +585,13 @@ int gsvc_set_deterministic(int on);
  * gy of the deformation network, and write the gradient tensors, until `stream` has passed; the optimizer's stream must wait for
  * it.  NULL (the default): everything on the caller's stream.  Process-wide; not for concurrent callers. */
 int gsvc_set_wgrad_stream(void *stream);
+/* gsvc_wgrad_hold(1): while a stream is set, those entries keep their weight-gradient launches back (their operands by value);
+ * gsvc_wgrad_flush(stream) records the event on `stream` NOW and queues every held product behind it — for a caller that runs
+ * several chain backward passes in a row and wants all their chain kernels queued before the first product starts beside them
+ * (a chain workgroup needs its whole CU).  Held launches that are never flushed are dropped by the next flush's owner: flush before
+ * gsvc_wgrad_hold(0). */
+int gsvc_wgrad_hold(int32_t on);
+int gsvc_wgrad_flush(void *stream);
 int gsvc_segment_rows_sum(const float *src, const int64_t *order, const int64_t *sorted_idx, int64_t n, int32_t C, float *dst,
                           int32_t accumulate, void *stream);
 
