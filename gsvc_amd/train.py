@@ -217,7 +217,11 @@ class Trainer:
         if self._steps_seen <= 8:
             return
         self._blocked_ema = b if self._blocked_ema is None else 0.8 * self._blocked_ema + 0.2 * b
-        if self._steps_seen < 16:
+        self._ema_n = getattr(self, "_ema_n", 0) + 1
+        if self._steps_seen < 16 or self._ema_n < 8:
+            # (the average needs a few steps of its own: a fit that leaves the deterministic mode, or follows a synchronisation, starts
+            # it with ONE step's wait — bench.py's first timed steps after its frozen pretrain were decided by a 0.008 ms sample and ran
+            # host-bound for 57 steps; until then the row count decides)
             return
         before = ctx.gpu_bound_hint
         if self._blocked_ema > 4e-4:
